@@ -1,0 +1,166 @@
+/*
+ * loghisto_gpu.h -- C ABI of liblhgpu.so, the MI355X (gfx950) engine behind
+ * loghisto's histogram hot path.
+ *
+ * The reference (spacejam/loghisto, Go) has no FFI on this path: the boundary is
+ * the bodies of three Go functions, which a cgo binding replaces with calls into
+ * this library (the binding is shown in INTEGRATION.md):
+ *
+ *   (*MetricSystem).Histogram        /root/reference/metrics.go:273-295
+ *       -> lh_intern (once per name) + lh_submit / lh_submit_pairs (batched)
+ *   collectRawMetrics, histogram part /root/reference/metrics.go:460-463
+ *       -> lh_flip            (the epoch boundary: steal the interval's cells)
+ *   processHistograms + percentile   /root/reference/metrics.go:336-418
+ *       -> lh_extract         (count, sum, avg, uint64(sum), percentiles)
+ *   RawMetricSet.Histograms          /root/reference/metrics.go:54-60
+ *       -> lh_buckets         (occupied (key,count) cells of one metric)
+ *   compress / decompress            /root/reference/metrics.go:316-332
+ *       -> computed on device inside lh_submit*; lh_compress_device and
+ *          lh_codec_tables expose the codec for parity tests.
+ *
+ * Conventions:
+ *   - every entry point returns an int status (LH_OK == 0); nothing aborts.
+ *     The Go layer logs non-zero codes through glog and carries on, exactly as
+ *     it does for percentile()'s error (metrics.go:379-384).
+ *   - ingest is lossless and may block (back-pressure) but never drops
+ *     (metrics.go:273-295 is synchronous); only emission may be dropped, by the
+ *     caller.
+ *   - lh_submit* are thread-safe and copy the caller's buffer before returning
+ *     (cgo rule: C may not retain Go memory).
+ *   - a sample belongs to exactly one snapshot: everything submitted before
+ *     lh_flip returns is in that snapshot, everything after is in the next
+ *     (metrics.go:460-463).
+ *   - plain pointers and sizes only; `stream` arguments are hipStream_t passed
+ *     as void* (NULL = the engine's own stream).
+ *
+ * Bucket keys are the reference's int16 keys.  Dense rows are indexed by
+ * bin = (uint16)key ^ 0x8000, so ascending bin == ascending key == ascending
+ * decompressed value.
+ */
+#ifndef LOGHISTO_GPU_H
+#define LOGHISTO_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LH_ABI_VERSION 1
+#define LH_NKEYS 65536            /* int16 key space (metrics.go:316)        */
+#define LH_NTHRESH 70980          /* extended-key thresholds incl. sentinel  */
+#define LH_MAX_PERCENTILES 32
+
+enum {
+    LH_OK = 0,
+    LH_EINVAL = 1,      /* bad argument                                      */
+    LH_ENOMEM = 2,      /* host or device allocation failed                  */
+    LH_EDEVICE = 3,     /* HIP runtime error (see lh_last_error)             */
+    LH_ENODEVICE = 4,   /* no usable gfx950 device                           */
+    LH_EBUSY = 5,       /* lh_flip: every epoch buffer still has a live snapshot */
+    LH_ERANGE = 6,      /* metric id >= max_metrics / table full             */
+    LH_ESTATE = 7       /* call not valid in this state                      */
+};
+
+typedef struct lh_engine lh_engine;
+typedef struct lh_snapshot lh_snapshot;
+
+typedef struct lh_config {
+    uint32_t struct_size;   /* sizeof(lh_config), for ABI growth              */
+    int32_t  device;        /* HIP device ordinal                             */
+    uint32_t max_metrics;   /* dense rows per epoch buffer (512 KiB each)     */
+    uint32_t num_buffers;   /* epoch buffers, >= 2                            */
+    uint32_t num_lanes;     /* host staging lanes (one HIP stream each)       */
+    uint32_t reserved0;
+    uint64_t lane_samples;  /* samples per pinned half-buffer of a lane       */
+} lh_config;
+
+/* Per-metric result of processHistograms (metrics.go:336-376). */
+typedef struct lh_stats {
+    uint64_t count;        /* totalCount                                      */
+    double   sum;          /* totalSum (fixed parallel order)  */
+    double   avg;          /* sum / float64(count); NaN when count == 0       */
+    uint64_t agg_sum_add;  /* uint64(totalSum), amd64 conversion (metrics.go:374) */
+    uint32_t nbuckets;     /* occupied buckets                                */
+    uint32_t present;      /* 1 iff the metric received a sample this epoch   */
+} lh_stats;
+
+int lh_abi_version(void);
+const char *lh_strerror(int code);
+/* Thread-local text of the last HIP failure seen by this thread ("" if none). */
+const char *lh_last_error(void);
+
+int lh_default_config(lh_config *cfg);
+/* NewMetricSystem (metrics.go:143) calls this; Stop (metrics.go:651) -> lh_destroy. */
+int lh_create(const lh_config *cfg, lh_engine **out);
+int lh_destroy(lh_engine *e);
+
+/* name -> dense metric id (idempotent, thread-safe).  Replaces the string-keyed
+ * outer map of histogramCache (metrics.go:119). */
+int lh_intern(lh_engine *e, const char *name, size_t len, uint32_t *id);
+int lh_lookup(lh_engine *e, const char *name, size_t len, uint32_t *id); /* LH_ERANGE if unknown */
+int lh_num_metrics(lh_engine *e, uint32_t *n);
+/* Copies up to cap bytes of the name (no terminator); *len receives the full length. */
+int lh_metric_name(lh_engine *e, uint32_t id, char *buf, size_t cap, size_t *len);
+
+/* Host-memory ingest: Histogram(name, v[i]) for i < n (metrics.go:273). */
+int lh_submit(lh_engine *e, uint32_t id, const double *v, size_t n);
+/* Mixed batch: Histogram(name(ids[i]), v[i]). */
+int lh_submit_pairs(lh_engine *e, const uint32_t *ids, const double *v, size_t n);
+/* Device-memory ingest for GPU-resident producers; asynchronous on `stream`.
+ * The buffers must stay valid until the stream reaches this point. */
+int lh_submit_device(lh_engine *e, uint32_t id, const double *d_v, size_t n, void *stream);
+int lh_submit_pairs_device(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t n, void *stream);
+/* Push partially filled staging buffers to the device (asynchronous). */
+int lh_flush(lh_engine *e);
+/* Wait until every sample submitted so far is in the bucket arrays. */
+int lh_sync(lh_engine *e);
+
+/* Epoch boundary (metrics.go:460-463).  Returns LH_EBUSY if no epoch buffer is
+ * free; the current epoch simply keeps accumulating in that case. */
+int lh_flip(lh_engine *e, lh_snapshot **out);
+/* processHistograms for metrics [0, nmetrics) of the snapshot.
+ *   p[np]                     percentiles in [0,1] (metrics.go:145-155)
+ *   stats[nmetrics]
+ *   pvals[nmetrics*np]        always exactly some decompress(key)
+ *   pkeys[nmetrics*np]        (may be NULL) the selected int16 keys
+ *   pvalid[nmetrics*np]       (may be NULL) 0 where the reference returns
+ *                             "Invalid percentile" (metrics.go:417) or count==0 */
+int lh_extract(lh_snapshot *s, const double *p, size_t np, lh_stats *stats,
+               double *pvals, int16_t *pkeys, uint8_t *pvalid, size_t nmetrics);
+/* Same for metrics [first, first+nmetrics): the rows a rank owns after a
+ * reduce-scatter merge. */
+int lh_extract_rows(lh_snapshot *s, uint32_t first, size_t nmetrics, const double *p, size_t np,
+                    lh_stats *stats, double *pvals, int16_t *pkeys, uint8_t *pvalid);
+/* Occupied cells of one metric, ascending key. *n receives the number of
+ * occupied cells even when it exceeds cap. */
+int lh_buckets(lh_snapshot *s, uint32_t id, int16_t *keys, uint64_t *counts, size_t cap, size_t *n);
+/* Dense device view of the snapshot for the multi-GPU merge: row r of metric r
+ * is d_counts + r*65536 (uint64).  After an in-place reduction the caller must
+ * call lh_snapshot_mark_dirty so that extract/clear cover the merged cells. */
+int lh_snapshot_rows(lh_snapshot *s, void **d_counts, uint32_t *nrows);
+int lh_snapshot_ranges(lh_snapshot *s, void **d_ranges /* uint32[nrows][2] lo,hi bins */);
+int lh_snapshot_mark_dirty(lh_snapshot *s, uint32_t first_row, uint32_t nrows, uint32_t lo_bin, uint32_t hi_bin);
+/* Stream on which the snapshot's extract/clear work is ordered (hipStream_t). */
+int lh_snapshot_stream(lh_snapshot *s, void **stream);
+/* Returns the snapshot's buffer to the pool (cleared asynchronously). */
+int lh_release(lh_snapshot *s);
+
+/* Codec access for parity tests. */
+/* key[i] = compress(d_v[i]) on device (metrics.go:316-322). */
+int lh_compress_device(lh_engine *e, const double *d_v, int16_t *d_keys, size_t n, void *stream);
+/* Same arithmetic but through the device restatement of Go's math.Log instead of
+ * the fast path + threshold table (cross-check of the two device routes). */
+int lh_compress_device_golog(lh_engine *e, const double *d_v, int16_t *d_keys, size_t n, void *stream);
+/* Copies the device-generated tables to host: Tx[LH_NTHRESH] (thresholds in
+ * x = 1+|v| space) and D[LH_NKEYS] (decompress by bin).  Either may be NULL. */
+int lh_codec_tables(lh_engine *e, double *Tx, double *D);
+/* max |v_log_f32(m) - log2(m)| over all 2^23 fp32 mantissas m in [1,2): the
+ * measured bound the fast path's guard band rests on. */
+int lh_selftest_vlog(lh_engine *e, double *max_abs_err);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOGHISTO_GPU_H */

@@ -1,0 +1,115 @@
+"""ctypes binding of liblhgpu.so (include/loghisto_gpu.h).
+
+There is no fallback: if the shared object is missing or does not export the ABI
+this module raises.  All bucket arithmetic happens in the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblhgpu.so")
+
+ABI_VERSION = 1
+NKEYS = 65536
+NTHRESH = 70980
+MAX_PERCENTILES = 32
+
+OK, EINVAL, ENOMEM, EDEVICE, ENODEVICE, EBUSY, ERANGE, ESTATE = range(8)
+
+
+class LhConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("max_metrics", C.c_uint32),
+                ("num_buffers", C.c_uint32), ("num_lanes", C.c_uint32), ("reserved0", C.c_uint32),
+                ("lane_samples", C.c_uint64)]
+
+
+class LhStats(C.Structure):
+    _fields_ = [("count", C.c_uint64), ("sum", C.c_double), ("avg", C.c_double),
+                ("agg_sum_add", C.c_uint64), ("nbuckets", C.c_uint32), ("present", C.c_uint32)]
+
+
+_vp, _sz = C.c_void_p, C.c_size_t
+_dp, _u32p, _u64p = C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+_i16p, _u8p = C.POINTER(C.c_int16), C.POINTER(C.c_uint8)
+
+# name -> (restype, argtypes): every symbol include/loghisto_gpu.h declares.
+SIGNATURES = {
+    "lh_abi_version": (C.c_int, []),
+    "lh_strerror": (C.c_char_p, [C.c_int]),
+    "lh_last_error": (C.c_char_p, []),
+    "lh_default_config": (C.c_int, [C.POINTER(LhConfig)]),
+    "lh_create": (C.c_int, [C.POINTER(LhConfig), C.POINTER(_vp)]),
+    "lh_destroy": (C.c_int, [_vp]),
+    "lh_intern": (C.c_int, [_vp, C.c_char_p, _sz, _u32p]),
+    "lh_lookup": (C.c_int, [_vp, C.c_char_p, _sz, _u32p]),
+    "lh_num_metrics": (C.c_int, [_vp, _u32p]),
+    "lh_metric_name": (C.c_int, [_vp, C.c_uint32, C.c_char_p, _sz, C.POINTER(_sz)]),
+    "lh_submit": (C.c_int, [_vp, C.c_uint32, _vp, _sz]),
+    "lh_submit_pairs": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "lh_submit_device": (C.c_int, [_vp, C.c_uint32, _vp, _sz, _vp]),
+    "lh_submit_pairs_device": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
+    "lh_flush": (C.c_int, [_vp]),
+    "lh_sync": (C.c_int, [_vp]),
+    "lh_flip": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "lh_extract": (C.c_int, [_vp, _dp, _sz, C.POINTER(LhStats), _dp, _i16p, _u8p, _sz]),
+    "lh_extract_rows": (C.c_int, [_vp, C.c_uint32, _sz, _dp, _sz, C.POINTER(LhStats), _dp, _i16p, _u8p]),
+    "lh_buckets": (C.c_int, [_vp, C.c_uint32, _i16p, _u64p, _sz, C.POINTER(_sz)]),
+    "lh_snapshot_rows": (C.c_int, [_vp, C.POINTER(_vp), _u32p]),
+    "lh_snapshot_ranges": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "lh_snapshot_mark_dirty": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "lh_snapshot_stream": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "lh_release": (C.c_int, [_vp]),
+    "lh_compress_device": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
+    "lh_compress_device_golog": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
+    "lh_codec_tables": (C.c_int, [_vp, _dp, _dp]),
+    "lh_selftest_vlog": (C.c_int, [_vp, _dp]),
+}
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+class LhError(RuntimeError):
+    def __init__(self, code: int, where: str, detail: str = ""):
+        self.code = code
+        msg = f"{where}: {lib().lh_strerror(code).decode()} (code {code})"
+        if detail:
+            msg += f" [{detail}]"
+        super().__init__(msg)
+
+
+def lib():
+    """Load liblhgpu.so; raises NativeLibraryError if it is absent or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -m loghisto_amd.build` "
+            "(hipcc, gfx950). loghisto_amd has no CPU path.")
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as exc:  # e.g. libamdhip64 not found
+        raise NativeLibraryError(f"cannot load {LIB_PATH}: {exc}") from exc
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError as exc:
+            raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from exc
+        fn.restype = res
+        fn.argtypes = args
+    if L.lh_abi_version() != ABI_VERSION:
+        raise NativeLibraryError(f"ABI mismatch: library {L.lh_abi_version()}, binding {ABI_VERSION}")
+    _lib = L
+    return L
+
+
+def check(code: int, where: str):
+    if code != OK:
+        detail = lib().lh_last_error().decode() if code in (EDEVICE, ENODEVICE) else ""
+        raise LhError(code, where, detail)

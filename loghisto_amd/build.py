@@ -1,0 +1,67 @@
+"""In-tree build of liblhgpu.so (hipcc, gfx950 only).
+
+`python -m loghisto_amd.build` or `__graft_entry__.build()`.  The shared object is
+written next to this file so that it travels to the GPU box with the repository
+snapshot; it is git-ignored.  hipcc cross-compiles gfx950 without a GPU.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+LIB = os.path.join(_HERE, "liblhgpu.so")
+
+# -ffp-contract=off: lh_codec.h restates Go's math.Log/Exp operation by operation.
+_COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wextra",
+           "-Wno-unused-parameter"]
+_UNITS = [
+    ("lh_kernels.hip", ["--offload-arch=gfx950"]),
+    ("lh_engine.cc", []),
+]
+
+
+def _hipcc() -> str:
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found; liblhgpu.so cannot be built")
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_native(force: bool = False, verbose: bool = False) -> str:
+    hipcc = _hipcc()
+    bdir = os.path.join(_HERE, "build")
+    os.makedirs(bdir, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(INCLUDE, "loghisto_gpu.h"))
+    objs = []
+    for src, extra in _UNITS:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(bdir, os.path.splitext(src)[0] + ".o")
+        if force or _stale(o, [s] + headers):
+            cmd = [hipcc] + _COMMON + extra + ["-I", INCLUDE, "-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+        objs.append(o)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_native(force="--force" in sys.argv, verbose=True))

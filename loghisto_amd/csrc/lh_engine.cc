@@ -1,0 +1,786 @@
+// lh_engine.cc -- host runtime and C ABI of liblhgpu.so (include/loghisto_gpu.h).
+//
+// What lives here, and what it replaces in the reference:
+//   * name -> id intern table        : outer map of histogramCache (metrics.go:119)
+//   * staging lanes (pinned double buffers + one HIP stream each)
+//                                    : the per-call path of Histogram (metrics.go:273-295),
+//                                      batched because a cgo crossing costs more than the
+//                                      whole Go fast path (SURVEY.md 8b "cost model")
+//   * epoch buffers + flip           : the map swap in collectRawMetrics (metrics.go:460-463)
+//   * extract                        : processHistograms / percentile (metrics.go:336-418)
+//
+// All bucket arithmetic runs in the kernels of lh_kernels.hip.  There is no CPU
+// compute path: without a gfx950 device lh_create fails with LH_ENODEVICE.
+#include "../../include/loghisto_gpu.h"
+#include "lh_kernels.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <shared_mutex>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+thread_local char g_last_error[512] = "";
+
+void set_last_error(const char *what, hipError_t e)
+{
+    std::snprintf(g_last_error, sizeof(g_last_error), "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
+}
+
+#define HIPCHK(expr)                                                                                        \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess) {                                                                             \
+            set_last_error(#expr, _e);                                                                      \
+            return LH_EDEVICE;                                                                              \
+        }                                                                                                   \
+    } while (0)
+
+enum BufState { BUF_FREE = 0, BUF_CURRENT = 1, BUF_SNAPSHOT = 2 };
+
+struct EpochBuffer {
+    uint64_t *counts = nullptr;  // [max_metrics][65536]
+    uint32_t *ranges = nullptr;  // [max_metrics][2]
+    hipEvent_t cleared = nullptr; // recorded on xstream after the last clear
+    BufState state = BUF_FREE;
+};
+
+enum LaneMode { LANE_NONE = 0, LANE_SINGLE = 1, LANE_PAIRS = 2 };
+
+struct Lane {
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+    double *h_vals[2] = {nullptr, nullptr};
+    uint32_t *h_ids[2] = {nullptr, nullptr};
+    double *d_vals[2] = {nullptr, nullptr};
+    uint32_t *d_ids[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    bool inflight[2] = {false, false};
+    int cur = 0;
+    size_t fill = 0;
+    LaneMode mode = LANE_NONE;
+    uint32_t single_id = 0;
+};
+
+// One D2H block per extract call.
+struct ExtractLayout {
+    size_t off_stats, off_pvals, off_pkeys, off_pvalid, off_err, total;
+};
+
+ExtractLayout extract_layout(size_t nmetrics, size_t np)
+{
+    ExtractLayout L;
+    size_t o = 0;
+    L.off_stats = o; o += nmetrics * sizeof(lh::ExtractOut);
+    L.off_pvals = o; o += nmetrics * np * sizeof(double);
+    L.off_pkeys = o; o += (nmetrics * np * sizeof(int16_t) + 7) & ~size_t(7);
+    L.off_pvalid = o; o += (nmetrics * np + 7) & ~size_t(7);
+    L.off_err = o; o += 8;
+    L.total = o;
+    return L;
+}
+
+} // namespace
+
+struct lh_engine {
+    lh_config cfg{};
+    int device = 0;
+    int num_cus = 256;
+
+    double *d_Tx = nullptr;
+    double *d_D = nullptr;
+    uint32_t *d_err = nullptr;
+
+    std::vector<EpochBuffer> bufs;
+    int cur = 0;
+    std::shared_mutex epoch_mu; // submitters shared, flip unique (histogramMu, metrics.go:121)
+
+    std::mutex streams_mu;
+    std::vector<hipStream_t> epoch_streams; // streams that touched the current epoch buffer
+    std::vector<hipEvent_t> flip_events;
+
+    hipStream_t main_stream = nullptr; // device submits with stream == NULL
+    hipStream_t xstream = nullptr;     // extract / clear
+
+    std::vector<std::unique_ptr<Lane>> lanes;
+
+    std::shared_mutex names_mu;
+    std::unordered_map<std::string, uint32_t> name2id;
+    std::vector<std::string> names;
+
+    std::mutex xmu; // extract scratch
+    unsigned char *d_xbuf = nullptr;
+    unsigned char *h_xbuf = nullptr;
+    size_t xbuf_bytes = 0;
+    double *d_p = nullptr;
+    double *h_p = nullptr;
+
+    std::atomic<int> live_snapshots{0};
+};
+
+struct lh_snapshot {
+    lh_engine *e;
+    int buf;
+};
+
+namespace {
+
+int use_device(lh_engine *e)
+{
+    HIPCHK(hipSetDevice(e->device));
+    return LH_OK;
+}
+
+// Make `s` wait for the current epoch buffer's last clear the first time it is
+// used in this epoch, and remember it so lh_flip can order the extract after it.
+int epoch_touch_stream(lh_engine *e, hipStream_t s)
+{
+    std::lock_guard<std::mutex> g(e->streams_mu);
+    for (hipStream_t t : e->epoch_streams)
+        if (t == s) return LH_OK;
+    HIPCHK(hipStreamWaitEvent(s, e->bufs[(size_t)e->cur].cleared, 0));
+    e->epoch_streams.push_back(s);
+    return LH_OK;
+}
+
+int launch_single(lh_engine *e, uint32_t id, const double *d_v, size_t n, hipStream_t s)
+{
+    EpochBuffer &b = e->bufs[(size_t)e->cur];
+    HIPCHK(lh::launch_ingest_single(d_v, n, b.counts + (size_t)id * LH_NKEYS, b.ranges + 2 * (size_t)id,
+                                    e->d_Tx, e->num_cus, s));
+    return LH_OK;
+}
+
+int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t n, hipStream_t s)
+{
+    EpochBuffer &b = e->bufs[(size_t)e->cur];
+    HIPCHK(lh::launch_ingest_pairs(d_ids, d_v, n, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx, e->d_err,
+                                   e->num_cus, s));
+    return LH_OK;
+}
+
+// Lane mutex held, epoch lock held (shared or unique).
+int lane_launch(lh_engine *e, Lane &ln)
+{
+    if (ln.fill == 0) return LH_OK;
+    const int h = ln.cur;
+    const size_t n = ln.fill;
+    int rc = epoch_touch_stream(e, ln.stream);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(ln.d_vals[h], ln.h_vals[h], n * sizeof(double), hipMemcpyHostToDevice, ln.stream));
+    if (ln.mode == LANE_PAIRS) {
+        HIPCHK(hipMemcpyAsync(ln.d_ids[h], ln.h_ids[h], n * sizeof(uint32_t), hipMemcpyHostToDevice, ln.stream));
+        rc = launch_pairs(e, ln.d_ids[h], ln.d_vals[h], n, ln.stream);
+    } else {
+        rc = launch_single(e, ln.single_id, ln.d_vals[h], n, ln.stream);
+    }
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(ln.done[h], ln.stream));
+    ln.inflight[h] = true;
+    ln.cur ^= 1;
+    ln.fill = 0;
+    ln.mode = LANE_NONE;
+    if (ln.inflight[ln.cur]) { // back-pressure: never drop (metrics.go:273-295 is synchronous)
+        HIPCHK(hipEventSynchronize(ln.done[ln.cur]));
+        ln.inflight[ln.cur] = false;
+    }
+    return LH_OK;
+}
+
+Lane &pick_lane(lh_engine *e)
+{
+    const size_t h = std::hash<std::thread::id>()(std::this_thread::get_id());
+    return *e->lanes[h % e->lanes.size()];
+}
+
+int flush_all_lanes(lh_engine *e)
+{
+    for (auto &lp : e->lanes) {
+        std::lock_guard<std::mutex> g(lp->mu);
+        int rc = lane_launch(e, *lp);
+        if (rc) return rc;
+    }
+    return LH_OK;
+}
+
+void free_engine(lh_engine *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();
+    for (auto &lp : e->lanes) {
+        if (!lp) continue;
+        for (int h = 0; h < 2; h++) {
+            if (lp->h_vals[h]) (void)hipHostFree(lp->h_vals[h]);
+            if (lp->h_ids[h]) (void)hipHostFree(lp->h_ids[h]);
+            if (lp->d_vals[h]) (void)hipFree(lp->d_vals[h]);
+            if (lp->d_ids[h]) (void)hipFree(lp->d_ids[h]);
+            if (lp->done[h]) (void)hipEventDestroy(lp->done[h]);
+        }
+        if (lp->stream) (void)hipStreamDestroy(lp->stream);
+    }
+    for (auto &b : e->bufs) {
+        if (b.counts) (void)hipFree(b.counts);
+        if (b.ranges) (void)hipFree(b.ranges);
+        if (b.cleared) (void)hipEventDestroy(b.cleared);
+    }
+    for (hipEvent_t ev : e->flip_events) (void)hipEventDestroy(ev);
+    if (e->d_Tx) (void)hipFree(e->d_Tx);
+    if (e->d_D) (void)hipFree(e->d_D);
+    if (e->d_err) (void)hipFree(e->d_err);
+    if (e->d_xbuf) (void)hipFree(e->d_xbuf);
+    if (e->h_xbuf) (void)hipHostFree(e->h_xbuf);
+    if (e->d_p) (void)hipFree(e->d_p);
+    if (e->h_p) (void)hipHostFree(e->h_p);
+    if (e->main_stream) (void)hipStreamDestroy(e->main_stream);
+    if (e->xstream) (void)hipStreamDestroy(e->xstream);
+    delete e;
+}
+
+int ensure_xbuf(lh_engine *e, size_t bytes)
+{
+    if (bytes <= e->xbuf_bytes) return LH_OK;
+    if (e->d_xbuf) (void)hipFree(e->d_xbuf);
+    if (e->h_xbuf) (void)hipHostFree(e->h_xbuf);
+    e->d_xbuf = nullptr;
+    e->h_xbuf = nullptr;
+    e->xbuf_bytes = 0;
+    size_t cap = bytes + bytes / 4 + 4096;
+    HIPCHK(hipMalloc((void **)&e->d_xbuf, cap));
+    HIPCHK(hipHostMalloc((void **)&e->h_xbuf, cap, hipHostMallocDefault));
+    e->xbuf_bytes = cap;
+    return LH_OK;
+}
+
+int create_impl(const lh_config *cfg_in, lh_engine *e)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        std::snprintf(g_last_error, sizeof(g_last_error), "no HIP device visible");
+        return LH_ENODEVICE;
+    }
+    if (cfg_in->device < 0 || cfg_in->device >= ndev) return LH_EINVAL;
+    e->device = cfg_in->device;
+    HIPCHK(hipSetDevice(e->device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, e->device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        std::snprintf(g_last_error, sizeof(g_last_error), "device %d is %s; this library carries gfx950 code only",
+                      e->device, prop.gcnArchName);
+        return LH_ENODEVICE;
+    }
+    e->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+
+    HIPCHK(hipStreamCreateWithFlags(&e->main_stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&e->xstream, hipStreamNonBlocking));
+
+    HIPCHK(hipMalloc((void **)&e->d_Tx, sizeof(double) * LH_NTHRESH));
+    HIPCHK(hipMalloc((void **)&e->d_D, sizeof(double) * LH_NKEYS));
+    HIPCHK(hipMalloc((void **)&e->d_err, 8));
+    HIPCHK(hipMemsetAsync(e->d_err, 0, 8, e->xstream));
+    HIPCHK(lh::launch_gen_tables(e->d_Tx, e->d_D, e->xstream));
+    HIPCHK(hipMalloc((void **)&e->d_p, sizeof(double) * LH_MAX_PERCENTILES));
+    HIPCHK(hipHostMalloc((void **)&e->h_p, sizeof(double) * LH_MAX_PERCENTILES, hipHostMallocDefault));
+
+    const size_t M = e->cfg.max_metrics;
+    e->bufs.resize(e->cfg.num_buffers);
+    for (auto &b : e->bufs) {
+        HIPCHK(hipMalloc((void **)&b.counts, M * LH_NKEYS * sizeof(uint64_t)));
+        HIPCHK(hipMalloc((void **)&b.ranges, M * 2 * sizeof(uint32_t)));
+        HIPCHK(hipMemsetAsync(b.counts, 0, M * LH_NKEYS * sizeof(uint64_t), e->xstream));
+        HIPCHK(lh::launch_init_ranges(b.ranges, (uint32_t)M, e->xstream));
+        HIPCHK(hipEventCreateWithFlags(&b.cleared, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(b.cleared, e->xstream));
+        b.state = BUF_FREE;
+    }
+    e->cur = 0;
+    e->bufs[0].state = BUF_CURRENT;
+
+    for (uint32_t i = 0; i < e->cfg.num_lanes; i++) {
+        std::unique_ptr<Lane> ln(new (std::nothrow) Lane());
+        if (!ln) return LH_ENOMEM;
+        HIPCHK(hipStreamCreateWithFlags(&ln->stream, hipStreamNonBlocking));
+        for (int h = 0; h < 2; h++) {
+            HIPCHK(hipHostMalloc((void **)&ln->h_vals[h], e->cfg.lane_samples * sizeof(double), hipHostMallocDefault));
+            HIPCHK(hipHostMalloc((void **)&ln->h_ids[h], e->cfg.lane_samples * sizeof(uint32_t), hipHostMallocDefault));
+            HIPCHK(hipMalloc((void **)&ln->d_vals[h], e->cfg.lane_samples * sizeof(double)));
+            HIPCHK(hipMalloc((void **)&ln->d_ids[h], e->cfg.lane_samples * sizeof(uint32_t)));
+            HIPCHK(hipEventCreateWithFlags(&ln->done[h], hipEventDisableTiming));
+        }
+        e->lanes.push_back(std::move(ln));
+    }
+    HIPCHK(hipStreamSynchronize(e->xstream));
+    return LH_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int lh_abi_version(void) { return LH_ABI_VERSION; }
+
+const char *lh_strerror(int code)
+{
+    switch (code) {
+    case LH_OK: return "ok";
+    case LH_EINVAL: return "invalid argument";
+    case LH_ENOMEM: return "out of memory";
+    case LH_EDEVICE: return "HIP runtime error";
+    case LH_ENODEVICE: return "no usable gfx950 device";
+    case LH_EBUSY: return "no free epoch buffer (release a snapshot first)";
+    case LH_ERANGE: return "metric id out of range";
+    case LH_ESTATE: return "invalid state for this call";
+    default: return "unknown error";
+    }
+}
+
+const char *lh_last_error(void) { return g_last_error; }
+
+int lh_default_config(lh_config *cfg)
+{
+    if (!cfg) return LH_EINVAL;
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->struct_size = (uint32_t)sizeof(lh_config);
+    cfg->device = 0;
+    cfg->max_metrics = 1024;
+    cfg->num_buffers = 2;
+    cfg->num_lanes = 4;
+    cfg->lane_samples = 1u << 20; // 8 MiB of float64 per half-buffer
+    return LH_OK;
+}
+
+int lh_create(const lh_config *cfg, lh_engine **out)
+{
+    if (!cfg || !out) return LH_EINVAL;
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(lh_config)) return LH_EINVAL;
+    if (cfg->max_metrics == 0 || cfg->num_buffers < 2 || cfg->num_buffers > 16 || cfg->num_lanes == 0 ||
+        cfg->num_lanes > 256 || cfg->lane_samples < 2 || cfg->lane_samples > (1ull << 28))
+        return LH_EINVAL;
+    lh_engine *e = new (std::nothrow) lh_engine();
+    if (!e) return LH_ENOMEM;
+    e->cfg = *cfg;
+    int rc = create_impl(cfg, e);
+    if (rc != LH_OK) {
+        free_engine(e);
+        return rc;
+    }
+    *out = e;
+    return LH_OK;
+}
+
+int lh_destroy(lh_engine *e)
+{
+    if (!e) return LH_EINVAL;
+    if (e->live_snapshots.load() != 0) return LH_ESTATE;
+    free_engine(e);
+    return LH_OK;
+}
+
+int lh_intern(lh_engine *e, const char *name, size_t len, uint32_t *id)
+{
+    if (!e || (!name && len) || !id) return LH_EINVAL;
+    std::string key(name ? name : "", len);
+    {
+        std::shared_lock<std::shared_mutex> g(e->names_mu);
+        auto it = e->name2id.find(key);
+        if (it != e->name2id.end()) { *id = it->second; return LH_OK; }
+    }
+    std::unique_lock<std::shared_mutex> g(e->names_mu);
+    auto it = e->name2id.find(key);
+    if (it != e->name2id.end()) { *id = it->second; return LH_OK; }
+    if (e->names.size() >= e->cfg.max_metrics) return LH_ERANGE;
+    const uint32_t nid = (uint32_t)e->names.size();
+    e->names.push_back(key);
+    e->name2id.emplace(std::move(key), nid);
+    *id = nid;
+    return LH_OK;
+}
+
+int lh_lookup(lh_engine *e, const char *name, size_t len, uint32_t *id)
+{
+    if (!e || (!name && len) || !id) return LH_EINVAL;
+    std::string key(name ? name : "", len);
+    std::shared_lock<std::shared_mutex> g(e->names_mu);
+    auto it = e->name2id.find(key);
+    if (it == e->name2id.end()) return LH_ERANGE;
+    *id = it->second;
+    return LH_OK;
+}
+
+int lh_num_metrics(lh_engine *e, uint32_t *n)
+{
+    if (!e || !n) return LH_EINVAL;
+    std::shared_lock<std::shared_mutex> g(e->names_mu);
+    *n = (uint32_t)e->names.size();
+    return LH_OK;
+}
+
+int lh_metric_name(lh_engine *e, uint32_t id, char *buf, size_t cap, size_t *len)
+{
+    if (!e || !len || (!buf && cap)) return LH_EINVAL;
+    std::shared_lock<std::shared_mutex> g(e->names_mu);
+    if (id >= e->names.size()) return LH_ERANGE;
+    const std::string &s = e->names[id];
+    *len = s.size();
+    if (cap) std::memcpy(buf, s.data(), s.size() < cap ? s.size() : cap);
+    return LH_OK;
+}
+
+int lh_submit(lh_engine *e, uint32_t id, const double *v, size_t n)
+{
+    if (!e || (!v && n)) return LH_EINVAL;
+    if (id >= e->cfg.max_metrics) return LH_ERANGE;
+    if (n == 0) return LH_OK;
+    int rc = use_device(e);
+    if (rc) return rc;
+    std::shared_lock<std::shared_mutex> eg(e->epoch_mu);
+    Lane &ln = pick_lane(e);
+    std::lock_guard<std::mutex> g(ln.mu);
+    if (ln.fill && (ln.mode != LANE_SINGLE || ln.single_id != id)) {
+        rc = lane_launch(e, ln);
+        if (rc) return rc;
+    }
+    const size_t cap = (size_t)e->cfg.lane_samples;
+    while (n) {
+        ln.mode = LANE_SINGLE;
+        ln.single_id = id;
+        const size_t take = (cap - ln.fill) < n ? (cap - ln.fill) : n;
+        std::memcpy(ln.h_vals[ln.cur] + ln.fill, v, take * sizeof(double));
+        ln.fill += take;
+        v += take;
+        n -= take;
+        if (ln.fill == cap) {
+            rc = lane_launch(e, ln);
+            if (rc) return rc;
+        }
+    }
+    return LH_OK;
+}
+
+int lh_submit_pairs(lh_engine *e, const uint32_t *ids, const double *v, size_t n)
+{
+    if (!e || ((!v || !ids) && n)) return LH_EINVAL;
+    if (n == 0) return LH_OK;
+    for (size_t i = 0; i < n; i++)
+        if (ids[i] >= e->cfg.max_metrics) return LH_ERANGE;
+    int rc = use_device(e);
+    if (rc) return rc;
+    std::shared_lock<std::shared_mutex> eg(e->epoch_mu);
+    Lane &ln = pick_lane(e);
+    std::lock_guard<std::mutex> g(ln.mu);
+    if (ln.fill && ln.mode != LANE_PAIRS) {
+        rc = lane_launch(e, ln);
+        if (rc) return rc;
+    }
+    const size_t cap = (size_t)e->cfg.lane_samples;
+    while (n) {
+        ln.mode = LANE_PAIRS;
+        const size_t take = (cap - ln.fill) < n ? (cap - ln.fill) : n;
+        std::memcpy(ln.h_vals[ln.cur] + ln.fill, v, take * sizeof(double));
+        std::memcpy(ln.h_ids[ln.cur] + ln.fill, ids, take * sizeof(uint32_t));
+        ln.fill += take;
+        v += take;
+        ids += take;
+        n -= take;
+        if (ln.fill == cap) {
+            rc = lane_launch(e, ln);
+            if (rc) return rc;
+        }
+    }
+    return LH_OK;
+}
+
+int lh_submit_device(lh_engine *e, uint32_t id, const double *d_v, size_t n, void *stream)
+{
+    if (!e || (!d_v && n)) return LH_EINVAL;
+    if (id >= e->cfg.max_metrics) return LH_ERANGE;
+    if (((uintptr_t)d_v & 7) != 0) return LH_EINVAL;
+    if (n == 0) return LH_OK;
+    int rc = use_device(e);
+    if (rc) return rc;
+    hipStream_t s = stream ? (hipStream_t)stream : e->main_stream;
+    std::shared_lock<std::shared_mutex> eg(e->epoch_mu);
+    rc = epoch_touch_stream(e, s);
+    if (rc) return rc;
+    return launch_single(e, id, d_v, n, s);
+}
+
+int lh_submit_pairs_device(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t n, void *stream)
+{
+    if (!e || ((!d_v || !d_ids) && n)) return LH_EINVAL;
+    if (((uintptr_t)d_v & 7) != 0 || ((uintptr_t)d_ids & 3) != 0) return LH_EINVAL;
+    if (n == 0) return LH_OK;
+    int rc = use_device(e);
+    if (rc) return rc;
+    hipStream_t s = stream ? (hipStream_t)stream : e->main_stream;
+    std::shared_lock<std::shared_mutex> eg(e->epoch_mu);
+    rc = epoch_touch_stream(e, s);
+    if (rc) return rc;
+    return launch_pairs(e, d_ids, d_v, n, s);
+}
+
+int lh_flush(lh_engine *e)
+{
+    if (!e) return LH_EINVAL;
+    int rc = use_device(e);
+    if (rc) return rc;
+    std::shared_lock<std::shared_mutex> eg(e->epoch_mu);
+    return flush_all_lanes(e);
+}
+
+int lh_sync(lh_engine *e)
+{
+    if (!e) return LH_EINVAL;
+    int rc = use_device(e);
+    if (rc) return rc;
+    std::vector<hipStream_t> ss;
+    {
+        std::shared_lock<std::shared_mutex> eg(e->epoch_mu);
+        rc = flush_all_lanes(e);
+        if (rc) return rc;
+        std::lock_guard<std::mutex> g(e->streams_mu);
+        ss = e->epoch_streams;
+    }
+    for (hipStream_t s : ss) HIPCHK(hipStreamSynchronize(s));
+    uint32_t err = 0;
+    HIPCHK(hipMemcpy(&err, e->d_err, sizeof(err), hipMemcpyDeviceToHost));
+    if (err) {
+        HIPCHK(hipMemset(e->d_err, 0, 8));
+        return LH_ERANGE;
+    }
+    return LH_OK;
+}
+
+int lh_flip(lh_engine *e, lh_snapshot **out)
+{
+    if (!e || !out) return LH_EINVAL;
+    *out = nullptr;
+    int rc = use_device(e);
+    if (rc) return rc;
+    std::unique_lock<std::shared_mutex> eg(e->epoch_mu);
+    int next = -1;
+    for (size_t i = 0; i < e->bufs.size(); i++)
+        if (e->bufs[i].state == BUF_FREE) { next = (int)i; break; }
+    if (next < 0) return LH_EBUSY;
+    lh_snapshot *s = new (std::nothrow) lh_snapshot();
+    if (!s) return LH_ENOMEM;
+    rc = flush_all_lanes(e);
+    if (rc) { delete s; return rc; }
+    {
+        std::lock_guard<std::mutex> g(e->streams_mu);
+        while (e->flip_events.size() < e->epoch_streams.size()) {
+            hipEvent_t ev;
+            hipError_t he = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (he != hipSuccess) { set_last_error("hipEventCreateWithFlags", he); delete s; return LH_EDEVICE; }
+            e->flip_events.push_back(ev);
+        }
+        for (size_t i = 0; i < e->epoch_streams.size(); i++) {
+            hipError_t he = hipEventRecord(e->flip_events[i], e->epoch_streams[i]);
+            if (he == hipSuccess) he = hipStreamWaitEvent(e->xstream, e->flip_events[i], 0);
+            if (he != hipSuccess) { set_last_error("flip event chain", he); delete s; return LH_EDEVICE; }
+        }
+        e->epoch_streams.clear();
+    }
+    s->e = e;
+    s->buf = e->cur;
+    e->bufs[(size_t)e->cur].state = BUF_SNAPSHOT;
+    e->cur = next;
+    e->bufs[(size_t)next].state = BUF_CURRENT;
+    e->live_snapshots.fetch_add(1);
+    *out = s;
+    return LH_OK;
+}
+
+int lh_extract(lh_snapshot *s, const double *p, size_t np, lh_stats *stats, double *pvals, int16_t *pkeys,
+               uint8_t *pvalid, size_t nmetrics)
+{
+    return lh_extract_rows(s, 0, nmetrics, p, np, stats, pvals, pkeys, pvalid);
+}
+
+int lh_extract_rows(lh_snapshot *s, uint32_t first, size_t nmetrics, const double *p, size_t np, lh_stats *stats,
+                    double *pvals, int16_t *pkeys, uint8_t *pvalid)
+{
+    if (!s || (nmetrics && !stats) || (np && nmetrics && (!p || !pvals))) return LH_EINVAL;
+    lh_engine *e = s->e;
+    if (np > LH_MAX_PERCENTILES || (uint64_t)first + nmetrics > e->cfg.max_metrics) return LH_EINVAL;
+    if (nmetrics == 0) return LH_OK;
+    int rc = use_device(e);
+    if (rc) return rc;
+    static_assert(sizeof(lh::ExtractOut) == sizeof(lh_stats), "lh_stats layout");
+    std::lock_guard<std::mutex> g(e->xmu);
+    const ExtractLayout L = extract_layout(nmetrics, np);
+    rc = ensure_xbuf(e, L.total);
+    if (rc) return rc;
+    EpochBuffer &b = e->bufs[(size_t)s->buf];
+    if (np) {
+        std::memcpy(e->h_p, p, np * sizeof(double));
+        HIPCHK(hipMemcpyAsync(e->d_p, e->h_p, np * sizeof(double), hipMemcpyHostToDevice, e->xstream));
+    }
+    HIPCHK(lh::launch_extract(b.counts + (size_t)first * LH_NKEYS, b.ranges + 2 * (size_t)first,
+                              (uint32_t)nmetrics, e->d_p, (uint32_t)np, e->d_D,
+                              reinterpret_cast<lh::ExtractOut *>(e->d_xbuf + L.off_stats),
+                              reinterpret_cast<double *>(e->d_xbuf + L.off_pvals),
+                              reinterpret_cast<int16_t *>(e->d_xbuf + L.off_pkeys), e->d_xbuf + L.off_pvalid,
+                              e->xstream));
+    HIPCHK(hipMemcpyAsync(e->d_xbuf + L.off_err, e->d_err, 4, hipMemcpyDeviceToDevice, e->xstream));
+    HIPCHK(hipMemcpyAsync(e->h_xbuf, e->d_xbuf, L.total, hipMemcpyDeviceToHost, e->xstream));
+    HIPCHK(hipStreamSynchronize(e->xstream));
+    std::memcpy(stats, e->h_xbuf + L.off_stats, nmetrics * sizeof(lh_stats));
+    if (np) {
+        std::memcpy(pvals, e->h_xbuf + L.off_pvals, nmetrics * np * sizeof(double));
+        if (pkeys) std::memcpy(pkeys, e->h_xbuf + L.off_pkeys, nmetrics * np * sizeof(int16_t));
+        if (pvalid) std::memcpy(pvalid, e->h_xbuf + L.off_pvalid, nmetrics * np);
+    }
+    uint32_t err;
+    std::memcpy(&err, e->h_xbuf + L.off_err, 4);
+    if (err) {
+        HIPCHK(hipMemsetAsync(e->d_err, 0, 8, e->xstream));
+        return LH_ERANGE;
+    }
+    return LH_OK;
+}
+
+int lh_buckets(lh_snapshot *s, uint32_t id, int16_t *keys, uint64_t *counts, size_t cap, size_t *n)
+{
+    if (!s || !n || (cap && (!keys || !counts))) return LH_EINVAL;
+    lh_engine *e = s->e;
+    if (id >= e->cfg.max_metrics) return LH_ERANGE;
+    int rc = use_device(e);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(e->xmu);
+    EpochBuffer &b = e->bufs[(size_t)s->buf];
+    uint32_t r[2];
+    HIPCHK(hipMemcpyAsync(r, b.ranges + 2 * (size_t)id, sizeof(r), hipMemcpyDeviceToHost, e->xstream));
+    HIPCHK(hipStreamSynchronize(e->xstream));
+    *n = 0;
+    if (r[0] > r[1]) return LH_OK;
+    const size_t span = (size_t)r[1] - r[0] + 1;
+    rc = ensure_xbuf(e, span * sizeof(uint64_t));
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(e->h_xbuf, b.counts + (size_t)id * LH_NKEYS + r[0], span * sizeof(uint64_t),
+                          hipMemcpyDeviceToHost, e->xstream));
+    HIPCHK(hipStreamSynchronize(e->xstream));
+    const uint64_t *row = reinterpret_cast<const uint64_t *>(e->h_xbuf);
+    size_t k = 0;
+    for (size_t i = 0; i < span; i++) {
+        if (!row[i]) continue;
+        if (k < cap) {
+            keys[k] = (int16_t)(uint16_t)((r[0] + i) ^ 0x8000u);
+            counts[k] = row[i];
+        }
+        k++;
+    }
+    *n = k;
+    return LH_OK;
+}
+
+int lh_snapshot_rows(lh_snapshot *s, void **d_counts, uint32_t *nrows)
+{
+    if (!s || !d_counts) return LH_EINVAL;
+    *d_counts = s->e->bufs[(size_t)s->buf].counts;
+    if (nrows) *nrows = s->e->cfg.max_metrics;
+    return LH_OK;
+}
+
+int lh_snapshot_ranges(lh_snapshot *s, void **d_ranges)
+{
+    if (!s || !d_ranges) return LH_EINVAL;
+    *d_ranges = s->e->bufs[(size_t)s->buf].ranges;
+    return LH_OK;
+}
+
+int lh_snapshot_mark_dirty(lh_snapshot *s, uint32_t first_row, uint32_t nrows, uint32_t lo_bin, uint32_t hi_bin)
+{
+    if (!s) return LH_EINVAL;
+    lh_engine *e = s->e;
+    if ((uint64_t)first_row + nrows > e->cfg.max_metrics || lo_bin > hi_bin || hi_bin >= LH_NKEYS) return LH_EINVAL;
+    int rc = use_device(e);
+    if (rc) return rc;
+    HIPCHK(lh::launch_mark_dirty(e->bufs[(size_t)s->buf].ranges, first_row, nrows, lo_bin, hi_bin, e->xstream));
+    return LH_OK;
+}
+
+int lh_snapshot_stream(lh_snapshot *s, void **stream)
+{
+    if (!s || !stream) return LH_EINVAL;
+    *stream = (void *)s->e->xstream;
+    return LH_OK;
+}
+
+int lh_release(lh_snapshot *s)
+{
+    if (!s) return LH_EINVAL;
+    lh_engine *e = s->e;
+    int rc = use_device(e);
+    if (rc) return rc;
+    EpochBuffer &b = e->bufs[(size_t)s->buf];
+    {
+        std::lock_guard<std::mutex> g(e->xmu);
+        HIPCHK(lh::launch_clear(b.counts, b.ranges, e->cfg.max_metrics, e->xstream));
+        HIPCHK(hipEventRecord(b.cleared, e->xstream));
+    }
+    {
+        std::unique_lock<std::shared_mutex> eg(e->epoch_mu);
+        b.state = BUF_FREE;
+    }
+    e->live_snapshots.fetch_sub(1);
+    delete s;
+    return LH_OK;
+}
+
+int lh_compress_device(lh_engine *e, const double *d_v, int16_t *d_keys, size_t n, void *stream)
+{
+    if (!e || ((!d_v || !d_keys) && n)) return LH_EINVAL;
+    int rc = use_device(e);
+    if (rc) return rc;
+    HIPCHK(lh::launch_compress(d_v, d_keys, n, e->d_Tx, false, stream ? (hipStream_t)stream : e->main_stream));
+    return LH_OK;
+}
+
+int lh_compress_device_golog(lh_engine *e, const double *d_v, int16_t *d_keys, size_t n, void *stream)
+{
+    if (!e || ((!d_v || !d_keys) && n)) return LH_EINVAL;
+    int rc = use_device(e);
+    if (rc) return rc;
+    HIPCHK(lh::launch_compress(d_v, d_keys, n, e->d_Tx, true, stream ? (hipStream_t)stream : e->main_stream));
+    return LH_OK;
+}
+
+int lh_codec_tables(lh_engine *e, double *Tx, double *D)
+{
+    if (!e) return LH_EINVAL;
+    int rc = use_device(e);
+    if (rc) return rc;
+    if (Tx) HIPCHK(hipMemcpy(Tx, e->d_Tx, sizeof(double) * LH_NTHRESH, hipMemcpyDeviceToHost));
+    if (D) HIPCHK(hipMemcpy(D, e->d_D, sizeof(double) * LH_NKEYS, hipMemcpyDeviceToHost));
+    return LH_OK;
+}
+
+int lh_selftest_vlog(lh_engine *e, double *max_abs_err)
+{
+    if (!e || !max_abs_err) return LH_EINVAL;
+    int rc = use_device(e);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(e->xmu);
+    rc = ensure_xbuf(e, 64);
+    if (rc) return rc;
+    HIPCHK(lh::launch_vlog_selftest(reinterpret_cast<double *>(e->d_xbuf), e->xstream));
+    HIPCHK(hipMemcpyAsync(e->h_xbuf, e->d_xbuf, sizeof(double), hipMemcpyDeviceToHost, e->xstream));
+    HIPCHK(hipStreamSynchronize(e->xstream));
+    std::memcpy(max_abs_err, e->h_xbuf, sizeof(double));
+    return LH_OK;
+}
+
+} // extern "C"

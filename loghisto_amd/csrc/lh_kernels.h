@@ -1,0 +1,45 @@
+// lh_kernels.h -- launch interface between the host runtime (lh_engine.cc) and
+// the gfx950 kernels (lh_kernels.hip).  Internal; the public ABI is
+// include/loghisto_gpu.h.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace lh {
+
+struct ExtractOut {          // device mirror of lh_stats, one per metric
+    uint64_t count;
+    double   sum;
+    double   avg;
+    uint64_t agg_sum_add;
+    uint32_t nbuckets;
+    uint32_t present;
+};
+
+// Table generation (once per engine).
+hipError_t launch_gen_tables(double *d_Tx, double *d_D, hipStream_t s);
+
+// K1: ingest.  counts: [nmetrics][65536] u64; ranges: [nmetrics][2] u32 (lo,hi bin).
+hipError_t launch_ingest_single(const double *d_v, size_t n, uint64_t *row, uint32_t *range,
+                                const double *d_Tx, int num_cus, hipStream_t s);
+hipError_t launch_ingest_pairs(const uint32_t *d_ids, const double *d_v, size_t n, uint64_t *counts,
+                               uint32_t *ranges, uint32_t nmetrics, const double *d_Tx, uint32_t *d_err,
+                               int num_cus, hipStream_t s);
+
+// K2: extract.  One workgroup per metric.
+hipError_t launch_extract(const uint64_t *counts, const uint32_t *ranges, uint32_t nmetrics,
+                          const double *d_p, uint32_t np, const double *d_D, ExtractOut *out,
+                          double *pvals, int16_t *pkeys, uint8_t *pvalid, hipStream_t s);
+
+// K3: clear the dirty span of every row and reset the ranges.
+hipError_t launch_clear(uint64_t *counts, uint32_t *ranges, uint32_t nmetrics, hipStream_t s);
+hipError_t launch_init_ranges(uint32_t *ranges, uint32_t nmetrics, hipStream_t s);
+hipError_t launch_mark_dirty(uint32_t *ranges, uint32_t first, uint32_t nrows, uint32_t lo, uint32_t hi, hipStream_t s);
+
+// Codec-only kernels (parity tests).
+hipError_t launch_compress(const double *d_v, int16_t *d_keys, size_t n, const double *d_Tx, bool golog, hipStream_t s);
+hipError_t launch_vlog_selftest(double *d_maxerr, hipStream_t s);
+
+} // namespace lh

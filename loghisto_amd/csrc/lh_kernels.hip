@@ -1,0 +1,522 @@
+// lh_kernels.hip -- gfx950 kernels of the loghisto hot path.
+//
+//   K1 k_ingest_single / k_ingest_pairs : compress + fan-in
+//        reference: compress (metrics.go:316-322) + Histogram (metrics.go:273-295)
+//   K2 k_extract                         : processHistograms + percentile
+//        reference: metrics.go:336-387, 391-418
+//   K3 k_clear_spans / k_init_ranges     : epoch buffer recycle
+//        reference: the `make(map...)` half of the flip, metrics.go:461-462
+//   table generation + codec-only kernels for parity tests.
+//
+// Built with -ffp-contract=off: the Go-math restatements in lh_codec.h must be
+// evaluated operation by operation.  Where an FMA is wanted it is explicit.
+//
+// HBM-bound integer/indexing work: no MFMA anywhere.  The design points are
+// 16-B/lane coalesced streaming loads, LDS-private u32 histograms per workgroup,
+// a wave-uniform shortcut for constant streams, and one u64 global atomic per
+// occupied (workgroup, bin) at flush.
+#include "lh_kernels.h"
+#include "lh_codec.h"
+
+namespace lh {
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u2_t __attribute__((ext_vector_type(2)));
+
+// ---------------------------------------------------------------------------
+// Table generation
+// ---------------------------------------------------------------------------
+__global__ void k_gen_thresholds(double *__restrict__ Tx)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= LH_NTHRESH) return;
+    if (j == 0) { Tx[0] = 1.0; return; }
+    const uint64_t one_bits = 0x3ff0000000000000ull, max_bits = 0x7fefffffffffffffull;
+    if ((int)j > d_kext_golog(__longlong_as_double((long long)max_bits))) {
+        Tx[j] = __longlong_as_double(0x7ff0000000000000ll); // +Inf: unreachable
+        return;
+    }
+    // invariant: kext(lo) < j <= kext(hi); kext(1.0) == 0.
+    uint64_t lo = one_bits, hi = max_bits;
+    while (hi - lo > 1) {
+        const uint64_t mid = lo + (hi - lo) / 2;
+        if (d_kext_golog(__longlong_as_double((long long)mid)) >= (int)j) hi = mid; else lo = mid;
+    }
+    Tx[j] = __longlong_as_double((long long)hi);
+}
+
+__global__ void k_gen_decompress(double *__restrict__ D)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < LH_NKEYS) D[b] = d_decompress_bin(b);
+}
+
+hipError_t launch_gen_tables(double *d_Tx, double *d_D, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_gen_thresholds, dim3((LH_NTHRESH + 255) / 256), dim3(256), 0, s, d_Tx);
+    hipLaunchKernelGGL(k_gen_decompress, dim3(LH_NKEYS / 256), dim3(256), 0, s, d_D);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// K1 single-metric ingest
+// ---------------------------------------------------------------------------
+constexpr int K1_BLOCK = 512;                      // 8 waves; 2 workgroups per CU
+constexpr int K1_UNROLL = 4;                       // 16-B loads in flight per lane
+constexpr uint32_t K1_WIN = 16384;                 // LDS window, u32 bins (64 KiB)
+constexpr uint32_t K1_WIN_LO = 32768 - K1_WIN / 2; // keys [-8192, 8191]
+constexpr size_t K1_LDS_BYTES = K1_WIN * sizeof(uint32_t) + 16;
+
+// Out-of-window cell: straight to the global row.
+__device__ __forceinline__ void global_cell_add(uint64_t *row, uint32_t *range, uint32_t bin, uint64_t c)
+{
+    atomicAdd(reinterpret_cast<unsigned long long *>(&row[bin]), (unsigned long long)c);
+    atomicMin(&range[0], bin);
+    atomicMax(&range[1], bin);
+}
+
+__device__ __forceinline__ void k1_add(uint32_t *h, uint64_t *row, uint32_t *range, uint32_t bin)
+{
+    const uint32_t rel = bin - K1_WIN_LO;
+    if (rel < K1_WIN) atomicAdd(&h[rel], 1u);
+    else global_cell_add(row, range, bin, 1);
+}
+
+// All 64 lanes active.  A wave whose 64 samples share one bucket (constant or
+// tightly clustered streams) would serialise 64 same-address LDS atomics; one
+// lane adds 64 instead.
+__device__ __forceinline__ void k1_add_fullwave(uint32_t *h, uint64_t *row, uint32_t *range, uint32_t bin)
+{
+    const uint32_t first = __builtin_amdgcn_readfirstlane(bin);
+    if (__builtin_amdgcn_ballot_w64(bin != first) == 0ull) {
+        if (__lane_id() == 0) {
+            const uint32_t rel = first - K1_WIN_LO;
+            if (rel < K1_WIN) atomicAdd(&h[rel], 64u);
+            else global_cell_add(row, range, first, 64);
+        }
+    } else {
+        k1_add(h, row, range, bin);
+    }
+}
+
+__global__ __launch_bounds__(K1_BLOCK) void k_ingest_single(const double *__restrict__ v, size_t n,
+                                                            uint64_t *__restrict__ row,
+                                                            uint32_t *__restrict__ range,
+                                                            const double *__restrict__ Tx)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *h = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *s_minmax = h + K1_WIN; // [0]=min rel bin, [1]=max rel bin
+    const uint32_t tid = threadIdx.x;
+
+    for (uint32_t i = tid; i < K1_WIN; i += K1_BLOCK) h[i] = 0;
+    if (tid == 0) { s_minmax[0] = 0xffffffffu; s_minmax[1] = 0; }
+    __syncthreads();
+
+    // 16-B alignment: at most one scalar head sample, then pairs, then an odd tail.
+    const size_t head = (((uintptr_t)v & 8) && n) ? 1 : 0;
+    const d2_t *vp = reinterpret_cast<const d2_t *>(v + head);
+    const size_t npair = (n - head) / 2;
+    const size_t tile = (size_t)K1_BLOCK * K1_UNROLL; // pairs per workgroup iteration
+    const size_t nfull = npair / tile;
+
+    for (size_t t = blockIdx.x; t < nfull; t += gridDim.x) {
+        const d2_t *p = vp + t * tile + tid;
+        d2_t r[K1_UNROLL];
+#pragma unroll
+        for (int u = 0; u < K1_UNROLL; u++) r[u] = __builtin_nontemporal_load(p + u * K1_BLOCK);
+#pragma unroll
+        for (int u = 0; u < K1_UNROLL; u++) {
+            k1_add_fullwave(h, row, range, lh_bin_of(r[u].x, Tx));
+            k1_add_fullwave(h, row, range, lh_bin_of(r[u].y, Tx));
+        }
+    }
+    // remainder pairs (guarded), owned by the workgroup next in the rotation
+    if (blockIdx.x == nfull % gridDim.x) {
+        for (size_t i = nfull * tile + tid; i < npair; i += K1_BLOCK) {
+            const d2_t r = vp[i];
+            k1_add(h, row, range, lh_bin_of(r.x, Tx));
+            k1_add(h, row, range, lh_bin_of(r.y, Tx));
+        }
+        if (tid == 0 && head) k1_add(h, row, range, lh_bin_of(v[0], Tx));
+        if (tid == 1 && ((n - head) & 1)) k1_add(h, row, range, lh_bin_of(v[n - 1], Tx));
+    }
+    __syncthreads();
+
+    // flush: one u64 atomic per occupied LDS bin
+    uint32_t lmin = 0xffffffffu, lmax = 0;
+    for (uint32_t i = tid; i < K1_WIN; i += K1_BLOCK) {
+        const uint32_t c = h[i];
+        if (c) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(&row[K1_WIN_LO + i]), (unsigned long long)c);
+            lmin = min(lmin, i);
+            lmax = max(lmax, i);
+        }
+    }
+    if (lmin != 0xffffffffu) { atomicMin(&s_minmax[0], lmin); atomicMax(&s_minmax[1], lmax); }
+    __syncthreads();
+    if (tid == 0 && s_minmax[0] != 0xffffffffu) {
+        atomicMin(&range[0], K1_WIN_LO + s_minmax[0]);
+        atomicMax(&range[1], K1_WIN_LO + s_minmax[1]);
+    }
+}
+
+hipError_t launch_ingest_single(const double *d_v, size_t n, uint64_t *row, uint32_t *range,
+                                const double *d_Tx, int num_cus, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ingest_single),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)K1_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const size_t tile_samples = (size_t)K1_BLOCK * K1_UNROLL * 2;
+    size_t want = (n + tile_samples - 1) / tile_samples;
+    size_t cap = (size_t)num_cus * 2;
+    unsigned grid = (unsigned)(want < cap ? want : cap);
+    if (grid == 0) grid = 1;
+    hipLaunchKernelGGL(k_ingest_single, dim3(grid), dim3(K1_BLOCK), K1_LDS_BYTES, s, d_v, n, row, range, d_Tx);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// K1 mixed (id, value) ingest -- v1: straight global u64 atomics.
+// ---------------------------------------------------------------------------
+constexpr int KP_BLOCK = 256;
+
+__device__ __forceinline__ void kp_add(uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
+                                       uint32_t nmetrics, uint32_t *__restrict__ err, uint32_t id,
+                                       double v, const double *__restrict__ Tx)
+{
+    if (id >= nmetrics) { atomicOr(err, 1u); return; }
+    const uint32_t bin = lh_bin_of(v, Tx);
+    atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)id * LH_NKEYS + bin]), 1ull);
+    // ranges only widen: a stale read can cost a redundant atomic, never miss one
+    uint32_t *r = ranges + 2 * (size_t)id;
+    if (bin < r[0]) atomicMin(&r[0], bin);
+    if (bin > r[1]) atomicMax(&r[1], bin);
+}
+
+__global__ __launch_bounds__(KP_BLOCK) void k_ingest_pairs(const uint32_t *__restrict__ ids,
+                                                           const double *__restrict__ v, size_t n,
+                                                           uint64_t *__restrict__ counts,
+                                                           uint32_t *__restrict__ ranges, uint32_t nmetrics,
+                                                           const double *__restrict__ Tx,
+                                                           uint32_t *__restrict__ err, int vec)
+{
+    const size_t gtid = (size_t)blockIdx.x * KP_BLOCK + threadIdx.x;
+    const size_t gsz = (size_t)gridDim.x * KP_BLOCK;
+    if (vec) {
+        const size_t npair = n / 2;
+        const d2_t *vp = reinterpret_cast<const d2_t *>(v);
+        const u2_t *ip = reinterpret_cast<const u2_t *>(ids);
+        for (size_t i = gtid; i < npair; i += gsz) {
+            const d2_t r = __builtin_nontemporal_load(vp + i);
+            const u2_t m = __builtin_nontemporal_load(ip + i);
+            kp_add(counts, ranges, nmetrics, err, m.x, r.x, Tx);
+            kp_add(counts, ranges, nmetrics, err, m.y, r.y, Tx);
+        }
+        if (gtid == 0 && (n & 1)) kp_add(counts, ranges, nmetrics, err, ids[n - 1], v[n - 1], Tx);
+    } else {
+        for (size_t i = gtid; i < n; i += gsz) kp_add(counts, ranges, nmetrics, err, ids[i], v[i], Tx);
+    }
+}
+
+hipError_t launch_ingest_pairs(const uint32_t *d_ids, const double *d_v, size_t n, uint64_t *counts,
+                               uint32_t *ranges, uint32_t nmetrics, const double *d_Tx, uint32_t *d_err,
+                               int num_cus, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    const int vec = (((uintptr_t)d_v & 15) == 0 && ((uintptr_t)d_ids & 7) == 0) ? 1 : 0;
+    size_t want = (n / 2 + KP_BLOCK - 1) / KP_BLOCK;
+    size_t cap = (size_t)num_cus * 8;
+    unsigned grid = (unsigned)(want < cap ? want : cap);
+    if (grid == 0) grid = 1;
+    hipLaunchKernelGGL(k_ingest_pairs, dim3(grid), dim3(KP_BLOCK), 0, s, d_ids, d_v, n, counts, ranges,
+                       nmetrics, d_Tx, d_err, vec);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// K2 extract
+// ---------------------------------------------------------------------------
+constexpr int K2_BLOCK = 256;
+constexpr int K2_WAVES = K2_BLOCK / 64;
+constexpr int K2_PER_THREAD = 4;
+constexpr int K2_TILE = K2_BLOCK * K2_PER_THREAD;
+constexpr int K2_MAXP = 32;
+
+// uint64(float64) as Go compiles it for amd64 (metrics.go:374).
+__device__ inline uint64_t d_f64_to_u64_amd64(double f)
+{
+    const double two63 = 9223372036854775808.0;
+    if (f != f) return 0x8000000000000000ull;
+    if (f < two63) {
+        if (f <= -two63) return 0x8000000000000000ull;
+        return (uint64_t)(long long)f;
+    }
+    const double g = f - two63;
+    if (g >= two63) return 0;
+    return (uint64_t)(long long)g ^ 0x8000000000000000ull;
+}
+
+__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t x, int d)
+{
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    lo = __shfl_up(lo, d, 64);
+    hi = __shfl_up(hi, d, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_down_u64(uint64_t x, int d)
+{
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    lo = __shfl_down(lo, d, 64);
+    hi = __shfl_down(hi, d, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ double shfl_down_f64(double x, int d)
+{
+    return __longlong_as_double((long long)shfl_down_u64((uint64_t)__double_as_longlong(x), d));
+}
+
+__global__ __launch_bounds__(K2_BLOCK) void k_extract(const uint64_t *__restrict__ counts,
+                                                      const uint32_t *__restrict__ ranges,
+                                                      const double *__restrict__ p, uint32_t np,
+                                                      const double *__restrict__ D,
+                                                      ExtractOut *__restrict__ out,
+                                                      double *__restrict__ pvals, int16_t *__restrict__ pkeys,
+                                                      uint8_t *__restrict__ pvalid)
+{
+    __shared__ uint64_t s_cnt[K2_WAVES];
+    __shared__ double s_sum[K2_WAVES];
+    __shared__ uint32_t s_nb[K2_WAVES];
+    __shared__ uint64_t s_wtot[K2_WAVES];
+    __shared__ uint32_t s_found[K2_MAXP];
+    __shared__ double s_p[K2_MAXP];
+
+    const uint32_t m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t *row = counts + (size_t)m * LH_NKEYS;
+    const uint32_t lo = ranges[2 * (size_t)m], hi = ranges[2 * (size_t)m + 1];
+
+    if (tid < K2_MAXP) {
+        s_found[tid] = 0xffffffffu;
+        s_p[tid] = tid < np ? p[tid] : 2.0;
+    }
+
+    // ---- pass 1: totalCount, totalSum, occupied buckets (metrics.go:342-347)
+    uint64_t cnt = 0;
+    double sum = 0;
+    uint32_t nb = 0;
+    if (lo <= hi) {
+        for (uint32_t b = lo + tid; b <= hi; b += K2_BLOCK) {
+            const uint64_t c = row[b];
+            if (c) {
+                cnt += c;
+                sum += D[b] * (double)c; // value * float64(*count), metrics.go:344
+                nb++;
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        cnt += shfl_down_u64(cnt, d);
+        sum += shfl_down_f64(sum, d);
+        nb += __shfl_down(nb, d, 64);
+    }
+    if (lane == 0) { s_cnt[wave] = cnt; s_sum[wave] = sum; s_nb[wave] = nb; }
+    __syncthreads();
+    uint64_t total = 0;
+    double tsum = 0;
+    uint32_t tnb = 0;
+#pragma unroll
+    for (int w = 0; w < K2_WAVES; w++) { total += s_cnt[w]; tsum += s_sum[w]; tnb += s_nb[w]; }
+
+    if (tid == 0) {
+        ExtractOut o;
+        o.count = total;
+        o.sum = tsum;
+        o.avg = tsum / (double)total; // metrics.go:356 (0/0 = NaN when empty)
+        o.agg_sum_add = d_f64_to_u64_amd64(tsum);
+        o.nbuckets = tnb;
+        o.present = total ? 1u : 0u;
+        out[m] = o;
+    }
+
+    // ---- pass 2: percentile (metrics.go:406-418) as a prefix scan in bin order
+    if (total && np) {
+        const double ftotal = (double)total;
+        uint64_t carry = 0;
+        for (uint32_t base = lo; base <= hi; base += K2_TILE) {
+            const uint32_t b0 = base + tid * K2_PER_THREAD;
+            uint64_t c[K2_PER_THREAD];
+#pragma unroll
+            for (int k = 0; k < K2_PER_THREAD; k++) c[k] = (b0 + k <= hi) ? row[b0 + k] : 0;
+            uint64_t tsumc = 0;
+#pragma unroll
+            for (int k = 0; k < K2_PER_THREAD; k++) tsumc += c[k];
+            // inclusive wave scan of thread totals
+            uint64_t inc = tsumc;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint64_t y = shfl_up_u64(inc, d);
+                if ((int)lane >= d) inc += y;
+            }
+            __syncthreads(); // s_wtot reuse across tiles
+            if (lane == 63) s_wtot[wave] = inc;
+            __syncthreads();
+            uint64_t wbase = 0, tile_total = 0;
+#pragma unroll
+            for (int w = 0; w < K2_WAVES; w++) {
+                if (w < (int)wave) wbase += s_wtot[w];
+                tile_total += s_wtot[w];
+            }
+            uint64_t sofar = carry + wbase + (inc - tsumc);
+#pragma unroll
+            for (int k = 0; k < K2_PER_THREAD; k++) {
+                if (c[k]) {
+                    sofar += c[k];
+                    const double q = (double)sofar / ftotal; // metrics.go:413
+                    for (uint32_t i = 0; i < np; i++)
+                        if (q >= s_p[i]) atomicMin(&s_found[i], b0 + k);
+                }
+            }
+            carry += tile_total;
+        }
+    }
+    __syncthreads();
+    if (tid < np) {
+        const uint32_t fb = s_found[tid];
+        const size_t o = (size_t)m * np + tid;
+        if (fb != 0xffffffffu) {
+            pvals[o] = D[fb];
+            pkeys[o] = (int16_t)bin_to_key(fb);
+            pvalid[o] = 1;
+        } else {
+            pvals[o] = 0;
+            pkeys[o] = 0;
+            pvalid[o] = 0;
+        }
+    }
+}
+
+hipError_t launch_extract(const uint64_t *counts, const uint32_t *ranges, uint32_t nmetrics,
+                          const double *d_p, uint32_t np, const double *d_D, ExtractOut *out,
+                          double *pvals, int16_t *pkeys, uint8_t *pvalid, hipStream_t s)
+{
+    if (nmetrics == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_extract, dim3(nmetrics), dim3(K2_BLOCK), 0, s, counts, ranges, d_p, np, d_D, out,
+                       pvals, pkeys, pvalid);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// K3 clear / ranges
+// ---------------------------------------------------------------------------
+constexpr int K3_SPLIT = 8; // blocks per row; each owns 8192 bins
+
+__global__ __launch_bounds__(256) void k_clear_spans(uint64_t *__restrict__ counts,
+                                                     const uint32_t *__restrict__ ranges)
+{
+    const uint32_t m = blockIdx.x;
+    const uint32_t lo = ranges[2 * (size_t)m], hi = ranges[2 * (size_t)m + 1];
+    if (lo > hi) return;
+    const uint32_t seg = LH_NKEYS / K3_SPLIT;
+    const uint32_t a = max(lo, blockIdx.y * seg), b = min(hi, (blockIdx.y + 1) * seg - 1);
+    uint64_t *row = counts + (size_t)m * LH_NKEYS;
+    for (uint32_t i = a + threadIdx.x; i <= b && i >= a; i += 256) row[i] = 0;
+}
+
+__global__ void k_init_ranges(uint32_t *__restrict__ ranges, uint32_t nmetrics)
+{
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < nmetrics) { ranges[2 * (size_t)m] = LH_NKEYS; ranges[2 * (size_t)m + 1] = 0; }
+}
+
+__global__ void k_mark_dirty(uint32_t *__restrict__ ranges, uint32_t first, uint32_t nrows, uint32_t lo, uint32_t hi)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nrows) {
+        uint32_t *r = ranges + 2 * (size_t)(first + i);
+        r[0] = min(r[0], lo);
+        r[1] = max(r[1], hi);
+    }
+}
+
+hipError_t launch_clear(uint64_t *counts, uint32_t *ranges, uint32_t nmetrics, hipStream_t s)
+{
+    if (nmetrics == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_clear_spans, dim3(nmetrics, K3_SPLIT), dim3(256), 0, s, counts, ranges);
+    hipLaunchKernelGGL(k_init_ranges, dim3((nmetrics + 255) / 256), dim3(256), 0, s, ranges, nmetrics);
+    return hipGetLastError();
+}
+
+hipError_t launch_init_ranges(uint32_t *ranges, uint32_t nmetrics, hipStream_t s)
+{
+    if (nmetrics == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_init_ranges, dim3((nmetrics + 255) / 256), dim3(256), 0, s, ranges, nmetrics);
+    return hipGetLastError();
+}
+
+hipError_t launch_mark_dirty(uint32_t *ranges, uint32_t first, uint32_t nrows, uint32_t lo, uint32_t hi, hipStream_t s)
+{
+    if (nrows == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_mark_dirty, dim3((nrows + 255) / 256), dim3(256), 0, s, ranges, first, nrows, lo, hi);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Codec-only kernels (parity tests)
+// ---------------------------------------------------------------------------
+__global__ void k_compress(const double *__restrict__ v, int16_t *__restrict__ keys, size_t n,
+                           const double *__restrict__ Tx, int golog)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double val = v[i];
+        uint32_t bin;
+        if (golog) {
+            const double x = 1.0 + fabs(val);
+            const uint32_t eb = ((uint32_t)__double2hiint(x)) >> 20;
+            const int kext = (eb < 0x7ffu) ? d_kext_golog(x) : 0;
+            bin = bin_from_kext(kext, val);
+        } else {
+            bin = lh_bin_of(val, Tx);
+        }
+        keys[i] = (int16_t)bin_to_key(bin);
+    }
+}
+
+hipError_t launch_compress(const double *d_v, int16_t *d_keys, size_t n, const double *d_Tx, bool golog, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    size_t want = (n + 255) / 256;
+    unsigned grid = (unsigned)(want < 4096 ? want : 4096);
+    hipLaunchKernelGGL(k_compress, dim3(grid), dim3(256), 0, s, d_v, d_keys, n, d_Tx, golog ? 1 : 0);
+    return hipGetLastError();
+}
+
+__global__ void k_vlog_selftest(unsigned long long *__restrict__ maxerr_bits)
+{
+    const double inv_ln2 = 1.44269504088896338700e+00;
+    double worst = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (1u << 23); i += gridDim.x * blockDim.x) {
+        const float m = __uint_as_float(0x3f800000u | i);
+        const double hw = (double)__builtin_amdgcn_logf(m);
+        const double ref = d_go_log((double)m) * inv_ln2;
+        const double err = fabs(hw - ref);
+        worst = err > worst ? err : worst;
+    }
+    // non-negative doubles order like their bit patterns
+    atomicMax(maxerr_bits, (unsigned long long)__double_as_longlong(worst));
+}
+
+hipError_t launch_vlog_selftest(double *d_maxerr, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(d_maxerr, 0, sizeof(double), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_vlog_selftest, dim3(1024), dim3(256), 0, s, reinterpret_cast<unsigned long long *>(d_maxerr));
+    return hipGetLastError();
+}
+
+} // namespace lh

@@ -1,0 +1,217 @@
+"""Thin object wrapper over the C ABI: Engine (lh_engine) and Snapshot (lh_snapshot).
+
+Nothing is computed here; every method is one or two calls into liblhgpu.so.
+Reference counterparts are cited on the C declarations in include/loghisto_gpu.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _native as N
+
+
+def _ptr(x) -> int:
+    """Raw address of a torch tensor / numpy array / int."""
+    if x is None:
+        return 0
+    if isinstance(x, int):
+        return x
+    if hasattr(x, "data_ptr"):
+        return int(x.data_ptr())
+    if isinstance(x, np.ndarray):
+        return int(x.ctypes.data)
+    raise TypeError(f"cannot take the address of {type(x)!r}")
+
+
+def _stream_handle(stream) -> int:
+    if stream is None:
+        return 0
+    if isinstance(stream, int):
+        return stream
+    if hasattr(stream, "cuda_stream"):  # torch.cuda.Stream
+        return int(stream.cuda_stream)
+    raise TypeError(f"not a stream: {type(stream)!r}")
+
+
+class Snapshot:
+    """One interval's cells, stolen at the epoch flip (metrics.go:460-463)."""
+
+    def __init__(self, engine: "Engine", handle: int):
+        self.engine = engine
+        self._h = C.c_void_p(handle)
+
+    def extract(self, percentiles: Sequence[float], nmetrics: Optional[int] = None, first: int = 0):
+        """processHistograms for metrics [first, first+nmetrics) -> dict of numpy arrays."""
+        L = N.lib()
+        if nmetrics is None:
+            nmetrics = self.engine.num_metrics() - first
+        p = np.ascontiguousarray(percentiles, dtype=np.float64)
+        np_ = int(p.size)
+        stats = (N.LhStats * max(nmetrics, 1))()
+        pvals = np.zeros((nmetrics, np_), dtype=np.float64)
+        pkeys = np.zeros((nmetrics, np_), dtype=np.int16)
+        pvalid = np.zeros((nmetrics, np_), dtype=np.uint8)
+        N.check(L.lh_extract_rows(self._h, first, nmetrics, p.ctypes.data_as(C.POINTER(C.c_double)), np_, stats,
+                                  pvals.ctypes.data_as(C.POINTER(C.c_double)),
+                                  pkeys.ctypes.data_as(C.POINTER(C.c_int16)),
+                                  pvalid.ctypes.data_as(C.POINTER(C.c_uint8))), "lh_extract_rows")
+        raw = np.frombuffer(stats, dtype=np.dtype([("count", "<u8"), ("sum", "<f8"), ("avg", "<f8"),
+                                                   ("agg_sum_add", "<u8"), ("nbuckets", "<u4"),
+                                                   ("present", "<u4")]), count=nmetrics).copy()
+        return dict(count=raw["count"], sum=raw["sum"], avg=raw["avg"], agg_sum_add=raw["agg_sum_add"],
+                    nbuckets=raw["nbuckets"], present=raw["present"], pvals=pvals, pkeys=pkeys, pvalid=pvalid)
+
+    def buckets(self, metric_id: int):
+        """Occupied (key, count) cells of one metric, ascending key."""
+        L = N.lib()
+        n = C.c_size_t(0)
+        N.check(L.lh_buckets(self._h, metric_id, None, None, 0, C.byref(n)), "lh_buckets")
+        keys = np.zeros(n.value, dtype=np.int16)
+        counts = np.zeros(n.value, dtype=np.uint64)
+        if n.value:
+            N.check(L.lh_buckets(self._h, metric_id, keys.ctypes.data_as(C.POINTER(C.c_int16)),
+                                 counts.ctypes.data_as(C.POINTER(C.c_uint64)), n.value, C.byref(n)), "lh_buckets")
+        return keys, counts
+
+    def dense_row(self, metric_id: int) -> np.ndarray:
+        """Dense uint64[65536] row (bin = key ^ 0x8000) rebuilt from lh_buckets."""
+        keys, counts = self.buckets(metric_id)
+        row = np.zeros(N.NKEYS, dtype=np.uint64)
+        row[(keys.astype(np.int64) & 0xFFFF) ^ 0x8000] = counts
+        return row
+
+    def device_rows(self):
+        """(device pointer of uint64[nrows][65536], nrows)."""
+        p, n = C.c_void_p(0), C.c_uint32(0)
+        N.check(N.lib().lh_snapshot_rows(self._h, C.byref(p), C.byref(n)), "lh_snapshot_rows")
+        return int(p.value), int(n.value)
+
+    def device_ranges(self) -> int:
+        p = C.c_void_p(0)
+        N.check(N.lib().lh_snapshot_ranges(self._h, C.byref(p)), "lh_snapshot_ranges")
+        return int(p.value)
+
+    def mark_dirty(self, first_row: int, nrows: int, lo_bin: int = 0, hi_bin: int = N.NKEYS - 1):
+        N.check(N.lib().lh_snapshot_mark_dirty(self._h, first_row, nrows, lo_bin, hi_bin), "lh_snapshot_mark_dirty")
+
+    def stream(self) -> int:
+        p = C.c_void_p(0)
+        N.check(N.lib().lh_snapshot_stream(self._h, C.byref(p)), "lh_snapshot_stream")
+        return int(p.value or 0)
+
+    def release(self):
+        if self._h is not None and self._h.value:
+            N.check(N.lib().lh_release(self._h), "lh_release")
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.release()
+
+
+class Engine:
+    def __init__(self, device: int = 0, max_metrics: int = 1024, num_buffers: int = 2, num_lanes: int = 4,
+                 lane_samples: int = 1 << 20):
+        L = N.lib()
+        cfg = N.LhConfig()
+        N.check(L.lh_default_config(C.byref(cfg)), "lh_default_config")
+        cfg.device, cfg.max_metrics, cfg.num_buffers = device, max_metrics, num_buffers
+        cfg.num_lanes, cfg.lane_samples = num_lanes, lane_samples
+        h = C.c_void_p(0)
+        N.check(L.lh_create(C.byref(cfg), C.byref(h)), "lh_create")
+        self._h = h
+        self.max_metrics = max_metrics
+
+    # -- names -------------------------------------------------------------
+    def intern(self, name: str) -> int:
+        b = name.encode()
+        out = C.c_uint32(0)
+        N.check(N.lib().lh_intern(self._h, b, len(b), C.byref(out)), "lh_intern")
+        return int(out.value)
+
+    def lookup(self, name: str) -> Optional[int]:
+        b = name.encode()
+        out = C.c_uint32(0)
+        rc = N.lib().lh_lookup(self._h, b, len(b), C.byref(out))
+        if rc == N.ERANGE:
+            return None
+        N.check(rc, "lh_lookup")
+        return int(out.value)
+
+    def num_metrics(self) -> int:
+        out = C.c_uint32(0)
+        N.check(N.lib().lh_num_metrics(self._h, C.byref(out)), "lh_num_metrics")
+        return int(out.value)
+
+    def metric_name(self, metric_id: int) -> str:
+        ln = C.c_size_t(0)
+        buf = C.create_string_buffer(4096)
+        N.check(N.lib().lh_metric_name(self._h, metric_id, buf, 4096, C.byref(ln)), "lh_metric_name")
+        return buf.raw[:min(ln.value, 4096)].decode()
+
+    # -- ingest ------------------------------------------------------------
+    def submit(self, metric_id: int, values):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        N.check(N.lib().lh_submit(self._h, metric_id, v.ctypes.data, v.size), "lh_submit")
+
+    def submit_pairs(self, ids, values):
+        i = np.ascontiguousarray(ids, dtype=np.uint32)
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        if i.size != v.size:
+            raise ValueError("ids and values differ in length")
+        N.check(N.lib().lh_submit_pairs(self._h, i.ctypes.data, v.ctypes.data, v.size), "lh_submit_pairs")
+
+    def submit_device(self, metric_id: int, d_values, n: Optional[int] = None, stream=None):
+        n = int(d_values.numel()) if n is None else n
+        N.check(N.lib().lh_submit_device(self._h, metric_id, _ptr(d_values), n, _stream_handle(stream)),
+                "lh_submit_device")
+
+    def submit_pairs_device(self, d_ids, d_values, n: Optional[int] = None, stream=None):
+        n = int(d_values.numel()) if n is None else n
+        N.check(N.lib().lh_submit_pairs_device(self._h, _ptr(d_ids), _ptr(d_values), n, _stream_handle(stream)),
+                "lh_submit_pairs_device")
+
+    def flush(self):
+        N.check(N.lib().lh_flush(self._h), "lh_flush")
+
+    def sync(self):
+        N.check(N.lib().lh_sync(self._h), "lh_sync")
+
+    # -- epoch -------------------------------------------------------------
+    def flip(self) -> Snapshot:
+        h = C.c_void_p(0)
+        N.check(N.lib().lh_flip(self._h, C.byref(h)), "lh_flip")
+        return Snapshot(self, h.value)
+
+    # -- codec (parity tests) -----------------------------------------------
+    def compress_device(self, d_values, d_keys, n: int, golog: bool = False, stream=None):
+        fn = N.lib().lh_compress_device_golog if golog else N.lib().lh_compress_device
+        N.check(fn(self._h, _ptr(d_values), _ptr(d_keys), n, _stream_handle(stream)), "lh_compress_device")
+
+    def codec_tables(self):
+        tx = np.zeros(N.NTHRESH, dtype=np.float64)
+        d = np.zeros(N.NKEYS, dtype=np.float64)
+        N.check(N.lib().lh_codec_tables(self._h, tx.ctypes.data_as(C.POINTER(C.c_double)),
+                                        d.ctypes.data_as(C.POINTER(C.c_double))), "lh_codec_tables")
+        return tx, d
+
+    def selftest_vlog(self) -> float:
+        out = C.c_double(0)
+        N.check(N.lib().lh_selftest_vlog(self._h, C.byref(out)), "lh_selftest_vlog")
+        return float(out.value)
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            N.check(N.lib().lh_destroy(self._h), "lh_destroy")
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -1,0 +1,73 @@
+"""CPU tests of the drop-in boundary: liblhgpu.so builds, loads, exports every
+symbol include/loghisto_gpu.h declares, and refuses to run without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "loghisto_gpu.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(lh_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(native_lib):
+    from loghisto_amd import _native
+    declared = header_symbols()
+    assert len(declared) >= 25
+    raw = C.CDLL(_native.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), f"{name} declared in loghisto_gpu.h but not exported"
+    assert sorted(_native.SIGNATURES) == declared, "ctypes binding and header disagree"
+
+
+def test_abi_version_and_strerror(native_lib):
+    assert native_lib.lh_abi_version() == 1
+    msgs = {native_lib.lh_strerror(c).decode() for c in range(8)}
+    assert len(msgs) == 8 and "ok" in msgs
+
+
+def test_struct_layouts_match_header(native_lib):
+    from loghisto_amd import _native
+    assert C.sizeof(_native.LhConfig) == 32
+    assert C.sizeof(_native.LhStats) == 40
+    cfg = _native.LhConfig()
+    assert native_lib.lh_default_config(C.byref(cfg)) == 0
+    assert cfg.struct_size == 32 and cfg.max_metrics >= 1 and cfg.num_buffers >= 2
+
+
+def test_argument_validation_needs_no_gpu(native_lib):
+    from loghisto_amd import _native
+    cfg = _native.LhConfig()
+    native_lib.lh_default_config(C.byref(cfg))
+    h = C.c_void_p(0)
+    assert native_lib.lh_create(None, C.byref(h)) == _native.EINVAL
+    cfg.num_buffers = 1
+    assert native_lib.lh_create(C.byref(cfg), C.byref(h)) == _native.EINVAL
+    assert native_lib.lh_flush(None) == _native.EINVAL
+    assert native_lib.lh_release(None) == _native.EINVAL
+
+
+def test_no_cpu_fallback():
+    """Without a gfx950 device the product path must fail loudly, not compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import loghisto_amd
+    with pytest.raises(loghisto_amd.LhError) as ei:
+        loghisto_amd.Engine()
+    assert ei.value.code == 4  # LH_ENODEVICE
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "loghisto_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cc", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", text, flags=re.M), f
+                assert "lh_oracle" not in text and "lho_" not in text, f
