@@ -115,8 +115,11 @@ def main():
     n = int(args.samples)
     eng = loghisto_amd.Engine(device=local_rank, max_metrics=1, num_buffers=2, num_lanes=1, lane_samples=1 << 16)
     data = make_samples(n, args.dist, seed=2 + rank)
-    stream = torch.cuda.current_stream()
     torch.cuda.synchronize()
+    # a non-default stream: the default stream's handle is 0, which the C ABI reads as
+    # "use the engine's own stream" and torch events would then not bracket the kernel
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
 
     k1_events = []
 
@@ -178,7 +181,13 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r01_k1_pmc.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_read_bytes_per_launch")
+                # PMC passes cannot run inside this process: the committed rocprofv3 --pmc summary
+                # of this same command supplies HBM bytes per K1 launch (read + write, corrected
+                # as the microarch guide prescribes; see the JSON's "corrections").  It only
+                # applies to the workload it was measured on.
+                j = json.load(open(pmc))
+                if n * BYTES_PER_SAMPLE == int(j["algorithmic_bytes_per_launch"]) and args.dist == "lognormal":
+                    traffic = j["hbm_read_bytes_per_launch"] + j["hbm_write_bytes_per_launch"]
             except Exception:
                 traffic = None
         result = {

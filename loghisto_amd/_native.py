@@ -92,6 +92,10 @@ def lib():
         raise NativeLibraryError(
             f"{LIB_PATH} is missing: build it with `python -m loghisto_amd.build` "
             "(hipcc, gfx950). loghisto_amd has no CPU path.")
+    # One HIP runtime per process: torch bundles its own libamdhip64, and streams /
+    # device pointers are shared between torch (plumbing) and this library, so
+    # torch's copy must be the one liblhgpu.so binds to.  Import torch first.
+    import torch  # noqa: F401
     try:
         L = C.CDLL(LIB_PATH)
     except OSError as exc:  # e.g. libamdhip64 not found

@@ -266,8 +266,10 @@ int ensure_xbuf(lh_engine *e, size_t bytes)
 int create_impl(const lh_config *cfg_in, lh_engine *e)
 {
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
-        std::snprintf(g_last_error, sizeof(g_last_error), "no HIP device visible");
+    hipError_t dc = hipGetDeviceCount(&ndev);
+    if (dc != hipSuccess || ndev <= 0) {
+        std::snprintf(g_last_error, sizeof(g_last_error), "no HIP device visible (hipGetDeviceCount: %s, count %d)",
+                      hipGetErrorString(dc), ndev);
         return LH_ENODEVICE;
     }
     if (cfg_in->device < 0 || cfg_in->device >= ndev) return LH_EINVAL;

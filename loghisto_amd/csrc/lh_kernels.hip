@@ -373,14 +373,24 @@ __global__ __launch_bounds__(K2_BLOCK) void k_extract(const uint64_t *__restrict
                 tile_total += s_wtot[w];
             }
             uint64_t sofar = carry + wbase + (inc - tsumc);
+            double q[K2_PER_THREAD]; // float64(sofar)/float64(totalCount), metrics.go:413; -1 for empty buckets
 #pragma unroll
             for (int k = 0; k < K2_PER_THREAD; k++) {
-                if (c[k]) {
-                    sofar += c[k];
-                    const double q = (double)sofar / ftotal; // metrics.go:413
-                    for (uint32_t i = 0; i < np; i++)
-                        if (q >= s_p[i]) atomicMin(&s_found[i], b0 + k);
-                }
+                sofar += c[k];
+                q[k] = c[k] ? (double)sofar / ftotal : -1.0;
+            }
+            // q is non-decreasing in bin order and bins ascend with the lane id, so the
+            // answer for percentile i inside this wave is the first lane that has a hit:
+            // at most one LDS atomic per (wave, percentile).
+            for (uint32_t i = 0; i < np; i++) {
+                if (s_found[i] < base) continue; // settled by an earlier tile (uniform branch)
+                const double pi = s_p[i];
+                uint32_t hit = 0xffffffffu;
+#pragma unroll
+                for (int k = K2_PER_THREAD - 1; k >= 0; k--)
+                    if (q[k] >= pi && q[k] >= 0.0) hit = b0 + k;
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit != 0xffffffffu);
+                if (mask && lane == (uint32_t)__builtin_ctzll(mask)) atomicMin(&s_found[i], hit);
             }
             carry += tile_total;
         }

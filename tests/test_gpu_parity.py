@@ -63,8 +63,13 @@ def check_stats(row, got, m=0, pcts=PCTS):
     assert int(got["nbuckets"][m]) == want["nbuckets"]
     assert bool(got["present"][m]) == (want["count"] > 0)
     if want["count"]:
-        assert got["sum"][m] == pytest.approx(want["sum"], rel=SUM_RTOL)
-        assert got["avg"][m] == pytest.approx(want["avg"], rel=SUM_RTOL)
+        # _sum is a float64 accumulation whose order the reference itself does not fix (Go map
+        # order, metrics.go:342); the bound is the usual one for reordered sums: relative to the
+        # sum of |terms| (== relative to the sum for the non-negative streams of BASELINE.json;
+        # for signed streams the terms cancel and only this form is meaningful).
+        mag = float(np.sum(np.abs(oracle.decompress_table()) * np.asarray(row, dtype=np.float64)))
+        assert abs(got["sum"][m] - want["sum"]) <= SUM_RTOL * mag
+        assert abs(got["avg"][m] - want["avg"]) <= SUM_RTOL * mag / want["count"]
         # bit-identical percentile values and keys
         assert np.array_equal(got["pvalid"][m], want["pvalid"])
         assert np.array_equal(got["pkeys"][m], want["pkeys"])

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Contention sweep of the ingest kernel: kernel-only time per
+distribution at n samples, HIP events on the launch stream.  Prints one JSON line
+per distribution.  GPU only."""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+import loghisto_amd  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--samples", type=float, default=1e8)
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--pairs", type=int, default=0, help="if >0: mixed stream over this many names, Zipf(1.0) ids")
+    a = ap.parse_args()
+    n = int(a.samples)
+    torch.cuda.set_device(0)
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    eng = loghisto_amd.Engine(max_metrics=max(1, a.pairs), num_buffers=2, num_lanes=1, lane_samples=1 << 16)
+    for kind in ["lognormal", "constant", "uniform", "exponential", "normal", "loguniform", "lognormal25"]:
+        data = bench.make_samples(n, kind, 7)
+        ids = None
+        if a.pairs:
+            w = 1.0 / torch.arange(1, a.pairs + 1, dtype=torch.float64, device="cuda")
+            ids = torch.multinomial(w / w.sum(), n, replacement=True).to(torch.int32)
+        ms = []
+        for r in range(a.reps + 2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            if ids is None:
+                eng.submit_device(0, data, n, stream=stream)
+            else:
+                eng.submit_pairs_device(ids, data, n, stream=stream)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            if r >= 2:
+                ms.append(e0.elapsed_time(e1))
+            snap = eng.flip()
+            st = snap.extract([0.5], max(1, a.pairs))
+            snap.release()
+            assert int(st["count"].sum()) == n
+        avg = sum(ms) / len(ms)
+        bps = 12 if a.pairs else 8
+        print(json.dumps({"dist": kind, "names": a.pairs or 1, "n": n, "avg_ms": avg, "min_ms": min(ms),
+                          "Gsamples_per_s": n / avg / 1e6, "GBps": n * bps / avg / 1e6,
+                          "frac_hbm_peak": n * bps / avg / 1e6 / 8000.0,
+                          "occupied_buckets": int(st["nbuckets"].sum())}), flush=True)
+        del data
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
