@@ -1,0 +1,68 @@
+"""Worker for tests/test_merge_gloo.py: one process per rank, gloo backend, CPU tensors.
+
+Each rank buckets ITS slice of a seeded mixed stream for ALL names with the oracle
+(standing in for the device rows, which need a GPU), merges with
+loghisto_amd.merge.merge_rows, and checks the merged rows against the oracle run on
+the whole stream."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+NKEYS = 65536
+
+
+def make_stream(n, nmetrics, seed=11):
+    rng = np.random.default_rng(seed)
+    w = 1.0 / np.arange(1, nmetrics + 1)
+    ids = rng.choice(nmetrics, size=n, p=w / w.sum()).astype(np.uint32)
+    v = rng.lognormal(np.log(1e5) + 0.002 * ids, 1.0)
+    v[::97] *= -1.0   # signed keys too
+    return ids, v
+
+
+def rows_and_ranges(ids, v, nmetrics):
+    import oracle
+    rows = oracle.histogram_pairs(ids, v, nmetrics)
+    ranges = np.zeros((nmetrics, 2), dtype=np.int32)
+    for m in range(nmetrics):
+        nz = np.nonzero(rows[m])[0]
+        ranges[m] = (nz[0], nz[-1]) if nz.size else (NKEYS, 0)
+    return rows, ranges
+
+
+def run(rank, world, port, plan, nmetrics, n, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from loghisto_amd import merge
+        ids, v = make_stream(n, nmetrics)
+        lo, hi = n * rank // world, n * (rank + 1) // world     # data-parallel slice of the stream
+        rows, ranges = rows_and_ranges(ids[lo:hi], v[lo:hi], nmetrics)
+        t_rows = torch.from_numpy(rows.view(np.int64))
+        t_ranges = torch.from_numpy(ranges)
+        first, last = merge.merge_rows(t_rows, t_ranges, plan=plan)
+        want_rows, want_ranges = rows_and_ranges(ids, v, nmetrics)
+        assert np.array_equal(t_ranges.numpy(), want_ranges), "merged ranges"
+        got = t_rows.numpy().view(np.uint64)
+        if plan == "allreduce":
+            assert (first, last) == (0, nmetrics)
+        else:
+            assert (first, last) == merge.owned_rows(nmetrics, rank, world)
+        assert np.array_equal(got[first:last], want_rows[first:last]), "merged rows"
+        # every rank's owned block together covers all names exactly once
+        cover = torch.zeros(nmetrics, dtype=torch.int64)
+        cover[first:last] = 1
+        dist.all_reduce(cover)
+        expect = world if plan == "allreduce" else 1
+        assert bool((cover == expect).all())
+        open(os.path.join(out_dir, f"ok_{plan}_{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
