@@ -21,6 +21,7 @@ _COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", 
            "-Wno-unused-parameter"]
 _UNITS = [
     ("lh_kernels.hip", ["--offload-arch=gfx950"]),
+    ("lh_kernels_part.hip", ["--offload-arch=gfx950"]),
     ("lh_engine.cc", []),
 ]
 

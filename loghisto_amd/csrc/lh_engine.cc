@@ -127,6 +127,11 @@ struct lh_engine {
     double *h_p = nullptr;
 
     std::atomic<int> live_snapshots{0};
+
+    // scratch of the partitioned mixed-ingest kernels, one per launching stream
+    struct Scratch { void *p = nullptr; size_t bytes = 0; };
+    std::mutex scratch_mu;
+    std::unordered_map<hipStream_t, Scratch> scratch;
 };
 
 struct lh_snapshot {
@@ -165,8 +170,34 @@ int launch_single(lh_engine *e, uint32_t id, const double *d_v, size_t n, hipStr
 int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t n, hipStream_t s)
 {
     EpochBuffer &b = e->bufs[(size_t)e->cur];
-    HIPCHK(lh::launch_ingest_pairs(d_ids, d_v, n, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx, e->d_err,
-                                   e->num_cus, s));
+    const size_t kMaxLaunch = size_t(1) << 30;
+    while (n) {
+        const size_t take = n < kMaxLaunch ? n : kMaxLaunch;
+        const size_t need = lh::part_scratch_bytes(take, e->cfg.max_metrics, e->num_cus);
+        if (need) {
+            // large launch over many names: partition by name, then reduce in LDS
+            std::lock_guard<std::mutex> g(e->scratch_mu);
+            lh_engine::Scratch &sc = e->scratch[s];
+            if (sc.bytes < need) {
+                if (sc.p) {
+                    HIPCHK(hipStreamSynchronize(s)); // earlier launches on this stream still read it
+                    HIPCHK(hipFree(sc.p));
+                    sc.p = nullptr;
+                    sc.bytes = 0;
+                }
+                HIPCHK(hipMalloc(&sc.p, need));
+                sc.bytes = need;
+            }
+            HIPCHK(lh::launch_ingest_pairs_part(d_ids, d_v, take, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx,
+                                                e->d_err, sc.p, sc.bytes, e->num_cus, s));
+        } else {
+            HIPCHK(lh::launch_ingest_pairs(d_ids, d_v, take, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx,
+                                           e->d_err, e->num_cus, s));
+        }
+        d_ids += take;
+        d_v += take;
+        n -= take;
+    }
     return LH_OK;
 }
 
@@ -236,6 +267,8 @@ void free_engine(lh_engine *e)
         if (b.cleared) (void)hipEventDestroy(b.cleared);
     }
     for (hipEvent_t ev : e->flip_events) (void)hipEventDestroy(ev);
+    for (auto &kv : e->scratch)
+        if (kv.second.p) (void)hipFree(kv.second.p);
     if (e->d_Tx) (void)hipFree(e->d_Tx);
     if (e->d_D) (void)hipFree(e->d_D);
     if (e->d_err) (void)hipFree(e->d_err);

@@ -28,6 +28,13 @@ hipError_t launch_ingest_pairs(const uint32_t *d_ids, const double *d_v, size_t 
                                uint32_t *ranges, uint32_t nmetrics, const double *d_Tx, uint32_t *d_err,
                                int num_cus, hipStream_t s);
 
+// Partitioned mixed ingest (lh_kernels_part.hip).  part_scratch_bytes returns 0 when the launch
+// should use the direct kernel instead (small n, one name, or too many names per partition).
+size_t part_scratch_bytes(size_t n, uint32_t nmetrics, int num_cus);
+hipError_t launch_ingest_pairs_part(const uint32_t *d_ids, const double *d_v, size_t n, uint64_t *counts,
+                                    uint32_t *ranges, uint32_t nmetrics, const double *d_Tx, uint32_t *d_err,
+                                    void *scratch, size_t scratch_bytes, int num_cus, hipStream_t s);
+
 // K2: extract.  One workgroup per metric.
 hipError_t launch_extract(const uint64_t *counts, const uint32_t *ranges, uint32_t nmetrics,
                           const double *d_p, uint32_t np, const double *d_D, ExtractOut *out,

@@ -348,3 +348,83 @@ def test_names_intern(engine, la):
     with pytest.raises(la.LhError) as ei:
         engine.intern("one too many")
     assert ei.value.code == 6
+
+
+# ---- partitioned mixed ingest (lh_kernels_part.hip) -----------------------------------
+
+def _zipf_ids(rng, n, M):
+    w = 1.0 / np.arange(1, M + 1)
+    return rng.choice(M, size=n, p=w / w.sum()).astype(np.uint32)
+
+
+@pytest.mark.parametrize("M,n,kind", [
+    (1024, 3_000_001, "lognormal"),      # BASELINE config 3 shape: 256 partitions x 4 names
+    (1024, 1_000_000, "constant"),       # one cell per name: the wave-uniform path
+    (37, 700_001, "signed_wide"),        # odd name count, keys on both sides, out-of-window records
+    (2, 200_000, "lognormal"),           # single partition
+    (300, 131_072, "loguniform"),        # exactly the partitioned-path threshold
+    (300, 131_071, "loguniform"),        # one below: direct-atomic path
+])
+def test_ingest_pairs_partitioned(la, torch_cuda, M, n, kind):
+    rng = np.random.default_rng(M * 7 + n)
+    ids = _zipf_ids(rng, n, M)
+    if kind == "lognormal":
+        v = rng.lognormal(math.log(1e5) + 0.002 * ids, 1.0)
+    elif kind == "constant":
+        v = np.full(n, 123.0)
+    elif kind == "signed_wide":
+        v = rng.normal(0, 1e3, n) * 10.0 ** rng.integers(0, 60, n)
+        v[::1000] = math.inf
+        v[1::1000] = 1e300
+    else:
+        v = 10.0 ** rng.uniform(-3, 18, n)
+    e = la.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16)
+    try:
+        e.submit_pairs_device(dev(torch_cuda, ids), dev(torch_cuda, v))
+        e.sync()
+        with e.flip() as snap:
+            got = snap.extract(PCTS, M)
+            want = oracle.histogram_pairs(ids, v, M)
+            assert int(got["count"].sum()) == n
+            for m in range(M):
+                wc = int(want[m].sum())
+                assert int(got["count"][m]) == wc, m
+                if wc and (m < 8 or m % 61 == 0 or m == M - 1):
+                    assert np.array_equal(snap.dense_row(m), want[m]), m
+                    check_stats(want[m], got, m)
+    finally:
+        e.close()
+
+
+def test_pairs_partitioned_bad_ids_and_reuse(la, torch_cuda):
+    rng = np.random.default_rng(99)
+    M, n = 64, 400_000
+    ids = _zipf_ids(rng, n, M)
+    v = rng.lognormal(10, 1, n)
+    bad = ids.copy()
+    bad[[5, 77777, n - 1]] = [M, 0xFFFFFFFF, 123456]
+    e = la.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16)
+    try:
+        for rep in range(3):     # scratch and chunk pools are reused across launches
+            e.submit_pairs_device(dev(torch_cuda, ids), dev(torch_cuda, v))
+            e.sync()
+            with e.flip() as snap:
+                got = snap.extract([0.5], M)
+                assert int(got["count"].sum()) == n
+                assert np.array_equal(snap.dense_row(0), oracle.histogram_pairs(ids, v, M)[0])
+        e.submit_pairs_device(dev(torch_cuda, bad), dev(torch_cuda, v))
+        with pytest.raises(la.LhError) as ei:
+            e.sync()
+        assert ei.value.code == 6
+        with e.flip() as snap:   # the three bad samples are skipped, the rest land exactly
+            keep = np.ones(n, dtype=bool)
+            keep[[5, 77777, n - 1]] = False
+            want = oracle.histogram_pairs(ids[keep], v[keep], M)
+            try:
+                got = snap.extract([0.5], M)
+            except la.LhError:
+                got = snap.extract([0.5], M)   # the sticky id error is reported once
+            assert int(got["count"].sum()) == n - 3
+            assert np.array_equal(snap.dense_row(1), want[1])
+    finally:
+        e.close()
