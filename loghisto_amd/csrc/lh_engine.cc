@@ -173,7 +173,7 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
     const size_t kMaxLaunch = size_t(1) << 30;
     while (n) {
         const size_t take = n < kMaxLaunch ? n : kMaxLaunch;
-        const size_t need = lh::part_scratch_bytes(take, e->cfg.max_metrics, e->num_cus);
+        const size_t need = lh::part_aligned(d_ids, d_v) ? lh::part_scratch_bytes(take, e->cfg.max_metrics, e->num_cus) : 0;
         if (need) {
             // large launch over many names: partition by name, then reduce in LDS
             std::lock_guard<std::mutex> g(e->scratch_mu);

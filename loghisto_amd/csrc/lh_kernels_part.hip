@@ -27,17 +27,19 @@
 #include "lh_kernels.h"
 #include "lh_codec.h"
 
+#include <cstdlib>
+
 namespace lh {
 
 constexpr int NPMAX = 256;             // partitions (power of two, <= 256)
 constexpr uint32_t CHUNK = 1024;       // records per chunk (4 KiB)
-constexpr int P1_BLOCK = 512;
+constexpr int P1_BLOCK = 512;          // 8 waves; three workgroups per CU (measured: 1024x4 is 10 % slower)
 constexpr int P1_SPT = 8;              // samples per thread per tile
 constexpr int P1_TILE = P1_BLOCK * P1_SPT;
 constexpr uint32_t INVALID = 0xffffffffu;
-constexpr int P2_BLOCK = 512;
+constexpr int P2_BLOCK = 1024;           // 16 waves: two workgroups (64 KiB windows each) fill a CU
 constexpr uint32_t P2_WINWORDS = 16384; // 64 KiB of uint32 windows per workgroup
-constexpr uint32_t P2_SLOTS = 1024;
+constexpr uint32_t P2_SLOTS = 1024;  // work slots of P2 (measured: 768 is 25 % slower, fewer waves in flight)
 constexpr size_t PART_MIN_SAMPLES = 131072;
 constexpr uint32_t PART_MAX_MPP = 256;
 
@@ -67,7 +69,7 @@ static bool make_plan(size_t n, uint32_t nmetrics, int num_cus, PartPlan &P)
     while ((P.mpp << (lw + 1)) <= P2_WINWORDS) lw++;
     P.log_w = lw; // window = 2^log_w bins per name, mpp * window <= 16384
     const size_t ntiles = (n + P1_TILE - 1) / P1_TILE;
-    size_t g1 = (size_t)num_cus * 2;
+    size_t g1 = (size_t)num_cus * 3; // ~44 KiB LDS per workgroup: three 512-thread workgroups per CU
     if (g1 > ntiles) g1 = ntiles;
     P.g1 = (uint32_t)g1;
     const size_t tiles_per_wg = (ntiles + g1 - 1) / g1;
@@ -83,6 +85,11 @@ static bool make_plan(size_t n, uint32_t nmetrics, int num_cus, PartPlan &P)
     return true;
 }
 
+bool part_aligned(const uint32_t *d_ids, const double *d_v)
+{
+    return (((uintptr_t)d_v & 15) == 0) && (((uintptr_t)d_ids & 7) == 0);
+}
+
 size_t part_scratch_bytes(size_t n, uint32_t nmetrics, int num_cus)
 {
     PartPlan P;
@@ -92,18 +99,35 @@ size_t part_scratch_bytes(size_t n, uint32_t nmetrics, int num_cus)
 // ---------------------------------------------------------------------------
 // P1: compress + partition scatter
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(P1_BLOCK) void k_part_scatter(const uint32_t *__restrict__ ids,
+typedef double pd2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t pu2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t pu4_t __attribute__((ext_vector_type(4)));
+
+// Record format (4 bytes): partition << 24 | local name id << 16 | bin.
+// ids must be 8-byte and v 16-byte aligned (the launcher checks).
+//
+// Write-out is LINE-BUFFERED: measured, letting each tile emit its ~16-record (64 B) runs directly
+// costs 2.8 ms of a 5.0 ms kernel and 1.6x write amplification (partial lines evicted before their
+// other half arrives).  So every partition owns one 128-byte staging line in LDS; a tile emits only
+// whole, aligned lines (staged leftovers + new records) and keeps the remainder staged.
+constexpr uint32_t LINE = 16; // records per staged line (64 B, one aligned HBM sector pair)
+
+__global__ __launch_bounds__(P1_BLOCK, 6) void k_part_scatter(const uint32_t *__restrict__ ids,
                                                            const double *__restrict__ v, size_t n,
                                                            uint32_t nmetrics, uint32_t log_np,
                                                            const double *__restrict__ Tx,
                                                            uint32_t *__restrict__ records,
                                                            uint32_t *__restrict__ cdesc, uint32_t chunks_per_wg,
-                                                           uint32_t *__restrict__ err)
+                                                           uint32_t *__restrict__ err, uint32_t dbg)
 {
     __shared__ uint32_t s_cnt[NPMAX], s_off[NPMAX], s_cfill[NPMAX], s_cbase[NPMAX];
-    __shared__ uint32_t s_of[NPMAX], s_obase[NPMAX], s_onew[NPMAX];
+    __shared__ uint32_t s_sf[NPMAX];             // records currently staged per partition (< LINE)
+    __shared__ uint32_t s_d1[NPMAX], s_n1[NPMAX]; // this tile: global index / count of the staged records to emit
+    // per partition, for sorted position i:  i < E ? global[(i < T ? A : B) + i] : stage[i - E + sf0]
+    // packed as {A, B, T, E | sf0 << 16}
+    __shared__ __attribute__((aligned(16))) pu4_t s_tbl[NPMAX];
     __shared__ uint32_t s_sorted[P1_TILE];
-    __shared__ uint8_t s_spart[P1_TILE];
+    __shared__ uint32_t s_stage[NPMAX * LINE];
     __shared__ uint32_t s_wsum[4];
     __shared__ uint32_t s_pool_next, s_total;
 
@@ -111,38 +135,62 @@ __global__ __launch_bounds__(P1_BLOCK) void k_part_scatter(const uint32_t *__res
     const uint32_t np = 1u << log_np, pmask = np - 1;
     const uint32_t pool_base = blockIdx.x * chunks_per_wg;
 
-    if (tid < NPMAX) { s_cnt[tid] = 0; s_cfill[tid] = CHUNK; s_cbase[tid] = INVALID; }
+    if (tid < NPMAX) { s_cnt[tid] = 0; s_cfill[tid] = CHUNK; s_cbase[tid] = INVALID; s_sf[tid] = 0; s_d1[tid] = INVALID; }
     if (tid == 0) s_pool_next = 0;
     __syncthreads();
 
     const size_t ntiles = (n + P1_TILE - 1) / P1_TILE;
-    for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const size_t base = tile * P1_TILE;
-        uint32_t rec[P1_SPT], pr[P1_SPT];
-        uint32_t idv[P1_SPT];
-        double val[P1_SPT];
+    const size_t npairs = (n + 1) / 2;
+    const pd2_t *vp = reinterpret_cast<const pd2_t *>(v);
+    const pu2_t *ip = reinterpret_cast<const pu2_t *>(ids);
+    constexpr int NPAIR = P1_SPT / 2;
+    pu2_t idv[NPAIR];
+    pd2_t val[NPAIR];
+    // software pipeline: the loads of tile t+1 are issued right after tile t's samples have been
+    // consumed, so their latency hides behind tile t's scan / LDS sort / copy-out phases.
+    // Lane layout: pair index = tile*2048 + j*P1_BLOCK + tid, 16 B of values + 8 B of ids per lane.
+    auto load_tile = [&](size_t tile) {
+        const size_t pbase = tile * (P1_TILE / 2);
 #pragma unroll
-        for (int j = 0; j < P1_SPT; j++) {
-            const size_t i = base + (size_t)j * P1_BLOCK + tid;
-            const bool ok = i < n;
-            idv[j] = ok ? __builtin_nontemporal_load(ids + i) : INVALID;
-            val[j] = ok ? __builtin_nontemporal_load(v + i) : 0.0;
+        for (int j = 0; j < NPAIR; j++) {
+            const size_t i = pbase + (size_t)j * P1_BLOCK + tid;
+            if (tile < ntiles && i < npairs) {
+                // the last pair of an odd-length stream reads one element past n inside the same
+                // 16-byte granule; it is masked below
+                idv[j] = __builtin_nontemporal_load(ip + i);
+                val[j] = __builtin_nontemporal_load(vp + i);
+            } else {
+                idv[j] = (pu2_t){INVALID, INVALID};
+                val[j] = (pd2_t){0.0, 0.0};
+            }
         }
+    };
+    load_tile(blockIdx.x);
+    for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const size_t pbase = tile * (P1_TILE / 2);
+        uint32_t rec[P1_SPT], pr[P1_SPT];
 #pragma unroll
         for (int j = 0; j < P1_SPT; j++) {
+            const size_t i = 2 * (pbase + (size_t)(j >> 1) * P1_BLOCK + tid) + (j & 1);
+            const uint32_t id = (j & 1) ? idv[j >> 1].y : idv[j >> 1].x;
+            const double x = (j & 1) ? val[j >> 1].y : val[j >> 1].x;
             pr[j] = INVALID;
             rec[j] = 0;
-            if (idv[j] < nmetrics) {
-                const uint32_t bin = lh_bin_of(val[j], Tx);
-                const uint32_t p = idv[j] & pmask;
-                rec[j] = ((idv[j] >> log_np) << 16) | bin;
-                const uint32_t rank = atomicAdd(&s_cnt[p], 1u);
-                pr[j] = p | (rank << 8);
-            } else if (base + (size_t)j * P1_BLOCK + tid < n) {
-                atomicOr(err, 1u); // id >= nmetrics: reported by lh_sync / lh_extract
+            if (i < n && id != INVALID) {
+                if (id < nmetrics) {
+                    const uint32_t bin = (dbg & 2u) ? (uint32_t)(__double2loint(x) & 0xffff) : lh_bin_of(x, Tx);
+                    const uint32_t p = id & pmask;
+                    rec[j] = (p << 24) | ((id >> log_np) << 16) | bin;
+                    pr[j] = p | (atomicAdd(&s_cnt[p], 1u) << 8);
+                } else {
+                    atomicOr(err, 1u); // id >= nmetrics: reported by lh_sync / lh_extract
+                }
+            } else if (i < n) {
+                atomicOr(err, 1u);     // id == 0xffffffff
             }
         }
         __syncthreads();
+        load_tile(tile + gridDim.x);
 
         // exclusive scan of the per-partition counts + chunk bookkeeping (threads 0..255)
         uint32_t c = 0, inc = 0;
@@ -160,60 +208,100 @@ __global__ __launch_bounds__(P1_BLOCK) void k_part_scatter(const uint32_t *__res
         if (tid < NPMAX) {
             uint32_t wbase = 0;
             for (uint32_t w = 0; w < wave; w++) wbase += s_wsum[w];
-            s_off[tid] = wbase + inc - c;
+            const uint32_t off = wbase + inc - c;
+            s_off[tid] = off;
             if (tid == NPMAX - 1) s_total = wbase + inc;
             s_cnt[tid] = 0; // ranks are already in registers
+            s_d1[tid] = INVALID;
             if (c) {
                 const uint32_t p = tid;
-                const uint32_t f = s_cfill[p], cb = s_cbase[p];
-                s_of[p] = f;
-                s_obase[p] = cb;
-                const uint32_t room = CHUNK - f;
-                if (c > room) {
-                    const uint32_t over = c - room;
+                const uint32_t sf = s_sf[p], cf = s_cfill[p], cb = s_cbase[p];
+                const uint32_t total = sf + c, nfull = total / LINE, out = nfull * LINE;
+                const uint32_t room = CHUNK - cf; // multiple of LINE (0 when there is no open chunk)
+                uint32_t first = 0;
+                if (out > room) {
+                    const uint32_t over = out - room;
                     const uint32_t k = (over + CHUNK - 1) / CHUNK;
-                    const uint32_t first = pool_base + atomicAdd(&s_pool_next, k);
-                    s_onew[p] = first;
-                    if (cb != INVALID) cdesc[cb] = (p << 16) | CHUNK; // the old chunk is now full
+                    first = pool_base + atomicAdd(&s_pool_next, k); // k consecutive chunks
+                    if (cb != INVALID) cdesc[cb] = (p << 16) | CHUNK;  // the old chunk is now full
                     for (uint32_t q = 0; q + 1 < k; q++) cdesc[first + q] = (p << 16) | CHUNK;
                     s_cbase[p] = first + k - 1;
                     s_cfill[p] = over - (k - 1) * CHUNK;
                 } else {
-                    s_cfill[p] = f + c;
+                    s_cfill[p] = cf + out;
+                }
+                s_sf[p] = total - out;
+                // emitted element u = sf + (i - off) of this partition goes to
+                //   u < room : cb*CHUNK + cf + u            = A + i
+                //   else     : first*CHUNK + (u - room)      = B + i     (new chunks are consecutive)
+                pu4_t t;
+                t.x = cb * CHUNK + cf + sf - off;
+                t.y = first * CHUNK + sf - off - room;
+                t.z = room ? off + room - sf : off;
+                const uint32_t E = nfull ? off + out - sf : off;
+                t.w = E | ((nfull ? 0u : sf) << 16);
+                s_tbl[p] = t;
+                if (nfull && sf) {
+                    s_d1[p] = room ? cb * CHUNK + cf : first * CHUNK;
+                    s_n1[p] = sf;
                 }
             }
         }
         __syncthreads();
 
-        // tile-local counting sort into LDS
+        // tile-local counting sort into LDS ...
 #pragma unroll
         for (int j = 0; j < P1_SPT; j++) {
-            if (pr[j] != INVALID) {
-                const uint32_t p = pr[j] & 0xffu;
-                const uint32_t pos = s_off[p] + (pr[j] >> 8);
-                s_sorted[pos] = rec[j];
-                s_spart[pos] = (uint8_t)p;
-            }
+            if (pr[j] != INVALID) s_sorted[s_off[pr[j] & 0xffu] + (pr[j] >> 8)] = rec[j];
         }
+        // ... and, independently, the previously staged records of partitions that emit a line
+        if (!(dbg & 1u))
+            for (uint32_t e = tid; e < NPMAX * LINE; e += P1_BLOCK) {
+                const uint32_t p = e / LINE, u = e % LINE;
+                const uint32_t d = s_d1[p];
+                if (d != INVALID && u < s_n1[p]) records[d + u] = s_stage[e];
+            }
         __syncthreads();
 
-        // copy out: every partition's records of this tile form one contiguous run
+        // copy out: whole lines to HBM, the remainder of each partition into its staging line
         const uint32_t tile_total = s_total;
         for (uint32_t i = tid; i < tile_total; i += P1_BLOCK) {
-            const uint32_t p = s_spart[i];
-            const uint32_t f = s_of[p] + (i - s_off[p]);
-            size_t dst;
-            if (f < CHUNK) {
-                dst = (size_t)s_obase[p] * CHUNK + f;
+            const uint32_t r = s_sorted[i];
+            const pu4_t t = s_tbl[r >> 24];
+            const uint32_t E = t.w & 0xffffu;
+            if (i < E) {
+                if (!(dbg & 1u)) records[(i < t.z ? t.x : t.y) + i] = r;
             } else {
-                const uint32_t f2 = f - CHUNK;
-                dst = ((size_t)s_onew[p] + f2 / CHUNK) * CHUNK + (f2 % CHUNK);
+                s_stage[(r >> 24) * LINE + (i - E) + (t.w >> 16)] = r;
             }
-            records[dst] = s_sorted[i];
         }
         // (the next tile's first barrier separates this copy-out from the next bookkeeping)
     }
     __syncthreads();
+
+    // drain: the staged remainders (one partial line per partition) and the open chunks' descriptors
+    if (tid < NPMAX) {
+        s_d1[tid] = INVALID;
+        const uint32_t p = tid, sf = s_sf[p];
+        if (sf) {
+            uint32_t cf = s_cfill[p], cb = s_cbase[p];
+            if (cf == CHUNK) { // no open chunk, or it is exactly full
+                if (cb != INVALID) cdesc[cb] = (p << 16) | CHUNK;
+                cb = pool_base + atomicAdd(&s_pool_next, 1u);
+                cf = 0;
+                s_cbase[p] = cb;
+            }
+            s_d1[p] = cb * CHUNK + cf;
+            s_n1[p] = sf;
+            s_cfill[p] = cf + sf;
+        }
+    }
+    __syncthreads();
+    for (uint32_t e = tid; e < NPMAX * LINE; e += P1_BLOCK) {
+        const uint32_t p = e / LINE, u = e % LINE;
+        const uint32_t d = s_d1[p];
+        if (d != INVALID && u < s_n1[p]) records[d + u] = s_stage[e];
+    }
     if (tid < np && s_cbase[tid] != INVALID) cdesc[s_cbase[tid]] = (tid << 16) | s_cfill[tid];
 }
 
@@ -331,7 +419,7 @@ __device__ __forceinline__ void p2_global_add(uint64_t *__restrict__ counts, uin
     if (bin > r[1]) atomicMax(&r[1], bin);
 }
 
-__global__ __launch_bounds__(P2_BLOCK) void k_part_hist(const uint32_t *__restrict__ records,
+__global__ __launch_bounds__(P2_BLOCK, 8) void k_part_hist(const uint32_t *__restrict__ records,
                                                         const uint32_t *__restrict__ cdesc,
                                                         const uint32_t *__restrict__ sorted,
                                                         const uint32_t *__restrict__ part_start,
@@ -355,68 +443,145 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist(const uint32_t *__restri
     const uint32_t W = 1u << log_w, words = mpp << log_w;
 
     for (uint32_t i = tid; i < words; i += P2_BLOCK) h[i] = 0;
-    if (tid < mpp) { s_mn[tid] = INVALID; s_mx[tid] = 0; }
     __syncthreads();
 
-    // window origins from the slot's first chunk (streams are unimodal per name in practice;
-    // a badly placed window only costs speed: out-of-window records go to global atomics)
+    // ---- window placement.  A sample of the slot (its first chunk, <= 1 024 records) is
+    // bucketed coarsely into h[name][bin >> log_cw] (W coarse cells span the whole key space);
+    // each name's window is the run of coarse cells with the largest mass, centred among ties.
+    // A badly placed window only costs speed: out-of-window records go to global atomics.
+    const uint32_t log_cw = 16 - log_w;
     {
         const uint32_t c0 = list[0];
         const uint32_t n0 = cdesc[c0] & 0xffffu;
         const uint32_t *b0 = records + (size_t)c0 * CHUNK;
         for (uint32_t i = tid; i < n0; i += P2_BLOCK) {
             const uint32_t rec = b0[i];
-            atomicMin(&s_mn[rec >> 16], rec & 0xffffu);
-            atomicMax(&s_mx[rec >> 16], rec & 0xffffu);
+            atomicAdd(&h[(((rec >> 16) & 0xffu) << log_w) + ((rec & 0xffffu) >> log_cw)], 1u);
         }
     }
     __syncthreads();
-    if (tid < mpp) {
-        uint32_t org = 32768u - W / 2; // unseen name: centre on key 0
-        if (s_mn[tid] != INVALID) {
-            const uint32_t mid = (s_mn[tid] + s_mx[tid]) / 2;
-            org = mid > W / 2 ? mid - W / 2 : 0;
+    {
+        const uint32_t wl = (W >> log_cw) ? (W >> log_cw) : 1u; // coarse cells per window
+        const uint32_t S = W >= 64 ? (W >> 6) : 1u;             // coarse cells per lane
+        for (uint32_t l = wave; l < mpp; l += P2_BLOCK / 64) {
+            uint32_t *hl = h + (l << log_w);
+            const bool on = lane * S < W;
+            // inclusive prefix sums in place (lane-serial segments + wave scan of the segment totals)
+            uint32_t run = 0;
+            if (on)
+                for (uint32_t k = 0; k < S; k++) { run += hl[lane * S + k]; hl[lane * S + k] = run; }
+            uint32_t inc = run;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(inc, d, 64);
+                if ((int)lane >= d) inc += y;
+            }
+            const uint32_t excl = inc - run;
+            const uint32_t total = __shfl(inc, 63, 64);
+            if (on)
+                for (uint32_t k = 0; k < S; k++) hl[lane * S + k] += excl;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // best start cell: (mass << 16 | 65535 - s) maximises mass then minimises s; the mirrored
+            // packing finds the largest s with the same mass
+            uint32_t best_lo = 0, best_hi = 0;
+            if (on)
+                for (uint32_t k = 0; k < S; k++) {
+                    const uint32_t s = lane * S + k;
+                    if (s + wl <= W) {
+                        const uint32_t mass = hl[s + wl - 1] - (s ? hl[s - 1] : 0u);
+                        const uint32_t a = (mass << 16) | (65535u - s), b = (mass << 16) | s;
+                        best_lo = a > best_lo ? a : best_lo;
+                        best_hi = b > best_hi ? b : best_hi;
+                    }
+                }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const uint32_t a = __shfl_xor(best_lo, d, 64), b = __shfl_xor(best_hi, d, 64);
+                best_lo = a > best_lo ? a : best_lo;
+                best_hi = b > best_hi ? b : best_hi;
+            }
+            if (lane == 0) {
+                uint32_t org = 32768u - W / 2; // name absent from the sample: centre on key 0
+                if (total) {
+                    const uint32_t smin = 65535u - (best_lo & 0xffffu), smax = best_hi & 0xffffu;
+                    const uint32_t centre = ((smin + smax + wl) << log_cw) >> 1;
+                    org = centre > W / 2 ? centre - W / 2 : 0u;
+                }
+                if (org > LH_NKEYS - W) org = LH_NKEYS - W;
+                s_org[l] = org;
+                s_mn[l] = INVALID; // flush ranges
+                s_mx[l] = 0;
+            }
         }
-        if (org > LH_NKEYS - W) org = LH_NKEYS - W;
-        s_org[tid] = org;
-        s_mn[tid] = INVALID; // reused for the flush ranges
-        s_mx[tid] = 0;
     }
+    __syncthreads();
+    for (uint32_t i = tid; i < words; i += P2_BLOCK) h[i] = 0;
     __syncthreads();
 
-    // one chunk per wave per iteration: 1 024 records = 4 x (64 lanes x 16 B)
-    for (uint32_t j = wave; j < cnt; j += P2_BLOCK / 64) {
-        const uint32_t cid = __builtin_amdgcn_readfirstlane(list[j]);
-        const uint32_t cn = __builtin_amdgcn_readfirstlane(cdesc[cid] & 0xffffu);
-        const u4_t *src = reinterpret_cast<const u4_t *>(records + (size_t)cid * CHUNK);
+    // one chunk per wave per iteration: 1 024 records = 4 x (64 lanes x 16 B).  Double-buffered: the
+    // next chunk's descriptor and its four 16-B loads are in flight while this chunk is reduced.
+    auto load_chunk = [&](uint32_t cidx, u4_t (&dst)[CHUNK / 256]) {
+        const u4_t *src = reinterpret_cast<const u4_t *>(records + (size_t)cidx * CHUNK) + lane;
+#pragma unroll
+        for (uint32_t q = 0; q < CHUNK / 256; q++) dst[q] = __builtin_nontemporal_load(src + q * 64);
+    };
+    auto reduce_chunk = [&](const u4_t (&r4)[CHUNK / 256], uint32_t cn) {
+        const bool full = cn == CHUNK; // wave-uniform
 #pragma unroll
         for (uint32_t q = 0; q < CHUNK / 256; q++) {
-            const uint32_t k = q * 256 + lane * 4;
-            if (q * 256 >= cn) break; // wave-uniform
-            const u4_t r4 = __builtin_nontemporal_load(src + (k >> 2));
-            const uint32_t rr[4] = {r4.x, r4.y, r4.z, r4.w};
+            const uint32_t rr[4] = {r4[q].x, r4[q].y, r4[q].z, r4[q].w};
 #pragma unroll
             for (int t = 0; t < 4; t++) {
-                const bool ok = k + t < cn;
                 const uint32_t rec = rr[t];
-                // constant streams: the whole wave carries one record value
-                const uint32_t f0 = __builtin_amdgcn_readfirstlane(rec);
-                const unsigned long long act = __builtin_amdgcn_ballot_w64(ok);
-                const unsigned long long dif = __builtin_amdgcn_ballot_w64(ok && rec != f0);
-                const uint32_t l = rec >> 16, b = rec & 0xffffu;
-                const uint32_t rel = b - s_org[l & (PART_MAX_MPP - 1)];
-                if (act && dif == 0ull && (act & 1ull)) {
-                    if (lane == 0) {
-                        const uint32_t nact = (uint32_t)__builtin_popcountll(act);
-                        if (rel < W) atomicAdd(&h[(l << log_w) + rel], nact);
-                        else p2_global_add(counts, ranges, (l << log_np) | p, b, nact);
+                const uint32_t l = (rec >> 16) & 0xffu, b = rec & 0xffffu;
+                const uint32_t rel = b - s_org[l];
+                if (full) {
+                    // constant streams: the whole wave carries one record value -> one lane adds 64
+                    const uint32_t f0 = __builtin_amdgcn_readfirstlane(rec);
+                    if (__builtin_amdgcn_ballot_w64(rec != f0) == 0ull) {
+                        if (lane == 0) {
+                            if (rel < W) atomicAdd(&h[(l << log_w) + rel], 64u);
+                            else p2_global_add(counts, ranges, (l << log_np) | p, b, 64);
+                        }
+                    } else {
+                        if (rel < W) atomicAdd(&h[(l << log_w) + rel], 1u);
+                        else p2_global_add(counts, ranges, (l << log_np) | p, b, 1);
                     }
-                } else if (ok) {
+                } else if (q * 256 + lane * 4 + t < cn) {
                     if (rel < W) atomicAdd(&h[(l << log_w) + rel], 1u);
                     else p2_global_add(counts, ranges, (l << log_np) | p, b, 1);
                 }
             }
         }
+    };
+    constexpr uint32_t WSTEP = P2_BLOCK / 64;
+    u4_t bufA[CHUNK / 256], bufB[CHUNK / 256];
+    uint32_t j = wave;
+    uint32_t cnA = 0, cnB = 0;
+    if (j < cnt) {
+        const uint32_t cid = __builtin_amdgcn_readfirstlane(list[j]);
+        cnA = __builtin_amdgcn_readfirstlane(cdesc[cid] & 0xffffu);
+        load_chunk(cid, bufA);
+    }
+    while (j < cnt) {
+        // A holds chunk j; fetch chunk j+WSTEP into B, reduce A
+        if (j + WSTEP < cnt) {
+            const uint32_t cid = __builtin_amdgcn_readfirstlane(list[j + WSTEP]);
+            cnB = __builtin_amdgcn_readfirstlane(cdesc[cid] & 0xffffu);
+            load_chunk(cid, bufB);
+        }
+        reduce_chunk(bufA, cnA);
+        j += WSTEP;
+        if (j >= cnt) break;
+        // B holds chunk j; fetch chunk j+WSTEP into A, reduce B
+        if (j + WSTEP < cnt) {
+            const uint32_t cid = __builtin_amdgcn_readfirstlane(list[j + WSTEP]);
+            cnA = __builtin_amdgcn_readfirstlane(cdesc[cid] & 0xffffu);
+            load_chunk(cid, bufA);
+        }
+        reduce_chunk(bufB, cnB);
+        j += WSTEP;
     }
     __syncthreads();
 
@@ -445,6 +610,7 @@ hipError_t launch_ingest_pairs_part(const uint32_t *d_ids, const double *d_v, si
 {
     PartPlan P;
     if (!make_plan(n, nmetrics, num_cus, P) || scratch_bytes < P.total || !scratch) return hipErrorInvalidValue;
+    if (((uintptr_t)d_v & 15) || ((uintptr_t)d_ids & 7)) return hipErrorInvalidValue; // see part_aligned()
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_part_hist),
@@ -464,12 +630,16 @@ hipError_t launch_ingest_pairs_part(const uint32_t *d_ids, const double *d_v, si
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(small, 0, (3 * NPMAX + 3 * P2_SLOTS + 64) * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
+    // LH_DEBUG_FLAGS (tuning only, never set by tests or bench): 1 = P1 skips its record stores,
+    // 2 = P1 skips compress, 4 = skip P2.  Results are wrong with any bit set.
+    static const uint32_t dbg = getenv("LH_DEBUG_FLAGS") ? (uint32_t)atoi(getenv("LH_DEBUG_FLAGS")) : 0u;
     hipLaunchKernelGGL(k_part_scatter, dim3(P.g1), dim3(P1_BLOCK), 0, s, d_ids, d_v, n, nmetrics, P.log_np, d_Tx,
-                       records, cdesc, P.chunks_per_wg, d_err);
+                       records, cdesc, P.chunks_per_wg, d_err, dbg);
     const unsigned plan_grid = (P.nchunks + PL_PER_WG - 1) / PL_PER_WG;
     hipLaunchKernelGGL(k_plan_count, dim3(plan_grid), dim3(PL_BLOCK), 0, s, cdesc, P.nchunks, pc);
     hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(PL_BLOCK), 0, s, pc, part_start, cursor, slots, nslots, P.np);
     hipLaunchKernelGGL(k_plan_scatter, dim3(plan_grid), dim3(PL_BLOCK), 0, s, cdesc, P.nchunks, cursor, sorted);
+    if (!(dbg & 4u))
     hipLaunchKernelGGL(k_part_hist, dim3(P2_SLOTS), dim3(P2_BLOCK), P2_LDS_BYTES, s, records, cdesc, sorted,
                        part_start, slots, nslots, P.log_np, P.mpp, P.log_w, counts, ranges);
     return hipGetLastError();

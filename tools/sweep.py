@@ -19,13 +19,14 @@ def main():
     ap.add_argument("--samples", type=float, default=1e8)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--pairs", type=int, default=0, help="if >0: mixed stream over this many names, Zipf(1.0) ids")
+    ap.add_argument("--dists", default="lognormal,constant,uniform,exponential,normal,loguniform,lognormal25")
     a = ap.parse_args()
     n = int(a.samples)
     torch.cuda.set_device(0)
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     eng = loghisto_amd.Engine(max_metrics=max(1, a.pairs), num_buffers=2, num_lanes=1, lane_samples=1 << 16)
-    for kind in ["lognormal", "constant", "uniform", "exponential", "normal", "loguniform", "lognormal25"]:
+    for kind in a.dists.split(","):
         data = bench.make_samples(n, kind, 7)
         ids = None
         if a.pairs:
