@@ -1,0 +1,64 @@
+"""GPU side of the multi-GPU merge plumbing.  Only one GPU is reachable here, so this
+drives loghisto_amd.merge.merge_snapshot through a single-rank RCCL group: it checks
+the zero-copy aliasing of the snapshot's HBM rows as torch tensors, the stream
+hand-off between torch's stream and the snapshot's extract stream, and that
+extract after the merge sees the merged cells.  The world-size-2 arithmetic is
+covered on CPU by tests/test_merge_gloo.py."""
+import math
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def test_merge_snapshot_single_rank_rccl(native_lib, torch_cuda):
+    torch = torch_cuda
+    import torch.distributed as dist
+    import loghisto_amd
+    from loghisto_amd import merge
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        M = 6
+        rng = np.random.default_rng(8)
+        n = 500_000
+        ids = rng.integers(0, M, n).astype(np.uint32)
+        v = rng.lognormal(math.log(1e5), 1.0, n)
+        want = oracle.histogram_pairs(ids, v, M)
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as eng:
+                eng.submit_pairs_device(torch.from_numpy(ids.view(np.int32)).cuda(), torch.from_numpy(v).cuda(),
+                                        stream=stream)
+                snap = eng.flip()
+                rows, ranges = merge.snapshot_tensors(snap, M)
+                for plan in ("allreduce", "reduce_scatter"):
+                    first, last = merge.merge_snapshot(snap, M, plan=plan)
+                    assert (first, last) == (0, M)
+                # the aliased tensors ARE the snapshot's memory
+                torch.cuda.synchronize()
+                assert np.array_equal(rows.cpu().numpy().view(np.uint64), want)
+                r = ranges.cpu().numpy()
+                for m in range(M):
+                    nz = np.nonzero(want[m])[0]
+                    assert (r[m][0], r[m][1]) == (nz[0], nz[-1])
+                # a cell injected through the alias (as a peer's contribution would be) is seen by extract
+                rows[2, 40000] += 5
+                snap.mark_dirty(2, 1, 40000, 40000)
+                merge.merge_snapshot(snap, M, plan="allreduce")
+                got = snap.extract([1.0], M)
+                assert int(got["count"][2]) == int(want[2].sum()) + 5
+                assert int(got["pkeys"][2][0]) == 40000 - 32768
+                snap.release()
+    finally:
+        dist.destroy_process_group()
