@@ -1,0 +1,233 @@
+// loghisto.hpp -- C++ host layer with the reference's MetricSystem API over the C ABI
+// (include/loghisto_gpu.h).
+//
+// The reference is Go; no Go toolchain exists in the build image, so the host side a cgo
+// binding would provide is written in C++ with the same names, argument
+// meaning, key naming and error behaviour as /root/reference/metrics.go:
+//
+//   NewMetricSystem(interval, sysStats)            metrics.go:143   -> MetricSystem(...)
+//   SpecifyPercentiles                             metrics.go:199
+//   Subscribe/UnsubscribeTo{Raw,Processed}Metrics  metrics.go:205-228  (Channel<T> ~ buffered Go chan)
+//   StartTimer / TimerToken.Stop                   metrics.go:232-246
+//   Counter / Histogram                            metrics.go:251-295
+//   RegisterGaugeFunc / DeregisterGaugeFunc        metrics.go:299-310
+//   collectRawMetrics / processMetrics             metrics.go:420-506 (unexported in Go; public here
+//                                                   because the reference's tests call them)
+//   Start / Stop, reaper                           metrics.go:530-653
+//   GraphiteProtocol / OpenTSDBProtocol            graphite.go:73, opentsdb.go:83
+//
+// What moved to the GPU: compress + the per-(name,bucket) fan-in (Histogram), the epoch flip of the
+// histogram cells (collectRawMetrics) and processHistograms/percentile (processMetrics).  Counters,
+// rates, gauges, subscriptions and the reaper stay on the host exactly as in the reference.
+#pragma once
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdint>
+#include <deque>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <shared_mutex>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+struct lh_engine;
+struct lh_snapshot;
+
+namespace loghisto {
+
+// Buffered channel with Go's non-blocking-send semantics (select { case ch <- v: default: }).
+template <class T> class Channel {
+public:
+    explicit Channel(size_t capacity) : cap_(capacity) {}
+    bool TrySend(T v)
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        if (closed_ || q_.size() >= cap_) return false;
+        q_.push_back(std::move(v));
+        cv_.notify_one();
+        return true;
+    }
+    // false on timeout or when closed and drained
+    bool Receive(T &out, std::chrono::nanoseconds timeout)
+    {
+        std::unique_lock<std::mutex> g(mu_);
+        if (!cv_.wait_for(g, timeout, [&] { return !q_.empty() || closed_; })) return false;
+        if (q_.empty()) return false;
+        out = std::move(q_.front());
+        q_.pop_front();
+        return true;
+    }
+    bool TryReceive(T &out) { return Receive(out, std::chrono::nanoseconds(0)); }
+    void Close()
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        closed_ = true;
+        cv_.notify_all();
+    }
+    bool Closed()
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        return closed_;
+    }
+    size_t Len()
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        return q_.size();
+    }
+
+private:
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<T> q_;
+    size_t cap_;
+    bool closed_ = false;
+};
+
+// metrics.go:47-50
+struct ProcessedMetricSet {
+    std::chrono::system_clock::time_point Time;
+    std::unordered_map<std::string, double> Metrics;
+};
+
+// metrics.go:54-60.  Histograms holds the occupied (key -> count) cells per name; it is
+// materialised from the device only when somebody asks (raw subscribers, tests).
+struct RawMetricSet {
+    std::chrono::system_clock::time_point Time;
+    std::unordered_map<std::string, uint64_t> Counters;
+    std::unordered_map<std::string, uint64_t> Rates;
+    std::unordered_map<std::string, double> Gauges;
+    const std::unordered_map<std::string, std::map<int16_t, uint64_t>> &Histograms();
+    ~RawMetricSet();
+
+    // implementation state
+    lh_snapshot *snapshot = nullptr;
+    std::vector<std::string> names; // dense id -> name at flip time
+    std::mutex mu;
+    bool hist_ready = false;
+    std::unordered_map<std::string, std::map<int16_t, uint64_t>> hist;
+    void Release(); // return the epoch buffer (called by processMetrics' caller / destructor)
+};
+
+class MetricSystem;
+
+// metrics.go:63-67
+struct TimerToken {
+    std::string Name;
+    std::chrono::steady_clock::time_point Start;
+    MetricSystem *System;
+    // metrics.go:242-246: submits float64(duration in ns) as a histogram sample, returns the duration
+    std::chrono::nanoseconds Stop();
+};
+
+struct Options {
+    int device = 0;
+    uint32_t max_metrics = 1024;  // histogram names
+    uint32_t num_buffers = 3;     // intervals that may be in flight (flip .. processed)
+    uint32_t num_lanes = 8;       // staging lanes inside the engine
+    uint32_t stage_samples = 4096; // per-thread (id,value) pairs per crossing into the library
+    uint64_t lane_samples = 1u << 20;
+};
+
+class MetricSystem {
+public:
+    // NewMetricSystem, metrics.go:143
+    MetricSystem(std::chrono::nanoseconds interval, bool sysStats, const Options &opt = Options());
+    ~MetricSystem();
+    MetricSystem(const MetricSystem &) = delete;
+    MetricSystem &operator=(const MetricSystem &) = delete;
+
+    void SpecifyPercentiles(const std::map<std::string, double> &percentiles); // label is a "%s" format
+    void SubscribeToRawMetrics(std::shared_ptr<Channel<std::shared_ptr<RawMetricSet>>> ch);
+    void UnsubscribeFromRawMetrics(std::shared_ptr<Channel<std::shared_ptr<RawMetricSet>>> ch);
+    void SubscribeToProcessedMetrics(std::shared_ptr<Channel<std::shared_ptr<ProcessedMetricSet>>> ch);
+    void UnsubscribeFromProcessedMetrics(std::shared_ptr<Channel<std::shared_ptr<ProcessedMetricSet>>> ch);
+
+    TimerToken StartTimer(const std::string &name);
+    void Counter(const std::string &name, uint64_t amount);
+    void Histogram(const std::string &name, double value);
+    void RegisterGaugeFunc(const std::string &name, std::function<double()> f);
+    void DeregisterGaugeFunc(const std::string &name);
+
+    std::shared_ptr<RawMetricSet> collectRawMetrics();
+    std::shared_ptr<ProcessedMetricSet> processMetrics(const std::shared_ptr<RawMetricSet> &raw);
+    // the `_agg_*` keys the reaper adds after processMetrics, metrics.go:590-608
+    void addAggregates(const std::shared_ptr<RawMetricSet> &raw, ProcessedMetricSet &processed);
+
+    void Start();
+    void Stop();
+
+    // diagnostics
+    int last_status() const { return last_status_.load(); } // last non-zero lh_* code (0 if none)
+    uint64_t dropped_intervals() const { return dropped_intervals_.load(); }
+    bool engine_ready() const { return engine_ != nullptr; }
+
+private:
+    struct Stage;
+    Stage *stage();
+    void ship(Stage &s);
+    bool ensure_engine();
+    uint32_t intern(const std::string &name);
+    void updateSubscribers();
+    void reaper();
+    void note(int rc, const char *where);
+
+    std::chrono::nanoseconds interval_;
+    Options opt_;
+    std::map<std::string, double> percentiles_;
+    std::mutex percentiles_mu_;
+
+    lh_engine *engine_ = nullptr;
+    std::mutex engine_mu_;
+
+    // histogramMu (metrics.go:121): submitters shared, the flip exclusive
+    std::shared_mutex histogram_mu_;
+    std::mutex stages_mu_;
+    std::vector<std::unique_ptr<Stage>> stages_;
+    std::atomic<bool> hist_used_{false};
+    uint64_t instance_id_;
+
+    std::mutex names_mu_;
+    std::vector<std::string> names_;
+
+    // counters (host side as in the reference, metrics.go:112-117)
+    std::mutex counter_store_mu_;
+    std::unordered_map<std::string, uint64_t> counter_store_;
+
+    // lifetime histogram aggregates (metrics.go:122-125)
+    std::mutex hist_count_mu_;
+    std::unordered_map<std::string, uint64_t> hist_count_store_;
+
+    std::mutex gauge_mu_;
+    std::unordered_map<std::string, std::function<double()>> gauge_funcs_;
+
+    using RawCh = std::shared_ptr<Channel<std::shared_ptr<RawMetricSet>>>;
+    using ProcCh = std::shared_ptr<Channel<std::shared_ptr<ProcessedMetricSet>>>;
+    struct SubOp { int kind; RawCh raw; ProcCh proc; };
+    std::mutex pending_mu_;
+    std::vector<SubOp> pending_;
+    std::mutex subs_mu_;
+    std::vector<RawCh> raw_subs_;
+    std::vector<ProcCh> proc_subs_;
+    std::unordered_map<void *, int> raw_bad_, proc_bad_;
+
+    std::atomic<bool> reaping_{false};
+    std::atomic<bool> shutdown_{false};
+    std::mutex shutdown_mu_;
+    std::condition_variable shutdown_cv_;
+    std::thread reaper_thread_;
+    std::atomic<int> last_status_{0};
+    std::atomic<uint64_t> dropped_intervals_{0};
+};
+
+// graphite.go:73 / opentsdb.go:83: "cockroach.<host>.<metric with _ -> .> %f %d\n" and
+// "put <metric> <unix> %f host=<host>\n".  Downstream text formatting; kept for config 5.
+std::string GraphiteProtocol(const ProcessedMetricSet &ms);
+std::string OpenTSDBProtocol(const ProcessedMetricSet &ms);
+
+} // namespace loghisto

@@ -23,6 +23,13 @@ _UNITS = [
     ("lh_kernels.hip", ["--offload-arch=gfx950"]),
     ("lh_kernels_part.hip", ["--offload-arch=gfx950"]),
     ("lh_engine.cc", []),
+    ("host/metric_system.cc", []),   # C++ host layer with the reference's MetricSystem API (include/loghisto.hpp)
+]
+
+# standalone C++ programs linked against liblhgpu.so: (source relative to the repo root, output name)
+_PROGRAMS = [
+    ("tests/cpp/metrics_test.cc", "metrics_test"),   # metrics_test.go restated
+    ("tools/c5_driver.cc", "c5_driver"),             # BASELINE config 5 driver
 ]
 
 
@@ -45,11 +52,11 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     bdir = os.path.join(_HERE, "build")
     os.makedirs(bdir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    headers.append(os.path.join(INCLUDE, "loghisto_gpu.h"))
+    headers += [os.path.join(INCLUDE, "loghisto_gpu.h"), os.path.join(INCLUDE, "loghisto.hpp")]
     objs = []
     for src, extra in _UNITS:
         s = os.path.join(CSRC, src)
-        o = os.path.join(bdir, os.path.splitext(src)[0] + ".o")
+        o = os.path.join(bdir, os.path.splitext(src)[0].replace("/", "_") + ".o")
         if force or _stale(o, [s] + headers):
             cmd = [hipcc] + _COMMON + extra + ["-I", INCLUDE, "-c", s, "-o", o]
             if verbose:
@@ -61,6 +68,18 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+    root = os.path.dirname(_HERE)
+    for src, name in _PROGRAMS:
+        s = os.path.join(root, src)
+        if not os.path.exists(s):
+            continue
+        out = os.path.join(bdir, name)
+        if force or _stale(out, [s, LIB] + headers):
+            cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-Wall", "-I", INCLUDE, s, "-o", out,
+                   "-L", _HERE, "-llhgpu", "-Wl,-rpath," + _HERE, "-Wl,-rpath,$ORIGIN/.."]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
     return LIB
 
 

@@ -1,0 +1,565 @@
+// metric_system.cc -- C++ host layer: the reference's MetricSystem API over the C ABI.
+// See include/loghisto.hpp for the mapping to /root/reference/metrics.go.
+//
+// Concurrency model.  The reference serialises every Histogram call on one RWMutex word plus
+// four map probes (metrics.go:275-279) -- that, not the logarithm, is what limits it.  Here each
+// producer thread owns a staging buffer guarded by its own (uncontended) mutex; the epoch flip
+// takes every stage mutex, drains the buffers, calls lh_flip and releases them, which gives the
+// same "a sample belongs to exactly one interval" cut (metrics.go:460-463) without any shared
+// cache line on the submit path.  One crossing into the library moves `stage_samples` samples.
+#include "../../../include/loghisto.hpp"
+#include "../../../include/loghisto_gpu.h"
+
+#include <unistd.h>
+
+#include <algorithm>
+#include <cinttypes>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+namespace loghisto {
+
+namespace {
+
+std::atomic<uint64_t> g_next_instance{1};
+
+std::string fmt_label(const std::string &label, const std::string &name)
+{
+    // labels are Go format strings with one %s (metrics.go:145-155, 383)
+    std::string out;
+    out.reserve(label.size() + name.size());
+    for (size_t i = 0; i < label.size(); i++) {
+        if (label[i] == '%' && i + 1 < label.size() && label[i + 1] == 's') {
+            out += name;
+            i++;
+        } else if (label[i] == '%' && i + 1 < label.size() && label[i + 1] == '%') {
+            out += '%';
+            i++;
+        } else {
+            out += label[i];
+        }
+    }
+    return out;
+}
+
+std::chrono::system_clock::time_point truncate_to(std::chrono::nanoseconds interval)
+{
+    using namespace std::chrono;
+    const int64_t ivl = std::max<int64_t>(1, interval.count());
+    const int64_t now = duration_cast<nanoseconds>(system_clock::now().time_since_epoch()).count();
+    return system_clock::time_point(duration_cast<system_clock::duration>(nanoseconds(now / ivl * ivl)));
+}
+
+double read_proc_status_kb(const char *key)
+{
+    std::ifstream f("/proc/self/status");
+    std::string line;
+    const size_t klen = std::strlen(key);
+    while (std::getline(f, line))
+        if (line.compare(0, klen, key) == 0) return std::atof(line.c_str() + klen + 1);
+    return 0;
+}
+
+std::string hostname()
+{
+    char buf[256];
+    if (gethostname(buf, sizeof(buf)) != 0) return "unknown";
+    buf[sizeof(buf) - 1] = 0;
+    return buf;
+}
+
+} // namespace
+
+struct MetricSystem::Stage {
+    std::mutex mu;
+    std::vector<uint32_t> ids;
+    std::vector<double> vals;
+    size_t n = 0;
+    std::unordered_map<std::string, uint32_t> idcache;  // name -> dense id, thread private
+    std::unordered_map<std::string, uint64_t> counters; // counterCache share of this thread
+};
+
+// ---------------------------------------------------------------------------
+// RawMetricSet
+// ---------------------------------------------------------------------------
+const std::unordered_map<std::string, std::map<int16_t, uint64_t>> &RawMetricSet::Histograms()
+{
+    std::lock_guard<std::mutex> g(mu);
+    if (hist_ready) return hist;
+    hist_ready = true;
+    if (!snapshot || names.empty()) return hist;
+    std::vector<lh_stats> st(names.size());
+    if (lh_extract(snapshot, nullptr, 0, st.data(), nullptr, nullptr, nullptr, names.size()) != LH_OK) return hist;
+    std::vector<int16_t> keys;
+    std::vector<uint64_t> counts;
+    for (size_t id = 0; id < names.size(); id++) {
+        if (!st[id].present) continue; // the name has no map entry this interval
+        keys.resize(st[id].nbuckets);
+        counts.resize(st[id].nbuckets);
+        size_t n = 0;
+        if (lh_buckets(snapshot, (uint32_t)id, keys.data(), counts.data(), keys.size(), &n) != LH_OK) continue;
+        auto &m = hist[names[id]];
+        for (size_t i = 0; i < std::min(n, keys.size()); i++) m[keys[i]] = counts[i];
+    }
+    return hist;
+}
+
+void RawMetricSet::Release()
+{
+    std::lock_guard<std::mutex> g(mu);
+    if (snapshot) {
+        lh_release(snapshot);
+        snapshot = nullptr;
+    }
+}
+
+RawMetricSet::~RawMetricSet() { Release(); }
+
+// ---------------------------------------------------------------------------
+// MetricSystem
+// ---------------------------------------------------------------------------
+MetricSystem::MetricSystem(std::chrono::nanoseconds interval, bool sysStats, const Options &opt)
+    : interval_(interval), opt_(opt), instance_id_(g_next_instance.fetch_add(1))
+{
+    // metrics.go:145-155
+    percentiles_ = {{"%s_min", 0},    {"%s_50", .5},    {"%s_75", .75},     {"%s_90", .9}, {"%s_95", .95},
+                    {"%s_99", .99},   {"%s_99.9", .999}, {"%s_99.99", .9999}, {"%s_max", 1}};
+    if (sysStats) { // metrics.go:172-193: Go runtime statistics; nearest process-level analogues
+        gauge_funcs_["sys.Alloc"] = [] { return read_proc_status_kb("VmRSS:") * 1024.0; };
+        gauge_funcs_["sys.NumGC"] = [] { return 0.0; };
+        gauge_funcs_["sys.PauseTotalNs"] = [] { return 0.0; };
+        gauge_funcs_["sys.NumGoroutine"] = [] { return read_proc_status_kb("Threads:"); };
+    }
+}
+
+MetricSystem::~MetricSystem()
+{
+    Stop();
+    if (engine_) {
+        lh_destroy(engine_);
+        engine_ = nullptr;
+    }
+}
+
+void MetricSystem::note(int rc, const char *where)
+{
+    if (rc == LH_OK) return;
+    const int prev = last_status_.exchange(rc);
+    if (prev != rc) // the reference logs through glog and carries on (metrics.go:379-384)
+        std::fprintf(stderr, "loghisto: %s: %s [%s]\n", where, lh_strerror(rc), lh_last_error());
+}
+
+bool MetricSystem::ensure_engine()
+{
+    if (engine_) return true;
+    std::lock_guard<std::mutex> g(engine_mu_);
+    if (engine_) return true;
+    lh_config cfg;
+    lh_default_config(&cfg);
+    cfg.device = opt_.device;
+    cfg.max_metrics = opt_.max_metrics;
+    cfg.num_buffers = opt_.num_buffers;
+    cfg.num_lanes = opt_.num_lanes;
+    cfg.lane_samples = opt_.lane_samples;
+    lh_engine *e = nullptr;
+    const int rc = lh_create(&cfg, &e);
+    if (rc != LH_OK) {
+        note(rc, "lh_create");
+        return false;
+    }
+    engine_ = e;
+    return true;
+}
+
+void MetricSystem::SpecifyPercentiles(const std::map<std::string, double> &percentiles)
+{
+    std::lock_guard<std::mutex> g(percentiles_mu_);
+    percentiles_ = percentiles;
+}
+
+MetricSystem::Stage *MetricSystem::stage()
+{
+    // one-entry cache in front of a per-thread map keyed by the system's instance id
+    thread_local uint64_t last_id = 0;
+    thread_local Stage *last_stage = nullptr;
+    thread_local std::unordered_map<uint64_t, Stage *> mine;
+    if (last_id == instance_id_) return last_stage;
+    auto it = mine.find(instance_id_);
+    if (it == mine.end()) {
+        auto st = std::make_unique<Stage>();
+        st->ids.resize(opt_.stage_samples);
+        st->vals.resize(opt_.stage_samples);
+        Stage *raw = st.get();
+        {
+            std::lock_guard<std::mutex> g(stages_mu_);
+            stages_.push_back(std::move(st));
+        }
+        it = mine.emplace(instance_id_, raw).first;
+    }
+    last_id = instance_id_;
+    last_stage = it->second;
+    return last_stage;
+}
+
+uint32_t MetricSystem::intern(const std::string &name)
+{
+    uint32_t id = 0;
+    const int rc = lh_intern(engine_, name.data(), name.size(), &id);
+    if (rc != LH_OK) {
+        note(rc, "lh_intern");
+        return UINT32_MAX;
+    }
+    std::lock_guard<std::mutex> g(names_mu_);
+    if (names_.size() <= id) names_.resize(id + 1);
+    names_[id] = name;
+    return id;
+}
+
+void MetricSystem::ship(Stage &s)
+{
+    if (s.n == 0) return;
+    note(lh_submit_pairs(engine_, s.ids.data(), s.vals.data(), s.n), "lh_submit_pairs");
+    s.n = 0;
+}
+
+TimerToken MetricSystem::StartTimer(const std::string &name)
+{
+    return TimerToken{name, std::chrono::steady_clock::now(), this};
+}
+
+std::chrono::nanoseconds TimerToken::Stop()
+{
+    const auto d = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - Start);
+    System->Histogram(Name, (double)d.count());
+    return d;
+}
+
+void MetricSystem::Counter(const std::string &name, uint64_t amount)
+{
+    Stage *st = stage();
+    std::lock_guard<std::mutex> g(st->mu);
+    st->counters[name] += amount;
+}
+
+void MetricSystem::Histogram(const std::string &name, double value)
+{
+    if (!engine_ && !ensure_engine()) return; // no device: reported through last_status(), nothing to compute on
+    Stage *st = stage();
+    std::lock_guard<std::mutex> g(st->mu);
+    uint32_t id;
+    auto it = st->idcache.find(name);
+    if (it != st->idcache.end()) {
+        id = it->second;
+    } else {
+        id = intern(name);
+        if (id == UINT32_MAX) return;
+        st->idcache.emplace(name, id);
+    }
+    st->ids[st->n] = id;
+    st->vals[st->n] = value; // compress() happens on the GPU
+    hist_used_.store(true, std::memory_order_relaxed);
+    if (++st->n == st->ids.size()) ship(*st);
+}
+
+void MetricSystem::RegisterGaugeFunc(const std::string &name, std::function<double()> f)
+{
+    std::lock_guard<std::mutex> g(gauge_mu_);
+    gauge_funcs_[name] = std::move(f);
+}
+
+void MetricSystem::DeregisterGaugeFunc(const std::string &name)
+{
+    std::lock_guard<std::mutex> g(gauge_mu_);
+    gauge_funcs_.erase(name);
+}
+
+std::shared_ptr<RawMetricSet> MetricSystem::collectRawMetrics()
+{
+    auto raw = std::make_shared<RawMetricSet>();
+    raw->Time = truncate_to(interval_);
+
+    std::unordered_map<std::string, uint64_t> fresh;
+    {
+        // the epoch boundary: every stage is held while its counters are stolen, its samples shipped and
+        // the device buffers flipped (counterMu / histogramMu write locks, metrics.go:425-428, 460-463)
+        std::lock_guard<std::mutex> sg(stages_mu_);
+        for (auto &st : stages_) st->mu.lock();
+        for (auto &st : stages_) {
+            for (auto &kv : st->counters) fresh[kv.first] += kv.second;
+            st->counters.clear();
+        }
+        if (hist_used_.load() && engine_) {
+            for (auto &st : stages_) ship(*st);
+            lh_snapshot *snap = nullptr;
+            const int rc = lh_flip(engine_, &snap);
+            if (rc == LH_OK) raw->snapshot = snap;
+            else note(rc, "lh_flip"); // LH_EBUSY: the epoch keeps accumulating, nothing is lost
+        }
+        for (auto &st : stages_) st->mu.unlock();
+    }
+    {
+        std::lock_guard<std::mutex> g(names_mu_);
+        raw->names = names_;
+    }
+    raw->Rates = fresh; // metrics.go:430-433
+    {
+        std::lock_guard<std::mutex> g(counter_store_mu_); // metrics.go:435-458
+        for (auto &kv : fresh) counter_store_[kv.first] += kv.second;
+        raw->Counters = counter_store_;
+    }
+    {
+        std::lock_guard<std::mutex> g(gauge_mu_); // metrics.go:465-470
+        for (auto &kv : gauge_funcs_) raw->Gauges[kv.first] = kv.second();
+    }
+    return raw;
+}
+
+std::shared_ptr<ProcessedMetricSet> MetricSystem::processMetrics(const std::shared_ptr<RawMetricSet> &raw)
+{
+    auto out = std::make_shared<ProcessedMetricSet>();
+    out->Time = raw->Time;
+    auto &m = out->Metrics;
+    for (auto &kv : raw->Counters) m[kv.first] = (double)kv.second;       // metrics.go:487-489
+    for (auto &kv : raw->Rates) m[kv.first + "_rate"] = (double)kv.second; // metrics.go:491-493
+
+    // processHistograms for every name in one extract (metrics.go:336-387, 495-499)
+    if (raw->snapshot && !raw->names.empty()) {
+        std::vector<std::string> labels;
+        std::vector<double> ps;
+        {
+            std::lock_guard<std::mutex> g(percentiles_mu_);
+            for (auto &kv : percentiles_) { labels.push_back(kv.first); ps.push_back(kv.second); }
+        }
+        const size_t n = raw->names.size(), np = ps.size();
+        std::vector<lh_stats> st(n);
+        std::vector<double> pv(n * np);
+        std::vector<uint8_t> ok(n * np);
+        int rc;
+        {
+            std::lock_guard<std::mutex> g(raw->mu);
+            rc = raw->snapshot ? lh_extract(raw->snapshot, ps.data(), np, st.data(), pv.data(), nullptr, ok.data(), n)
+                               : LH_ESTATE;
+        }
+        note(rc, "lh_extract");
+        if (rc == LH_OK || rc == LH_ERANGE) {
+            for (size_t id = 0; id < n; id++) {
+                if (!st[id].present) continue;
+                const std::string &name = raw->names[id];
+                m[name + "_count"] = (double)st[id].count;
+                m[name + "_sum"] = st[id].sum;
+                m[name + "_avg"] = st[id].avg;
+                {
+                    std::lock_guard<std::mutex> g(hist_count_mu_); // metrics.go:359-376
+                    hist_count_store_[name + "_sum"] += st[id].agg_sum_add; // uint64(totalSum), wrapping add
+                    hist_count_store_[name + "_count"] += st[id].count;
+                }
+                for (size_t i = 0; i < np; i++) {
+                    if (ok[id * np + i]) m[fmt_label(labels[i], name)] = pv[id * np + i];
+                    else std::fprintf(stderr, "loghisto: unable to calculate percentile: Invalid percentile.  "
+                                              "Should be between 0 and 1.\n"); // metrics.go:379-384
+                }
+            }
+        }
+    }
+    for (auto &kv : raw->Gauges) m[kv.first] = kv.second; // metrics.go:501-503
+    return out;
+}
+
+void MetricSystem::addAggregates(const std::shared_ptr<RawMetricSet> &raw, ProcessedMetricSet &processed)
+{
+    for (const std::string &name : raw->names) { // metrics.go:590-608
+        if (!processed.Metrics.count(name + "_count")) continue;
+        uint64_t agg_count = 0, agg_sum = 0;
+        bool have = false;
+        {
+            std::lock_guard<std::mutex> g(hist_count_mu_);
+            auto c = hist_count_store_.find(name + "_count"), s = hist_count_store_.find(name + "_sum");
+            if (c != hist_count_store_.end() && s != hist_count_store_.end()) {
+                agg_count = c->second;
+                agg_sum = s->second;
+                have = true;
+            }
+        }
+        if (have && agg_count > 0) {
+            processed.Metrics[name + "_agg_avg"] = (double)(agg_sum / agg_count); // integer division
+            processed.Metrics[name + "_agg_count"] = (double)agg_count;
+            processed.Metrics[name + "_agg_sum"] = (double)agg_sum;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// subscriptions + reaper (glue; metrics.go:203-228, 508-639)
+// ---------------------------------------------------------------------------
+void MetricSystem::SubscribeToRawMetrics(RawCh ch)
+{
+    std::lock_guard<std::mutex> g(pending_mu_);
+    pending_.push_back({0, std::move(ch), nullptr});
+}
+void MetricSystem::UnsubscribeFromRawMetrics(RawCh ch)
+{
+    std::lock_guard<std::mutex> g(pending_mu_);
+    pending_.push_back({1, std::move(ch), nullptr});
+}
+void MetricSystem::SubscribeToProcessedMetrics(ProcCh ch)
+{
+    std::lock_guard<std::mutex> g(pending_mu_);
+    pending_.push_back({2, nullptr, std::move(ch)});
+}
+void MetricSystem::UnsubscribeFromProcessedMetrics(ProcCh ch)
+{
+    std::lock_guard<std::mutex> g(pending_mu_);
+    pending_.push_back({3, nullptr, std::move(ch)});
+}
+
+void MetricSystem::updateSubscribers()
+{
+    std::vector<SubOp> ops;
+    {
+        std::lock_guard<std::mutex> g(pending_mu_);
+        ops.swap(pending_);
+    }
+    std::lock_guard<std::mutex> g(subs_mu_);
+    for (auto &op : ops) {
+        switch (op.kind) {
+        case 0: raw_subs_.push_back(op.raw); break;
+        case 1: raw_subs_.erase(std::remove(raw_subs_.begin(), raw_subs_.end(), op.raw), raw_subs_.end()); break;
+        case 2: proc_subs_.push_back(op.proc); break;
+        case 3: proc_subs_.erase(std::remove(proc_subs_.begin(), proc_subs_.end(), op.proc), proc_subs_.end()); break;
+        }
+    }
+}
+
+namespace {
+template <class Ch, class Item>
+void broadcast(std::vector<Ch> &subs, std::unordered_map<void *, int> &bad, const Item &item)
+{
+    // non-blocking send; a subscriber that is full on 2 consecutive intervals is forgotten and its
+    // channel closed (metrics.go:567-580, 613-626)
+    for (size_t i = 0; i < subs.size();) {
+        void *key = subs[i].get();
+        if (subs[i]->TrySend(item)) {
+            bad.erase(key);
+            i++;
+        } else if (++bad[key] >= 2) {
+            subs[i]->Close();
+            bad.erase(key);
+            subs.erase(subs.begin() + (long)i);
+        } else {
+            i++;
+        }
+    }
+}
+} // namespace
+
+void MetricSystem::reaper()
+{
+    // processing pool: a 16-deep hand-off, the interval is dropped when it is full (metrics.go:533-545, 630-637)
+    Channel<std::shared_ptr<RawMetricSet>> work(16);
+    std::vector<std::thread> pool;
+    const unsigned nworkers = std::max(4u, std::thread::hardware_concurrency() / 4);
+    for (unsigned w = 0; w < std::min(nworkers, 8u); w++) {
+        pool.emplace_back([&] {
+            std::shared_ptr<RawMetricSet> raw;
+            while (!work.Closed() || work.Len()) {
+                if (!work.Receive(raw, std::chrono::milliseconds(50))) continue;
+                auto processed = processMetrics(raw);
+                addAggregates(raw, *processed);
+                raw->Release();
+                std::lock_guard<std::mutex> g(subs_mu_);
+                broadcast(proc_subs_, proc_bad_, processed);
+            }
+        });
+    }
+    const int64_t ivl = std::max<int64_t>(1, interval_.count());
+    while (true) {
+        using namespace std::chrono;
+        const int64_t now = duration_cast<nanoseconds>(system_clock::now().time_since_epoch()).count();
+        const nanoseconds tts(ivl - now % ivl);
+        {
+            std::unique_lock<std::mutex> g(shutdown_mu_);
+            if (shutdown_cv_.wait_for(g, tts, [&] { return shutdown_.load(); })) break;
+        }
+        auto raw = collectRawMetrics();
+        updateSubscribers();
+        {
+            std::lock_guard<std::mutex> g(subs_mu_);
+            if (!raw_subs_.empty()) {
+                raw->Histograms(); // materialise while the snapshot is alive
+                broadcast(raw_subs_, raw_bad_, raw);
+            }
+        }
+        if (!work.TrySend(raw)) {
+            dropped_intervals_.fetch_add(1);
+            std::fprintf(stderr, "loghisto: processing of metrics is taking longer than this node can handle; "
+                                 "dropping this entire interval\n");
+            raw->Release();
+        }
+    }
+    work.Close();
+    for (auto &t : pool) t.join();
+    reaping_.store(false);
+}
+
+void MetricSystem::Start()
+{
+    bool expected = false;
+    if (!reaping_.compare_exchange_strong(expected, true)) return;
+    shutdown_.store(false);
+    reaper_thread_ = std::thread([this] { reaper(); });
+}
+
+void MetricSystem::Stop()
+{
+    {
+        std::lock_guard<std::mutex> g(shutdown_mu_);
+        shutdown_.store(true);
+    }
+    shutdown_cv_.notify_all();
+    if (reaper_thread_.joinable()) reaper_thread_.join();
+}
+
+// ---------------------------------------------------------------------------
+// serializers (graphite.go:37-75, opentsdb.go:45-85)
+// ---------------------------------------------------------------------------
+std::string GraphiteProtocol(const ProcessedMetricSet &ms)
+{
+    const std::string host = hostname();
+    const long long t = (long long)std::chrono::duration_cast<std::chrono::seconds>(ms.Time.time_since_epoch()).count();
+    std::string out;
+    out.reserve(ms.Metrics.size() * 64);
+    char num[400];
+    for (auto &kv : ms.Metrics) {
+        std::string metric = kv.first;
+        std::replace(metric.begin(), metric.end(), '_', '.');
+        out += "cockroach.";
+        out += host;
+        out += '.';
+        out += metric;
+        std::snprintf(num, sizeof(num), " %f %lld\n", kv.second, t);
+        out += num;
+    }
+    return out;
+}
+
+std::string OpenTSDBProtocol(const ProcessedMetricSet &ms)
+{
+    const std::string host = hostname();
+    const long long t = (long long)std::chrono::duration_cast<std::chrono::seconds>(ms.Time.time_since_epoch()).count();
+    std::string out;
+    out.reserve(ms.Metrics.size() * 64);
+    char num[400];
+    for (auto &kv : ms.Metrics) {
+        out += "put ";
+        out += kv.first;
+        std::snprintf(num, sizeof(num), " %lld %f host=", t, kv.second);
+        out += num;
+        out += host;
+        out += '\n';
+    }
+    return out;
+}
+
+} // namespace loghisto

@@ -1,0 +1,295 @@
+// metrics_test.cc -- the reference's metrics_test.go restated against the C++ host layer
+// (include/loghisto.hpp) over the C ABI.  `--cpu` runs the tests that need no GPU (counters, rates,
+// gauges, subscriptions, serializers: that logic is host-side in the reference too); without it the
+// histogram tests run as well and need an MI355X.  Exit code = number of failed tests.
+#include "loghisto.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+
+using namespace loghisto;
+using namespace std::chrono_literals;
+
+static int g_failed = 0, g_checks = 0;
+#define CHECK(cond)                                                                                      \
+    do {                                                                                                 \
+        g_checks++;                                                                                      \
+        if (!(cond)) { std::printf("    CHECK FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); ok = false; } \
+    } while (0)
+#define TEST(name) static void name(bool &ok)
+#define RUN(name)                                                  \
+    do {                                                           \
+        bool ok = true;                                            \
+        name(ok);                                                  \
+        std::printf("%s %s\n", ok ? "PASS" : "FAIL", #name);       \
+        if (!ok) g_failed++;                                       \
+    } while (0)
+
+using RawCh = Channel<std::shared_ptr<RawMetricSet>>;
+using ProcCh = Channel<std::shared_ptr<ProcessedMetricSet>>;
+
+// ---- host-only -------------------------------------------------------------------------------
+TEST(TestRate) // metrics_test.go:202-223
+{
+    MetricSystem ms(1us, false);
+    ms.Counter("rate1", 777);
+    auto m = ms.processMetrics(ms.collectRawMetrics())->Metrics;
+    CHECK(m["rate1_rate"] == 777);
+    ms.Counter("rate1", 1223);
+    m = ms.processMetrics(ms.collectRawMetrics())->Metrics;
+    CHECK(m["rate1_rate"] == 1223);
+    ms.Counter("rate1", 1223);
+    ms.Counter("rate1", 1223);
+    m = ms.processMetrics(ms.collectRawMetrics())->Metrics;
+    CHECK(m["rate1_rate"] == 2446);
+}
+
+TEST(TestCounter) // metrics_test.go:225-240
+{
+    MetricSystem ms(1us, false);
+    ms.Counter("counter1", 3290);
+    auto m = ms.processMetrics(ms.collectRawMetrics())->Metrics;
+    CHECK(m["counter1"] == 3290);
+    ms.Counter("counter1", 10000);
+    m = ms.processMetrics(ms.collectRawMetrics())->Metrics;
+    CHECK(m["counter1"] == 13290);
+}
+
+TEST(TestCounterManyThreads)
+{
+    MetricSystem ms(1us, false);
+    std::vector<std::thread> th;
+    for (int t = 0; t < 8; t++)
+        th.emplace_back([&] { for (int i = 0; i < 10000; i++) ms.Counter("c", 3); });
+    for (auto &x : th) x.join();
+    auto raw = ms.collectRawMetrics();
+    CHECK(raw->Counters["c"] == 240000 && raw->Rates["c"] == 240000);
+}
+
+TEST(TestSysStats) // metrics_test.go:174-181
+{
+    MetricSystem ms(1us, true);
+    auto g = ms.collectRawMetrics()->Gauges;
+    CHECK(g.count("sys.Alloc") && g["sys.Alloc"] > 0);
+}
+
+TEST(TestRawBroadcast) // metrics_test.go:321-346
+{
+    auto ch = std::make_shared<RawCh>(128);
+    MetricSystem ms(1ms, false);
+    ms.SubscribeToRawMetrics(ch);
+    ms.Counter("counter2", 10);
+    ms.Counter("counter2", 111);
+    ms.Start();
+    std::shared_ptr<RawMetricSet> raw;
+    CHECK(ch->Receive(raw, 2s));
+    if (raw) {
+        CHECK(raw->Counters["counter2"] == 121);
+        CHECK(raw->Rates["counter2"] == 121);
+    }
+    ms.UnsubscribeFromRawMetrics(ch);
+    ms.Stop();
+}
+
+TEST(TestUpdateSubscribers) // metrics_test.go:242-287
+{
+    auto rc = std::make_shared<RawCh>(1);
+    auto pc = std::make_shared<ProcCh>(1);
+    MetricSystem ms(2ms, false);
+    ms.SubscribeToRawMetrics(rc);
+    ms.SubscribeToProcessedMetrics(pc);
+    ms.Counter("counter5", 33);
+    ms.Start();
+    std::shared_ptr<RawMetricSet> r;
+    std::shared_ptr<ProcessedMetricSet> p;
+    CHECK(rc->Receive(r, 2s));
+    ms.UnsubscribeFromRawMetrics(rc);
+    CHECK(pc->Receive(p, 2s));
+    ms.UnsubscribeFromProcessedMetrics(pc);
+    std::this_thread::sleep_for(50ms);
+    while (rc->TryReceive(r)) {}
+    while (pc->TryReceive(p)) {}
+    std::this_thread::sleep_for(50ms);
+    CHECK(!rc->TryReceive(r) && !pc->TryReceive(p)); // nothing after unsubscribing
+    ms.Stop();
+}
+
+TEST(TestSlowSubscriberIsDropped) // metrics.go:567-580
+{
+    auto pc = std::make_shared<ProcCh>(1);
+    MetricSystem ms(1ms, false);
+    ms.SubscribeToProcessedMetrics(pc);
+    ms.Start();
+    std::this_thread::sleep_for(100ms);
+    ms.Stop();
+    CHECK(pc->Closed());   // full twice in a row: forgotten and closed, the reaper never blocked
+}
+
+TEST(TestMetricSystemStop) // metrics_test.go:348-363
+{
+    auto threads = [] { std::FILE *f = std::fopen("/proc/self/status", "r"); char l[256]; int n = 0;
+                        while (std::fgets(l, sizeof l, f)) if (!std::strncmp(l, "Threads:", 8)) n = std::atoi(l + 8);
+                        std::fclose(f); return n; };
+    const int before = threads();
+    { MetricSystem ms(1us, false); ms.Start(); ms.Stop(); }
+    std::this_thread::sleep_for(20ms);
+    CHECK(threads() <= before);
+}
+
+TEST(TestSerializers) // graphite_test.go / opentsdb_test.go shape + exact line format
+{
+    ProcessedMetricSet pm;
+    pm.Time = std::chrono::system_clock::time_point(std::chrono::seconds(1418352105));
+    pm.Metrics["some_ipc_99.9"] = 1001.25;
+    const std::string g = GraphiteProtocol(pm), o = OpenTSDBProtocol(pm);
+    CHECK(g.rfind("cockroach.", 0) == 0 && g.find(".some.ipc.99.9 1001.250000 1418352105\n") != std::string::npos);
+    CHECK(o.rfind("put some_ipc_99.9 1418352105 1001.250000 host=", 0) == 0 && o.back() == '\n');
+}
+
+// ---- histogram paths: need the GPU ---------------------------------------------------------------
+TEST(TestTimer) // metrics_test.go:183-200
+{
+    MetricSystem ms(1us, false);
+    auto t1 = ms.StartTimer("timer1");
+    auto t2 = ms.StartTimer("timer1");
+    std::this_thread::sleep_for(50us);
+    t1.Stop();
+    std::this_thread::sleep_for(5us);
+    t2.Stop();
+    auto t3 = ms.StartTimer("timer1");
+    std::this_thread::sleep_for(10us);
+    t3.Stop();
+    auto r = ms.processMetrics(ms.collectRawMetrics())->Metrics;
+    CHECK(ms.engine_ready());
+    CHECK(r["timer1_count"] == 3);
+    CHECK(!(r["timer1_min"] > r["timer1_50"] || r["timer1_50"] > r["timer1_max"]));
+}
+
+TEST(TestProcessedBroadcast) // metrics_test.go:289-319
+{
+    auto ch = std::make_shared<ProcCh>(128);
+    MetricSystem ms(1ms, false);
+    ms.SubscribeToProcessedMetrics(ch);
+    ms.Histogram("histogram1", 33);
+    ms.Histogram("histogram1", 59);
+    ms.Histogram("histogram1", 330000);
+    ms.Start();
+    std::shared_ptr<ProcessedMetricSet> pm;
+    CHECK(ch->Receive(pm, 5s));
+    if (pm) {
+        CHECK((int)pm->Metrics["histogram1_sum"] == 331132);
+        CHECK((int)pm->Metrics["histogram1_agg_avg"] == 110377);
+        CHECK((int)pm->Metrics["histogram1_count"] == 3);
+    }
+    ms.UnsubscribeFromProcessedMetrics(ch);
+    ms.Stop();
+}
+
+TEST(ExampleMetricSystem) // metrics_test.go:28-109: presence of the documented keys
+{
+    auto ch = std::make_shared<ProcCh>(2);
+    MetricSystem ms(2ms, true);
+    ms.SubscribeToProcessedMetrics(ch);
+    ms.RegisterGaugeFunc("gauge", [] { return 33.0; });
+    auto tok = ms.StartTimer("submit_metrics");
+    ms.Counter("range_splits", 1);
+    ms.Histogram("some_ipc", 123);
+    tok.Stop();
+    ms.Start();
+    std::shared_ptr<ProcessedMetricSet> pm;
+    CHECK(ch->Receive(pm, 5s));
+    if (pm) {
+        for (const char *k : {"range_splits", "range_splits_rate", "some_ipc_99.9", "some_ipc_max", "some_ipc_count",
+                              "some_ipc_agg_count", "some_ipc_sum", "some_ipc_avg", "some_ipc_agg_avg",
+                              "submit_metrics_sum", "sys.NumGoroutine", "sys.PauseTotalNs", "gauge"})
+            CHECK(pm->Metrics.count(k));
+        CHECK(pm->Metrics["some_ipc_count"] == 1);
+        CHECK(std::fabs(pm->Metrics["some_ipc_max"] / 123 - 1) < 0.01);
+        CHECK(pm->Metrics["some_ipc_max"] == 122.96509077982394); // decompress(482), bit-exact
+    }
+    ms.Stop();
+}
+
+TEST(TestRawHistogramsAndInvalidPercentile)
+{
+    MetricSystem ms(1us, false);
+    ms.SpecifyPercentiles({{"%s_p50", 0.5}, {"%s_bad", 1.5}});
+    for (double v : {33.0, 59.0, 330000.0, 33.0}) ms.Histogram("h", v);
+    auto raw = ms.collectRawMetrics();
+    auto &h = raw->Histograms();
+    CHECK(h.count("h") && h.at("h").size() == 3);
+    if (h.count("h")) {
+        CHECK(h.at("h").at(353) == 2 && h.at("h").at(409) == 1 && h.at("h").at(1271) == 1); // compress keys
+    }
+    auto m = ms.processMetrics(raw)->Metrics;
+    CHECK(m.count("h_p50") && !m.count("h_bad")); // metrics.go:379-384: error logged, key omitted
+    CHECK(m["h_p50"] == 33.123967614754356);      // decompress(353)
+    // next interval: "h" received nothing -> absent, like a name missing from histogramCache
+    ms.Histogram("other", 1.0);
+    m = ms.processMetrics(ms.collectRawMetrics())->Metrics;
+    CHECK(!m.count("h_count") && m["other_count"] == 1);
+}
+
+TEST(TestProducersAreLosslessAcrossIntervals)
+{
+    // a sample belongs to exactly one interval (metrics.go:460-463): many producers, the collector
+    // flipping concurrently; the per-interval counts must add up to exactly what was submitted
+    MetricSystem ms(1us, false);
+    const int T = 8, N = 200000;
+    std::atomic<bool> done{false};
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++)
+        th.emplace_back([&] {
+            for (int i = 0; i < N; i++) {
+                ms.Histogram(i % 3 ? "a" : "b", 100.0 + i % 977);
+                if (i % 5 == 0) ms.Counter("ev", 1);
+            }
+        });
+    double total = 0, ev = 0;
+    std::thread collector([&] {
+        while (!done.load()) {
+            auto raw = ms.collectRawMetrics();
+            auto m = ms.processMetrics(raw)->Metrics;
+            raw->Release();
+            total += (m.count("a_count") ? m["a_count"] : 0) + (m.count("b_count") ? m["b_count"] : 0);
+            ev += m.count("ev_rate") ? m["ev_rate"] : 0;
+            std::this_thread::sleep_for(2ms);
+        }
+    });
+    for (auto &x : th) x.join();
+    done.store(true);
+    collector.join();
+    auto raw = ms.collectRawMetrics();
+    auto m = ms.processMetrics(raw)->Metrics;
+    total += (m.count("a_count") ? m["a_count"] : 0) + (m.count("b_count") ? m["b_count"] : 0);
+    ev += m.count("ev_rate") ? m["ev_rate"] : 0;
+    CHECK(total == (double)T * N);
+    CHECK(ev == (double)T * (N / 5));
+    CHECK(m["ev"] == (double)T * (N / 5)); // lifetime counter
+    CHECK(ms.last_status() == 0 || ms.last_status() == 5 /* LH_EBUSY is benign here */);
+}
+
+int main(int argc, char **argv)
+{
+    const bool cpu_only = argc > 1 && !std::strcmp(argv[1], "--cpu");
+    RUN(TestRate);
+    RUN(TestCounter);
+    RUN(TestCounterManyThreads);
+    RUN(TestSysStats);
+    RUN(TestRawBroadcast);
+    RUN(TestUpdateSubscribers);
+    RUN(TestSlowSubscriberIsDropped);
+    RUN(TestMetricSystemStop);
+    RUN(TestSerializers);
+    if (!cpu_only) {
+        RUN(TestTimer);
+        RUN(TestProcessedBroadcast);
+        RUN(ExampleMetricSystem);
+        RUN(TestRawHistogramsAndInvalidPercentile);
+        RUN(TestProducersAreLosslessAcrossIntervals);
+    }
+    std::printf("%d checks, %d failed tests\n", g_checks, g_failed);
+    return g_failed;
+}
