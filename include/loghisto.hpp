@@ -189,8 +189,8 @@ private:
     std::shared_mutex histogram_mu_;
     std::mutex stages_mu_;
     std::vector<std::unique_ptr<Stage>> stages_;
-    std::atomic<bool> hist_used_{false};
-    uint64_t instance_id_;
+    alignas(64) std::atomic<bool> hist_used_{false}; // own cache line: written once, read by every producer
+    alignas(64) uint64_t instance_id_;
 
     std::mutex names_mu_;
     std::vector<std::string> names_;
@@ -221,7 +221,7 @@ private:
     std::mutex shutdown_mu_;
     std::condition_variable shutdown_cv_;
     std::thread reaper_thread_;
-    std::atomic<int> last_status_{0};
+    alignas(64) std::atomic<int> last_status_{0};
     std::atomic<uint64_t> dropped_intervals_{0};
 };
 

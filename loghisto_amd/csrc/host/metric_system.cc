@@ -259,7 +259,8 @@ void MetricSystem::Histogram(const std::string &name, double value)
     }
     st->ids[st->n] = id;
     st->vals[st->n] = value; // compress() happens on the GPU
-    hist_used_.store(true, std::memory_order_relaxed);
+    // read-mostly: an unconditional store here would bounce one cache line between every producer core
+    if (!hist_used_.load(std::memory_order_relaxed)) hist_used_.store(true, std::memory_order_relaxed);
     if (++st->n == st->ids.size()) ship(*st);
 }
 
