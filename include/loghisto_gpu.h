@@ -136,6 +136,12 @@ int lh_extract_rows(lh_snapshot *s, uint32_t first, size_t nmetrics, const doubl
 /* Occupied cells of one metric, ascending key. *n receives the number of
  * occupied cells even when it exceeds cap. */
 int lh_buckets(lh_snapshot *s, uint32_t id, int16_t *keys, uint64_t *counts, size_t cap, size_t *n);
+/* The same for metrics [first, first+nmetrics) at once, compacted on the device: CSR arrays with
+ * offsets[nmetrics+1]; metric first+i owns keys/counts[offsets[i] .. offsets[i+1]).  *total receives
+ * the number of occupied cells; if it exceeds cap only offsets/total are filled (size and call again).
+ * This is RawMetricSet.Histograms (metrics.go:54-60) for every name in one crossing. */
+int lh_buckets_all(lh_snapshot *s, uint32_t first, size_t nmetrics, uint64_t *offsets, int16_t *keys,
+                   uint64_t *counts, size_t cap, size_t *total);
 /* Dense device view of the snapshot for the multi-GPU merge: row r of metric r
  * is d_counts + r*65536 (uint64).  After an in-place reduction the caller must
  * call lh_snapshot_mark_dirty so that extract/clear cover the merged cells. */

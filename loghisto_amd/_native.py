@@ -56,6 +56,7 @@ SIGNATURES = {
     "lh_extract": (C.c_int, [_vp, _dp, _sz, C.POINTER(LhStats), _dp, _i16p, _u8p, _sz]),
     "lh_extract_rows": (C.c_int, [_vp, C.c_uint32, _sz, _dp, _sz, C.POINTER(LhStats), _dp, _i16p, _u8p]),
     "lh_buckets": (C.c_int, [_vp, C.c_uint32, _i16p, _u64p, _sz, C.POINTER(_sz)]),
+    "lh_buckets_all": (C.c_int, [_vp, C.c_uint32, _sz, _u64p, _i16p, _u64p, _sz, C.POINTER(_sz)]),
     "lh_snapshot_rows": (C.c_int, [_vp, C.POINTER(_vp), _u32p]),
     "lh_snapshot_ranges": (C.c_int, [_vp, C.POINTER(_vp)]),
     "lh_snapshot_mark_dirty": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),

@@ -90,18 +90,19 @@ const std::unordered_map<std::string, std::map<int16_t, uint64_t>> &RawMetricSet
     if (hist_ready) return hist;
     hist_ready = true;
     if (!snapshot || names.empty()) return hist;
-    std::vector<lh_stats> st(names.size());
-    if (lh_extract(snapshot, nullptr, 0, st.data(), nullptr, nullptr, nullptr, names.size()) != LH_OK) return hist;
-    std::vector<int16_t> keys;
-    std::vector<uint64_t> counts;
-    for (size_t id = 0; id < names.size(); id++) {
-        if (!st[id].present) continue; // the name has no map entry this interval
-        keys.resize(st[id].nbuckets);
-        counts.resize(st[id].nbuckets);
-        size_t n = 0;
-        if (lh_buckets(snapshot, (uint32_t)id, keys.data(), counts.data(), keys.size(), &n) != LH_OK) continue;
+    // one crossing for every name: device-compacted CSR listing of the occupied cells
+    const size_t n = names.size();
+    std::vector<uint64_t> offsets(n + 1);
+    size_t total = 0;
+    if (lh_buckets_all(snapshot, 0, n, offsets.data(), nullptr, nullptr, 0, &total) != LH_OK) return hist;
+    std::vector<int16_t> keys(total);
+    std::vector<uint64_t> counts(total);
+    if (total && lh_buckets_all(snapshot, 0, n, offsets.data(), keys.data(), counts.data(), total, &total) != LH_OK)
+        return hist;
+    for (size_t id = 0; id < n; id++) {
+        if (offsets[id] == offsets[id + 1]) continue; // the name has no map entry this interval
         auto &m = hist[names[id]];
-        for (size_t i = 0; i < std::min(n, keys.size()); i++) m[keys[i]] = counts[i];
+        for (uint64_t i = offsets[id]; i < offsets[id + 1]; i++) m.emplace_hint(m.end(), keys[i], counts[i]);
     }
     return hist;
 }

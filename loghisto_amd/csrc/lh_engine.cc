@@ -123,8 +123,6 @@ struct lh_engine {
     unsigned char *d_xbuf = nullptr;
     unsigned char *h_xbuf = nullptr;
     size_t xbuf_bytes = 0;
-    double *d_p = nullptr;
-    double *h_p = nullptr;
 
     std::atomic<int> live_snapshots{0};
 
@@ -274,8 +272,6 @@ void free_engine(lh_engine *e)
     if (e->d_err) (void)hipFree(e->d_err);
     if (e->d_xbuf) (void)hipFree(e->d_xbuf);
     if (e->h_xbuf) (void)hipHostFree(e->h_xbuf);
-    if (e->d_p) (void)hipFree(e->d_p);
-    if (e->h_p) (void)hipHostFree(e->h_p);
     if (e->main_stream) (void)hipStreamDestroy(e->main_stream);
     if (e->xstream) (void)hipStreamDestroy(e->xstream);
     delete e;
@@ -325,8 +321,6 @@ int create_impl(const lh_config *cfg_in, lh_engine *e)
     HIPCHK(hipMalloc((void **)&e->d_err, 8));
     HIPCHK(hipMemsetAsync(e->d_err, 0, 8, e->xstream));
     HIPCHK(lh::launch_gen_tables(e->d_Tx, e->d_D, e->xstream));
-    HIPCHK(hipMalloc((void **)&e->d_p, sizeof(double) * LH_MAX_PERCENTILES));
-    HIPCHK(hipHostMalloc((void **)&e->h_p, sizeof(double) * LH_MAX_PERCENTILES, hipHostMallocDefault));
 
     const size_t M = e->cfg.max_metrics;
     e->bufs.resize(e->cfg.num_buffers);
@@ -659,17 +653,12 @@ int lh_extract_rows(lh_snapshot *s, uint32_t first, size_t nmetrics, const doubl
     rc = ensure_xbuf(e, L.total);
     if (rc) return rc;
     EpochBuffer &b = e->bufs[(size_t)s->buf];
-    if (np) {
-        std::memcpy(e->h_p, p, np * sizeof(double));
-        HIPCHK(hipMemcpyAsync(e->d_p, e->h_p, np * sizeof(double), hipMemcpyHostToDevice, e->xstream));
-    }
     HIPCHK(lh::launch_extract(b.counts + (size_t)first * LH_NKEYS, b.ranges + 2 * (size_t)first,
-                              (uint32_t)nmetrics, e->d_p, (uint32_t)np, e->d_D,
+                              (uint32_t)nmetrics, p, (uint32_t)np, e->d_D,
                               reinterpret_cast<lh::ExtractOut *>(e->d_xbuf + L.off_stats),
                               reinterpret_cast<double *>(e->d_xbuf + L.off_pvals),
                               reinterpret_cast<int16_t *>(e->d_xbuf + L.off_pkeys), e->d_xbuf + L.off_pvalid,
-                              e->xstream));
-    HIPCHK(hipMemcpyAsync(e->d_xbuf + L.off_err, e->d_err, 4, hipMemcpyDeviceToDevice, e->xstream));
+                              e->d_err, reinterpret_cast<uint32_t *>(e->d_xbuf + L.off_err), e->xstream));
     HIPCHK(hipMemcpyAsync(e->h_xbuf, e->d_xbuf, L.total, hipMemcpyDeviceToHost, e->xstream));
     HIPCHK(hipStreamSynchronize(e->xstream));
     std::memcpy(stats, e->h_xbuf + L.off_stats, nmetrics * sizeof(lh_stats));
@@ -697,8 +686,11 @@ int lh_buckets(lh_snapshot *s, uint32_t id, int16_t *keys, uint64_t *counts, siz
     std::lock_guard<std::mutex> g(e->xmu);
     EpochBuffer &b = e->bufs[(size_t)s->buf];
     uint32_t r[2];
-    HIPCHK(hipMemcpyAsync(r, b.ranges + 2 * (size_t)id, sizeof(r), hipMemcpyDeviceToHost, e->xstream));
+    rc = ensure_xbuf(e, 64);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(e->h_xbuf, b.ranges + 2 * (size_t)id, sizeof(r), hipMemcpyDeviceToHost, e->xstream));
     HIPCHK(hipStreamSynchronize(e->xstream));
+    std::memcpy(r, e->h_xbuf, sizeof(r));
     *n = 0;
     if (r[0] > r[1]) return LH_OK;
     const size_t span = (size_t)r[1] - r[0] + 1;
@@ -718,6 +710,58 @@ int lh_buckets(lh_snapshot *s, uint32_t id, int16_t *keys, uint64_t *counts, siz
         k++;
     }
     *n = k;
+    return LH_OK;
+}
+
+int lh_buckets_all(lh_snapshot *s, uint32_t first, size_t nmetrics, uint64_t *offsets, int16_t *keys,
+                   uint64_t *counts, size_t cap, size_t *total)
+{
+    if (!s || !offsets || !total || (cap && (!keys || !counts))) return LH_EINVAL;
+    lh_engine *e = s->e;
+    if ((uint64_t)first + nmetrics > e->cfg.max_metrics) return LH_EINVAL;
+    *total = 0;
+    offsets[0] = 0;
+    if (nmetrics == 0) return LH_OK;
+    int rc = use_device(e);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(e->xmu);
+    EpochBuffer &b = e->bufs[(size_t)s->buf];
+    const uint64_t *rows = b.counts + (size_t)first * LH_NKEYS;
+    const uint32_t *rng = b.ranges + 2 * (size_t)first;
+    // pass 1: occupied cells per row
+    const size_t off_bytes = (nmetrics + 1) * sizeof(uint64_t);
+    rc = ensure_xbuf(e, off_bytes + nmetrics * sizeof(uint32_t));
+    if (rc) return rc;
+    uint32_t *d_nc = reinterpret_cast<uint32_t *>(e->d_xbuf + off_bytes);
+    HIPCHK(lh::launch_count_cells(rows, rng, (uint32_t)nmetrics, d_nc, e->xstream));
+    HIPCHK(hipMemcpyAsync(e->h_xbuf + off_bytes, d_nc, nmetrics * sizeof(uint32_t), hipMemcpyDeviceToHost, e->xstream));
+    HIPCHK(hipStreamSynchronize(e->xstream));
+    const uint32_t *h_nc = reinterpret_cast<const uint32_t *>(e->h_xbuf + off_bytes);
+    uint64_t run = 0;
+    for (size_t i = 0; i < nmetrics; i++) {
+        offsets[i] = run;
+        run += h_nc[i];
+    }
+    offsets[nmetrics] = run;
+    *total = (size_t)run;
+    if (run == 0 || run > cap) return LH_OK; // caller sizes its arrays from *total and calls again
+    // pass 2: compaction at the prefix offsets
+    const size_t keys_off = (off_bytes + 15) & ~size_t(15);
+    const size_t vals_off = (keys_off + run * sizeof(int16_t) + 15) & ~size_t(15);
+    const size_t need = vals_off + run * sizeof(uint64_t);
+    std::vector<uint64_t> keep(offsets, offsets + nmetrics + 1); // ensure_xbuf may reallocate the staging
+    rc = ensure_xbuf(e, need);
+    if (rc) return rc;
+    std::memcpy(e->h_xbuf, keep.data(), off_bytes);
+    HIPCHK(hipMemcpyAsync(e->d_xbuf, e->h_xbuf, off_bytes, hipMemcpyHostToDevice, e->xstream));
+    HIPCHK(lh::launch_compact_cells(rows, rng, (uint32_t)nmetrics, reinterpret_cast<const uint64_t *>(e->d_xbuf),
+                                    reinterpret_cast<int16_t *>(e->d_xbuf + keys_off),
+                                    reinterpret_cast<uint64_t *>(e->d_xbuf + vals_off), e->xstream));
+    HIPCHK(hipMemcpyAsync(e->h_xbuf + keys_off, e->d_xbuf + keys_off, need - keys_off, hipMemcpyDeviceToHost,
+                          e->xstream));
+    HIPCHK(hipStreamSynchronize(e->xstream));
+    std::memcpy(keys, e->h_xbuf + keys_off, run * sizeof(int16_t));
+    std::memcpy(counts, e->h_xbuf + vals_off, run * sizeof(uint64_t));
     return LH_OK;
 }
 

@@ -38,8 +38,15 @@ hipError_t launch_ingest_pairs_part(const uint32_t *d_ids, const double *d_v, si
 
 // K2: extract.  One workgroup per metric.
 hipError_t launch_extract(const uint64_t *counts, const uint32_t *ranges, uint32_t nmetrics,
-                          const double *d_p, uint32_t np, const double *d_D, ExtractOut *out,
-                          double *pvals, int16_t *pkeys, uint8_t *pvalid, hipStream_t s);
+                          const double *h_p /* host */, uint32_t np, const double *d_D, ExtractOut *out,
+                          double *pvals, int16_t *pkeys, uint8_t *pvalid, const uint32_t *err_in,
+                          uint32_t *err_out, hipStream_t s);
+
+// K5: occupied cells of every row as CSR arrays (ascending key within a row).
+hipError_t launch_count_cells(const uint64_t *counts, const uint32_t *ranges, uint32_t nmetrics, uint32_t *ncells,
+                              hipStream_t s);
+hipError_t launch_compact_cells(const uint64_t *counts, const uint32_t *ranges, uint32_t nmetrics,
+                                const uint64_t *offsets, int16_t *keys, uint64_t *vals, hipStream_t s);
 
 // K3: clear the dirty span of every row and reset the ranges.
 hipError_t launch_clear(uint64_t *counts, uint32_t *ranges, uint32_t nmetrics, hipStream_t s);

@@ -281,13 +281,17 @@ __device__ __forceinline__ double shfl_down_f64(double x, int d)
     return __longlong_as_double((long long)shfl_down_u64((uint64_t)__double_as_longlong(x), d));
 }
 
+struct PctArgs { double p[K2_MAXP]; }; // percentile list by value: no H2D copy on the extract path
+
 __global__ __launch_bounds__(K2_BLOCK) void k_extract(const uint64_t *__restrict__ counts,
                                                       const uint32_t *__restrict__ ranges,
-                                                      const double *__restrict__ p, uint32_t np,
+                                                      const PctArgs pa, uint32_t np,
                                                       const double *__restrict__ D,
                                                       ExtractOut *__restrict__ out,
                                                       double *__restrict__ pvals, int16_t *__restrict__ pkeys,
-                                                      uint8_t *__restrict__ pvalid)
+                                                      uint8_t *__restrict__ pvalid,
+                                                      const uint32_t *__restrict__ err_in,
+                                                      uint32_t *__restrict__ err_out)
 {
     __shared__ uint64_t s_cnt[K2_WAVES];
     __shared__ double s_sum[K2_WAVES];
@@ -302,8 +306,9 @@ __global__ __launch_bounds__(K2_BLOCK) void k_extract(const uint64_t *__restrict
 
     if (tid < K2_MAXP) {
         s_found[tid] = 0xffffffffu;
-        s_p[tid] = tid < np ? p[tid] : 2.0;
+        s_p[tid] = tid < np ? pa.p[tid] : 2.0;
     }
+    if (blockIdx.x == 0 && tid == 0) *err_out = *err_in; // sticky bad-id flag rides along with the results
 
     // ---- pass 1: totalCount, totalSum, occupied buckets (metrics.go:342-347)
     uint64_t cnt = 0;
@@ -412,12 +417,89 @@ __global__ __launch_bounds__(K2_BLOCK) void k_extract(const uint64_t *__restrict
 }
 
 hipError_t launch_extract(const uint64_t *counts, const uint32_t *ranges, uint32_t nmetrics,
-                          const double *d_p, uint32_t np, const double *d_D, ExtractOut *out,
-                          double *pvals, int16_t *pkeys, uint8_t *pvalid, hipStream_t s)
+                          const double *h_p, uint32_t np, const double *d_D, ExtractOut *out,
+                          double *pvals, int16_t *pkeys, uint8_t *pvalid, const uint32_t *err_in,
+                          uint32_t *err_out, hipStream_t s)
 {
     if (nmetrics == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_extract, dim3(nmetrics), dim3(K2_BLOCK), 0, s, counts, ranges, d_p, np, d_D, out,
-                       pvals, pkeys, pvalid);
+    PctArgs pa;
+    for (uint32_t i = 0; i < (uint32_t)K2_MAXP; i++) pa.p[i] = i < np ? h_p[i] : 2.0;
+    hipLaunchKernelGGL(k_extract, dim3(nmetrics), dim3(K2_BLOCK), 0, s, counts, ranges, pa, np, d_D, out,
+                       pvals, pkeys, pvalid, err_in, err_out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// K5 occupied-cell listing (RawMetricSet.Histograms, metrics.go:54-60): the sparse
+// map[int16]*uint64 of every name, as CSR arrays, compacted on the device.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_count_cells(const uint64_t *__restrict__ counts,
+                                                     const uint32_t *__restrict__ ranges,
+                                                     uint32_t *__restrict__ ncells)
+{
+    __shared__ uint32_t s_n;
+    const uint32_t m = blockIdx.x;
+    const uint32_t lo = ranges[2 * (size_t)m], hi = ranges[2 * (size_t)m + 1];
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    uint32_t n = 0;
+    if (lo <= hi) {
+        const uint64_t *row = counts + (size_t)m * LH_NKEYS;
+        for (uint32_t b = lo + threadIdx.x; b <= hi; b += 256) n += row[b] != 0;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) n += __shfl_down(n, d, 64);
+    if ((threadIdx.x & 63) == 0 && n) atomicAdd(&s_n, n);
+    __syncthreads();
+    if (threadIdx.x == 0) ncells[m] = s_n;
+}
+
+__global__ __launch_bounds__(256) void k_compact_cells(const uint64_t *__restrict__ counts,
+                                                       const uint32_t *__restrict__ ranges,
+                                                       const uint64_t *__restrict__ offsets,
+                                                       int16_t *__restrict__ keys, uint64_t *__restrict__ vals)
+{
+    __shared__ uint32_t s_w[4];
+    const uint32_t m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t lo = ranges[2 * (size_t)m], hi = ranges[2 * (size_t)m + 1];
+    if (lo > hi) return;
+    const uint64_t *row = counts + (size_t)m * LH_NKEYS;
+    uint64_t base = offsets[m];
+    for (uint32_t t0 = lo; t0 <= hi; t0 += 256) { // ascending bin == ascending key
+        const uint32_t b = t0 + tid;
+        const uint64_t c = b <= hi ? row[b] : 0;
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(c != 0);
+        const uint32_t below = (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        __syncthreads(); // s_w reuse
+        if (lane == 0) s_w[wave] = (uint32_t)__builtin_popcountll(mask);
+        __syncthreads();
+        uint32_t wbase = 0, tile = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            if (w < (int)wave) wbase += s_w[w];
+            tile += s_w[w];
+        }
+        if (c) {
+            keys[base + wbase + below] = (int16_t)bin_to_key(b);
+            vals[base + wbase + below] = c;
+        }
+        base += tile;
+    }
+}
+
+hipError_t launch_count_cells(const uint64_t *counts, const uint32_t *ranges, uint32_t nmetrics, uint32_t *ncells,
+                              hipStream_t s)
+{
+    if (nmetrics == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_count_cells, dim3(nmetrics), dim3(256), 0, s, counts, ranges, ncells);
+    return hipGetLastError();
+}
+
+hipError_t launch_compact_cells(const uint64_t *counts, const uint32_t *ranges, uint32_t nmetrics,
+                                const uint64_t *offsets, int16_t *keys, uint64_t *vals, hipStream_t s)
+{
+    if (nmetrics == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_compact_cells, dim3(nmetrics), dim3(256), 0, s, counts, ranges, offsets, keys, vals);
     return hipGetLastError();
 }
 

@@ -70,7 +70,10 @@ static bool make_plan(size_t n, uint32_t nmetrics, int num_cus, PartPlan &P)
     P.log_w = lw; // window = 2^log_w bins per name, mpp * window <= 16384
     const size_t ntiles = (n + P1_TILE - 1) / P1_TILE;
     size_t g1 = (size_t)num_cus * 3; // ~44 KiB LDS per workgroup: three 512-thread workgroups per CU
-    if (g1 > ntiles) g1 = ntiles;
+    // every workgroup strands up to NP partially filled chunks (1 MiB at NP = 256): give a workgroup
+    // at least 8 tiles so that a lane-sized launch (1M samples) needs ~33 MB of scratch, not ~270 MB
+    if (g1 > (ntiles + 7) / 8) g1 = (ntiles + 7) / 8;
+    if (g1 < 1) g1 = 1;
     P.g1 = (uint32_t)g1;
     const size_t tiles_per_wg = (ntiles + g1 - 1) / g1;
     P.chunks_per_wg = (uint32_t)(tiles_per_wg * (P1_TILE / CHUNK) + P.np + 1);

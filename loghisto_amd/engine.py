@@ -76,6 +76,21 @@ class Snapshot:
                                  counts.ctypes.data_as(C.POINTER(C.c_uint64)), n.value, C.byref(n)), "lh_buckets")
         return keys, counts
 
+    def buckets_all(self, nmetrics: int, first: int = 0):
+        """CSR listing of the occupied cells of metrics [first, first+nmetrics): (offsets, keys, counts)."""
+        L = N.lib()
+        offsets = np.zeros(nmetrics + 1, dtype=np.uint64)
+        total = C.c_size_t(0)
+        op = offsets.ctypes.data_as(C.POINTER(C.c_uint64))
+        N.check(L.lh_buckets_all(self._h, first, nmetrics, op, None, None, 0, C.byref(total)), "lh_buckets_all")
+        keys = np.zeros(total.value, dtype=np.int16)
+        counts = np.zeros(total.value, dtype=np.uint64)
+        if total.value:
+            N.check(L.lh_buckets_all(self._h, first, nmetrics, op, keys.ctypes.data_as(C.POINTER(C.c_int16)),
+                                     counts.ctypes.data_as(C.POINTER(C.c_uint64)), total.value, C.byref(total)),
+                    "lh_buckets_all")
+        return offsets, keys, counts
+
     def dense_row(self, metric_id: int) -> np.ndarray:
         """Dense uint64[65536] row (bin = key ^ 0x8000) rebuilt from lh_buckets."""
         keys, counts = self.buckets(metric_id)

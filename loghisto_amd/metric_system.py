@@ -64,11 +64,11 @@ class RawMetricSet:  # metrics.go:54-60
         if self._hist is None:
             self._hist = {}
             if self._snapshot is not None:
-                present = self._snapshot.extract([], len(self._names))["present"] if self._names else []
+                offsets, keys, counts = self._snapshot.buckets_all(len(self._names))
                 for mid, name in enumerate(self._names):
-                    if present[mid]:
-                        keys, counts = self._snapshot.buckets(mid)
-                        self._hist[name] = {int(k): int(c) for k, c in zip(keys, counts)}
+                    lo, hi = int(offsets[mid]), int(offsets[mid + 1])
+                    if hi > lo:
+                        self._hist[name] = {int(k): int(c) for k, c in zip(keys[lo:hi], counts[lo:hi])}
         return self._hist
 
     def release(self):
