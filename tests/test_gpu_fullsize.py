@@ -29,6 +29,9 @@ def test_c2_one_billion_samples(native_lib, torch_cuda):
     g = torch.Generator(device="cuda")
     g.manual_seed(2)
     data = torch.randn(n, dtype=torch.float64, device="cuda", generator=g).add_(math.log(1e5)).exp_()
+    # the generator kernels run asynchronously on torch's stream; submit_device(stream=None) runs on the
+    # engine's own non-blocking stream, so the producer must be finished first (lh_submit_device contract)
+    torch.cuda.synchronize()
     with loghisto_amd.Engine(max_metrics=2, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as eng:
         eng.submit_device(0, data)
         with eng.flip() as snap:
