@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-flips", type=int, default=1000)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3"],
+                    help="c2 (default, the headline): one metric; c3: 1024 Zipf names, (id, value) stream")
+    ap.add_argument("--names", type=int, default=1024, help="histogram names for --workload c3")
     return ap.parse_args()
 
 
@@ -113,8 +116,18 @@ def main():
     from loghisto_amd import merge
 
     n = int(args.samples)
-    eng = loghisto_amd.Engine(device=local_rank, max_metrics=1, num_buffers=2, num_lanes=1, lane_samples=1 << 16)
-    data = make_samples(n, args.dist, seed=2 + rank)
+    c3 = args.workload == "c3"
+    M = args.names if c3 else 1
+    bytes_per_sample = 12 if c3 else BYTES_PER_SAMPLE       # float64 + uint32 id for mixed streams
+    eng = loghisto_amd.Engine(device=local_rank, max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16)
+    data = make_samples(n, args.dist, seed=(3 if c3 else 2) + rank)
+    ids = None
+    if c3:  # id ~ Zipf(1.0) over ranks, value ~ lognormal(ln 1e5 + 0.002*id, 1)
+        g = torch.Generator(device="cuda")
+        g.manual_seed(1003 + rank)
+        w = 1.0 / torch.arange(1, M + 1, dtype=torch.float64, device="cuda")
+        ids = torch.multinomial(w / w.sum(), n, replacement=True, generator=g).to(torch.int32)
+        data.mul_(torch.exp(0.002 * ids.to(torch.float64)))
     torch.cuda.synchronize()
     # a non-default stream: the default stream's handle is 0, which the C ABI reads as
     # "use the engine's own stream" and torch events would then not bracket the kernel
@@ -127,14 +140,17 @@ def main():
         if timed:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(stream)
-        eng.submit_device(0, data, n, stream=stream)          # K1 on torch's current stream
+        if c3:
+            eng.submit_pairs_device(ids, data, n, stream=stream)   # P1 + plan + P2 on torch's current stream
+        else:
+            eng.submit_device(0, data, n, stream=stream)       # K1 on torch's current stream
         if timed:
             b.record(stream)
             k1_events.append((a, b))
         snap = eng.flip()
         if world > 1:
-            merge.merge_snapshot(snap, 1, plan="allreduce")
-        out = snap.extract(PCTS, 1)                            # K2 + D2H + sync
+            merge.merge_snapshot(snap, M, plan="allreduce")
+        out = snap.extract(PCTS, M)                            # K2 + D2H + sync
         snap.release()                                         # K3 (async)
         return out
 
@@ -157,10 +173,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    assert int(out["count"][0]) == n * world, (int(out["count"][0]), n, world)
+    assert int(out["count"].sum()) == n * world, (int(out["count"].sum()), n, world)
     k1_ms = [a.elapsed_time(b) for a, b in k1_events]
     k1_avg_ms = sum(k1_ms) / len(k1_ms)
-    achieved = n * BYTES_PER_SAMPLE / (k1_avg_ms * 1e-3) / 1e9
+    achieved = n * bytes_per_sample / (k1_avg_ms * 1e-3) / 1e9
 
     # p99 extract latency: flip -> stats on host (BASELINE.json metric, part 2)
     lat = []
@@ -170,7 +186,7 @@ def main():
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         snap = eng.flip()
-        snap.extract(PCTS, 1)
+        snap.extract(PCTS, M)
         lat.append(time.perf_counter() - t1)
         snap.release()
     lat_us = np.array(lat) * 1e6 if lat else np.array([float("nan")])
@@ -186,7 +202,7 @@ def main():
                 # as the microarch guide prescribes; see the JSON's "corrections").  It only
                 # applies to the workload it was measured on.
                 j = json.load(open(pmc))
-                if n * BYTES_PER_SAMPLE == int(j["algorithmic_bytes_per_launch"]) and args.dist == "lognormal":
+                if not c3 and n * BYTES_PER_SAMPLE == int(j["algorithmic_bytes_per_launch"]) and args.dist == "lognormal":
                     traffic = j["hbm_read_bytes_per_launch"] + j["hbm_write_bytes_per_launch"]
             except Exception:
                 traffic = None
@@ -196,17 +212,20 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C2 single-metric float64 stream, one ingest kernel + one percentile scan per step",
-                       "samples_per_gpu_per_step": n, "distribution": args.dist, "metrics": 1,
+            "config": {"workload": ("C3 mixed (uint32 id, float64 value) stream over Zipf(1.0) names, partitioned ingest + "
+                                    "one percentile scan per name per step") if c3 else
+                                   "C2 single-metric float64 stream, one ingest kernel + one percentile scan per step",
+                       "samples_per_gpu_per_step": n, "distribution": args.dist, "metrics": M,
                        "percentiles": PCTS, "merge": "allreduce(uint64 row) at flip" if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "kernel": "k_ingest_single", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_part_scatter+k_plan_*+k_part_hist" if c3 else "k_ingest_single",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": n * BYTES_PER_SAMPLE, "avg_launch_ms": k1_avg_ms,
+                         "algorithmic_bytes_per_launch": n * bytes_per_sample, "avg_launch_ms": k1_avg_ms,
                          "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},
             "extract_latency_us": {"p50": float(np.percentile(lat_us, 50)), "p99": float(np.percentile(lat_us, 99)),
                                    "flips": len(lat)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not c3:
             cb, cpu_counts, ncpu = cpu_baseline(data, args.cpu_seconds)
             # the same samples through the GPU path must give the same row
             eng.submit_device(0, data[:ncpu], ncpu, stream=stream)
