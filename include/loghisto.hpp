@@ -57,7 +57,10 @@ public:
     bool Receive(T &out, std::chrono::nanoseconds timeout)
     {
         std::unique_lock<std::mutex> g(mu_);
-        if (!cv_.wait_for(g, timeout, [&] { return !q_.empty() || closed_; })) return false;
+        // system_clock deadline -> pthread_cond_timedwait (the steady-clock form, pthread_cond_clockwait,
+        // is not intercepted by GCC 11's ThreadSanitizer and floods it with false positives)
+        if (!cv_.wait_until(g, std::chrono::system_clock::now() + timeout, [&] { return !q_.empty() || closed_; }))
+            return false;
         if (q_.empty()) return false;
         out = std::move(q_.front());
         q_.pop_front();

@@ -459,7 +459,10 @@ void broadcast(std::vector<Ch> &subs, std::unordered_map<void *, int> &bad, cons
 void MetricSystem::reaper()
 {
     // processing pool: a 16-deep hand-off, the interval is dropped when it is full (metrics.go:533-545, 630-637)
-    Channel<std::shared_ptr<RawMetricSet>> work(16);
+    // heap-allocated so that ThreadSanitizer sees a fresh mutex per reaper run (std::mutex has a trivial
+    // destructor; a stack slot reused by the next run looks like a double lock to it)
+    auto work_p = std::make_shared<Channel<std::shared_ptr<RawMetricSet>>>(16);
+    auto &work = *work_p;
     std::vector<std::thread> pool;
     const unsigned nworkers = std::max(4u, std::thread::hardware_concurrency() / 4);
     for (unsigned w = 0; w < std::min(nworkers, 8u); w++) {
@@ -482,7 +485,7 @@ void MetricSystem::reaper()
         const nanoseconds tts(ivl - now % ivl);
         {
             std::unique_lock<std::mutex> g(shutdown_mu_);
-            if (shutdown_cv_.wait_for(g, tts, [&] { return shutdown_.load(); })) break;
+            if (shutdown_cv_.wait_until(g, system_clock::now() + tts, [&] { return shutdown_.load(); })) break;
         }
         auto raw = collectRawMetrics();
         updateSubscribers();

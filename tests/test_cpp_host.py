@@ -42,3 +42,22 @@ def test_config5_driver_is_lossless(native_lib, torch_cuda):
     assert res["events_accounted"] == res["events_submitted"] > 1e7
     assert res["dropped_intervals"] == 0 and res["submit_failures"] == 0
     assert res["intervals_emitted"] >= 4 and res["graphite_lines"] == res["keys_emitted"]
+
+
+def test_cpp_host_layer_under_thread_sanitizer(native_lib, tmp_path):
+    """the host runtime is race-checked with ThreadSanitizer (host-only tests:
+    counters, subscriptions, reaper, channels; TSan cannot follow the HIP runtime's own threads)."""
+    out = str(tmp_path / "metrics_test_tsan")
+    lib_dir = os.path.join(ROOT, "loghisto_amd")
+    build = run(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread", "-I", os.path.join(ROOT, "include"),
+                 os.path.join(ROOT, "tests", "cpp", "metrics_test.cc"),
+                 os.path.join(lib_dir, "csrc", "host", "metric_system.cc"), "-o", out,
+                 "-L", lib_dir, "-llhgpu", "-Wl,-rpath," + lib_dir])
+    if build.returncode != 0 and "tsan" in build.stdout.lower():
+        pytest.skip("libtsan not available")
+    assert build.returncode == 0, build.stdout
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66")
+    r = subprocess.run([out, "--cpu"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=env)
+    print(r.stdout[-3000:])
+    assert "ThreadSanitizer" not in r.stdout, r.stdout[-3000:]
+    assert r.returncode == 0
