@@ -228,6 +228,38 @@ private:
     std::atomic<uint64_t> dropped_intervals_{0};
 };
 
+// submitter.go:27-159: subscribes a 60-deep channel, serialises every ProcessedMetricSet, keeps the last 60
+// requests in an evicting ring and (re)sends the backlog once per interval over a fresh TCP/UDP connection
+// with a 5 s deadline.  Pure host I/O downstream of the hot path; kept so that the API surface is whole.
+class Submitter {
+public:
+    using Serializer = std::function<std::string(const ProcessedMetricSet &)>;
+    // NewSubmitter(metricSystem, serializer, destinationNetwork ("tcp" | "udp"), destinationAddress "host:port")
+    Submitter(MetricSystem *ms, Serializer serializer, std::string network, std::string address,
+              std::chrono::nanoseconds interval);
+    ~Submitter();
+    void Start();
+    void Shutdown();
+    std::string DestinationNetwork, DestinationAddress;
+    uint64_t sent_requests() const { return sent_.load(); }
+    uint64_t evicted_requests() const { return evicted_.load(); }
+
+private:
+    bool submit(const std::string &request);
+    bool retryBacklog();
+    void appendToBacklog(std::string request);
+    MetricSystem *ms_;
+    Serializer serializer_;
+    std::chrono::nanoseconds interval_;
+    std::shared_ptr<Channel<std::shared_ptr<ProcessedMetricSet>>> chan_;
+    std::mutex backlog_mu_;
+    std::string backlog_[60];
+    int head_ = 0, tail_ = 0;
+    std::atomic<bool> shutdown_{false};
+    std::atomic<uint64_t> sent_{0}, evicted_{0};
+    std::thread recv_thread_, send_thread_;
+};
+
 // graphite.go:73 / opentsdb.go:83: "cockroach.<host>.<metric with _ -> .> %f %d\n" and
 // "put <metric> <unix> %f host=<host>\n".  Downstream text formatting; kept for config 5.
 std::string GraphiteProtocol(const ProcessedMetricSet &ms);

@@ -10,6 +10,10 @@
 #include "../../../include/loghisto.hpp"
 #include "../../../include/loghisto_gpu.h"
 
+#include <arpa/inet.h>
+#include <netdb.h>
+#include <sys/socket.h>
+#include <sys/time.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -524,6 +528,109 @@ void MetricSystem::Stop()
     }
     shutdown_cv_.notify_all();
     if (reaper_thread_.joinable()) reaper_thread_.join();
+}
+
+// ---------------------------------------------------------------------------
+// Submitter (submitter.go:27-159)
+// ---------------------------------------------------------------------------
+Submitter::Submitter(MetricSystem *ms, Serializer serializer, std::string network, std::string address,
+                     std::chrono::nanoseconds interval)
+    : DestinationNetwork(std::move(network)), DestinationAddress(std::move(address)), ms_(ms),
+      serializer_(std::move(serializer)), interval_(interval),
+      chan_(std::make_shared<Channel<std::shared_ptr<ProcessedMetricSet>>>(60)) // submitter.go:55
+{
+    ms_->SubscribeToProcessedMetrics(chan_);
+}
+
+Submitter::~Submitter() { Shutdown(); }
+
+bool Submitter::submit(const std::string &request) // submitter.go:106-116
+{
+    const size_t colon = DestinationAddress.rfind(':');
+    if (colon == std::string::npos) return false;
+    const std::string host = DestinationAddress.substr(0, colon), port = DestinationAddress.substr(colon + 1);
+    addrinfo hints{}, *res = nullptr;
+    hints.ai_family = AF_UNSPEC;
+    hints.ai_socktype = DestinationNetwork == "udp" ? SOCK_DGRAM : SOCK_STREAM;
+    if (getaddrinfo(host.c_str(), port.c_str(), &hints, &res) != 0 || !res) return false;
+    bool ok = false;
+    const int fd = socket(res->ai_family, res->ai_socktype, res->ai_protocol);
+    if (fd >= 0) {
+        timeval tv{5, 0}; // 5 s deadline
+        setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof tv);
+        setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+        if (connect(fd, res->ai_addr, res->ai_addrlen) == 0) {
+            size_t off = 0;
+            ok = true;
+            while (off < request.size()) {
+                const ssize_t n = ::send(fd, request.data() + off, request.size() - off, MSG_NOSIGNAL);
+                if (n <= 0) { ok = false; break; }
+                off += (size_t)n;
+            }
+        }
+        close(fd);
+    }
+    freeaddrinfo(res);
+    return ok;
+}
+
+bool Submitter::retryBacklog() // submitter.go:70-93
+{
+    while (true) {
+        std::string request;
+        {
+            std::lock_guard<std::mutex> g(backlog_mu_);
+            if (head_ == tail_) return true;
+            request = backlog_[head_];
+        }
+        if (!submit(request)) return false;
+        sent_.fetch_add(1);
+        std::lock_guard<std::mutex> g(backlog_mu_);
+        head_ = (head_ + 1) % 60;
+    }
+}
+
+void Submitter::appendToBacklog(std::string request) // submitter.go:95-104
+{
+    std::lock_guard<std::mutex> g(backlog_mu_);
+    backlog_[tail_] = std::move(request);
+    tail_ = (tail_ + 1) % 60;
+    if (head_ == tail_) { // ran into the head: evict it
+        head_ = (head_ + 1) % 60;
+        evicted_.fetch_add(1);
+    }
+}
+
+void Submitter::Start() // submitter.go:119-149
+{
+    recv_thread_ = std::thread([this] {
+        std::shared_ptr<ProcessedMetricSet> pm;
+        while (!shutdown_.load()) {
+            if (chan_->Receive(pm, std::chrono::milliseconds(20))) appendToBacklog(serializer_(*pm));
+            else if (chan_->Closed()) return; // we can no longer make progress
+        }
+    });
+    send_thread_ = std::thread([this] {
+        const int64_t ivl = std::max<int64_t>(1, interval_.count());
+        while (!shutdown_.load()) {
+            retryBacklog();
+            using namespace std::chrono;
+            const int64_t now = duration_cast<nanoseconds>(system_clock::now().time_since_epoch()).count();
+            int64_t tts = ivl - now % ivl;
+            while (tts > 0 && !shutdown_.load()) { // interruptible sleep to the next interval boundary
+                const int64_t step = std::min<int64_t>(tts, 20000000);
+                std::this_thread::sleep_for(nanoseconds(step));
+                tts -= step;
+            }
+        }
+    });
+}
+
+void Submitter::Shutdown() // submitter.go:152-159
+{
+    if (shutdown_.exchange(true)) return;
+    if (recv_thread_.joinable()) recv_thread_.join();
+    if (send_thread_.joinable()) send_thread_.join();
 }
 
 // ---------------------------------------------------------------------------

@@ -148,6 +148,58 @@ TEST(TestSerializers) // graphite_test.go / opentsdb_test.go shape + exact line 
     CHECK(o.rfind("put some_ipc_99.9 1418352105 1001.250000 host=", 0) == 0 && o.back() == '\n');
 }
 
+// graphite_test.go:8-23 / opentsdb_test.go:8-23 run the serializer + submit against localhost:7777 without
+// asserting anything; here a local sink is listening and the bytes are checked.
+#include <arpa/inet.h>
+#include <netinet/in.h>
+#include <sys/socket.h>
+#include <unistd.h>
+TEST(TestSubmitterGraphite)
+{
+    int lfd = socket(AF_INET, SOCK_STREAM, 0);
+    sockaddr_in a{};
+    a.sin_family = AF_INET;
+    a.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
+    CHECK(bind(lfd, (sockaddr *)&a, sizeof a) == 0 && listen(lfd, 16) == 0);
+    socklen_t l = sizeof a;
+    getsockname(lfd, (sockaddr *)&a, &l);
+    const int port = ntohs(a.sin_port);
+    std::string received;
+    std::atomic<bool> stop{false};
+    std::thread sink([&] {
+        char buf[65536];
+        while (!stop.load()) {
+            timeval tv{0, 50000};
+            fd_set rs;
+            FD_ZERO(&rs);
+            FD_SET(lfd, &rs);
+            if (select(lfd + 1, &rs, nullptr, nullptr, &tv) <= 0) continue;
+            int c = accept(lfd, nullptr, nullptr);
+            ssize_t n;
+            while ((n = read(c, buf, sizeof buf)) > 0) received.append(buf, (size_t)n);
+            close(c);
+        }
+    });
+    {
+        MetricSystem ms(5ms, false);
+        Submitter s(&ms, GraphiteProtocol, "tcp", "127.0.0.1:" + std::to_string(port), 5ms);
+        s.Start();
+        ms.Counter("requests_total", 7);
+        ms.Start();
+        std::this_thread::sleep_for(150ms);
+        s.Shutdown();
+        ms.Stop();
+        CHECK(s.sent_requests() >= 2);
+        CHECK(s.DestinationNetwork == "tcp");
+    }
+    stop.store(true);
+    sink.join();
+    close(lfd);
+    CHECK(received.find(".requests.total 7.000000 ") != std::string::npos);      // lifetime counter, '_' -> '.'
+    CHECK(received.find(".requests.total.rate 7.000000 ") != std::string::npos); // first interval's rate
+    CHECK(received.rfind("cockroach.", 0) == 0);
+}
+
 // ---- histogram paths: need the GPU ---------------------------------------------------------------
 TEST(TestTimer) // metrics_test.go:183-200
 {
@@ -283,6 +335,7 @@ int main(int argc, char **argv)
     RUN(TestSlowSubscriberIsDropped);
     RUN(TestMetricSystemStop);
     RUN(TestSerializers);
+    RUN(TestSubmitterGraphite);
     if (!cpu_only) {
         RUN(TestTimer);
         RUN(TestProcessedBroadcast);

@@ -19,7 +19,7 @@ def test_cpp_host_layer_cpu_tests(native_lib):
     r = run([os.path.join(BUILD, "metrics_test"), "--cpu"])
     print(r.stdout)
     assert r.returncode == 0, r.stdout
-    assert r.stdout.count("PASS ") >= 9 and "FAIL" not in r.stdout
+    assert r.stdout.count("PASS ") >= 10 and "FAIL" not in r.stdout
 
 
 @pytest.mark.gpu
@@ -27,7 +27,7 @@ def test_cpp_host_layer_all_tests(native_lib, torch_cuda):
     r = run([os.path.join(BUILD, "metrics_test")])
     print(r.stdout)
     assert r.returncode == 0, r.stdout
-    assert r.stdout.count("PASS ") >= 14 and "FAIL" not in r.stdout
+    assert r.stdout.count("PASS ") >= 15 and "FAIL" not in r.stdout
 
 
 @pytest.mark.gpu
