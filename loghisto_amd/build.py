@@ -58,7 +58,7 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
         s = os.path.join(CSRC, src)
         o = os.path.join(bdir, os.path.splitext(src)[0].replace("/", "_") + ".o")
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + _COMMON + extra + ["-I", INCLUDE, "-c", s, "-o", o]
+            cmd = [hipcc] + _COMMON + extra + os.environ.get("LH_EXTRA_CXXFLAGS", "").split() + ["-I", INCLUDE, "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
