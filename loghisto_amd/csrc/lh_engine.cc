@@ -171,6 +171,15 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
     const size_t kMaxLaunch = size_t(1) << 30;
     while (n) {
         const size_t take = n < kMaxLaunch ? n : kMaxLaunch;
+        if (lh::small_supported(take, e->cfg.max_metrics, d_ids, d_v)) {
+            // a handful of names: every workgroup keeps all of them in LDS, one streaming pass
+            HIPCHK(lh::launch_ingest_pairs_small(d_ids, d_v, take, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx,
+                                                 e->d_err, e->num_cus, s));
+            d_ids += take;
+            d_v += take;
+            n -= take;
+            continue;
+        }
         const size_t need = lh::part_aligned(d_ids, d_v) ? lh::part_scratch_bytes(take, e->cfg.max_metrics, e->num_cus) : 0;
         if (need) {
             // large launch over many names: partition by name, then reduce in LDS

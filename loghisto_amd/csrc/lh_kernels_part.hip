@@ -26,6 +26,7 @@
 // launches fall back to direct global atomics.
 #include "lh_kernels.h"
 #include "lh_codec.h"
+#include "lh_windows.h"
 
 #include <cstdlib>
 
@@ -448,10 +449,8 @@ __global__ __launch_bounds__(P2_BLOCK, 8) void k_part_hist(const uint32_t *__res
     for (uint32_t i = tid; i < words; i += P2_BLOCK) h[i] = 0;
     __syncthreads();
 
-    // ---- window placement.  A sample of the slot (its first chunk, <= 1 024 records) is
-    // bucketed coarsely into h[name][bin >> log_cw] (W coarse cells span the whole key space);
-    // each name's window is the run of coarse cells with the largest mass, centred among ties.
-    // A badly placed window only costs speed: out-of-window records go to global atomics.
+    // ---- window placement (lh_windows.h): a sample of the slot (its first chunk, <= 1 024 records)
+    // is bucketed coarsely into h[name][bin >> log_cw]; choose_windows picks the max-mass run per name.
     const uint32_t log_cw = 16 - log_w;
     {
         const uint32_t c0 = list[0];
@@ -463,61 +462,7 @@ __global__ __launch_bounds__(P2_BLOCK, 8) void k_part_hist(const uint32_t *__res
         }
     }
     __syncthreads();
-    {
-        const uint32_t wl = (W >> log_cw) ? (W >> log_cw) : 1u; // coarse cells per window
-        const uint32_t S = W >= 64 ? (W >> 6) : 1u;             // coarse cells per lane
-        for (uint32_t l = wave; l < mpp; l += P2_BLOCK / 64) {
-            uint32_t *hl = h + (l << log_w);
-            const bool on = lane * S < W;
-            // inclusive prefix sums in place (lane-serial segments + wave scan of the segment totals)
-            uint32_t run = 0;
-            if (on)
-                for (uint32_t k = 0; k < S; k++) { run += hl[lane * S + k]; hl[lane * S + k] = run; }
-            uint32_t inc = run;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t y = __shfl_up(inc, d, 64);
-                if ((int)lane >= d) inc += y;
-            }
-            const uint32_t excl = inc - run;
-            const uint32_t total = __shfl(inc, 63, 64);
-            if (on)
-                for (uint32_t k = 0; k < S; k++) hl[lane * S + k] += excl;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // best start cell: (mass << 16 | 65535 - s) maximises mass then minimises s; the mirrored
-            // packing finds the largest s with the same mass
-            uint32_t best_lo = 0, best_hi = 0;
-            if (on)
-                for (uint32_t k = 0; k < S; k++) {
-                    const uint32_t s = lane * S + k;
-                    if (s + wl <= W) {
-                        const uint32_t mass = hl[s + wl - 1] - (s ? hl[s - 1] : 0u);
-                        const uint32_t a = (mass << 16) | (65535u - s), b = (mass << 16) | s;
-                        best_lo = a > best_lo ? a : best_lo;
-                        best_hi = b > best_hi ? b : best_hi;
-                    }
-                }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                const uint32_t a = __shfl_xor(best_lo, d, 64), b = __shfl_xor(best_hi, d, 64);
-                best_lo = a > best_lo ? a : best_lo;
-                best_hi = b > best_hi ? b : best_hi;
-            }
-            if (lane == 0) {
-                uint32_t org = 32768u - W / 2; // name absent from the sample: centre on key 0
-                if (total) {
-                    const uint32_t smin = 65535u - (best_lo & 0xffffu), smax = best_hi & 0xffffu;
-                    const uint32_t centre = ((smin + smax + wl) << log_cw) >> 1;
-                    org = centre > W / 2 ? centre - W / 2 : 0u;
-                }
-                if (org > LH_NKEYS - W) org = LH_NKEYS - W;
-                s_org[l] = org;
-                s_mn[l] = INVALID; // flush ranges
-                s_mx[l] = 0;
-            }
-        }
-    }
+    choose_windows(h, s_org, s_mn, s_mx, mpp, log_w, wave, lane, P2_BLOCK / 64); // lh_windows.h
     __syncthreads();
     for (uint32_t i = tid; i < words; i += P2_BLOCK) h[i] = 0;
     __syncthreads();

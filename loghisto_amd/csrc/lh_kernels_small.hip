@@ -1,0 +1,174 @@
+// lh_kernels_small.hip -- mixed (id, value) ingest when the engine has FEW names (<= 16), gfx950.
+//
+// Reference semantics: Histogram(name, v) = histogramCache[name][compress(v)] += 1
+// (metrics.go:273-295, 316-322).  With a handful of names every workgroup can keep all of them in
+// LDS, so this is a single streaming pass like K1 (lh_kernels.hip): 12 algorithmic bytes per sample
+// and nothing written back but the flush -- no partition pass (lh_kernels_part.hip needs 20 B/sample).
+//
+// LDS: 16 384 uint32 bins (64 KiB) split evenly: 1 name -> 16 384 bins, 4 -> 4 096, 16 -> 1 024.
+// Each workgroup places its windows from its own first tile (lh_windows.h); records outside a window
+// go to global atomics (exact).  Two 512-thread workgroups per CU, grid-stride over 4 096-sample tiles.
+#include "lh_kernels.h"
+#include "lh_codec.h"
+#include "lh_windows.h"
+
+namespace lh {
+
+typedef double sd2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t su2_t __attribute__((ext_vector_type(2)));
+
+constexpr int KS_BLOCK = 512;
+constexpr int KS_UNROLL = 4;                  // (16-B values + 8-B ids) loads in flight per lane
+constexpr uint32_t KS_WORDS = 16384;
+constexpr uint32_t KS_MAXM = 16;
+constexpr size_t KS_LDS_BYTES = (KS_WORDS + 3 * KS_MAXM) * sizeof(uint32_t) + 16;
+constexpr size_t KS_MIN_SAMPLES = 65536;
+
+bool small_supported(size_t n, uint32_t nmetrics, const uint32_t *d_ids, const double *d_v)
+{
+    return nmetrics >= 1 && nmetrics <= KS_MAXM && n >= KS_MIN_SAMPLES && (((uintptr_t)d_v & 15) == 0) &&
+           (((uintptr_t)d_ids & 7) == 0);
+}
+
+__device__ __forceinline__ void ks_global_add(uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
+                                              uint32_t m, uint32_t bin, uint64_t c)
+{
+    atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)m * LH_NKEYS + bin]), (unsigned long long)c);
+    uint32_t *r = ranges + 2 * (size_t)m;
+    if (bin < r[0]) atomicMin(&r[0], bin);
+    if (bin > r[1]) atomicMax(&r[1], bin);
+}
+
+__global__ __launch_bounds__(KS_BLOCK) void k_ingest_pairs_small(const uint32_t *__restrict__ ids,
+                                                                 const double *__restrict__ v, size_t n,
+                                                                 uint64_t *__restrict__ counts,
+                                                                 uint32_t *__restrict__ ranges, uint32_t nmetrics,
+                                                                 uint32_t log_w, const double *__restrict__ Tx,
+                                                                 uint32_t *__restrict__ err)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *h = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *s_org = h + KS_WORDS;
+    uint32_t *s_mn = s_org + KS_MAXM;
+    uint32_t *s_mx = s_mn + KS_MAXM;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t W = 1u << log_w, words = nmetrics << log_w, log_cw = 16 - log_w;
+
+    const size_t npair = n / 2; // the odd tail sample is handled by workgroup 0
+    const sd2_t *vp = reinterpret_cast<const sd2_t *>(v);
+    const su2_t *ip = reinterpret_cast<const su2_t *>(ids);
+    const size_t tile = (size_t)KS_BLOCK * KS_UNROLL; // pairs per workgroup iteration
+    const size_t ntiles = (npair + tile - 1) / tile;
+
+    for (uint32_t i = tid; i < words; i += KS_BLOCK) h[i] = 0;
+    __syncthreads();
+    // window placement from this workgroup's first tile (<= 4 096 samples)
+    if ((size_t)blockIdx.x < ntiles) {
+        const size_t base = (size_t)blockIdx.x * tile;
+        for (int u = 0; u < KS_UNROLL; u++) {
+            const size_t i = base + (size_t)u * KS_BLOCK + tid;
+            if (i < npair) {
+                const su2_t id = ip[i];
+                const sd2_t x = vp[i];
+                if (id.x < nmetrics) atomicAdd(&h[(id.x << log_w) + (lh_bin_of(x.x, Tx) >> log_cw)], 1u);
+                if (id.y < nmetrics) atomicAdd(&h[(id.y << log_w) + (lh_bin_of(x.y, Tx) >> log_cw)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    choose_windows(h, s_org, s_mn, s_mx, nmetrics, log_w, wave, lane, KS_BLOCK / 64);
+    __syncthreads();
+    for (uint32_t i = tid; i < words; i += KS_BLOCK) h[i] = 0;
+    __syncthreads();
+
+    auto add = [&](uint32_t id, double x, bool fullwave) {
+        if (id >= nmetrics) { atomicOr(err, 1u); return; } // reported by lh_sync / lh_extract
+        const uint32_t bin = lh_bin_of(x, Tx);
+        const uint32_t rel = bin - s_org[id];
+        if (fullwave) {
+            // constant streams: all 64 lanes carry the same (name, bucket) -> one lane adds 64
+            const uint32_t key = (id << 16) | bin;
+            const uint32_t f0 = __builtin_amdgcn_readfirstlane(key);
+            if (__builtin_amdgcn_ballot_w64(key != f0) == 0ull) {
+                if (lane == 0) {
+                    if (rel < W) atomicAdd(&h[(id << log_w) + rel], 64u);
+                    else ks_global_add(counts, ranges, id, bin, 64);
+                }
+                return;
+            }
+        }
+        if (rel < W) atomicAdd(&h[(id << log_w) + rel], 1u);
+        else ks_global_add(counts, ranges, id, bin, 1);
+    };
+
+    const size_t nfull = npair / tile;
+    for (size_t t = blockIdx.x; t < nfull; t += gridDim.x) {
+        const size_t base = t * tile + tid;
+        su2_t idr[KS_UNROLL];
+        sd2_t vr[KS_UNROLL];
+#pragma unroll
+        for (int u = 0; u < KS_UNROLL; u++) {
+            idr[u] = __builtin_nontemporal_load(ip + base + (size_t)u * KS_BLOCK);
+            vr[u] = __builtin_nontemporal_load(vp + base + (size_t)u * KS_BLOCK);
+        }
+#pragma unroll
+        for (int u = 0; u < KS_UNROLL; u++) {
+            // a bad id breaks wave uniformity of the branch inside add(); checked there
+            const bool ok = __builtin_amdgcn_ballot_w64(idr[u].x >= nmetrics || idr[u].y >= nmetrics) == 0ull;
+            add(idr[u].x, vr[u].x, ok);
+            add(idr[u].y, vr[u].y, ok);
+        }
+    }
+    if (blockIdx.x == nfull % gridDim.x) { // remainder pairs + odd tail (guarded)
+        for (size_t i = nfull * tile + tid; i < npair; i += KS_BLOCK) {
+            const su2_t id = ip[i];
+            const sd2_t x = vp[i];
+            add(id.x, x.x, false);
+            add(id.y, x.y, false);
+        }
+        if (tid == 0 && (n & 1)) add(ids[n - 1], v[n - 1], false);
+    }
+    __syncthreads();
+
+    // flush: one uint64 atomic per occupied cell
+    for (uint32_t i = tid; i < words; i += KS_BLOCK) {
+        const uint32_t c = h[i];
+        if (c) {
+            const uint32_t l = i >> log_w, b = s_org[l] + (i & (W - 1));
+            atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)l * LH_NKEYS + b]), (unsigned long long)c);
+            atomicMin(&s_mn[l], b);
+            atomicMax(&s_mx[l], b);
+        }
+    }
+    __syncthreads();
+    if (tid < nmetrics && s_mn[tid] != 0xffffffffu) {
+        uint32_t *r = ranges + 2 * (size_t)tid;
+        if (s_mn[tid] < r[0]) atomicMin(&r[0], s_mn[tid]);
+        if (s_mx[tid] > r[1]) atomicMax(&r[1], s_mx[tid]);
+    }
+}
+
+hipError_t launch_ingest_pairs_small(const uint32_t *d_ids, const double *d_v, size_t n, uint64_t *counts,
+                                     uint32_t *ranges, uint32_t nmetrics, const double *d_Tx, uint32_t *d_err,
+                                     int num_cus, hipStream_t s)
+{
+    if (!small_supported(n, nmetrics, d_ids, d_v)) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ingest_pairs_small),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)KS_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    uint32_t log_w = 0;
+    while ((nmetrics << (log_w + 1)) <= KS_WORDS) log_w++; // window = 2^log_w bins per name
+    const size_t tile_samples = (size_t)KS_BLOCK * KS_UNROLL * 2;
+    size_t want = (n + tile_samples - 1) / tile_samples;
+    const size_t cap = (size_t)num_cus * 2;
+    const unsigned grid = (unsigned)(want < cap ? want : cap);
+    hipLaunchKernelGGL(k_ingest_pairs_small, dim3(grid ? grid : 1), dim3(KS_BLOCK), KS_LDS_BYTES, s, d_ids, d_v, n,
+                       counts, ranges, nmetrics, log_w, d_Tx, d_err);
+    return hipGetLastError();
+}
+
+} // namespace lh
