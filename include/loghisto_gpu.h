@@ -112,7 +112,8 @@ int lh_submit_pairs(lh_engine *e, const uint32_t *ids, const double *v, size_t n
  * Ordering contract: the kernel is enqueued on `stream` (NULL = the engine's own non-blocking
  * stream, which does NOT synchronise with the legacy default stream).  The producer of the buffers
  * must therefore either run on the same stream or be complete before the call, and the buffers must
- * stay valid until the stream reaches this point (lh_sync / lh_flip + lh_extract imply it). */
+ * stay valid until the stream reaches this point (lh_sync / lh_flip + lh_extract imply it).  A
+ * caller-owned stream must outlive the next lh_flip, which records an event on it. */
 int lh_submit_device(lh_engine *e, uint32_t id, const double *d_v, size_t n, void *stream);
 int lh_submit_pairs_device(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t n, void *stream);
 /* Push partially filled staging buffers to the device (asynchronous). */

@@ -160,8 +160,16 @@ int epoch_touch_stream(lh_engine *e, hipStream_t s)
 int launch_single(lh_engine *e, uint32_t id, const double *d_v, size_t n, hipStream_t s)
 {
     EpochBuffer &b = e->bufs[(size_t)e->cur];
-    HIPCHK(lh::launch_ingest_single(d_v, n, b.counts + (size_t)id * LH_NKEYS, b.ranges + 2 * (size_t)id,
-                                    e->d_Tx, e->num_cus, s));
+    // a workgroup's uint32 LDS bins must not wrap even if every sample of the launch lands in one
+    // bucket: keep one launch below 2^32 samples
+    const size_t kMaxLaunch = size_t(1) << 31;
+    while (n) {
+        const size_t take = n < kMaxLaunch ? n : kMaxLaunch;
+        HIPCHK(lh::launch_ingest_single(d_v, take, b.counts + (size_t)id * LH_NKEYS, b.ranges + 2 * (size_t)id,
+                                        e->d_Tx, e->num_cus, s));
+        d_v += take;
+        n -= take;
+    }
     return LH_OK;
 }
 

@@ -18,6 +18,8 @@
 #include "lh_kernels.h"
 #include "lh_codec.h"
 
+#include <atomic>
+
 namespace lh {
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
@@ -193,7 +195,7 @@ hipError_t launch_ingest_single(const double *d_v, size_t n, uint64_t *row, uint
                                 const double *d_Tx, int num_cus, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false}; // benign if two threads race: both set the same attribute
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ingest_single),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)K1_LDS_BYTES);

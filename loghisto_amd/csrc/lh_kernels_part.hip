@@ -26,6 +26,8 @@
 // launches fall back to direct global atomics.
 #include "lh_kernels.h"
 #include "lh_codec.h"
+
+#include <atomic>
 #include "lh_windows.h"
 
 #include <cstdlib>
@@ -559,7 +561,7 @@ hipError_t launch_ingest_pairs_part(const uint32_t *d_ids, const double *d_v, si
     PartPlan P;
     if (!make_plan(n, nmetrics, num_cus, P) || scratch_bytes < P.total || !scratch) return hipErrorInvalidValue;
     if (((uintptr_t)d_v & 15) || ((uintptr_t)d_ids & 7)) return hipErrorInvalidValue; // see part_aligned()
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false}; // benign if two threads race: both set the same attribute
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_part_hist),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)P2_LDS_BYTES);

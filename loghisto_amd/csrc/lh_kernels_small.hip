@@ -10,6 +10,8 @@
 // go to global atomics (exact).  Two 512-thread workgroups per CU, grid-stride over 4 096-sample tiles.
 #include "lh_kernels.h"
 #include "lh_codec.h"
+
+#include <atomic>
 #include "lh_windows.h"
 
 namespace lh {
@@ -153,7 +155,7 @@ hipError_t launch_ingest_pairs_small(const uint32_t *d_ids, const double *d_v, s
                                      int num_cus, hipStream_t s)
 {
     if (!small_supported(n, nmetrics, d_ids, d_v)) return hipErrorInvalidValue;
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false}; // benign if two threads race: both set the same attribute
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ingest_pairs_small),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)KS_LDS_BYTES);
