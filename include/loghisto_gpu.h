@@ -157,6 +157,24 @@ int lh_snapshot_stream(lh_snapshot *s, void **stream);
 /* Returns the snapshot's buffer to the pool (cleared asynchronously). */
 int lh_release(lh_snapshot *s);
 
+/* Self-metrics of the engine (exposed by the host layer as gauges through
+ * RegisterGaugeFunc, metrics.go:299).  Monotonic since lh_create. */
+typedef struct lh_counters {
+    uint64_t samples_single;       /* through k_ingest_single                           */
+    uint64_t samples_small;        /* mixed, single-pass LDS kernel (<= 16 names)       */
+    uint64_t samples_partitioned;  /* mixed, partition + LDS reduce                     */
+    uint64_t samples_direct;       /* mixed, one global atomic per sample (small launches) */
+    uint64_t launches;             /* ingest launches of any kind                       */
+    uint64_t flips;                /* successful lh_flip calls                          */
+    uint64_t flips_busy;           /* lh_flip calls that returned LH_EBUSY              */
+    uint64_t extracts;             /* lh_extract / lh_extract_rows calls                */
+    uint64_t backpressure_waits;   /* submitters that had to wait for a staging half-buffer */
+    uint64_t window_misses;        /* samples the single-pass kernel sent to global atomics */
+    uint32_t small_path_disabled;  /* 1 once adaptive dispatch moved few-name streams to the partitioned path */
+    uint32_t reserved;
+} lh_counters;
+int lh_get_counters(lh_engine *e, lh_counters *out);
+
 /* Codec access for parity tests. */
 /* key[i] = compress(d_v[i]) on device (metrics.go:316-322). */
 int lh_compress_device(lh_engine *e, const double *d_v, int16_t *d_keys, size_t n, void *stream);

@@ -25,6 +25,13 @@ class LhConfig(C.Structure):
                 ("lane_samples", C.c_uint64)]
 
 
+class LhCounters(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("samples_single", "samples_small", "samples_partitioned", "samples_direct",
+                                           "launches", "flips", "flips_busy", "extracts", "backpressure_waits",
+                                           "window_misses")] + [("small_path_disabled", C.c_uint32),
+                                                                ("reserved", C.c_uint32)]
+
+
 class LhStats(C.Structure):
     _fields_ = [("count", C.c_uint64), ("sum", C.c_double), ("avg", C.c_double),
                 ("agg_sum_add", C.c_uint64), ("nbuckets", C.c_uint32), ("present", C.c_uint32)]
@@ -62,6 +69,7 @@ SIGNATURES = {
     "lh_snapshot_mark_dirty": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "lh_snapshot_stream": (C.c_int, [_vp, C.POINTER(_vp)]),
     "lh_release": (C.c_int, [_vp]),
+    "lh_get_counters": (C.c_int, [_vp, C.POINTER(LhCounters)]),
     "lh_compress_device": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
     "lh_compress_device_golog": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
     "lh_codec_tables": (C.c_int, [_vp, _dp, _dp]),

@@ -126,6 +126,15 @@ struct lh_engine {
 
     std::atomic<int> live_snapshots{0};
 
+    // adaptive dispatch of mixed launches with few names: the single-pass kernel reports how many samples
+    // missed its LDS windows; when that exceeds 2 % the engine uses the partitioned path (wider windows)
+    std::atomic<uint64_t> small_samples{0};
+    std::atomic<bool> small_disabled{false};
+
+    // self-metrics (lh_get_counters)
+    std::atomic<uint64_t> c_single{0}, c_small{0}, c_part{0}, c_direct{0}, c_launches{0}, c_flips{0}, c_busy{0},
+        c_extracts{0}, c_waits{0}, c_misses{0};
+
     // scratch of the partitioned mixed-ingest kernels, one per launching stream
     struct Scratch { void *p = nullptr; size_t bytes = 0; };
     std::mutex scratch_mu;
@@ -167,6 +176,8 @@ int launch_single(lh_engine *e, uint32_t id, const double *d_v, size_t n, hipStr
         const size_t take = n < kMaxLaunch ? n : kMaxLaunch;
         HIPCHK(lh::launch_ingest_single(d_v, take, b.counts + (size_t)id * LH_NKEYS, b.ranges + 2 * (size_t)id,
                                         e->d_Tx, e->num_cus, s));
+        e->c_single.fetch_add(take, std::memory_order_relaxed);
+        e->c_launches.fetch_add(1, std::memory_order_relaxed);
         d_v += take;
         n -= take;
     }
@@ -179,10 +190,14 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
     const size_t kMaxLaunch = size_t(1) << 30;
     while (n) {
         const size_t take = n < kMaxLaunch ? n : kMaxLaunch;
-        if (lh::small_supported(take, e->cfg.max_metrics, d_ids, d_v)) {
+        if (!e->small_disabled.load(std::memory_order_relaxed) &&
+            lh::small_supported(take, e->cfg.max_metrics, d_ids, d_v)) {
             // a handful of names: every workgroup keeps all of them in LDS, one streaming pass
             HIPCHK(lh::launch_ingest_pairs_small(d_ids, d_v, take, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx,
                                                  e->d_err, e->num_cus, s));
+            e->small_samples.fetch_add(take, std::memory_order_relaxed);
+            e->c_small.fetch_add(take, std::memory_order_relaxed);
+            e->c_launches.fetch_add(1, std::memory_order_relaxed);
             d_ids += take;
             d_v += take;
             n -= take;
@@ -205,10 +220,13 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
             }
             HIPCHK(lh::launch_ingest_pairs_part(d_ids, d_v, take, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx,
                                                 e->d_err, sc.p, sc.bytes, e->num_cus, s));
+            e->c_part.fetch_add(take, std::memory_order_relaxed);
         } else {
             HIPCHK(lh::launch_ingest_pairs(d_ids, d_v, take, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx,
                                            e->d_err, e->num_cus, s));
+            e->c_direct.fetch_add(take, std::memory_order_relaxed);
         }
+        e->c_launches.fetch_add(1, std::memory_order_relaxed);
         d_ids += take;
         d_v += take;
         n -= take;
@@ -238,6 +256,7 @@ int lane_launch(lh_engine *e, Lane &ln)
     ln.fill = 0;
     ln.mode = LANE_NONE;
     if (ln.inflight[ln.cur]) { // back-pressure: never drop (metrics.go:273-295 is synchronous)
+        if (hipEventQuery(ln.done[ln.cur]) != hipSuccess) e->c_waits.fetch_add(1, std::memory_order_relaxed);
         HIPCHK(hipEventSynchronize(ln.done[ln.cur]));
         ln.inflight[ln.cur] = false;
     }
@@ -619,7 +638,10 @@ int lh_flip(lh_engine *e, lh_snapshot **out)
     int next = -1;
     for (size_t i = 0; i < e->bufs.size(); i++)
         if (e->bufs[i].state == BUF_FREE) { next = (int)i; break; }
-    if (next < 0) return LH_EBUSY;
+    if (next < 0) {
+        e->c_busy.fetch_add(1, std::memory_order_relaxed);
+        return LH_EBUSY;
+    }
     lh_snapshot *s = new (std::nothrow) lh_snapshot();
     if (!s) return LH_ENOMEM;
     rc = flush_all_lanes(e);
@@ -645,6 +667,7 @@ int lh_flip(lh_engine *e, lh_snapshot **out)
     e->cur = next;
     e->bufs[(size_t)next].state = BUF_CURRENT;
     e->live_snapshots.fetch_add(1);
+    e->c_flips.fetch_add(1, std::memory_order_relaxed);
     *out = s;
     return LH_OK;
 }
@@ -684,10 +707,20 @@ int lh_extract_rows(lh_snapshot *s, uint32_t first, size_t nmetrics, const doubl
         if (pkeys) std::memcpy(pkeys, e->h_xbuf + L.off_pkeys, nmetrics * np * sizeof(int16_t));
         if (pvalid) std::memcpy(pvalid, e->h_xbuf + L.off_pvalid, nmetrics * np);
     }
-    uint32_t err;
+    uint32_t err, nfall;
     std::memcpy(&err, e->h_xbuf + L.off_err, 4);
+    std::memcpy(&nfall, e->h_xbuf + L.off_err + 4, 4);
+    e->c_extracts.fetch_add(1, std::memory_order_relaxed);
+    if (nfall) {
+        e->c_misses.fetch_add(nfall, std::memory_order_relaxed);
+        const uint64_t seen = e->small_samples.exchange(0);
+        // more than 2 % of the samples fell outside the LDS windows: the names' spans are wider than
+        // 16384/names bins; the partitioned path gives every name 4 096 bins
+        if ((uint64_t)nfall * 50 > seen && e->cfg.max_metrics > 4) e->small_disabled.store(true);
+        HIPCHK(hipMemsetAsync(reinterpret_cast<uint32_t *>(e->d_err) + 1, 0, 4, e->xstream));
+    }
     if (err) {
-        HIPCHK(hipMemsetAsync(e->d_err, 0, 8, e->xstream));
+        HIPCHK(hipMemsetAsync(e->d_err, 0, 4, e->xstream));
         return LH_ERANGE;
     }
     return LH_OK;
@@ -833,6 +866,24 @@ int lh_release(lh_snapshot *s)
     }
     e->live_snapshots.fetch_sub(1);
     delete s;
+    return LH_OK;
+}
+
+int lh_get_counters(lh_engine *e, lh_counters *out)
+{
+    if (!e || !out) return LH_EINVAL;
+    out->samples_single = e->c_single.load();
+    out->samples_small = e->c_small.load();
+    out->samples_partitioned = e->c_part.load();
+    out->samples_direct = e->c_direct.load();
+    out->launches = e->c_launches.load();
+    out->flips = e->c_flips.load();
+    out->flips_busy = e->c_busy.load();
+    out->extracts = e->c_extracts.load();
+    out->backpressure_waits = e->c_waits.load();
+    out->window_misses = e->c_misses.load();
+    out->small_path_disabled = e->small_disabled.load() ? 1u : 0u;
+    out->reserved = 0;
     return LH_OK;
 }
 

@@ -338,7 +338,10 @@ __global__ __launch_bounds__(K2_BLOCK) void k_extract(const uint64_t *__restrict
         s_found[tid] = 0xffffffffu;
         s_p[tid] = tid < np ? pa.p[tid] : 2.0;
     }
-    if (blockIdx.x == 0 && tid == 0) *err_out = *err_in; // sticky bad-id flag rides along with the results
+    if (blockIdx.x == 0 && tid == 0) { // sticky bad-id flag + small-kernel fallback counter ride along with the results
+        err_out[0] = err_in[0];
+        err_out[1] = err_in[1];
+    }
 
     // ---- pass 1: totalCount, totalSum, occupied buckets (metrics.go:342-347)
     uint64_t cnt = 0;

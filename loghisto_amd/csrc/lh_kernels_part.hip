@@ -414,7 +414,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan_scatter(const uint32_t *__res
 // P2: per-partition LDS histogram
 // ---------------------------------------------------------------------------
 typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
-constexpr size_t P2_LDS_BYTES = (P2_WINWORDS + 3 * PART_MAX_MPP) * sizeof(uint32_t) + 16;
+constexpr size_t P2_LDS_BYTES = (P2_WINWORDS + 3 * PART_MAX_MPP + 2 * OV_SLOTS) * sizeof(uint32_t) + 16;
 
 __device__ __forceinline__ void p2_global_add(uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
                                               uint32_t m, uint32_t bin, uint64_t c)
@@ -440,6 +440,8 @@ __global__ __launch_bounds__(P2_BLOCK, 8) void k_part_hist(const uint32_t *__res
     uint32_t *s_org = h + P2_WINWORDS;
     uint32_t *s_mn = s_org + PART_MAX_MPP;
     uint32_t *s_mx = s_mn + PART_MAX_MPP;
+    uint32_t *ov_key = s_mx + PART_MAX_MPP; // out-of-window records, aggregated per slot (lh_windows.h)
+    uint32_t *ov_cnt = ov_key + OV_SLOTS;
 
     const uint32_t slot = blockIdx.x;
     if (slot >= *nslots) return;
@@ -467,6 +469,7 @@ __global__ __launch_bounds__(P2_BLOCK, 8) void k_part_hist(const uint32_t *__res
     choose_windows(h, s_org, s_mn, s_mx, mpp, log_w, wave, lane, P2_BLOCK / 64); // lh_windows.h
     __syncthreads();
     for (uint32_t i = tid; i < words; i += P2_BLOCK) h[i] = 0;
+    ov_init(ov_key, ov_cnt, tid, P2_BLOCK);
     __syncthreads();
 
     // one chunk per wave per iteration: 1 024 records = 4 x (64 lanes x 16 B).  Double-buffered: the
@@ -492,15 +495,15 @@ __global__ __launch_bounds__(P2_BLOCK, 8) void k_part_hist(const uint32_t *__res
                     if (__builtin_amdgcn_ballot_w64(rec != f0) == 0ull) {
                         if (lane == 0) {
                             if (rel < W) atomicAdd(&h[(l << log_w) + rel], 64u);
-                            else p2_global_add(counts, ranges, (l << log_np) | p, b, 64);
+                            else if (!ov_add(ov_key, ov_cnt, (l << 16) | b, 64u)) p2_global_add(counts, ranges, (l << log_np) | p, b, 64);
                         }
                     } else {
                         if (rel < W) atomicAdd(&h[(l << log_w) + rel], 1u);
-                        else p2_global_add(counts, ranges, (l << log_np) | p, b, 1);
+                        else if (!ov_add(ov_key, ov_cnt, (l << 16) | b, 1u)) p2_global_add(counts, ranges, (l << log_np) | p, b, 1);
                     }
                 } else if (q * 256 + lane * 4 + t < cn) {
                     if (rel < W) atomicAdd(&h[(l << log_w) + rel], 1u);
-                    else p2_global_add(counts, ranges, (l << log_np) | p, b, 1);
+                    else if (!ov_add(ov_key, ov_cnt, (l << 16) | b, 1u)) p2_global_add(counts, ranges, (l << log_np) | p, b, 1);
                 }
             }
         }
@@ -546,6 +549,9 @@ __global__ __launch_bounds__(P2_BLOCK, 8) void k_part_hist(const uint32_t *__res
             atomicMax(&s_mx[l], b);
         }
     }
+    for (uint32_t i = tid; i < OV_SLOTS; i += P2_BLOCK)
+        if (ov_key[i] != OV_EMPTY)
+            p2_global_add(counts, ranges, ((ov_key[i] >> 16) << log_np) | p, ov_key[i] & 0xffffu, ov_cnt[i]);
     __syncthreads();
     if (tid < mpp && s_mn[tid] != INVALID) {
         uint32_t *r = ranges + 2 * (size_t)((tid << log_np) | p);

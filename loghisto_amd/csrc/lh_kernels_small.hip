@@ -23,7 +23,7 @@ constexpr int KS_BLOCK = 512;
 constexpr int KS_UNROLL = 4;                  // (16-B values + 8-B ids) loads in flight per lane
 constexpr uint32_t KS_WORDS = 16384;
 constexpr uint32_t KS_MAXM = 16;
-constexpr size_t KS_LDS_BYTES = (KS_WORDS + 3 * KS_MAXM) * sizeof(uint32_t) + 16;
+constexpr size_t KS_LDS_BYTES = (KS_WORDS + 3 * KS_MAXM + 2 * OV_SLOTS) * sizeof(uint32_t) + 16;
 constexpr size_t KS_MIN_SAMPLES = 65536;
 
 bool small_supported(size_t n, uint32_t nmetrics, const uint32_t *d_ids, const double *d_v)
@@ -53,6 +53,8 @@ __global__ __launch_bounds__(KS_BLOCK) void k_ingest_pairs_small(const uint32_t 
     uint32_t *s_org = h + KS_WORDS;
     uint32_t *s_mn = s_org + KS_MAXM;
     uint32_t *s_mx = s_mn + KS_MAXM;
+    uint32_t *ov_key = s_mx + KS_MAXM; // out-of-window records, aggregated per workgroup (lh_windows.h)
+    uint32_t *ov_cnt = ov_key + OV_SLOTS;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t W = 1u << log_w, words = nmetrics << log_w, log_cw = 16 - log_w;
 
@@ -81,8 +83,10 @@ __global__ __launch_bounds__(KS_BLOCK) void k_ingest_pairs_small(const uint32_t 
     choose_windows(h, s_org, s_mn, s_mx, nmetrics, log_w, wave, lane, KS_BLOCK / 64);
     __syncthreads();
     for (uint32_t i = tid; i < words; i += KS_BLOCK) h[i] = 0;
+    ov_init(ov_key, ov_cnt, tid, KS_BLOCK);
     __syncthreads();
 
+    uint32_t nfall = 0; // samples this thread sent to global atomics: feeds the engine's adaptive dispatch
     auto add = [&](uint32_t id, double x, bool fullwave) {
         if (id >= nmetrics) { atomicOr(err, 1u); return; } // reported by lh_sync / lh_extract
         const uint32_t bin = lh_bin_of(x, Tx);
@@ -94,13 +98,13 @@ __global__ __launch_bounds__(KS_BLOCK) void k_ingest_pairs_small(const uint32_t 
             if (__builtin_amdgcn_ballot_w64(key != f0) == 0ull) {
                 if (lane == 0) {
                     if (rel < W) atomicAdd(&h[(id << log_w) + rel], 64u);
-                    else ks_global_add(counts, ranges, id, bin, 64);
+                    else if (!ov_add(ov_key, ov_cnt, key, 64u)) { ks_global_add(counts, ranges, id, bin, 64); nfall += 64; }
                 }
                 return;
             }
         }
         if (rel < W) atomicAdd(&h[(id << log_w) + rel], 1u);
-        else ks_global_add(counts, ranges, id, bin, 1);
+        else if (!ov_add(ov_key, ov_cnt, (id << 16) | bin, 1u)) { ks_global_add(counts, ranges, id, bin, 1); nfall++; }
     };
 
     const size_t nfull = npair / tile;
@@ -131,6 +135,9 @@ __global__ __launch_bounds__(KS_BLOCK) void k_ingest_pairs_small(const uint32_t 
         if (tid == 0 && (n & 1)) add(ids[n - 1], v[n - 1], false);
     }
     __syncthreads();
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) nfall += __shfl_down(nfall, d, 64);
+    if (lane == 0 && nfall) atomicAdd(&err[1], nfall); // err[1]: fallback counter, read back with the extract
 
     // flush: one uint64 atomic per occupied cell
     for (uint32_t i = tid; i < words; i += KS_BLOCK) {
@@ -142,6 +149,8 @@ __global__ __launch_bounds__(KS_BLOCK) void k_ingest_pairs_small(const uint32_t 
             atomicMax(&s_mx[l], b);
         }
     }
+    for (uint32_t i = tid; i < OV_SLOTS; i += KS_BLOCK)
+        if (ov_key[i] != OV_EMPTY) ks_global_add(counts, ranges, ov_key[i] >> 16, ov_key[i] & 0xffffu, ov_cnt[i]);
     __syncthreads();
     if (tid < nmetrics && s_mn[tid] != 0xffffffffu) {
         uint32_t *r = ranges + 2 * (size_t)tid;

@@ -220,6 +220,12 @@ class Engine:
         N.check(N.lib().lh_selftest_vlog(self._h, C.byref(out)), "lh_selftest_vlog")
         return float(out.value)
 
+    def counters(self) -> dict:
+        """Self-metrics of the engine (lh_get_counters)."""
+        c = N.LhCounters()
+        N.check(N.lib().lh_get_counters(self._h, C.byref(c)), "lh_get_counters")
+        return {k: int(getattr(c, k)) for k, _ in N.LhCounters._fields_ if k != "reserved"}
+
     def close(self):
         if self._h is not None and self._h.value:
             N.check(N.lib().lh_destroy(self._h), "lh_destroy")

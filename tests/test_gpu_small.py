@@ -79,3 +79,37 @@ def test_small_path_reports_bad_ids(native_lib, torch_cuda):
         with e.flip() as snap:
             rows = np.stack([snap.dense_row(m) for m in range(M)])
     assert np.array_equal(rows, oracle.histogram_pairs(ids[keep], v[keep], M))
+
+
+def test_adaptive_dispatch_and_counters(native_lib, torch_cuda):
+    """16 names whose spans (4 146 buckets) dwarf the 1 024-bin windows: the first interval runs through the
+    single-pass kernel and reports its window misses; from then on the engine uses the partitioned path.
+    Results are exact either way."""
+    import loghisto_amd
+    rng = np.random.default_rng(7)
+    M, n = 16, 600_000
+    ids = rng.integers(0, M, n).astype(np.uint32)
+    v = 10.0 ** rng.uniform(-3, 18, n)
+    want = oracle.histogram_pairs(ids, v, M)
+    d_ids, d_v = _dev(torch_cuda, ids), _dev(torch_cuda, v)
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        for interval in range(3):
+            e.submit_pairs_device(d_ids, d_v)
+            with e.flip() as snap:
+                got = snap.extract(PCTS, M)
+                assert np.array_equal(snap.dense_row(3), want[3])
+            assert int(got["count"].sum()) == n
+            c = e.counters()
+            assert c["flips"] == interval + 1 and c["extracts"] >= interval + 1
+        assert c["samples_small"] == n                 # only the first interval
+        assert c["samples_partitioned"] == 2 * n       # the two after it
+        assert c["small_path_disabled"] == 1 and c["window_misses"] > n // 50
+    # a well-behaved stream keeps the single-pass kernel
+    v2 = rng.lognormal(math.log(1e5), 1.0, n)
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        for _ in range(2):
+            e.submit_pairs_device(d_ids, _dev(torch_cuda, v2))
+            with e.flip() as snap:
+                snap.extract(PCTS, M)
+        c = e.counters()
+        assert c["samples_small"] == 2 * n and c["small_path_disabled"] == 0
