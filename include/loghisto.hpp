@@ -155,6 +155,8 @@ public:
     void Counter(const std::string &name, uint64_t amount);
     void Histogram(const std::string &name, double value);
     void RegisterGaugeFunc(const std::string &name, std::function<double()> f);
+    // opt-in: publishes the engine's self-metrics (lh_get_counters) as gauges "<prefix>samples_small", ...
+    void RegisterEngineGauges(const std::string &prefix = "loghisto.gpu.");
     void DeregisterGaugeFunc(const std::string &name);
 
     std::shared_ptr<RawMetricSet> collectRawMetrics();

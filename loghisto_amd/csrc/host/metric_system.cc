@@ -275,6 +275,25 @@ void MetricSystem::RegisterGaugeFunc(const std::string &name, std::function<doub
     gauge_funcs_[name] = std::move(f);
 }
 
+void MetricSystem::RegisterEngineGauges(const std::string &prefix)
+{
+    auto read = [this](uint64_t lh_counters::*field) {
+        return [this, field]() -> double {
+            lh_counters c{};
+            if (!engine_ || lh_get_counters(engine_, &c) != LH_OK) return 0.0;
+            return (double)(c.*field);
+        };
+    };
+    RegisterGaugeFunc(prefix + "samples_single", read(&lh_counters::samples_single));
+    RegisterGaugeFunc(prefix + "samples_small", read(&lh_counters::samples_small));
+    RegisterGaugeFunc(prefix + "samples_partitioned", read(&lh_counters::samples_partitioned));
+    RegisterGaugeFunc(prefix + "samples_direct", read(&lh_counters::samples_direct));
+    RegisterGaugeFunc(prefix + "launches", read(&lh_counters::launches));
+    RegisterGaugeFunc(prefix + "flips_busy", read(&lh_counters::flips_busy));
+    RegisterGaugeFunc(prefix + "backpressure_waits", read(&lh_counters::backpressure_waits));
+    RegisterGaugeFunc(prefix + "window_misses", read(&lh_counters::window_misses));
+}
+
 void MetricSystem::DeregisterGaugeFunc(const std::string &name)
 {
     std::lock_guard<std::mutex> g(gauge_mu_);

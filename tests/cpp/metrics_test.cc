@@ -321,6 +321,12 @@ TEST(TestProducersAreLosslessAcrossIntervals)
     CHECK(ev == (double)T * (N / 5));
     CHECK(m["ev"] == (double)T * (N / 5)); // lifetime counter
     CHECK(ms.last_status() == 0 || ms.last_status() == 5 /* LH_EBUSY is benign here */);
+    // the engine's self-metrics, published as gauges
+    ms.RegisterEngineGauges();
+    auto g = ms.collectRawMetrics()->Gauges;
+    const double seen = g["loghisto.gpu.samples_small"] + g["loghisto.gpu.samples_partitioned"] +
+                        g["loghisto.gpu.samples_direct"] + g["loghisto.gpu.samples_single"];
+    CHECK(seen == (double)T * N && g["loghisto.gpu.launches"] > 0);
 }
 
 int main(int argc, char **argv)
