@@ -152,6 +152,22 @@ int lh_buckets_all(lh_snapshot *s, uint32_t first, size_t nmetrics, uint64_t *of
 int lh_snapshot_rows(lh_snapshot *s, void **d_counts, uint32_t *nrows);
 int lh_snapshot_ranges(lh_snapshot *s, void **d_ranges /* uint32[nrows][2] lo,hi bins */);
 int lh_snapshot_mark_dirty(lh_snapshot *s, uint32_t first_row, uint32_t nrows, uint32_t lo_bin, uint32_t hi_bin);
+/* K4 -- multi-GPU merge of a snapshot across the ranks of an RCCL communicator (one process per GPU).
+ * Ingest is data-parallel: every rank buckets its own slice of the stream for ALL names; the only
+ * exchange is this integer SUM of the occupied window of the uint64 bucket matrix at the flip
+ * (cells are a commutative sum, metrics.go:278, 292).  The reference is single-process: no counterpart.
+ *   comm   ncclComm_t (as void*) created by the caller with the RCCL named by lh_set_rccl_library
+ *   plan   LH_MERGE_ALLREDUCE: every rank ends with every merged row;
+ *          LH_MERGE_REDUCE_SCATTER: rank r ends with the merged rows of names
+ *          [r*ceil(nrows/nranks), ...) and extracts those with lh_extract_rows
+ *   first_owned / last_owned  receive the [first, last) rows holding merged data on this rank
+ * Runs on the snapshot's stream; dirty ranges are merged too, so extract/clear stay exact. */
+enum { LH_MERGE_ALLREDUCE = 0, LH_MERGE_REDUCE_SCATTER = 1 };
+int lh_snapshot_merge(lh_snapshot *s, void *comm, int nranks, int rank, int plan, uint32_t nrows,
+                      uint32_t *first_owned, uint32_t *last_owned);
+/* Path (or soname) of the RCCL shared object the communicator comes from; default "librccl.so".
+ * Process-wide; call before the first lh_snapshot_merge. */
+int lh_set_rccl_library(const char *path);
 /* Stream on which the snapshot's extract/clear work is ordered (hipStream_t). */
 int lh_snapshot_stream(lh_snapshot *s, void **stream);
 /* Returns the snapshot's buffer to the pool (cleared asynchronously). */

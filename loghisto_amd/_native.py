@@ -67,6 +67,8 @@ SIGNATURES = {
     "lh_snapshot_rows": (C.c_int, [_vp, C.POINTER(_vp), _u32p]),
     "lh_snapshot_ranges": (C.c_int, [_vp, C.POINTER(_vp)]),
     "lh_snapshot_mark_dirty": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "lh_snapshot_merge": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_uint32, _u32p, _u32p]),
+    "lh_set_rccl_library": (C.c_int, [C.c_char_p]),
     "lh_snapshot_stream": (C.c_int, [_vp, C.POINTER(_vp)]),
     "lh_release": (C.c_int, [_vp]),
     "lh_get_counters": (C.c_int, [_vp, C.POINTER(LhCounters)]),

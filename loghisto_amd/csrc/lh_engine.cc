@@ -16,6 +16,9 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <dlfcn.h>
+
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstring>
@@ -838,6 +841,127 @@ int lh_snapshot_mark_dirty(lh_snapshot *s, uint32_t first_row, uint32_t nrows, u
     int rc = use_device(e);
     if (rc) return rc;
     HIPCHK(lh::launch_mark_dirty(e->bufs[(size_t)s->buf].ranges, first_row, nrows, lo_bin, hi_bin, e->xstream));
+    return LH_OK;
+}
+
+// ---- K4: RCCL merge ------------------------------------------------------------------------------
+namespace {
+// The few RCCL entry points K4 needs, resolved at run time from the caller's RCCL (no link-time
+// dependency: single-GPU users never load it).  Enum values are NCCL's stable public ABI.
+typedef int (*nccl_allreduce_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
+typedef int (*nccl_reducescatter_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
+constexpr int kNcclUint32 = 3, kNcclUint64 = 5, kNcclSum = 0, kNcclMin = 3;
+std::mutex g_rccl_mu;
+std::string g_rccl_path = "librccl.so";
+void *g_rccl_handle = nullptr;
+nccl_allreduce_fn g_allreduce = nullptr;
+nccl_reducescatter_fn g_reducescatter = nullptr;
+
+int rccl_resolve()
+{
+    std::lock_guard<std::mutex> g(g_rccl_mu);
+    if (g_allreduce && g_reducescatter) return LH_OK;
+    g_rccl_handle = dlopen(g_rccl_path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!g_rccl_handle) {
+        std::snprintf(g_last_error, sizeof(g_last_error), "dlopen(%s): %s", g_rccl_path.c_str(), dlerror());
+        return LH_EDEVICE;
+    }
+    g_allreduce = reinterpret_cast<nccl_allreduce_fn>(dlsym(g_rccl_handle, "ncclAllReduce"));
+    g_reducescatter = reinterpret_cast<nccl_reducescatter_fn>(dlsym(g_rccl_handle, "ncclReduceScatter"));
+    if (!g_allreduce || !g_reducescatter) {
+        std::snprintf(g_last_error, sizeof(g_last_error), "%s lacks ncclAllReduce/ncclReduceScatter", g_rccl_path.c_str());
+        return LH_EDEVICE;
+    }
+    return LH_OK;
+}
+
+#define NCCLCHK(expr)                                                                          \
+    do {                                                                                       \
+        const int _r = (expr);                                                                 \
+        if (_r != 0) {                                                                         \
+            std::snprintf(g_last_error, sizeof(g_last_error), "%s: RCCL error %d", #expr, _r); \
+            return LH_EDEVICE;                                                                 \
+        }                                                                                      \
+    } while (0)
+} // namespace
+
+int lh_set_rccl_library(const char *path)
+{
+    if (!path || !*path) return LH_EINVAL;
+    std::lock_guard<std::mutex> g(g_rccl_mu);
+    if (g_allreduce) return LH_ESTATE; // already resolved
+    g_rccl_path = path;
+    return LH_OK;
+}
+
+int lh_snapshot_merge(lh_snapshot *s, void *comm, int nranks, int rank, int plan, uint32_t nrows,
+                      uint32_t *first_owned, uint32_t *last_owned)
+{
+    if (!s || !comm || nranks < 1 || rank < 0 || rank >= nranks || nrows == 0) return LH_EINVAL;
+    if (plan != LH_MERGE_ALLREDUCE && plan != LH_MERGE_REDUCE_SCATTER) return LH_EINVAL;
+    lh_engine *e = s->e;
+    if (nrows > e->cfg.max_metrics) return LH_EINVAL;
+    int rc = use_device(e);
+    if (rc) return rc;
+    rc = rccl_resolve();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(e->xmu);
+    EpochBuffer &b = e->bufs[(size_t)s->buf];
+    hipStream_t st = e->xstream;
+    const uint32_t per = (nrows + (uint32_t)nranks - 1) / (uint32_t)nranks;
+    uint32_t own_lo = 0, own_hi = nrows;
+    if (plan == LH_MERGE_REDUCE_SCATTER) {
+        own_lo = std::min<uint32_t>((uint32_t)rank * per, nrows);
+        own_hi = std::min<uint32_t>(own_lo + per, nrows);
+    }
+    if (first_owned) *first_owned = own_lo;
+    if (last_owned) *last_owned = own_hi;
+
+    // 1. dirty ranges: min(lo), max(hi) over the ranks with ONE MIN all-reduce on (lo, ~hi)
+    const size_t rbytes = (size_t)nrows * 2 * sizeof(uint32_t);
+    rc = ensure_xbuf(e, rbytes);
+    if (rc) return rc;
+    uint32_t *d_tmp = reinterpret_cast<uint32_t *>(e->d_xbuf);
+    HIPCHK(lh::launch_ranges_flip_hi(d_tmp, b.ranges, nrows, st));
+    NCCLCHK(g_allreduce(d_tmp, d_tmp, (size_t)nrows * 2, kNcclUint32, kNcclMin, comm, st));
+    HIPCHK(lh::launch_ranges_flip_hi(b.ranges, d_tmp, nrows, st)); // (lo, ~~hi) back in place
+    HIPCHK(hipMemcpyAsync(e->h_xbuf, b.ranges, rbytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const uint32_t *hr = reinterpret_cast<const uint32_t *>(e->h_xbuf);
+    uint32_t wlo = LH_NKEYS, whi = 0;
+    for (uint32_t r = 0; r < nrows; r++) {
+        if (hr[2 * r] <= hr[2 * r + 1]) {
+            wlo = std::min(wlo, hr[2 * r]);
+            whi = std::max(whi, hr[2 * r + 1]);
+        }
+    }
+    if (wlo > whi) return LH_OK; // nothing anywhere (every rank computes the same window: no hang)
+    const uint32_t width = whi - wlo + 1;
+
+    // 2. the window of the bucket matrix
+    if (plan == LH_MERGE_ALLREDUCE) {
+        if (nrows == 1) { // contiguous in place
+            uint64_t *p = b.counts + wlo;
+            NCCLCHK(g_allreduce(p, p, width, kNcclUint64, kNcclSum, comm, st));
+            return LH_OK;
+        }
+        const size_t bytes = (size_t)nrows * width * sizeof(uint64_t);
+        rc = ensure_xbuf(e, bytes);
+        if (rc) return rc;
+        uint64_t *buf = reinterpret_cast<uint64_t *>(e->d_xbuf);
+        HIPCHK(lh::launch_pack_window(b.counts, buf, nrows, nrows, wlo, width, st));
+        NCCLCHK(g_allreduce(buf, buf, (size_t)nrows * width, kNcclUint64, kNcclSum, comm, st));
+        HIPCHK(lh::launch_unpack_window(b.counts, buf, 0, nrows, wlo, width, st));
+        return LH_OK;
+    }
+    // reduce-scatter by contiguous name blocks, padded to nranks*per rows
+    const size_t send_elems = (size_t)nranks * per * width, recv_elems = (size_t)per * width;
+    rc = ensure_xbuf(e, (send_elems + recv_elems) * sizeof(uint64_t));
+    if (rc) return rc;
+    uint64_t *send = reinterpret_cast<uint64_t *>(e->d_xbuf), *recv = send + send_elems;
+    HIPCHK(lh::launch_pack_window(b.counts, send, nrows, (uint32_t)nranks * per, wlo, width, st));
+    NCCLCHK(g_reducescatter(send, recv, recv_elems, kNcclUint64, kNcclSum, comm, st));
+    HIPCHK(lh::launch_unpack_window(b.counts, recv, own_lo, own_hi - own_lo, wlo, width, st));
     return LH_OK;
 }
 

@@ -54,6 +54,13 @@ hipError_t launch_count_cells(const uint64_t *counts, const uint32_t *ranges, ui
 hipError_t launch_compact_cells(const uint64_t *counts, const uint32_t *ranges, uint32_t nmetrics,
                                 const uint64_t *offsets, int16_t *keys, uint64_t *vals, hipStream_t s);
 
+// K4 helpers (multi-GPU merge): the collective itself is RCCL, called from lh_engine.cc.
+hipError_t launch_ranges_flip_hi(uint32_t *dst, const uint32_t *src, uint32_t nrows, hipStream_t s);
+hipError_t launch_pack_window(const uint64_t *counts, uint64_t *buf, uint32_t nrows, uint32_t prows, uint32_t wlo,
+                              uint32_t width, hipStream_t s);
+hipError_t launch_unpack_window(uint64_t *counts, const uint64_t *buf, uint32_t first_row, uint32_t nrows_out,
+                                uint32_t wlo, uint32_t width, hipStream_t s);
+
 // K3: clear the dirty span of every row and reset the ranges.
 hipError_t launch_clear(uint64_t *counts, uint32_t *ranges, uint32_t nmetrics, hipStream_t s);
 hipError_t launch_init_ranges(uint32_t *ranges, uint32_t nmetrics, hipStream_t s);

@@ -537,6 +537,60 @@ hipError_t launch_compact_cells(const uint64_t *counts, const uint32_t *ranges, 
 }
 
 // ---------------------------------------------------------------------------
+// K4 helpers: pack / unpack for the multi-GPU merge (the collective itself is RCCL, lh_engine.cc)
+// ---------------------------------------------------------------------------
+// ranges (lo, hi) -> (lo, ~hi): one MIN all-reduce then yields min(lo) and max(hi)
+__global__ void k_ranges_flip_hi(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint32_t nrows)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nrows) { dst[2 * (size_t)i] = src[2 * (size_t)i]; dst[2 * (size_t)i + 1] = ~src[2 * (size_t)i + 1]; }
+}
+
+// window [wlo, wlo+width) of rows [0, nrows) <-> dense [prows][width] buffer (rows >= nrows are zero padding)
+__global__ void k_pack_window(const uint64_t *__restrict__ counts, uint64_t *__restrict__ buf, uint32_t nrows,
+                              uint32_t prows, uint32_t wlo, uint32_t width)
+{
+    const size_t total = (size_t)prows * width;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t r = (uint32_t)(i / width), c = (uint32_t)(i % width);
+        buf[i] = r < nrows ? counts[(size_t)r * LH_NKEYS + wlo + c] : 0ull;
+    }
+}
+
+__global__ void k_unpack_window(uint64_t *__restrict__ counts, const uint64_t *__restrict__ buf, uint32_t first_row,
+                                uint32_t nrows_out, uint32_t wlo, uint32_t width)
+{
+    const size_t total = (size_t)nrows_out * width;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t r = (uint32_t)(i / width), c = (uint32_t)(i % width);
+        counts[(size_t)(first_row + r) * LH_NKEYS + wlo + c] = buf[i];
+    }
+}
+
+hipError_t launch_ranges_flip_hi(uint32_t *dst, const uint32_t *src, uint32_t nrows, hipStream_t s)
+{
+    if (!nrows) return hipSuccess;
+    hipLaunchKernelGGL(k_ranges_flip_hi, dim3((nrows + 255) / 256), dim3(256), 0, s, dst, src, nrows);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_window(const uint64_t *counts, uint64_t *buf, uint32_t nrows, uint32_t prows, uint32_t wlo,
+                              uint32_t width, hipStream_t s)
+{
+    if (!prows || !width) return hipSuccess;
+    hipLaunchKernelGGL(k_pack_window, dim3(2048), dim3(256), 0, s, counts, buf, nrows, prows, wlo, width);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack_window(uint64_t *counts, const uint64_t *buf, uint32_t first_row, uint32_t nrows_out,
+                                uint32_t wlo, uint32_t width, hipStream_t s)
+{
+    if (!nrows_out || !width) return hipSuccess;
+    hipLaunchKernelGGL(k_unpack_window, dim3(2048), dim3(256), 0, s, counts, buf, first_row, nrows_out, wlo, width);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // K3 clear / ranges
 // ---------------------------------------------------------------------------
 constexpr int K3_SPLIT = 8; // blocks per row; each owns 8192 bins

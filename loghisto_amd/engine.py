@@ -112,6 +112,15 @@ class Snapshot:
     def mark_dirty(self, first_row: int, nrows: int, lo_bin: int = 0, hi_bin: int = N.NKEYS - 1):
         N.check(N.lib().lh_snapshot_mark_dirty(self._h, first_row, nrows, lo_bin, hi_bin), "lh_snapshot_mark_dirty")
 
+    def merge_rccl(self, comm: int, nranks: int, rank: int, nrows: int, plan: str = "allreduce"):
+        """K4 through the C ABI: RCCL merge on the snapshot's stream (comm = ncclComm_t as int).
+        Returns the [first, last) rows that hold merged data on this rank."""
+        first, last = C.c_uint32(0), C.c_uint32(0)
+        N.check(N.lib().lh_snapshot_merge(self._h, C.c_void_p(comm), nranks, rank,
+                                          0 if plan == "allreduce" else 1, nrows, C.byref(first), C.byref(last)),
+                "lh_snapshot_merge")
+        return int(first.value), int(last.value)
+
     def stream(self) -> int:
         p = C.c_void_p(0)
         N.check(N.lib().lh_snapshot_stream(self._h, C.byref(p)), "lh_snapshot_stream")

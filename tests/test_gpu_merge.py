@@ -62,3 +62,61 @@ def test_merge_snapshot_single_rank_rccl(native_lib, torch_cuda):
                 snap.release()
     finally:
         dist.destroy_process_group()
+
+
+def test_native_rccl_merge_through_the_c_abi(native_lib, torch_cuda):
+    """K4 without torch.distributed: lh_snapshot_merge drives RCCL directly (what a cgo caller would use).
+    One GPU is reachable, so the communicator has a single rank; that still runs the whole path --
+    range merge through the bit-flipped MIN all-reduce, window pack / collective / unpack for both plans --
+    and must leave the cells exactly as they were."""
+    import ctypes as C
+    torch = torch_cuda
+    import loghisto_amd
+    from loghisto_amd import _native
+
+    rccl_path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    if not os.path.exists(rccl_path):
+        rccl_path = "/opt/rocm/lib/librccl.so"
+    rc = _native.lib().lh_set_rccl_library(rccl_path.encode())
+    assert rc in (0, 7)          # 7: already resolved by an earlier test in this process
+    rccl = C.CDLL(rccl_path)
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p(0)
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        M = 5
+        rng = np.random.default_rng(12)
+        n = 400_000
+        ids = rng.integers(0, M, n).astype(np.uint32)
+        ids[ids == 3] = 1                          # row 3 stays empty
+        v = rng.normal(0, 1e4, n)                  # signed: window spans both sides of key 0
+        want = oracle.histogram_pairs(ids, v, M)
+        with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as eng:
+            eng.submit_pairs(ids, v)
+            snap = eng.flip()
+            assert snap.merge_rccl(comm.value, 1, 0, M, plan="allreduce") == (0, M)
+            assert snap.merge_rccl(comm.value, 1, 0, M, plan="reduce_scatter") == (0, M)
+            assert snap.merge_rccl(comm.value, 1, 0, 1, plan="allreduce") == (0, 1)   # single-row in-place form
+            got = snap.extract([0.0, 0.5, 1.0], M)
+            for m in range(M):
+                assert np.array_equal(snap.dense_row(m), want[m]), m
+                ref = oracle.process_dense(want[m], [0.0, 0.5, 1.0])
+                assert int(got["count"][m]) == ref["count"]
+                if ref["count"]:
+                    assert np.array_equal(got["pkeys"][m], ref["pkeys"])
+            snap.release()
+            # an empty snapshot: every rank sees an empty window and returns without a collective
+            snap = eng.flip()
+            assert snap.merge_rccl(comm.value, 1, 0, M, plan="reduce_scatter") == (0, M)
+            assert snap.extract([0.5], M)["count"].sum() == 0
+            snap.release()
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
