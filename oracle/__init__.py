@@ -63,6 +63,8 @@ def lib():
         L.lho_bench_faithful.argtypes = [dp, C.c_size_t, C.c_int, u64p]
         L.lho_bench_dense.restype = C.c_double
         L.lho_bench_dense.argtypes = [dp, C.c_size_t, C.c_int, u64p]
+        L.lho_bench_dense_reps.restype = C.c_double
+        L.lho_bench_dense_reps.argtypes = [dp, C.c_size_t, C.c_int, C.c_int, u64p]
         _lib = L
     return _lib
 
@@ -177,6 +179,14 @@ def bench_faithful(v, threads: int):
     v = np.ascontiguousarray(v, dtype=np.float64)
     counts = np.zeros(NKEYS, dtype=np.uint64)
     s = lib().lho_bench_faithful(_dp(v), v.size, threads, _u64p(counts))
+    return s, counts
+
+
+def bench_dense_reps(v, threads: int, reps: int):
+    """seconds, counts (== reps x the true row): every thread loops `reps` times over its slice."""
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    counts = np.zeros(NKEYS, dtype=np.uint64)
+    s = lib().lho_bench_dense_reps(_dp(v), v.size, threads, reps, _u64p(counts))
     return s, counts
 
 

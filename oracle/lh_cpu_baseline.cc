@@ -95,6 +95,32 @@ double lho_bench_faithful(const double *v, size_t n, int threads, uint64_t *coun
     return t1 - t0;
 }
 
+// Same as lho_bench_dense but every thread passes `reps` times over its slice inside the timed region, so
+// that thread start-up and the final merge do not dominate on many-core hosts.  counts_out receives
+// reps x the true row.
+double lho_bench_dense_reps(const double *v, size_t n, int threads, int reps, uint64_t *counts_out)
+{
+    if (threads < 1) threads = 1;
+    if (reps < 1) reps = 1;
+    std::vector<std::vector<uint64_t>> rows((size_t)threads, std::vector<uint64_t>(LHO_NKEYS, 0));
+    std::vector<std::thread> th;
+    double t0 = now_s();
+    for (int t = 0; t < threads; t++) {
+        size_t lo = n * (size_t)t / (size_t)threads, hi = n * (size_t)(t + 1) / (size_t)threads;
+        th.emplace_back([&, t, lo, hi] {
+            for (int r = 0; r < reps; r++) lho_histogram_dense(v + lo, hi - lo, rows[(size_t)t].data());
+        });
+    }
+    for (auto &x : th) x.join();
+    if (counts_out) {
+        std::memset(counts_out, 0, sizeof(uint64_t) * LHO_NKEYS);
+        for (auto &r : rows)
+            for (size_t b = 0; b < LHO_NKEYS; b++) counts_out[b] += r[b];
+    }
+    double t1 = now_s();
+    return t1 - t0;
+}
+
 double lho_bench_dense(const double *v, size_t n, int threads, uint64_t *counts_out)
 {
     if (threads < 1) threads = 1;
