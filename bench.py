@@ -71,10 +71,33 @@ def make_samples(n: int, kind: str, seed: int) -> torch.Tensor:
     return v.mul_(sigma).add_(math.log(1e5)).exp_()
 
 
+def effective_cores() -> int:
+    """Cores this process may actually use: min(cpu_count, affinity mask, cgroup CPU quota).
+    (The MI355X box reports 256 CPUs but its cgroup grants 16: threads beyond that only time-slice.)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]       # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(math.ceil(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())             # cgroup v1
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, int(math.ceil(q / p))))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(samples: torch.Tensor, target_s: float):
     """Oracle timed on this box's host cores (bounded sample of the same workload)."""
     import oracle
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     probe = samples[: 1 << 21].cpu().numpy()
     t1, _ = oracle.bench_dense(probe, 1)
     rate1 = probe.size / max(t1, 1e-9)                       # one core
@@ -82,7 +105,7 @@ def cpu_baseline(samples: torch.Tensor, target_s: float):
     host = samples[:n].cpu().numpy()
     # every thread passes `reps` times over its slice so that thread start-up and the final merge do not
     # dominate on a many-core host: about target_s seconds of wall time if the cores scaled perfectly / 4
-    reps = int(max(1, min(256, target_s * rate1 * cores / 4 / n)))
+    reps = int(max(1, min(256, target_s * rate1 * cores / 2 / n)))
     t, counts = oracle.bench_dense_reps(host, cores, reps)
     assert int(counts.sum()) == n * reps and not (counts % reps).any()
     counts = counts // reps
@@ -95,7 +118,8 @@ def cpu_baseline(samples: torch.Tensor, target_s: float):
         "value": n_timed / t, "unit": "samples/s", "cores": cores, "kind": "port",
         "sample": f"first {n} samples of the step's stream, {reps} passes per thread ({t:.2f} s wall); C oracle "
                   f"(Go math.Log restated), per-thread dense uint64[65536] rows + merge (BASELINE.md form B), "
-                  f"{cores} threads; one thread alone: {rate1:.3g} samples/s",
+                  f"{cores} threads = the cores this process is granted (host reports {os.cpu_count()} CPUs); "
+                  f"one thread alone: {rate1:.3g} samples/s",
         "faithful_form": {"value": na / ta, "cores": cores, "value_1thread": (na // 4) / ta1,
                           "sample": f"{na} samples; shared lock + map[name][int16] + atomic per call "
                                     "(cost shape of metrics.go:273-295, BASELINE.md form A)"},

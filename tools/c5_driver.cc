@@ -22,6 +22,21 @@
 using namespace loghisto;
 using Clock = std::chrono::steady_clock;
 
+// cores this process may actually use: the cgroup quota can be far below hardware_concurrency()
+// (the MI355X box reports 256 CPUs and grants 16; threads beyond the quota only time-slice)
+static unsigned granted_cores()
+{
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64];
+        long period = 0;
+        if (std::fscanf(f, "%63s %ld", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0)
+            n = std::min<unsigned>(n, (unsigned)std::max(1L, (std::atol(q) + period - 1) / period));
+        std::fclose(f);
+    }
+    return n;
+}
+
 static double arg_d(int argc, char **argv, const char *key, double def)
 {
     for (int i = 1; i + 1 < argc; i++)
@@ -96,7 +111,7 @@ static bool submit_tcp(int port, const std::string &req) // submitter.go:106-116
 
 int main(int argc, char **argv)
 {
-    const int T = (int)arg_d(argc, argv, "--threads", std::max(1u, std::thread::hardware_concurrency() / 2));
+    const int T = (int)arg_d(argc, argv, "--threads", std::max(1u, granted_cores() - 2)); // leave room for reaper, submitter, sink
     const double seconds = arg_d(argc, argv, "--seconds", 10);
     const double target = arg_d(argc, argv, "--rate", 100e6); // events/s over all threads; 0 = unthrottled
     const int NH = (int)arg_d(argc, argv, "--hist-names", 1024), NT = 256, NC = 256;
