@@ -30,6 +30,7 @@
 #include <atomic>
 #include "lh_windows.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace lh {
@@ -62,7 +63,11 @@ static uint32_t ilog2_ceil(uint32_t x)
 static bool make_plan(size_t n, uint32_t nmetrics, int num_cus, PartPlan &P)
 {
     if (n < PART_MIN_SAMPLES || n > (size_t(1) << 31) || nmetrics < 2) return false;
-    uint32_t want_np = (nmetrics + 3) / 4;
+    // names per partition: 4 gives every name a 4 096-bin LDS window in P2.  LH_PART_NAMES (tuning only)
+    // overrides it: fewer partitions mean longer contiguous runs in P1 but narrower windows in P2.
+    static const uint32_t names_per_part =
+        getenv("LH_PART_NAMES") ? (uint32_t)std::max(1, atoi(getenv("LH_PART_NAMES"))) : 4u;
+    uint32_t want_np = (nmetrics + names_per_part - 1) / names_per_part;
     P.log_np = ilog2_ceil(want_np);
     if (P.log_np > 8) P.log_np = 8;
     P.np = 1u << P.log_np;
