@@ -276,6 +276,16 @@ __global__ __launch_bounds__(P1_BLOCK, 6) void k_part_scatter(const uint32_t *__
 
         // copy out: whole lines to HBM, the remainder of each partition into its staging line
         const uint32_t tile_total = s_total;
+        if (dbg & 8u) {
+            // TIMING-ONLY ablation (results are wrong): the same number of bytes leaves the CU as one 16-B store
+            // per lane instead of four 4-B stores, to tell store-issue cost from store-bandwidth cost
+            for (uint32_t i4 = tid * 4; i4 + 3 < tile_total; i4 += P1_BLOCK * 4) {
+                const pu4_t r4 = *reinterpret_cast<const pu4_t *>(&s_sorted[i4]);
+                const pu4_t t = s_tbl[r4.x >> 24];
+                const uint32_t dst = ((i4 < t.z ? t.x : t.y) + i4) & ~3u;
+                *reinterpret_cast<pu4_t *>(&records[dst]) = r4;
+            }
+        } else
         for (uint32_t i = tid; i < tile_total; i += P1_BLOCK) {
             const uint32_t r = s_sorted[i];
             const pu4_t t = s_tbl[r >> 24];
