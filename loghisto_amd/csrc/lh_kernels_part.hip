@@ -9,48 +9,56 @@
 // ~12 ns), i.e. ~1 % of the HBM roofline.  So the stream is PARTITIONED BY NAME first
 // and each partition is then reduced in LDS:
 //
-//   P1  k_part_scatter : read (id, v) [12 B], compress on the fly, emit a 4-byte record
-//                        (local name id << 16 | bin) into the chunk list of partition
-//                        id % NP.  Tile-local counting sort in LDS so that every
-//                        partition's records leave the CU as one contiguous run;
-//                        chunks (1 024 records) come from a workgroup-private pool, so
-//                        the hot loop has no global atomics at all.
-//   plan k_plan_*      : group the ~n/1024 chunk descriptors by partition and cut them
-//                        into <= 1 024 equal work slots (three tiny kernels).
+//   P1  k_scatter_samples : read (id, v) [12 B], compress on the fly, emit a 4-byte record
+//                        (partition << 24 | local name << 16 | bin) into the chunk list of
+//                        partition id % 256.  Tile-local counting sort in LDS so that every
+//                        partition's records leave the CU as contiguous, line-buffered runs;
+//                        chunks (1 024 records) come from a workgroup-private pool, so the
+//                        hot loop has no global atomics at all.
+//   plan k_plan_*      : group the chunk descriptors by partition and cut them into equal
+//                        work slots (three tiny kernels).
+//   P1b k_scatter_records (only above 1 024 names): the same scatter once more, on the 4-byte
+//                        records of each level-1 slot, by the next bits of the name id -- up
+//                        to 64 sub-partitions, 16 384 partitions in all -- so that P2 again
+//                        sees at most 4 names per partition.  +8 B/sample of traffic.
 //   P2  k_part_hist    : one workgroup per slot: LDS windows (uint32) for the few names
 //                        of that partition, ds_add per record, then ONE uint64 global
 //                        atomic per occupied cell at flush.
 //
-// HBM traffic: 12 (read) + 4 (write) + 4 (read) = 20 B/sample against 12 B algorithmic.
-// Everything is exact: records carry the exact bin; out-of-window records and small
-// launches fall back to direct global atomics.
+// HBM traffic: 12 (read) + 4 (write) + 4 (read) = 20 B/sample against 12 B algorithmic
+// (28 B/sample with the second level).  Everything is exact: records carry the exact bin;
+// out-of-window records and small launches fall back to direct global atomics.
 #include "lh_kernels.h"
 #include "lh_codec.h"
-
-#include <atomic>
 #include "lh_windows.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 namespace lh {
 
-constexpr int NPMAX = 256;             // partitions (power of two, <= 256)
+constexpr int NPMAX = 256;             // partitions per scatter pass (power of two, <= 256)
+constexpr uint32_t NQMAX = 16384;      // partitions after the second level
 constexpr uint32_t CHUNK = 1024;       // records per chunk (4 KiB)
 constexpr int P1_BLOCK = 512;          // 8 waves; three workgroups per CU (measured: 1024x4 is 10 % slower)
 constexpr int P1_SPT = 8;              // samples per thread per tile
 constexpr int P1_TILE = P1_BLOCK * P1_SPT;
 constexpr uint32_t INVALID = 0xffffffffu;
-constexpr int P2_BLOCK = 1024;           // 16 waves: two workgroups (64 KiB windows each) fill a CU
+constexpr int P2_BLOCK = 1024;         // 16 waves: two workgroups (64 KiB windows each) fill a CU
 constexpr uint32_t P2_WINWORDS = 16384; // 64 KiB of uint32 windows per workgroup
-constexpr uint32_t P2_SLOTS = 1024;  // work slots of P2 (measured: 768 is 25 % slower, fewer waves in flight)
+constexpr uint32_t SLOT_EXTRA = 1024;  // work slots beyond one per partition (measured: 512 is 25 % slower)
 constexpr size_t PART_MIN_SAMPLES = 131072;
 constexpr uint32_t PART_MAX_MPP = 256;
+// chunk descriptor: partition tag << 11 | records in the chunk (1..1024); INVALID = unused
+constexpr uint32_t CD_SHIFT = 11, CD_MASK = (1u << CD_SHIFT) - 1;
 
 struct PartPlan {
-    uint32_t log_np, np, mpp, log_w;
-    uint32_t g1, chunks_per_wg, nchunks;
-    size_t off_records, off_cdesc, off_sorted, off_small, total;
+    uint32_t log_np, np, mpp;          // level 1: partitions, names per partition
+    uint32_t log_ns, ns;               // level 2: sub-partitions per partition (1 = no second level)
+    uint32_t log_nq, nq, mpp2, log_w;  // what P2 sees
+    uint32_t g1, chunks_per_wg, nchunks1, nchunks2;
+    size_t off_rec1, off_cd1, off_sorted1, off_small1, off_rec2, off_cd2, off_sorted2, off_small2, total;
 };
 
 static uint32_t ilog2_ceil(uint32_t x)
@@ -60,22 +68,34 @@ static uint32_t ilog2_ceil(uint32_t x)
     return l;
 }
 
+// words of the "small" region of one level: pc, part_start, cursor [nq each], slots [3 x (nq + SLOT_EXTRA)],
+// nslots [1], pool_start [nq + SLOT_EXTRA + 1]
+static size_t small_words(uint32_t nq) { return (size_t)3 * nq + 3 * (nq + SLOT_EXTRA) + 1 + (nq + SLOT_EXTRA + 1) + 16; }
+
 static bool make_plan(size_t n, uint32_t nmetrics, int num_cus, PartPlan &P)
 {
     if (n < PART_MIN_SAMPLES || n > (size_t(1) << 31) || nmetrics < 2) return false;
     // names per partition: 4 gives every name a 4 096-bin LDS window in P2.  LH_PART_NAMES (tuning only)
-    // overrides it: fewer partitions mean longer contiguous runs in P1 but narrower windows in P2.
+    // overrides it: fewer partitions mean longer contiguous runs in P1 but narrower windows in P2
+    // (measured at 1 024 names, profiles/r01c: 4 is the best overall).
     static const uint32_t names_per_part =
         getenv("LH_PART_NAMES") ? (uint32_t)std::max(1, atoi(getenv("LH_PART_NAMES"))) : 4u;
-    uint32_t want_np = (nmetrics + names_per_part - 1) / names_per_part;
-    P.log_np = ilog2_ceil(want_np);
-    if (P.log_np > 8) P.log_np = 8;
+    static const bool two_level = !(getenv("LH_PART_ONE_LEVEL") && atoi(getenv("LH_PART_ONE_LEVEL")));
+    const uint32_t want_np = (nmetrics + names_per_part - 1) / names_per_part;
+    P.log_np = std::min(8u, ilog2_ceil(want_np));
     P.np = 1u << P.log_np;
     P.mpp = (nmetrics + P.np - 1) >> P.log_np;
     if (P.mpp > PART_MAX_MPP) return false;
+    P.log_ns = 0;
+    if (two_level && P.mpp > names_per_part)
+        P.log_ns = std::min(6u, ilog2_ceil((P.mpp + names_per_part - 1) / names_per_part));
+    P.ns = 1u << P.log_ns;
+    P.log_nq = P.log_np + P.log_ns;
+    P.nq = 1u << P.log_nq;
+    P.mpp2 = (P.mpp + P.ns - 1) >> P.log_ns;
     uint32_t lw = 0;
-    while ((P.mpp << (lw + 1)) <= P2_WINWORDS) lw++;
-    P.log_w = lw; // window = 2^log_w bins per name, mpp * window <= 16384
+    while ((P.mpp2 << (lw + 1)) <= P2_WINWORDS) lw++;
+    P.log_w = lw; // window = 2^log_w bins per name, mpp2 * window <= 16384
     const size_t ntiles = (n + P1_TILE - 1) / P1_TILE;
     size_t g1 = (size_t)num_cus * 3; // ~44 KiB LDS per workgroup: three 512-thread workgroups per CU
     // every workgroup strands up to NP partially filled chunks (1 MiB at NP = 256): give a workgroup
@@ -85,13 +105,19 @@ static bool make_plan(size_t n, uint32_t nmetrics, int num_cus, PartPlan &P)
     P.g1 = (uint32_t)g1;
     const size_t tiles_per_wg = (ntiles + g1 - 1) / g1;
     P.chunks_per_wg = (uint32_t)(tiles_per_wg * (P1_TILE / CHUNK) + P.np + 1);
-    P.nchunks = P.g1 * P.chunks_per_wg;
+    P.nchunks1 = P.g1 * P.chunks_per_wg;
+    // level 2: every level-1 slot re-scatters its chunks into <= cnt + ns + 1 chunks
+    P.nchunks2 = P.log_ns ? P.nchunks1 + (P.np + SLOT_EXTRA) * (P.ns + 1) : 0;
     size_t o = 0;
-    P.off_records = o; o += (size_t)P.nchunks * CHUNK * sizeof(uint32_t);
-    P.off_cdesc = o; o += (size_t)P.nchunks * sizeof(uint32_t);
-    P.off_sorted = o; o += (size_t)P.nchunks * sizeof(uint32_t);
-    o = (o + 255) & ~size_t(255);
-    P.off_small = o; o += (3 * NPMAX + 3 * P2_SLOTS + 64) * sizeof(uint32_t);
+    auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~size_t(255); return at; };
+    P.off_rec1 = take((size_t)P.nchunks1 * CHUNK * sizeof(uint32_t));
+    P.off_cd1 = take((size_t)P.nchunks1 * sizeof(uint32_t));
+    P.off_sorted1 = take((size_t)P.nchunks1 * sizeof(uint32_t));
+    P.off_small1 = take(small_words(P.np) * sizeof(uint32_t));
+    P.off_rec2 = take((size_t)P.nchunks2 * CHUNK * sizeof(uint32_t));
+    P.off_cd2 = take((size_t)P.nchunks2 * sizeof(uint32_t));
+    P.off_sorted2 = take((size_t)P.nchunks2 * sizeof(uint32_t));
+    P.off_small2 = take(P.log_ns ? small_words(P.nq) * sizeof(uint32_t) : 0);
     P.total = o;
     return true;
 }
@@ -108,46 +134,197 @@ size_t part_scratch_bytes(size_t n, uint32_t nmetrics, int num_cus)
 }
 
 // ---------------------------------------------------------------------------
-// P1: compress + partition scatter
+// Scatter machinery shared by P1 (samples) and P1b (records)
 // ---------------------------------------------------------------------------
 typedef double pd2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t pu2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t pu4_t __attribute__((ext_vector_type(4)));
 
-// Record format (4 bytes): partition << 24 | local name id << 16 | bin.
-// ids must be 8-byte and v 16-byte aligned (the launcher checks).
-//
 // Write-out is LINE-BUFFERED: measured, letting each tile emit its ~16-record (64 B) runs directly
 // costs 2.8 ms of a 5.0 ms kernel and 1.6x write amplification (partial lines evicted before their
-// other half arrives).  So every partition owns one 128-byte staging line in LDS; a tile emits only
-// whole, aligned lines (staged leftovers + new records) and keeps the remainder staged.
+// other half arrives).  So every partition owns one staging line in LDS; a tile emits only whole,
+// aligned lines (staged leftovers + new records) and keeps the remainder staged.
 constexpr uint32_t LINE = 16; // records per staged line (64 B, one aligned HBM sector pair)
 
-__global__ __launch_bounds__(P1_BLOCK, 6) void k_part_scatter(const uint32_t *__restrict__ ids,
-                                                           const double *__restrict__ v, size_t n,
-                                                           uint32_t nmetrics, uint32_t log_np,
-                                                           const double *__restrict__ Tx,
-                                                           uint32_t *__restrict__ records,
-                                                           uint32_t *__restrict__ cdesc, uint32_t chunks_per_wg,
-                                                           uint32_t *__restrict__ err, uint32_t dbg)
-{
-    __shared__ uint32_t s_cnt[NPMAX], s_off[NPMAX], s_cfill[NPMAX], s_cbase[NPMAX];
-    __shared__ uint32_t s_sf[NPMAX];             // records currently staged per partition (< LINE)
-    __shared__ uint32_t s_d1[NPMAX], s_n1[NPMAX]; // this tile: global index / count of the staged records to emit
+struct ScatterLds {
+    uint32_t cnt[NPMAX], off[NPMAX], cfill[NPMAX], cbase[NPMAX];
+    uint32_t sf[NPMAX];             // records currently staged per partition (< LINE)
+    uint32_t d1[NPMAX], n1[NPMAX];  // this tile: global index / count of the staged records to emit
     // per partition, for sorted position i:  i < E ? global[(i < T ? A : B) + i] : stage[i - E + sf0]
     // packed as {A, B, T, E | sf0 << 16}
-    __shared__ __attribute__((aligned(16))) pu4_t s_tbl[NPMAX];
-    __shared__ uint32_t s_sorted[P1_TILE];
-    __shared__ uint32_t s_stage[NPMAX * LINE];
-    __shared__ uint32_t s_wsum[4];
-    __shared__ uint32_t s_pool_next, s_total;
+    pu4_t tbl[NPMAX];
+    uint32_t sorted[P1_TILE];
+    uint32_t stage[NPMAX * LINE];
+    uint32_t wsum[4];
+    uint32_t pool_next, total;
+};
 
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ void scatter_init(ScatterLds &L, uint32_t tid)
+{
+    if (tid < NPMAX) { L.cnt[tid] = 0; L.cfill[tid] = CHUNK; L.cbase[tid] = INVALID; L.sf[tid] = 0; L.d1[tid] = INVALID; }
+    if (tid == 0) L.pool_next = 0;
+}
+
+// Phases after the rank atomics of a tile: scan + chunk bookkeeping, tile-local counting sort, copy-out.
+// pr[j] = partition | rank << 8 (INVALID for an absent sample); rec[j] carries the partition in bits 24..31.
+// tag(p) = (p << tag_shift) | tag_base is the partition id written into chunk descriptors.
+// `prefetch` issues the next tile's loads; it runs right after the first barrier.
+template <class Prefetch>
+__device__ __forceinline__ void scatter_tile(ScatterLds &L, const uint32_t (&rec)[P1_SPT], const uint32_t (&pr)[P1_SPT],
+                                             uint32_t *__restrict__ records, uint32_t *__restrict__ cdesc,
+                                             uint32_t pool_base, uint32_t tag_shift, uint32_t tag_base, uint32_t dbg,
+                                             uint32_t tid, Prefetch prefetch)
+{
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    __syncthreads();
+    prefetch();
+
+    // exclusive scan of the per-partition counts + chunk bookkeeping (threads 0..255)
+    uint32_t c = 0, inc = 0;
+    if (tid < NPMAX) {
+        c = L.cnt[tid];
+        inc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(inc, d, 64);
+            if ((int)lane >= d) inc += y;
+        }
+        if (lane == 63) L.wsum[wave] = inc;
+    }
+    __syncthreads();
+    if (tid < NPMAX) {
+        uint32_t wbase = 0;
+        for (uint32_t w = 0; w < wave; w++) wbase += L.wsum[w];
+        const uint32_t off = wbase + inc - c;
+        L.off[tid] = off;
+        if (tid == NPMAX - 1) L.total = wbase + inc;
+        L.cnt[tid] = 0; // ranks are already in registers
+        L.d1[tid] = INVALID;
+        if (c) {
+            const uint32_t p = tid, tag = ((p << tag_shift) | tag_base) << CD_SHIFT;
+            const uint32_t sf = L.sf[p], cf = L.cfill[p], cb = L.cbase[p];
+            const uint32_t total = sf + c, nfull = total / LINE, out = nfull * LINE;
+            const uint32_t room = CHUNK - cf; // multiple of LINE (0 when there is no open chunk)
+            uint32_t first = 0;
+            if (out > room) {
+                const uint32_t over = out - room;
+                const uint32_t k = (over + CHUNK - 1) / CHUNK;
+                first = pool_base + atomicAdd(&L.pool_next, k);   // k consecutive chunks
+                if (cb != INVALID) cdesc[cb] = tag | CHUNK;        // the old chunk is now full
+                for (uint32_t q = 0; q + 1 < k; q++) cdesc[first + q] = tag | CHUNK;
+                L.cbase[p] = first + k - 1;
+                L.cfill[p] = over - (k - 1) * CHUNK;
+            } else {
+                L.cfill[p] = cf + out;
+            }
+            L.sf[p] = total - out;
+            // emitted element u = sf + (i - off) of this partition goes to
+            //   u < room : cb*CHUNK + cf + u            = A + i
+            //   else     : first*CHUNK + (u - room)      = B + i     (new chunks are consecutive)
+            pu4_t t;
+            t.x = cb * CHUNK + cf + sf - off;
+            t.y = first * CHUNK + sf - off - room;
+            t.z = room ? off + room - sf : off;
+            const uint32_t E = nfull ? off + out - sf : off;
+            t.w = E | ((nfull ? 0u : sf) << 16);
+            L.tbl[p] = t;
+            if (nfull && sf) {
+                L.d1[p] = room ? cb * CHUNK + cf : first * CHUNK;
+                L.n1[p] = sf;
+            }
+        }
+    }
+    __syncthreads();
+
+    // tile-local counting sort into LDS ...
+#pragma unroll
+    for (int j = 0; j < P1_SPT; j++) {
+        if (pr[j] != INVALID) L.sorted[L.off[pr[j] & 0xffu] + (pr[j] >> 8)] = rec[j];
+    }
+    // ... and, independently, the previously staged records of partitions that emit a line
+    if (!(dbg & 1u))
+        for (uint32_t e = tid; e < NPMAX * LINE; e += P1_BLOCK) {
+            const uint32_t p = e / LINE, u = e % LINE;
+            const uint32_t d = L.d1[p];
+            if (d != INVALID && u < L.n1[p]) records[d + u] = L.stage[e];
+        }
+    __syncthreads();
+
+    // copy out: whole lines to HBM, the remainder of each partition into its staging line
+    const uint32_t tile_total = L.total;
+    if (dbg & 8u) {
+        // TIMING-ONLY ablation (results are wrong): the same number of bytes leaves the CU as one 16-B store
+        // per lane instead of four 4-B stores, to tell store-issue cost from store-bandwidth cost
+        for (uint32_t i4 = tid * 4; i4 + 3 < tile_total; i4 += P1_BLOCK * 4) {
+            const pu4_t r4 = *reinterpret_cast<const pu4_t *>(&L.sorted[i4]);
+            const pu4_t t = L.tbl[r4.x >> 24];
+            const uint32_t dst = ((i4 < t.z ? t.x : t.y) + i4) & ~3u;
+            *reinterpret_cast<pu4_t *>(&records[dst]) = r4;
+        }
+    } else
+    for (uint32_t i = tid; i < tile_total; i += P1_BLOCK) {
+        const uint32_t r = L.sorted[i];
+        const pu4_t t = L.tbl[r >> 24];
+        const uint32_t E = t.w & 0xffffu;
+        if (i < E) {
+            if (!(dbg & 1u)) records[(i < t.z ? t.x : t.y) + i] = r;
+        } else {
+            L.stage[(r >> 24) * LINE + (i - E) + (t.w >> 16)] = r;
+        }
+    }
+    // (the next tile's first barrier separates this copy-out from the next bookkeeping)
+}
+
+// Drain: the staged remainders (one partial line per partition) and the open chunks' descriptors.
+__device__ __forceinline__ void scatter_drain(ScatterLds &L, uint32_t *__restrict__ records,
+                                              uint32_t *__restrict__ cdesc, uint32_t pool_base, uint32_t np,
+                                              uint32_t tag_shift, uint32_t tag_base, uint32_t tid)
+{
+    __syncthreads();
+    if (tid < NPMAX) {
+        L.d1[tid] = INVALID;
+        const uint32_t p = tid, sf = L.sf[p];
+        if (sf) {
+            uint32_t cf = L.cfill[p], cb = L.cbase[p];
+            if (cf == CHUNK) { // no open chunk, or it is exactly full
+                if (cb != INVALID) cdesc[cb] = (((p << tag_shift) | tag_base) << CD_SHIFT) | CHUNK;
+                cb = pool_base + atomicAdd(&L.pool_next, 1u);
+                cf = 0;
+                L.cbase[p] = cb;
+            }
+            L.d1[p] = cb * CHUNK + cf;
+            L.n1[p] = sf;
+            L.cfill[p] = cf + sf;
+        }
+    }
+    __syncthreads();
+    for (uint32_t e = tid; e < NPMAX * LINE; e += P1_BLOCK) {
+        const uint32_t p = e / LINE, u = e % LINE;
+        const uint32_t d = L.d1[p];
+        if (d != INVALID && u < L.n1[p]) records[d + u] = L.stage[e];
+    }
+    if (tid < np && L.cbase[tid] != INVALID)
+        cdesc[L.cbase[tid]] = (((tid << tag_shift) | tag_base) << CD_SHIFT) | L.cfill[tid];
+}
+
+// ---------------------------------------------------------------------------
+// P1: compress + partition scatter of (id, value) samples
+// Record format (4 bytes): partition << 24 | local name id << 16 | bin.
+// ids must be 8-byte and v 16-byte aligned (the launcher checks).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(P1_BLOCK, 6) void k_scatter_samples(const uint32_t *__restrict__ ids,
+                                                                 const double *__restrict__ v, size_t n,
+                                                                 uint32_t nmetrics, uint32_t log_np,
+                                                                 const double *__restrict__ Tx,
+                                                                 uint32_t *__restrict__ records,
+                                                                 uint32_t *__restrict__ cdesc, uint32_t chunks_per_wg,
+                                                                 uint32_t *__restrict__ err, uint32_t dbg)
+{
+    __shared__ __attribute__((aligned(16))) ScatterLds L;
+    const uint32_t tid = threadIdx.x;
     const uint32_t np = 1u << log_np, pmask = np - 1;
     const uint32_t pool_base = blockIdx.x * chunks_per_wg;
-
-    if (tid < NPMAX) { s_cnt[tid] = 0; s_cfill[tid] = CHUNK; s_cbase[tid] = INVALID; s_sf[tid] = 0; s_d1[tid] = INVALID; }
-    if (tid == 0) s_pool_next = 0;
+    scatter_init(L, tid);
     __syncthreads();
 
     const size_t ntiles = (n + P1_TILE - 1) / P1_TILE;
@@ -192,7 +369,7 @@ __global__ __launch_bounds__(P1_BLOCK, 6) void k_part_scatter(const uint32_t *__
                     const uint32_t bin = (dbg & 2u) ? (uint32_t)(__double2loint(x) & 0xffff) : lh_bin_of(x, Tx);
                     const uint32_t p = id & pmask;
                     rec[j] = (p << 24) | ((id >> log_np) << 16) | bin;
-                    pr[j] = p | (atomicAdd(&s_cnt[p], 1u) << 8);
+                    pr[j] = p | (atomicAdd(&L.cnt[p], 1u) << 8);
                 } else {
                     atomicOr(err, 1u); // id >= nmetrics: reported by lh_sync / lh_extract
                 }
@@ -200,130 +377,78 @@ __global__ __launch_bounds__(P1_BLOCK, 6) void k_part_scatter(const uint32_t *__
                 atomicOr(err, 1u);     // id == 0xffffffff
             }
         }
-        __syncthreads();
-        load_tile(tile + gridDim.x);
+        scatter_tile(L, rec, pr, records, cdesc, pool_base, 0u, 0u, dbg, tid,
+                     [&] { load_tile(tile + gridDim.x); });
+    }
+    scatter_drain(L, records, cdesc, pool_base, np, 0u, 0u, tid);
+}
 
-        // exclusive scan of the per-partition counts + chunk bookkeeping (threads 0..255)
-        uint32_t c = 0, inc = 0;
-        if (tid < NPMAX) {
-            c = s_cnt[tid];
-            inc = c;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t y = __shfl_up(inc, d, 64);
-                if ((int)lane >= d) inc += y;
-            }
-            if (lane == 63) s_wsum[wave] = inc;
-        }
-        __syncthreads();
-        if (tid < NPMAX) {
-            uint32_t wbase = 0;
-            for (uint32_t w = 0; w < wave; w++) wbase += s_wsum[w];
-            const uint32_t off = wbase + inc - c;
-            s_off[tid] = off;
-            if (tid == NPMAX - 1) s_total = wbase + inc;
-            s_cnt[tid] = 0; // ranks are already in registers
-            s_d1[tid] = INVALID;
-            if (c) {
-                const uint32_t p = tid;
-                const uint32_t sf = s_sf[p], cf = s_cfill[p], cb = s_cbase[p];
-                const uint32_t total = sf + c, nfull = total / LINE, out = nfull * LINE;
-                const uint32_t room = CHUNK - cf; // multiple of LINE (0 when there is no open chunk)
-                uint32_t first = 0;
-                if (out > room) {
-                    const uint32_t over = out - room;
-                    const uint32_t k = (over + CHUNK - 1) / CHUNK;
-                    first = pool_base + atomicAdd(&s_pool_next, k); // k consecutive chunks
-                    if (cb != INVALID) cdesc[cb] = (p << 16) | CHUNK;  // the old chunk is now full
-                    for (uint32_t q = 0; q + 1 < k; q++) cdesc[first + q] = (p << 16) | CHUNK;
-                    s_cbase[p] = first + k - 1;
-                    s_cfill[p] = over - (k - 1) * CHUNK;
-                } else {
-                    s_cfill[p] = cf + out;
-                }
-                s_sf[p] = total - out;
-                // emitted element u = sf + (i - off) of this partition goes to
-                //   u < room : cb*CHUNK + cf + u            = A + i
-                //   else     : first*CHUNK + (u - room)      = B + i     (new chunks are consecutive)
-                pu4_t t;
-                t.x = cb * CHUNK + cf + sf - off;
-                t.y = first * CHUNK + sf - off - room;
-                t.z = room ? off + room - sf : off;
-                const uint32_t E = nfull ? off + out - sf : off;
-                t.w = E | ((nfull ? 0u : sf) << 16);
-                s_tbl[p] = t;
-                if (nfull && sf) {
-                    s_d1[p] = room ? cb * CHUNK + cf : first * CHUNK;
-                    s_n1[p] = sf;
-                }
-            }
-        }
-        __syncthreads();
+// ---------------------------------------------------------------------------
+// P1b: second partition level.  One workgroup per level-1 work slot re-scatters that slot's records by
+// the next log_ns bits of the local name id.  Output partition q = sub << log_np | p, so that the name
+// is again (local >> log_ns) << log_nq | q, i.e. P2 works unchanged with log_nq in place of log_np.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(P1_BLOCK, 6) void k_scatter_records(const uint32_t *__restrict__ in_records,
+                                                                 const uint32_t *__restrict__ in_cdesc,
+                                                                 const uint32_t *__restrict__ in_sorted,
+                                                                 const uint32_t *__restrict__ in_part_start,
+                                                                 const uint32_t *__restrict__ in_slots,
+                                                                 const uint32_t *__restrict__ in_nslots,
+                                                                 const uint32_t *__restrict__ pool_start,
+                                                                 uint32_t log_np, uint32_t log_ns,
+                                                                 uint32_t *__restrict__ records,
+                                                                 uint32_t *__restrict__ cdesc, uint32_t dbg)
+{
+    __shared__ __attribute__((aligned(16))) ScatterLds L;
+    const uint32_t slot = blockIdx.x;
+    if (slot >= *in_nslots) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t p1 = in_slots[3 * slot], first = in_slots[3 * slot + 1], cnt = in_slots[3 * slot + 2];
+    const uint32_t *list = in_sorted + in_part_start[p1] + first;
+    const uint32_t ns = 1u << log_ns, smask = ns - 1;
+    const uint32_t pool_base = pool_start[slot];
+    scatter_init(L, tid);
+    __syncthreads();
 
-        // tile-local counting sort into LDS ...
+    constexpr uint32_t CPT = P1_TILE / CHUNK; // chunks per tile
+    const uint32_t ntiles = (cnt + CPT - 1) / CPT;
+    uint32_t in[P1_SPT];
+    uint32_t okmask = 0; // bit j: in[j] holds a record (a record may legitimately be 0xffffffff: no sentinel)
+    // record j of a thread: chunk (tile*CPT + j/2), offset (j&1)*512 + tid
+    auto load_tile = [&](uint32_t tile) {
+        okmask = 0;
 #pragma unroll
         for (int j = 0; j < P1_SPT; j++) {
-            if (pr[j] != INVALID) s_sorted[s_off[pr[j] & 0xffu] + (pr[j] >> 8)] = rec[j];
-        }
-        // ... and, independently, the previously staged records of partitions that emit a line
-        if (!(dbg & 1u))
-            for (uint32_t e = tid; e < NPMAX * LINE; e += P1_BLOCK) {
-                const uint32_t p = e / LINE, u = e % LINE;
-                const uint32_t d = s_d1[p];
-                if (d != INVALID && u < s_n1[p]) records[d + u] = s_stage[e];
-            }
-        __syncthreads();
-
-        // copy out: whole lines to HBM, the remainder of each partition into its staging line
-        const uint32_t tile_total = s_total;
-        if (dbg & 8u) {
-            // TIMING-ONLY ablation (results are wrong): the same number of bytes leaves the CU as one 16-B store
-            // per lane instead of four 4-B stores, to tell store-issue cost from store-bandwidth cost
-            for (uint32_t i4 = tid * 4; i4 + 3 < tile_total; i4 += P1_BLOCK * 4) {
-                const pu4_t r4 = *reinterpret_cast<const pu4_t *>(&s_sorted[i4]);
-                const pu4_t t = s_tbl[r4.x >> 24];
-                const uint32_t dst = ((i4 < t.z ? t.x : t.y) + i4) & ~3u;
-                *reinterpret_cast<pu4_t *>(&records[dst]) = r4;
-            }
-        } else
-        for (uint32_t i = tid; i < tile_total; i += P1_BLOCK) {
-            const uint32_t r = s_sorted[i];
-            const pu4_t t = s_tbl[r >> 24];
-            const uint32_t E = t.w & 0xffffu;
-            if (i < E) {
-                if (!(dbg & 1u)) records[(i < t.z ? t.x : t.y) + i] = r;
-            } else {
-                s_stage[(r >> 24) * LINE + (i - E) + (t.w >> 16)] = r;
+            const uint32_t ci = tile * CPT + (uint32_t)(j >> 1);
+            in[j] = 0;
+            if (tile < ntiles && ci < cnt) {
+                const uint32_t cid = list[ci];
+                const uint32_t cn = in_cdesc[cid] & CD_MASK;
+                const uint32_t o = (uint32_t)(j & 1) * P1_BLOCK + tid;
+                if (o < cn) {
+                    in[j] = __builtin_nontemporal_load(in_records + (size_t)cid * CHUNK + o);
+                    okmask |= 1u << j;
+                }
             }
         }
-        // (the next tile's first barrier separates this copy-out from the next bookkeeping)
-    }
-    __syncthreads();
-
-    // drain: the staged remainders (one partial line per partition) and the open chunks' descriptors
-    if (tid < NPMAX) {
-        s_d1[tid] = INVALID;
-        const uint32_t p = tid, sf = s_sf[p];
-        if (sf) {
-            uint32_t cf = s_cfill[p], cb = s_cbase[p];
-            if (cf == CHUNK) { // no open chunk, or it is exactly full
-                if (cb != INVALID) cdesc[cb] = (p << 16) | CHUNK;
-                cb = pool_base + atomicAdd(&s_pool_next, 1u);
-                cf = 0;
-                s_cbase[p] = cb;
+    };
+    load_tile(0);
+    for (uint32_t tile = 0; tile < ntiles; tile++) {
+        uint32_t rec[P1_SPT], pr[P1_SPT];
+#pragma unroll
+        for (int j = 0; j < P1_SPT; j++) {
+            pr[j] = INVALID;
+            rec[j] = 0;
+            if (okmask & (1u << j)) {
+                const uint32_t local = (in[j] >> 16) & 0xffu, bin = in[j] & 0xffffu;
+                const uint32_t sub = local & smask;
+                rec[j] = (sub << 24) | ((local >> log_ns) << 16) | bin;
+                pr[j] = sub | (atomicAdd(&L.cnt[sub], 1u) << 8);
             }
-            s_d1[p] = cb * CHUNK + cf;
-            s_n1[p] = sf;
-            s_cfill[p] = cf + sf;
         }
+        scatter_tile(L, rec, pr, records, cdesc, pool_base, log_np, p1, dbg, tid, [&] { load_tile(tile + 1); });
     }
-    __syncthreads();
-    for (uint32_t e = tid; e < NPMAX * LINE; e += P1_BLOCK) {
-        const uint32_t p = e / LINE, u = e % LINE;
-        const uint32_t d = s_d1[p];
-        if (d != INVALID && u < s_n1[p]) records[d + u] = s_stage[e];
-    }
-    if (tid < np && s_cbase[tid] != INVALID) cdesc[s_cbase[tid]] = (tid << 16) | s_cfill[tid];
+    scatter_drain(L, records, cdesc, pool_base, ns, log_np, p1, tid);
 }
 
 // ---------------------------------------------------------------------------
@@ -333,95 +458,143 @@ constexpr int PL_BLOCK = 256;
 constexpr int PL_PER_WG = 2048; // descriptors per workgroup
 
 __global__ __launch_bounds__(PL_BLOCK) void k_plan_count(const uint32_t *__restrict__ cdesc, uint32_t nchunks,
-                                                         uint32_t *__restrict__ pc)
+                                                         uint32_t *__restrict__ pc, uint32_t nq)
 {
-    __shared__ uint32_t s_h[NPMAX];
-    s_h[threadIdx.x] = 0;
+    extern __shared__ uint32_t s_dyn[];
+    uint32_t *s_h = s_dyn; // [nq]
+    for (uint32_t i = threadIdx.x; i < nq; i += PL_BLOCK) s_h[i] = 0;
     __syncthreads();
     const uint32_t lo = blockIdx.x * PL_PER_WG;
     for (uint32_t i = lo + threadIdx.x; i < lo + PL_PER_WG && i < nchunks; i += PL_BLOCK) {
         const uint32_t d = cdesc[i];
-        if (d != INVALID) atomicAdd(&s_h[d >> 16], 1u);
+        if (d != INVALID) atomicAdd(&s_h[d >> CD_SHIFT], 1u);
     }
     __syncthreads();
-    if (s_h[threadIdx.x]) atomicAdd(&pc[threadIdx.x], s_h[threadIdx.x]);
+    for (uint32_t i = threadIdx.x; i < nq; i += PL_BLOCK)
+        if (s_h[i]) atomicAdd(&pc[i], s_h[i]);
 }
 
-// one workgroup of 256 threads; thread p owns partition p
-__global__ __launch_bounds__(PL_BLOCK) void k_plan_scan(const uint32_t *__restrict__ pc,
+constexpr int PS_BLOCK = 1024;
+
+// exclusive block scan over PS_BLOCK threads; returns the exclusive prefix, *total receives the sum
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t val, uint32_t *s_w /*[17]*/, uint32_t *total)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = val;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(inc, d, 64);
+        if ((int)lane >= d) inc += y;
+    }
+    __syncthreads(); // s_w reuse
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+    for (uint32_t w = 0; w < PS_BLOCK / 64; w++) {
+        if (w < wave) wbase += s_w[w];
+        tot += s_w[w];
+    }
+    *total = tot;
+    return wbase + inc - val;
+}
+
+// One workgroup.  Thread t owns partitions [t*E, (t+1)*E), E = ceil(nq / PS_BLOCK).
+// pool_extra > 0: also lay out private chunk pools for a following scatter level (slot s gets
+// cnt + pool_extra chunks starting at pool_start[s]).
+__global__ __launch_bounds__(PS_BLOCK) void k_plan_scan(const uint32_t *__restrict__ pc,
                                                         uint32_t *__restrict__ part_start,
                                                         uint32_t *__restrict__ cursor,
                                                         uint32_t *__restrict__ slots,
-                                                        uint32_t *__restrict__ nslots, uint32_t np)
+                                                        uint32_t *__restrict__ nslots,
+                                                        uint32_t *__restrict__ pool_start, uint32_t nq,
+                                                        uint32_t pool_extra)
 {
-    __shared__ uint32_t s_a[NPMAX], s_b[NPMAX];
-    const uint32_t p = threadIdx.x;
-    const uint32_t c = pc[p];
-    s_a[p] = c;
-    __syncthreads();
-    // serial prefix by one thread: 256 entries, negligible
-    if (p == 0) {
-        uint32_t run = 0;
-        for (uint32_t i = 0; i < NPMAX; i++) { const uint32_t t = s_a[i]; s_a[i] = run; run += t; }
-        s_b[0] = run; // total chunks
+    __shared__ uint32_t s_w[17];
+    constexpr uint32_t EMAX = NQMAX / PS_BLOCK;
+    const uint32_t E = (nq + PS_BLOCK - 1) / PS_BLOCK;
+    const uint32_t q0 = threadIdx.x * E;
+    uint32_t c[EMAX];
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t e = 0; e < EMAX; e++) {
+        c[e] = (e < E && q0 + e < nq) ? pc[q0 + e] : 0u;
+        mine += c[e];
     }
-    __syncthreads();
-    const uint32_t total = s_b[0];
-    const uint32_t start = s_a[p];
-    part_start[p] = start;
-    cursor[p] = start;
-    __syncthreads();
-    uint32_t target = (total + (P2_SLOTS - np) - 1) / (P2_SLOTS - np);
+    uint32_t total = 0;
+    uint32_t run = block_excl_scan(mine, s_w, &total);
+#pragma unroll
+    for (uint32_t e = 0; e < EMAX; e++) {
+        if (e < E && q0 + e < nq) {
+            part_start[q0 + e] = run;
+            cursor[q0 + e] = run;
+            run += c[e];
+        }
+    }
+    uint32_t target = (total + SLOT_EXTRA - 1) / SLOT_EXTRA; // chunks per slot
     if (target == 0) target = 1;
-    const uint32_t k = (c + target - 1) / target;
-    s_a[p] = k;
-    __syncthreads();
-    if (p == 0) {
-        uint32_t run = 0;
-        for (uint32_t i = 0; i < NPMAX; i++) { const uint32_t t = s_a[i]; s_a[i] = run; run += t; }
-        *nslots = run;
+    uint32_t kmine = 0;
+#pragma unroll
+    for (uint32_t e = 0; e < EMAX; e++) kmine += (c[e] + target - 1) / target;
+    uint32_t nsl = 0;
+    uint32_t s0 = block_excl_scan(kmine, s_w, &nsl);
+    if (threadIdx.x == 0) *nslots = nsl; // <= total/target + nq <= SLOT_EXTRA + nq
+#pragma unroll
+    for (uint32_t e = 0; e < EMAX; e++) {
+        const uint32_t k = (c[e] + target - 1) / target;
+        for (uint32_t j = 0; j < k; j++) {
+            const uint32_t first = j * target;
+            slots[3 * (s0 + j) + 0] = q0 + e;
+            slots[3 * (s0 + j) + 1] = first;
+            slots[3 * (s0 + j) + 2] = (c[e] - first) < target ? (c[e] - first) : target;
+        }
+        s0 += k;
     }
-    __syncthreads();
-    const uint32_t s0 = s_a[p];
-    for (uint32_t j = 0; j < k; j++) {
-        const uint32_t first = j * target;
-        const uint32_t cnt = (c - first) < target ? (c - first) : target;
-        slots[3 * (s0 + j) + 0] = p;
-        slots[3 * (s0 + j) + 1] = first;
-        slots[3 * (s0 + j) + 2] = cnt;
+    if (pool_extra) {
+        __threadfence_block();
+        __syncthreads();
+        if (threadIdx.x == 0) { // <= nq + SLOT_EXTRA slots; only used for the 256-partition first level
+            uint32_t at = 0;
+            for (uint32_t s = 0; s < nsl; s++) {
+                pool_start[s] = at;
+                at += slots[3 * s + 2] + pool_extra;
+            }
+            pool_start[nsl] = at;
+        }
     }
 }
 
 __global__ __launch_bounds__(PL_BLOCK) void k_plan_scatter(const uint32_t *__restrict__ cdesc, uint32_t nchunks,
                                                            uint32_t *__restrict__ cursor,
-                                                           uint32_t *__restrict__ sorted)
+                                                           uint32_t *__restrict__ sorted, uint32_t nq)
 {
-    __shared__ uint32_t s_h[NPMAX], s_base[NPMAX];
-    s_h[threadIdx.x] = 0;
+    extern __shared__ uint32_t s_dyn[];
+    uint32_t *s_h = s_dyn; // [nq]: counts, then bases
+    for (uint32_t i = threadIdx.x; i < nq; i += PL_BLOCK) s_h[i] = 0;
     __syncthreads();
     const uint32_t lo = blockIdx.x * PL_PER_WG;
-    uint32_t pr[PL_PER_WG / PL_BLOCK];
+    uint32_t q[PL_PER_WG / PL_BLOCK], rank[PL_PER_WG / PL_BLOCK];
 #pragma unroll
     for (int j = 0; j < PL_PER_WG / PL_BLOCK; j++) {
         const uint32_t i = lo + j * PL_BLOCK + threadIdx.x;
-        pr[j] = INVALID;
+        q[j] = INVALID;
+        rank[j] = 0;
         if (i < nchunks) {
             const uint32_t d = cdesc[i];
             if (d != INVALID) {
-                const uint32_t p = d >> 16;
-                pr[j] = p | (atomicAdd(&s_h[p], 1u) << 8);
+                q[j] = d >> CD_SHIFT;
+                rank[j] = atomicAdd(&s_h[q[j]], 1u);
             }
         }
     }
     __syncthreads();
-    {
-        const uint32_t c = s_h[threadIdx.x];
-        s_base[threadIdx.x] = c ? atomicAdd(&cursor[threadIdx.x], c) : 0;
+    for (uint32_t i = threadIdx.x; i < nq; i += PL_BLOCK) {
+        const uint32_t c = s_h[i];
+        if (c) s_h[i] = atomicAdd(&cursor[i], c); // count -> base of this workgroup's run
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < PL_PER_WG / PL_BLOCK; j++) {
-        if (pr[j] != INVALID) sorted[s_base[pr[j] & 0xffu] + (pr[j] >> 8)] = lo + j * PL_BLOCK + threadIdx.x;
+        if (q[j] != INVALID) sorted[s_h[q[j]] + rank[j]] = lo + j * PL_BLOCK + threadIdx.x;
     }
 }
 
@@ -440,15 +613,16 @@ __device__ __forceinline__ void p2_global_add(uint64_t *__restrict__ counts, uin
     if (bin > r[1]) atomicMax(&r[1], bin);
 }
 
+// log_nq: name id = local << log_nq | partition.  mpp: names per partition.
 __global__ __launch_bounds__(P2_BLOCK, 8) void k_part_hist(const uint32_t *__restrict__ records,
-                                                        const uint32_t *__restrict__ cdesc,
-                                                        const uint32_t *__restrict__ sorted,
-                                                        const uint32_t *__restrict__ part_start,
-                                                        const uint32_t *__restrict__ slots,
-                                                        const uint32_t *__restrict__ nslots, uint32_t log_np,
-                                                        uint32_t mpp, uint32_t log_w,
-                                                        uint64_t *__restrict__ counts,
-                                                        uint32_t *__restrict__ ranges)
+                                                           const uint32_t *__restrict__ cdesc,
+                                                           const uint32_t *__restrict__ sorted,
+                                                           const uint32_t *__restrict__ part_start,
+                                                           const uint32_t *__restrict__ slots,
+                                                           const uint32_t *__restrict__ nslots, uint32_t log_nq,
+                                                           uint32_t mpp, uint32_t log_w,
+                                                           uint64_t *__restrict__ counts,
+                                                           uint32_t *__restrict__ ranges)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *h = reinterpret_cast<uint32_t *>(smem);
@@ -473,7 +647,7 @@ __global__ __launch_bounds__(P2_BLOCK, 8) void k_part_hist(const uint32_t *__res
     const uint32_t log_cw = 16 - log_w;
     {
         const uint32_t c0 = list[0];
-        const uint32_t n0 = cdesc[c0] & 0xffffu;
+        const uint32_t n0 = cdesc[c0] & CD_MASK;
         const uint32_t *b0 = records + (size_t)c0 * CHUNK;
         for (uint32_t i = tid; i < n0; i += P2_BLOCK) {
             const uint32_t rec = b0[i];
@@ -481,7 +655,7 @@ __global__ __launch_bounds__(P2_BLOCK, 8) void k_part_hist(const uint32_t *__res
         }
     }
     __syncthreads();
-    choose_windows(h, s_org, s_mn, s_mx, mpp, log_w, wave, lane, P2_BLOCK / 64); // lh_windows.h
+    choose_windows(h, s_org, s_mn, s_mx, mpp, log_w, wave, lane, P2_BLOCK / 64);
     __syncthreads();
     for (uint32_t i = tid; i < words; i += P2_BLOCK) h[i] = 0;
     ov_init(ov_key, ov_cnt, tid, P2_BLOCK);
@@ -510,15 +684,18 @@ __global__ __launch_bounds__(P2_BLOCK, 8) void k_part_hist(const uint32_t *__res
                     if (__builtin_amdgcn_ballot_w64(rec != f0) == 0ull) {
                         if (lane == 0) {
                             if (rel < W) atomicAdd(&h[(l << log_w) + rel], 64u);
-                            else if (!ov_add(ov_key, ov_cnt, (l << 16) | b, 64u)) p2_global_add(counts, ranges, (l << log_np) | p, b, 64);
+                            else if (!ov_add(ov_key, ov_cnt, (l << 16) | b, 64u))
+                                p2_global_add(counts, ranges, (l << log_nq) | p, b, 64);
                         }
                     } else {
                         if (rel < W) atomicAdd(&h[(l << log_w) + rel], 1u);
-                        else if (!ov_add(ov_key, ov_cnt, (l << 16) | b, 1u)) p2_global_add(counts, ranges, (l << log_np) | p, b, 1);
+                        else if (!ov_add(ov_key, ov_cnt, (l << 16) | b, 1u))
+                            p2_global_add(counts, ranges, (l << log_nq) | p, b, 1);
                     }
                 } else if (q * 256 + lane * 4 + t < cn) {
                     if (rel < W) atomicAdd(&h[(l << log_w) + rel], 1u);
-                    else if (!ov_add(ov_key, ov_cnt, (l << 16) | b, 1u)) p2_global_add(counts, ranges, (l << log_np) | p, b, 1);
+                    else if (!ov_add(ov_key, ov_cnt, (l << 16) | b, 1u))
+                        p2_global_add(counts, ranges, (l << log_nq) | p, b, 1);
                 }
             }
         }
@@ -529,14 +706,14 @@ __global__ __launch_bounds__(P2_BLOCK, 8) void k_part_hist(const uint32_t *__res
     uint32_t cnA = 0, cnB = 0;
     if (j < cnt) {
         const uint32_t cid = __builtin_amdgcn_readfirstlane(list[j]);
-        cnA = __builtin_amdgcn_readfirstlane(cdesc[cid] & 0xffffu);
+        cnA = __builtin_amdgcn_readfirstlane(cdesc[cid] & CD_MASK);
         load_chunk(cid, bufA);
     }
     while (j < cnt) {
         // A holds chunk j; fetch chunk j+WSTEP into B, reduce A
         if (j + WSTEP < cnt) {
             const uint32_t cid = __builtin_amdgcn_readfirstlane(list[j + WSTEP]);
-            cnB = __builtin_amdgcn_readfirstlane(cdesc[cid] & 0xffffu);
+            cnB = __builtin_amdgcn_readfirstlane(cdesc[cid] & CD_MASK);
             load_chunk(cid, bufB);
         }
         reduce_chunk(bufA, cnA);
@@ -545,7 +722,7 @@ __global__ __launch_bounds__(P2_BLOCK, 8) void k_part_hist(const uint32_t *__res
         // B holds chunk j; fetch chunk j+WSTEP into A, reduce B
         if (j + WSTEP < cnt) {
             const uint32_t cid = __builtin_amdgcn_readfirstlane(list[j + WSTEP]);
-            cnA = __builtin_amdgcn_readfirstlane(cdesc[cid] & 0xffffu);
+            cnA = __builtin_amdgcn_readfirstlane(cdesc[cid] & CD_MASK);
             load_chunk(cid, bufA);
         }
         reduce_chunk(bufB, cnB);
@@ -558,7 +735,7 @@ __global__ __launch_bounds__(P2_BLOCK, 8) void k_part_hist(const uint32_t *__res
         const uint32_t c = h[i];
         if (c) {
             const uint32_t l = i >> log_w, b = s_org[l] + (i & (W - 1));
-            atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)((l << log_np) | p) * LH_NKEYS + b]),
+            atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)((l << log_nq) | p) * LH_NKEYS + b]),
                       (unsigned long long)c);
             atomicMin(&s_mn[l], b);
             atomicMax(&s_mx[l], b);
@@ -566,13 +743,48 @@ __global__ __launch_bounds__(P2_BLOCK, 8) void k_part_hist(const uint32_t *__res
     }
     for (uint32_t i = tid; i < OV_SLOTS; i += P2_BLOCK)
         if (ov_key[i] != OV_EMPTY)
-            p2_global_add(counts, ranges, ((ov_key[i] >> 16) << log_np) | p, ov_key[i] & 0xffffu, ov_cnt[i]);
+            p2_global_add(counts, ranges, ((ov_key[i] >> 16) << log_nq) | p, ov_key[i] & 0xffffu, ov_cnt[i]);
     __syncthreads();
     if (tid < mpp && s_mn[tid] != INVALID) {
-        uint32_t *r = ranges + 2 * (size_t)((tid << log_np) | p);
+        uint32_t *r = ranges + 2 * (size_t)((tid << log_nq) | p);
         if (s_mn[tid] < r[0]) atomicMin(&r[0], s_mn[tid]);
         if (s_mx[tid] > r[1]) atomicMax(&r[1], s_mx[tid]);
     }
+}
+
+// ---------------------------------------------------------------------------
+// launcher
+// ---------------------------------------------------------------------------
+struct LevelPtrs {
+    uint32_t *records, *cdesc, *sorted, *pc, *part_start, *cursor, *slots, *nslots, *pool_start;
+};
+
+static LevelPtrs level_ptrs(unsigned char *base, size_t off_rec, size_t off_cd, size_t off_sorted, size_t off_small,
+                            uint32_t nq)
+{
+    LevelPtrs L;
+    L.records = reinterpret_cast<uint32_t *>(base + off_rec);
+    L.cdesc = reinterpret_cast<uint32_t *>(base + off_cd);
+    L.sorted = reinterpret_cast<uint32_t *>(base + off_sorted);
+    uint32_t *small = reinterpret_cast<uint32_t *>(base + off_small);
+    L.pc = small;
+    L.part_start = small + nq;
+    L.cursor = small + 2 * (size_t)nq;
+    L.slots = small + 3 * (size_t)nq;
+    L.nslots = L.slots + 3 * (size_t)(nq + SLOT_EXTRA);
+    L.pool_start = L.nslots + 1;
+    return L;
+}
+
+static hipError_t run_plan(const LevelPtrs &L, uint32_t nchunks, uint32_t nq, uint32_t pool_extra, hipStream_t s)
+{
+    const unsigned grid = (nchunks + PL_PER_WG - 1) / PL_PER_WG;
+    const size_t lds = (size_t)nq * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_plan_count, dim3(grid), dim3(PL_BLOCK), lds, s, L.cdesc, nchunks, L.pc, nq);
+    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(PS_BLOCK), 0, s, L.pc, L.part_start, L.cursor, L.slots, L.nslots,
+                       L.pool_start, nq, pool_extra);
+    hipLaunchKernelGGL(k_plan_scatter, dim3(grid), dim3(PL_BLOCK), lds, s, L.cdesc, nchunks, L.cursor, L.sorted, nq);
+    return hipGetLastError();
 }
 
 hipError_t launch_ingest_pairs_part(const uint32_t *d_ids, const double *d_v, size_t n, uint64_t *counts,
@@ -581,38 +793,55 @@ hipError_t launch_ingest_pairs_part(const uint32_t *d_ids, const double *d_v, si
 {
     PartPlan P;
     if (!make_plan(n, nmetrics, num_cus, P) || scratch_bytes < P.total || !scratch) return hipErrorInvalidValue;
-    if (((uintptr_t)d_v & 15) || ((uintptr_t)d_ids & 7)) return hipErrorInvalidValue; // see part_aligned()
-    static std::atomic<bool> attr_set{false}; // benign if two threads race: both set the same attribute
+    if (!part_aligned(d_ids, d_v)) return hipErrorInvalidValue;
+    static std::atomic<bool> attr_set{false}; // benign if two threads race: both set the same attributes
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_part_hist),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)P2_LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_plan_count),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NQMAX * sizeof(uint32_t)));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_plan_scatter),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NQMAX * sizeof(uint32_t)));
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     unsigned char *base = static_cast<unsigned char *>(scratch);
-    uint32_t *records = reinterpret_cast<uint32_t *>(base + P.off_records);
-    uint32_t *cdesc = reinterpret_cast<uint32_t *>(base + P.off_cdesc);
-    uint32_t *sorted = reinterpret_cast<uint32_t *>(base + P.off_sorted);
-    uint32_t *small = reinterpret_cast<uint32_t *>(base + P.off_small);
-    uint32_t *pc = small, *part_start = small + NPMAX, *cursor = small + 2 * NPMAX;
-    uint32_t *slots = small + 3 * NPMAX, *nslots = slots + 3 * P2_SLOTS;
+    const LevelPtrs L1 = level_ptrs(base, P.off_rec1, P.off_cd1, P.off_sorted1, P.off_small1, P.np);
 
-    hipError_t e = hipMemsetAsync(cdesc, 0xff, (size_t)P.nchunks * sizeof(uint32_t), s);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(small, 0, (3 * NPMAX + 3 * P2_SLOTS + 64) * sizeof(uint32_t), s);
-    if (e != hipSuccess) return e;
     // LH_DEBUG_FLAGS (tuning only, never set by tests or bench): 1 = P1 skips its record stores,
-    // 2 = P1 skips compress, 4 = skip P2.  Results are wrong with any bit set.
+    // 2 = P1 skips compress, 4 = skip P2, 8 = 16-B store ablation.  Results are wrong with any bit set.
     static const uint32_t dbg = getenv("LH_DEBUG_FLAGS") ? (uint32_t)atoi(getenv("LH_DEBUG_FLAGS")) : 0u;
-    hipLaunchKernelGGL(k_part_scatter, dim3(P.g1), dim3(P1_BLOCK), 0, s, d_ids, d_v, n, nmetrics, P.log_np, d_Tx,
-                       records, cdesc, P.chunks_per_wg, d_err, dbg);
-    const unsigned plan_grid = (P.nchunks + PL_PER_WG - 1) / PL_PER_WG;
-    hipLaunchKernelGGL(k_plan_count, dim3(plan_grid), dim3(PL_BLOCK), 0, s, cdesc, P.nchunks, pc);
-    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(PL_BLOCK), 0, s, pc, part_start, cursor, slots, nslots, P.np);
-    hipLaunchKernelGGL(k_plan_scatter, dim3(plan_grid), dim3(PL_BLOCK), 0, s, cdesc, P.nchunks, cursor, sorted);
+
+    hipError_t e = hipMemsetAsync(L1.cdesc, 0xff, (size_t)P.nchunks1 * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(L1.pc, 0, small_words(P.np) * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_scatter_samples, dim3(P.g1), dim3(P1_BLOCK), 0, s, d_ids, d_v, n, nmetrics, P.log_np, d_Tx,
+                       L1.records, L1.cdesc, P.chunks_per_wg, d_err, dbg);
+    e = run_plan(L1, P.nchunks1, P.np, P.log_ns ? P.ns + 1 : 0u, s);
+    if (e != hipSuccess) return e;
+
+    const LevelPtrs *last = &L1;
+    LevelPtrs L2;
+    if (P.log_ns) {
+        L2 = level_ptrs(base, P.off_rec2, P.off_cd2, P.off_sorted2, P.off_small2, P.nq);
+        e = hipMemsetAsync(L2.cdesc, 0xff, (size_t)P.nchunks2 * sizeof(uint32_t), s);
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(L2.pc, 0, small_words(P.nq) * sizeof(uint32_t), s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_scatter_records, dim3(P.np + SLOT_EXTRA), dim3(P1_BLOCK), 0, s, L1.records, L1.cdesc,
+                           L1.sorted, L1.part_start, L1.slots, L1.nslots, L1.pool_start, P.log_np, P.log_ns,
+                           L2.records, L2.cdesc, dbg);
+        e = run_plan(L2, P.nchunks2, P.nq, 0u, s);
+        if (e != hipSuccess) return e;
+        last = &L2;
+    }
     if (!(dbg & 4u))
-    hipLaunchKernelGGL(k_part_hist, dim3(P2_SLOTS), dim3(P2_BLOCK), P2_LDS_BYTES, s, records, cdesc, sorted,
-                       part_start, slots, nslots, P.log_np, P.mpp, P.log_w, counts, ranges);
+        hipLaunchKernelGGL(k_part_hist, dim3(P.nq + SLOT_EXTRA), dim3(P2_BLOCK), P2_LDS_BYTES, s, last->records,
+                           last->cdesc, last->sorted, last->part_start, last->slots, last->nslots, P.log_nq, P.mpp2,
+                           P.log_w, counts, ranges);
     return hipGetLastError();
 }
 
