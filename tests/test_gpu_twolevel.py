@@ -26,8 +26,10 @@ def _dev(torch, a):
     (65536, 500_000, "edge"),            # includes the record value 0xffffffff and the last name
     (20000, 2_000_000, "constant"),
 ])
-def test_two_level_partitioned_ingest(native_lib, torch_cuda, M, n, kind):
+def test_two_level_partitioned_ingest(native_lib, torch_cuda, M, n, kind, monkeypatch):
     import loghisto_amd
+    # the engine only uses the second level above 8 192 names (it is slower below); force it for every case
+    monkeypatch.setenv("LH_PART_TWO_LEVEL_ABOVE", "0")
     rng = np.random.default_rng(M + n)
     w = 1.0 / np.arange(1, M + 1)
     ids = rng.choice(M, size=n, p=w / w.sum()).astype(np.uint32)
