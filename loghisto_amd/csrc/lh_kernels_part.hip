@@ -80,13 +80,13 @@ static bool make_plan(size_t n, uint32_t nmetrics, int num_cus, PartPlan &P)
     // (measured at 1 024 names, profiles/r01c: 4 is the best overall).
     static const uint32_t names_per_part =
         getenv("LH_PART_NAMES") ? (uint32_t)std::max(1, atoi(getenv("LH_PART_NAMES"))) : 4u;
-    // Second level only when a level-1 partition holds more than 32 names (> 8 192 names in all).
+    // Second level only when a level-1 partition holds more than 64 names (> 16 384 names in all).
     // Measured (profiles/r01j): at 4 096 / 8 192 names one level is faster (149 / 127 vs 79 / 76 G samples/s:
     // 1 024 / 512-bin windows plus the overflow table still catch most records, and the extra pass costs
-    // 8 B/sample); at 65 536 names two levels win (72 vs 27 G/s).  LH_PART_TWO_LEVEL_ABOVE overrides the
+    // 8 B/sample), at 16 384 still 73 vs 63; at 65 536 names two levels win (72 vs 27 G/s).  LH_PART_TWO_LEVEL_ABOVE overrides the
     // threshold (tests force the second level at small name counts with 0); read per call on purpose.
     const char *thr_env = getenv("LH_PART_TWO_LEVEL_ABOVE");
-    const uint32_t two_level_above = thr_env ? (uint32_t)std::max(0, atoi(thr_env)) : 32u;
+    const uint32_t two_level_above = thr_env ? (uint32_t)std::max(0, atoi(thr_env)) : 64u;
     const uint32_t want_np = (nmetrics + names_per_part - 1) / names_per_part;
     P.log_np = std::min(8u, ilog2_ceil(want_np));
     P.np = 1u << P.log_np;
