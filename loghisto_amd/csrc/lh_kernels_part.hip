@@ -17,7 +17,7 @@
 //                        hot loop has no global atomics at all.
 //   plan k_plan_*      : group the chunk descriptors by partition and cut them into equal
 //                        work slots (three tiny kernels).
-//   P1b k_scatter_records (only above 1 024 names): the same scatter once more, on the 4-byte
+//   P1b k_scatter_records (only above 16 384 names): the same scatter once more, on the 4-byte
 //                        records of each level-1 slot, by the next bits of the name id -- up
 //                        to 64 sub-partitions, 16 384 partitions in all -- so that P2 again
 //                        sees at most 4 names per partition.  +8 B/sample of traffic.
