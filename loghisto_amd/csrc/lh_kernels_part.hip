@@ -58,6 +58,7 @@ struct PartPlan {
     uint32_t log_ns, ns;               // level 2: sub-partitions per partition (1 = no second level)
     uint32_t log_nq, nq, mpp2, log_w;  // what P2 sees
     uint32_t g1, chunks_per_wg, nchunks1, nchunks2;
+    uint32_t extra1;                   // work slots beyond one per partition in the level-1 plan
     size_t off_rec1, off_cd1, off_sorted1, off_small1, off_rec2, off_cd2, off_sorted2, off_small2, total;
 };
 
@@ -68,9 +69,9 @@ static uint32_t ilog2_ceil(uint32_t x)
     return l;
 }
 
-// words of the "small" region of one level: pc, part_start, cursor [nq each], slots [3 x (nq + SLOT_EXTRA)],
-// nslots [1], pool_start [nq + SLOT_EXTRA + 1]
-static size_t small_words(uint32_t nq) { return (size_t)3 * nq + 3 * (nq + SLOT_EXTRA) + 1 + (nq + SLOT_EXTRA + 1) + 16; }
+// words of the "small" region of one level: pc, part_start, cursor [nq each], slots [3 x (nq + extra)],
+// nslots [1], pool_start [nq + extra + 1]   (extra = slots beyond one per partition)
+static size_t small_words(uint32_t nq, uint32_t extra) { return (size_t)3 * nq + 3 * (nq + extra) + 1 + (nq + extra + 1) + 16; }
 
 static bool make_plan(size_t n, uint32_t nmetrics, int num_cus, PartPlan &P)
 {
@@ -112,18 +113,21 @@ static bool make_plan(size_t n, uint32_t nmetrics, int num_cus, PartPlan &P)
     const size_t tiles_per_wg = (ntiles + g1 - 1) / g1;
     P.chunks_per_wg = (uint32_t)(tiles_per_wg * (P1_TILE / CHUNK) + P.np + 1);
     P.nchunks1 = P.g1 * P.chunks_per_wg;
-    // level 2: every level-1 slot re-scatters its chunks into <= cnt + ns + 1 chunks
-    P.nchunks2 = P.log_ns ? P.nchunks1 + (P.np + SLOT_EXTRA) * (P.ns + 1) : 0;
+    // level 2: every level-1 slot is one P1b workgroup and re-scatters its chunks into <= cnt + ns + 1 chunks.
+    // Measured at 65 536 names: with 1 024 extra slots P1b ran 1 280 workgroups in 1.67 uneven waves (4.6 ms for
+    // 8 GB); 4 096 extra slots give ~5.7 waves of shorter workgroups.
+    P.extra1 = P.log_ns ? 4096u : SLOT_EXTRA;
+    P.nchunks2 = P.log_ns ? P.nchunks1 + (P.np + P.extra1) * (P.ns + 1) : 0;
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~size_t(255); return at; };
     P.off_rec1 = take((size_t)P.nchunks1 * CHUNK * sizeof(uint32_t));
     P.off_cd1 = take((size_t)P.nchunks1 * sizeof(uint32_t));
     P.off_sorted1 = take((size_t)P.nchunks1 * sizeof(uint32_t));
-    P.off_small1 = take(small_words(P.np) * sizeof(uint32_t));
+    P.off_small1 = take(small_words(P.np, P.extra1) * sizeof(uint32_t));
     P.off_rec2 = take((size_t)P.nchunks2 * CHUNK * sizeof(uint32_t));
     P.off_cd2 = take((size_t)P.nchunks2 * sizeof(uint32_t));
     P.off_sorted2 = take((size_t)P.nchunks2 * sizeof(uint32_t));
-    P.off_small2 = take(P.log_ns ? small_words(P.nq) * sizeof(uint32_t) : 0);
+    P.off_small2 = take(P.log_ns ? small_words(P.nq, SLOT_EXTRA) * sizeof(uint32_t) : 0);
     P.total = o;
     return true;
 }
@@ -513,7 +517,7 @@ __global__ __launch_bounds__(PS_BLOCK) void k_plan_scan(const uint32_t *__restri
                                                         uint32_t *__restrict__ slots,
                                                         uint32_t *__restrict__ nslots,
                                                         uint32_t *__restrict__ pool_start, uint32_t nq,
-                                                        uint32_t pool_extra)
+                                                        uint32_t pool_extra, uint32_t slot_extra)
 {
     __shared__ uint32_t s_w[17];
     constexpr uint32_t EMAX = NQMAX / PS_BLOCK;
@@ -536,14 +540,14 @@ __global__ __launch_bounds__(PS_BLOCK) void k_plan_scan(const uint32_t *__restri
             run += c[e];
         }
     }
-    uint32_t target = (total + SLOT_EXTRA - 1) / SLOT_EXTRA; // chunks per slot
+    uint32_t target = (total + slot_extra - 1) / slot_extra; // chunks per slot
     if (target == 0) target = 1;
     uint32_t kmine = 0;
 #pragma unroll
     for (uint32_t e = 0; e < EMAX; e++) kmine += (c[e] + target - 1) / target;
     uint32_t nsl = 0;
     uint32_t s0 = block_excl_scan(kmine, s_w, &nsl);
-    if (threadIdx.x == 0) *nslots = nsl; // <= total/target + nq <= SLOT_EXTRA + nq
+    if (threadIdx.x == 0) *nslots = nsl; // <= total/target + nq <= slot_extra + nq
 #pragma unroll
     for (uint32_t e = 0; e < EMAX; e++) {
         const uint32_t k = (c[e] + target - 1) / target;
@@ -766,7 +770,7 @@ struct LevelPtrs {
 };
 
 static LevelPtrs level_ptrs(unsigned char *base, size_t off_rec, size_t off_cd, size_t off_sorted, size_t off_small,
-                            uint32_t nq)
+                            uint32_t nq, uint32_t extra)
 {
     LevelPtrs L;
     L.records = reinterpret_cast<uint32_t *>(base + off_rec);
@@ -777,18 +781,19 @@ static LevelPtrs level_ptrs(unsigned char *base, size_t off_rec, size_t off_cd, 
     L.part_start = small + nq;
     L.cursor = small + 2 * (size_t)nq;
     L.slots = small + 3 * (size_t)nq;
-    L.nslots = L.slots + 3 * (size_t)(nq + SLOT_EXTRA);
+    L.nslots = L.slots + 3 * (size_t)(nq + extra);
     L.pool_start = L.nslots + 1;
     return L;
 }
 
-static hipError_t run_plan(const LevelPtrs &L, uint32_t nchunks, uint32_t nq, uint32_t pool_extra, hipStream_t s)
+static hipError_t run_plan(const LevelPtrs &L, uint32_t nchunks, uint32_t nq, uint32_t pool_extra, uint32_t slot_extra,
+                           hipStream_t s)
 {
     const unsigned grid = (nchunks + PL_PER_WG - 1) / PL_PER_WG;
     const size_t lds = (size_t)nq * sizeof(uint32_t);
     hipLaunchKernelGGL(k_plan_count, dim3(grid), dim3(PL_BLOCK), lds, s, L.cdesc, nchunks, L.pc, nq);
     hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(PS_BLOCK), 0, s, L.pc, L.part_start, L.cursor, L.slots, L.nslots,
-                       L.pool_start, nq, pool_extra);
+                       L.pool_start, nq, pool_extra, slot_extra);
     hipLaunchKernelGGL(k_plan_scatter, dim3(grid), dim3(PL_BLOCK), lds, s, L.cdesc, nchunks, L.cursor, L.sorted, nq);
     return hipGetLastError();
 }
@@ -814,7 +819,7 @@ hipError_t launch_ingest_pairs_part(const uint32_t *d_ids, const double *d_v, si
         attr_set = true;
     }
     unsigned char *base = static_cast<unsigned char *>(scratch);
-    const LevelPtrs L1 = level_ptrs(base, P.off_rec1, P.off_cd1, P.off_sorted1, P.off_small1, P.np);
+    const LevelPtrs L1 = level_ptrs(base, P.off_rec1, P.off_cd1, P.off_sorted1, P.off_small1, P.np, P.extra1);
 
     // LH_DEBUG_FLAGS (tuning only, never set by tests or bench): 1 = P1 skips its record stores,
     // 2 = P1 skips compress, 4 = skip P2, 8 = 16-B store ablation.  Results are wrong with any bit set.
@@ -822,30 +827,30 @@ hipError_t launch_ingest_pairs_part(const uint32_t *d_ids, const double *d_v, si
 
     hipError_t e = hipMemsetAsync(L1.cdesc, 0xff, (size_t)P.nchunks1 * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(L1.pc, 0, small_words(P.np) * sizeof(uint32_t), s);
+    e = hipMemsetAsync(L1.pc, 0, small_words(P.np, P.extra1) * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_scatter_samples, dim3(P.g1), dim3(P1_BLOCK), 0, s, d_ids, d_v, n, nmetrics, P.log_np, d_Tx,
                        L1.records, L1.cdesc, P.chunks_per_wg, d_err, dbg);
-    e = run_plan(L1, P.nchunks1, P.np, P.log_ns ? P.ns + 1 : 0u, s);
+    e = run_plan(L1, P.nchunks1, P.np, P.log_ns ? P.ns + 1 : 0u, P.extra1, s);
     if (e != hipSuccess) return e;
 
     const LevelPtrs *last = &L1;
     LevelPtrs L2;
     if (P.log_ns) {
-        L2 = level_ptrs(base, P.off_rec2, P.off_cd2, P.off_sorted2, P.off_small2, P.nq);
+        L2 = level_ptrs(base, P.off_rec2, P.off_cd2, P.off_sorted2, P.off_small2, P.nq, SLOT_EXTRA);
         e = hipMemsetAsync(L2.cdesc, 0xff, (size_t)P.nchunks2 * sizeof(uint32_t), s);
         if (e != hipSuccess) return e;
-        e = hipMemsetAsync(L2.pc, 0, small_words(P.nq) * sizeof(uint32_t), s);
+        e = hipMemsetAsync(L2.pc, 0, small_words(P.nq, SLOT_EXTRA) * sizeof(uint32_t), s);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_scatter_records, dim3(P.np + SLOT_EXTRA), dim3(P1_BLOCK), 0, s, L1.records, L1.cdesc,
+        hipLaunchKernelGGL(k_scatter_records, dim3(P.np + P.extra1), dim3(P1_BLOCK), 0, s, L1.records, L1.cdesc,
                            L1.sorted, L1.part_start, L1.slots, L1.nslots, L1.pool_start, P.log_np, P.log_ns,
                            L2.records, L2.cdesc, dbg);
-        e = run_plan(L2, P.nchunks2, P.nq, 0u, s);
+        e = run_plan(L2, P.nchunks2, P.nq, 0u, SLOT_EXTRA, s);
         if (e != hipSuccess) return e;
         last = &L2;
     }
     if (!(dbg & 4u))
-        hipLaunchKernelGGL(k_part_hist, dim3(P.nq + SLOT_EXTRA), dim3(P2_BLOCK), P2_LDS_BYTES, s, last->records,
+        hipLaunchKernelGGL(k_part_hist, dim3((P.log_ns ? P.nq : P.np) + SLOT_EXTRA), dim3(P2_BLOCK), P2_LDS_BYTES, s, last->records,
                            last->cdesc, last->sorted, last->part_start, last->slots, last->nslots, P.log_nq, P.mpp2,
                            P.log_w, counts, ranges);
     return hipGetLastError();
