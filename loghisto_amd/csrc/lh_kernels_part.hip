@@ -562,14 +562,16 @@ __global__ __launch_bounds__(PS_BLOCK) void k_plan_scan(const uint32_t *__restri
     if (pool_extra) {
         __threadfence_block();
         __syncthreads();
-        if (threadIdx.x == 0) { // <= nq + SLOT_EXTRA slots; only used for the 256-partition first level
-            uint32_t at = 0;
-            for (uint32_t s = 0; s < nsl; s++) {
-                pool_start[s] = at;
-                at += slots[3 * s + 2] + pool_extra;
-            }
-            pool_start[nsl] = at;
+        uint32_t carry = 0; // prefix of (chunks + pool_extra) over the slots, PS_BLOCK slots per round
+        for (uint32_t base = 0; base < nsl; base += PS_BLOCK) {
+            const uint32_t sidx = base + threadIdx.x;
+            const uint32_t val = sidx < nsl ? slots[3 * sidx + 2] + pool_extra : 0u;
+            uint32_t round_total = 0;
+            const uint32_t excl = block_excl_scan(val, s_w, &round_total);
+            if (sidx < nsl) pool_start[sidx] = carry + excl;
+            carry += round_total;
         }
+        if (threadIdx.x == 0) pool_start[nsl] = carry;
     }
 }
 
