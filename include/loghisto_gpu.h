@@ -168,6 +168,44 @@ int lh_snapshot_merge(lh_snapshot *s, void *comm, int nranks, int rank, int plan
 /* Path (or soname) of the RCCL shared object the communicator comes from; default "librccl.so".
  * Process-wide; call before the first lh_snapshot_merge. */
 int lh_set_rccl_library(const char *path);
+/* K6 -- the interval's histogram keys as wire text, assembled and formatted on the device.
+ * Replaces, for the histogram part of a ProcessedMetricSet, one fmt.Sprintf + map insert per key:
+ *   processMetrics    /root/reference/metrics.go:495-499   <name>_count, _sum, _avg, percentile labels
+ *   addAggregates     /root/reference/metrics.go:590-608   <name>_agg_avg, _agg_count, _agg_sum
+ *   GraphiteProtocol  /root/reference/graphite.go:37-48    "cockroach.<host>.<key, _ -> .> %f %d\n"
+ *   OpenTSDBProtocol  /root/reference/opentsdb.go:45-58    "put <key> %d %f host=<host>\n"
+ * One line per key:  prefix  key  sep  value  suffix  with value printed as Go's %f prints a float64
+ * (exact decimal expansion, 6 fractional digits, round-half-even, "NaN", "+Inf", "-Inf") and
+ * key = fmt.Sprintf(label, name).  Lines are metric-major for metrics [first, first+nmetrics) that have
+ * samples in this interval, keys in the order _count, _sum, _avg, labels[0..np), then (with
+ * LH_SER_AGGREGATES, for names whose lifetime count is > 0) _agg_avg, _agg_count, _agg_sum; keys whose
+ * percentile is invalid (metrics.go:379-384) are omitted.  Go's map iteration order is random, so this
+ * is one of the orders the reference can produce.
+ *   labels[np]  Go format strings holding exactly one %s ("%s_99.9"); "%%" is a literal %
+ *   fmt         NUL-terminated pieces; LH_FMT_UNDERSCORE_TO_DOT applies graphite.go:42 to the key
+ *   out/cap     host buffer; *len receives the byte count even when it exceeds cap, in which case
+ *               nothing is written (size and call again).  No trailing NUL.
+ * Every name in the range must have been interned.  prefix+sep+suffix+labels are limited to 2 KiB. */
+typedef struct lh_line_format {
+    const char *prefix;     /* "cockroach.<host>."        | "put "              */
+    const char *sep;        /* " "                        | " <unix time> "     */
+    const char *suffix;     /* " <unix time>\n"           | " host=<host>\n"    */
+    uint32_t    flags;      /* LH_FMT_UNDERSCORE_TO_DOT   | 0                   */
+    uint32_t    reserved;
+} lh_line_format;
+enum { LH_FMT_UNDERSCORE_TO_DOT = 1 };
+enum { LH_SER_AGGREGATES = 1 };
+int lh_serialize(lh_snapshot *s, uint32_t first, size_t nmetrics, const double *p, const char *const *labels,
+                 size_t np, const lh_line_format *fmt, uint32_t flags, char *out, size_t cap, size_t *len);
+/* processHistograms' lifetime side effect (metrics.go:359-376) for every row of the snapshot, kept in
+ * HBM: life_sum[m] += uint64(totalSum_m) (amd64 conversion, wrapping add), life_count[m] += count_m.
+ * Applied at most once per snapshot; later calls return LH_OK without effect. */
+int lh_snapshot_accumulate(lh_snapshot *s);
+/* The lifetime stores of metrics [first, first+n) (histogramCountStore, metrics.go:127). */
+int lh_lifetime(lh_engine *e, uint32_t first, size_t n, uint64_t *count, uint64_t *sum);
+/* Go's %f of n float64 values, formatted on the device (parity tests of the formatter):
+ * value i occupies out[i*slot .. i*slot + lens[i]); slot must be >= 336. */
+int lh_format_f(lh_engine *e, const double *v, size_t n, char *out, size_t slot, uint32_t *lens);
 /* Stream on which the snapshot's extract/clear work is ordered (hipStream_t). */
 int lh_snapshot_stream(lh_snapshot *s, void **stream);
 /* Returns the snapshot's buffer to the pool (cleared asynchronously). */

@@ -32,6 +32,16 @@ class LhCounters(C.Structure):
                                                                 ("reserved", C.c_uint32)]
 
 
+class LhLineFormat(C.Structure):
+    _fields_ = [("prefix", C.c_char_p), ("sep", C.c_char_p), ("suffix", C.c_char_p),
+                ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+FMT_UNDERSCORE_TO_DOT = 1
+SER_AGGREGATES = 1
+FMT_SLOT = 336
+
+
 class LhStats(C.Structure):
     _fields_ = [("count", C.c_uint64), ("sum", C.c_double), ("avg", C.c_double),
                 ("agg_sum_add", C.c_uint64), ("nbuckets", C.c_uint32), ("present", C.c_uint32)]
@@ -69,6 +79,11 @@ SIGNATURES = {
     "lh_snapshot_mark_dirty": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "lh_snapshot_merge": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_uint32, _u32p, _u32p]),
     "lh_set_rccl_library": (C.c_int, [C.c_char_p]),
+    "lh_serialize": (C.c_int, [_vp, C.c_uint32, _sz, _dp, C.POINTER(C.c_char_p), _sz, C.POINTER(LhLineFormat),
+                               C.c_uint32, _vp, _sz, C.POINTER(_sz)]),
+    "lh_snapshot_accumulate": (C.c_int, [_vp]),
+    "lh_lifetime": (C.c_int, [_vp, C.c_uint32, _sz, _u64p, _u64p]),
+    "lh_format_f": (C.c_int, [_vp, _dp, _sz, _vp, _sz, _u32p]),
     "lh_snapshot_stream": (C.c_int, [_vp, C.POINTER(_vp)]),
     "lh_release": (C.c_int, [_vp]),
     "lh_get_counters": (C.c_int, [_vp, C.POINTER(LhCounters)]),

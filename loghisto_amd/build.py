@@ -23,6 +23,7 @@ _UNITS = [
     ("lh_kernels.hip", ["--offload-arch=gfx950"]),
     ("lh_kernels_part.hip", ["--offload-arch=gfx950"]),
     ("lh_kernels_small.hip", ["--offload-arch=gfx950"]),
+    ("lh_kernels_fmt.hip", ["--offload-arch=gfx950"]),
     ("lh_engine.cc", []),
     ("host/metric_system.cc", []),   # C++ host layer with the reference's MetricSystem API (include/loghisto.hpp)
 ]

@@ -127,6 +127,17 @@ struct lh_engine {
     unsigned char *h_xbuf = nullptr;
     size_t xbuf_bytes = 0;
 
+    // K6 (lh_serialize): names, lifetime stores and the text buffer in HBM; all guarded by xmu
+    std::string name_blob;              // names back to back (names_mu)
+    std::vector<uint32_t> name_off{0};  // [names.size() + 1] (names_mu)
+    char *d_names = nullptr;
+    uint32_t *d_name_off = nullptr;
+    size_t d_names_cap = 0, d_name_off_cap = 0, names_uploaded = 0;
+    uint64_t *d_life = nullptr;         // [max_metrics][2] lifetime (count, sum), metrics.go:127
+    char *d_text = nullptr;
+    size_t d_text_cap = 0;
+    char *d_blob = nullptr;             // SER_BLOB_MAX bytes
+
     std::atomic<int> live_snapshots{0};
 
     // adaptive dispatch of mixed launches with few names: the single-pass kernel reports how many samples
@@ -147,6 +158,7 @@ struct lh_engine {
 struct lh_snapshot {
     lh_engine *e;
     int buf;
+    bool life_applied = false; // lh_snapshot_accumulate ran (xmu)
 };
 
 namespace {
@@ -311,6 +323,11 @@ void free_engine(lh_engine *e)
     if (e->d_err) (void)hipFree(e->d_err);
     if (e->d_xbuf) (void)hipFree(e->d_xbuf);
     if (e->h_xbuf) (void)hipHostFree(e->h_xbuf);
+    if (e->d_names) (void)hipFree(e->d_names);
+    if (e->d_name_off) (void)hipFree(e->d_name_off);
+    if (e->d_life) (void)hipFree(e->d_life);
+    if (e->d_text) (void)hipFree(e->d_text);
+    if (e->d_blob) (void)hipFree(e->d_blob);
     if (e->main_stream) (void)hipStreamDestroy(e->main_stream);
     if (e->xstream) (void)hipStreamDestroy(e->xstream);
     delete e;
@@ -362,6 +379,9 @@ int create_impl(const lh_config *cfg_in, lh_engine *e)
     HIPCHK(lh::launch_gen_tables(e->d_Tx, e->d_D, e->xstream));
 
     const size_t M = e->cfg.max_metrics;
+    HIPCHK(hipMalloc((void **)&e->d_life, M * 2 * sizeof(uint64_t)));
+    HIPCHK(hipMemsetAsync(e->d_life, 0, M * 2 * sizeof(uint64_t), e->xstream));
+    HIPCHK(hipMalloc((void **)&e->d_blob, lh::SER_BLOB_MAX));
     e->bufs.resize(e->cfg.num_buffers);
     for (auto &b : e->bufs) {
         HIPCHK(hipMalloc((void **)&b.counts, M * LH_NKEYS * sizeof(uint64_t)));
@@ -471,6 +491,8 @@ int lh_intern(lh_engine *e, const char *name, size_t len, uint32_t *id)
     if (e->names.size() >= e->cfg.max_metrics) return LH_ERANGE;
     const uint32_t nid = (uint32_t)e->names.size();
     e->names.push_back(key);
+    e->name_blob += key;
+    e->name_off.push_back((uint32_t)e->name_blob.size());
     e->name2id.emplace(std::move(key), nid);
     *id = nid;
     return LH_OK;
@@ -675,6 +697,8 @@ int lh_flip(lh_engine *e, lh_snapshot **out)
     return LH_OK;
 }
 
+static int after_extract(lh_engine *e, uint32_t err, uint32_t nfall);
+
 int lh_extract(lh_snapshot *s, const double *p, size_t np, lh_stats *stats, double *pvals, int16_t *pkeys,
                uint8_t *pvalid, size_t nmetrics)
 {
@@ -713,6 +737,12 @@ int lh_extract_rows(lh_snapshot *s, uint32_t first, size_t nmetrics, const doubl
     uint32_t err, nfall;
     std::memcpy(&err, e->h_xbuf + L.off_err, 4);
     std::memcpy(&nfall, e->h_xbuf + L.off_err + 4, 4);
+    return after_extract(e, err, nfall);
+}
+
+// The sticky bad-id flag and the single-pass kernel's window-miss counter ride along with every extract.
+static int after_extract(lh_engine *e, uint32_t err, uint32_t nfall)
+{
     e->c_extracts.fetch_add(1, std::memory_order_relaxed);
     if (nfall) {
         e->c_misses.fetch_add(nfall, std::memory_order_relaxed);
@@ -962,6 +992,252 @@ int lh_snapshot_merge(lh_snapshot *s, void *comm, int nranks, int rank, int plan
     HIPCHK(lh::launch_pack_window(b.counts, send, nrows, (uint32_t)nranks * per, wlo, width, st));
     NCCLCHK(g_reducescatter(send, recv, recv_elems, kNcclUint64, kNcclSum, comm, st));
     HIPCHK(lh::launch_unpack_window(b.counts, recv, own_lo, own_hi - own_lo, wlo, width, st));
+    return LH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// K6: wire text on the device (lh_kernels_fmt.hip)
+// ---------------------------------------------------------------------------
+namespace {
+
+// Names interned since the last call go to HBM (xmu held).
+int upload_names(lh_engine *e, size_t *nnames)
+{
+    std::shared_lock<std::shared_mutex> g(e->names_mu);
+    const size_t nn = e->names.size();
+    *nnames = nn;
+    if (e->names_uploaded == nn && e->d_name_off) return LH_OK;
+    const size_t nbytes = e->name_blob.size();
+    if (nbytes + 1 > e->d_names_cap) {
+        if (e->d_names) (void)hipFree(e->d_names);
+        e->d_names = nullptr;
+        e->d_names_cap = 0;
+        const size_t cap = 2 * nbytes + 4096;
+        HIPCHK(hipMalloc((void **)&e->d_names, cap));
+        e->d_names_cap = cap;
+    }
+    if (nn + 1 > e->d_name_off_cap) {
+        if (e->d_name_off) (void)hipFree(e->d_name_off);
+        e->d_name_off = nullptr;
+        e->d_name_off_cap = 0;
+        const size_t cap = 2 * (nn + 1) + 1024;
+        HIPCHK(hipMalloc((void **)&e->d_name_off, cap * sizeof(uint32_t)));
+        e->d_name_off_cap = cap;
+    }
+    // whole table each time it grew: a few MB at 65 536 names, and only in intervals that saw new names
+    if (nbytes) HIPCHK(hipMemcpyAsync(e->d_names, e->name_blob.data(), nbytes, hipMemcpyHostToDevice, e->xstream));
+    HIPCHK(hipMemcpyAsync(e->d_name_off, e->name_off.data(), (nn + 1) * sizeof(uint32_t), hipMemcpyHostToDevice,
+                          e->xstream));
+    HIPCHK(hipStreamSynchronize(e->xstream)); // the host vectors may grow once names_mu is dropped
+    e->names_uploaded = nn;
+    return LH_OK;
+}
+
+// label = pre "%s" post with "%%" -> '%'; exactly one %s
+bool split_label(const char *label, std::string *pre, std::string *post)
+{
+    int seen = 0;
+    std::string *cur = pre;
+    for (const char *c = label; *c; c++) {
+        if (c[0] == '%' && c[1] == 's') {
+            if (seen++) return false;
+            cur = post;
+            c++;
+        } else if (c[0] == '%' && c[1] == '%') {
+            *cur += '%';
+            c++;
+        } else if (c[0] == '%') {
+            return false;
+        } else {
+            *cur += *c;
+        }
+    }
+    return seen == 1;
+}
+
+struct BlobBuilder {
+    std::string bytes;
+    bool dots;
+    bool ok = true;
+    void put(const std::string &s, bool is_key, uint32_t *off, uint32_t *len)
+    {
+        *off = (uint32_t)bytes.size();
+        *len = (uint32_t)s.size();
+        for (char c : s) bytes += (is_key && dots && c == '_') ? '.' : c;
+        if (bytes.size() > lh::SER_BLOB_MAX) ok = false;
+    }
+    void key(const std::string &pre, const std::string &post, lh::SerKey *k)
+    {
+        uint32_t o, l;
+        put(pre, true, &o, &l);
+        k->pre_off = (uint16_t)o; k->pre_len = (uint16_t)l;
+        put(post, true, &o, &l);
+        k->post_off = (uint16_t)o; k->post_len = (uint16_t)l;
+    }
+};
+
+} // namespace
+
+int lh_serialize(lh_snapshot *s, uint32_t first, size_t nmetrics, const double *p, const char *const *labels,
+                 size_t np, const lh_line_format *fmt, uint32_t flags, char *out, size_t cap, size_t *len)
+{
+    if (!s || !fmt || !len || (np && (!p || !labels)) || (cap && !out)) return LH_EINVAL;
+    if (!fmt->prefix || !fmt->sep || !fmt->suffix || np > LH_MAX_PERCENTILES) return LH_EINVAL;
+    *len = 0;
+    lh_engine *e = s->e;
+    if (nmetrics == 0) return LH_OK;
+    int rc = use_device(e);
+    if (rc) return rc;
+
+    lh::SerArgs a{};
+    BlobBuilder bb;
+    bb.dots = (fmt->flags & LH_FMT_UNDERSCORE_TO_DOT) != 0;
+    bb.put(fmt->prefix, false, &a.prefix_off, &a.prefix_len);
+    bb.put(fmt->sep, false, &a.sep_off, &a.sep_len);
+    bb.put(fmt->suffix, false, &a.suffix_off, &a.suffix_len);
+    uint32_t nk = 0;
+    bb.key("", "_count", &a.keys[nk++]); // metrics.go:349-351
+    bb.key("", "_sum", &a.keys[nk++]);
+    bb.key("", "_avg", &a.keys[nk++]);
+    for (size_t i = 0; i < np; i++) {
+        std::string pre, post;
+        if (!labels[i] || !split_label(labels[i], &pre, &post)) return LH_EINVAL;
+        bb.key(pre, post, &a.keys[nk++]);
+    }
+    if (flags & LH_SER_AGGREGATES) { // metrics.go:601-606
+        bb.key("", "_agg_avg", &a.keys[nk++]);
+        bb.key("", "_agg_count", &a.keys[nk++]);
+        bb.key("", "_agg_sum", &a.keys[nk++]);
+    }
+    if (!bb.ok) return LH_EINVAL;
+
+    std::lock_guard<std::mutex> g(e->xmu);
+    size_t nnames = 0;
+    rc = upload_names(e, &nnames);
+    if (rc) return rc;
+    if ((uint64_t)first + nmetrics > nnames) return LH_EINVAL;
+
+    const uint64_t nlines = (uint64_t)nmetrics * nk;
+    const uint32_t nb = lh::ser_blocks(nlines);
+    const ExtractLayout L = extract_layout(nmetrics, np);
+    const size_t off_lens = (L.total + 15) & ~size_t(15);
+    const size_t off_bsum = off_lens + ((nlines * 4 + 15) & ~size_t(15));
+    const size_t off_boff = off_bsum + (((size_t)nb * 4 + 15) & ~size_t(15));
+    const size_t total_x = off_boff + ((size_t)nb + 1) * 8;
+    rc = ensure_xbuf(e, total_x);
+    if (rc) return rc;
+
+    EpochBuffer &b = e->bufs[(size_t)s->buf];
+    HIPCHK(hipMemcpyAsync(e->d_blob, bb.bytes.data(), bb.bytes.size(), hipMemcpyHostToDevice, e->xstream));
+    HIPCHK(lh::launch_extract(b.counts + (size_t)first * LH_NKEYS, b.ranges + 2 * (size_t)first, (uint32_t)nmetrics,
+                              p, (uint32_t)np, e->d_D, reinterpret_cast<lh::ExtractOut *>(e->d_xbuf + L.off_stats),
+                              reinterpret_cast<double *>(e->d_xbuf + L.off_pvals),
+                              reinterpret_cast<int16_t *>(e->d_xbuf + L.off_pkeys), e->d_xbuf + L.off_pvalid,
+                              e->d_err, reinterpret_cast<uint32_t *>(e->d_xbuf + L.off_err), e->xstream));
+    a.stats = reinterpret_cast<const lh::ExtractOut *>(e->d_xbuf + L.off_stats);
+    a.pvals = reinterpret_cast<const double *>(e->d_xbuf + L.off_pvals);
+    a.pvalid = e->d_xbuf + L.off_pvalid;
+    a.life = e->d_life;
+    a.names = e->d_names;
+    a.name_off = e->d_name_off;
+    a.blob = e->d_blob;
+    a.blob_len = (uint32_t)bb.bytes.size();
+    a.first = first;
+    a.nmetrics = (uint32_t)nmetrics;
+    a.np = (uint32_t)np;
+    a.nkeys = nk;
+    a.flags = bb.dots ? lh::SER_DOTS : 0u;
+    uint32_t *d_lens = reinterpret_cast<uint32_t *>(e->d_xbuf + off_lens);
+    uint32_t *d_bsum = reinterpret_cast<uint32_t *>(e->d_xbuf + off_bsum);
+    uint64_t *d_boff = reinterpret_cast<uint64_t *>(e->d_xbuf + off_boff);
+    HIPCHK(lh::launch_ser_len(a, d_lens, d_bsum, d_boff, e->xstream));
+    HIPCHK(hipMemcpyAsync(e->h_xbuf, d_boff + nb, 8, hipMemcpyDeviceToHost, e->xstream));
+    HIPCHK(hipMemcpyAsync(e->h_xbuf + 8, e->d_xbuf + L.off_err, 8, hipMemcpyDeviceToHost, e->xstream));
+    HIPCHK(hipStreamSynchronize(e->xstream)); // also keeps bb.bytes alive until the blob copy is done
+    uint64_t total = 0;
+    uint32_t err, nfall;
+    std::memcpy(&total, e->h_xbuf, 8);
+    std::memcpy(&err, e->h_xbuf + 8, 4);
+    std::memcpy(&nfall, e->h_xbuf + 12, 4);
+    *len = (size_t)total;
+    const int erc = after_extract(e, err, nfall); // LH_ERANGE: some sample carried a bad id (text is still produced)
+    if (erc != LH_OK && erc != LH_ERANGE) return erc;
+    if (total == 0 || total > cap) return erc;
+    if (total + 16 > e->d_text_cap) {
+        if (e->d_text) (void)hipFree(e->d_text);
+        e->d_text = nullptr;
+        e->d_text_cap = 0;
+        const size_t want = (size_t)total + (size_t)total / 4 + 4096;
+        HIPCHK(hipMalloc((void **)&e->d_text, want));
+        e->d_text_cap = want;
+    }
+    HIPCHK(lh::launch_ser_write(a, d_lens, d_boff, e->d_text, e->xstream));
+    HIPCHK(hipMemcpyAsync(out, e->d_text, (size_t)total, hipMemcpyDeviceToHost, e->xstream));
+    HIPCHK(hipStreamSynchronize(e->xstream));
+    return erc;
+}
+
+int lh_snapshot_accumulate(lh_snapshot *s)
+{
+    if (!s) return LH_EINVAL;
+    lh_engine *e = s->e;
+    int rc = use_device(e);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(e->xmu);
+    if (s->life_applied) return LH_OK;
+    const size_t M = e->cfg.max_metrics;
+    const ExtractLayout L = extract_layout(M, 0);
+    rc = ensure_xbuf(e, L.total);
+    if (rc) return rc;
+    EpochBuffer &b = e->bufs[(size_t)s->buf];
+    lh::ExtractOut *d_stats = reinterpret_cast<lh::ExtractOut *>(e->d_xbuf + L.off_stats);
+    HIPCHK(lh::launch_extract(b.counts, b.ranges, (uint32_t)M, nullptr, 0, e->d_D, d_stats,
+                              reinterpret_cast<double *>(e->d_xbuf + L.off_pvals),
+                              reinterpret_cast<int16_t *>(e->d_xbuf + L.off_pkeys), e->d_xbuf + L.off_pvalid,
+                              e->d_err, reinterpret_cast<uint32_t *>(e->d_xbuf + L.off_err), e->xstream));
+    HIPCHK(lh::launch_life_add(d_stats, e->d_life, (uint32_t)M, e->xstream));
+    s->life_applied = true;
+    return LH_OK;
+}
+
+int lh_lifetime(lh_engine *e, uint32_t first, size_t n, uint64_t *count, uint64_t *sum)
+{
+    if (!e || (n && (!count || !sum))) return LH_EINVAL;
+    if ((uint64_t)first + n > e->cfg.max_metrics) return LH_EINVAL;
+    if (n == 0) return LH_OK;
+    int rc = use_device(e);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(e->xmu);
+    rc = ensure_xbuf(e, n * 16);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(e->h_xbuf, e->d_life + 2 * (size_t)first, n * 16, hipMemcpyDeviceToHost, e->xstream));
+    HIPCHK(hipStreamSynchronize(e->xstream));
+    const uint64_t *h = reinterpret_cast<const uint64_t *>(e->h_xbuf);
+    for (size_t i = 0; i < n; i++) { count[i] = h[2 * i]; sum[i] = h[2 * i + 1]; }
+    return LH_OK;
+}
+
+int lh_format_f(lh_engine *e, const double *v, size_t n, char *out, size_t slot, uint32_t *lens)
+{
+    if (!e || (n && (!v || !out || !lens)) || slot < lh::SER_FMT_SLOT || n > (size_t(1) << 24)) return LH_EINVAL;
+    if (n == 0) return LH_OK;
+    int rc = use_device(e);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(e->xmu);
+    const size_t off_out = (n * 8 + 15) & ~size_t(15);
+    const size_t off_lens = off_out + n * lh::SER_FMT_SLOT;
+    const size_t total = off_lens + n * 4;
+    rc = ensure_xbuf(e, total);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(e->d_xbuf, v, n * 8, hipMemcpyHostToDevice, e->xstream));
+    HIPCHK(lh::launch_format_f(reinterpret_cast<const double *>(e->d_xbuf), reinterpret_cast<char *>(e->d_xbuf + off_out),
+                               reinterpret_cast<uint32_t *>(e->d_xbuf + off_lens), (uint32_t)n, e->xstream));
+    HIPCHK(hipMemcpyAsync(e->h_xbuf + off_out, e->d_xbuf + off_out, total - off_out, hipMemcpyDeviceToHost,
+                          e->xstream));
+    HIPCHK(hipStreamSynchronize(e->xstream));
+    std::memcpy(lens, e->h_xbuf + off_lens, n * 4);
+    for (size_t i = 0; i < n; i++)
+        std::memcpy(out + i * slot, e->h_xbuf + off_out + i * lh::SER_FMT_SLOT, lens[i]);
     return LH_OK;
 }
 

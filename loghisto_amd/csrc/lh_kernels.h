@@ -61,6 +61,31 @@ hipError_t launch_pack_window(const uint64_t *counts, uint64_t *buf, uint32_t nr
 hipError_t launch_unpack_window(uint64_t *counts, const uint64_t *buf, uint32_t first_row, uint32_t nrows_out,
                                 uint32_t wlo, uint32_t width, hipStream_t s);
 
+// K6 (lh_kernels_fmt.hip): ProcessedMetricSet keys + Go "%f" + wire lines, one thread per (metric, key).
+struct SerKey { uint16_t pre_off, pre_len, post_off, post_len; }; // key = pre + name + post, strings in the blob
+constexpr uint32_t SER_DOTS = 1u;                                 // '_' -> '.' in the name (graphite.go:42)
+constexpr uint32_t SER_MAX_KEYS = 3 + 32 + 3;                     // _count _sum _avg, percentiles, _agg_*
+constexpr uint32_t SER_BLOB_MAX = 2048;
+constexpr uint32_t SER_FMT_SLOT = 336;                            // longest "%f" of a float64 is 317 bytes
+struct SerArgs {
+    const ExtractOut *stats;  // [nmetrics] rows first .. first+nmetrics
+    const double *pvals;      // [nmetrics][np]
+    const uint8_t *pvalid;    // [nmetrics][np]
+    const uint64_t *life;     // [max_metrics][2] lifetime (count, sum); read only when nkeys includes _agg_*
+    const char *names;        // name bytes of every interned metric, back to back
+    const uint32_t *name_off; // [num_names + 1]
+    const char *blob;         // prefix | sep | suffix | key strings
+    uint32_t blob_len, first, nmetrics, np, nkeys, flags;
+    uint32_t prefix_off, prefix_len, sep_off, sep_len, suffix_off, suffix_len;
+    SerKey keys[SER_MAX_KEYS];
+};
+uint32_t ser_blocks(uint64_t nlines);
+// lens[nlines], bsum[ser_blocks], boff[ser_blocks + 1]; boff[ser_blocks] receives the total byte count
+hipError_t launch_ser_len(const SerArgs &a, uint32_t *lens, uint32_t *bsum, uint64_t *boff, hipStream_t s);
+hipError_t launch_ser_write(const SerArgs &a, const uint32_t *lens, const uint64_t *boff, char *out, hipStream_t s);
+hipError_t launch_life_add(const ExtractOut *stats, uint64_t *life, uint32_t n, hipStream_t s);
+hipError_t launch_format_f(const double *d_v, char *d_out, uint32_t *d_lens, uint32_t n, hipStream_t s);
+
 // K3: clear the dirty span of every row and reset the ranges.
 hipError_t launch_clear(uint64_t *counts, uint32_t *ranges, uint32_t nmetrics, hipStream_t s);
 hipError_t launch_init_ranges(uint32_t *ranges, uint32_t nmetrics, hipStream_t s);

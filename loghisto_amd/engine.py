@@ -91,6 +91,38 @@ class Snapshot:
                     "lh_buckets_all")
         return offsets, keys, counts
 
+    def serialize(self, percentiles, prefix: str, sep: str, suffix: str, underscore_to_dot: bool = False,
+                  aggregates: bool = False, nmetrics: Optional[int] = None, first: int = 0) -> bytes:
+        """K6: the interval's histogram keys as wire text, formatted on the device (lh_serialize).
+        `percentiles` is the reference's label -> p mapping ({"%s_50": .5, ...}), in the order the keys
+        should appear."""
+        L = N.lib()
+        if nmetrics is None:
+            nmetrics = self.engine.num_metrics() - first
+        labels = list(percentiles.keys())
+        p = np.ascontiguousarray([percentiles[k] for k in labels], dtype=np.float64)
+        lab = (C.c_char_p * max(1, len(labels)))(*[k.encode() for k in labels])
+        fmt = N.LhLineFormat(prefix.encode(), sep.encode(), suffix.encode(),
+                             N.FMT_UNDERSCORE_TO_DOT if underscore_to_dot else 0, 0)
+        flags = N.SER_AGGREGATES if aggregates else 0
+        n = C.c_size_t(0)
+        pp = p.ctypes.data_as(C.POINTER(C.c_double))
+        rc = L.lh_serialize(self._h, first, nmetrics, pp, lab, len(labels), C.byref(fmt), flags, None, 0, C.byref(n))
+        if rc != N.ERANGE:
+            N.check(rc, "lh_serialize")
+        if n.value == 0:
+            return b""
+        buf = C.create_string_buffer(n.value)
+        rc = L.lh_serialize(self._h, first, nmetrics, pp, lab, len(labels), C.byref(fmt), flags, buf, n.value,
+                            C.byref(n))
+        if rc != N.ERANGE:
+            N.check(rc, "lh_serialize")
+        return buf.raw[:n.value]
+
+    def accumulate(self):
+        """processHistograms' lifetime side effect (metrics.go:359-376), once per snapshot, in HBM."""
+        N.check(N.lib().lh_snapshot_accumulate(self._h), "lh_snapshot_accumulate")
+
     def dense_row(self, metric_id: int) -> np.ndarray:
         """Dense uint64[65536] row (bin = key ^ 0x8000) rebuilt from lh_buckets."""
         keys, counts = self.buckets(metric_id)
@@ -228,6 +260,32 @@ class Engine:
         out = C.c_double(0)
         N.check(N.lib().lh_selftest_vlog(self._h, C.byref(out)), "lh_selftest_vlog")
         return float(out.value)
+
+    def lifetime(self, n: Optional[int] = None, first: int = 0):
+        """(count, sum) lifetime stores of metrics [first, first+n) (histogramCountStore, metrics.go:127)."""
+        if n is None:
+            n = self.num_metrics() - first
+        cnt = np.zeros(n, dtype=np.uint64)
+        sm = np.zeros(n, dtype=np.uint64)
+        if n:
+            N.check(N.lib().lh_lifetime(self._h, first, n, cnt.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                        sm.ctypes.data_as(C.POINTER(C.c_uint64))), "lh_lifetime")
+        return cnt, sm
+
+    def format_f(self, values) -> list:
+        """Go's %f of each float64, formatted by the device formatter (lh_format_f)."""
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        out: list = []
+        step = 1 << 16
+        for i in range(0, v.size, step):
+            part = v[i:i + step]
+            buf = C.create_string_buffer(part.size * N.FMT_SLOT)
+            lens = np.zeros(part.size, dtype=np.uint32)
+            N.check(N.lib().lh_format_f(self._h, part.ctypes.data_as(C.POINTER(C.c_double)), part.size, buf,
+                                        N.FMT_SLOT, lens.ctypes.data_as(C.POINTER(C.c_uint32))), "lh_format_f")
+            raw = buf.raw
+            out.extend(raw[k * N.FMT_SLOT:k * N.FMT_SLOT + int(lens[k])].decode() for k in range(part.size))
+        return out
 
     def counters(self) -> dict:
         """Self-metrics of the engine (lh_get_counters)."""

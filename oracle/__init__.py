@@ -65,6 +65,7 @@ def lib():
         L.lho_bench_dense.argtypes = [dp, C.c_size_t, C.c_int, u64p]
         L.lho_bench_dense_reps.restype = C.c_double
         L.lho_bench_dense_reps.argtypes = [dp, C.c_size_t, C.c_int, C.c_int, u64p]
+        L.lho_format_f.restype = C.c_int; L.lho_format_f.argtypes = [C.c_double, C.c_char_p]
         _lib = L
     return _lib
 
@@ -172,6 +173,54 @@ def process_histograms(name: str, counts: np.ndarray, percentiles=None) -> dict:
     for i, lab in enumerate(labels):
         if r["pvalid"][i]:
             out[lab % name] = float(r["pvals"][i])
+    return out
+
+
+def format_f(v: float) -> str:
+    """fmt.Sprintf("%f", v) (graphite.go:40, opentsdb.go:48)."""
+    buf = C.create_string_buffer(336)
+    n = lib().lho_format_f(float(v), buf)
+    return buf.raw[:n].decode()
+
+
+def fmt_label(label: str, name: str) -> str:
+    """fmt.Sprintf(label, name) for labels holding one %s (metrics.go:383)."""
+    return label.replace("%%", "\0").replace("%s", name).replace("\0", "%")
+
+
+def wire_lines(names, counts_rows, percentiles, prefix: str, sep: str, suffix: str, underscore_to_dot: bool = False,
+               life=None, sums=None) -> list:
+    """The lines GraphiteProtocol / OpenTSDBProtocol emit for the histogram keys of one interval
+    (metrics.go:495-499, 590-608; graphite.go:37-48; opentsdb.go:45-58), metric-major, keys in the order
+    _count, _sum, _avg, labels, _agg_avg, _agg_count, _agg_sum.  counts_rows[i] is the dense row of
+    names[i]; life = (count[], sum[]) lifetime stores AFTER this interval or None; sums (optional)
+    overrides the oracle's ascending-key _sum/_avg with the caller's float64 sums (their order of
+    summation is unpinned)."""
+    labels = list(percentiles.keys())
+    ps = [percentiles[k] for k in labels]
+    out = []
+
+    def line(key, value):
+        if underscore_to_dot:
+            key = key.replace("_", ".")
+        out.append(f"{prefix}{key}{sep}{format_f(value)}{suffix}")
+
+    for i, name in enumerate(names):
+        r = process_dense(counts_rows[i], ps)
+        if r["count"] == 0:
+            continue
+        s = r["sum"] if sums is None else float(sums[i])
+        line(f"{name}_count", float(r["count"]))
+        line(f"{name}_sum", s)
+        line(f"{name}_avg", s / float(r["count"]))
+        for j, lab in enumerate(labels):
+            if r["pvalid"][j]:
+                line(fmt_label(lab, name), float(r["pvals"][j]))
+        if life is not None and int(life[0][i]) > 0:
+            lc, ls = int(life[0][i]), int(life[1][i])
+            line(f"{name}_agg_avg", float(ls // lc))
+            line(f"{name}_agg_count", float(lc))
+            line(f"{name}_agg_sum", float(ls))
     return out
 
 

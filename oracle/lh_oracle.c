@@ -8,6 +8,7 @@
 #include "lh_oracle.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -297,4 +298,12 @@ int lho_percentile(uint64_t total, const double *values, const uint64_t *counts,
     if (rc) *out = 0;
     free(a);
     return rc;
+}
+
+/* fmt.Sprintf("%f", v), graphite.go:40 / opentsdb.go:48 */
+int lho_format_f(double v, char *dst)
+{
+    if (isnan(v)) { memcpy(dst, "NaN", 4); return 3; }
+    if (isinf(v)) { memcpy(dst, v < 0 ? "-Inf" : "+Inf", 5); return 4; }
+    return snprintf(dst, 336, "%.6f", v);
 }

@@ -106,6 +106,14 @@ int lho_percentile(uint64_t total, const double *values, const uint64_t *counts,
 /* uint64(float64) with amd64 CVTTSD2SQ semantics (metrics.go:374). */
 uint64_t lho_f64_to_u64_amd64(double f);
 
+/* Go's fmt "%f" of a float64 (graphite.go:40, opentsdb.go:48): strconv.FormatFloat(v, 'f', 6, 64) --
+ * the exact decimal expansion of the binary value rounded half-even to 6 fractional digits -- with Go's
+ * spellings "NaN", "+Inf", "-Inf".  C99 printf("%.6f") under round-to-nearest has the same contract and
+ * glibc implements it exactly; tests/test_oracle.py cross-checks it against Python's decimal module.
+ * PARITY UNPINNED by the reference: its tests hold no formatted golden (graphite_test.go and
+ * opentsdb_test.go only open a socket).  dst needs 336 bytes; returns the length (no NUL counted). */
+int lho_format_f(double v, char *dst);
+
 #ifdef __cplusplus
 }
 #endif
