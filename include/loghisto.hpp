@@ -92,10 +92,20 @@ private:
     bool closed_ = false;
 };
 
+// Bulk wire path (no counterpart in the reference): which serializer's text the reaper
+// prepares on the GPU while it still holds the interval's snapshot (MetricSystem::SetWireFormat).
+enum class WireFormat { None = 0, Graphite = 1, OpenTSDB = 2 };
+
 // metrics.go:47-50
 struct ProcessedMetricSet {
     std::chrono::system_clock::time_point Time;
     std::unordered_map<std::string, double> Metrics;
+
+    // Filled only when a wire format is set: the complete request GraphiteProtocol / OpenTSDBProtocol would
+    // build from this interval -- histogram keys formatted on the device by lh_serialize, counters / rates /
+    // gauges appended by the host -- so the serializer returns it instead of one snprintf per key.
+    WireFormat wire_format = WireFormat::None;
+    std::string wire;
 };
 
 // metrics.go:54-60.  Histograms holds the occupied (key -> count) cells per name; it is
@@ -167,6 +177,12 @@ public:
     void Start();
     void Stop();
 
+    // Opt-in bulk wire path: processMetrics also calls lh_snapshot_accumulate + lh_serialize and attaches the
+    // text to the ProcessedMetricSet.  With histogram_keys_in_map = false the histogram keys are NOT inserted
+    // into ProcessedMetricSet::Metrics (65 536 names x 15 keys is ~1e6 string-keyed inserts per interval);
+    // counters, rates and gauges always are.
+    void SetWireFormat(WireFormat f, bool histogram_keys_in_map = true);
+
     // diagnostics
     int last_status() const { return last_status_.load(); } // last non-zero lh_* code (0 if none)
     uint64_t dropped_intervals() const { return dropped_intervals_.load(); }
@@ -181,6 +197,8 @@ private:
     void updateSubscribers();
     void reaper();
     void note(int rc, const char *where);
+    void serializeHistograms(RawMetricSet &raw, const std::vector<std::string> &labels, const std::vector<double> &ps,
+                             WireFormat wf, std::string &text);
 
     std::chrono::nanoseconds interval_;
     Options opt_;
@@ -189,6 +207,10 @@ private:
 
     lh_engine *engine_ = nullptr;
     std::mutex engine_mu_;
+
+    std::atomic<int> wire_format_{0};
+    std::atomic<bool> wire_keep_map_{true};
+    std::atomic<size_t> wire_bytes_hint_{0};
 
     // histogramMu (metrics.go:121): submitters shared, the flip exclusive
     std::shared_mutex histogram_mu_;

@@ -350,6 +350,7 @@ std::shared_ptr<ProcessedMetricSet> MetricSystem::processMetrics(const std::shar
     for (auto &kv : raw->Rates) m[kv.first + "_rate"] = (double)kv.second; // metrics.go:491-493
 
     // processHistograms for every name in one extract (metrics.go:336-387, 495-499)
+    size_t n_map = 0;
     if (raw->snapshot && !raw->names.empty()) {
         std::vector<std::string> labels;
         std::vector<double> ps;
@@ -357,7 +358,23 @@ std::shared_ptr<ProcessedMetricSet> MetricSystem::processMetrics(const std::shar
             std::lock_guard<std::mutex> g(percentiles_mu_);
             for (auto &kv : percentiles_) { labels.push_back(kv.first); ps.push_back(kv.second); }
         }
-        const size_t n = raw->names.size(), np = ps.size();
+        const size_t n = raw->names.size();
+        const WireFormat wf = (WireFormat)wire_format_.load();
+        if (wf != WireFormat::None) {
+            out->wire_format = wf;
+            serializeHistograms(*raw, labels, ps, wf, out->wire);
+        }
+        if (wf != WireFormat::None && !wire_keep_map_.load()) n_map = 0;
+        else n_map = n;
+    }
+    if (n_map) {
+        std::vector<std::string> labels;
+        std::vector<double> ps;
+        {
+            std::lock_guard<std::mutex> g(percentiles_mu_);
+            for (auto &kv : percentiles_) { labels.push_back(kv.first); ps.push_back(kv.second); }
+        }
+        const size_t n = n_map, np = ps.size();
         std::vector<lh_stats> st(n);
         std::vector<double> pv(n * np);
         std::vector<uint8_t> ok(n * np);
@@ -389,7 +406,70 @@ std::shared_ptr<ProcessedMetricSet> MetricSystem::processMetrics(const std::shar
         }
     }
     for (auto &kv : raw->Gauges) m[kv.first] = kv.second; // metrics.go:501-503
+    if (out->wire_format != WireFormat::None) {
+        // the keys that never were on the device: counters, rates, gauges (a few hundred at most)
+        ProcessedMetricSet rest;
+        rest.Time = out->Time;
+        for (auto &kv : raw->Counters) rest.Metrics[kv.first] = (double)kv.second;
+        for (auto &kv : raw->Rates) rest.Metrics[kv.first + "_rate"] = (double)kv.second;
+        for (auto &kv : raw->Gauges) rest.Metrics[kv.first] = kv.second;
+        out->wire += out->wire_format == WireFormat::Graphite ? GraphiteProtocol(rest) : OpenTSDBProtocol(rest);
+    }
     return out;
+}
+
+void MetricSystem::SetWireFormat(WireFormat f, bool histogram_keys_in_map)
+{
+    wire_keep_map_.store(histogram_keys_in_map);
+    wire_format_.store((int)f);
+}
+
+// The histogram keys of the interval as wire text, formatted on the device (K6): processHistograms' lifetime
+// side effect first (metrics.go:359-376), then every key incl. _agg_* in one lh_serialize.
+void MetricSystem::serializeHistograms(RawMetricSet &raw, const std::vector<std::string> &labels,
+                                       const std::vector<double> &ps, WireFormat wf, std::string &text)
+{
+    const std::string host = hostname();
+    const long long t =
+        (long long)std::chrono::duration_cast<std::chrono::seconds>(raw.Time.time_since_epoch()).count();
+    const std::string ts = std::to_string(t);
+    std::string prefix, sep, suffix;
+    lh_line_format fmt{};
+    if (wf == WireFormat::Graphite) { // graphite.go:40
+        prefix = "cockroach." + host + ".";
+        sep = " ";
+        suffix = " " + ts + "\n";
+        fmt.flags = LH_FMT_UNDERSCORE_TO_DOT;
+    } else {                          // opentsdb.go:48
+        prefix = "put ";
+        sep = " " + ts + " ";
+        suffix = " host=" + host + "\n";
+    }
+    fmt.prefix = prefix.c_str();
+    fmt.sep = sep.c_str();
+    fmt.suffix = suffix.c_str();
+    std::vector<const char *> lab;
+    for (auto &l : labels) lab.push_back(l.c_str());
+
+    std::lock_guard<std::mutex> g(raw.mu);
+    if (!raw.snapshot) return;
+    note(lh_snapshot_accumulate(raw.snapshot), "lh_snapshot_accumulate");
+    const size_t n = raw.names.size();
+    size_t need = 0;
+    text.resize(std::max<size_t>(wire_bytes_hint_.load(), 4096));
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const int rc = lh_serialize(raw.snapshot, 0, n, ps.data(), lab.data(), ps.size(), &fmt, LH_SER_AGGREGATES,
+                                    &text[0], text.size(), &need);
+        if (rc != LH_OK && rc != LH_ERANGE) {
+            note(rc, "lh_serialize");
+            text.clear();
+            return;
+        }
+        if (need <= text.size()) break;
+        text.resize(need + need / 8);
+    }
+    text.resize(need);
+    wire_bytes_hint_.store(need + need / 8);
 }
 
 void MetricSystem::addAggregates(const std::shared_ptr<RawMetricSet> &raw, ProcessedMetricSet &processed)
@@ -657,6 +737,7 @@ void Submitter::Shutdown() // submitter.go:152-159
 // ---------------------------------------------------------------------------
 std::string GraphiteProtocol(const ProcessedMetricSet &ms)
 {
+    if (ms.wire_format == WireFormat::Graphite) return ms.wire; // prepared in bulk by processMetrics
     const std::string host = hostname();
     const long long t = (long long)std::chrono::duration_cast<std::chrono::seconds>(ms.Time.time_since_epoch()).count();
     std::string out;
@@ -677,6 +758,7 @@ std::string GraphiteProtocol(const ProcessedMetricSet &ms)
 
 std::string OpenTSDBProtocol(const ProcessedMetricSet &ms)
 {
+    if (ms.wire_format == WireFormat::OpenTSDB) return ms.wire;
     const std::string host = hostname();
     const long long t = (long long)std::chrono::duration_cast<std::chrono::seconds>(ms.Time.time_since_epoch()).count();
     std::string out;

@@ -42,10 +42,44 @@ DEFAULT_PERCENTILES = {
 }
 
 
+def _hostname() -> str:
+    import socket
+    try:
+        return socket.gethostname()
+    except OSError:
+        return "unknown"  # graphite.go:52-55
+
+
+def _go_f(v: float) -> str:
+    """fmt.Sprintf("%f", v) for the few host-side keys (counters, rates, gauges)."""
+    if v != v:
+        return "NaN"
+    if v in (float("inf"), float("-inf")):
+        return "+Inf" if v > 0 else "-Inf"
+    return "%f" % v
+
+
+def GraphiteProtocol(ms: "ProcessedMetricSet") -> bytes:  # graphite.go:37-75
+    if ms.wire_format == "graphite":
+        return ms.wire
+    host, ts = _hostname(), int(ms.Time)
+    return "".join(f"cockroach.{host}.{k.replace('_', '.')} {_go_f(v)} {ts}\n" for k, v in ms.Metrics.items()).encode()
+
+
+def OpenTSDBProtocol(ms: "ProcessedMetricSet") -> bytes:  # opentsdb.go:45-85
+    if ms.wire_format == "opentsdb":
+        return ms.wire
+    host, ts = _hostname(), int(ms.Time)
+    return "".join(f"put {k} {ts} {_go_f(v)} host={host}\n" for k, v in ms.Metrics.items()).encode()
+
+
 @dataclass
 class ProcessedMetricSet:  # metrics.go:47-50
     Time: float
     Metrics: Dict[str, float]
+    # bulk wire path (MetricSystem.SetWireFormat): the whole request, histogram keys formatted on the device
+    wire_format: Optional[str] = None
+    wire: bytes = b""
 
 
 @dataclass
@@ -106,6 +140,8 @@ class MetricSystem:
                  stage_samples: int = 4096, engine: Optional[Engine] = None):
         """NewMetricSystem(interval, sysStats), metrics.go:143.  `interval` in seconds."""
         self.percentiles = dict(DEFAULT_PERCENTILES)
+        self._wire_format: Optional[str] = None
+        self._wire_keep_map = True
         self.interval = float(interval)
         self._device, self._max_metrics, self._stage_cap = device, max_metrics, stage_samples
         self._engine = engine
@@ -266,10 +302,42 @@ class MetricSystem:
             metrics[name] = float(count)
         for name, count in raw.Rates.items():
             metrics[f"{name}_rate"] = float(count)
-        metrics.update(self.processHistograms(raw))
+        host_keys = dict(metrics)
+        wf = self._wire_format
+        wire = b""
+        if wf is not None and raw._snapshot is not None and raw._names:
+            wire = self.serializeHistograms(raw, wf)
+        if wf is None or self._wire_keep_map:
+            metrics.update(self.processHistograms(raw))
         for name, value in raw.Gauges.items():
             metrics[name] = value
-        return ProcessedMetricSet(Time=raw.Time, Metrics=metrics)
+            host_keys[name] = value
+        out = ProcessedMetricSet(Time=raw.Time, Metrics=metrics)
+        if wf is not None and raw._snapshot is not None and raw._names:
+            rest = ProcessedMetricSet(Time=raw.Time, Metrics=host_keys)
+            out.wire_format = wf
+            out.wire = wire + (GraphiteProtocol(rest) if wf == "graphite" else OpenTSDBProtocol(rest))
+        return out
+
+    def SetWireFormat(self, kind: Optional[str], histogram_keys_in_map: bool = True):
+        """Opt-in bulk wire path (no counterpart in the reference): processMetrics also runs
+        lh_snapshot_accumulate + lh_serialize (K6) and attaches the request GraphiteProtocol /
+        OpenTSDBProtocol would build; with histogram_keys_in_map=False the histogram keys are not
+        inserted into Metrics.  kind: None | "graphite" | "opentsdb"."""
+        if kind not in (None, "graphite", "opentsdb"):
+            raise ValueError(kind)
+        self._wire_keep_map = histogram_keys_in_map
+        self._wire_format = kind
+
+    def serializeHistograms(self, raw: RawMetricSet, kind: str) -> bytes:
+        """Histogram keys of the interval incl. _agg_* as wire text, formatted on the device."""
+        host, ts = _hostname(), str(int(raw.Time))
+        raw._snapshot.accumulate()  # processHistograms' lifetime side effect, metrics.go:359-376
+        if kind == "graphite":      # graphite.go:40
+            return raw._snapshot.serialize(self.percentiles, f"cockroach.{host}.", " ", f" {ts}\n",
+                                           underscore_to_dot=True, aggregates=True, nmetrics=len(raw._names))
+        return raw._snapshot.serialize(self.percentiles, "put ", f" {ts} ", f" host={host}\n",  # opentsdb.go:48
+                                       aggregates=True, nmetrics=len(raw._names))
 
     def _add_aggregates(self, raw: RawMetricSet, processed: ProcessedMetricSet):  # metrics.go:590-608
         for name in raw._names:

@@ -16,7 +16,7 @@ import sys
 
 
 def short(name: str) -> str:
-    name = name.split("(")[0]
+    name = name.replace("(anonymous namespace)::", "").split("(")[0]
     return name if len(name) <= 70 else name[:67] + "..."
 
 

@@ -4,10 +4,12 @@
 // histogram tests run as well and need an MI355X.  Exit code = number of failed tests.
 #include "loghisto.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <thread>
+#include <vector>
 
 using namespace loghisto;
 using namespace std::chrono_literals;
@@ -329,6 +331,67 @@ TEST(TestProducersAreLosslessAcrossIntervals)
     CHECK(seen == (double)T * N && g["loghisto.gpu.launches"] > 0);
 }
 
+static std::vector<std::string> sorted_lines(const std::string &text)
+{
+    std::vector<std::string> out;
+    size_t pos = 0;
+    while (pos < text.size()) {
+        const size_t nl = text.find('\n', pos);
+        out.push_back(text.substr(pos, nl - pos));
+        pos = nl == std::string::npos ? text.size() : nl + 1;
+    }
+    std::sort(out.begin(), out.end());
+    return out;
+}
+
+TEST(TestBulkWireMatchesPerKeySerializer)
+{
+    // SetWireFormat: the request prepared on the GPU (lh_serialize) holds exactly the lines the per-key
+    // serializer builds from the map (graphite.go:37-48, opentsdb.go:45-58), _agg_* keys included
+    for (WireFormat wf : {WireFormat::Graphite, WireFormat::OpenTSDB}) {
+        MetricSystem ms(1us, false);
+        ms.SetWireFormat(wf, true);
+        ms.RegisterGaugeFunc("some_gauge", [] { return 12.5; });
+        for (int interval = 0; interval < 3; interval++) {
+            for (int i = 0; i < 20000; i++) {
+                ms.Histogram("rpc_latency_" + std::to_string(i % 7), 1000.0 + (i * 37) % 90001 + interval);
+                if (interval != 1) ms.Histogram("only.sometimes", 0.25 * i);
+            }
+            ms.Counter("requests_total", 5 + interval);
+            auto raw = ms.collectRawMetrics();
+            auto pm = ms.processMetrics(raw);
+            ms.addAggregates(raw, *pm);
+            raw->Release();
+            CHECK(pm->wire_format == wf && !pm->wire.empty());
+            ProcessedMetricSet plain;
+            plain.Time = pm->Time;
+            plain.Metrics = pm->Metrics;
+            const std::string per_key = wf == WireFormat::Graphite ? GraphiteProtocol(plain) : OpenTSDBProtocol(plain);
+            const std::string bulk = wf == WireFormat::Graphite ? GraphiteProtocol(*pm) : OpenTSDBProtocol(*pm);
+            CHECK(bulk == pm->wire);
+            const auto a = sorted_lines(per_key), b = sorted_lines(bulk);
+            CHECK(a.size() == b.size() && a.size() >= 7 * 15 + 3);
+            CHECK(a == b);
+            if (a != b)
+                for (size_t i = 0; i < std::min(a.size(), b.size()); i++)
+                    if (a[i] != b[i]) { std::printf("    per-key: %s\n    bulk:    %s\n", a[i].c_str(), b[i].c_str()); break; }
+        }
+        // without the map: the histogram keys exist only as text
+        ms.SetWireFormat(wf, false);
+        ms.Histogram("rpc_latency_0", 42.0);
+        ms.Counter("requests_total", 1);
+        auto raw = ms.collectRawMetrics();
+        auto pm = ms.processMetrics(raw);
+        raw->Release();
+        CHECK(!pm->Metrics.count("rpc_latency_0_count") && pm->Metrics.count("requests_total"));
+        CHECK(pm->wire.find(wf == WireFormat::Graphite ? "rpc.latency.0.count 1.000000" : "rpc_latency_0_count") !=
+              std::string::npos);
+        CHECK(pm->wire.find(wf == WireFormat::Graphite ? "rpc.latency.0.agg.count 8575.000000"
+                                                       : "rpc_latency_0_agg_count") != std::string::npos);
+        CHECK(ms.last_status() == 0);
+    }
+}
+
 int main(int argc, char **argv)
 {
     const bool cpu_only = argc > 1 && !std::strcmp(argv[1], "--cpu");
@@ -348,6 +411,7 @@ int main(int argc, char **argv)
         RUN(ExampleMetricSystem);
         RUN(TestRawHistogramsAndInvalidPercentile);
         RUN(TestProducersAreLosslessAcrossIntervals);
+        RUN(TestBulkWireMatchesPerKeySerializer);
     }
     std::printf("%d checks, %d failed tests\n", g_checks, g_failed);
     return g_failed;

@@ -8,6 +8,7 @@ import queue
 import threading
 import time
 
+import numpy as np
 import pytest
 
 from loghisto_amd.metric_system import MetricSystem
@@ -208,3 +209,52 @@ def test_invalid_percentile_is_omitted_like_the_reference(native_lib, torch_cuda
     raw.release()
     assert "x_p50" in m and "x_bad" not in m   # metrics.go:379-384
     ms.Stop()
+
+
+def test_serializers_per_key():
+    """GraphiteProtocol / OpenTSDBProtocol (graphite.go:37-75, opentsdb.go:45-85) on the values the
+    reference's own serializer tests submit (graphite_test.go, opentsdb_test.go)."""
+    import socket
+    from loghisto_amd.metric_system import GraphiteProtocol, OpenTSDBProtocol, ProcessedMetricSet
+    host = socket.gethostname()
+    ms = ProcessedMetricSet(Time=1411104988.0, Metrics={"test.3": 50.54, "test_4": 10.21, "nan": float("nan"),
+                                                        "inf": float("inf")})
+    g = GraphiteProtocol(ms).decode().split("\n")
+    assert f"cockroach.{host}.test.3 50.540000 1411104988" in g and f"cockroach.{host}.test.4 10.210000 1411104988" in g
+    assert f"cockroach.{host}.nan NaN 1411104988" in g and f"cockroach.{host}.inf +Inf 1411104988" in g
+    t = OpenTSDBProtocol(ms).decode().split("\n")
+    assert f"put test.3 1411104988 50.540000 host={host}" in t and f"put test_4 1411104988 10.210000 host={host}" in t
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["graphite", "opentsdb"])
+def test_bulk_wire_matches_per_key_serializer(native_lib, torch_cuda, kind):
+    """SetWireFormat: the request prepared on the GPU holds exactly the lines the per-key serializer builds
+    from the map, _agg_* keys included, over several intervals."""
+    from loghisto_amd.metric_system import (GraphiteProtocol, MetricSystem, OpenTSDBProtocol, ProcessedMetricSet)
+    ser = GraphiteProtocol if kind == "graphite" else OpenTSDBProtocol
+    ms = MetricSystem(1e-6, False)
+    ms.SetWireFormat(kind, True)
+    ms.RegisterGaugeFunc("some_gauge", lambda: 12.5)
+    rng = np.random.default_rng(4)
+    for interval in range(3):
+        for i, v in enumerate(rng.lognormal(10, 1, 5000)):
+            ms.Histogram(f"rpc_latency_{i % 7}", float(v))
+            if interval != 1:
+                ms.Histogram("only.sometimes", 0.25 * i)
+        ms.Counter("requests_total", 5 + interval)
+        raw = ms.collectRawMetrics()
+        pm = ms.processMetrics(raw)
+        ms._add_aggregates(raw, pm)
+        raw.release()
+        assert pm.wire_format == kind and ser(pm) is pm.wire
+        per_key = ser(ProcessedMetricSet(Time=pm.Time, Metrics=pm.Metrics))
+        assert sorted(per_key.split(b"\n")) == sorted(pm.wire.split(b"\n"))
+        assert pm.wire.count(b"\n") >= 7 * 15 + 3
+    ms.SetWireFormat(kind, False)
+    ms.Histogram("rpc_latency_0", 42.0)
+    raw = ms.collectRawMetrics()
+    pm = ms.processMetrics(raw)
+    raw.release()
+    assert "rpc_latency_0_count" not in pm.Metrics and "some_gauge" in pm.Metrics
+    assert (b"rpc.latency.0.count 1.000000" if kind == "graphite" else b"rpc_latency_0_count") in pm.wire
