@@ -14,6 +14,11 @@
  *       -> lh_extract         (count, sum, avg, uint64(sum), percentiles)
  *   RawMetricSet.Histograms          /root/reference/metrics.go:54-60
  *       -> lh_buckets         (occupied (key,count) cells of one metric)
+ *   processMetrics/addAggregates key loops + the serializers' per-key line
+ *                                    /root/reference/metrics.go:483-506, 590-608,
+ *                                    graphite.go:37-48, opentsdb.go:45-58
+ *       -> lh_snapshot_accumulate + lh_serialize (keys, Go's %f and the wire
+ *          lines assembled on the device; optional, for large name spaces)
  *   compress / decompress            /root/reference/metrics.go:316-332
  *       -> computed on device inside lh_submit*; lh_compress_device and
  *          lh_codec_tables expose the codec for parity tests.

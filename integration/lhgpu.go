@@ -168,6 +168,38 @@ func (raw *RawMetricSet) fillHistograms(g *gpuEngine) {
 	}
 }
 
+// Bulk wire text (K6): the interval's histogram keys as a finished Graphite request, assembled and
+// formatted on the device; replaces the per-key loops of metrics.go:483-506, 590-608 and graphite.go:37-48.
+func (ms *MetricSystem) graphiteRequest(raw *RawMetricSet, host string) []byte {
+	C.lh_snapshot_accumulate(raw.snap) // histogramCountStore += ..., metrics.go:359-376
+	labels, ps := ms.percentileLabelsAndValues()
+	clabels := make([]*C.char, len(labels))
+	for i, l := range labels {
+		clabels[i] = C.CString(l)
+		defer C.free(unsafe.Pointer(clabels[i]))
+	}
+	ts := strconv.FormatInt(raw.Time.Unix(), 10)
+	f := C.lh_line_format{
+		prefix: C.CString("cockroach." + host + "."), sep: C.CString(" "), suffix: C.CString(" " + ts + "\n"),
+		flags: C.LH_FMT_UNDERSCORE_TO_DOT,
+	}
+	defer C.free(unsafe.Pointer(f.prefix))
+	defer C.free(unsafe.Pointer(f.sep))
+	defer C.free(unsafe.Pointer(f.suffix))
+	buf := make([]byte, ms.lastRequestBytes+ms.lastRequestBytes/8+4096)
+	var n C.size_t
+	for {
+		C.lh_serialize(raw.snap, 0, C.size_t(len(ms.gpu.names)), (*C.double)(&ps[0]), &clabels[0],
+			C.size_t(len(ps)), &f, C.LH_SER_AGGREGATES, (*C.char)(unsafe.Pointer(&buf[0])), C.size_t(len(buf)), &n)
+		if int(n) <= len(buf) {
+			break
+		}
+		buf = make([]byte, int(n)+int(n)/8) // *len reports the need; nothing was written
+	}
+	ms.lastRequestBytes = int(n)
+	return append(buf[:n], GraphiteProtocol(ms.hostSideKeys(raw))...) // counters, rates, gauges
+}
+
 	// once: comm is an ncclComm_t from RCCL's own cgo binding; tell the library which RCCL that is
 	C.lh_set_rccl_library(C.CString("librccl.so"))
 	...

@@ -205,3 +205,35 @@ def test_cpu_baseline_forms_are_exact():
         _, a = oracle.bench_faithful(v, threads)
         _, b = oracle.bench_dense(v, threads)
         assert np.array_equal(a, ref) and np.array_equal(b, ref)
+
+
+def test_format_f_is_go_percent_f():
+    """fmt.Sprintf("%f") (graphite.go:40, opentsdb.go:48) = the exact decimal expansion rounded half-even to 6
+    places: the oracle's formatter against Python's decimal module (an independent exact implementation)."""
+    import decimal
+    import math
+    import random
+    import struct
+    from decimal import Decimal
+    decimal.getcontext().prec = 2000
+
+    def exact(v):
+        if math.isnan(v):
+            return "NaN"
+        if math.isinf(v):
+            return "-Inf" if v < 0 else "+Inf"
+        s = format(Decimal(v).quantize(Decimal("0.000001"), rounding=decimal.ROUND_HALF_EVEN), "f")
+        return "-0.000000" if v == 0 and math.copysign(1, v) < 0 else s
+
+    rnd = random.Random(1)
+    vals = [0.0, -0.0, 0.5, 5e-7, 1.5e-6, 2.5e-6, 0.9999995, 999999.9999995, 2.0 ** 53, 2.0 ** 64, 1e22, 1e23, 1e300,
+            1.7976931348623157e308, 5e-324, 50.54, 10.21, 43.32, 12.3, float("nan"), float("inf"), -float("inf")]
+    vals += [k / 128.0 for k in range(1, 2001, 2)]                   # exact ties
+    vals += [struct.unpack("<d", struct.pack("<Q", rnd.getrandbits(64)))[0] for _ in range(20000)]
+    vals += [rnd.uniform(0, 1e6) for _ in range(20000)]
+    for v in vals:
+        assert oracle.format_f(v) == exact(v), repr(v)
+    # values the reference's docs print with %v, through %f
+    assert oracle.format_f(58.739891704145194) == "58.739892"
+    assert oracle.format_f(2.4642914167480484e+07) == "24642914.167480"
+    assert oracle.format_f(-657.5233632152207) == "-657.523363"
