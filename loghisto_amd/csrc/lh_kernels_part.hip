@@ -81,13 +81,14 @@ static bool make_plan(size_t n, uint32_t nmetrics, int num_cus, PartPlan &P)
     // (measured at 1 024 names, profiles/r01c: 4 is the best overall).
     static const uint32_t names_per_part =
         getenv("LH_PART_NAMES") ? (uint32_t)std::max(1, atoi(getenv("LH_PART_NAMES"))) : 4u;
-    // Second level only when a level-1 partition holds more than 64 names (> 16 384 names in all).
-    // Measured (profiles/r01j): at 4 096 / 8 192 names one level is faster (149 / 127 vs 79 / 76 G samples/s:
-    // 1 024 / 512-bin windows plus the overflow table still catch most records, and the extra pass costs
-    // 8 B/sample), at 16 384 still 73 vs 63; at 65 536 names two levels win (72 vs 27 G/s).  LH_PART_TWO_LEVEL_ABOVE overrides the
-    // threshold (tests force the second level at small name counts with 0); read per call on purpose.
+    // Second level only when a level-1 partition holds more than 32 names (> 8 192 names in all).
+    // Measured at 1e9 samples (profiles/r01j): 8 192 names one level 139 vs two levels 105 G samples/s (512-bin
+    // windows plus the overflow table still catch most records, and the extra pass costs 8 B/sample);
+    // 12 288 names 85 vs 100; 16 384 names 73 vs 94; 65 536 names 27 vs 77.  LH_PART_TWO_LEVEL_ABOVE overrides
+    // the threshold, in names per level-1 partition (tests force the second level at small name counts with 0);
+    // read per call on purpose.
     const char *thr_env = getenv("LH_PART_TWO_LEVEL_ABOVE");
-    const uint32_t two_level_above = thr_env ? (uint32_t)std::max(0, atoi(thr_env)) : 64u;
+    const uint32_t two_level_above = thr_env ? (uint32_t)std::max(0, atoi(thr_env)) : 32u;
     const uint32_t want_np = (nmetrics + names_per_part - 1) / names_per_part;
     P.log_np = std::min(8u, ilog2_ceil(want_np));
     P.np = 1u << P.log_np;
@@ -651,27 +652,48 @@ __global__ __launch_bounds__(P2_BLOCK, 8) void k_part_hist(const uint32_t *__res
     const uint32_t *list = sorted + part_start[p] + first;
     const uint32_t W = 1u << log_w, words = mpp << log_w;
 
-    for (uint32_t i = tid; i < words; i += P2_BLOCK) h[i] = 0;
-    __syncthreads();
-
-    // ---- window placement (lh_windows.h): a sample of the slot (its first chunk, <= 1 024 records)
-    // is bucketed coarsely into h[name][bin >> log_cw]; choose_windows picks the max-mass run per name.
-    const uint32_t log_cw = 16 - log_w;
-    {
-        const uint32_t c0 = list[0];
-        const uint32_t n0 = cdesc[c0] & CD_MASK;
-        const uint32_t *b0 = records + (size_t)c0 * CHUNK;
-        for (uint32_t i = tid; i < n0; i += P2_BLOCK) {
-            const uint32_t rec = b0[i];
-            atomicAdd(&h[(((rec >> 16) & 0xffu) << log_w) + ((rec & 0xffffu) >> log_cw)], 1u);
-        }
-    }
-    __syncthreads();
-    choose_windows(h, s_org, s_mn, s_mx, mpp, log_w, wave, lane, P2_BLOCK / 64);
-    __syncthreads();
+    // ---- window placement from a sample of the slot: its first chunk (<= 1 024 records = one per thread).
+    // The sample's loads are issued first so that their latency hides behind the zeroing of the windows.
+    const uint32_t c0 = list[0];
+    const uint32_t n0 = cdesc[c0] & CD_MASK;
+    const uint32_t srec = tid < n0 ? records[(size_t)c0 * CHUNK + tid] : INVALID;
     for (uint32_t i = tid; i < words; i += P2_BLOCK) h[i] = 0;
     ov_init(ov_key, ov_cnt, tid, P2_BLOCK);
+    if (tid < mpp) { s_mn[tid] = INVALID; s_mx[tid] = 0; }
     __syncthreads();
+    // Fast path: per-name min / max bin of the sample.  When every name's sampled span fits its window
+    // (the usual case: a 4 096-bin window is 41 e-folds wide) the window is centred on the span.
+    if (tid < n0) {
+        const uint32_t l = (srec >> 16) & 0xffu, b = srec & 0xffffu;
+        if (b < s_mn[l]) atomicMin(&s_mn[l], b);
+        if (b > s_mx[l]) atomicMax(&s_mx[l], b);
+    }
+    __syncthreads();
+    const bool fits = tid >= mpp || s_mn[tid] == INVALID || s_mx[tid] - s_mn[tid] < W - W / 4;
+    if (__syncthreads_and(fits)) {
+        if (tid < mpp) {
+            uint32_t org = 32768u - W / 2; // name absent from the sample: centre on key 0
+            if (s_mn[tid] != INVALID) {
+                const uint32_t centre = (s_mn[tid] + s_mx[tid] + 1) >> 1;
+                org = centre > W / 2 ? centre - W / 2 : 0u;
+            }
+            if (org > 65536u - W) org = 65536u - W;
+            s_org[tid] = org;
+            s_mn[tid] = INVALID; // reused as the flush ranges
+            s_mx[tid] = 0;
+        }
+        __syncthreads();
+    } else {
+        // Wide or multi-modal sample (lh_windows.h): bucket it coarsely into h[name][bin >> log_cw];
+        // choose_windows picks the max-mass run per name.
+        const uint32_t log_cw = 16 - log_w;
+        if (tid < n0) atomicAdd(&h[(((srec >> 16) & 0xffu) << log_w) + ((srec & 0xffffu) >> log_cw)], 1u);
+        __syncthreads();
+        choose_windows(h, s_org, s_mn, s_mx, mpp, log_w, wave, lane, P2_BLOCK / 64);
+        __syncthreads();
+        for (uint32_t i = tid; i < words; i += P2_BLOCK) h[i] = 0;
+        __syncthreads();
+    }
 
     // one chunk per wave per iteration: 1 024 records = 4 x (64 lanes x 16 B).  Double-buffered: the
     // next chunk's descriptor and its four 16-B loads are in flight while this chunk is reduced.
