@@ -44,6 +44,13 @@ constexpr uint32_t CHUNK = 1024;       // records per chunk (4 KiB)
 constexpr int P1_BLOCK = 512;          // 8 waves; three workgroups per CU (measured: 1024x4 is 10 % slower)
 constexpr int P1_SPT = 8;              // samples per thread per tile
 constexpr int P1_TILE = P1_BLOCK * P1_SPT;
+// tuning knobs (profiles/r01c): records per staged line and P1 workgroups per CU
+#ifndef LH_LINE
+#define LH_LINE 16
+#endif
+#ifndef LH_P1_WGS_PER_CU
+#define LH_P1_WGS_PER_CU 3
+#endif
 constexpr uint32_t INVALID = 0xffffffffu;
 constexpr int P2_BLOCK = 1024;         // 16 waves: two workgroups (64 KiB windows each) fill a CU
 constexpr uint32_t P2_WINWORDS = 16384; // 64 KiB of uint32 windows per workgroup
@@ -105,7 +112,7 @@ static bool make_plan(size_t n, uint32_t nmetrics, int num_cus, PartPlan &P)
     while ((P.mpp2 << (lw + 1)) <= P2_WINWORDS) lw++;
     P.log_w = lw; // window = 2^log_w bins per name, mpp2 * window <= 16384
     const size_t ntiles = (n + P1_TILE - 1) / P1_TILE;
-    size_t g1 = (size_t)num_cus * 3; // ~44 KiB LDS per workgroup: three 512-thread workgroups per CU
+    size_t g1 = (size_t)num_cus * LH_P1_WGS_PER_CU; // ~44 KiB LDS per workgroup: three 512-thread workgroups per CU
     // every workgroup strands up to NP partially filled chunks (1 MiB at NP = 256): give a workgroup
     // at least 8 tiles so that a lane-sized launch (1M samples) needs ~33 MB of scratch, not ~270 MB
     if (g1 > (ntiles + 7) / 8) g1 = (ntiles + 7) / 8;
@@ -155,7 +162,7 @@ typedef uint32_t pu4_t __attribute__((ext_vector_type(4)));
 // costs 2.8 ms of a 5.0 ms kernel and 1.6x write amplification (partial lines evicted before their
 // other half arrives).  So every partition owns one staging line in LDS; a tile emits only whole,
 // aligned lines (staged leftovers + new records) and keeps the remainder staged.
-constexpr uint32_t LINE = 16; // records per staged line (64 B, one aligned HBM sector pair)
+constexpr uint32_t LINE = LH_LINE; // records per staged line (16 = 64 B, one aligned HBM sector pair)
 
 struct ScatterLds {
     uint32_t cnt[NPMAX], off[NPMAX], cfill[NPMAX], cbase[NPMAX];
