@@ -489,6 +489,7 @@ int lh_intern(lh_engine *e, const char *name, size_t len, uint32_t *id)
     auto it = e->name2id.find(key);
     if (it != e->name2id.end()) { *id = it->second; return LH_OK; }
     if (e->names.size() >= e->cfg.max_metrics) return LH_ERANGE;
+    if (e->name_blob.size() + key.size() > (size_t(1) << 31)) return LH_ERANGE; // uint32 offsets in HBM (K6)
     const uint32_t nid = (uint32_t)e->names.size();
     e->names.push_back(key);
     e->name_blob += key;
