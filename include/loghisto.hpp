@@ -15,6 +15,8 @@
 //                                                   because the reference's tests call them)
 //   Start / Stop, reaper                           metrics.go:530-653
 //   GraphiteProtocol / OpenTSDBProtocol            graphite.go:73, opentsdb.go:83
+//   NewSubmitter / Start / Shutdown                submitter.go:52-159 -> Submitter
+//   PrintBenchmark                                 print_benchmark.go:49
 //
 // What moved to the GPU: compress + the per-(name,bucket) fan-in (Histogram), the epoch flip of the
 // histogram cells (collectRawMetrics) and processHistograms/percentile (processMetrics).  Counters,
@@ -288,5 +290,16 @@ private:
 // "put <metric> <unix> %f host=<host>\n".  Downstream text formatting; kept for config 5.
 std::string GraphiteProtocol(const ProcessedMetricSet &ms);
 std::string OpenTSDBProtocol(const ProcessedMetricSet &ms);
+
+// print_benchmark.go:49-106: runs `op` on `concurrency` threads, timing every call into the histogram `name`
+// of a 1 s MetricSystem, and once per interval prints the same 19 keys in the same order through a
+// tabwriter-shaped table (values as Go's %v prints a float64).  The reference never returns; `run_for` == 0
+// keeps that behaviour, a positive duration stops the workers and returns (tests, scripted runs).
+void PrintBenchmark(const std::string &name, unsigned concurrency, std::function<void()> op,
+                    std::chrono::nanoseconds run_for = std::chrono::nanoseconds(0), std::FILE *out = stdout,
+                    const Options &opt = Options());
+// fmt.Println's rendering of a float64 (%v = %g with the shortest round-trip digits; exponent form when the
+// decimal exponent is < -4 or >= 6: "2.4642914167480484e+07" but "469769.7083161708", readme.md:35-43)
+std::string FormatGoV(double v);
 
 } // namespace loghisto

@@ -17,6 +17,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <charconv>
 #include <cinttypes>
 #include <cmath>
 #include <cstdio>
@@ -773,6 +774,110 @@ std::string OpenTSDBProtocol(const ProcessedMetricSet &ms)
         out += '\n';
     }
     return out;
+}
+
+// ---------------------------------------------------------------------------
+// PrintBenchmark (print_benchmark.go:49-106)
+// ---------------------------------------------------------------------------
+std::string FormatGoV(double v)
+{
+    if (std::isnan(v)) return "NaN";
+    if (std::isinf(v)) return v < 0 ? "-Inf" : "+Inf";
+    // shortest digits that round-trip, as strconv.FormatFloat(v, 'g', -1, 64) picks them
+    char buf[64];
+    auto r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::scientific);
+    std::string sci(buf, r.ptr); // [-]d[.ddd]e[+-]XX
+    std::string out;
+    size_t i = 0;
+    if (sci[0] == '-') { out = "-"; i = 1; }
+    const size_t epos = sci.find('e');
+    std::string digits;
+    for (size_t k = i; k < epos; k++)
+        if (sci[k] != '.') digits += sci[k];
+    const int exp = std::atoi(sci.c_str() + epos + 1);
+    if (digits == "0") return out + "0";
+    if (exp < -4 || exp >= 6) { // strconv %g: %e when exp < -4 || exp >= eprec, eprec = 6 for the shortest form
+        out += digits[0];
+        if (digits.size() > 1) { out += '.'; out += digits.substr(1); }
+        char e[8];
+        std::snprintf(e, sizeof e, "e%c%02d", exp < 0 ? '-' : '+', exp < 0 ? -exp : exp);
+        return out + e;
+    }
+    if (exp < 0) {
+        out += "0.";
+        out.append((size_t)(-exp - 1), '0');
+        return out + digits;
+    }
+    if ((size_t)exp + 1 >= digits.size()) {
+        out += digits;
+        out.append((size_t)exp + 1 - digits.size(), '0');
+        return out;
+    }
+    return out + digits.substr(0, (size_t)exp + 1) + "." + digits.substr((size_t)exp + 1);
+}
+
+namespace {
+void print_interval(std::FILE *out, const std::string &name, const ProcessedMetricSet &m)
+{
+    static const char *suffixes[] = {"_count", "_max", "_99.99", "_99.9", "_99", "_95", "_90", "_75", "_50", "_min",
+                                     "_sum", "_avg", "_agg_avg", "_agg_count", "_agg_sum"}; // print_benchmark.go:76-97
+    std::vector<std::string> keys;
+    for (const char *sfx : suffixes) keys.push_back(name + sfx);
+    for (const char *k : {"sys.Alloc", "sys.NumGC", "sys.PauseTotalNs", "sys.NumGoroutine"}) keys.push_back(k);
+    // time.Time's default rendering: 2014-08-09 17:44:57 -0400 EDT
+    const std::time_t t = std::chrono::system_clock::to_time_t(m.Time);
+    std::tm tm{};
+    localtime_r(&t, &tm);
+    char ts[64];
+    std::strftime(ts, sizeof ts, "%Y-%m-%d %H:%M:%S %z %Z", &tm);
+    std::fprintf(out, "%s\n", ts);
+    // text/tabwriter with Init(out, 0, 8, 0, '\t', 0): the "<key>:" cells form one column, padded with tabs
+    // to the smallest multiple of 8 that holds the widest cell
+    size_t width = 0;
+    for (auto &k : keys) width = std::max(width, k.size() + 1);
+    width = (width + 7) / 8 * 8;
+    for (auto &k : keys) {
+        auto it = m.Metrics.find(k);
+        const double v = it == m.Metrics.end() ? 0.0 : it->second; // a missing map key reads as 0 in Go
+        const size_t textw = k.size() + 1;
+        std::string line = k + ":";
+        line.append((width - textw + 7) / 8, '\t');
+        std::fprintf(out, "%s %s\n", line.c_str(), FormatGoV(v).c_str());
+    }
+    std::fprintf(out, "\n");
+    std::fflush(out);
+}
+} // namespace
+
+void PrintBenchmark(const std::string &name, unsigned concurrency, std::function<void()> op,
+                    std::chrono::nanoseconds run_for, std::FILE *out, const Options &opt)
+{
+    MetricSystem ms(std::chrono::seconds(1), true, opt);
+    auto mc = std::make_shared<Channel<std::shared_ptr<ProcessedMetricSet>>>(1);
+    ms.SubscribeToProcessedMetrics(mc);
+    ms.Start();
+    std::atomic<bool> stop{false};
+    std::thread receiver([&] {
+        std::shared_ptr<ProcessedMetricSet> m;
+        while (!stop.load() || mc->Len())
+            if (mc->Receive(m, std::chrono::milliseconds(50))) print_interval(out, name, *m);
+    });
+    std::vector<std::thread> workers;
+    for (unsigned i = 0; i < concurrency; i++)
+        workers.emplace_back([&] {
+            while (!stop.load(std::memory_order_relaxed)) {
+                TimerToken timer = ms.StartTimer(name);
+                op();
+                timer.Stop();
+            }
+        });
+    if (run_for.count() > 0) std::this_thread::sleep_for(run_for);
+    else
+        for (;;) std::this_thread::sleep_for(std::chrono::hours(1)); // <-make(chan struct{})
+    stop.store(true);
+    for (auto &w : workers) w.join();
+    ms.Stop();
+    receiver.join();
 }
 
 } // namespace loghisto

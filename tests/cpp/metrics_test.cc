@@ -331,6 +331,69 @@ TEST(TestProducersAreLosslessAcrossIntervals)
     CHECK(seen == (double)T * N && g["loghisto.gpu.launches"] > 0);
 }
 
+TEST(TestFormatGoV)
+{
+    // fmt.Println of a float64, on the values the reference's own docs print (readme.md:35-43,
+    // print_benchmark.go:31-48): shortest round-trip digits, %e from 1e6 upwards and below 1e-4
+    CHECK(FormatGoV(2.4642914167480484e+07) == "2.4642914167480484e+07");
+    CHECK(FormatGoV(4913.768840299134) == "4913.768840299134");
+    CHECK(FormatGoV(58.739891704145194) == "58.739891704145194");
+    CHECK(FormatGoV(-657.5233632152207) == "-657.5233632152207");
+    CHECK(FormatGoV(3.982478339757623e+07) == "3.982478339757623e+07");
+    CHECK(FormatGoV(3.4366224772310276e+06) == "3.4366224772310276e+06");
+    CHECK(FormatGoV(469769.7083161708) == "469769.7083161708");
+    CHECK(FormatGoV(129313.15075081984) == "129313.15075081984");
+    CHECK(FormatGoV(9.975892639594093e+09) == "9.975892639594093e+09");
+    CHECK(FormatGoV(605039.5827022133) == "605039.5827022133");
+    CHECK(FormatGoV(16488) == "16488" && FormatGoV(618937) == "618937" && FormatGoV(121095) == "121095");
+    CHECK(FormatGoV(7.4950269894e+10) == "7.4950269894e+10" && FormatGoV(2.94946542e+08) == "2.94946542e+08");
+    CHECK(FormatGoV(997328) == "997328" && FormatGoV(1e6) == "1e+06" && FormatGoV(100000) == "100000");
+    CHECK(FormatGoV(0) == "0" && FormatGoV(0.0001) == "0.0001" && FormatGoV(0.00001) == "1e-05");
+    CHECK(FormatGoV(0.5) == "0.5" && FormatGoV(1e100) == "1e+100" && FormatGoV(-2.5e-7) == "-2.5e-07");
+    CHECK(FormatGoV(NAN) == "NaN" && FormatGoV(INFINITY) == "+Inf" && FormatGoV(-INFINITY) == "-Inf");
+}
+
+TEST(TestPrintBenchmark) // print_benchmark.go:49-106
+{
+    std::FILE *f = std::tmpfile();
+    std::atomic<uint64_t> calls{0};
+    PrintBenchmark("raft_AppendLogEntries", 3, [&] {
+        calls.fetch_add(1);
+        std::this_thread::sleep_for(200us);
+    }, 2500ms, f);
+    std::rewind(f);
+    std::string text;
+    char buf[4096];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, n);
+    std::fclose(f);
+    CHECK(calls.load() > 1000);
+    // at least one full interval: a time line, the 19 keys in the reference's order, a blank line
+    const char *order[] = {"_count:", "_max:", "_99.99:", "_99.9:", "_99:", "_95:", "_90:", "_75:", "_50:", "_min:",
+                           "_sum:", "_avg:", "_agg_avg:", "_agg_count:", "_agg_sum:"};
+    size_t pos = 0;
+    for (const char *k : order) {
+        const size_t at = text.find(std::string("raft_AppendLogEntries") + k, pos);
+        CHECK(at != std::string::npos);
+        if (at == std::string::npos) break;
+        pos = at;
+    }
+    for (const char *k : {"sys.Alloc:", "sys.NumGC:", "sys.PauseTotalNs:", "sys.NumGoroutine:"})
+        CHECK(text.find(k, pos) != std::string::npos);
+    // tabwriter shape: the widest cell "raft_AppendLogEntries_agg_count:" is 32 wide -> no tab, the others pad
+    // with tabs to column 32
+    CHECK(text.find("raft_AppendLogEntries_agg_count: ") != std::string::npos);
+    CHECK(text.find("raft_AppendLogEntries_max:\t ") != std::string::npos);
+    CHECK(text.find("sys.NumGC:\t\t\t 0\n") != std::string::npos);
+    // a sleep of 200 us is timed at >= 200 000 ns: the median prints in Go's %v form
+    const size_t p50 = text.find("raft_AppendLogEntries_50:");
+    CHECK(p50 != std::string::npos);
+    if (p50 != std::string::npos) {
+        const double v = std::atof(text.c_str() + text.find(' ', p50));
+        CHECK(v >= 200000.0 && v < 5e7);
+    }
+}
+
 static std::vector<std::string> sorted_lines(const std::string &text)
 {
     std::vector<std::string> out;
@@ -405,6 +468,7 @@ int main(int argc, char **argv)
     RUN(TestMetricSystemStop);
     RUN(TestSerializers);
     RUN(TestSubmitterGraphite);
+    RUN(TestFormatGoV);
     if (!cpu_only) {
         RUN(TestTimer);
         RUN(TestProcessedBroadcast);
@@ -412,6 +476,7 @@ int main(int argc, char **argv)
         RUN(TestRawHistogramsAndInvalidPercentile);
         RUN(TestProducersAreLosslessAcrossIntervals);
         RUN(TestBulkWireMatchesPerKeySerializer);
+        RUN(TestPrintBenchmark);
     }
     std::printf("%d checks, %d failed tests\n", g_checks, g_failed);
     return g_failed;
