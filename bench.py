@@ -247,7 +247,7 @@ def main():
                                    "C2 single-metric float64 stream, one ingest kernel + one percentile scan per step",
                        "samples_per_gpu_per_step": n, "distribution": args.dist, "metrics": M,
                        "percentiles": PCTS, "merge": "allreduce(uint64 row) at flip" if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "kernel": "k_part_scatter+k_plan_*+k_part_hist" if c3 else "k_ingest_single",
+            "roofline": {"bound": "hbm", "kernel": "k_scatter_samples+k_plan_*+k_part_hist" if c3 else "k_ingest_single",
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": n * bytes_per_sample, "avg_launch_ms": k1_avg_ms,
