@@ -198,25 +198,26 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const uint32_t (&rec
     prefetch();
 
     // exclusive scan of the per-partition counts + chunk bookkeeping (threads 0..255)
-    uint32_t c = 0, inc = 0;
+    // (no barrier between the wave scans and their bases: every scanning wave sums the counts of the waves
+    // before it itself, three extra LDS reads at most, instead of meeting the others at a barrier)
     if (tid < NPMAX) {
-        c = L.cnt[tid];
-        inc = c;
+        const uint32_t c = L.cnt[tid];
+        uint32_t inc = c;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t y = __shfl_up(inc, d, 64);
             if ((int)lane >= d) inc += y;
         }
-        if (lane == 63) L.wsum[wave] = inc;
-    }
-    __syncthreads();
-    if (tid < NPMAX) {
         uint32_t wbase = 0;
-        for (uint32_t w = 0; w < wave; w++) wbase += L.wsum[w];
+        for (uint32_t w = 0; w < wave; w++) { // wave-uniform trip count
+            uint32_t x = L.cnt[w * 64 + lane];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+            wbase += x;
+        }
         const uint32_t off = wbase + inc - c;
         L.off[tid] = off;
         if (tid == NPMAX - 1) L.total = wbase + inc;
-        L.cnt[tid] = 0; // ranks are already in registers
         L.d1[tid] = INVALID;
         if (c) {
             const uint32_t p = tid, tag = ((p << tag_shift) | tag_base) << CD_SHIFT;
@@ -254,6 +255,9 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const uint32_t (&rec
     }
     __syncthreads();
 
+    // the counts have been consumed by every scanning wave (ranks are in registers); the next tile's rank
+    // atomics come after the barrier below
+    if (tid < NPMAX) L.cnt[tid] = 0;
     // tile-local counting sort into LDS ...
 #pragma unroll
     for (int j = 0; j < P1_SPT; j++) {
