@@ -122,6 +122,10 @@ int main(int argc, char **argv)
     opt.num_lanes = (uint32_t)std::min(64, std::max(8, T / 2));
     opt.stage_samples = 8192;
     MetricSystem ms(std::chrono::milliseconds(interval_ms), false, opt);
+    // --bulk 1: the Graphite request is prepared on the GPU (K6, lh_serialize) instead of one %f per key; the map
+    // is still filled because the event accounting below reads it
+    const bool bulk = arg_d(argc, argv, "--bulk", 0) != 0;
+    if (bulk) ms.SetWireFormat(WireFormat::Graphite, true);
 
     std::vector<std::string> hn, tn, cn;
     char b[32];
