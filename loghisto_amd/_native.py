@@ -141,5 +141,5 @@ def lib():
 
 def check(code: int, where: str):
     if code != OK:
-        detail = lib().lh_last_error().decode() if code in (EDEVICE, ENODEVICE) else ""
+        detail = lib().lh_last_error().decode() if code in (EDEVICE, ENODEVICE, ENOMEM) else ""
         raise LhError(code, where, detail)

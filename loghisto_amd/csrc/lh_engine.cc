@@ -39,6 +39,9 @@ thread_local char g_last_error[512] = "";
 void set_last_error(const char *what, hipError_t e)
 {
     std::snprintf(g_last_error, sizeof(g_last_error), "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
+    // the runtime keeps the failure as this thread's "last error"; the launch wrappers report hipGetLastError(),
+    // so leaving it in place would fail the next, unrelated launch (e.g. an lh_create after an out-of-memory one)
+    (void)hipGetLastError();
 }
 
 #define HIPCHK(expr)                                                                                        \
@@ -46,7 +49,7 @@ void set_last_error(const char *what, hipError_t e)
         hipError_t _e = (expr);                                                                             \
         if (_e != hipSuccess) {                                                                             \
             set_last_error(#expr, _e);                                                                      \
-            return LH_EDEVICE;                                                                              \
+            return _e == hipErrorOutOfMemory ? LH_ENOMEM : LH_EDEVICE;                                      \
         }                                                                                                   \
     } while (0)
 

@@ -428,3 +428,15 @@ def test_pairs_partitioned_bad_ids_and_reuse(la, torch_cuda):
             assert np.array_equal(snap.dense_row(1), want[1])
     finally:
         e.close()
+
+
+def test_create_reports_out_of_memory(la, torch_cuda):
+    """An engine that cannot fit in HBM (2 TiB of rows per epoch buffer) fails with LH_ENOMEM, it does not abort;
+    the process keeps working afterwards."""
+    with pytest.raises(la.LhError) as ei:
+        la.Engine(max_metrics=1 << 22, num_buffers=2, num_lanes=1, lane_samples=1 << 16)
+    assert ei.value.code == 2
+    with la.Engine(max_metrics=2, num_lanes=1, lane_samples=1 << 16) as e:
+        e.submit(0, np.array([1.0, 2.0, 3.0]))
+        with e.flip() as snap:
+            assert int(snap.extract([], 1)["count"][0]) == 3
