@@ -57,6 +57,7 @@ constexpr uint32_t P2_WINWORDS = 16384; // 64 KiB of uint32 windows per workgrou
 constexpr uint32_t SLOT_EXTRA = 1024;  // work slots beyond one per partition (measured: 512 is 25 % slower)
 constexpr size_t PART_MIN_SAMPLES = 131072;
 constexpr uint32_t PART_MAX_MPP = 256;
+constexpr uint32_t PART_HOT_MAX_NAMES = 4096; // k_scatter_samples<true>: names covered by the hot-slot map
 // chunk descriptor: partition tag << 11 | records in the chunk (1..1024); INVALID = unused
 constexpr uint32_t CD_SHIFT = 11, CD_MASK = (1u << CD_SHIFT) - 1;
 
@@ -66,6 +67,7 @@ struct PartPlan {
     uint32_t log_nq, nq, mpp2, log_w;  // what P2 sees
     uint32_t g1, chunks_per_wg, nchunks1, nchunks2;
     uint32_t extra1;                   // work slots beyond one per partition in the level-1 plan
+    bool hot;                          // P1 keeps LDS windows for the hottest names (k_scatter_samples<true>)
     size_t off_rec1, off_cd1, off_sorted1, off_small1, off_rec2, off_cd2, off_sorted2, off_small2, total;
 };
 
@@ -112,7 +114,13 @@ static bool make_plan(size_t n, uint32_t nmetrics, int num_cus, PartPlan &P)
     while ((P.mpp2 << (lw + 1)) <= P2_WINWORDS) lw++;
     P.log_w = lw; // window = 2^log_w bins per name, mpp2 * window <= 16384
     const size_t ntiles = (n + P1_TILE - 1) / P1_TILE;
-    size_t g1 = (size_t)num_cus * LH_P1_WGS_PER_CU; // ~44 KiB LDS per workgroup: three 512-thread workgroups per CU
+    // Hot-name windows inside P1 (k_scatter_samples<true>, +36 KiB of LDS: two workgroups per CU): only with one
+    // partition level, a name table that fits the one-byte slot map, and a launch long enough (>= 32 tiles per
+    // workgroup) to amortise the per-workgroup selection of the hot names.  LH_PART_HOT=0 turns it off (tuning).
+    static const bool hot_enabled = !(getenv("LH_PART_HOT") && atoi(getenv("LH_PART_HOT")) == 0);
+    P.hot = hot_enabled && P.log_ns == 0 && nmetrics <= PART_HOT_MAX_NAMES && ntiles >= (size_t)num_cus * 2 * 32;
+    // ~44 KiB LDS per workgroup: three 512-thread workgroups per CU (two with the hot windows)
+    size_t g1 = (size_t)num_cus * (P.hot ? 2 : LH_P1_WGS_PER_CU);
     // every workgroup strands up to NP partially filled chunks (1 MiB at NP = 256): give a workgroup
     // at least 8 tiles so that a lane-sized launch (1M samples) needs ~33 MB of scratch, not ~270 MB
     if (g1 > (ntiles + 7) / 8) g1 = (ntiles + 7) / 8;
@@ -334,16 +342,42 @@ __device__ __forceinline__ void scatter_drain(ScatterLds &L, uint32_t *__restric
 // Record format (4 bytes): partition << 24 | local name id << 16 | bin.
 // ids must be 8-byte and v 16-byte aligned (the launcher checks).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(P1_BLOCK, 6) void k_scatter_samples(const uint32_t *__restrict__ ids,
-                                                                 const double *__restrict__ v, size_t n,
-                                                                 uint32_t nmetrics, uint32_t log_np,
-                                                                 const double *__restrict__ Tx,
-                                                                 uint32_t *__restrict__ records,
-                                                                 uint32_t *__restrict__ cdesc, uint32_t chunks_per_wg,
-                                                                 uint32_t *__restrict__ err, uint32_t dbg)
+// Hot names (HOT = true).  Metric streams are skewed: under BASELINE config 3's Zipf(1.0) over 1 024 names
+// the 16 most frequent names carry 45 % of the samples.  Each workgroup picks the HOT_NAMES names that are
+// most frequent in its own first tile and keeps a HOT_W-bin LDS window for each; a sample of a hot name that
+// falls inside its window is counted right there (one LDS atomic, like the single-pass kernels) and never
+// becomes a record, so it costs no record store, no sort and no P2 work.  Everything else -- cold names and
+// hot samples outside their window -- takes the scatter path unchanged, so the result stays exact.  The
+// windows are flushed with one uint64 atomic per occupied bin when the workgroup ends.
+constexpr uint32_t HOT_NAMES = 16, HOT_LOGW = 9, HOT_W = 1u << HOT_LOGW;
+constexpr uint32_t HOT_MAXM = PART_HOT_MAX_NAMES; // names the hot-slot map covers (one byte each)
+static_assert(HOT_MAXM <= (uint32_t)P1_TILE, "the per-name counts of the selection live in ScatterLds::sorted");
+constexpr uint32_t HOT_COLD = 0xffu;
+struct HotLds {
+    uint32_t win[HOT_NAMES * HOT_W];
+    uint32_t org[HOT_NAMES], name[HOT_NAMES], mn[HOT_NAMES], mx[HOT_NAMES];
+    uint32_t wmax[P1_BLOCK / 64];
+    uint32_t pick;
+    uint8_t slot_of[HOT_MAXM];
+};
+constexpr size_t HOT_LDS_BYTES = sizeof(HotLds);
+
+template <bool HOT>
+__global__ __launch_bounds__(P1_BLOCK, HOT ? 4 : 6) void k_scatter_samples(const uint32_t *__restrict__ ids,
+                                                                           const double *__restrict__ v, size_t n,
+                                                                           uint32_t nmetrics, uint32_t log_np,
+                                                                           const double *__restrict__ Tx,
+                                                                           uint32_t *__restrict__ records,
+                                                                           uint32_t *__restrict__ cdesc,
+                                                                           uint32_t chunks_per_wg,
+                                                                           uint64_t *__restrict__ counts,
+                                                                           uint32_t *__restrict__ ranges,
+                                                                           uint32_t *__restrict__ err, uint32_t dbg)
 {
     __shared__ __attribute__((aligned(16))) ScatterLds L;
-    const uint32_t tid = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char hot_smem[];
+    HotLds &H = *reinterpret_cast<HotLds *>(hot_smem); // only touched when HOT
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t np = 1u << log_np, pmask = np - 1;
     const uint32_t pool_base = blockIdx.x * chunks_per_wg;
     scatter_init(L, tid);
@@ -376,6 +410,90 @@ __global__ __launch_bounds__(P1_BLOCK, 6) void k_scatter_samples(const uint32_t 
         }
     };
     load_tile(blockIdx.x);
+
+    if (HOT) {
+        // ---- pick the hot names from this workgroup's first tile (it is already in registers).
+        // Per-name counts live in L.sorted, which the scatter does not use before the first tile.
+        uint32_t *cnt = L.sorted; // nmetrics <= HOT_MAXM == P1_TILE words
+        for (uint32_t i = tid; i < nmetrics; i += P1_BLOCK) cnt[i] = 0;
+        for (uint32_t i = tid; i < HOT_MAXM; i += P1_BLOCK) H.slot_of[i] = (uint8_t)HOT_COLD;
+        for (uint32_t i = tid; i < HOT_NAMES * HOT_W; i += P1_BLOCK) H.win[i] = 0;
+        if (tid < HOT_NAMES) { H.name[tid] = INVALID; H.mn[tid] = INVALID; H.mx[tid] = 0; H.org[tid] = 0; }
+        __syncthreads();
+        const size_t pbase0 = (size_t)blockIdx.x * (P1_TILE / 2);
+#pragma unroll
+        for (int j = 0; j < P1_SPT; j++) {
+            const size_t i = 2 * (pbase0 + (size_t)(j >> 1) * P1_BLOCK + tid) + (j & 1);
+            const uint32_t id = (j & 1) ? idv[j >> 1].y : idv[j >> 1].x;
+            if (i < n && id < nmetrics) atomicAdd(&cnt[id], 1u);
+        }
+        __syncthreads();
+        // thread t owns names t, t + 512, ...: (count << 12 | name) packs into 32 bits (count <= 4 096)
+        constexpr int OWN = HOT_MAXM / P1_BLOCK;
+        uint32_t own[OWN];
+#pragma unroll
+        for (int k = 0; k < OWN; k++) {
+            const uint32_t id = tid + (uint32_t)k * P1_BLOCK;
+            own[k] = id < nmetrics ? (cnt[id] << 12) | id : 0u;
+        }
+        for (uint32_t r = 0; r < HOT_NAMES; r++) {
+            uint32_t best = 0;
+#pragma unroll
+            for (int k = 0; k < OWN; k++) best = own[k] > best ? own[k] : best;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const uint32_t o = __shfl_xor(best, d, 64);
+                best = o > best ? o : best;
+            }
+            if (lane == 0) H.wmax[wave] = best;
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t b = 0;
+                for (int w = 0; w < P1_BLOCK / 64; w++) b = H.wmax[w] > b ? H.wmax[w] : b;
+                H.pick = b;
+                if (b >> 12) { // at least one sample: a hot slot
+                    H.name[r] = b & 0xfffu;
+                    H.slot_of[b & 0xfffu] = (uint8_t)r;
+                }
+            }
+            __syncthreads();
+            const uint32_t b = H.pick;
+            if ((b >> 12) == 0) break; // uniform: fewer than HOT_NAMES names in the tile
+#pragma unroll
+            for (int k = 0; k < OWN; k++)
+                if (own[k] == b) own[k] = 0;
+        }
+        __syncthreads();
+        // window origins: centre of the hot name's sampled bins (as k_part_hist does)
+#pragma unroll
+        for (int j = 0; j < P1_SPT; j++) {
+            const size_t i = 2 * (pbase0 + (size_t)(j >> 1) * P1_BLOCK + tid) + (j & 1);
+            const uint32_t id = (j & 1) ? idv[j >> 1].y : idv[j >> 1].x;
+            const double x = (j & 1) ? val[j >> 1].y : val[j >> 1].x;
+            if (i < n && id < nmetrics) {
+                const uint32_t hs = H.slot_of[id];
+                if (hs != HOT_COLD) {
+                    const uint32_t bin = lh_bin_of(x, Tx);
+                    if (bin < H.mn[hs]) atomicMin(&H.mn[hs], bin);
+                    if (bin > H.mx[hs]) atomicMax(&H.mx[hs], bin);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < HOT_NAMES) {
+            uint32_t org = 32768u - HOT_W / 2;
+            if (H.mn[tid] != INVALID) {
+                const uint32_t centre = (H.mn[tid] + H.mx[tid] + 1) >> 1;
+                org = centre > HOT_W / 2 ? centre - HOT_W / 2 : 0u;
+            }
+            if (org > 65536u - HOT_W) org = 65536u - HOT_W;
+            H.org[tid] = org;
+            H.mn[tid] = INVALID; // reused as the flush ranges
+            H.mx[tid] = 0;
+        }
+        __syncthreads();
+    }
+
     for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const size_t pbase = tile * (P1_TILE / 2);
         uint32_t rec[P1_SPT], pr[P1_SPT];
@@ -389,9 +507,22 @@ __global__ __launch_bounds__(P1_BLOCK, 6) void k_scatter_samples(const uint32_t 
             if (i < n && id != INVALID) {
                 if (id < nmetrics) {
                     const uint32_t bin = (dbg & 2u) ? (uint32_t)(__double2loint(x) & 0xffff) : lh_bin_of(x, Tx);
-                    const uint32_t p = id & pmask;
-                    rec[j] = (p << 24) | ((id >> log_np) << 16) | bin;
-                    pr[j] = p | (atomicAdd(&L.cnt[p], 1u) << 8);
+                    bool counted = false;
+                    if (HOT) {
+                        const uint32_t hs = H.slot_of[id];
+                        if (hs != HOT_COLD) {
+                            const uint32_t rel = bin - H.org[hs];
+                            if (rel < HOT_W) {
+                                atomicAdd(&H.win[(hs << HOT_LOGW) + rel], 1u);
+                                counted = true;
+                            }
+                        }
+                    }
+                    if (!counted) {
+                        const uint32_t p = id & pmask;
+                        rec[j] = (p << 24) | ((id >> log_np) << 16) | bin;
+                        pr[j] = p | (atomicAdd(&L.cnt[p], 1u) << 8);
+                    }
                 } else {
                     atomicOr(err, 1u); // id >= nmetrics: reported by lh_sync / lh_extract
                 }
@@ -403,6 +534,27 @@ __global__ __launch_bounds__(P1_BLOCK, 6) void k_scatter_samples(const uint32_t 
                      [&] { load_tile(tile + gridDim.x); });
     }
     scatter_drain(L, records, cdesc, pool_base, np, 0u, 0u, tid);
+
+    if (HOT) {
+        __syncthreads();
+        // flush the hot windows: one uint64 atomic per occupied bin
+        for (uint32_t i = tid; i < HOT_NAMES * HOT_W; i += P1_BLOCK) {
+            const uint32_t c = H.win[i];
+            if (c) {
+                const uint32_t hs = i >> HOT_LOGW, b = H.org[hs] + (i & (HOT_W - 1));
+                atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)H.name[hs] * LH_NKEYS + b]),
+                          (unsigned long long)c);
+                atomicMin(&H.mn[hs], b);
+                atomicMax(&H.mx[hs], b);
+            }
+        }
+        __syncthreads();
+        if (tid < HOT_NAMES && H.mn[tid] != INVALID) {
+            uint32_t *r = ranges + 2 * (size_t)H.name[tid];
+            if (H.mn[tid] < r[0]) atomicMin(&r[0], H.mn[tid]);
+            if (H.mx[tid] > r[1]) atomicMax(&r[1], H.mx[tid]);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -850,6 +1002,9 @@ hipError_t launch_ingest_pairs_part(const uint32_t *d_ids, const double *d_v, si
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_plan_scatter),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NQMAX * sizeof(uint32_t)));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_samples<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)HOT_LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -864,8 +1019,12 @@ hipError_t launch_ingest_pairs_part(const uint32_t *d_ids, const double *d_v, si
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(L1.pc, 0, small_words(P.np, P.extra1) * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_scatter_samples, dim3(P.g1), dim3(P1_BLOCK), 0, s, d_ids, d_v, n, nmetrics, P.log_np, d_Tx,
-                       L1.records, L1.cdesc, P.chunks_per_wg, d_err, dbg);
+    if (P.hot)
+        hipLaunchKernelGGL(k_scatter_samples<true>, dim3(P.g1), dim3(P1_BLOCK), HOT_LDS_BYTES, s, d_ids, d_v, n, nmetrics,
+                           P.log_np, d_Tx, L1.records, L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, dbg);
+    else
+        hipLaunchKernelGGL(k_scatter_samples<false>, dim3(P.g1), dim3(P1_BLOCK), 0, s, d_ids, d_v, n, nmetrics,
+                           P.log_np, d_Tx, L1.records, L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, dbg);
     e = run_plan(L1, P.nchunks1, P.np, P.log_ns ? P.ns + 1 : 0u, P.extra1, s);
     if (e != hipSuccess) return e;
 

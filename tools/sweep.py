@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--pairs", type=int, default=0, help="if >0: mixed stream over this many names, Zipf(1.0) ids")
     ap.add_argument("--dists", default="lognormal,constant,uniform,exponential,normal,loguniform,lognormal25")
+    ap.add_argument("--ids", default="zipf", choices=["zipf", "uniform", "zipf0.5"], help="name distribution of --pairs")
     a = ap.parse_args()
     n = int(a.samples)
     torch.cuda.set_device(0)
@@ -30,7 +31,8 @@ def main():
         data = bench.make_samples(n, kind, 7)
         ids = None
         if a.pairs:
-            w = 1.0 / torch.arange(1, a.pairs + 1, dtype=torch.float64, device="cuda")
+            w = torch.arange(1, a.pairs + 1, dtype=torch.float64, device="cuda") ** {"zipf": -1.0, "uniform": 0.0,
+                                                                                      "zipf0.5": -0.5}[a.ids]
             ids = torch.multinomial(w / w.sum(), n, replacement=True).to(torch.int32)
         ms = []
         for r in range(a.reps + 2):
@@ -50,7 +52,7 @@ def main():
             assert int(st["count"].sum()) == n
         avg = sum(ms) / len(ms)
         bps = 12 if a.pairs else 8
-        print(json.dumps({"dist": kind, "names": a.pairs or 1, "n": n, "avg_ms": avg, "min_ms": min(ms),
+        print(json.dumps({"dist": kind, "names": a.pairs or 1, "ids": a.ids if a.pairs else None, "n": n, "avg_ms": avg, "min_ms": min(ms),
                           "Gsamples_per_s": n / avg / 1e6, "GBps": n * bps / avg / 1e6,
                           "frac_hbm_peak": n * bps / avg / 1e6 / 8000.0,
                           "occupied_buckets": int(st["nbuckets"].sum())}), flush=True)
