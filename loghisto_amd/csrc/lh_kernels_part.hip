@@ -35,6 +35,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 
 namespace lh {
 
@@ -271,13 +272,29 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const uint32_t (&rec
     for (int j = 0; j < P1_SPT; j++) {
         if (pr[j] != INVALID) L.sorted[L.off[pr[j] & 0xffu] + (pr[j] >> 8)] = rec[j];
     }
-    // ... and, independently, the previously staged records of partitions that emit a line
-    if (!(dbg & 1u))
-        for (uint32_t e = tid; e < NPMAX * LINE; e += P1_BLOCK) {
-            const uint32_t p = e / LINE, u = e % LINE;
+    // ... and, independently, the previously staged records of partitions that emit a line.  One thread per
+    // eight staged slots writes them as two 16-byte stores when any of them is live: the line's start d1 is
+    // 64-byte aligned, and the slots at or beyond n1 belong to the same emitted line, which the copy-out below
+    // (after the barrier, so ordered after these stores) fills with this tile's records.
+    static_assert(P1_BLOCK * 8 == NPMAX * LINE || LINE != 16, "one thread per 8 staged records");
+    if (!(dbg & 1u)) {
+        if (LINE == 16) {
+            const uint32_t p = tid >> 1, u0 = (tid & 1u) * 8u;
             const uint32_t d = L.d1[p];
-            if (d != INVALID && u < L.n1[p]) records[d + u] = L.stage[e];
+            if (d != INVALID && u0 < L.n1[p]) {
+                const pu4_t a = *reinterpret_cast<const pu4_t *>(&L.stage[p * LINE + u0]);
+                const pu4_t b = *reinterpret_cast<const pu4_t *>(&L.stage[p * LINE + u0 + 4]);
+                *reinterpret_cast<pu4_t *>(&records[d + u0]) = a;
+                *reinterpret_cast<pu4_t *>(&records[d + u0 + 4]) = b;
+            }
+        } else {
+            for (uint32_t e = tid; e < NPMAX * LINE; e += P1_BLOCK) {
+                const uint32_t p = e / LINE, u = e % LINE;
+                const uint32_t d = L.d1[p];
+                if (d != INVALID && u < L.n1[p]) records[d + u] = L.stage[e];
+            }
         }
+    }
     __syncthreads();
 
     // copy out: whole lines to HBM, the remainder of each partition into its staging line
@@ -496,40 +513,43 @@ __global__ __launch_bounds__(P1_BLOCK, HOT ? 4 : 6) void k_scatter_samples(const
 
     for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const size_t pbase = tile * (P1_TILE / 2);
+        // every tile but the last is full: no per-sample bounds arithmetic there (workgroup-uniform branch,
+        // two copies of the classification code)
+        const bool full_tile = (tile + 1) * (size_t)P1_TILE <= n;
         uint32_t rec[P1_SPT], pr[P1_SPT];
+        auto classify = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-        for (int j = 0; j < P1_SPT; j++) {
-            const size_t i = 2 * (pbase + (size_t)(j >> 1) * P1_BLOCK + tid) + (j & 1);
-            const uint32_t id = (j & 1) ? idv[j >> 1].y : idv[j >> 1].x;
-            const double x = (j & 1) ? val[j >> 1].y : val[j >> 1].x;
-            pr[j] = INVALID;
-            rec[j] = 0;
-            if (i < n && id != INVALID) {
-                if (id < nmetrics) {
-                    const uint32_t bin = (dbg & 2u) ? (uint32_t)(__double2loint(x) & 0xffff) : lh_bin_of(x, Tx);
-                    bool counted = false;
-                    if (HOT) {
-                        const uint32_t hs = H.slot_of[id];
-                        if (hs != HOT_COLD) {
-                            const uint32_t rel = bin - H.org[hs];
-                            if (rel < HOT_W) {
-                                atomicAdd(&H.win[(hs << HOT_LOGW) + rel], 1u);
-                                counted = true;
-                            }
+            for (int j = 0; j < P1_SPT; j++) {
+                const uint32_t id = (j & 1) ? idv[j >> 1].y : idv[j >> 1].x;
+                const double x = (j & 1) ? val[j >> 1].y : val[j >> 1].x;
+                pr[j] = INVALID;
+                rec[j] = 0;
+                bool live = true; // load_tile pads pairs beyond the stream with id 0xffffffff: not an error
+                if (!FULL) live = 2 * (pbase + (size_t)(j >> 1) * P1_BLOCK + tid) + (j & 1) < n;
+                if (!live) continue;
+                if (id >= nmetrics) {
+                    atomicOr(err, 1u); // reported by lh_sync / lh_extract
+                    continue;
+                }
+                const uint32_t bin = (dbg & 2u) ? (uint32_t)(__double2loint(x) & 0xffff) : lh_bin_of(x, Tx);
+                if (HOT) {
+                    const uint32_t hs = H.slot_of[id];
+                    if (hs != HOT_COLD) {
+                        const uint32_t rel = bin - H.org[hs];
+                        if (rel < HOT_W) {
+                            atomicAdd(&H.win[(hs << HOT_LOGW) + rel], 1u);
+                            continue;
                         }
                     }
-                    if (!counted) {
-                        const uint32_t p = id & pmask;
-                        rec[j] = (p << 24) | ((id >> log_np) << 16) | bin;
-                        pr[j] = p | (atomicAdd(&L.cnt[p], 1u) << 8);
-                    }
-                } else {
-                    atomicOr(err, 1u); // id >= nmetrics: reported by lh_sync / lh_extract
                 }
-            } else if (i < n) {
-                atomicOr(err, 1u);     // id == 0xffffffff
+                const uint32_t p = id & pmask;
+                rec[j] = (p << 24) | ((id >> log_np) << 16) | bin;
+                pr[j] = p | (atomicAdd(&L.cnt[p], 1u) << 8);
             }
-        }
+        };
+        if (full_tile) classify(std::true_type{});
+        else classify(std::false_type{});
         scatter_tile(L, rec, pr, records, cdesc, pool_base, 0u, 0u, dbg, tid,
                      [&] { load_tile(tile + gridDim.x); });
     }
