@@ -58,7 +58,6 @@ constexpr uint32_t P2_WINWORDS = 16384; // 64 KiB of uint32 windows per workgrou
 constexpr uint32_t SLOT_EXTRA = 1024;  // work slots beyond one per partition (measured: 512 is 25 % slower)
 constexpr size_t PART_MIN_SAMPLES = 131072;
 constexpr uint32_t PART_MAX_MPP = 256;
-constexpr uint32_t PART_HOT_MAX_NAMES = 4096; // k_scatter_samples<true>: names covered by the hot-slot map
 // chunk descriptor: partition tag << 11 | records in the chunk (1..1024); INVALID = unused
 constexpr uint32_t CD_SHIFT = 11, CD_MASK = (1u << CD_SHIFT) - 1;
 
@@ -115,11 +114,15 @@ static bool make_plan(size_t n, uint32_t nmetrics, int num_cus, PartPlan &P)
     while ((P.mpp2 << (lw + 1)) <= P2_WINWORDS) lw++;
     P.log_w = lw; // window = 2^log_w bins per name, mpp2 * window <= 16384
     const size_t ntiles = (n + P1_TILE - 1) / P1_TILE;
-    // Hot-name windows inside P1 (k_scatter_samples<true>, +36 KiB of LDS: two workgroups per CU): only with one
-    // partition level, a name table that fits the one-byte slot map, and a launch long enough (>= 32 tiles per
-    // workgroup) to amortise the per-workgroup selection of the hot names.  LH_PART_HOT=0 turns it off (tuning).
+    // Hot-name windows inside P1 (k_scatter_samples<true>, +34 KiB of LDS: two workgroups per CU) when the launch
+    // is long enough (>= 32 tiles per workgroup) to amortise the per-workgroup selection of the hot names.
+    // LH_PART_HOT=0 turns it off (tuning).
     static const bool hot_enabled = !(getenv("LH_PART_HOT") && atoi(getenv("LH_PART_HOT")) == 0);
-    P.hot = hot_enabled && P.log_ns == 0 && nmetrics <= PART_HOT_MAX_NAMES && ntiles >= (size_t)num_cus * 2 * 32;
+    // LH_PART_HOT_MIN_TILES (tests: exercise the hot path on small inputs) overrides the tiles-per-workgroup bar;
+    // read per call on purpose.
+    const char *mt_env = getenv("LH_PART_HOT_MIN_TILES");
+    const size_t min_tiles = mt_env ? (size_t)std::max(1, atoi(mt_env)) : 32;
+    P.hot = hot_enabled && ntiles >= (size_t)num_cus * 2 * min_tiles;
     // ~44 KiB LDS per workgroup: three 512-thread workgroups per CU (two with the hot windows)
     size_t g1 = (size_t)num_cus * (P.hot ? 2 : LH_P1_WGS_PER_CU);
     // every workgroup strands up to NP partially filled chunks (1 MiB at NP = 256): give a workgroup
@@ -367,15 +370,19 @@ __device__ __forceinline__ void scatter_drain(ScatterLds &L, uint32_t *__restric
 // hot samples outside their window -- takes the scatter path unchanged, so the result stays exact.  The
 // windows are flushed with one uint64 atomic per occupied bin when the workgroup ends.
 constexpr uint32_t HOT_NAMES = 16, HOT_LOGW = 9, HOT_W = 1u << HOT_LOGW;
-constexpr uint32_t HOT_MAXM = PART_HOT_MAX_NAMES; // names the hot-slot map covers (one byte each)
-static_assert(HOT_MAXM <= (uint32_t)P1_TILE, "the per-name counts of the selection live in ScatterLds::sorted");
-constexpr uint32_t HOT_COLD = 0xffu;
+// Selection works on a 2 048-entry (tag, count) table in ScatterLds::sorted: exact for <= 2 048 names, a hashed
+// heavy-hitter sketch above (an entry belongs to the first name that claims it; names that lose the race for an
+// entry are simply not candidates).  The name -> slot map is direct-mapped on the low 8 bits of the id; a
+// candidate whose map entry is taken is skipped.  Both only decide WHICH names get a window, never a count.
+constexpr uint32_t HOT_TAGS = 2048, HOT_MAPW = 256, HOT_ROUNDS = 24;
+static_assert(2 * HOT_TAGS <= (uint32_t)P1_TILE, "the selection table lives in ScatterLds::sorted");
+constexpr uint32_t HOT_EMPTY = 0xffffffffu;
 struct HotLds {
     uint32_t win[HOT_NAMES * HOT_W];
     uint32_t org[HOT_NAMES], name[HOT_NAMES], mn[HOT_NAMES], mx[HOT_NAMES];
     uint32_t wmax[P1_BLOCK / 64];
-    uint32_t pick;
-    uint8_t slot_of[HOT_MAXM];
+    uint32_t pick, nsel;
+    uint32_t hmap[HOT_MAPW]; // id << 8 | slot, HOT_EMPTY when free
 };
 constexpr size_t HOT_LDS_BYTES = sizeof(HotLds);
 
@@ -430,30 +437,36 @@ __global__ __launch_bounds__(P1_BLOCK, HOT ? 4 : 6) void k_scatter_samples(const
 
     if (HOT) {
         // ---- pick the hot names from this workgroup's first tile (it is already in registers).
-        // Per-name counts live in L.sorted, which the scatter does not use before the first tile.
-        uint32_t *cnt = L.sorted; // nmetrics <= HOT_MAXM == P1_TILE words
-        for (uint32_t i = tid; i < nmetrics; i += P1_BLOCK) cnt[i] = 0;
-        for (uint32_t i = tid; i < HOT_MAXM; i += P1_BLOCK) H.slot_of[i] = (uint8_t)HOT_COLD;
+        // The selection table lives in L.sorted, which the scatter does not use before the first tile.
+        uint32_t *tag = L.sorted, *cnt = L.sorted + HOT_TAGS;
+        for (uint32_t i = tid; i < 2 * HOT_TAGS; i += P1_BLOCK) L.sorted[i] = 0;
+        for (uint32_t i = tid; i < HOT_MAPW; i += P1_BLOCK) H.hmap[i] = HOT_EMPTY;
         for (uint32_t i = tid; i < HOT_NAMES * HOT_W; i += P1_BLOCK) H.win[i] = 0;
         if (tid < HOT_NAMES) { H.name[tid] = INVALID; H.mn[tid] = INVALID; H.mx[tid] = 0; H.org[tid] = 0; }
+        if (tid == 0) H.nsel = 0;
         __syncthreads();
         const size_t pbase0 = (size_t)blockIdx.x * (P1_TILE / 2);
+        const bool exact = nmetrics <= HOT_TAGS;
 #pragma unroll
         for (int j = 0; j < P1_SPT; j++) {
             const size_t i = 2 * (pbase0 + (size_t)(j >> 1) * P1_BLOCK + tid) + (j & 1);
             const uint32_t id = (j & 1) ? idv[j >> 1].y : idv[j >> 1].x;
-            if (i < n && id < nmetrics) atomicAdd(&cnt[id], 1u);
+            if (i < n && id < nmetrics) {
+                const uint32_t h = exact ? id : (id * 2654435761u) >> 21;
+                const uint32_t old = atomicCAS(&tag[h], 0u, id + 1u);
+                if (old == 0u || old == id + 1u) atomicAdd(&cnt[h], 1u);
+            }
         }
         __syncthreads();
-        // thread t owns names t, t + 512, ...: (count << 12 | name) packs into 32 bits (count <= 4 096)
-        constexpr int OWN = HOT_MAXM / P1_BLOCK;
+        // thread t owns entries t, t + 512, ...: (count << 11 | entry) packs into 24 bits (count <= 4 096)
+        constexpr int OWN = HOT_TAGS / P1_BLOCK;
         uint32_t own[OWN];
 #pragma unroll
         for (int k = 0; k < OWN; k++) {
-            const uint32_t id = tid + (uint32_t)k * P1_BLOCK;
-            own[k] = id < nmetrics ? (cnt[id] << 12) | id : 0u;
+            const uint32_t e = tid + (uint32_t)k * P1_BLOCK;
+            own[k] = cnt[e] ? (cnt[e] << 11) | e : 0u;
         }
-        for (uint32_t r = 0; r < HOT_NAMES; r++) {
+        for (uint32_t r = 0; r < HOT_ROUNDS; r++) {
             uint32_t best = 0;
 #pragma unroll
             for (int k = 0; k < OWN; k++) best = own[k] > best ? own[k] : best;
@@ -468,14 +481,18 @@ __global__ __launch_bounds__(P1_BLOCK, HOT ? 4 : 6) void k_scatter_samples(const
                 uint32_t b = 0;
                 for (int w = 0; w < P1_BLOCK / 64; w++) b = H.wmax[w] > b ? H.wmax[w] : b;
                 H.pick = b;
-                if (b >> 12) { // at least one sample: a hot slot
-                    H.name[r] = b & 0xfffu;
-                    H.slot_of[b & 0xfffu] = (uint8_t)r;
+                if (b) {
+                    const uint32_t id = tag[b & (HOT_TAGS - 1)] - 1u, m = id & (HOT_MAPW - 1), slot = H.nsel;
+                    if (H.hmap[m] == HOT_EMPTY) { // else: skipped, the next candidate gets its turn
+                        H.hmap[m] = (id << 8) | slot;
+                        H.name[slot] = id;
+                        H.nsel = slot + 1;
+                    }
                 }
             }
             __syncthreads();
             const uint32_t b = H.pick;
-            if ((b >> 12) == 0) break; // uniform: fewer than HOT_NAMES names in the tile
+            if (b == 0 || H.nsel == HOT_NAMES) break; // uniform: no candidates left, or all windows taken
 #pragma unroll
             for (int k = 0; k < OWN; k++)
                 if (own[k] == b) own[k] = 0;
@@ -488,8 +505,8 @@ __global__ __launch_bounds__(P1_BLOCK, HOT ? 4 : 6) void k_scatter_samples(const
             const uint32_t id = (j & 1) ? idv[j >> 1].y : idv[j >> 1].x;
             const double x = (j & 1) ? val[j >> 1].y : val[j >> 1].x;
             if (i < n && id < nmetrics) {
-                const uint32_t hs = H.slot_of[id];
-                if (hs != HOT_COLD) {
+                const uint32_t e = H.hmap[id & (HOT_MAPW - 1)], hs = e & 0xffu;
+                if ((e >> 8) == id) {
                     const uint32_t bin = lh_bin_of(x, Tx);
                     if (bin < H.mn[hs]) atomicMin(&H.mn[hs], bin);
                     if (bin > H.mx[hs]) atomicMax(&H.mx[hs], bin);
@@ -534,8 +551,8 @@ __global__ __launch_bounds__(P1_BLOCK, HOT ? 4 : 6) void k_scatter_samples(const
                 }
                 const uint32_t bin = (dbg & 2u) ? (uint32_t)(__double2loint(x) & 0xffff) : lh_bin_of(x, Tx);
                 if (HOT) {
-                    const uint32_t hs = H.slot_of[id];
-                    if (hs != HOT_COLD) {
+                    const uint32_t e = H.hmap[id & (HOT_MAPW - 1)], hs = e & 0xffu;
+                    if ((e >> 8) == id) {
                         const uint32_t rel = bin - H.org[hs];
                         if (rel < HOT_W) {
                             atomicAdd(&H.win[(hs << HOT_LOGW) + rel], 1u);
