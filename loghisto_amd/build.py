@@ -33,6 +33,7 @@ _PROGRAMS = [
     ("tests/cpp/metrics_test.cc", "metrics_test"),   # metrics_test.go restated
     ("tools/c5_driver.cc", "c5_driver"),             # BASELINE config 5 driver
     ("tools/wire_bench.cc", "wire_bench"),           # per-key vs bulk (K6) ProcessedMetricSet serialization
+    ("tools/latency.cc", "latency"),                 # flip -> extract latency at the C ABI
 ]
 
 

@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <functional>
@@ -128,6 +129,8 @@ struct lh_engine {
     std::mutex xmu; // extract scratch
     unsigned char *d_xbuf = nullptr;
     unsigned char *h_xbuf = nullptr;
+    unsigned char *d_hxbuf = nullptr; // device-side address of the pinned h_xbuf (zero-copy results), or null
+    uint32_t xseq = 0;                // completion-flag sequence of the zero-copy extract (xmu)
     size_t xbuf_bytes = 0;
 
     // K6 (lh_serialize): names, lifetime stores and the text buffer in HBM; all guarded by xmu
@@ -343,10 +346,14 @@ int ensure_xbuf(lh_engine *e, size_t bytes)
     if (e->h_xbuf) (void)hipHostFree(e->h_xbuf);
     e->d_xbuf = nullptr;
     e->h_xbuf = nullptr;
+    e->d_hxbuf = nullptr;
     e->xbuf_bytes = 0;
     size_t cap = bytes + bytes / 4 + 4096;
     HIPCHK(hipMalloc((void **)&e->d_xbuf, cap));
     HIPCHK(hipHostMalloc((void **)&e->h_xbuf, cap, hipHostMallocDefault));
+    void *dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, e->h_xbuf, 0) == hipSuccess) e->d_hxbuf = static_cast<unsigned char *>(dp);
+    else (void)hipGetLastError(); // no mapping: results always travel by copy
     e->xbuf_bytes = cap;
     return LH_OK;
 }
@@ -377,8 +384,8 @@ int create_impl(const lh_config *cfg_in, lh_engine *e)
 
     HIPCHK(hipMalloc((void **)&e->d_Tx, sizeof(double) * LH_NTHRESH));
     HIPCHK(hipMalloc((void **)&e->d_D, sizeof(double) * LH_NKEYS));
-    HIPCHK(hipMalloc((void **)&e->d_err, 8));
-    HIPCHK(hipMemsetAsync(e->d_err, 0, 8, e->xstream));
+    HIPCHK(hipMalloc((void **)&e->d_err, 16)); // [0] bad id flag, [1] window misses, [2] extract done counter
+    HIPCHK(hipMemsetAsync(e->d_err, 0, 16, e->xstream));
     HIPCHK(lh::launch_gen_tables(e->d_Tx, e->d_D, e->xstream));
 
     const size_t M = e->cfg.max_metrics;
@@ -721,17 +728,46 @@ int lh_extract_rows(lh_snapshot *s, uint32_t first, size_t nmetrics, const doubl
     static_assert(sizeof(lh::ExtractOut) == sizeof(lh_stats), "lh_stats layout");
     std::lock_guard<std::mutex> g(e->xmu);
     const ExtractLayout L = extract_layout(nmetrics, np);
-    rc = ensure_xbuf(e, L.total);
+    rc = ensure_xbuf(e, L.total + 16);
     if (rc) return rc;
     EpochBuffer &b = e->bufs[(size_t)s->buf];
+    // Small results (the latency path: one or a few metrics) are written by the kernel straight into the pinned
+    // host block through its device mapping: one launch + one sync, no separate copy.  Large ones go through
+    // HBM and one DMA (fine-grained stores over PCIe would be slower than the copy engine).
+    const bool zero_copy = e->d_hxbuf != nullptr && L.total <= 32768 && !getenv("LH_NO_ZERO_COPY");
+    unsigned char *xb = zero_copy ? e->d_hxbuf : e->d_xbuf;
+    lh::ExtractNotify nt;
+    volatile uint32_t *flag = reinterpret_cast<volatile uint32_t *>(e->h_xbuf + L.total);
+    if (zero_copy) {
+        if (++e->xseq == 0) e->xseq = 1;
+        *flag = 0;
+        nt.done_ctr = e->d_err + 2;
+        nt.host_flag = reinterpret_cast<uint32_t *>(e->d_hxbuf + L.total);
+        nt.seq = e->xseq;
+    }
     HIPCHK(lh::launch_extract(b.counts + (size_t)first * LH_NKEYS, b.ranges + 2 * (size_t)first,
                               (uint32_t)nmetrics, p, (uint32_t)np, e->d_D,
-                              reinterpret_cast<lh::ExtractOut *>(e->d_xbuf + L.off_stats),
-                              reinterpret_cast<double *>(e->d_xbuf + L.off_pvals),
-                              reinterpret_cast<int16_t *>(e->d_xbuf + L.off_pkeys), e->d_xbuf + L.off_pvalid,
-                              e->d_err, reinterpret_cast<uint32_t *>(e->d_xbuf + L.off_err), e->xstream));
-    HIPCHK(hipMemcpyAsync(e->h_xbuf, e->d_xbuf, L.total, hipMemcpyDeviceToHost, e->xstream));
-    HIPCHK(hipStreamSynchronize(e->xstream));
+                              reinterpret_cast<lh::ExtractOut *>(xb + L.off_stats),
+                              reinterpret_cast<double *>(xb + L.off_pvals),
+                              reinterpret_cast<int16_t *>(xb + L.off_pkeys), xb + L.off_pvalid,
+                              e->d_err, reinterpret_cast<uint32_t *>(xb + L.off_err), e->xstream, nt));
+    if (zero_copy) {
+        // spin on the completion word the last workgroup stores after its system-scope release: no driver call
+        // on the latency path; after 2 ms (a flip queued behind long ingest kernels) fall back to the stream
+        const auto t0 = std::chrono::steady_clock::now();
+        uint32_t spins = 0;
+        while (*flag != nt.seq) {
+            __builtin_ia32_pause();
+            if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+                HIPCHK(hipStreamSynchronize(e->xstream));
+                break;
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    } else {
+        HIPCHK(hipMemcpyAsync(e->h_xbuf, e->d_xbuf, L.total, hipMemcpyDeviceToHost, e->xstream));
+        HIPCHK(hipStreamSynchronize(e->xstream));
+    }
     std::memcpy(stats, e->h_xbuf + L.off_stats, nmetrics * sizeof(lh_stats));
     if (np) {
         std::memcpy(pvals, e->h_xbuf + L.off_pvals, nmetrics * np * sizeof(double));

@@ -43,10 +43,14 @@ hipError_t launch_ingest_pairs_part(const uint32_t *d_ids, const double *d_v, si
                                     void *scratch, size_t scratch_bytes, int num_cus, hipStream_t s);
 
 // K2: extract.  One workgroup per metric.
+// ExtractNotify (optional): when the outputs live in host-mapped memory the last workgroup to finish stores
+// `seq` into *host_flag (system-scope release after every workgroup's results), so the host can spin on a word
+// of pinned memory instead of going through a stream synchronisation.  done_ctr: device uint32, zero between calls.
+struct ExtractNotify { uint32_t *done_ctr = nullptr; uint32_t *host_flag = nullptr; uint32_t seq = 0; };
 hipError_t launch_extract(const uint64_t *counts, const uint32_t *ranges, uint32_t nmetrics,
                           const double *h_p /* host */, uint32_t np, const double *d_D, ExtractOut *out,
                           double *pvals, int16_t *pkeys, uint8_t *pvalid, const uint32_t *err_in,
-                          uint32_t *err_out, hipStream_t s);
+                          uint32_t *err_out, hipStream_t s, ExtractNotify notify = ExtractNotify());
 
 // K5: occupied cells of every row as CSR arrays (ascending key within a row).
 hipError_t launch_count_cells(const uint64_t *counts, const uint32_t *ranges, uint32_t nmetrics, uint32_t *ncells,

@@ -321,7 +321,7 @@ __global__ __launch_bounds__(K2_BLOCK) void k_extract(const uint64_t *__restrict
                                                       double *__restrict__ pvals, int16_t *__restrict__ pkeys,
                                                       uint8_t *__restrict__ pvalid,
                                                       const uint32_t *__restrict__ err_in,
-                                                      uint32_t *__restrict__ err_out)
+                                                      uint32_t *__restrict__ err_out, const ExtractNotify nt)
 {
     __shared__ uint64_t s_cnt[K2_WAVES];
     __shared__ double s_sum[K2_WAVES];
@@ -447,18 +447,27 @@ __global__ __launch_bounds__(K2_BLOCK) void k_extract(const uint64_t *__restrict
             pvalid[o] = 0;
         }
     }
+    if (nt.host_flag) { // zero-copy results: tell the host when the last workgroup is done
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0 && atomicAdd(nt.done_ctr, 1u) == gridDim.x - 1) {
+            atomicExch(nt.done_ctr, 0u);
+            __threadfence_system();
+            __hip_atomic_store(nt.host_flag, nt.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 hipError_t launch_extract(const uint64_t *counts, const uint32_t *ranges, uint32_t nmetrics,
                           const double *h_p, uint32_t np, const double *d_D, ExtractOut *out,
                           double *pvals, int16_t *pkeys, uint8_t *pvalid, const uint32_t *err_in,
-                          uint32_t *err_out, hipStream_t s)
+                          uint32_t *err_out, hipStream_t s, ExtractNotify notify)
 {
     if (nmetrics == 0) return hipSuccess;
     PctArgs pa;
     for (uint32_t i = 0; i < (uint32_t)K2_MAXP; i++) pa.p[i] = i < np ? h_p[i] : 2.0;
     hipLaunchKernelGGL(k_extract, dim3(nmetrics), dim3(K2_BLOCK), 0, s, counts, ranges, pa, np, d_D, out,
-                       pvals, pkeys, pvalid, err_in, err_out);
+                       pvals, pkeys, pvalid, err_in, err_out, notify);
     return hipGetLastError();
 }
 
