@@ -598,6 +598,9 @@ __global__ __launch_bounds__(P1_BLOCK, HOT ? 4 : 6) void k_scatter_samples(const
 // P1b: second partition level.  One workgroup per level-1 work slot re-scatters that slot's records by
 // the next log_ns bits of the local name id.  Output partition q = sub << log_np | p, so that the name
 // is again (local >> log_ns) << log_nq | q, i.e. P2 works unchanged with log_nq in place of log_np.
+// (Hot-name windows were tried here too -- the names of one level-1 partition are skewed as well -- and measured
+// slower: 65 536 names 7.47 -> 8.00 ms, one rank's config-4 slice 1.49 -> 1.79 ms.  The per-slot selection and
+// the drop to two workgroups per CU cost more than the records saved.)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(P1_BLOCK, 6) void k_scatter_records(const uint32_t *__restrict__ in_records,
                                                                  const uint32_t *__restrict__ in_cdesc,
