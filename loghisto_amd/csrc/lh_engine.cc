@@ -209,6 +209,18 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
 {
     EpochBuffer &b = e->bufs[(size_t)e->cur];
     const size_t kMaxLaunch = size_t(1) << 30;
+    // Slices taken at an odd sample index leave BOTH arrays one element short of the vector-load alignment of
+    // the fast kernels (ids 8-byte, values 16-byte): peel that one sample through the direct kernel instead of
+    // sending the whole launch down the one-atomic-per-sample path (25x slower).
+    if (n > 1 && ((uintptr_t)d_ids & 7) == 4 && ((uintptr_t)d_v & 15) == 8) {
+        HIPCHK(lh::launch_ingest_pairs(d_ids, d_v, 1, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx, e->d_err,
+                                       e->num_cus, s));
+        e->c_direct.fetch_add(1, std::memory_order_relaxed);
+        e->c_launches.fetch_add(1, std::memory_order_relaxed);
+        d_ids++;
+        d_v++;
+        n--;
+    }
     while (n) {
         const size_t take = n < kMaxLaunch ? n : kMaxLaunch;
         if (!e->small_disabled.load(std::memory_order_relaxed) &&
