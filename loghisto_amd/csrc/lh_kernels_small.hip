@@ -1,13 +1,16 @@
-// lh_kernels_small.hip -- mixed (id, value) ingest when the engine has FEW names (<= 16), gfx950.
+// lh_kernels_small.hip -- mixed (id, value) ingest when the engine has FEW names (<= 32), gfx950.
 //
 // Reference semantics: Histogram(name, v) = histogramCache[name][compress(v)] += 1
 // (metrics.go:273-295, 316-322).  With a handful of names every workgroup can keep all of them in
 // LDS, so this is a single streaming pass like K1 (lh_kernels.hip): 12 algorithmic bytes per sample
 // and nothing written back but the flush -- no partition pass (lh_kernels_part.hip needs 20 B/sample).
 //
-// LDS: 16 384 uint32 bins (64 KiB) split evenly: 1 name -> 16 384 bins, 4 -> 4 096, 16 -> 1 024.
-// Each workgroup places its windows from its own first tile (lh_windows.h); records outside a window
-// go to global atomics (exact).  Two 512-thread workgroups per CU, grid-stride over 4 096-sample tiles.
+// LDS: 16 384 uint32 bins (64 KiB) split evenly: 1 name -> 16 384 bins, 4 -> 4 096, 16 -> 1 024; two
+// 512-thread workgroups per CU.  17 .. 32 names: 32 768 bins (128 KiB, again >= 1 024 bins per name), one
+// 1 024-thread workgroup per CU (the same 16 waves): 1.96-1.99 ms per 1e9 samples against 3.4 ms through the
+// partitioned path.  Not beyond 32: with 512-bin windows a lognormal(sigma = 1) stream loses 1 % of its samples
+// to the global-atomic path and 64 names take 3.9 ms, more than the partitioned path with its hot windows.  Each workgroup places its windows from its own first
+// tile (lh_windows.h); records outside a window go to global atomics (exact).  Grid-stride over tiles.
 #include "lh_kernels.h"
 #include "lh_codec.h"
 
@@ -19,11 +22,10 @@ namespace lh {
 typedef double sd2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t su2_t __attribute__((ext_vector_type(2)));
 
-constexpr int KS_BLOCK = 512;
 constexpr int KS_UNROLL = 4;                  // (16-B values + 8-B ids) loads in flight per lane
-constexpr uint32_t KS_WORDS = 16384;
-constexpr uint32_t KS_MAXM = 16;
-constexpr size_t KS_LDS_BYTES = (KS_WORDS + 3 * KS_MAXM + 2 * OV_SLOTS) * sizeof(uint32_t) + 16;
+constexpr uint32_t KS_MAXM = 32;
+constexpr uint32_t KS_MAXM_SMALL = 16;        // up to here: 64 KiB windows, 512 threads
+constexpr size_t ks_lds_bytes(uint32_t words) { return (words + 3 * KS_MAXM + 2 * OV_SLOTS) * sizeof(uint32_t) + 16; }
 constexpr size_t KS_MIN_SAMPLES = 65536;
 
 bool small_supported(size_t n, uint32_t nmetrics, const uint32_t *d_ids, const double *d_v)
@@ -41,6 +43,7 @@ __device__ __forceinline__ void ks_global_add(uint64_t *__restrict__ counts, uin
     if (bin > r[1]) atomicMax(&r[1], bin);
 }
 
+template <uint32_t KS_WORDS, int KS_BLOCK>
 __global__ __launch_bounds__(KS_BLOCK) void k_ingest_pairs_small(const uint32_t *__restrict__ ids,
                                                                  const double *__restrict__ v, size_t n,
                                                                  uint64_t *__restrict__ counts,
@@ -166,19 +169,29 @@ hipError_t launch_ingest_pairs_small(const uint32_t *d_ids, const double *d_v, s
     if (!small_supported(n, nmetrics, d_ids, d_v)) return hipErrorInvalidValue;
     static std::atomic<bool> attr_set{false}; // benign if two threads race: both set the same attribute
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ingest_pairs_small),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)KS_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ingest_pairs_small<16384, 512>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ks_lds_bytes(16384));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ingest_pairs_small<32768, 1024>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ks_lds_bytes(32768));
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    const bool big = nmetrics > KS_MAXM_SMALL;
+    const uint32_t words = big ? 32768u : 16384u;
+    const int block = big ? 1024 : 512;
     uint32_t log_w = 0;
-    while ((nmetrics << (log_w + 1)) <= KS_WORDS) log_w++; // window = 2^log_w bins per name
-    const size_t tile_samples = (size_t)KS_BLOCK * KS_UNROLL * 2;
+    while ((nmetrics << (log_w + 1)) <= words) log_w++; // window = 2^log_w bins per name
+    const size_t tile_samples = (size_t)block * KS_UNROLL * 2;
     size_t want = (n + tile_samples - 1) / tile_samples;
-    const size_t cap = (size_t)num_cus * 2;
+    const size_t cap = (size_t)num_cus * (big ? 1 : 2);
     const unsigned grid = (unsigned)(want < cap ? want : cap);
-    hipLaunchKernelGGL(k_ingest_pairs_small, dim3(grid ? grid : 1), dim3(KS_BLOCK), KS_LDS_BYTES, s, d_ids, d_v, n,
-                       counts, ranges, nmetrics, log_w, d_Tx, d_err);
+    if (big)
+        hipLaunchKernelGGL((k_ingest_pairs_small<32768, 1024>), dim3(grid ? grid : 1), dim3(1024), ks_lds_bytes(32768), s,
+                           d_ids, d_v, n, counts, ranges, nmetrics, log_w, d_Tx, d_err);
+    else
+        hipLaunchKernelGGL((k_ingest_pairs_small<16384, 512>), dim3(grid ? grid : 1), dim3(512), ks_lds_bytes(16384), s,
+                           d_ids, d_v, n, counts, ranges, nmetrics, log_w, d_Tx, d_err);
     return hipGetLastError();
 }
 

@@ -29,7 +29,7 @@ def _ids(rng, M, n, skew):
 
 @pytest.mark.parametrize("M,n,kind,skew", [
     (1024, 3_000_001, "lognormal", 1.0),     # config 3's shape; odd length
-    (37, 2_500_000, "constant", 1.0),        # fewer names than hot slots + same-bin contention
+    (37, 2_500_000, "constant", 1.0),        # few names (just above the single-pass kernel's 32) + same-bin contention
     (5000, 3_000_000, "signed", 1.0),        # hashed selection (> 2 048 names); two clusters of bins per name
     (65536, 4_000_000, "lognormal", 1.0),    # hot windows + second partition level
     (300, 2_200_000, "wide", 1.5),           # hot names whose samples mostly miss their 512-bin window

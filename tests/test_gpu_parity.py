@@ -360,7 +360,7 @@ def _zipf_ids(rng, n, M):
 @pytest.mark.parametrize("M,n,kind", [
     (1024, 3_000_001, "lognormal"),      # BASELINE config 3 shape: 256 partitions x 4 names
     (1024, 1_000_000, "constant"),       # one cell per name: the wave-uniform path
-    (37, 700_001, "signed_wide"),        # odd name count, keys on both sides, out-of-window records
+    (77, 700_001, "signed_wide"),        # odd name count, keys on both sides, out-of-window records
     (2, 200_000, "lognormal"),           # single partition
     (300, 131_072, "loguniform"),        # exactly the partitioned-path threshold
     (300, 131_071, "loguniform"),        # one below: direct-atomic path
@@ -398,7 +398,7 @@ def test_ingest_pairs_partitioned(la, torch_cuda, M, n, kind):
 
 def test_pairs_partitioned_bad_ids_and_reuse(la, torch_cuda):
     rng = np.random.default_rng(99)
-    M, n = 64, 400_000
+    M, n = 96, 400_000
     ids = _zipf_ids(rng, n, M)
     v = rng.lognormal(10, 1, n)
     bad = ids.copy()

@@ -27,6 +27,11 @@ def _dev(torch, a):
     (8, 65_536, "loguniform"),           # exactly the kernel's threshold
     (8, 65_535, "loguniform"),           # one below: direct-atomic kernel
     (5, 400_000, "shifting"),            # distribution moves after the first tile: windows misplaced, still exact
+    (17, 1_200_001, "lognormal"),        # 128 KiB variant (1 024 threads): 1 024-bin windows
+    (32, 900_000, "constant"),
+    (32, 1_500_000, "signed_wide"),      # mostly outside the windows
+    (31, 700_001, "shifting"),
+    (33, 1_000_000, "lognormal"),        # one above the single-pass limit: partitioned path
 ])
 def test_small_name_count_ingest(native_lib, torch_cuda, M, n, kind):
     import loghisto_amd
