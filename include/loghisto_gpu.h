@@ -220,7 +220,7 @@ int lh_release(lh_snapshot *s);
  * RegisterGaugeFunc, metrics.go:299).  Monotonic since lh_create. */
 typedef struct lh_counters {
     uint64_t samples_single;       /* through k_ingest_single                           */
-    uint64_t samples_small;        /* mixed, single-pass LDS kernel (<= 16 names)       */
+    uint64_t samples_small;        /* mixed, single-pass LDS kernel (<= 32 names)       */
     uint64_t samples_partitioned;  /* mixed, partition + LDS reduce                     */
     uint64_t samples_direct;       /* mixed, one global atomic per sample (small launches) */
     uint64_t launches;             /* ingest launches of any kind                       */

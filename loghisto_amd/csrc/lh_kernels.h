@@ -33,7 +33,7 @@ hipError_t launch_ingest_pairs(const uint32_t *d_ids, const double *d_v, size_t 
 size_t part_scratch_bytes(size_t n, uint32_t nmetrics, int num_cus);
 bool part_aligned(const uint32_t *d_ids, const double *d_v); // 8-B ids / 16-B values: vector loads
 
-// Few names (<= 16): single streaming pass with every name's window in LDS (lh_kernels_small.hip).
+// Few names (<= 32): single streaming pass with every name's window in LDS (lh_kernels_small.hip).
 bool small_supported(size_t n, uint32_t nmetrics, const uint32_t *d_ids, const double *d_v);
 hipError_t launch_ingest_pairs_small(const uint32_t *d_ids, const double *d_v, size_t n, uint64_t *counts,
                                      uint32_t *ranges, uint32_t nmetrics, const double *d_Tx, uint32_t *d_err,
