@@ -35,6 +35,7 @@ def test_struct_layouts_match_header(native_lib):
     from loghisto_amd import _native
     assert C.sizeof(_native.LhConfig) == 32
     assert C.sizeof(_native.LhStats) == 40
+    assert C.sizeof(_native.LhLineFormat) == 32 and C.sizeof(_native.LhCounters) == 88
     cfg = _native.LhConfig()
     assert native_lib.lh_default_config(C.byref(cfg)) == 0
     assert cfg.struct_size == 32 and cfg.max_metrics >= 1 and cfg.num_buffers >= 2
@@ -50,6 +51,13 @@ def test_argument_validation_needs_no_gpu(native_lib):
     assert native_lib.lh_create(C.byref(cfg), C.byref(h)) == _native.EINVAL
     assert native_lib.lh_flush(None) == _native.EINVAL
     assert native_lib.lh_release(None) == _native.EINVAL
+    # K6 entry points
+    n = C.c_size_t(0)
+    fmt = _native.LhLineFormat(b"put ", b" 1 ", b"\n", 0, 0)
+    assert native_lib.lh_serialize(None, 0, 1, None, None, 0, C.byref(fmt), 0, None, 0, C.byref(n)) == _native.EINVAL
+    assert native_lib.lh_snapshot_accumulate(None) == _native.EINVAL
+    assert native_lib.lh_lifetime(None, 0, 1, None, None) == _native.EINVAL
+    assert native_lib.lh_format_f(None, None, 1, None, 336, None) == _native.EINVAL
 
 
 def test_no_cpu_fallback():
