@@ -799,7 +799,7 @@ std::string FormatGoV(double v)
     if (exp < -4 || exp >= 6) { // strconv %g: %e when exp < -4 || exp >= eprec, eprec = 6 for the shortest form
         out += digits[0];
         if (digits.size() > 1) { out += '.'; out += digits.substr(1); }
-        char e[8];
+        char e[16]; // |exp| <= 324
         std::snprintf(e, sizeof e, "e%c%02d", exp < 0 ? '-' : '+', exp < 0 ? -exp : exp);
         return out + e;
     }
