@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define LH_ABI_VERSION 1
+#define LH_ABI_VERSION 2
 #define LH_NKEYS 65536            /* int16 key space (metrics.go:316)        */
 #define LH_NTHRESH 70980          /* extended-key thresholds incl. sentinel  */
 #define LH_MAX_PERCENTILES 32
@@ -229,10 +229,39 @@ typedef struct lh_counters {
     uint64_t extracts;             /* lh_extract / lh_extract_rows calls                */
     uint64_t backpressure_waits;   /* submitters that had to wait for a staging half-buffer */
     uint64_t window_misses;        /* samples the single-pass kernel sent to global atomics */
-    uint32_t small_path_disabled;  /* 1 once adaptive dispatch moved few-name streams to the partitioned path */
+    uint32_t small_path_disabled;  /* 1 while adaptive dispatch routes few-name streams through the partitioned path */
     uint32_t reserved;
+    uint64_t scratch_bytes;        /* HBM scratch of the partitioned mixed ingest (one block per engine)  */
+    uint64_t sublaunches;          /* partitioned sub-launches (a large launch is cut so the scratch stays bounded) */
 } lh_counters;
 int lh_get_counters(lh_engine *e, lh_counters *out);
+
+/* Dispatch settings.  Every option only chooses among EXACT kernel paths or sizes a buffer: no option (and no
+ * environment variable -- the library never calls getenv) can change a result.  Takes effect for later calls;
+ * not synchronised with concurrent submits (set options before the producers start).
+ *   LH_OPT_TWO_LEVEL_ABOVE    second scatter level when a level-1 partition holds more names than this (default 32,
+ *                             i.e. above 8 192 names; 0 forces it whenever there are more than 4 names per partition)
+ *   LH_OPT_HOT_MIN_TILES      hot-name windows in the scatter pass when every workgroup gets >= this many
+ *                             4 096-sample tiles (default 32); 1 exercises the path on small inputs
+ *   LH_OPT_HOT_WINDOWS        0 / 1: hot-name windows allowed (default 1)
+ *   LH_OPT_NAMES_PER_PARTITION names per LDS-reduce partition, 1..64 (default 4 = 4 096-bin windows)
+ *   LH_OPT_EXTRACT_ZERO_COPY  0 / 1: small extract results are stored straight into pinned host memory (default 1)
+ *   LH_OPT_SCRATCH_CAP_BYTES  upper bound of the mixed ingest's scratch block (default 1.5 GiB, >= 64 MiB)
+ *   LH_OPT_SUBLAUNCH_PAIRS    largest partitioned sub-launch, 2^22 .. 2^30 pairs, rounded down to a power of two
+ *                             (default 2^28)
+ *   LH_OPT_SMALL_PATH         0 / 1: the single-pass kernel for <= 32 names (1 also re-arms it after adaptive
+ *                             dispatch turned it off) */
+enum {
+    LH_OPT_TWO_LEVEL_ABOVE = 1,
+    LH_OPT_HOT_MIN_TILES = 2,
+    LH_OPT_HOT_WINDOWS = 3,
+    LH_OPT_NAMES_PER_PARTITION = 4,
+    LH_OPT_EXTRACT_ZERO_COPY = 5,
+    LH_OPT_SCRATCH_CAP_BYTES = 6,
+    LH_OPT_SUBLAUNCH_PAIRS = 7,
+    LH_OPT_SMALL_PATH = 8
+};
+int lh_set_option(lh_engine *e, int option, uint64_t value);
 
 /* Codec access for parity tests. */
 /* key[i] = compress(d_v[i]) on device (metrics.go:316-322). */

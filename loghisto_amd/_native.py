@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblhgpu.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 NKEYS = 65536
 NTHRESH = 70980
 MAX_PERCENTILES = 32
@@ -29,7 +29,13 @@ class LhCounters(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("samples_single", "samples_small", "samples_partitioned", "samples_direct",
                                            "launches", "flips", "flips_busy", "extracts", "backpressure_waits",
                                            "window_misses")] + [("small_path_disabled", C.c_uint32),
-                                                                ("reserved", C.c_uint32)]
+                                                                ("reserved", C.c_uint32),
+                                                                ("scratch_bytes", C.c_uint64),
+                                                                ("sublaunches", C.c_uint64)]
+
+# lh_set_option keys (include/loghisto_gpu.h)
+OPT_TWO_LEVEL_ABOVE, OPT_HOT_MIN_TILES, OPT_HOT_WINDOWS, OPT_NAMES_PER_PARTITION = 1, 2, 3, 4
+OPT_EXTRACT_ZERO_COPY, OPT_SCRATCH_CAP_BYTES, OPT_SUBLAUNCH_PAIRS, OPT_SMALL_PATH = 5, 6, 7, 8
 
 
 class LhLineFormat(C.Structure):
@@ -87,6 +93,7 @@ SIGNATURES = {
     "lh_snapshot_stream": (C.c_int, [_vp, C.POINTER(_vp)]),
     "lh_release": (C.c_int, [_vp]),
     "lh_get_counters": (C.c_int, [_vp, C.POINTER(LhCounters)]),
+    "lh_set_option": (C.c_int, [_vp, C.c_int, C.c_uint64]),
     "lh_compress_device": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
     "lh_compress_device_golog": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
     "lh_codec_tables": (C.c_int, [_vp, _dp, _dp]),

@@ -22,6 +22,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -155,10 +156,24 @@ struct lh_engine {
     std::atomic<uint64_t> c_single{0}, c_small{0}, c_part{0}, c_direct{0}, c_launches{0}, c_flips{0}, c_busy{0},
         c_extracts{0}, c_waits{0}, c_misses{0};
 
-    // scratch of the partitioned mixed-ingest kernels, one per launching stream
-    struct Scratch { void *p = nullptr; size_t bytes = 0; };
+    // Scratch of the partitioned mixed-ingest kernels: ONE block per engine, shared by every launching stream
+    // (a stream that finds it last used by another stream waits on `scratch_done` first; partitioned launches fill
+    // the chip, so nothing is lost by running them one after another).  Large launches are cut into sub-launches
+    // so that the block stays below `scratch_cap` (lh_set_option(LH_OPT_SCRATCH_CAP_BYTES)).
     std::mutex scratch_mu;
-    std::unordered_map<hipStream_t, Scratch> scratch;
+    void *scratch_p = nullptr;
+    size_t scratch_bytes = 0;
+    hipEvent_t scratch_done = nullptr;
+    hipStream_t scratch_stream = nullptr; // stream of the last launch that used the block
+    bool scratch_used = false;
+    std::atomic<uint64_t> c_scratch{0}, c_sublaunches{0};
+    size_t scratch_cap = size_t(1536) << 20;     // 1.5 GiB
+    size_t sublaunch_pairs = size_t(1) << 28;
+
+    lh::PartTuning tune;                  // lh_set_option; never the environment in the product build
+    bool zero_copy_enabled = true;
+    uint32_t flips_since_small_off = 0;   // adaptive dispatch re-arms the single-pass path every 64 flips (epoch_mu)
+    bool small_forced_off = false;        // LH_OPT_SMALL_PATH = 0: never re-armed
 };
 
 struct lh_snapshot {
@@ -222,7 +237,7 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
         n--;
     }
     while (n) {
-        const size_t take = n < kMaxLaunch ? n : kMaxLaunch;
+        size_t take = n < kMaxLaunch ? n : kMaxLaunch;
         if (!e->small_disabled.load(std::memory_order_relaxed) &&
             lh::small_supported(take, e->cfg.max_metrics, d_ids, d_v)) {
             // a handful of names: every workgroup keeps all of them in LDS, one streaming pass
@@ -236,24 +251,41 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
             n -= take;
             continue;
         }
-        const size_t need = lh::part_aligned(d_ids, d_v) ? lh::part_scratch_bytes(take, e->cfg.max_metrics, e->num_cus) : 0;
-        if (need) {
-            // large launch over many names: partition by name, then reduce in LDS
-            std::lock_guard<std::mutex> g(e->scratch_mu);
-            lh_engine::Scratch &sc = e->scratch[s];
-            if (sc.bytes < need) {
-                if (sc.p) {
-                    HIPCHK(hipStreamSynchronize(s)); // earlier launches on this stream still read it
-                    HIPCHK(hipFree(sc.p));
-                    sc.p = nullptr;
-                    sc.bytes = 0;
-                }
-                HIPCHK(hipMalloc(&sc.p, need));
-                sc.bytes = need;
+        if (lh::part_aligned(d_ids, d_v) && lh::part_scratch_bytes(take, e->cfg.max_metrics, e->num_cus, e->tune)) {
+            // large launch over many names: partition by name, then reduce in LDS.  Sub-launches keep the scratch
+            // block bounded: at most `sublaunch_pairs` pairs each, halved until the block fits `scratch_cap`
+            // (power-of-two cuts keep both arrays on their vector alignment).
+            size_t sub = take < e->sublaunch_pairs ? take : e->sublaunch_pairs;
+            size_t need = lh::part_scratch_bytes(sub, e->cfg.max_metrics, e->num_cus, e->tune);
+            while (need > e->scratch_cap && sub > (size_t(1) << 22)) {
+                size_t half = size_t(1) << 22;
+                while (half * 2 < sub) half *= 2;
+                sub = half;
+                need = lh::part_scratch_bytes(sub, e->cfg.max_metrics, e->num_cus, e->tune);
             }
+            if (need == 0) return LH_EDEVICE; // cannot happen: sub >= 2^22 >= the partitioned path's minimum
+            take = sub;
+            std::lock_guard<std::mutex> g(e->scratch_mu);
+            if (e->scratch_bytes < need) {
+                if (e->scratch_p) {
+                    if (e->scratch_used) HIPCHK(hipEventSynchronize(e->scratch_done)); // earlier launches still read it
+                    HIPCHK(hipFree(e->scratch_p));
+                    e->scratch_p = nullptr;
+                    e->scratch_bytes = 0;
+                    e->scratch_used = false;
+                }
+                HIPCHK(hipMalloc(&e->scratch_p, need));
+                e->scratch_bytes = need;
+                e->c_scratch.store(need, std::memory_order_relaxed);
+            }
+            if (e->scratch_used && e->scratch_stream != s) HIPCHK(hipStreamWaitEvent(s, e->scratch_done, 0));
             HIPCHK(lh::launch_ingest_pairs_part(d_ids, d_v, take, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx,
-                                                e->d_err, sc.p, sc.bytes, e->num_cus, s));
+                                                e->d_err, e->scratch_p, e->scratch_bytes, e->num_cus, e->tune, s));
+            HIPCHK(hipEventRecord(e->scratch_done, s));
+            e->scratch_stream = s;
+            e->scratch_used = true;
             e->c_part.fetch_add(take, std::memory_order_relaxed);
+            e->c_sublaunches.fetch_add(1, std::memory_order_relaxed);
         } else {
             HIPCHK(lh::launch_ingest_pairs(d_ids, d_v, take, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx,
                                            e->d_err, e->num_cus, s));
@@ -334,8 +366,8 @@ void free_engine(lh_engine *e)
         if (b.cleared) (void)hipEventDestroy(b.cleared);
     }
     for (hipEvent_t ev : e->flip_events) (void)hipEventDestroy(ev);
-    for (auto &kv : e->scratch)
-        if (kv.second.p) (void)hipFree(kv.second.p);
+    if (e->scratch_p) (void)hipFree(e->scratch_p);
+    if (e->scratch_done) (void)hipEventDestroy(e->scratch_done);
     if (e->d_Tx) (void)hipFree(e->d_Tx);
     if (e->d_D) (void)hipFree(e->d_D);
     if (e->d_err) (void)hipFree(e->d_err);
@@ -393,6 +425,7 @@ int create_impl(const lh_config *cfg_in, lh_engine *e)
 
     HIPCHK(hipStreamCreateWithFlags(&e->main_stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&e->xstream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&e->scratch_done, hipEventDisableTiming));
 
     HIPCHK(hipMalloc((void **)&e->d_Tx, sizeof(double) * LH_NTHRESH));
     HIPCHK(hipMalloc((void **)&e->d_D, sizeof(double) * LH_NKEYS));
@@ -481,6 +514,15 @@ int lh_create(const lh_config *cfg, lh_engine **out)
     lh_engine *e = new (std::nothrow) lh_engine();
     if (!e) return LH_ENOMEM;
     e->cfg = *cfg;
+#ifdef LH_TUNING
+    // tools/ builds only (-DLH_TUNING): the sweep scripts steer the dispatch through the environment
+    if (const char *v = getenv("LH_PART_NAMES")) e->tune.names_per_part = (uint32_t)std::max(1, atoi(v));
+    if (const char *v = getenv("LH_PART_TWO_LEVEL_ABOVE")) e->tune.two_level_above = (uint32_t)std::max(0, atoi(v));
+    if (const char *v = getenv("LH_PART_HOT")) e->tune.hot = atoi(v) != 0;
+    if (const char *v = getenv("LH_PART_HOT_MIN_TILES")) e->tune.hot_min_tiles = (uint32_t)std::max(1, atoi(v));
+    if (const char *v = getenv("LH_DEBUG_FLAGS")) e->tune.dbg = (uint32_t)atoi(v);
+    if (getenv("LH_NO_ZERO_COPY")) e->zero_copy_enabled = false;
+#endif
     int rc = create_impl(cfg, e);
     if (rc != LH_OK) {
         free_engine(e);
@@ -716,6 +758,15 @@ int lh_flip(lh_engine *e, lh_snapshot **out)
     e->bufs[(size_t)next].state = BUF_CURRENT;
     e->live_snapshots.fetch_add(1);
     e->c_flips.fetch_add(1, std::memory_order_relaxed);
+    // adaptive dispatch is not one-way: the few-name single-pass kernel gets another interval every 64 flips
+    // (its window-miss counter turns it off again if the stream is still too wide for it)
+    if (e->small_disabled.load(std::memory_order_relaxed) && !e->small_forced_off) {
+        if (++e->flips_since_small_off >= 64) {
+            e->flips_since_small_off = 0;
+            e->small_samples.store(0);
+            e->small_disabled.store(false);
+        }
+    }
     *out = s;
     return LH_OK;
 }
@@ -746,7 +797,7 @@ int lh_extract_rows(lh_snapshot *s, uint32_t first, size_t nmetrics, const doubl
     // Small results (the latency path: one or a few metrics) are written by the kernel straight into the pinned
     // host block through its device mapping: one launch + one sync, no separate copy.  Large ones go through
     // HBM and one DMA (fine-grained stores over PCIe would be slower than the copy engine).
-    const bool zero_copy = e->d_hxbuf != nullptr && L.total <= 32768 && !getenv("LH_NO_ZERO_COPY");
+    const bool zero_copy = e->d_hxbuf != nullptr && L.total <= 32768 && e->zero_copy_enabled;
     unsigned char *xb = zero_copy ? e->d_hxbuf : e->d_xbuf;
     lh::ExtractNotify nt;
     volatile uint32_t *flag = reinterpret_cast<volatile uint32_t *>(e->h_xbuf + L.total);
@@ -1336,7 +1387,62 @@ int lh_get_counters(lh_engine *e, lh_counters *out)
     out->window_misses = e->c_misses.load();
     out->small_path_disabled = e->small_disabled.load() ? 1u : 0u;
     out->reserved = 0;
+    out->scratch_bytes = e->c_scratch.load();
+    out->sublaunches = e->c_sublaunches.load();
     return LH_OK;
+}
+
+int lh_set_option(lh_engine *e, int option, uint64_t value)
+{
+    if (!e) return LH_EINVAL;
+    switch (option) {
+    case LH_OPT_TWO_LEVEL_ABOVE:
+        if (value > 256) return LH_EINVAL;
+        e->tune.two_level_above = (uint32_t)value;
+        return LH_OK;
+    case LH_OPT_HOT_MIN_TILES:
+        if (value < 1 || value > (1u << 20)) return LH_EINVAL;
+        e->tune.hot_min_tiles = (uint32_t)value;
+        return LH_OK;
+    case LH_OPT_HOT_WINDOWS:
+        if (value > 1) return LH_EINVAL;
+        e->tune.hot = value != 0;
+        return LH_OK;
+    case LH_OPT_NAMES_PER_PARTITION:
+        if (value < 1 || value > 64) return LH_EINVAL;
+        e->tune.names_per_part = (uint32_t)value;
+        return LH_OK;
+    case LH_OPT_EXTRACT_ZERO_COPY:
+        if (value > 1) return LH_EINVAL;
+        e->zero_copy_enabled = value != 0;
+        return LH_OK;
+    case LH_OPT_SCRATCH_CAP_BYTES: {
+        if (value < (uint64_t(64) << 20)) return LH_EINVAL;
+        std::lock_guard<std::mutex> g(e->scratch_mu);
+        e->scratch_cap = (size_t)value;
+        return LH_OK;
+    }
+    case LH_OPT_SUBLAUNCH_PAIRS: {
+        if (value < (uint64_t(1) << 22) || value > (uint64_t(1) << 30)) return LH_EINVAL;
+        size_t p2 = size_t(1) << 22;
+        while (p2 * 2 <= value) p2 *= 2;
+        std::lock_guard<std::mutex> g(e->scratch_mu);
+        e->sublaunch_pairs = p2;
+        return LH_OK;
+    }
+    case LH_OPT_SMALL_PATH:
+        if (value > 1) return LH_EINVAL;
+        e->small_disabled.store(value == 0);
+        e->small_forced_off = value == 0;
+        return LH_OK;
+#ifdef LH_TUNING
+    case 100: // timing ablations of the scatter kernels (results are wrong): tools/ builds only
+        e->tune.dbg = (uint32_t)value;
+        return LH_OK;
+#endif
+    default:
+        return LH_EINVAL;
+    }
 }
 
 int lh_compress_device(lh_engine *e, const double *d_v, int16_t *d_keys, size_t n, void *stream)

@@ -28,9 +28,19 @@ hipError_t launch_ingest_pairs(const uint32_t *d_ids, const double *d_v, size_t 
                                uint32_t *ranges, uint32_t nmetrics, const double *d_Tx, uint32_t *d_err,
                                int num_cus, hipStream_t s);
 
+// Dispatch settings of the partitioned mixed ingest (lh_set_option).  Every setting only chooses among
+// exact kernel paths; none of them is read from the environment in the product build.
+struct PartTuning {
+    uint32_t names_per_part = 4;    // names per LDS-reduce partition: 4 gives every name a 4 096-bin window in P2
+    uint32_t two_level_above = 32;  // second scatter level when a level-1 partition holds more names than this
+    uint32_t hot_min_tiles = 32;    // hot-name windows in P1 when every workgroup gets at least this many tiles
+    bool hot = true;                // hot-name windows allowed at all
+    uint32_t dbg = 0;               // -DLH_TUNING builds only: timing ablations (results are wrong); ignored otherwise
+};
+
 // Partitioned mixed ingest (lh_kernels_part.hip).  part_scratch_bytes returns 0 when the launch
 // should use the direct kernel instead (small n, one name, or too many names per partition).
-size_t part_scratch_bytes(size_t n, uint32_t nmetrics, int num_cus);
+size_t part_scratch_bytes(size_t n, uint32_t nmetrics, int num_cus, const PartTuning &tune);
 bool part_aligned(const uint32_t *d_ids, const double *d_v); // 8-B ids / 16-B values: vector loads
 
 // Few names (<= 32): single streaming pass with every name's window in LDS (lh_kernels_small.hip).
@@ -40,7 +50,8 @@ hipError_t launch_ingest_pairs_small(const uint32_t *d_ids, const double *d_v, s
                                      int num_cus, hipStream_t s);
 hipError_t launch_ingest_pairs_part(const uint32_t *d_ids, const double *d_v, size_t n, uint64_t *counts,
                                     uint32_t *ranges, uint32_t nmetrics, const double *d_Tx, uint32_t *d_err,
-                                    void *scratch, size_t scratch_bytes, int num_cus, hipStream_t s);
+                                    void *scratch, size_t scratch_bytes, int num_cus, const PartTuning &tune,
+                                    hipStream_t s);
 
 // K2: extract.  One workgroup per metric.
 // ExtractNotify (optional): when the outputs live in host-mapped memory the last workgroup to finish stores

@@ -34,7 +34,6 @@
 
 #include <algorithm>
 #include <atomic>
-#include <cstdlib>
 #include <type_traits>
 
 namespace lh {
@@ -53,6 +52,12 @@ constexpr int P1_TILE = P1_BLOCK * P1_SPT;
 #define LH_P1_WGS_PER_CU 3
 #endif
 constexpr uint32_t INVALID = 0xffffffffu;
+// timing ablations of the scatter kernels: a kernel argument in -DLH_TUNING builds, the constant 0 otherwise
+#ifdef LH_TUNING
+#define LH_DBG(arg) (arg)
+#else
+#define LH_DBG(arg) 0u
+#endif
 constexpr int P2_BLOCK = 1024;         // 16 waves: two workgroups (64 KiB windows each) fill a CU
 constexpr uint32_t P2_WINWORDS = 16384; // 64 KiB of uint32 windows per workgroup
 constexpr uint32_t SLOT_EXTRA = 1024;  // work slots beyond one per partition (measured: 512 is 25 % slower)
@@ -82,22 +87,19 @@ static uint32_t ilog2_ceil(uint32_t x)
 // nslots [1], pool_start [nq + extra + 1]   (extra = slots beyond one per partition)
 static size_t small_words(uint32_t nq, uint32_t extra) { return (size_t)3 * nq + 3 * (nq + extra) + 1 + (nq + extra + 1) + 16; }
 
-static bool make_plan(size_t n, uint32_t nmetrics, int num_cus, PartPlan &P)
+static bool make_plan(size_t n, uint32_t nmetrics, int num_cus, const PartTuning &tune, PartPlan &P)
 {
     if (n < PART_MIN_SAMPLES || n > (size_t(1) << 31) || nmetrics < 2) return false;
-    // names per partition: 4 gives every name a 4 096-bin LDS window in P2.  LH_PART_NAMES (tuning only)
-    // overrides it: fewer partitions mean longer contiguous runs in P1 but narrower windows in P2
-    // (measured at 1 024 names, profiles/r01c: 4 is the best overall).
-    static const uint32_t names_per_part =
-        getenv("LH_PART_NAMES") ? (uint32_t)std::max(1, atoi(getenv("LH_PART_NAMES"))) : 4u;
+    // names per partition: 4 gives every name a 4 096-bin LDS window in P2.  Fewer partitions mean longer
+    // contiguous runs in P1 but narrower windows in P2 (measured at 1 024 names, profiles/r01c: 4 is the best
+    // overall).
+    const uint32_t names_per_part = std::max(1u, tune.names_per_part);
     // Second level only when a level-1 partition holds more than 32 names (> 8 192 names in all).
     // Measured at 1e9 samples (profiles/r01j): 8 192 names one level 139 vs two levels 105 G samples/s (512-bin
     // windows plus the overflow table still catch most records, and the extra pass costs 8 B/sample);
-    // 12 288 names 85 vs 100; 16 384 names 73 vs 94; 65 536 names 27 vs 77.  LH_PART_TWO_LEVEL_ABOVE overrides
-    // the threshold, in names per level-1 partition (tests force the second level at small name counts with 0);
-    // read per call on purpose.
-    const char *thr_env = getenv("LH_PART_TWO_LEVEL_ABOVE");
-    const uint32_t two_level_above = thr_env ? (uint32_t)std::max(0, atoi(thr_env)) : 32u;
+    // 12 288 names 85 vs 100; 16 384 names 73 vs 94; 65 536 names 27 vs 77.  lh_set_option(LH_OPT_TWO_LEVEL_ABOVE)
+    // overrides the threshold, in names per level-1 partition (tests force the second level at small name counts).
+    const uint32_t two_level_above = tune.two_level_above;
     const uint32_t want_np = (nmetrics + names_per_part - 1) / names_per_part;
     P.log_np = std::min(8u, ilog2_ceil(want_np));
     P.np = 1u << P.log_np;
@@ -115,14 +117,10 @@ static bool make_plan(size_t n, uint32_t nmetrics, int num_cus, PartPlan &P)
     P.log_w = lw; // window = 2^log_w bins per name, mpp2 * window <= 16384
     const size_t ntiles = (n + P1_TILE - 1) / P1_TILE;
     // Hot-name windows inside P1 (k_scatter_samples<true>, +34 KiB of LDS: two workgroups per CU) when the launch
-    // is long enough (>= 32 tiles per workgroup) to amortise the per-workgroup selection of the hot names.
-    // LH_PART_HOT=0 turns it off (tuning).
-    static const bool hot_enabled = !(getenv("LH_PART_HOT") && atoi(getenv("LH_PART_HOT")) == 0);
-    // LH_PART_HOT_MIN_TILES (tests: exercise the hot path on small inputs) overrides the tiles-per-workgroup bar;
-    // read per call on purpose.
-    const char *mt_env = getenv("LH_PART_HOT_MIN_TILES");
-    const size_t min_tiles = mt_env ? (size_t)std::max(1, atoi(mt_env)) : 32;
-    P.hot = hot_enabled && ntiles >= (size_t)num_cus * 2 * min_tiles;
+    // is long enough (>= 32 tiles per workgroup) to amortise the per-workgroup selection of the hot names
+    // (lh_set_option(LH_OPT_HOT_MIN_TILES / LH_OPT_HOT_WINDOWS): tests exercise the path on small inputs).
+    const size_t min_tiles = std::max<size_t>(1, tune.hot_min_tiles);
+    P.hot = tune.hot && ntiles >= (size_t)num_cus * 2 * min_tiles;
     // ~44 KiB LDS per workgroup: three 512-thread workgroups per CU (two with the hot windows)
     size_t g1 = (size_t)num_cus * (P.hot ? 2 : LH_P1_WGS_PER_CU);
     // every workgroup strands up to NP partially filled chunks (1 MiB at NP = 256): give a workgroup
@@ -157,10 +155,10 @@ bool part_aligned(const uint32_t *d_ids, const double *d_v)
     return (((uintptr_t)d_v & 15) == 0) && (((uintptr_t)d_ids & 7) == 0);
 }
 
-size_t part_scratch_bytes(size_t n, uint32_t nmetrics, int num_cus)
+size_t part_scratch_bytes(size_t n, uint32_t nmetrics, int num_cus, const PartTuning &tune)
 {
     PartPlan P;
-    return make_plan(n, nmetrics, num_cus, P) ? P.total : 0;
+    return make_plan(n, nmetrics, num_cus, tune, P) ? P.total : 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -396,8 +394,9 @@ __global__ __launch_bounds__(P1_BLOCK, HOT ? 4 : 6) void k_scatter_samples(const
                                                                            uint32_t chunks_per_wg,
                                                                            uint64_t *__restrict__ counts,
                                                                            uint32_t *__restrict__ ranges,
-                                                                           uint32_t *__restrict__ err, uint32_t dbg)
+                                                                           uint32_t *__restrict__ err, uint32_t dbg_arg)
 {
+    const uint32_t dbg = LH_DBG(dbg_arg);
     __shared__ __attribute__((aligned(16))) ScatterLds L;
     extern __shared__ __attribute__((aligned(16))) unsigned char hot_smem[];
     HotLds &H = *reinterpret_cast<HotLds *>(hot_smem); // only touched when HOT
@@ -611,8 +610,9 @@ __global__ __launch_bounds__(P1_BLOCK, 6) void k_scatter_records(const uint32_t 
                                                                  const uint32_t *__restrict__ pool_start,
                                                                  uint32_t log_np, uint32_t log_ns,
                                                                  uint32_t *__restrict__ records,
-                                                                 uint32_t *__restrict__ cdesc, uint32_t dbg)
+                                                                 uint32_t *__restrict__ cdesc, uint32_t dbg_arg)
 {
+    const uint32_t dbg = LH_DBG(dbg_arg);
     __shared__ __attribute__((aligned(16))) ScatterLds L;
     const uint32_t slot = blockIdx.x;
     if (slot >= *in_nslots) return;
@@ -1027,10 +1027,11 @@ static hipError_t run_plan(const LevelPtrs &L, uint32_t nchunks, uint32_t nq, ui
 
 hipError_t launch_ingest_pairs_part(const uint32_t *d_ids, const double *d_v, size_t n, uint64_t *counts,
                                     uint32_t *ranges, uint32_t nmetrics, const double *d_Tx, uint32_t *d_err,
-                                    void *scratch, size_t scratch_bytes, int num_cus, hipStream_t s)
+                                    void *scratch, size_t scratch_bytes, int num_cus, const PartTuning &tune,
+                                    hipStream_t s)
 {
     PartPlan P;
-    if (!make_plan(n, nmetrics, num_cus, P) || scratch_bytes < P.total || !scratch) return hipErrorInvalidValue;
+    if (!make_plan(n, nmetrics, num_cus, tune, P) || scratch_bytes < P.total || !scratch) return hipErrorInvalidValue;
     if (!part_aligned(d_ids, d_v)) return hipErrorInvalidValue;
     static std::atomic<bool> attr_set{false}; // benign if two threads race: both set the same attributes
     if (!attr_set) {
@@ -1051,9 +1052,14 @@ hipError_t launch_ingest_pairs_part(const uint32_t *d_ids, const double *d_v, si
     unsigned char *base = static_cast<unsigned char *>(scratch);
     const LevelPtrs L1 = level_ptrs(base, P.off_rec1, P.off_cd1, P.off_sorted1, P.off_small1, P.np, P.extra1);
 
-    // LH_DEBUG_FLAGS (tuning only, never set by tests or bench): 1 = P1 skips its record stores,
-    // 2 = P1 skips compress, 4 = skip P2, 8 = 16-B store ablation.  Results are wrong with any bit set.
-    static const uint32_t dbg = getenv("LH_DEBUG_FLAGS") ? (uint32_t)atoi(getenv("LH_DEBUG_FLAGS")) : 0u;
+    // Ablation bits exist in -DLH_TUNING builds only (tools/): 1 = P1 skips its record stores, 2 = P1 skips
+    // compress, 4 = skip P2, 8 = 16-B store ablation.  Results are wrong with any bit set; the product build
+    // compiles them out (LH_DBG() is the constant 0) and never reads the environment.
+#ifdef LH_TUNING
+    const uint32_t dbg = tune.dbg;
+#else
+    const uint32_t dbg = 0;
+#endif
 
     hipError_t e = hipMemsetAsync(L1.cdesc, 0xff, (size_t)P.nchunks1 * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;

@@ -293,6 +293,10 @@ class Engine:
         N.check(N.lib().lh_get_counters(self._h, C.byref(c)), "lh_get_counters")
         return {k: int(getattr(c, k)) for k, _ in N.LhCounters._fields_ if k != "reserved"}
 
+    def set_option(self, option: int, value: int):
+        """Dispatch settings (lh_set_option): they choose among exact kernel paths, never a result."""
+        N.check(N.lib().lh_set_option(self._h, int(option), int(value)), "lh_set_option")
+
     def close(self):
         if self._h is not None and self._h.value:
             N.check(N.lib().lh_destroy(self._h), "lh_destroy")

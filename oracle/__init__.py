@@ -47,10 +47,13 @@ def lib():
         L.lho_compress.restype = C.c_int16; L.lho_compress.argtypes = [C.c_double]
         L.lho_decompress.restype = C.c_double; L.lho_decompress.argtypes = [C.c_int16]
         L.lho_kext.restype = C.c_int32; L.lho_kext.argtypes = [C.c_double]
+        L.lho_kext_many.restype = None; L.lho_kext_many.argtypes = [dp, C.c_size_t, C.POINTER(C.c_int32)]
         L.lho_compress_many.restype = None; L.lho_compress_many.argtypes = [dp, C.c_size_t, i16p]
         L.lho_histogram_dense.restype = None; L.lho_histogram_dense.argtypes = [dp, C.c_size_t, u64p]
         L.lho_histogram_pairs.restype = C.c_int
         L.lho_histogram_pairs.argtypes = [u32p, dp, C.c_size_t, u64p, C.c_uint32]
+        L.lho_histogram_pairs_mt.restype = C.c_int
+        L.lho_histogram_pairs_mt.argtypes = [u32p, dp, C.c_size_t, u64p, C.c_uint32, C.c_int]
         L.lho_thresholds.restype = None; L.lho_thresholds.argtypes = [dp, C.c_size_t]
         L.lho_check_monotone.restype = C.c_size_t; L.lho_check_monotone.argtypes = [dp, C.c_size_t, C.c_int]
         L.lho_decompress_table.restype = None; L.lho_decompress_table.argtypes = [dp]
@@ -98,6 +101,14 @@ def compress_many(v) -> np.ndarray:
     return out
 
 
+def kext_many(x) -> np.ndarray:
+    """floor(100*Log(x)+0.5) before the int16 wrap, for x >= 1 (-1 for NaN/Inf)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty(x.shape, dtype=np.int32)
+    lib().lho_kext_many(_dp(x), x.size, out.ctypes.data_as(C.POINTER(C.c_int32)))
+    return out
+
+
 def histogram_dense(v, counts: np.ndarray | None = None) -> np.ndarray:
     v = np.ascontiguousarray(v, dtype=np.float64)
     if counts is None:
@@ -113,6 +124,51 @@ def histogram_pairs(ids, v, nmetrics: int, counts: np.ndarray | None = None) -> 
     if counts is None:
         counts = np.zeros((nmetrics, NKEYS), dtype=np.uint64)
     rc = lib().lho_histogram_pairs(_u32p(ids), _dp(v), v.size, _u64p(counts), nmetrics)
+    if rc != 0:
+        raise ValueError("metric id out of range")
+    return counts
+
+
+def granted_cores() -> int:
+    """Cores this process may actually use: min(cpu_count, affinity mask, cgroup CPU quota)."""
+    import math
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]       # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(math.ceil(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())             # cgroup v1
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, int(math.ceil(q / p))))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def histogram_dense_mt(v, threads: int | None = None) -> np.ndarray:
+    """histogram_dense over `threads` slices (per-thread rows, summed): full-size parity checks."""
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    counts = np.zeros(NKEYS, dtype=np.uint64)
+    lib().lho_bench_dense(_dp(v), v.size, threads or granted_cores(), _u64p(counts))
+    return counts
+
+
+def histogram_pairs_mt(ids, v, nmetrics: int, threads: int | None = None, counts: np.ndarray | None = None):
+    """histogram_pairs over `threads` slices adding atomically into one matrix: full-size parity checks."""
+    ids = np.ascontiguousarray(ids, dtype=np.uint32)
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    assert ids.size == v.size
+    if counts is None:
+        counts = np.zeros((nmetrics, NKEYS), dtype=np.uint64)
+    rc = lib().lho_histogram_pairs_mt(_u32p(ids), _dp(v), v.size, _u64p(counts), nmetrics,
+                                      threads or granted_cores())
     if rc != 0:
         raise ValueError("metric id out of range")
     return counts

@@ -121,6 +121,31 @@ double lho_bench_dense_reps(const double *v, size_t n, int threads, int reps, ui
     return t1 - t0;
 }
 
+// Threaded mixed-stream fan-in for FULL-SIZE parity checks (1e9 pairs): the same arithmetic as
+// lho_histogram_pairs (lho_compress per sample, +1 per (name, key) cell, metrics.go:273-295), the stream cut
+// into `threads` slices that add into ONE shared matrix with relaxed atomic adds -- the reference's own
+// fan-in is an atomic add per sample (metrics.go:278), and integer sums commute, so the result is the
+// sequential one bit for bit.  Returns -1 if any id is >= nmetrics (that sample is skipped), else 0.
+int lho_histogram_pairs_mt(const uint32_t *ids, const double *v, size_t n, uint64_t *counts, uint32_t nmetrics,
+                           int threads)
+{
+    if (threads < 1) threads = 1;
+    std::atomic<int> bad{0};
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++) {
+        size_t lo = n * (size_t)t / (size_t)threads, hi = n * (size_t)(t + 1) / (size_t)threads;
+        th.emplace_back([&, lo, hi] {
+            for (size_t i = lo; i < hi; i++) {
+                if (ids[i] >= nmetrics) { bad.store(1, std::memory_order_relaxed); continue; }
+                const uint32_t bin = (uint16_t)lho_compress(v[i]) ^ 0x8000u;
+                __atomic_fetch_add(&counts[(size_t)ids[i] * LHO_NKEYS + bin], 1ull, __ATOMIC_RELAXED);
+            }
+        });
+    }
+    for (auto &x : th) x.join();
+    return bad.load() ? -1 : 0;
+}
+
 double lho_bench_dense(const double *v, size_t n, int threads, uint64_t *counts_out)
 {
     if (threads < 1) threads = 1;

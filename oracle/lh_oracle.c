@@ -170,6 +170,11 @@ int32_t lho_kext(double x)
     return (int32_t)t;
 }
 
+void lho_kext_many(const double *x, size_t n, int32_t *out)
+{
+    for (size_t i = 0; i < n; i++) out[i] = lho_kext(x[i]);
+}
+
 void lho_compress_many(const double *v, size_t n, int16_t *out)
 {
     for (size_t i = 0; i < n; i++) out[i] = lho_compress(v[i]);

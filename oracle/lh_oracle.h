@@ -61,6 +61,7 @@ double lho_decompress(int16_t c);
 int32_t lho_kext(double x);
 
 void lho_compress_many(const double *v, size_t n, int16_t *out);
+void lho_kext_many(const double *x, size_t n, int32_t *out);
 
 /* Dense fan-in: counts[bin] += 1 with bin = (uint16)key ^ 0x8000, so ascending
  * bin == ascending key.  metrics.go:273-295 (dense restatement of the map). */
@@ -68,6 +69,11 @@ void lho_histogram_dense(const double *v, size_t n, uint64_t *counts /*[65536]*/
 /* Mixed stream: counts[ids[i]*65536 + bin] += 1. ids must be < nmetrics. */
 int lho_histogram_pairs(const uint32_t *ids, const double *v, size_t n,
                         uint64_t *counts, uint32_t nmetrics);
+
+/* The same over `threads` slices of the stream adding atomically into ONE matrix (lh_cpu_baseline.cc):
+ * full-size (1e9-pair) parity checks.  Integer sums commute: bit-identical to lho_histogram_pairs. */
+int lho_histogram_pairs_mt(const uint32_t *ids, const double *v, size_t n, uint64_t *counts,
+                           uint32_t nmetrics, int threads);
 
 /* Threshold table in x = 1+|v| space: Tx[j] = smallest double x >= 1 with
  * lho_kext(x) >= j, for j = 0..n-1 (Tx[0] = 1.0; +Inf where unreachable).

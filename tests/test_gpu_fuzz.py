@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import oracle
+from loghisto_amd import _native as N
 
 pytestmark = pytest.mark.gpu
 PCTS = [0.0, .5, .99, 1.0]
@@ -45,9 +46,7 @@ def test_mixed_ingest_fuzz(native_lib, torch_cuda, case, monkeypatch):
     M = int(rng.choice([1, 2, 3, 16, 17, 40, 255, 256, 257, 1000, 2048, 2049, 5000, 8193, 20000, 65536]))
     n = int(rng.integers(200_000, 3_000_000))
     skew = float(rng.choice([0.0, 0.5, 1.0, 1.5]))
-    if case % 2:
-        monkeypatch.setenv("LH_PART_HOT_MIN_TILES", "1")
-        monkeypatch.setenv("LH_PART_TWO_LEVEL_ABOVE", str(int(rng.choice([0, 4, 32]))))
+    two_level_above = int(rng.choice([0, 4, 32]))
     w = np.arange(1, M + 1, dtype=np.float64) ** -skew
     perm = rng.permutation(M)
     ids = perm[rng.choice(M, size=n, p=w / w.sum())].astype(np.uint32)
@@ -61,6 +60,9 @@ def test_mixed_ingest_fuzz(native_lib, torch_cuda, case, monkeypatch):
     d_ids, d_v = _dev(torch_cuda, ids), _dev(torch_cuda, v)
     torch_cuda.cuda.synchronize()
     with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=2, lane_samples=1 << 18) as e:
+        if case % 2:
+            e.set_option(N.OPT_HOT_MIN_TILES, 1)
+            e.set_option(N.OPT_TWO_LEVEL_ABOVE, two_level_above)
         for a, b in zip(cuts[:-1], cuts[1:]):
             if rng.random() < 0.25 and b - a < 600_000:
                 e.submit_pairs(ids[a:b], v[a:b])

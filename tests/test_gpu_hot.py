@@ -1,7 +1,7 @@
 """Hot-name windows inside the partition scatter (k_scatter_samples<true>, lh_kernels_part.hip): samples of a
 workgroup's most frequent names are counted in LDS windows instead of becoming records.  Which names are hot
 is a per-workgroup heuristic (first tile, hashed heavy-hitter table above 2 048 names); the result must be
-bit-exact whatever it picks.  LH_PART_HOT_MIN_TILES=1 turns the path on for inputs of a few million samples
+bit-exact whatever it picks.  lh_set_option(LH_OPT_HOT_MIN_TILES, 1) turns the path on for inputs of a few million samples
 (the engine itself only uses it for launches of >= 67 M samples)."""
 import math
 
@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import oracle
+from loghisto_amd import _native as N
 
 pytestmark = pytest.mark.gpu
 PCTS = [0.0, .5, .9, .99, 1.0]
@@ -38,8 +39,6 @@ def _ids(rng, M, n, skew):
 ])
 def test_hot_windows_are_exact(native_lib, torch_cuda, M, n, kind, skew, monkeypatch):
     import loghisto_amd
-    monkeypatch.setenv("LH_PART_HOT_MIN_TILES", "1")
-    monkeypatch.setenv("LH_PART_HOT", "1")
     rng = np.random.default_rng(M * 7 + n)
     ids = _ids(rng, M, n, skew)
     if kind == "lognormal":
@@ -65,6 +64,8 @@ def test_hot_windows_are_exact(native_lib, torch_cuda, M, n, kind, skew, monkeyp
     sample = sorted({int(order[0]), int(order[1]), int(order[7]), int(order[15]), int(order[16]), int(order[40 % M]),
                      int(order[M // 2]), int(order[-1]), 0, M - 1})
     with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        e.set_option(N.OPT_HOT_MIN_TILES, 1)
+        e.set_option(N.OPT_HOT_WINDOWS, 1)
         for rep in range(2):                     # scratch, ranges and windows are reused across launches and epochs
             e.submit_pairs_device(_dev(torch_cuda, ids), _dev(torch_cuda, v))
             e.sync()
@@ -83,7 +84,6 @@ def test_hot_windows_are_exact(native_lib, torch_cuda, M, n, kind, skew, monkeyp
 
 def test_hot_windows_with_bad_ids_and_two_launches_per_epoch(native_lib, torch_cuda, monkeypatch):
     import loghisto_amd
-    monkeypatch.setenv("LH_PART_HOT_MIN_TILES", "1")
     rng = np.random.default_rng(99)
     M, n = 512, 2_400_000
     ids = _ids(rng, M, n, 1.0)
@@ -93,6 +93,7 @@ def test_hot_windows_with_bad_ids_and_two_launches_per_epoch(native_lib, torch_c
     keep = np.ones(n, dtype=bool)
     keep[[3, 1_000_000, n - 1]] = False
     with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        e.set_option(N.OPT_HOT_MIN_TILES, 1)
         e.submit_pairs_device(_dev(torch_cuda, ids), _dev(torch_cuda, v))      # two launches into one epoch:
         e.submit_pairs_device(_dev(torch_cuda, bad), _dev(torch_cuda, v))      # windows flush twice into the same rows
         with pytest.raises(loghisto_amd.LhError) as ei:

@@ -135,6 +135,24 @@ def test_compress_at_every_threshold_neighbourhood(engine, torch_cuda):
     assert np.array_equal(golog, want)
 
 
+def test_compress_equals_the_go_handoff_fixture(engine, torch_cuda):
+    """tests/golden/thresholds_x.bin is the file integration/compress_thresholds_test.go feeds to real Go: the
+    HIP path must give exactly the keys recorded there (both signs), through both device routes -- so a `go test`
+    PASS on that file pins the GPU, not just the oracle, to Go's compress at every threshold."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_thresholds as mt
+    v, keys, _ = mt.read()
+    assert v.size == 3 * oracle.KEXT_MAX
+    fast, golog = _compress_both_routes(engine, torch_cuda, v)
+    assert np.array_equal(fast, keys) and np.array_equal(golog, keys)
+    neg = (-keys.astype(np.int32)).astype(np.int16)                 # -1 * i in int16 arithmetic, metrics.go:319
+    nz = v != 0
+    fast, golog = _compress_both_routes(engine, torch_cuda, -v[nz])
+    assert np.array_equal(fast, neg[nz]) and np.array_equal(golog, neg[nz])
+
+
 @pytest.mark.parametrize("name", list(dists(4, 0)))
 def test_compress_random(engine, torch_cuda, name):
     v = dists(300_000, 5)[name]
@@ -386,11 +404,17 @@ def test_ingest_pairs_partitioned(la, torch_cuda, M, n, kind):
             got = snap.extract(PCTS, M)
             want = oracle.histogram_pairs(ids, v, M)
             assert int(got["count"].sum()) == n
+            # EVERY row, cell by cell (no sampled rows): the device-compacted CSR listing of
+            # all occupied cells against the oracle's matrix
+            off, keys, counts = snap.buckets_all(M)
+            dense = np.zeros((M, 65536), dtype=np.uint64)
+            rows = np.repeat(np.arange(M), np.diff(off.astype(np.int64)))
+            dense[rows, oracle.key_to_bin(keys)] = counts
+            assert np.array_equal(dense, want)
             for m in range(M):
                 wc = int(want[m].sum())
                 assert int(got["count"][m]) == wc, m
-                if wc and (m < 8 or m % 61 == 0 or m == M - 1):
-                    assert np.array_equal(snap.dense_row(m), want[m]), m
+                if wc:
                     check_stats(want[m], got, m)
     finally:
         e.close()

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import oracle
+from loghisto_amd import _native as N
 
 pytestmark = pytest.mark.gpu
 PCTS = [0.0, .5, .9, .99, 1.0]
@@ -29,7 +30,6 @@ def _dev(torch, a):
 def test_two_level_partitioned_ingest(native_lib, torch_cuda, M, n, kind, monkeypatch):
     import loghisto_amd
     # the engine only uses the second level above 8 192 names (it is slower below); force it for every case
-    monkeypatch.setenv("LH_PART_TWO_LEVEL_ABOVE", "0")
     rng = np.random.default_rng(M + n)
     w = 1.0 / np.arange(1, M + 1)
     ids = rng.choice(M, size=n, p=w / w.sum()).astype(np.uint32)
@@ -47,6 +47,7 @@ def test_two_level_partitioned_ingest(native_lib, torch_cuda, M, n, kind, monkey
         ids[5000:6000] = M - 256          # same sub-partition pattern, partition 0
     sample = sorted({0, 1, 2, 255, 256, 257, 1023, 1024, M // 2, M // 2 + 1, M - 257, M - 256, M - 2, M - 1} & set(range(M)))
     with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        e.set_option(N.OPT_TWO_LEVEL_ABOVE, 0)
         e.submit_pairs_device(_dev(torch_cuda, ids), _dev(torch_cuda, v))
         e.sync()
         c = e.counters()

@@ -8,6 +8,7 @@ import json
 import math
 import os
 import struct
+import sys
 
 import numpy as np
 import pytest
@@ -237,3 +238,41 @@ def test_format_f_is_go_percent_f():
     assert oracle.format_f(58.739891704145194) == "58.739892"
     assert oracle.format_f(2.4642914167480484e+07) == "24642914.167480"
     assert oracle.format_f(-657.5233632152207) == "-657.523363"
+
+
+def test_threaded_forms_equal_the_sequential_oracle():
+    """The full-size parity checks (tests/test_gpu_fullsize.py, bench.py) run the oracle on every host core;
+    the threaded forms must be the sequential restatement bit for bit."""
+    rng = np.random.default_rng(11)
+    n, M = 300_000, 37
+    ids = rng.integers(0, M, n).astype(np.uint32)
+    v = rng.lognormal(8, 2.0, n) * np.where(rng.random(n) < 0.2, -1.0, 1.0)
+    v[:50] = [np.nan, np.inf, -np.inf, 0.0, 2.0196e142] * 10
+    assert np.array_equal(oracle.histogram_pairs_mt(ids, v, M, threads=5), oracle.histogram_pairs(ids, v, M))
+    assert np.array_equal(oracle.histogram_dense_mt(v, threads=3), oracle.histogram_dense(v))
+    with pytest.raises(ValueError):
+        oracle.histogram_pairs_mt(np.array([M], dtype=np.uint32), np.array([1.0]), M, threads=2)
+
+
+def test_threshold_fixture_matches_the_oracle():
+    """tests/golden/thresholds_x.bin is what integration/compress_thresholds_test.go feeds to real Go
+    (`go test` in a checkout of the reference closes the compress pin).  The committed file must be exactly
+    what the oracle produces today: 3 neighbours of each of the 70 978 thresholds, with the oracle's keys."""
+    import zlib
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_thresholds as mt
+    v, keys, flags = mt.read()
+    assert v.size == 3 * oracle.KEXT_MAX
+    assert np.array_equal(oracle.compress_many(v), keys)
+    ext = oracle.kext_many(1.0 + v)
+    assert np.array_equal(flags, (ext > 32767).astype(np.uint16))
+    # each triple straddles its threshold: prev < j <= at <= next
+    j = np.arange(1, oracle.KEXT_MAX + 1)
+    assert (ext[0::3] < j).all() and (ext[1::3] >= j).all() and (ext[2::3] >= ext[1::3]).all()
+    # regenerating gives the same bytes (the generator is deterministic)
+    v2, k2, f2 = mt.build()
+    assert np.array_equal(v2.view(np.uint64), v.view(np.uint64)) and np.array_equal(k2, keys) and np.array_equal(f2, flags)
+    # the Go file carries the decompress checksum it compares against
+    crc = zlib.crc32(oracle.decompress_table().tobytes())
+    go = open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "integration", "compress_thresholds_test.go")).read()
+    assert f"uint32({crc})" in go
