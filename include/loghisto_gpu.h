@@ -166,10 +166,22 @@ int lh_snapshot_mark_dirty(lh_snapshot *s, uint32_t first_row, uint32_t nrows, u
  *          LH_MERGE_REDUCE_SCATTER: rank r ends with the merged rows of names
  *          [r*ceil(nrows/nranks), ...) and extracts those with lh_extract_rows
  *   first_owned / last_owned  receive the [first, last) rows holding merged data on this rank
- * Runs on the snapshot's stream; dirty ranges are merged too, so extract/clear stay exact. */
+ * Runs on the snapshot's stream; dirty ranges are merged first (one MIN all-reduce on (lo, ~hi)), then every
+ * row's own merged window travels, packed back to back; the window plan (prefix sums, block sizes) is computed
+ * on the device and only two totals come back to size the collective.  Extract/clear stay exact. */
 enum { LH_MERGE_ALLREDUCE = 0, LH_MERGE_REDUCE_SCATTER = 1 };
 int lh_snapshot_merge(lh_snapshot *s, void *comm, int nranks, int rank, int plan, uint32_t nrows,
                       uint32_t *first_owned, uint32_t *last_owned);
+/* What the last lh_snapshot_merge on this engine moved.  Every row travels with its OWN merged window
+ * [lo_r, hi_r] (packed back to back), so an outlier sample widens one row, never the matrix. */
+typedef struct lh_merge_info {
+    uint64_t packed_cells;   /* sum over rows of the merged window widths                       */
+    uint64_t send_bytes;     /* bytes handed to the collective (reduce-scatter: nranks x largest block) */
+    uint64_t recv_bytes;     /* bytes this rank ends up with                                     */
+    uint32_t widest_row;     /* widest merged window, in cells                                   */
+    uint32_t occupied_rows;  /* rows with at least one cell on some rank                         */
+} lh_merge_info;
+int lh_snapshot_merge_info(lh_snapshot *s, lh_merge_info *out);
 /* Path (or soname) of the RCCL shared object the communicator comes from; default "librccl.so".
  * Process-wide; call before the first lh_snapshot_merge. */
 int lh_set_rccl_library(const char *path);

@@ -38,6 +38,11 @@ OPT_TWO_LEVEL_ABOVE, OPT_HOT_MIN_TILES, OPT_HOT_WINDOWS, OPT_NAMES_PER_PARTITION
 OPT_EXTRACT_ZERO_COPY, OPT_SCRATCH_CAP_BYTES, OPT_SUBLAUNCH_PAIRS, OPT_SMALL_PATH = 5, 6, 7, 8
 
 
+class LhMergeInfo(C.Structure):
+    _fields_ = [("packed_cells", C.c_uint64), ("send_bytes", C.c_uint64), ("recv_bytes", C.c_uint64),
+                ("widest_row", C.c_uint32), ("occupied_rows", C.c_uint32)]
+
+
 class LhLineFormat(C.Structure):
     _fields_ = [("prefix", C.c_char_p), ("sep", C.c_char_p), ("suffix", C.c_char_p),
                 ("flags", C.c_uint32), ("reserved", C.c_uint32)]
@@ -84,6 +89,7 @@ SIGNATURES = {
     "lh_snapshot_ranges": (C.c_int, [_vp, C.POINTER(_vp)]),
     "lh_snapshot_mark_dirty": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "lh_snapshot_merge": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_uint32, _u32p, _u32p]),
+    "lh_snapshot_merge_info": (C.c_int, [_vp, C.POINTER(LhMergeInfo)]),
     "lh_set_rccl_library": (C.c_int, [C.c_char_p]),
     "lh_serialize": (C.c_int, [_vp, C.c_uint32, _sz, _dp, C.POINTER(C.c_char_p), _sz, C.POINTER(LhLineFormat),
                                C.c_uint32, _vp, _sz, C.POINTER(_sz)]),

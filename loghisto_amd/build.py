@@ -84,6 +84,19 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
+    # test infrastructure: in-process stand-in for librccl.so (tests/cpp/rccl_stub.cc) so that N ranks of the
+    # C-ABI merge can run on the one reachable GPU
+    stub_src = os.path.join(root, "tests", "cpp", "rccl_stub.cc")
+    if os.path.exists(stub_src):
+        out = os.path.join(bdir, "librccl_stub.so")
+        if force or _stale(out, [stub_src]):
+            rocm = os.path.dirname(os.path.dirname(os.path.realpath(hipcc)))
+            cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", "-Wall", "-D__HIP_PLATFORM_AMD__",
+                   "-I", os.path.join(rocm, "include"), stub_src, "-o", out, "-L", os.path.join(rocm, "lib"),
+                   "-lamdhip64"]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
     return LIB
 
 

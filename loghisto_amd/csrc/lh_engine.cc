@@ -145,6 +145,12 @@ struct lh_engine {
     size_t d_text_cap = 0;
     char *d_blob = nullptr;             // SER_BLOB_MAX bytes
 
+    // K4 (lh_snapshot_merge): plan arrays + pack buffer (xmu)
+    uint64_t *d_mplan = nullptr;
+    uint64_t *d_mbuf = nullptr;
+    size_t mbuf_bytes = 0;
+    lh_merge_info merge_info{};
+
     std::atomic<int> live_snapshots{0};
 
     // adaptive dispatch of mixed launches with few names: the single-pass kernel reports how many samples
@@ -378,6 +384,8 @@ void free_engine(lh_engine *e)
     if (e->d_life) (void)hipFree(e->d_life);
     if (e->d_text) (void)hipFree(e->d_text);
     if (e->d_blob) (void)hipFree(e->d_blob);
+    if (e->d_mplan) (void)hipFree(e->d_mplan);
+    if (e->d_mbuf) (void)hipFree(e->d_mbuf);
     if (e->main_stream) (void)hipStreamDestroy(e->main_stream);
     if (e->xstream) (void)hipStreamDestroy(e->xstream);
     delete e;
@@ -1030,7 +1038,7 @@ int lh_set_rccl_library(const char *path)
 int lh_snapshot_merge(lh_snapshot *s, void *comm, int nranks, int rank, int plan, uint32_t nrows,
                       uint32_t *first_owned, uint32_t *last_owned)
 {
-    if (!s || !comm || nranks < 1 || rank < 0 || rank >= nranks || nrows == 0) return LH_EINVAL;
+    if (!s || !comm || nranks < 1 || nranks > 1024 || rank < 0 || rank >= nranks || nrows == 0) return LH_EINVAL;
     if (plan != LH_MERGE_ALLREDUCE && plan != LH_MERGE_REDUCE_SCATTER) return LH_EINVAL;
     lh_engine *e = s->e;
     if (nrows > e->cfg.max_metrics) return LH_EINVAL;
@@ -1042,59 +1050,99 @@ int lh_snapshot_merge(lh_snapshot *s, void *comm, int nranks, int rank, int plan
     EpochBuffer &b = e->bufs[(size_t)s->buf];
     hipStream_t st = e->xstream;
     const uint32_t per = (nrows + (uint32_t)nranks - 1) / (uint32_t)nranks;
+    const bool rs = plan == LH_MERGE_REDUCE_SCATTER;
     uint32_t own_lo = 0, own_hi = nrows;
-    if (plan == LH_MERGE_REDUCE_SCATTER) {
+    if (rs) {
         own_lo = std::min<uint32_t>((uint32_t)rank * per, nrows);
         own_hi = std::min<uint32_t>(own_lo + per, nrows);
     }
     if (first_owned) *first_owned = own_lo;
     if (last_owned) *last_owned = own_hi;
+    e->merge_info = lh_merge_info{};
 
-    // 1. dirty ranges: min(lo), max(hi) over the ranks with ONE MIN all-reduce on (lo, ~hi)
+    // plan arrays: P[max_metrics + 1], bstart[1025], info[4] -- allocated once, never moved
+    const size_t M = e->cfg.max_metrics;
+    if (!e->d_mplan) HIPCHK(hipMalloc((void **)&e->d_mplan, (M + 1 + 1025 + 4) * sizeof(uint64_t)));
+    uint64_t *d_P = e->d_mplan, *d_bstart = d_P + M + 1, *d_info = d_bstart + 1025;
+
+    // 1. dirty ranges: min(lo), max(hi) over the ranks with ONE MIN all-reduce on (lo, ~hi), in place
     const size_t rbytes = (size_t)nrows * 2 * sizeof(uint32_t);
-    rc = ensure_xbuf(e, rbytes);
+    rc = ensure_xbuf(e, rbytes + 64);
     if (rc) return rc;
     uint32_t *d_tmp = reinterpret_cast<uint32_t *>(e->d_xbuf);
     HIPCHK(lh::launch_ranges_flip_hi(d_tmp, b.ranges, nrows, st));
     NCCLCHK(g_allreduce(d_tmp, d_tmp, (size_t)nrows * 2, kNcclUint32, kNcclMin, comm, st));
     HIPCHK(lh::launch_ranges_flip_hi(b.ranges, d_tmp, nrows, st)); // (lo, ~~hi) back in place
-    HIPCHK(hipMemcpyAsync(e->h_xbuf, b.ranges, rbytes, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    const uint32_t *hr = reinterpret_cast<const uint32_t *>(e->h_xbuf);
-    uint32_t wlo = LH_NKEYS, whi = 0;
-    for (uint32_t r = 0; r < nrows; r++) {
-        if (hr[2 * r] <= hr[2 * r + 1]) {
-            wlo = std::min(wlo, hr[2 * r]);
-            whi = std::max(whi, hr[2 * r + 1]);
-        }
-    }
-    if (wlo > whi) return LH_OK; // nothing anywhere (every rank computes the same window: no hang)
-    const uint32_t width = whi - wlo + 1;
 
-    // 2. the window of the bucket matrix
-    if (plan == LH_MERGE_ALLREDUCE) {
-        if (nrows == 1) { // contiguous in place
-            uint64_t *p = b.counts + wlo;
-            NCCLCHK(g_allreduce(p, p, width, kNcclUint64, kNcclSum, comm, st));
-            return LH_OK;
+    // 2. the window plan, on the device: every row keeps its OWN merged window [lo_r, hi_r]; the windows are
+    //    packed back to back (CSR).  The host only needs two totals to size the collective; the plan kernel
+    //    stores them straight into pinned memory and the host spins on a completion word (no copy, no stream
+    //    synchronisation unless the stream is still busy with the interval's ingest after 2 ms).
+    const uint32_t nblocks = rs ? (uint32_t)nranks : 1u;
+    const uint32_t plan_per = rs ? per : nrows;
+    uint64_t info[4] = {0, 0, 0, 0};
+    if (e->d_hxbuf) {
+        volatile uint32_t *flag = reinterpret_cast<volatile uint32_t *>(e->h_xbuf + 32);
+        if (++e->xseq == 0) e->xseq = 1;
+        *flag = 0;
+        HIPCHK(lh::launch_merge_plan(b.ranges, nrows, plan_per, nblocks, d_P, d_bstart,
+                                     reinterpret_cast<uint64_t *>(e->d_hxbuf),
+                                     reinterpret_cast<uint32_t *>(e->d_hxbuf + 32), e->xseq, st));
+        const auto t0 = std::chrono::steady_clock::now();
+        uint32_t spins = 0;
+        while (*flag != e->xseq) {
+            __builtin_ia32_pause();
+            if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+                HIPCHK(hipStreamSynchronize(st));
+                break;
+            }
         }
-        const size_t bytes = (size_t)nrows * width * sizeof(uint64_t);
-        rc = ensure_xbuf(e, bytes);
-        if (rc) return rc;
-        uint64_t *buf = reinterpret_cast<uint64_t *>(e->d_xbuf);
-        HIPCHK(lh::launch_pack_window(b.counts, buf, nrows, nrows, wlo, width, st));
-        NCCLCHK(g_allreduce(buf, buf, (size_t)nrows * width, kNcclUint64, kNcclSum, comm, st));
-        HIPCHK(lh::launch_unpack_window(b.counts, buf, 0, nrows, wlo, width, st));
+        std::atomic_thread_fence(std::memory_order_acquire);
+        std::memcpy(info, e->h_xbuf, sizeof(info));
+    } else {
+        HIPCHK(lh::launch_merge_plan(b.ranges, nrows, plan_per, nblocks, d_P, d_bstart, d_info, nullptr, 0, st));
+        HIPCHK(hipMemcpyAsync(e->h_xbuf, d_info, sizeof(info), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        std::memcpy(info, e->h_xbuf, sizeof(info));
+    }
+    const uint64_t total = info[0], bmax = info[1];
+    e->merge_info.packed_cells = total;
+    e->merge_info.widest_row = (uint32_t)info[2];
+    e->merge_info.occupied_rows = (uint32_t)info[3];
+    if (total == 0) return LH_OK; // nothing anywhere (every rank computes the same plan: no hang)
+
+    // 3. pack -> collective -> unpack.  The pack buffer is its own grow-only allocation.
+    const uint64_t send_elems = rs ? (uint64_t)nranks * bmax : total, recv_elems = rs ? bmax : 0;
+    const size_t need = (size_t)(send_elems + recv_elems) * sizeof(uint64_t);
+    if (need > e->mbuf_bytes) {
+        if (e->d_mbuf) (void)hipFree(e->d_mbuf);
+        e->d_mbuf = nullptr;
+        e->mbuf_bytes = 0;
+        const size_t cap = need + need / 8 + 4096;
+        HIPCHK(hipMalloc((void **)&e->d_mbuf, cap));
+        e->mbuf_bytes = cap;
+    }
+    uint64_t *send = e->d_mbuf, *recv = send + send_elems;
+    e->merge_info.send_bytes = send_elems * sizeof(uint64_t);
+    e->merge_info.recv_bytes = (rs ? recv_elems : total) * sizeof(uint64_t);
+    HIPCHK(lh::launch_pack_rows(b.counts, b.ranges, d_P, d_bstart, nrows, plan_per, nblocks, rs ? bmax : total, send,
+                                st));
+    if (!rs) {
+        NCCLCHK(g_allreduce(send, send, (size_t)total, kNcclUint64, kNcclSum, comm, st));
+        HIPCHK(lh::launch_unpack_rows(b.counts, b.ranges, d_P, d_bstart, 0, 0, nrows, send, st));
         return LH_OK;
     }
-    // reduce-scatter by contiguous name blocks, padded to nranks*per rows
-    const size_t send_elems = (size_t)nranks * per * width, recv_elems = (size_t)per * width;
-    rc = ensure_xbuf(e, (send_elems + recv_elems) * sizeof(uint64_t));
-    if (rc) return rc;
-    uint64_t *send = reinterpret_cast<uint64_t *>(e->d_xbuf), *recv = send + send_elems;
-    HIPCHK(lh::launch_pack_window(b.counts, send, nrows, (uint32_t)nranks * per, wlo, width, st));
-    NCCLCHK(g_reducescatter(send, recv, recv_elems, kNcclUint64, kNcclSum, comm, st));
-    HIPCHK(lh::launch_unpack_window(b.counts, recv, own_lo, own_hi - own_lo, wlo, width, st));
+    // reduce-scatter by contiguous name blocks, every block padded to the largest one
+    NCCLCHK(g_reducescatter(send, recv, (size_t)recv_elems, kNcclUint64, kNcclSum, comm, st));
+    HIPCHK(lh::launch_unpack_rows(b.counts, b.ranges, d_P, d_bstart, (uint32_t)rank, own_lo, own_hi - own_lo, recv, st));
+    return LH_OK;
+}
+
+int lh_snapshot_merge_info(lh_snapshot *s, lh_merge_info *out)
+{
+    if (!s || !out) return LH_EINVAL;
+    std::lock_guard<std::mutex> g(s->e->xmu);
+    *out = s->e->merge_info;
     return LH_OK;
 }
 

@@ -555,25 +555,128 @@ __global__ void k_ranges_flip_hi(uint32_t *__restrict__ dst, const uint32_t *__r
     if (i < nrows) { dst[2 * (size_t)i] = src[2 * (size_t)i]; dst[2 * (size_t)i + 1] = ~src[2 * (size_t)i + 1]; }
 }
 
-// window [wlo, wlo+width) of rows [0, nrows) <-> dense [prows][width] buffer (rows >= nrows are zero padding)
-__global__ void k_pack_window(const uint64_t *__restrict__ counts, uint64_t *__restrict__ buf, uint32_t nrows,
-                              uint32_t prows, uint32_t wlo, uint32_t width)
+// ---- per-row windows, packed CSR ---------------------------------------------------------------
+// After the range merge every rank holds the same [lo_r, hi_r] for every row r.  Only those cells
+// travel: row r contributes w_r = hi_r - lo_r + 1 cells (0 when empty), packed back to back.  A single
+// outlier sample therefore widens ONE row's window (at most 512 KiB), never the whole matrix
+// (one global window made a +1e140 sample cost tens of GiB).
+//
+// k_merge_plan (one workgroup): P[r] = exclusive prefix of the widths, bstart[k] = P[min(k*per, nrows)] for the
+// nblocks owner blocks of `per` rows each (all-reduce: one block).  info = {total cells, largest block, widest
+// row, occupied rows}; when host_flag is set it is stored system-scope for the host, which needs the counts
+// to size the collective.
+constexpr int MP_BLOCK = 1024;
+__global__ __launch_bounds__(MP_BLOCK) void k_merge_plan(const uint32_t *__restrict__ ranges, uint32_t nrows,
+                                                         uint32_t per, uint32_t nblocks,
+                                                         unsigned long long *__restrict__ P /*[nrows+1]*/,
+                                                         unsigned long long *__restrict__ bstart /*[nblocks+1]*/,
+                                                         unsigned long long *__restrict__ info /*[4]*/,
+                                                         uint32_t *__restrict__ host_flag, uint32_t seq)
 {
-    const size_t total = (size_t)prows * width;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const uint32_t r = (uint32_t)(i / width), c = (uint32_t)(i % width);
-        buf[i] = r < nrows ? counts[(size_t)r * LH_NKEYS + wlo + c] : 0ull;
+    __shared__ unsigned long long s_w[MP_BLOCK / 64];
+    __shared__ uint32_t s_maxw[MP_BLOCK / 64], s_occ[MP_BLOCK / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t R = (nrows + MP_BLOCK - 1) / MP_BLOCK;
+    const uint32_t r0 = tid * R, r1 = min(nrows, r0 + R);
+    unsigned long long mine = 0;
+    uint32_t maxw = 0, occ = 0;
+    for (uint32_t r = r0; r < r1; r++) {
+        const uint32_t lo = ranges[2 * (size_t)r], hi = ranges[2 * (size_t)r + 1];
+        const uint32_t w = lo <= hi ? hi - lo + 1 : 0u;
+        mine += w;
+        maxw = max(maxw, w);
+        occ += w != 0;
+    }
+    unsigned long long inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long y = shfl_up_u64(inc, d);
+        if ((int)lane >= d) inc += y;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        maxw = max(maxw, (uint32_t)__shfl_xor(maxw, d, 64));
+        occ += __shfl_xor(occ, d, 64);
+    }
+    if (lane == 63) s_w[wave] = inc;
+    if (lane == 0) { s_maxw[wave] = maxw; s_occ[wave] = occ; }
+    __syncthreads();
+    unsigned long long base = 0, total = 0;
+    uint32_t gmax = 0, gocc = 0;
+    for (uint32_t w = 0; w < MP_BLOCK / 64; w++) {
+        if (w < wave) base += s_w[w];
+        total += s_w[w];
+        gmax = max(gmax, s_maxw[w]);
+        gocc += s_occ[w];
+    }
+    unsigned long long run = base + inc - mine;
+    for (uint32_t r = r0; r < r1; r++) {
+        const uint32_t lo = ranges[2 * (size_t)r], hi = ranges[2 * (size_t)r + 1];
+        P[r] = run;
+        run += lo <= hi ? hi - lo + 1 : 0u;
+    }
+    if (tid == 0) P[nrows] = total;
+    __syncthreads(); // workgroup-scope release/acquire: P[] written above is read below by other threads
+    unsigned long long bmax = 0;
+    if (tid == 0) {
+        for (uint32_t k = 0; k <= nblocks; k++) {
+            const unsigned long long at = P[min((unsigned long long)k * per, (unsigned long long)nrows)];
+            bstart[k] = at;
+            if (k) bmax = max(bmax, at - bstart[k - 1]);
+        }
+        info[0] = total;
+        info[1] = bmax;
+        info[2] = gmax;
+        info[3] = gocc;
+        if (host_flag) {
+            __threadfence_system();
+            __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
-__global__ void k_unpack_window(uint64_t *__restrict__ counts, const uint64_t *__restrict__ buf, uint32_t first_row,
-                                uint32_t nrows_out, uint32_t wlo, uint32_t width)
+// Row r's window <-> buf[(r / per) * bstride + (P[r] - bstart[r / per]) ...].  One workgroup per row.
+__global__ __launch_bounds__(256) void k_pack_rows(const uint64_t *__restrict__ counts,
+                                                   const uint32_t *__restrict__ ranges,
+                                                   const unsigned long long *__restrict__ P,
+                                                   const unsigned long long *__restrict__ bstart, uint32_t per,
+                                                   unsigned long long bstride, uint64_t *__restrict__ buf)
 {
-    const size_t total = (size_t)nrows_out * width;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const uint32_t r = (uint32_t)(i / width), c = (uint32_t)(i % width);
-        counts[(size_t)(first_row + r) * LH_NKEYS + wlo + c] = buf[i];
-    }
+    const uint32_t r = blockIdx.x;
+    const uint32_t lo = ranges[2 * (size_t)r], hi = ranges[2 * (size_t)r + 1];
+    if (lo > hi) return;
+    const uint32_t k = r / per;
+    uint64_t *dst = buf + (size_t)k * bstride + (P[r] - bstart[k]);
+    const uint64_t *src = counts + (size_t)r * LH_NKEYS + lo;
+    for (uint32_t i = threadIdx.x; i <= hi - lo; i += 256) dst[i] = src[i];
+}
+
+// Zero the tail of every owner block of the send buffer (blocks are padded to the largest one).
+__global__ __launch_bounds__(256) void k_pack_pad(const unsigned long long *__restrict__ bstart, uint32_t nblocks,
+                                                  unsigned long long bstride, uint64_t *__restrict__ buf)
+{
+    const uint32_t k = blockIdx.y;
+    if (k >= nblocks) return;
+    const unsigned long long used = bstart[k + 1] - bstart[k];
+    uint64_t *dst = buf + (size_t)k * bstride;
+    for (unsigned long long i = used + (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < bstride;
+         i += (unsigned long long)gridDim.x * 256)
+        dst[i] = 0;
+}
+
+// buf holds block `kblock` (rows first_row .. first_row + nrows_out) packed from offset 0.
+__global__ __launch_bounds__(256) void k_unpack_rows(uint64_t *__restrict__ counts,
+                                                     const uint32_t *__restrict__ ranges,
+                                                     const unsigned long long *__restrict__ P,
+                                                     const unsigned long long *__restrict__ bstart, uint32_t kblock,
+                                                     uint32_t first_row, const uint64_t *__restrict__ buf)
+{
+    const uint32_t r = first_row + blockIdx.x;
+    const uint32_t lo = ranges[2 * (size_t)r], hi = ranges[2 * (size_t)r + 1];
+    if (lo > hi) return;
+    const uint64_t *src = buf + (P[r] - bstart[kblock]);
+    uint64_t *dst = counts + (size_t)r * LH_NKEYS + lo;
+    for (uint32_t i = threadIdx.x; i <= hi - lo; i += 256) dst[i] = src[i];
 }
 
 hipError_t launch_ranges_flip_hi(uint32_t *dst, const uint32_t *src, uint32_t nrows, hipStream_t s)
@@ -583,19 +686,38 @@ hipError_t launch_ranges_flip_hi(uint32_t *dst, const uint32_t *src, uint32_t nr
     return hipGetLastError();
 }
 
-hipError_t launch_pack_window(const uint64_t *counts, uint64_t *buf, uint32_t nrows, uint32_t prows, uint32_t wlo,
-                              uint32_t width, hipStream_t s)
+hipError_t launch_merge_plan(const uint32_t *ranges, uint32_t nrows, uint32_t per, uint32_t nblocks, uint64_t *P,
+                             uint64_t *bstart, uint64_t *info, uint32_t *host_flag, uint32_t seq, hipStream_t s)
 {
-    if (!prows || !width) return hipSuccess;
-    hipLaunchKernelGGL(k_pack_window, dim3(2048), dim3(256), 0, s, counts, buf, nrows, prows, wlo, width);
+    hipLaunchKernelGGL(k_merge_plan, dim3(1), dim3(MP_BLOCK), 0, s, ranges, nrows, per, nblocks,
+                       reinterpret_cast<unsigned long long *>(P), reinterpret_cast<unsigned long long *>(bstart),
+                       reinterpret_cast<unsigned long long *>(info), host_flag, seq);
     return hipGetLastError();
 }
 
-hipError_t launch_unpack_window(uint64_t *counts, const uint64_t *buf, uint32_t first_row, uint32_t nrows_out,
-                                uint32_t wlo, uint32_t width, hipStream_t s)
+hipError_t launch_pack_rows(const uint64_t *counts, const uint32_t *ranges, const uint64_t *P, const uint64_t *bstart,
+                            uint32_t nrows, uint32_t per, uint32_t nblocks, uint64_t bstride, uint64_t *buf,
+                            hipStream_t s)
 {
-    if (!nrows_out || !width) return hipSuccess;
-    hipLaunchKernelGGL(k_unpack_window, dim3(2048), dim3(256), 0, s, counts, buf, first_row, nrows_out, wlo, width);
+    if (!nrows) return hipSuccess;
+    hipLaunchKernelGGL(k_pack_rows, dim3(nrows), dim3(256), 0, s, counts, ranges,
+                       reinterpret_cast<const unsigned long long *>(P),
+                       reinterpret_cast<const unsigned long long *>(bstart), per, (unsigned long long)bstride, buf);
+    if (nblocks > 1)
+        hipLaunchKernelGGL(k_pack_pad, dim3(64, nblocks), dim3(256), 0, s,
+                           reinterpret_cast<const unsigned long long *>(bstart), nblocks, (unsigned long long)bstride,
+                           buf);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack_rows(uint64_t *counts, const uint32_t *ranges, const uint64_t *P, const uint64_t *bstart,
+                              uint32_t kblock, uint32_t first_row, uint32_t nrows_out, const uint64_t *buf,
+                              hipStream_t s)
+{
+    if (!nrows_out) return hipSuccess;
+    hipLaunchKernelGGL(k_unpack_rows, dim3(nrows_out), dim3(256), 0, s, counts, ranges,
+                       reinterpret_cast<const unsigned long long *>(P),
+                       reinterpret_cast<const unsigned long long *>(bstart), kblock, first_row, buf);
     return hipGetLastError();
 }
 

@@ -153,6 +153,12 @@ class Snapshot:
                 "lh_snapshot_merge")
         return int(first.value), int(last.value)
 
+    def merge_info(self) -> dict:
+        """What the last merge moved (lh_snapshot_merge_info)."""
+        mi = N.LhMergeInfo()
+        N.check(N.lib().lh_snapshot_merge_info(self._h, C.byref(mi)), "lh_snapshot_merge_info")
+        return {k: int(getattr(mi, k)) for k, _ in N.LhMergeInfo._fields_}
+
     def stream(self) -> int:
         p = C.c_void_p(0)
         N.check(N.lib().lh_snapshot_stream(self._h, C.byref(p)), "lh_snapshot_stream")

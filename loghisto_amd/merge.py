@@ -16,8 +16,9 @@ Two plans:
                       the all-reduce bytes per link.
 
 uint64 counts are reduced through an int64 view: two's-complement addition is the
-same bits.  Dirty ranges are merged with MIN/MAX so extract/clear still visit only
-occupied spans.  The functions take plain tensors so that the CPU tests can drive
+same bits.  Dirty ranges are merged with MIN/MAX first; then every row travels with its
+OWN merged window, packed back to back (plan_windows), so an outlier sample in one name
+widens that row only and extract/clear still visit only occupied spans.  The functions take plain tensors so that the CPU tests can drive
 them with oracle-built rows; `merge_snapshot` binds them to a live lh_snapshot.
 """
 from __future__ import annotations
@@ -48,55 +49,97 @@ def merge_ranges(ranges: torch.Tensor, group=None) -> torch.Tensor:
     return ranges
 
 
-def merge_rows(rows: torch.Tensor, ranges: Optional[torch.Tensor] = None, plan: str = "allreduce",
-               group=None, window: Optional[Tuple[int, int]] = None) -> Tuple[int, int]:
-    """Sum `rows` (int64[nrows, 65536]) across ranks, in place.
+def plan_windows(ranges: torch.Tensor, world: int, plan: str):
+    """The window plan of a merge, from the MERGED ranges (identical on every rank).
 
-    window=(lo, hi) restricts the exchange to bins [lo, hi] of every row (callers
-    obtain it from the merged ranges); None moves whole rows.  Returns the
-    [first, last) rows that hold fully merged data on this rank.
+    Every row keeps its own window [lo_r, hi_r]; the windows travel packed back to back, so one outlier
+    sample widens one row (at most 65 536 cells), never the whole matrix.  Returns a dict:
+      width[nrows]   cells of row r (0 when the row is empty everywhere)
+      P[nrows + 1]   exclusive prefix of the widths (P[nrows] = total cells)
+      per            rows per owner block (reduce-scatter: ceil(nrows / world); all-reduce: nrows)
+      bstart[nb + 1] P at the owner-block boundaries;  bmax = largest block, in cells
+    The same plan is computed on the device by k_merge_plan for the C-ABI front-end (lh_snapshot_merge).
     """
+    nrows = ranges.shape[0]
+    lo = ranges[:, 0].to(torch.int64)
+    hi = ranges[:, 1].to(torch.int64)
+    width = (hi - lo + 1).clamp_(min=0)
+    P = torch.zeros(nrows + 1, dtype=torch.int64, device=ranges.device)
+    torch.cumsum(width, 0, out=P[1:])
+    if plan == "reduce_scatter":
+        per, nb = (nrows + world - 1) // world, world
+    else:
+        per, nb = nrows, 1
+    edges = torch.clamp(torch.arange(nb + 1, device=ranges.device, dtype=torch.int64) * per, max=nrows)
+    bstart = P[edges]
+    bmax = int((bstart[1:] - bstart[:-1]).max().item()) if nb else 0
+    return dict(lo=lo, width=width, P=P, per=per, nblocks=nb, bstart=bstart, bmax=bmax, total=int(P[-1].item()))
+
+
+_buffers = {}
+
+
+def _buffer(device, n: int) -> torch.Tensor:
+    """Grow-only int64 staging buffer per device (no allocation per merge)."""
+    key = str(device)
+    buf = _buffers.get(key)
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(max(n, 1) + max(n, 1) // 8, dtype=torch.int64, device=device)
+        _buffers[key] = buf
+    return buf[:n]
+
+
+last_info = {}   # what the last merge_rows call on this process moved (tests, bench)
+
+
+def merge_rows(rows: torch.Tensor, ranges: Optional[torch.Tensor] = None, plan: str = "allreduce",
+               group=None) -> Tuple[int, int]:
+    """Sum `rows` (int64[nrows, 65536]) across ranks, in place, moving only each row's merged window.
+
+    ranges (int32[nrows, 2], merged in place) bounds the occupied span of every row; None moves whole rows.
+    Returns the [first, last) rows that hold fully merged data on this rank."""
     assert rows.dtype == torch.int64 and rows.dim() == 2 and rows.shape[1] == NKEYS
+    if plan not in ("allreduce", "reduce_scatter"):
+        raise ValueError(f"unknown plan {plan!r}")
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     nrows = rows.shape[0]
     if ranges is not None:
         merge_ranges(ranges, group)
+    else:
+        ranges = torch.tensor([[0, NKEYS - 1]], dtype=torch.int32, device=rows.device).repeat(nrows, 1)
+    own = (0, nrows) if plan == "allreduce" else owned_rows(nrows, rank, world)
+    last_info.clear()
     if world == 1:
         return 0, nrows
-    if window is None and ranges is not None:
-        lo = int(ranges[:, 0].min().item())
-        hi = int(ranges[:, 1].max().item())
-        if lo > hi:
-            return (0, nrows) if plan == "allreduce" else owned_rows(nrows, rank, world)
-        window = (lo, hi)
-    full = window is None or (window[0] == 0 and window[1] == NKEYS - 1)
+    W = plan_windows(ranges, world, plan)
+    total, bmax, per = W["total"], W["bmax"], W["per"]
+    last_info.update(packed_cells=total, widest_row=int(W["width"].max().item()) if nrows else 0)
+    if total == 0:
+        return own
+    # packed position q (0 .. total) -> (row, column)
+    row_of = torch.repeat_interleave(torch.arange(nrows, device=rows.device), W["width"], output_size=total)
+    q = torch.arange(total, device=rows.device)
+    flat = row_of * NKEYS + (q - W["P"][row_of] + W["lo"][row_of])
+    cells = rows.view(-1)
     if plan == "allreduce":
-        if full or nrows == 1:
-            view = rows if full else rows[:, window[0]: window[1] + 1]
-            buf = view if view.is_contiguous() else view.contiguous()
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-            if buf.data_ptr() != view.data_ptr():
-                view.copy_(buf)
-        else:
-            buf = rows[:, window[0]: window[1] + 1].contiguous()
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-            rows[:, window[0]: window[1] + 1] = buf
-        return 0, nrows
-    if plan == "reduce_scatter":
-        per = (nrows + world - 1) // world
-        w0, w1 = (0, NKEYS - 1) if window is None else window
-        width = w1 - w0 + 1
-        # pad to world*per rows so every rank contributes equal blocks
-        send = torch.zeros((world * per, width), dtype=torch.int64, device=rows.device)
-        send[:nrows] = rows[:, w0: w1 + 1]
-        recv = torch.empty((per, width), dtype=torch.int64, device=rows.device)
-        dist.reduce_scatter_tensor(recv, send, op=dist.ReduceOp.SUM, group=group)
-        first, last = owned_rows(nrows, rank, world)
-        if last > first:
-            rows[first:last, w0: w1 + 1] = recv[: last - first]
-        return first, last
-    raise ValueError(f"unknown plan {plan!r}")
+        buf = _buffer(rows.device, total)
+        torch.index_select(cells, 0, flat, out=buf)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        cells[flat] = buf
+        last_info.update(send_bytes=total * 8, recv_bytes=total * 8)
+        return own
+    # reduce-scatter by contiguous name blocks, every block padded to the largest one
+    both = _buffer(rows.device, (world + 1) * bmax)
+    send, recv = both[: world * bmax], both[world * bmax:]
+    send.zero_()
+    blk = row_of // per
+    send[blk * bmax + (q - W["bstart"][blk])] = cells[flat]
+    dist.reduce_scatter_tensor(recv, send, op=dist.ReduceOp.SUM, group=group)
+    mine = blk == rank
+    cells[flat[mine]] = recv[(q - W["bstart"][blk])[mine]]
+    last_info.update(send_bytes=world * bmax * 8, recv_bytes=bmax * 8)
+    return own
 
 
 class _DeviceArray:

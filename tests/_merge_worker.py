@@ -18,12 +18,20 @@ if ROOT not in sys.path:
 NKEYS = 65536
 
 
-def make_stream(n, nmetrics, seed=11):
+def make_stream(n, nmetrics, seed=11, outliers=False):
     rng = np.random.default_rng(seed)
     w = 1.0 / np.arange(1, nmetrics + 1)
     ids = rng.choice(nmetrics, size=n, p=w / w.sum()).astype(np.uint32)
     v = rng.lognormal(np.log(1e5) + 0.002 * ids, 1.0)
-    v[::97] *= -1.0   # signed keys too
+    if outliers:
+        # ONE +1e140 sample in one name and ONE negative sample in another used to widen the
+        # window of EVERY row (one global [wlo, whi]); with per-row windows they widen two rows only
+        v[n // 3] = 1e140
+        ids[n // 3] = 0
+        v[2 * n // 3] = -5e6
+        ids[2 * n // 3] = nmetrics - 1
+    else:
+        v[::97] *= -1.0   # signed keys too
     return ids, v
 
 
@@ -37,18 +45,19 @@ def rows_and_ranges(ids, v, nmetrics):
     return rows, ranges
 
 
-def run(rank, world, port, plan, nmetrics, n, out_dir):
+def run(rank, world, port, plan, nmetrics, n, out_dir, outliers=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from loghisto_amd import merge
-        ids, v = make_stream(n, nmetrics)
+        ids, v = make_stream(n, nmetrics, outliers=outliers)
         lo, hi = n * rank // world, n * (rank + 1) // world     # data-parallel slice of the stream
         rows, ranges = rows_and_ranges(ids[lo:hi], v[lo:hi], nmetrics)
         t_rows = torch.from_numpy(rows.view(np.int64))
         t_ranges = torch.from_numpy(ranges)
         first, last = merge.merge_rows(t_rows, t_ranges, plan=plan)
+        info = dict(merge.last_info)
         want_rows, want_ranges = rows_and_ranges(ids, v, nmetrics)
         assert np.array_equal(t_ranges.numpy(), want_ranges), "merged ranges"
         got = t_rows.numpy().view(np.uint64)
@@ -63,6 +72,11 @@ def run(rank, world, port, plan, nmetrics, n, out_dir):
         dist.all_reduce(cover)
         expect = world if plan == "allreduce" else 1
         assert bool((cover == expect).all())
-        open(os.path.join(out_dir, f"ok_{plan}_{rank}"), "w").write("ok")
+        # what travelled: the sum of the per-row merged windows, nothing else
+        wr = want_ranges.astype(np.int64)
+        cells = int(np.clip(wr[:, 1] - wr[:, 0] + 1, 0, None).sum())
+        assert info["packed_cells"] == cells, (info, cells)
+        import json
+        open(os.path.join(out_dir, f"ok_{plan}_{rank}"), "w").write(json.dumps(info))
     finally:
         dist.destroy_process_group()

@@ -1,0 +1,120 @@
+"""N ranks of lh_snapshot_merge on ONE GPU (run as a subprocess by tests/test_gpu_merge.py).
+
+N engines on device 0 play N ranks; every rank buckets ITS slice of a seeded stream for ALL names on the GPU,
+flips, and calls lh_snapshot_merge from its own thread with a communicator of tests/cpp/rccl_stub.cc (an
+in-process stand-in for RCCL that reduces the threads' device buffers).  Checked against the oracle run on the
+WHOLE stream: merged ranges, every cell of the rows a rank ends up owning, extract on the owned rows, the
+bytes that travelled (per-row windows: outliers widen two rows, not the matrix).
+
+usage: python tests/_stub_merge_driver.py NRANKS NROWS PLAN OUTLIERS(0/1)
+"""
+import ctypes as C
+import json
+import math
+import os
+import sys
+import threading
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    nranks, M, plan, outliers = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
+    import torch
+    import loghisto_amd
+    import oracle
+    from loghisto_amd import _native as N
+    from loghisto_amd import merge
+    stub_path = os.path.join(ROOT, "loghisto_amd", "build", "librccl_stub.so")
+    N.check(N.lib().lh_set_rccl_library(stub_path.encode()), "lh_set_rccl_library")
+    stub = C.CDLL(stub_path)
+    comms = (C.c_void_p * nranks)()
+    assert stub.stub_comm_create(nranks, comms) == 0
+
+    rng = np.random.default_rng(100 * nranks + M)
+    n = 400_000
+    w = 1.0 / np.arange(1, M + 1)
+    ids = rng.choice(M, size=n, p=w / w.sum()).astype(np.uint32)
+    v = rng.lognormal(math.log(1e5) + 0.002 * ids, 1.0)
+    if M > 4:
+        ids[ids == 3] = 2                                   # row 3 is empty on every rank
+    if outliers:
+        v[n // 3], ids[n // 3] = 1e140, 0                  # one +1e140 sample in name 0
+        v[2 * n // 3], ids[2 * n // 3] = -5e6, M - 1       # one negative sample in the last name
+    want = oracle.histogram_pairs(ids, v, M)
+    want_ranges = np.zeros((M, 2), dtype=np.int64)
+    for m in range(M):
+        nz = np.nonzero(want[m])[0]
+        want_ranges[m] = (nz[0], nz[-1]) if nz.size else (65536, 0)
+    cells = int(np.clip(want_ranges[:, 1] - want_ranges[:, 0] + 1, 0, None).sum())
+
+    engines = [loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16)
+               for _ in range(nranks)]
+    snaps = []
+    for r, e in enumerate(engines):
+        lo, hi = n * r // nranks, n * (r + 1) // nranks    # data-parallel slice, all names
+        if hi > lo:
+            e.submit_pairs(ids[lo:hi], v[lo:hi])
+        snaps.append(e.flip())
+    results, errors = [None] * nranks, []
+
+    def rank_main(r):
+        try:
+            results[r] = snaps[r].merge_rccl(comms[r], nranks, r, M, plan=plan)
+        except Exception as exc:  # noqa: BLE001
+            errors.append((r, repr(exc)))
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(nranks)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errors, errors
+    assert all(not t.is_alive() for t in th), "a rank never left the collective"
+
+    per = -(-M // nranks)
+    covered = []
+    infos = []
+    for r in range(nranks):
+        first, last = results[r]
+        if plan == "allreduce":
+            assert (first, last) == (0, M)
+        else:
+            assert (first, last) == (min(r * per, M), min((r + 1) * per, M)), (r, first, last)
+        covered.extend(range(first, last))
+        snap = snaps[r]
+        info = snap.merge_info()
+        infos.append(info)
+        assert info["packed_cells"] == cells, (info, cells)
+        assert info["occupied_rows"] == int((want_ranges[:, 0] <= want_ranges[:, 1]).sum())
+        # merged ranges: identical on every rank, for every row
+        torch.cuda.synchronize()
+        got_ranges = merge.snapshot_tensors(snap, M)[1].cpu().numpy().view(np.uint32)
+        assert np.array_equal(got_ranges.astype(np.int64), want_ranges), r
+        if last > first:
+            off, keys, counts = snap.buckets_all(last - first, first=first)
+            got = np.zeros((last - first, 65536), dtype=np.uint64)
+            rows = np.repeat(np.arange(last - first), np.diff(off.astype(np.int64)))
+            got[rows, oracle.key_to_bin(keys)] = counts
+            assert np.array_equal(got, want[first:last]), f"rank {r}: merged rows differ"
+            st = snap.extract([0.0, 0.5, 1.0], last - first, first=first)
+            for m in range(first, last):
+                ref = oracle.process_dense(want[m], [0.0, 0.5, 1.0])
+                assert int(st["count"][m - first]) == ref["count"], m
+                if ref["count"]:
+                    assert np.array_equal(st["pkeys"][m - first], ref["pkeys"]), m
+    expect = sorted(list(range(M)) * (nranks if plan == "allreduce" else 1))
+    assert sorted(covered) == expect
+    for s in snaps:
+        s.release()
+    for e in engines:
+        e.close()
+    stub.stub_comm_destroy(nranks, comms)
+    print(json.dumps({"ok": True, "nranks": nranks, "rows": M, "plan": plan, "outliers": outliers, **infos[0]}))
+
+
+if __name__ == "__main__":
+    main()

@@ -120,3 +120,31 @@ def test_native_rccl_merge_through_the_c_abi(native_lib, torch_cuda):
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+@pytest.mark.parametrize("nranks,nrows,plan,outliers", [
+    (2, 5, "allreduce", 0),
+    (2, 5, "reduce_scatter", 0),        # ragged: blocks of 3 + 2 rows, one row empty everywhere
+    (4, 37, "reduce_scatter", 1),       # 10 + 10 + 10 + 7 rows; outliers in the first and the last block
+    (8, 64, "reduce_scatter", 1),       # config 4's rank count
+    (8, 5, "reduce_scatter", 0),        # more ranks than rows: ranks 5..7 own nothing
+    (4, 64, "allreduce", 1),
+])
+def test_c_abi_merge_with_n_ranks_on_one_gpu(native_lib, torch_cuda, nranks, nrows, plan, outliers):
+    """lh_snapshot_merge beyond one rank.  N engines on the one reachable GPU play N ranks;
+    tests/cpp/rccl_stub.cc stands in for RCCL (thread rendezvous + host reduction with RCCL's reduce-scatter
+    placement).  Runs in a subprocess because the RCCL library of a process can be chosen only once."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "_stub_merge_driver.py"), str(nranks), str(nrows),
+                        plan, str(outliers)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout
+    import json
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["ok"]
+    if outliers:
+        # two rows are ~47 000 and ~17 000 cells wide; the others ~1 000: per-row windows keep the exchange small
+        assert res["widest_row"] > 20_000
+        assert res["packed_cells"] < 0.25 * nrows * res["widest_row"]
