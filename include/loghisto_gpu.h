@@ -245,6 +245,7 @@ typedef struct lh_counters {
     uint32_t reserved;
     uint64_t scratch_bytes;        /* HBM scratch of the partitioned mixed ingest (one block per engine)  */
     uint64_t sublaunches;          /* partitioned sub-launches (a large launch is cut so the scratch stays bounded) */
+    uint64_t samples_partitioned_v2; /* of samples_partitioned: through the survey + 2-byte-record path          */
 } lh_counters;
 int lh_get_counters(lh_engine *e, lh_counters *out);
 
@@ -261,6 +262,9 @@ int lh_get_counters(lh_engine *e, lh_counters *out);
  *   LH_OPT_SCRATCH_CAP_BYTES  upper bound of the mixed ingest's scratch block (default 1.5 GiB, >= 64 MiB)
  *   LH_OPT_SUBLAUNCH_PAIRS    largest partitioned sub-launch, 2^22 .. 2^30 pairs, rounded down to a power of two
  *                             (default 2^28)
+ *   LH_OPT_PART_V2            0 / 1: the survey + 2-byte-record generation of the partitioned path (default 1;
+ *                             used for 33 .. 8 192 names)
+ *   LH_OPT_PART_V2_MIN_PAIRS  smallest launch that takes it (default 2^24; >= 2^17: tests exercise it on small inputs)
  *   LH_OPT_SMALL_PATH         0 / 1: the single-pass kernel for <= 32 names (1 also re-arms it after adaptive
  *                             dispatch turned it off) */
 enum {
@@ -271,7 +275,9 @@ enum {
     LH_OPT_EXTRACT_ZERO_COPY = 5,
     LH_OPT_SCRATCH_CAP_BYTES = 6,
     LH_OPT_SUBLAUNCH_PAIRS = 7,
-    LH_OPT_SMALL_PATH = 8
+    LH_OPT_SMALL_PATH = 8,
+    LH_OPT_PART_V2 = 9,
+    LH_OPT_PART_V2_MIN_PAIRS = 10
 };
 int lh_set_option(lh_engine *e, int option, uint64_t value);
 

@@ -31,11 +31,13 @@ class LhCounters(C.Structure):
                                            "window_misses")] + [("small_path_disabled", C.c_uint32),
                                                                 ("reserved", C.c_uint32),
                                                                 ("scratch_bytes", C.c_uint64),
-                                                                ("sublaunches", C.c_uint64)]
+                                                                ("sublaunches", C.c_uint64),
+                                                                ("samples_partitioned_v2", C.c_uint64)]
 
 # lh_set_option keys (include/loghisto_gpu.h)
 OPT_TWO_LEVEL_ABOVE, OPT_HOT_MIN_TILES, OPT_HOT_WINDOWS, OPT_NAMES_PER_PARTITION = 1, 2, 3, 4
 OPT_EXTRACT_ZERO_COPY, OPT_SCRATCH_CAP_BYTES, OPT_SUBLAUNCH_PAIRS, OPT_SMALL_PATH = 5, 6, 7, 8
+OPT_PART_V2, OPT_PART_V2_MIN_PAIRS = 9, 10
 
 
 class LhMergeInfo(C.Structure):

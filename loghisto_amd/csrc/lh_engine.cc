@@ -172,7 +172,7 @@ struct lh_engine {
     hipEvent_t scratch_done = nullptr;
     hipStream_t scratch_stream = nullptr; // stream of the last launch that used the block
     bool scratch_used = false;
-    std::atomic<uint64_t> c_scratch{0}, c_sublaunches{0};
+    std::atomic<uint64_t> c_scratch{0}, c_sublaunches{0}, c_part2{0};
     size_t scratch_cap = size_t(1536) << 20;     // 1.5 GiB
     size_t sublaunch_pairs = size_t(1) << 28;
 
@@ -262,12 +262,19 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
             // block bounded: at most `sublaunch_pairs` pairs each, halved until the block fits `scratch_cap`
             // (power-of-two cuts keep both arrays on their vector alignment).
             size_t sub = take < e->sublaunch_pairs ? take : e->sublaunch_pairs;
-            size_t need = lh::part_scratch_bytes(sub, e->cfg.max_metrics, e->num_cus, e->tune);
+            // second generation (survey + 2-byte records) when the launch is large enough and has <= 8 192 names
+            auto scratch_need = [&](size_t m, bool *v2) {
+                size_t b = lh::part2_scratch_bytes(m, e->cfg.max_metrics, e->num_cus, e->tune);
+                *v2 = b != 0;
+                return b ? b : lh::part_scratch_bytes(m, e->cfg.max_metrics, e->num_cus, e->tune);
+            };
+            bool v2 = false;
+            size_t need = scratch_need(sub, &v2);
             while (need > e->scratch_cap && sub > (size_t(1) << 22)) {
                 size_t half = size_t(1) << 22;
                 while (half * 2 < sub) half *= 2;
                 sub = half;
-                need = lh::part_scratch_bytes(sub, e->cfg.max_metrics, e->num_cus, e->tune);
+                need = scratch_need(sub, &v2);
             }
             if (need == 0) return LH_EDEVICE; // cannot happen: sub >= 2^22 >= the partitioned path's minimum
             take = sub;
@@ -285,8 +292,16 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
                 e->c_scratch.store(need, std::memory_order_relaxed);
             }
             if (e->scratch_used && e->scratch_stream != s) HIPCHK(hipStreamWaitEvent(s, e->scratch_done, 0));
-            HIPCHK(lh::launch_ingest_pairs_part(d_ids, d_v, take, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx,
-                                                e->d_err, e->scratch_p, e->scratch_bytes, e->num_cus, e->tune, s));
+            if (v2) {
+                HIPCHK(lh::launch_ingest_pairs_part2(d_ids, d_v, take, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx,
+                                                     e->d_err, e->scratch_p, e->scratch_bytes, e->num_cus, e->tune,
+                                                     s));
+                e->c_part2.fetch_add(take, std::memory_order_relaxed);
+            } else {
+                HIPCHK(lh::launch_ingest_pairs_part(d_ids, d_v, take, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx,
+                                                    e->d_err, e->scratch_p, e->scratch_bytes, e->num_cus, e->tune,
+                                                    s));
+            }
             HIPCHK(hipEventRecord(e->scratch_done, s));
             e->scratch_stream = s;
             e->scratch_used = true;
@@ -1437,6 +1452,7 @@ int lh_get_counters(lh_engine *e, lh_counters *out)
     out->reserved = 0;
     out->scratch_bytes = e->c_scratch.load();
     out->sublaunches = e->c_sublaunches.load();
+    out->samples_partitioned_v2 = e->c_part2.load();
     return LH_OK;
 }
 
@@ -1478,6 +1494,14 @@ int lh_set_option(lh_engine *e, int option, uint64_t value)
         e->sublaunch_pairs = p2;
         return LH_OK;
     }
+    case LH_OPT_PART_V2:
+        if (value > 1) return LH_EINVAL;
+        e->tune.v2 = value != 0;
+        return LH_OK;
+    case LH_OPT_PART_V2_MIN_PAIRS:
+        if (value < (1u << 17) || value > (uint64_t(1) << 31)) return LH_EINVAL;
+        e->tune.v2_min_samples = (size_t)value;
+        return LH_OK;
     case LH_OPT_SMALL_PATH:
         if (value > 1) return LH_EINVAL;
         e->small_disabled.store(value == 0);

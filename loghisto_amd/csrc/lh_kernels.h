@@ -35,6 +35,8 @@ struct PartTuning {
     uint32_t two_level_above = 32;  // second scatter level when a level-1 partition holds more names than this
     uint32_t hot_min_tiles = 32;    // hot-name windows in P1 when every workgroup gets at least this many tiles
     bool hot = true;                // hot-name windows allowed at all
+    bool v2 = true;                 // survey + 2-byte-record path (lh_kernels_part2.h) for <= 8 192 names
+    size_t v2_min_samples = 0;      // 0 = default (2^24): smaller launches do not amortise the survey
     uint32_t dbg = 0;               // -DLH_TUNING builds only: timing ablations (results are wrong); ignored otherwise
 };
 
@@ -52,6 +54,14 @@ hipError_t launch_ingest_pairs_part(const uint32_t *d_ids, const double *d_v, si
                                     uint32_t *ranges, uint32_t nmetrics, const double *d_Tx, uint32_t *d_err,
                                     void *scratch, size_t scratch_bytes, int num_cus, const PartTuning &tune,
                                     hipStream_t s);
+
+// Second generation (lh_kernels_part2.h): one survey per launch, 2-byte records, line-granular copy-out.
+// part2_scratch_bytes returns 0 when the launch should take the first-generation path.
+size_t part2_scratch_bytes(size_t n, uint32_t nmetrics, int num_cus, const PartTuning &tune);
+hipError_t launch_ingest_pairs_part2(const uint32_t *d_ids, const double *d_v, size_t n, uint64_t *counts,
+                                     uint32_t *ranges, uint32_t nmetrics, const double *d_Tx, uint32_t *d_err,
+                                     void *scratch, size_t scratch_bytes, int num_cus, const PartTuning &tune,
+                                     hipStream_t s);
 
 // K2: extract.  One workgroup per metric.
 // ExtractNotify (optional): when the outputs live in host-mapped memory the last workgroup to finish stores

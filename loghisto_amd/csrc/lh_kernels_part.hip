@@ -1096,4 +1096,6 @@ hipError_t launch_ingest_pairs_part(const uint32_t *d_ids, const double *d_v, si
     return hipGetLastError();
 }
 
+#include "lh_kernels_part2.h"
+
 } // namespace lh

@@ -1,0 +1,735 @@
+// lh_kernels_part2.h -- second generation of the partitioned mixed (id, value) ingest, gfx950.
+// Included at the end of lh_kernels_part.hip (same translation unit: it reuses the plan kernels, the chunk
+// descriptor format and lh_bin_of).  Reference semantics are unchanged:
+// Histogram(name, v) = histogramCache[name][compress(v)] += 1 (metrics.go:273-295, 316-322).
+//
+// What round 1 measured on k_scatter_samples (profiles/r01n): 35 % of the HBM roofline,
+// 1.44x the algorithmic traffic, ~72 VALU per wave-sample, 40 % LDS bank conflicts; the cold path (rank atomic,
+// LDS sort, per-record copy-out with a 16-byte table read and a 4-byte store each) was the cost, and only 45 %
+// of a Zipf(1.0) stream avoided it.  This version changes four things:
+//
+//   1. ONE survey per launch instead of one per workgroup (k_survey_count / k_survey_plan, ~1 M sampled pairs
+//      spread over the whole launch): per-name count, mean, min and max bin.  It yields, for every name, a
+//      4 096-bin "cold" window origin, and for the most frequent names LDS "hot" windows whose WIDTH follows the
+//      name's measured spread -- as many names as fit the CU's LDS (one 1 024-thread workgroup per CU owns
+//      ~90 KiB of windows: ~96 names at 1 024 names instead of 16).
+//   2. 2-BYTE RECORDS.  A cold sample is stored as (name-in-partition << log_w | bin - window origin): 14 bits.
+//      The record IS the LDS index P2 adds to, so P2 is a load and one ds_add per record -- no window search,
+//      no overflow table, no bounds test.  Record traffic halves (cold samples cost 12 + 2 + 2 B instead of
+//      12 + 4 + 4).  Samples outside their name's cold window (rare: the window spans 41 e-folds) are counted
+//      exactly through a small LDS table and global atomics.
+//   3. LINE-GRANULAR COPY-OUT.  The tile's records are laid out in LDS line by line (64-byte lines of 32
+//      records, staged leftovers first), so the copy-out is one aligned 16-byte LDS read and one 16-byte global
+//      store per 8 records instead of four LDS operations and a 4-byte store per record.
+//   4. 8 192-sample tiles on 1 024 threads: half the barriers per sample.
+//
+// Everything stays exact whatever the survey estimates: windows only decide where a sample is counted.
+
+constexpr int V2_BLOCK = 1024;
+constexpr int V2_SPT = 8;
+constexpr int V2_TILE = V2_BLOCK * V2_SPT;             // 8 192 samples
+constexpr uint32_t LINE2 = 32;                         // records per line (64 B)
+constexpr uint32_t V2_MAXLINES = (V2_TILE + NPMAX * (LINE2 - 1)) / LINE2 + 1;
+constexpr uint32_t V2_SORTED = V2_MAXLINES * LINE2;    // records
+constexpr uint32_t V2_MAX_NAMES = 8192;
+constexpr uint32_t V2_MAX_SLOTS = 512;                 // hot names
+constexpr size_t V2_MIN_SAMPLES = size_t(1) << 24;
+constexpr uint32_t V2_LDS_TOTAL = 160 * 1024;
+constexpr uint32_t SV_GRID = 256;                      // survey workgroups (one 4 096-sample tile each)
+
+typedef uint16_t rec16_t;
+
+struct Scatter2Lds {
+    uint32_t cnt[NPMAX], sf[NPMAX], cfill[NPMAX], cbase[NPMAX]; // persistent per partition
+    pu2_t tA[NPMAX];         // this tile: {staged before | emitted << 8, sorted base (records)}
+    uint32_t lbase[NPMAX];   // first line of the partition in this tile's emission
+    uint32_t newsf[NPMAX];
+    uint32_t dA[NPMAX], dB[NPMAX], room[NPMAX]; // destination of emitted record u: u < room ? dA + u : dB + u
+    uint16_t owner[512];     // line -> partition
+    __attribute__((aligned(16))) rec16_t sorted[V2_SORTED];
+    __attribute__((aligned(16))) rec16_t stage[NPMAX * LINE2];
+    uint32_t ov_key[OV_SLOTS], ov_cnt[OV_SLOTS];
+    uint32_t pool_next, nlines;
+};
+static_assert(V2_MAXLINES <= 512, "owner table");
+
+// Per-name entry of the survey's plan, 8 bytes: cold origin | hot origin << 16, hot LDS base | hot width << 16.
+// A name without a hot window has width 0.
+struct NameEntry { uint32_t org; uint32_t hot; };
+
+// ---------------------------------------------------------------------------
+// Survey
+// ---------------------------------------------------------------------------
+// g_stat layout (zero-initialised): cnt[M] u32 | mninv[M] u32 (max of 65535 - bin) | mx[M] u32 | sum[M] u64
+__global__ __launch_bounds__(V2_BLOCK) void k_survey_count(const uint32_t *__restrict__ ids,
+                                                           const double *__restrict__ v, size_t n,
+                                                           uint32_t nmetrics, const double *__restrict__ Tx,
+                                                           uint32_t *__restrict__ g_cnt,
+                                                           uint32_t *__restrict__ g_mninv,
+                                                           uint32_t *__restrict__ g_mx,
+                                                           unsigned long long *__restrict__ g_sum)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sv_smem[];
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(sv_smem);
+    uint32_t *s_sum = s_cnt + nmetrics, *s_mninv = s_sum + nmetrics, *s_mx = s_mninv + nmetrics;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < 4 * nmetrics; i += V2_BLOCK) s_cnt[i] = 0;
+    __syncthreads();
+    // workgroup w reads the 4 096 samples (2 048 pairs) that start at pair w * stride: spread over the launch
+    const size_t npairs = n / 2; // an odd last sample is not surveyed
+    const size_t stride = npairs / gridDim.x;
+    const pd2_t *vp = reinterpret_cast<const pd2_t *>(v);
+    const pu2_t *ip = reinterpret_cast<const pu2_t *>(ids);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const size_t i = (size_t)blockIdx.x * stride + (size_t)j * V2_BLOCK + tid;
+        if (i < npairs && (size_t)j * V2_BLOCK + tid < (stride ? stride : npairs)) {
+            const pu2_t id2 = ip[i];
+            const pd2_t x2 = vp[i];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t id = h ? id2.y : id2.x;
+                if (id < nmetrics) {
+                    const uint32_t bin = lh_bin_of(h ? x2.y : x2.x, Tx);
+                    atomicAdd(&s_cnt[id], 1u);
+                    atomicAdd(&s_sum[id], bin);
+                    atomicMax(&s_mninv[id], 65535u - bin);
+                    atomicMax(&s_mx[id], bin);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t m = tid; m < nmetrics; m += V2_BLOCK) {
+        const uint32_t c = s_cnt[m];
+        if (c) {
+            atomicAdd(&g_cnt[m], c);
+            atomicAdd(&g_sum[m], (unsigned long long)s_sum[m]);
+            atomicMax(&g_mninv[m], s_mninv[m]);
+            atomicMax(&g_mx[m], s_mx[m]);
+        }
+    }
+}
+
+// sums of a and b over the workgroup, returned to every thread
+__device__ __forceinline__ void block_sum2(uint32_t a, uint32_t b, uint32_t *s_a, uint32_t *s_b, uint32_t &ta,
+                                           uint32_t &tb)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        a += __shfl_xor(a, d, 64);
+        b += __shfl_xor(b, d, 64);
+    }
+    __syncthreads(); // s_a / s_b reuse
+    if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    ta = 0;
+    tb = 0;
+#pragma unroll
+    for (int w = 0; w < V2_BLOCK / 64; w++) { ta += s_a[w]; tb += s_b[w]; }
+}
+
+// One workgroup.  Thread t owns names [t * E, (t + 1) * E), E = ceil(M / 1024) <= 8.
+// hdr: [0] hot names, [1] cells used, [2] surveyed samples, [3] surveyed samples of the hot names
+__global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__restrict__ g_cnt,
+                                                          const uint32_t *__restrict__ g_mninv,
+                                                          const uint32_t *__restrict__ g_mx,
+                                                          const unsigned long long *__restrict__ g_sum,
+                                                          uint32_t nmetrics, uint32_t log_w, uint32_t cells,
+                                                          NameEntry *__restrict__ nt, pu4_t *__restrict__ hs,
+                                                          uint32_t *__restrict__ hdr)
+{
+    __shared__ uint32_t s_a[V2_BLOCK / 64], s_b[V2_BLOCK / 64];
+    constexpr uint32_t EMAX = V2_MAX_NAMES / V2_BLOCK;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t E = (nmetrics + V2_BLOCK - 1) / V2_BLOCK;
+    const uint32_t m0 = tid * E;
+    const uint32_t W = 1u << log_w;
+    uint32_t cnt[EMAX], want[EMAX], mean[EMAX], corg[EMAX];
+    uint32_t mysum = 0;
+#pragma unroll
+    for (uint32_t e = 0; e < EMAX; e++) {
+        cnt[e] = 0;
+        want[e] = 0;
+        mean[e] = 32768u;
+        corg[e] = 32768u - W / 2;
+        const uint32_t m = m0 + e;
+        if (e < E && m < nmetrics) {
+            const uint32_t c = g_cnt[m];
+            cnt[e] = c;
+            mysum += c;
+            if (c) {
+                const uint32_t mn = 65535u - g_mninv[m], mx = g_mx[m];
+                mean[e] = (uint32_t)(g_sum[m] / c);
+                // cold window: centred on the sampled span when it fits, on the mean bin otherwise
+                const uint32_t centre = (mx - mn < W) ? (mn + mx + 1) >> 1 : mean[e];
+                uint32_t o = centre > W / 2 ? centre - W / 2 : 0u;
+                if (o > 65536u - W) o = 65536u - W;
+                corg[e] = o;
+                // hot window the name would like: 3/4 of the sampled span (the span of a few thousand samples of
+                // a bell-shaped bin distribution is ~ +-3.5 sigma; 3/4 of it keeps ~99 %), in steps of 64 bins
+                if (c >= 16) {
+                    uint32_t w = (((mx - mn + 1) * 3u / 4u) + 63u) & ~63u;
+                    want[e] = w < 64u ? 64u : w;
+                }
+            }
+        }
+    }
+    uint32_t total_cnt, dummy;
+    block_sum2(mysum, 0, s_a, s_b, total_cnt, dummy);
+
+    // c16 = the 16th largest count: the largest tau with #{cnt >= tau} >= 16 (bisection on tau)
+    uint32_t lo = 0, hi = 1u << 21; // #{cnt >= lo} >= 16 assumed (tau = 0 counts every name); #{cnt >= hi} < 16
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        uint32_t k = 0;
+#pragma unroll
+        for (uint32_t e = 0; e < EMAX; e++) k += (cnt[e] >= mid && cnt[e] != 0) || (mid == 0);
+        uint32_t n_ge;
+        block_sum2(k, 0, s_a, s_b, n_ge, dummy);
+        if (n_ge >= 16) lo = mid; else hi = mid;
+    }
+    const uint32_t c16 = lo;
+#pragma unroll
+    for (uint32_t e = 0; e < EMAX; e++) {
+        if (want[e]) {
+            const uint32_t cap = cnt[e] >= c16 ? 512u : 256u;
+            if (want[e] > cap) want[e] = cap;
+        }
+    }
+    // the smallest tau >= 16 such that the windows of every name with cnt >= tau fit `cells` and the slot table
+    uint32_t flo = 15, fhi = (1u << 21) + 1; // fhi selects nothing: feasible
+    if (cells < 64) flo = fhi - 1;           // no LDS for hot windows at all
+    while (fhi - flo > 1) {
+        const uint32_t mid = flo + (fhi - flo) / 2;
+        uint32_t sw = 0, sn = 0;
+#pragma unroll
+        for (uint32_t e = 0; e < EMAX; e++)
+            if (want[e] && cnt[e] >= mid) { sw += want[e]; sn++; }
+        uint32_t tw, tn;
+        block_sum2(sw, sn, s_a, s_b, tw, tn);
+        if (tw <= cells && tn <= V2_MAX_SLOTS) fhi = mid; else flo = mid;
+    }
+    const uint32_t tau = fhi;
+    uint32_t sw = 0, sn = 0, sc = 0;
+#pragma unroll
+    for (uint32_t e = 0; e < EMAX; e++)
+        if (want[e] && cnt[e] >= tau) { sw += want[e]; sn++; sc += cnt[e]; }
+    // exclusive scans of (cells, slots) in name order
+    uint32_t incw = sw, incn = sn;
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t yw = __shfl_up(incw, d, 64), yn = __shfl_up(incn, d, 64);
+        if ((int)lane >= d) { incw += yw; incn += yn; }
+    }
+    __syncthreads();
+    if (lane == 63) { s_a[wave] = incw; s_b[wave] = incn; }
+    __syncthreads();
+    uint32_t basew = 0, basen = 0, totw = 0, totn = 0;
+#pragma unroll
+    for (int w = 0; w < V2_BLOCK / 64; w++) {
+        if (w < (int)wave) { basew += s_a[w]; basen += s_b[w]; }
+        totw += s_a[w];
+        totn += s_b[w];
+    }
+    uint32_t cellpos = basew + incw - sw, slot = basen + incn - sn;
+    uint32_t hot_cnt_total, dummy2;
+    block_sum2(sc, 0, s_a, s_b, hot_cnt_total, dummy2);
+#pragma unroll
+    for (uint32_t e = 0; e < EMAX; e++) {
+        const uint32_t m = m0 + e;
+        if (e < E && m < nmetrics) {
+            NameEntry ne;
+            ne.org = corg[e];
+            ne.hot = 0;
+            if (want[e] && cnt[e] >= tau) {
+                const uint32_t w = want[e];
+                uint32_t o = mean[e] > w / 2 ? mean[e] - w / 2 : 0u;
+                if (o > 65536u - w) o = 65536u - w;
+                ne.org |= o << 16;
+                ne.hot = cellpos | (w << 16);
+                hs[slot] = (pu4_t){m, o | (w << 16), cellpos, 0u};
+                cellpos += w;
+                slot++;
+            }
+            nt[m] = ne;
+        }
+    }
+    if (tid == 0) {
+        hdr[0] = totn;
+        hdr[1] = totw;
+        hdr[2] = total_cnt;
+        hdr[3] = hot_cnt_total;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// P1 v2: compress + hot windows + 2-byte-record scatter
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void v2_global_add(uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
+                                              uint32_t m, uint32_t bin, uint64_t c)
+{
+    atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)m * LH_NKEYS + bin]), (unsigned long long)c);
+    uint32_t *r = ranges + 2 * (size_t)m;
+    if (bin < r[0]) atomicMin(&r[0], bin);
+    if (bin > r[1]) atomicMax(&r[1], bin);
+}
+
+__global__ __launch_bounds__(V2_BLOCK) void k_scatter2(const uint32_t *__restrict__ ids,
+                                                       const double *__restrict__ v, size_t n, uint32_t nmetrics,
+                                                       uint32_t log_np, uint32_t log_w,
+                                                       const double *__restrict__ Tx,
+                                                       const NameEntry *__restrict__ g_nt,
+                                                       const pu4_t *__restrict__ g_hs,
+                                                       const uint32_t *__restrict__ g_hdr, uint32_t cells,
+                                                       rec16_t *__restrict__ records, uint32_t *__restrict__ cdesc,
+                                                       uint32_t chunks_per_wg, uint64_t *__restrict__ counts,
+                                                       uint32_t *__restrict__ ranges, uint32_t *__restrict__ err,
+                                                       uint32_t dbg_arg)
+{
+    const uint32_t dbg = LH_DBG(dbg_arg);
+    __shared__ __attribute__((aligned(16))) Scatter2Lds L;
+    extern __shared__ __attribute__((aligned(16))) unsigned char v2_smem[];
+    NameEntry *nt = reinterpret_cast<NameEntry *>(v2_smem);                        // [nmetrics]
+    uint32_t *win = reinterpret_cast<uint32_t *>(v2_smem + (size_t)nmetrics * 8);  // [cells]
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t np = 1u << log_np, pmask = np - 1, W = 1u << log_w;
+    const uint32_t pool_base = blockIdx.x * chunks_per_wg;
+
+    for (uint32_t i = tid; i < nmetrics; i += V2_BLOCK) nt[i] = g_nt[i];
+    for (uint32_t i = tid; i < cells; i += V2_BLOCK) win[i] = 0;
+    if (tid < NPMAX) { L.cnt[tid] = 0; L.sf[tid] = 0; L.cfill[tid] = CHUNK; L.cbase[tid] = INVALID; }
+    ov_init(L.ov_key, L.ov_cnt, tid, V2_BLOCK);
+    if (tid == 0) L.pool_next = 0;
+    __syncthreads();
+
+    const size_t ntiles = (n + V2_TILE - 1) / V2_TILE;
+    const size_t npairs = (n + 1) / 2;
+    const pd2_t *vp = reinterpret_cast<const pd2_t *>(v);
+    const pu2_t *ip = reinterpret_cast<const pu2_t *>(ids);
+    constexpr int NPAIR = V2_SPT / 2;
+    pu2_t idv[NPAIR];
+    pd2_t val[NPAIR];
+    auto load_tile = [&](size_t tile) {
+        const size_t pbase = tile * (V2_TILE / 2);
+#pragma unroll
+        for (int j = 0; j < NPAIR; j++) {
+            const size_t i = pbase + (size_t)j * V2_BLOCK + tid;
+            if (tile < ntiles && i < npairs) {
+                // the last pair of an odd-length stream reads one element past n inside the same 16-byte
+                // granule; it is masked below
+                idv[j] = __builtin_nontemporal_load(ip + i);
+                val[j] = __builtin_nontemporal_load(vp + i);
+            } else {
+                idv[j] = (pu2_t){INVALID, INVALID};
+                val[j] = (pd2_t){0.0, 0.0};
+            }
+        }
+    };
+    load_tile(blockIdx.x);
+
+    for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const size_t pbase = tile * (V2_TILE / 2);
+        const bool full_tile = (tile + 1) * (size_t)V2_TILE <= n;
+        uint32_t pr[V2_SPT];  // partition | rank << 8, INVALID when the sample left no record
+        uint32_t rec[V2_SPT];
+        // ---- phase 1: classify
+        auto classify = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+            for (int j = 0; j < V2_SPT; j++) {
+                const uint32_t id = (j & 1) ? idv[j >> 1].y : idv[j >> 1].x;
+                const double x = (j & 1) ? val[j >> 1].y : val[j >> 1].x;
+                pr[j] = INVALID;
+                rec[j] = 0;
+                bool live = true; // load_tile pads pairs beyond the stream with id 0xffffffff: not an error
+                if (!FULL) live = 2 * (pbase + (size_t)(j >> 1) * V2_BLOCK + tid) + (j & 1) < n;
+                if (!live) continue;
+                if (id >= nmetrics) {
+                    atomicOr(err, 1u); // reported by lh_sync / lh_extract
+                    continue;
+                }
+                const NameEntry ne = nt[id];
+                const uint32_t bin = (dbg & 2u) ? (uint32_t)(__double2loint(x) & 0xffff) : lh_bin_of(x, Tx);
+                const uint32_t hrel = bin - (ne.org >> 16);
+                if (hrel < (ne.hot >> 16)) { // a hot name inside its window: counted right here
+                    atomicAdd(&win[(ne.hot & 0xffffu) + hrel], 1u);
+                    continue;
+                }
+                const uint32_t crel = bin - (ne.org & 0xffffu);
+                if (crel < W) {
+                    const uint32_t p = id & pmask;
+                    rec[j] = ((id >> log_np) << log_w) | crel;
+                    pr[j] = p | (atomicAdd(&L.cnt[p], 1u) << 8);
+                } else if (!ov_add(L.ov_key, L.ov_cnt, (id << 16) | bin, 1u)) {
+                    v2_global_add(counts, ranges, id, bin, 1); // outside the cold window and the table is full
+                }
+            }
+        };
+        if (full_tile) classify(std::true_type{});
+        else classify(std::false_type{});
+        __syncthreads();                                   // barrier A: counts complete
+        load_tile(tile + gridDim.x);                       // next tile's loads fly during phases 2-4
+
+        // ---- phase 2: per-partition bookkeeping (threads 0..255).  sf / cnt are only READ here (other scanning
+        // waves sum them too); their new values are installed after barrier B.
+        if (tid < NPMAX) {
+            const uint32_t p = tid;
+            const uint32_t c = L.cnt[p], sf0 = L.sf[p];
+            const uint32_t total = sf0 + c, nfull = total / LINE2, out = nfull * LINE2;
+            // exclusive scan of the line counts: own wave by shuffles, earlier waves by re-summing their inputs
+            uint32_t inc = nfull;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(inc, d, 64);
+                if ((int)lane >= d) inc += y;
+            }
+            uint32_t wbase = 0;
+            for (uint32_t w = 0; w < wave; w++) { // wave-uniform trip count
+                uint32_t x = (L.sf[w * 64 + lane] + L.cnt[w * 64 + lane]) / LINE2;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+                wbase += x;
+            }
+            const uint32_t lb = wbase + inc - nfull;
+            if (tid == NPMAX - 1) L.nlines = wbase + inc;
+            L.lbase[p] = lb;
+            L.tA[p] = (pu2_t){sf0 | (out << 8), lb * LINE2};
+            L.newsf[p] = total - out;
+            if (nfull) {
+                const uint32_t tag = p << CD_SHIFT;
+                const uint32_t cf = L.cfill[p], cb = L.cbase[p];
+                const uint32_t room = CHUNK - cf; // multiple of LINE2 (0 when there is no open chunk)
+                uint32_t first = 0;
+                if (out > room) {
+                    const uint32_t over = out - room;
+                    const uint32_t k = (over + CHUNK - 1) / CHUNK;
+                    first = pool_base + atomicAdd(&L.pool_next, k);   // k consecutive chunks
+                    if (cb != INVALID) cdesc[cb] = tag | CHUNK;        // the old chunk is now full
+                    for (uint32_t q = 0; q + 1 < k; q++) cdesc[first + q] = tag | CHUNK;
+                    L.cbase[p] = first + k - 1;
+                    L.cfill[p] = over - (k - 1) * CHUNK;
+                } else {
+                    L.cfill[p] = cf + out;
+                }
+                L.dA[p] = cb * CHUNK + cf;
+                L.dB[p] = first * CHUNK - room;
+                L.room[p] = room;
+                for (uint32_t i = 0; i < nfull; i++) L.owner[lb + i] = (uint16_t)p;
+                // the staged leftovers open the partition's first line: aligned 16-byte LDS copies
+                for (uint32_t q = 0; q * 8 < sf0; q++)
+                    *reinterpret_cast<pu4_t *>(&L.sorted[lb * LINE2 + q * 8]) =
+                        *reinterpret_cast<const pu4_t *>(&L.stage[p * LINE2 + q * 8]);
+            }
+        }
+        __syncthreads();                                   // barrier B: plan of the tile is visible
+
+        // ---- phase 3: place the records
+        if (tid < NPMAX) { L.sf[tid] = L.newsf[tid]; L.cnt[tid] = 0; }
+#pragma unroll
+        for (int j = 0; j < V2_SPT; j++) {
+            if (pr[j] != INVALID) {
+                const uint32_t p = pr[j] & 0xffu;
+                const pu2_t a = L.tA[p];
+                const uint32_t u = (a.x & 0xffu) + (pr[j] >> 8), out = a.x >> 8;
+                if (u < out) L.sorted[a.y + u] = (rec16_t)rec[j];
+                else L.stage[p * LINE2 + (u - out)] = (rec16_t)rec[j];
+            }
+        }
+        __syncthreads();                                   // barrier C: lines complete
+
+        // ---- phase 4: copy whole lines out, 16 bytes per lane
+        const uint32_t npieces = L.nlines * 4;
+        if (!(dbg & 1u)) {
+            for (uint32_t i = tid; i < npieces; i += V2_BLOCK) {
+                const uint32_t line = i >> 2, q = i & 3u;
+                const uint32_t p = L.owner[line];
+                const uint32_t u = (line - L.lbase[p]) * LINE2 + q * 8;
+                const pu4_t r4 = *reinterpret_cast<const pu4_t *>(&L.sorted[line * LINE2 + q * 8]);
+                const uint32_t dst = (u < L.room[p] ? L.dA[p] : L.dB[p]) + u;
+                *reinterpret_cast<pu4_t *>(records + dst) = r4;
+            }
+        }
+        // (the next tile's barrier A separates this copy-out from the next bookkeeping)
+    }
+
+    // ---- drain: staged remainders and the open chunks' descriptors
+    __syncthreads();
+    if (tid < NPMAX) {
+        const uint32_t p = tid, sf = L.sf[p];
+        L.dA[p] = INVALID;
+        if (sf) {
+            uint32_t cf = L.cfill[p], cb = L.cbase[p];
+            if (cf == CHUNK) { // no open chunk, or it is exactly full
+                if (cb != INVALID) cdesc[cb] = (p << CD_SHIFT) | CHUNK;
+                cb = pool_base + atomicAdd(&L.pool_next, 1u);
+                cf = 0;
+                L.cbase[p] = cb;
+            }
+            L.dA[p] = cb * CHUNK + cf;
+            L.cfill[p] = cf + sf;
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t p = tid >> 2, q = tid & 3u; // 1 024 threads = 256 partitions x 4 pieces
+        const uint32_t d = L.dA[p];
+        if (d != INVALID && q * 8 < L.sf[p])
+            *reinterpret_cast<pu4_t *>(records + d + q * 8) = *reinterpret_cast<const pu4_t *>(&L.stage[p * LINE2 + q * 8]);
+    }
+    if (tid < np && L.cbase[tid] != INVALID) cdesc[L.cbase[tid]] = (tid << CD_SHIFT) | L.cfill[tid];
+
+    // ---- flush the hot windows (one uint64 atomic per occupied bin) and the out-of-window table
+    const uint32_t nhot = g_hdr[0];
+    for (uint32_t s = wave; s < nhot; s += V2_BLOCK / 64) {
+        const pu4_t h = g_hs[s];
+        const uint32_t name = h.x, org = h.y & 0xffffu, width = h.y >> 16, base = h.z;
+        uint32_t mn = INVALID, mx = 0;
+        for (uint32_t i = lane; i < width; i += 64) {
+            const uint32_t c = win[base + i];
+            if (c) {
+                const uint32_t b = org + i;
+                atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)name * LH_NKEYS + b]),
+                          (unsigned long long)c);
+                mn = min(mn, b);
+                mx = max(mx, b);
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            mn = min(mn, (uint32_t)__shfl_xor(mn, d, 64));
+            mx = max(mx, (uint32_t)__shfl_xor(mx, d, 64));
+        }
+        if (lane == 0 && mn != INVALID) {
+            uint32_t *r = ranges + 2 * (size_t)name;
+            if (mn < r[0]) atomicMin(&r[0], mn);
+            if (mx > r[1]) atomicMax(&r[1], mx);
+        }
+    }
+    for (uint32_t i = tid; i < OV_SLOTS; i += V2_BLOCK)
+        if (L.ov_key[i] != OV_EMPTY) v2_global_add(counts, ranges, L.ov_key[i] >> 16, L.ov_key[i] & 0xffffu, L.ov_cnt[i]);
+}
+
+// ---------------------------------------------------------------------------
+// P2 v2: the record is the LDS index
+// ---------------------------------------------------------------------------
+constexpr size_t P2V2_LDS_BYTES = (P2_WINWORDS + 3 * PART_MAX_MPP) * sizeof(uint32_t) + 16;
+
+__global__ __launch_bounds__(P2_BLOCK, 8) void k_part_hist2(const rec16_t *__restrict__ records,
+                                                            const uint32_t *__restrict__ cdesc,
+                                                            const uint32_t *__restrict__ sorted,
+                                                            const uint32_t *__restrict__ part_start,
+                                                            const uint32_t *__restrict__ slots,
+                                                            const uint32_t *__restrict__ nslots, uint32_t log_np,
+                                                            uint32_t mpp, uint32_t log_w, uint32_t nmetrics,
+                                                            const NameEntry *__restrict__ g_nt,
+                                                            uint64_t *__restrict__ counts,
+                                                            uint32_t *__restrict__ ranges)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *h = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *s_org = h + P2_WINWORDS;
+    uint32_t *s_mn = s_org + PART_MAX_MPP;
+    uint32_t *s_mx = s_mn + PART_MAX_MPP;
+    const uint32_t slot = blockIdx.x;
+    if (slot >= *nslots) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t p = slots[3 * slot], first = slots[3 * slot + 1], cnt = slots[3 * slot + 2];
+    const uint32_t *list = sorted + part_start[p] + first;
+    const uint32_t W = 1u << log_w, words = mpp << log_w;
+    for (uint32_t i = tid; i < words; i += P2_BLOCK) h[i] = 0;
+    if (tid < mpp) {
+        const uint32_t m = (tid << log_np) | p;
+        s_org[tid] = m < nmetrics ? (g_nt[m].org & 0xffffu) : 0u;
+        s_mn[tid] = INVALID;
+        s_mx[tid] = 0;
+    }
+    __syncthreads();
+
+    // one chunk (1 024 records = 2 KiB) per wave per iteration: two 16-byte loads per lane, double-buffered
+    auto load_chunk = [&](uint32_t cidx, u4_t (&dst)[2]) {
+        const u4_t *src = reinterpret_cast<const u4_t *>(records + (size_t)cidx * CHUNK) + lane;
+        dst[0] = __builtin_nontemporal_load(src);
+        dst[1] = __builtin_nontemporal_load(src + 64);
+    };
+    auto reduce_chunk = [&](const u4_t (&r4)[2], uint32_t cn) {
+#pragma unroll
+        for (uint32_t q = 0; q < 2; q++) {
+            const uint32_t rr[4] = {r4[q].x, r4[q].y, r4[q].z, r4[q].w};
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const uint32_t at = q * 512 + lane * 8 + (uint32_t)t * 2; // record index of the low half
+                if (at < cn) atomicAdd(&h[rr[t] & 0x3fffu], 1u);
+                if (at + 1 < cn) atomicAdd(&h[(rr[t] >> 16) & 0x3fffu], 1u);
+            }
+        }
+    };
+    constexpr uint32_t WSTEP = P2_BLOCK / 64;
+    u4_t bufA[2], bufB[2];
+    uint32_t j = wave;
+    uint32_t cnA = 0, cnB = 0;
+    if (j < cnt) {
+        const uint32_t cid = __builtin_amdgcn_readfirstlane(list[j]);
+        cnA = __builtin_amdgcn_readfirstlane(cdesc[cid] & CD_MASK);
+        load_chunk(cid, bufA);
+    }
+    while (j < cnt) {
+        if (j + WSTEP < cnt) {
+            const uint32_t cid = __builtin_amdgcn_readfirstlane(list[j + WSTEP]);
+            cnB = __builtin_amdgcn_readfirstlane(cdesc[cid] & CD_MASK);
+            load_chunk(cid, bufB);
+        }
+        reduce_chunk(bufA, cnA);
+        j += WSTEP;
+        if (j >= cnt) break;
+        if (j + WSTEP < cnt) {
+            const uint32_t cid = __builtin_amdgcn_readfirstlane(list[j + WSTEP]);
+            cnA = __builtin_amdgcn_readfirstlane(cdesc[cid] & CD_MASK);
+            load_chunk(cid, bufA);
+        }
+        reduce_chunk(bufB, cnB);
+        j += WSTEP;
+    }
+    __syncthreads();
+
+    // flush: one uint64 atomic per occupied cell
+    for (uint32_t i = tid; i < words; i += P2_BLOCK) {
+        const uint32_t c = h[i];
+        if (c) {
+            const uint32_t l = i >> log_w, b = s_org[l] + (i & (W - 1));
+            atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)((l << log_np) | p) * LH_NKEYS + b]),
+                      (unsigned long long)c);
+            atomicMin(&s_mn[l], b);
+            atomicMax(&s_mx[l], b);
+        }
+    }
+    __syncthreads();
+    if (tid < mpp && s_mn[tid] != INVALID) {
+        uint32_t *r = ranges + 2 * (size_t)((tid << log_np) | p);
+        if (s_mn[tid] < r[0]) atomicMin(&r[0], s_mn[tid]);
+        if (s_mx[tid] > r[1]) atomicMax(&r[1], s_mx[tid]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// plan + launcher
+// ---------------------------------------------------------------------------
+struct Part2Plan {
+    uint32_t log_np, np, mpp, log_w, cells, g1, chunks_per_wg, nchunks;
+    size_t off_rec, off_cd, off_sorted, off_small, off_stat, off_nt, off_hs, off_hdr, total;
+};
+
+static bool make_plan2(size_t n, uint32_t nmetrics, int num_cus, const PartTuning &tune, Part2Plan &P)
+{
+    if (!tune.v2 || n < (tune.v2_min_samples ? tune.v2_min_samples : V2_MIN_SAMPLES) || n > (size_t(1) << 31)) return false;
+    if (nmetrics < 2 || nmetrics > V2_MAX_NAMES) return false;
+    const uint32_t names_per_part = 4;
+    const uint32_t want_np = (nmetrics + names_per_part - 1) / names_per_part;
+    P.log_np = std::min(8u, ilog2_ceil(want_np));
+    P.np = 1u << P.log_np;
+    P.mpp = (nmetrics + P.np - 1) >> P.log_np;
+    if (P.mpp > PART_MAX_MPP) return false;
+    uint32_t lw = 0;
+    while ((P.mpp << (lw + 1)) <= P2_WINWORDS) lw++;
+    P.log_w = lw; // cold window = 2^log_w bins per name; the record (local << log_w | offset) is < 16 384
+    // hot windows: whatever LDS is left beside the scatter structures and the per-name table
+    const size_t fixed = sizeof(Scatter2Lds) + (size_t)nmetrics * sizeof(NameEntry) + 256;
+    P.cells = fixed + 4096 <= V2_LDS_TOTAL ? (uint32_t)((V2_LDS_TOTAL - fixed) / 4) & ~63u : 0u;
+    if (!tune.hot) P.cells = 0;
+    const size_t ntiles = (n + V2_TILE - 1) / V2_TILE;
+    size_t g1 = (size_t)num_cus; // one 1 024-thread workgroup per CU (it owns the CU's LDS)
+    if (g1 > (ntiles + 3) / 4) g1 = (ntiles + 3) / 4;
+    if (g1 < 1) g1 = 1;
+    P.g1 = (uint32_t)g1;
+    const size_t tiles_per_wg = (ntiles + g1 - 1) / g1;
+    P.chunks_per_wg = (uint32_t)(tiles_per_wg * (V2_TILE / CHUNK) + P.np + 1);
+    P.nchunks = P.g1 * P.chunks_per_wg;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~size_t(255); return at; };
+    P.off_rec = take((size_t)P.nchunks * CHUNK * sizeof(rec16_t));
+    P.off_cd = take((size_t)P.nchunks * sizeof(uint32_t));
+    P.off_sorted = take((size_t)P.nchunks * sizeof(uint32_t));
+    P.off_small = take(small_words(P.np, SLOT_EXTRA) * sizeof(uint32_t));
+    P.off_stat = take((size_t)nmetrics * 20);
+    P.off_nt = take((size_t)nmetrics * sizeof(NameEntry));
+    P.off_hs = take((size_t)V2_MAX_SLOTS * sizeof(pu4_t));
+    P.off_hdr = take(64);
+    P.total = o;
+    return true;
+}
+
+size_t part2_scratch_bytes(size_t n, uint32_t nmetrics, int num_cus, const PartTuning &tune)
+{
+    Part2Plan P;
+    return make_plan2(n, nmetrics, num_cus, tune, P) ? P.total : 0;
+}
+
+hipError_t launch_ingest_pairs_part2(const uint32_t *d_ids, const double *d_v, size_t n, uint64_t *counts,
+                                     uint32_t *ranges, uint32_t nmetrics, const double *d_Tx, uint32_t *d_err,
+                                     void *scratch, size_t scratch_bytes, int num_cus, const PartTuning &tune,
+                                     hipStream_t s)
+{
+    Part2Plan P;
+    if (!make_plan2(n, nmetrics, num_cus, tune, P) || scratch_bytes < P.total || !scratch) return hipErrorInvalidValue;
+    if (!part_aligned(d_ids, d_v)) return hipErrorInvalidValue;
+    const size_t p1_dyn = (size_t)nmetrics * sizeof(NameEntry) + (size_t)P.cells * 4;
+    const size_t sv_dyn = (size_t)nmetrics * 16;
+    static std::atomic<bool> attr_set{false}; // benign if two threads race: both set the same attributes
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_part_hist2),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)P2V2_LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter2),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(V2_LDS_TOTAL - sizeof(Scatter2Lds)));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_survey_count),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(V2_MAX_NAMES * 16));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_plan_count),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NQMAX * sizeof(uint32_t)));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_plan_scatter),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NQMAX * sizeof(uint32_t)));
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+#ifdef LH_TUNING
+    const uint32_t dbg = tune.dbg;
+#else
+    const uint32_t dbg = 0;
+#endif
+    unsigned char *base = static_cast<unsigned char *>(scratch);
+    LevelPtrs L1 = level_ptrs(base, P.off_rec, P.off_cd, P.off_sorted, P.off_small, P.np, SLOT_EXTRA);
+    rec16_t *records = reinterpret_cast<rec16_t *>(base + P.off_rec);
+    uint32_t *g_cnt = reinterpret_cast<uint32_t *>(base + P.off_stat);
+    uint32_t *g_mninv = g_cnt + nmetrics, *g_mx = g_mninv + nmetrics;
+    unsigned long long *g_sum = reinterpret_cast<unsigned long long *>(g_mx + nmetrics + (nmetrics & 1u));
+    NameEntry *g_nt = reinterpret_cast<NameEntry *>(base + P.off_nt);
+    pu4_t *g_hs = reinterpret_cast<pu4_t *>(base + P.off_hs);
+    uint32_t *g_hdr = reinterpret_cast<uint32_t *>(base + P.off_hdr);
+
+    hipError_t e = hipMemsetAsync(L1.cdesc, 0xff, (size_t)P.nchunks * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(L1.pc, 0, small_words(P.np, SLOT_EXTRA) * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(g_cnt, 0, (size_t)nmetrics * 20 + 8, s);
+    if (e != hipSuccess) return e;
+    const size_t sv_tiles = (n / 2 + 2047) / 2048;
+    const unsigned sv_grid = (unsigned)std::min<size_t>(SV_GRID, std::max<size_t>(1, sv_tiles));
+    hipLaunchKernelGGL(k_survey_count, dim3(sv_grid), dim3(V2_BLOCK), sv_dyn, s, d_ids, d_v, n, nmetrics, d_Tx, g_cnt,
+                       g_mninv, g_mx, g_sum);
+    hipLaunchKernelGGL(k_survey_plan, dim3(1), dim3(V2_BLOCK), 0, s, g_cnt, g_mninv, g_mx, g_sum, nmetrics, P.log_w,
+                       P.cells, g_nt, g_hs, g_hdr);
+    hipLaunchKernelGGL(k_scatter2, dim3(P.g1), dim3(V2_BLOCK), p1_dyn, s, d_ids, d_v, n, nmetrics, P.log_np, P.log_w,
+                       d_Tx, g_nt, g_hs, g_hdr, P.cells, records, L1.cdesc, P.chunks_per_wg, counts, ranges, d_err,
+                       dbg);
+    e = run_plan(L1, P.nchunks, P.np, 0u, SLOT_EXTRA, s);
+    if (e != hipSuccess) return e;
+    if (!(dbg & 4u))
+        hipLaunchKernelGGL(k_part_hist2, dim3(P.np + SLOT_EXTRA), dim3(P2_BLOCK), P2V2_LDS_BYTES, s, records, L1.cdesc,
+                           L1.sorted, L1.part_start, L1.slots, L1.nslots, P.log_np, P.mpp, P.log_w, nmetrics, g_nt,
+                           counts, ranges);
+    return hipGetLastError();
+}

@@ -1,0 +1,161 @@
+"""Second generation of the partitioned mixed ingest (loghisto_amd/csrc/lh_kernels_part2.h): one survey per
+launch, hot windows sized from the measured spread, 2-byte records, line-granular copy-out.
+
+The survey only decides WHERE a sample is counted (hot LDS window, 2-byte record into a 4 096-bin cold window,
+or the exact out-of-window path); every cell must equal the oracle's whatever it estimates.  The engine takes
+this path for launches of >= 2^24 pairs over 33 .. 8 192 names; lh_set_option(LH_OPT_PART_V2_MIN_PAIRS) lowers
+the bar so that the cases below (a few million pairs, seconds of oracle time) run through it.  Every row of
+every case is compared, cell by cell."""
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+from loghisto_amd import _native as N
+
+pytestmark = pytest.mark.gpu
+PCTS = [0.0, .5, .9, .99, .999, 1.0]
+
+
+def _dev(torch, a):
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.uint32:
+        a = a.view(np.int32)
+    return torch.from_numpy(a).cuda()
+
+
+def _ids(rng, M, n, skew, permute=True):
+    w = np.arange(1, M + 1, dtype=np.float64) ** -skew
+    perm = rng.permutation(M) if permute else np.arange(M)
+    return perm[rng.choice(M, size=n, p=w / w.sum())].astype(np.uint32)
+
+
+def _values(rng, kind, ids, n):
+    if kind == "lognormal":
+        return rng.lognormal(math.log(1e5) + 2e-3 * ids, 1.0)
+    if kind == "constant":
+        return 1000.0 + (ids % 5)
+    if kind == "allsame":
+        return np.full(n, 123.0)
+    if kind == "signed":                         # two lobes of bins per name, the mean bin between them
+        return rng.normal(0, 1e4, n)
+    if kind == "loguniform":                     # 4 147 occupied buckets: ~1 % of the samples miss a 4 096-bin window
+        return 10.0 ** rng.uniform(-3, 18, n)
+    if kind == "huge":                           # spans the whole key space: most samples miss every window
+        return 10.0 ** rng.uniform(-6, 140, n) * np.where(rng.random(n) < 0.5, -1.0, 1.0)
+    if kind == "sigma25":
+        return rng.lognormal(math.log(1e5), 2.5, n)
+    if kind == "drift":                          # the distribution moves during the launch: windows go stale
+        return rng.lognormal(math.log(1e3) + 9.0 * np.arange(n) / n, 0.5)
+    assert kind == "edge"
+    v = rng.lognormal(math.log(1e5), 1.0, n)
+    hot = int(np.bincount(ids).argmax())
+    sel = np.nonzero(ids == hot)[0]
+    v[sel[:3000]] = 2.0196e142                   # key +32767 on a hot name
+    v[sel[3000:6000]] = -2.0196e142
+    v[sel[6000:6100]] = float("nan")
+    v[sel[6100:6200]] = float("inf")
+    v[sel[6200:6300]] = 0.0
+    v[sel[6300:6400]] = 3e142                    # beyond the int16 domain: amd64 wrap
+    return v
+
+
+def _check(snap, ids, v, M, got):
+    want = oracle.histogram_pairs_mt(ids, v, M)
+    off, keys, counts = snap.buckets_all(M)
+    dense = np.zeros((M, N.NKEYS), dtype=np.uint64)
+    rows = np.repeat(np.arange(M), np.diff(off.astype(np.int64)))
+    dense[rows, oracle.key_to_bin(keys)] = counts
+    bad = np.nonzero((dense != want).any(axis=1))[0]
+    assert bad.size == 0, f"rows {bad[:8]} differ ({bad.size} rows)"
+    assert np.array_equal(got["count"].astype(np.int64), want.sum(axis=1).astype(np.int64))
+    for m in np.nonzero(want.sum(axis=1))[0][:: max(1, M // 64)]:
+        ref = oracle.process_dense(want[m], PCTS)
+        assert np.array_equal(got["pvals"][m].view(np.uint64), ref["pvals"].view(np.uint64)), m
+        assert np.array_equal(got["pkeys"][m], ref["pkeys"]), m
+
+
+CASES = [
+    (1024, 3_000_001, "lognormal", 1.0),     # config 3's shape; odd length
+    (1024, 2_500_000, "lognormal", 0.0),     # no skew: (almost) nothing is hot, everything takes the record path
+    (1024, 2_000_000, "constant", 1.0),      # 64-bin hot windows, many hot names
+    (37, 2_200_000, "allsame", 1.0),         # just above the single-pass kernel's 32 names; one bin per name
+    (300, 2_200_000, "signed", 1.5),         # hot windows centred between two lobes: they catch nothing
+    (1000, 2_400_000, "loguniform", 1.0),    # cold-window misses: out-of-window table + global atomics
+    (200, 1_500_000, "huge", 1.0),
+    (2048, 2_600_000, "sigma25", 1.0),       # 8 names per partition: 2 048-bin cold windows
+    (5000, 3_000_000, "lognormal", 1.0),     # 20 names per partition: 512-bin cold windows
+    (8192, 3_100_001, "edge", 1.0),          # the largest name count of this path
+    (33, 1_000_000, "drift", 0.5),
+    (1024, 2_000_000, "edge", 1.0),
+]
+
+
+@pytest.mark.parametrize("M,n,kind,skew", CASES)
+def test_survey_path_is_exact(native_lib, torch_cuda, M, n, kind, skew):
+    import loghisto_amd
+    rng = np.random.default_rng(M * 13 + n)
+    ids = _ids(rng, M, n, skew)
+    v = _values(rng, kind, ids, n)
+    d_ids, d_v = _dev(torch_cuda, ids), _dev(torch_cuda, v)
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        e.set_option(N.OPT_PART_V2_MIN_PAIRS, 1 << 17)
+        for rep in range(2):                     # scratch, survey tables and ranges are reused across launches / epochs
+            e.submit_pairs_device(d_ids, d_v)
+            e.sync()
+            c = e.counters()
+            assert c["samples_partitioned_v2"] == n * (rep + 1), c
+            with e.flip() as snap:
+                got = snap.extract(PCTS, M)
+                _check(snap, ids, v, M, got)
+
+
+def test_survey_path_bad_ids_sublaunches_and_two_launches_per_epoch(native_lib, torch_cuda):
+    import loghisto_amd
+    rng = np.random.default_rng(77)
+    M, n = 512, 9_000_001
+    ids = _ids(rng, M, n, 1.0)
+    v = rng.lognormal(10, 1.2, n)
+    bad = ids.copy()
+    where = [3, 4_200_000, n - 1]
+    bad[where] = [M, 0xFFFFFFFF, M + 5]
+    keep = np.ones(n, dtype=bool)
+    keep[where] = False
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        e.set_option(N.OPT_PART_V2_MIN_PAIRS, 1 << 17)
+        e.set_option(N.OPT_SUBLAUNCH_PAIRS, 1 << 22)       # 3 sub-launches per call, each with its own survey
+        e.submit_pairs_device(_dev(torch_cuda, ids), _dev(torch_cuda, v))
+        e.submit_pairs_device(_dev(torch_cuda, bad), _dev(torch_cuda, v))
+        with pytest.raises(loghisto_amd.LhError) as ei:
+            e.sync()
+        assert ei.value.code == 6
+        assert e.counters()["sublaunches"] == 6 and e.counters()["samples_partitioned_v2"] == 2 * n
+        with e.flip() as snap:
+            try:
+                got = snap.extract(PCTS, M)
+            except loghisto_amd.LhError:
+                got = snap.extract(PCTS, M)
+            _check(snap, np.concatenate([ids, ids[keep]]), np.concatenate([v, v[keep]]), M, got)
+
+
+def test_old_and_new_generation_agree(native_lib, torch_cuda):
+    """The same stream through both generations of the partitioned path: identical cells."""
+    import loghisto_amd
+    rng = np.random.default_rng(5)
+    M, n = 700, 2_300_000
+    ids = _ids(rng, M, n, 1.0)
+    v = rng.lognormal(9, 1.5, n) * np.where(rng.random(n) < 0.1, -1.0, 1.0)
+    d_ids, d_v = _dev(torch_cuda, ids), _dev(torch_cuda, v)
+    out = []
+    for v2 in (0, 1):
+        with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+            e.set_option(N.OPT_PART_V2_MIN_PAIRS, 1 << 17)
+            e.set_option(N.OPT_PART_V2, v2)
+            e.submit_pairs_device(d_ids, d_v)
+            e.sync()
+            assert (e.counters()["samples_partitioned_v2"] == n) == bool(v2)
+            with e.flip() as snap:
+                out.append(snap.buckets_all(M))
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)

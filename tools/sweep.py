@@ -21,12 +21,17 @@ def main():
     ap.add_argument("--pairs", type=int, default=0, help="if >0: mixed stream over this many names, Zipf(1.0) ids")
     ap.add_argument("--dists", default="lognormal,constant,uniform,exponential,normal,loguniform,lognormal25")
     ap.add_argument("--ids", default="zipf", choices=["zipf", "uniform", "zipf0.5"], help="name distribution of --pairs")
+    ap.add_argument("--opt", action="append", default=[], help="lh_set_option as ID=VALUE (repeatable), e.g. 9=0 turns "
+                                                               "the survey + 2-byte-record path off")
     a = ap.parse_args()
     n = int(a.samples)
     torch.cuda.set_device(0)
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     eng = loghisto_amd.Engine(max_metrics=max(1, a.pairs), num_buffers=2, num_lanes=1, lane_samples=1 << 16)
+    for kv in a.opt:
+        k, val = kv.split("=")
+        eng.set_option(int(k), int(val))
     for kind in a.dists.split(","):
         data = bench.make_samples(n, kind, 7)
         ids = None
@@ -55,7 +60,8 @@ def main():
         print(json.dumps({"dist": kind, "names": a.pairs or 1, "ids": a.ids if a.pairs else None, "n": n, "avg_ms": avg, "min_ms": min(ms),
                           "Gsamples_per_s": n / avg / 1e6, "GBps": n * bps / avg / 1e6,
                           "frac_hbm_peak": n * bps / avg / 1e6 / 8000.0,
-                          "occupied_buckets": int(st["nbuckets"].sum())}), flush=True)
+                          "occupied_buckets": int(st["nbuckets"].sum()), "opts": a.opt,
+                          "v2_samples": eng.counters()["samples_partitioned_v2"]}), flush=True)
         del data
     eng.close()
 
