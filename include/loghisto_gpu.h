@@ -265,6 +265,8 @@ int lh_get_counters(lh_engine *e, lh_counters *out);
  *   LH_OPT_PART_V2            0 / 1: the survey + 2-byte-record generation of the partitioned path (default 1;
  *                             used for 33 .. 8 192 names)
  *   LH_OPT_PART_V2_MIN_PAIRS  smallest launch that takes it (default 2^24; >= 2^17: tests exercise it on small inputs)
+ *   LH_OPT_PART_V2_SHAPE      0: one 1 024-thread scatter workgroup per CU over <= 256 partitions; 1: two
+ *                             512-thread workgroups per CU over <= 128 partitions
  *   LH_OPT_SMALL_PATH         0 / 1: the single-pass kernel for <= 32 names (1 also re-arms it after adaptive
  *                             dispatch turned it off) */
 enum {
@@ -277,7 +279,8 @@ enum {
     LH_OPT_SUBLAUNCH_PAIRS = 7,
     LH_OPT_SMALL_PATH = 8,
     LH_OPT_PART_V2 = 9,
-    LH_OPT_PART_V2_MIN_PAIRS = 10
+    LH_OPT_PART_V2_MIN_PAIRS = 10,
+    LH_OPT_PART_V2_SHAPE = 11
 };
 int lh_set_option(lh_engine *e, int option, uint64_t value);
 

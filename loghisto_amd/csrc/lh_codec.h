@@ -146,4 +146,23 @@ __device__ __forceinline__ uint32_t lh_bin_of(double v, const double *__restrict
     return bin_from_kext(kext, v);
 }
 
+// The same index in two steps, for kernels that classify several samples in straight-line code: the fast
+// part is branch-free (kext from the hardware log2; NaN / Inf give 0 as in lh_bin_of) and reports whether the
+// sample lies inside the guard band of a threshold; only then (about 1 sample in 4 000) must the caller take
+// lh_bin_of's exact table compare.
+__device__ __forceinline__ uint32_t lh_bin_fast(double v, bool &uncertain)
+{
+    const double x = 1.0 + fabs(v);
+    const uint32_t hi = (uint32_t)__double2hiint(x), lo = (uint32_t)__double2loint(x);
+    const uint32_t eb = hi >> 20;
+    const int e = (int)eb - 1023;
+    const float m = __uint_as_float(0x3f800000u | ((hi & 0xfffffu) << 3) | (lo >> 29));
+    const float l2 = __builtin_amdgcn_logf(m);
+    const double uq = __builtin_fma((double)e + (double)l2, 69.314718055994530942 * 16384.0, 8192.0);
+    const int u = (int)uq;
+    const bool finite = eb < 0x7ffu;
+    uncertain = finite && ((((uint32_t)u + LH_GUARD_Q14) & 16383u) < 2u * LH_GUARD_Q14);
+    return bin_from_kext(finite ? (u >> 14) : 0, v);
+}
+
 } // namespace lh

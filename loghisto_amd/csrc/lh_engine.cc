@@ -242,6 +242,7 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
         d_v++;
         n--;
     }
+    bool surveyed = false; // the second-generation path surveys once per call, not once per sub-launch
     while (n) {
         size_t take = n < kMaxLaunch ? n : kMaxLaunch;
         if (!e->small_disabled.load(std::memory_order_relaxed) &&
@@ -293,9 +294,11 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
             }
             if (e->scratch_used && e->scratch_stream != s) HIPCHK(hipStreamWaitEvent(s, e->scratch_done, 0));
             if (v2) {
-                HIPCHK(lh::launch_ingest_pairs_part2(d_ids, d_v, take, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx,
-                                                     e->d_err, e->scratch_p, e->scratch_bytes, e->num_cus, e->tune,
-                                                     s));
+                // one survey per call: the first sub-launch samples everything that is left of the call (n pairs)
+                HIPCHK(lh::launch_ingest_pairs_part2(d_ids, d_v, take, surveyed ? 0 : n, b.counts, b.ranges,
+                                                     e->cfg.max_metrics, e->d_Tx, e->d_err, e->scratch_p,
+                                                     e->scratch_bytes, e->num_cus, e->tune, s));
+                surveyed = true;
                 e->c_part2.fetch_add(take, std::memory_order_relaxed);
             } else {
                 HIPCHK(lh::launch_ingest_pairs_part(d_ids, d_v, take, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx,
@@ -1497,6 +1500,10 @@ int lh_set_option(lh_engine *e, int option, uint64_t value)
     case LH_OPT_PART_V2:
         if (value > 1) return LH_EINVAL;
         e->tune.v2 = value != 0;
+        return LH_OK;
+    case LH_OPT_PART_V2_SHAPE:
+        if (value > 1) return LH_EINVAL;
+        e->tune.v2_shape = (uint32_t)value;
         return LH_OK;
     case LH_OPT_PART_V2_MIN_PAIRS:
         if (value < (1u << 17) || value > (uint64_t(1) << 31)) return LH_EINVAL;

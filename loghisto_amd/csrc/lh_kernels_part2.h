@@ -25,33 +25,43 @@
 //
 // Everything stays exact whatever the survey estimates: windows only decide where a sample is counted.
 
-constexpr int V2_BLOCK = 1024;
-constexpr int V2_SPT = 8;
-constexpr int V2_TILE = V2_BLOCK * V2_SPT;             // 8 192 samples
+constexpr int V2_BLOCK = 1024;                         // survey kernels
+constexpr int V2_SPT = 8;                              // samples per thread per tile
 constexpr uint32_t LINE2 = 32;                         // records per line (64 B)
-constexpr uint32_t V2_MAXLINES = (V2_TILE + NPMAX * (LINE2 - 1)) / LINE2 + 1;
-constexpr uint32_t V2_SORTED = V2_MAXLINES * LINE2;    // records
 constexpr uint32_t V2_MAX_NAMES = 8192;
 constexpr uint32_t V2_MAX_SLOTS = 512;                 // hot names
 constexpr size_t V2_MIN_SAMPLES = size_t(1) << 24;
 constexpr uint32_t V2_LDS_TOTAL = 160 * 1024;
 constexpr uint32_t SV_GRID = 256;                      // survey workgroups (one 4 096-sample tile each)
+constexpr uint32_t P2V2_WINWORDS = 32768;              // 128 KiB of uint32 windows per P2 workgroup
+constexpr uint32_t V2_MISSQ = 1024;                    // out-of-window samples a tile can queue (per parity)
+constexpr uint32_t P2V2_SLOT_EXTRA = 256;              // P2 work slots beyond one per partition
 
 typedef uint16_t rec16_t;
 
-struct Scatter2Lds {
-    uint32_t cnt[NPMAX], sf[NPMAX], cfill[NPMAX], cbase[NPMAX]; // persistent per partition
-    pu2_t tA[NPMAX];         // this tile: {staged before | emitted << 8, sorted base (records)}
-    uint32_t lbase[NPMAX];   // first line of the partition in this tile's emission
-    uint32_t newsf[NPMAX];
-    uint32_t dA[NPMAX], dB[NPMAX], room[NPMAX]; // destination of emitted record u: u < room ? dA + u : dB + u
-    uint16_t owner[512];     // line -> partition
-    __attribute__((aligned(16))) rec16_t sorted[V2_SORTED];
-    __attribute__((aligned(16))) rec16_t stage[NPMAX * LINE2];
+// Two shapes of the scatter pass (both exact; lh_set_option(LH_OPT_PART_V2_SHAPE) picks one):
+//   <1024, 256>  one 1 024-thread workgroup per CU, 8 192-sample tiles, up to 256 partitions (4 names each at
+//                1 024 names -> 8 192-bin cold windows); the workgroup owns all of the CU's LDS
+//   < 512, 128>  two 512-thread workgroups per CU, 4 096-sample tiles, up to 128 partitions (8 names each ->
+//                4 096-bin cold windows); fewer hot cells each, but the two workgroups' phases overlap
+template <int BLOCK, int NPT> struct Scatter2LdsT {
+    static constexpr int TILE = BLOCK * V2_SPT;
+    static constexpr uint32_t MAXLINES = (TILE + NPT * (LINE2 - 1)) / LINE2 + 1;
+    static constexpr uint32_t OWNERS = (MAXLINES + 7) & ~7u;
+    uint32_t cnt[NPT], sf[NPT], cfill[NPT], cbase[NPT]; // persistent per partition
+    pu2_t tA[NPT];           // this tile: {staged before | emitted << 8, sorted base (records)}
+    uint32_t lbase[NPT];     // first line of the partition in this tile's emission
+    uint32_t newsf[NPT];
+    uint32_t dA[NPT], dB[NPT], room[NPT]; // destination of emitted record u: u < room ? dA + u : dB + u
+    uint16_t owner[OWNERS];  // line -> partition
+    __attribute__((aligned(16))) rec16_t sorted[MAXLINES * LINE2];
+    __attribute__((aligned(16))) rec16_t stage[NPT * LINE2];
     uint32_t ov_key[OV_SLOTS], ov_cnt[OV_SLOTS];
+    uint32_t missq[2][V2_MISSQ]; // samples outside their cold window (name << 16 | bin), by tile parity
+    uint32_t missn[2];
+    uint32_t dummy[64];      // target of the LDS operations of samples that leave nothing (keeps phases 1/3 branch-free)
     uint32_t pool_next, nlines;
 };
-static_assert(V2_MAXLINES <= 512, "owner table");
 
 // Per-name entry of the survey's plan, 8 bytes: cold origin | hot origin << 16, hot LDS base | hot width << 16.
 // A name without a hot window has width 0.
@@ -178,22 +188,12 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__rest
     uint32_t total_cnt, dummy;
     block_sum2(mysum, 0, s_a, s_b, total_cnt, dummy);
 
-    // c16 = the 16th largest count: the largest tau with #{cnt >= tau} >= 16 (bisection on tau)
-    uint32_t lo = 0, hi = 1u << 21; // #{cnt >= lo} >= 16 assumed (tau = 0 counts every name); #{cnt >= hi} < 16
-    while (hi - lo > 1) {
-        const uint32_t mid = lo + (hi - lo) / 2;
-        uint32_t k = 0;
-#pragma unroll
-        for (uint32_t e = 0; e < EMAX; e++) k += (cnt[e] >= mid && cnt[e] != 0) || (mid == 0);
-        uint32_t n_ge;
-        block_sum2(k, 0, s_a, s_b, n_ge, dummy);
-        if (n_ge >= 16) lo = mid; else hi = mid;
-    }
-    const uint32_t c16 = lo;
+    // names that carry at least 1/64 of the surveyed samples may have 512-bin windows, the others 256
+    const uint32_t big = total_cnt / 64u;
 #pragma unroll
     for (uint32_t e = 0; e < EMAX; e++) {
         if (want[e]) {
-            const uint32_t cap = cnt[e] >= c16 ? 512u : 256u;
+            const uint32_t cap = cnt[e] >= big ? 512u : 256u;
             if (want[e] > cap) want[e] = cap;
         }
     }
@@ -276,7 +276,20 @@ __device__ __forceinline__ void v2_global_add(uint64_t *__restrict__ counts, uin
     if (bin > r[1]) atomicMax(&r[1], bin);
 }
 
-__global__ __launch_bounds__(V2_BLOCK) void k_scatter2(const uint32_t *__restrict__ ids,
+// Global stores the compiler's s_waitcnt bookkeeping does not see (k_scatter2 explains why).  The s_nop covers the
+// "VMEM store of more than 8 bytes followed by a write of its data registers" hazard, which the compiler's hazard
+// recogniser cannot handle for an instruction inside an asm block.
+__device__ __forceinline__ void hidden_store_u4(void *p, pu4_t v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void hidden_store_u32(void *p, uint32_t v)
+{
+    asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
+
+template <int BLOCK, int NPT>
+__global__ __launch_bounds__(BLOCK, 4) void k_scatter2(const uint32_t *__restrict__ ids,
                                                        const double *__restrict__ v, size_t n, uint32_t nmetrics,
                                                        uint32_t log_np, uint32_t log_w,
                                                        const double *__restrict__ Tx,
@@ -289,19 +302,36 @@ __global__ __launch_bounds__(V2_BLOCK) void k_scatter2(const uint32_t *__restric
                                                        uint32_t dbg_arg)
 {
     const uint32_t dbg = LH_DBG(dbg_arg);
-    __shared__ __attribute__((aligned(16))) Scatter2Lds L;
+    // ONE LDS allocation: [Scatter2Lds][name table][hot windows].  Phases 1 and 3 address it through word / halfword
+    // offsets from its base, so that a sample's single LDS operation has one form whatever the sample turns into.
+    typedef Scatter2LdsT<BLOCK, NPT> LdsT;
+    static_assert(sizeof(LdsT) % 16 == 0, "the name table follows the struct in LDS");
+    static_assert(BLOCK >= 4 * NPT, "drain: one thread per 16-byte piece of a staged line");
+    constexpr int V2_TILE = LdsT::TILE;
     extern __shared__ __attribute__((aligned(16))) unsigned char v2_smem[];
-    NameEntry *nt = reinterpret_cast<NameEntry *>(v2_smem);                        // [nmetrics]
-    uint32_t *win = reinterpret_cast<uint32_t *>(v2_smem + (size_t)nmetrics * 8);  // [cells]
+    LdsT &L = *reinterpret_cast<LdsT *>(v2_smem);
+    NameEntry *nt = reinterpret_cast<NameEntry *>(v2_smem + sizeof(LdsT));         // [nmetrics]
+    uint32_t *lds32 = reinterpret_cast<uint32_t *>(v2_smem);
+    rec16_t *lds16 = reinterpret_cast<rec16_t *>(v2_smem);
+    const uint32_t win_w = (uint32_t)(sizeof(LdsT) / 4) + 2 * nmetrics;            // word offset of the hot windows
+    uint32_t *win = lds32 + win_w;                                                 // [cells]
+    constexpr uint32_t CNT_W = offsetof(LdsT, cnt) / 4, DUMMY_W = offsetof(LdsT, dummy) / 4;
+    constexpr uint32_t SORTED_H = offsetof(LdsT, sorted) / 2, STAGE_H = offsetof(LdsT, stage) / 2;
+    constexpr int V2_BLOCK = BLOCK;   // shadows the survey kernels' block size inside this kernel
+    constexpr int NPMAX = NPT;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t np = 1u << log_np, pmask = np - 1, W = 1u << log_w;
     const uint32_t pool_base = blockIdx.x * chunks_per_wg;
 
-    for (uint32_t i = tid; i < nmetrics; i += V2_BLOCK) nt[i] = g_nt[i];
+    for (uint32_t i = tid; i < nmetrics; i += V2_BLOCK) {
+        NameEntry ne = g_nt[i];
+        ne.hot += win_w; // hot base as a word offset from the LDS base (base + win_w < 65 536: fits the low half)
+        nt[i] = ne;
+    }
     for (uint32_t i = tid; i < cells; i += V2_BLOCK) win[i] = 0;
     if (tid < NPMAX) { L.cnt[tid] = 0; L.sf[tid] = 0; L.cfill[tid] = CHUNK; L.cbase[tid] = INVALID; }
     ov_init(L.ov_key, L.ov_cnt, tid, V2_BLOCK);
-    if (tid == 0) L.pool_next = 0;
+    if (tid == 0) { L.pool_next = 0; L.missn[0] = 0; L.missn[1] = 0; }
     __syncthreads();
 
     const size_t ntiles = (n + V2_TILE - 1) / V2_TILE;
@@ -309,71 +339,122 @@ __global__ __launch_bounds__(V2_BLOCK) void k_scatter2(const uint32_t *__restric
     const pd2_t *vp = reinterpret_cast<const pd2_t *>(v);
     const pu2_t *ip = reinterpret_cast<const pu2_t *>(ids);
     constexpr int NPAIR = V2_SPT / 2;
-    pu2_t idv[NPAIR];
-    pd2_t val[NPAIR];
-    auto load_tile = [&](size_t tile) {
+    // Two register sets, used by alternate tiles.  A set's loads are issued right after barrier A of the tile that
+    // last used it, a whole tile period before they are needed, so HBM always has ~96 KiB per CU in flight while
+    // the workgroup computes.
+    //
+    // For that to work the loop's STORES (copy-out, chunk descriptors) are issued from inline asm.  With ordinary
+    // stores the compiler's wait for `nxt` became s_waitcnt vmcnt(0) at the top of the loop: the stores sit
+    // between the loads and their use, their number is not a compile-time constant, so it drained everything --
+    // the loads just issued included -- and the kernel ran load, then compute, then load (measured: 3.3 ms per 1e9
+    // pairs whatever the workgroup shape).  A store has no result register, so hiding it from the compiler's
+    // counter bookkeeping is safe: vmcnt retires in order and operations the compiler does not know about only
+    // make its waits stricter.  (Hiding the LOADS instead is not safe: the register allocator may copy a
+    // destination register before the data has landed.)
+    pu2_t ida[NPAIR], idb[NPAIR];
+    pd2_t vaa[NPAIR], vab[NPAIR];
+    auto load_tile = [&](size_t tile, pu2_t (&di)[NPAIR], pd2_t (&dv)[NPAIR]) {
         const size_t pbase = tile * (V2_TILE / 2);
 #pragma unroll
         for (int j = 0; j < NPAIR; j++) {
-            const size_t i = pbase + (size_t)j * V2_BLOCK + tid;
-            if (tile < ntiles && i < npairs) {
-                // the last pair of an odd-length stream reads one element past n inside the same 16-byte
-                // granule; it is masked below
-                idv[j] = __builtin_nontemporal_load(ip + i);
-                val[j] = __builtin_nontemporal_load(vp + i);
-            } else {
-                idv[j] = (pu2_t){INVALID, INVALID};
-                val[j] = (pd2_t){0.0, 0.0};
-            }
+            // pairs beyond the stream (last tile, and the two tiles past the end that the pipeline touches) re-read
+            // the last pair; `lim` masks them.  The last pair of an odd-length stream reads one element past n inside
+            // the same 16-byte granule; it is masked too.
+            size_t i = pbase + (size_t)j * V2_BLOCK + tid;
+            i = i < npairs ? i : npairs - 1;
+            di[j] = __builtin_nontemporal_load(ip + i);
+            dv[j] = __builtin_nontemporal_load(vp + i);
         }
     };
-    load_tile(blockIdx.x);
+    load_tile(blockIdx.x, ida, vaa);
+    // The first tile must have landed before the second one is requested: otherwise the compiler interleaves the two
+    // sets' loads, cannot tell them apart by age, and the merged wait at the loop header becomes vmcnt(0) for every
+    // iteration.  (The empty asm "uses" the registers, which makes the compiler wait for them here.)
+    asm volatile("" : "+v"(ida[0]), "+v"(ida[1]), "+v"(ida[2]), "+v"(ida[3]), "+v"(vaa[0]), "+v"(vaa[1]), "+v"(vaa[2]),
+                      "+v"(vaa[3]));
+    static_assert(NPAIR == 4, "the asm above names four register pairs");
+    load_tile((size_t)blockIdx.x + gridDim.x, idb, vab);
 
-    for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const size_t pbase = tile * (V2_TILE / 2);
-        const bool full_tile = (tile + 1) * (size_t)V2_TILE <= n;
+    // One tile.  `di` / `dv` hold the tile's samples; once they have been classified (after barrier A) the same
+    // registers receive the loads of the tile two steps ahead.  The loop below alternates between the two register
+    // sets, so no value ever has to be copied from one set to the other -- a copy would have to wait for loads that
+    // were issued moments ago.
+    auto process_tile = [&](size_t tile, pu2_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
+        // samples of this tile that exist (every tile but the last is full)
+        const uint32_t lim = (tile + 1) * (size_t)V2_TILE <= n ? (uint32_t)V2_TILE : (uint32_t)(n - tile * (size_t)V2_TILE);
         uint32_t pr[V2_SPT];  // partition | rank << 8, INVALID when the sample left no record
         uint32_t rec[V2_SPT];
-        // ---- phase 1: classify
-        auto classify = [&](auto full_tag) {
-            constexpr bool FULL = decltype(full_tag)::value;
+        uint32_t rare = 0;    // some sample of this thread carried an id >= nmetrics
+        // ---- phase 1: classify.  Straight-line code, four samples at a time: their name-table reads, then their
+        // LDS atomics, are in flight together (one LDS round trip per batch instead of one per sample).
 #pragma unroll
-            for (int j = 0; j < V2_SPT; j++) {
-                const uint32_t id = (j & 1) ? idv[j >> 1].y : idv[j >> 1].x;
+        for (int h = 0; h < V2_SPT; h += 4) {
+            uint32_t id[4], bin[4], where[4], rank[4];
+            NameEntry ne[4];
+            uint32_t unc = 0, miss = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j = h + k;
+                const uint32_t raw = (j & 1) ? idv[j >> 1].y : idv[j >> 1].x;
+                // padding beyond the stream is not an error; an id >= nmetrics is (reported, sample skipped)
+                const bool live = 2u * ((uint32_t)(j >> 1) * V2_BLOCK + tid) + (uint32_t)(j & 1) < lim;
+                const bool ok = live && raw < nmetrics;
+                rare |= (live && !ok) ? 1u : 0u;
+                id[k] = ok ? raw : INVALID;
+                ne[k] = nt[ok ? raw : 0u];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j = h + k;
                 const double x = (j & 1) ? val[j >> 1].y : val[j >> 1].x;
-                pr[j] = INVALID;
-                rec[j] = 0;
-                bool live = true; // load_tile pads pairs beyond the stream with id 0xffffffff: not an error
-                if (!FULL) live = 2 * (pbase + (size_t)(j >> 1) * V2_BLOCK + tid) + (j & 1) < n;
-                if (!live) continue;
-                if (id >= nmetrics) {
-                    atomicOr(err, 1u); // reported by lh_sync / lh_extract
-                    continue;
-                }
-                const NameEntry ne = nt[id];
-                const uint32_t bin = (dbg & 2u) ? (uint32_t)(__double2loint(x) & 0xffff) : lh_bin_of(x, Tx);
-                const uint32_t hrel = bin - (ne.org >> 16);
-                if (hrel < (ne.hot >> 16)) { // a hot name inside its window: counted right here
-                    atomicAdd(&win[(ne.hot & 0xffffu) + hrel], 1u);
-                    continue;
-                }
-                const uint32_t crel = bin - (ne.org & 0xffffu);
-                if (crel < W) {
-                    const uint32_t p = id & pmask;
-                    rec[j] = ((id >> log_np) << log_w) | crel;
-                    pr[j] = p | (atomicAdd(&L.cnt[p], 1u) << 8);
-                } else if (!ov_add(L.ov_key, L.ov_cnt, (id << 16) | bin, 1u)) {
-                    v2_global_add(counts, ranges, id, bin, 1); // outside the cold window and the table is full
+                bool u;
+                bin[k] = (dbg & 2u) ? (uint32_t)(__double2loint(x) & 0xffff) : lh_bin_fast(x, u);
+                if (!(dbg & 2u) && u) unc |= 1u << k;
+            }
+            if (unc) { // inside the guard band of a bucket threshold (1 sample in ~4 000): exact table compare
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int j = h + k;
+                    if (unc & (1u << k)) bin[k] = lh_bin_of((j & 1) ? val[j >> 1].y : val[j >> 1].x, Tx);
                 }
             }
-        };
-        if (full_tile) classify(std::true_type{});
-        else classify(std::false_type{});
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j = h + k;
+                const uint32_t hrel = bin[k] - (ne[k].org >> 16), crel = bin[k] - (ne[k].org & 0xffffu);
+                const bool valid = id[k] != INVALID;
+                const bool hot = valid && hrel < (ne[k].hot >> 16);
+                const bool cold = valid && !hot && crel < W;
+                const uint32_t p = id[k] & pmask;
+                where[k] = hot ? (ne[k].hot & 0xffffu) + hrel : cold ? CNT_W + p : DUMMY_W + lane;
+                rec[j] = ((id[k] >> log_np) << log_w) | crel;
+                pr[j] = cold ? p : INVALID;
+                if (valid && !hot && !cold) miss |= 1u << k;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) rank[k] = atomicAdd(lds32 + where[k], 1u);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (pr[h + k] != INVALID) pr[h + k] |= rank[k] << 8;
+            if (miss) { // outside the name's cold window: queued, counted exactly after the copy-out (phase 4)
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (miss & (1u << k)) {
+                        const uint32_t key = (id[k] << 16) | bin[k];
+                        const uint32_t at = atomicAdd(&L.missn[par], 1u);
+                        if (at < V2_MISSQ) L.missq[par][at] = key;
+                        else if (!ov_add(L.ov_key, L.ov_cnt, key, 1u)) v2_global_add(counts, ranges, id[k], bin[k], 1);
+                    }
+            }
+        }
+        if (rare) atomicOr(err, 1u); // an id >= nmetrics: reported by lh_sync / lh_extract
         __syncthreads();                                   // barrier A: counts complete
-        load_tile(tile + gridDim.x);                       // next tile's loads fly during phases 2-4
+        // this register set is free again: it receives the tile two steps ahead (a whole tile period in flight)
+        load_tile(tile + 2 * (size_t)gridDim.x, idv, val);
 
         // ---- phase 2: per-partition bookkeeping (threads 0..255).  sf / cnt are only READ here (other scanning
         // waves sum them too); their new values are installed after barrier B.
+        if (tid == V2_BLOCK - 1) L.missn[par ^ 1u] = 0; // the other parity's queue was drained in the previous tile
         if (tid < NPMAX) {
             const uint32_t p = tid;
             const uint32_t c = L.cnt[p], sf0 = L.sf[p];
@@ -406,8 +487,9 @@ __global__ __launch_bounds__(V2_BLOCK) void k_scatter2(const uint32_t *__restric
                     const uint32_t over = out - room;
                     const uint32_t k = (over + CHUNK - 1) / CHUNK;
                     first = pool_base + atomicAdd(&L.pool_next, k);   // k consecutive chunks
-                    if (cb != INVALID) cdesc[cb] = tag | CHUNK;        // the old chunk is now full
-                    for (uint32_t q = 0; q + 1 < k; q++) cdesc[first + q] = tag | CHUNK;
+                    if (cb != INVALID) hidden_store_u32(cdesc + cb, tag | CHUNK);   // the old chunk is now full
+#pragma nounroll
+                    for (uint32_t q = 0; q + 1 < k; q++) hidden_store_u32(cdesc + first + q, tag | CHUNK);
                     L.cbase[p] = first + k - 1;
                     L.cfill[p] = over - (k - 1) * CHUNK;
                 } else {
@@ -416,8 +498,10 @@ __global__ __launch_bounds__(V2_BLOCK) void k_scatter2(const uint32_t *__restric
                 L.dA[p] = cb * CHUNK + cf;
                 L.dB[p] = first * CHUNK - room;
                 L.room[p] = room;
+#pragma nounroll
                 for (uint32_t i = 0; i < nfull; i++) L.owner[lb + i] = (uint16_t)p;
                 // the staged leftovers open the partition's first line: aligned 16-byte LDS copies
+#pragma nounroll
                 for (uint32_t q = 0; q * 8 < sf0; q++)
                     *reinterpret_cast<pu4_t *>(&L.sorted[lb * LINE2 + q * 8]) =
                         *reinterpret_cast<const pu4_t *>(&L.stage[p * LINE2 + q * 8]);
@@ -425,16 +509,19 @@ __global__ __launch_bounds__(V2_BLOCK) void k_scatter2(const uint32_t *__restric
         }
         __syncthreads();                                   // barrier B: plan of the tile is visible
 
-        // ---- phase 3: place the records
+        // ---- phase 3: place the records (again one form for every sample: eight table reads, eight stores)
         if (tid < NPMAX) { L.sf[tid] = L.newsf[tid]; L.cnt[tid] = 0; }
+        {
+            pu2_t a[V2_SPT];
 #pragma unroll
-        for (int j = 0; j < V2_SPT; j++) {
-            if (pr[j] != INVALID) {
+            for (int j = 0; j < V2_SPT; j++) a[j] = L.tA[pr[j] == INVALID ? 0u : (pr[j] & 0xffu)];
+#pragma unroll
+            for (int j = 0; j < V2_SPT; j++) {
                 const uint32_t p = pr[j] & 0xffu;
-                const pu2_t a = L.tA[p];
-                const uint32_t u = (a.x & 0xffu) + (pr[j] >> 8), out = a.x >> 8;
-                if (u < out) L.sorted[a.y + u] = (rec16_t)rec[j];
-                else L.stage[p * LINE2 + (u - out)] = (rec16_t)rec[j];
+                const uint32_t u = (a[j].x & 0xffu) + (pr[j] >> 8), out = a[j].x >> 8;
+                const uint32_t at = pr[j] == INVALID ? 2 * DUMMY_W + lane
+                                                     : (u < out ? SORTED_H + a[j].y + u : STAGE_H + p * LINE2 + (u - out));
+                lds16[at] = (rec16_t)rec[j];
             }
         }
         __syncthreads();                                   // barrier C: lines complete
@@ -448,10 +535,22 @@ __global__ __launch_bounds__(V2_BLOCK) void k_scatter2(const uint32_t *__restric
                 const uint32_t u = (line - L.lbase[p]) * LINE2 + q * 8;
                 const pu4_t r4 = *reinterpret_cast<const pu4_t *>(&L.sorted[line * LINE2 + q * 8]);
                 const uint32_t dst = (u < L.room[p] ? L.dA[p] : L.dB[p]) + u;
-                *reinterpret_cast<pu4_t *>(records + dst) = r4;
+                hidden_store_u4(records + dst, r4);
             }
         }
-        // (the next tile's barrier A separates this copy-out from the next bookkeeping)
+        // the tile's out-of-window samples, one per thread: aggregated in the small LDS table, else a global atomic
+        {
+            const uint32_t nq = min(L.missn[par], V2_MISSQ);
+            for (uint32_t i = tid; i < nq; i += V2_BLOCK) {
+                const uint32_t key = L.missq[par][i];
+                if (!ov_add(L.ov_key, L.ov_cnt, key, 1u)) v2_global_add(counts, ranges, key >> 16, key & 0xffffu, 1);
+            }
+        }
+        // (the next tile's barrier A separates this phase from the next bookkeeping)
+    };
+    for (size_t tile = blockIdx.x; tile < ntiles; tile += 2 * (size_t)gridDim.x) {
+        process_tile(tile, ida, vaa, 0u);
+        if (tile + gridDim.x < ntiles) process_tile(tile + gridDim.x, idb, vab, 1u); // workgroup-uniform
     }
 
     // ---- drain: staged remainders and the open chunks' descriptors
@@ -473,8 +572,8 @@ __global__ __launch_bounds__(V2_BLOCK) void k_scatter2(const uint32_t *__restric
     }
     __syncthreads();
     {
-        const uint32_t p = tid >> 2, q = tid & 3u; // 1 024 threads = 256 partitions x 4 pieces
-        const uint32_t d = L.dA[p];
+        const uint32_t p = tid >> 2, q = tid & 3u; // one thread per (partition, 16-byte piece of its staged line)
+        const uint32_t d = p < (uint32_t)NPMAX ? L.dA[p] : INVALID;
         if (d != INVALID && q * 8 < L.sf[p])
             *reinterpret_cast<pu4_t *>(records + d + q * 8) = *reinterpret_cast<const pu4_t *>(&L.stage[p * LINE2 + q * 8]);
     }
@@ -514,9 +613,9 @@ __global__ __launch_bounds__(V2_BLOCK) void k_scatter2(const uint32_t *__restric
 // ---------------------------------------------------------------------------
 // P2 v2: the record is the LDS index
 // ---------------------------------------------------------------------------
-constexpr size_t P2V2_LDS_BYTES = (P2_WINWORDS + 3 * PART_MAX_MPP) * sizeof(uint32_t) + 16;
+constexpr size_t P2V2_LDS_BYTES = (P2V2_WINWORDS + 3 * PART_MAX_MPP) * sizeof(uint32_t) + 16;
 
-__global__ __launch_bounds__(P2_BLOCK, 8) void k_part_hist2(const rec16_t *__restrict__ records,
+__global__ __launch_bounds__(P2_BLOCK) void k_part_hist2(const rec16_t *__restrict__ records,
                                                             const uint32_t *__restrict__ cdesc,
                                                             const uint32_t *__restrict__ sorted,
                                                             const uint32_t *__restrict__ part_start,
@@ -529,7 +628,7 @@ __global__ __launch_bounds__(P2_BLOCK, 8) void k_part_hist2(const rec16_t *__res
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *h = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *s_org = h + P2_WINWORDS;
+    uint32_t *s_org = h + P2V2_WINWORDS;
     uint32_t *s_mn = s_org + PART_MAX_MPP;
     uint32_t *s_mx = s_mn + PART_MAX_MPP;
     const uint32_t slot = blockIdx.x;
@@ -554,14 +653,26 @@ __global__ __launch_bounds__(P2_BLOCK, 8) void k_part_hist2(const rec16_t *__res
         dst[1] = __builtin_nontemporal_load(src + 64);
     };
     auto reduce_chunk = [&](const u4_t (&r4)[2], uint32_t cn) {
+        if (cn == CHUNK) { // full chunk (wave-uniform): sixteen unconditional LDS adds per lane
+#pragma unroll
+            for (uint32_t q = 0; q < 2; q++) {
+                const uint32_t rr[4] = {r4[q].x, r4[q].y, r4[q].z, r4[q].w};
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    atomicAdd(&h[rr[t] & 0x7fffu], 1u);
+                    atomicAdd(&h[(rr[t] >> 16) & 0x7fffu], 1u);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (uint32_t q = 0; q < 2; q++) {
             const uint32_t rr[4] = {r4[q].x, r4[q].y, r4[q].z, r4[q].w};
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 const uint32_t at = q * 512 + lane * 8 + (uint32_t)t * 2; // record index of the low half
-                if (at < cn) atomicAdd(&h[rr[t] & 0x3fffu], 1u);
-                if (at + 1 < cn) atomicAdd(&h[(rr[t] >> 16) & 0x3fffu], 1u);
+                if (at < cn) atomicAdd(&h[rr[t] & 0x7fffu], 1u);
+                if (at + 1 < cn) atomicAdd(&h[(rr[t] >> 16) & 0x7fffu], 1u);
             }
         }
     };
@@ -616,6 +727,8 @@ __global__ __launch_bounds__(P2_BLOCK, 8) void k_part_hist2(const rec16_t *__res
 // plan + launcher
 // ---------------------------------------------------------------------------
 struct Part2Plan {
+    uint32_t shape;            // 0 = <1024, 256>, 1 = <512, 128>
+    uint32_t block, tile, lds_fixed;
     uint32_t log_np, np, mpp, log_w, cells, g1, chunks_per_wg, nchunks;
     size_t off_rec, off_cd, off_sorted, off_small, off_stat, off_nt, off_hs, off_hdr, total;
 };
@@ -624,37 +737,46 @@ static bool make_plan2(size_t n, uint32_t nmetrics, int num_cus, const PartTunin
 {
     if (!tune.v2 || n < (tune.v2_min_samples ? tune.v2_min_samples : V2_MIN_SAMPLES) || n > (size_t(1) << 31)) return false;
     if (nmetrics < 2 || nmetrics > V2_MAX_NAMES) return false;
-    const uint32_t names_per_part = 4;
+    P.shape = tune.v2_shape ? 1u : 0u;
+    const uint32_t npt = P.shape ? 128u : 256u, wgs_per_cu = P.shape ? 2u : 1u;
+    P.block = P.shape ? 512u : 1024u;
+    P.tile = P.block * V2_SPT;
+    P.lds_fixed = (uint32_t)(P.shape ? sizeof(Scatter2LdsT<512, 128>) : sizeof(Scatter2LdsT<1024, 256>));
+    const uint32_t names_per_part = P.shape ? 8u : 4u;
     const uint32_t want_np = (nmetrics + names_per_part - 1) / names_per_part;
-    P.log_np = std::min(8u, ilog2_ceil(want_np));
+    P.log_np = std::min(ilog2_ceil(npt), ilog2_ceil(want_np));
     P.np = 1u << P.log_np;
     P.mpp = (nmetrics + P.np - 1) >> P.log_np;
     if (P.mpp > PART_MAX_MPP) return false;
     uint32_t lw = 0;
-    while ((P.mpp << (lw + 1)) <= P2_WINWORDS) lw++;
-    P.log_w = lw; // cold window = 2^log_w bins per name; the record (local << log_w | offset) is < 16 384
+    while ((P.mpp << (lw + 1)) <= P2V2_WINWORDS && lw < 13) lw++;
+    P.log_w = lw; // cold window = 2^log_w bins per name; the record (local << log_w | offset) is < 32 768
     // hot windows: whatever LDS is left beside the scatter structures and the per-name table
-    const size_t fixed = sizeof(Scatter2Lds) + (size_t)nmetrics * sizeof(NameEntry) + 256;
-    P.cells = fixed + 4096 <= V2_LDS_TOTAL ? (uint32_t)((V2_LDS_TOTAL - fixed) / 4) & ~63u : 0u;
+    const size_t budget = V2_LDS_TOTAL / wgs_per_cu;
+    const size_t fixed = P.lds_fixed + (size_t)nmetrics * sizeof(NameEntry) + 256;
+    P.cells = fixed + 4096 <= budget ? (uint32_t)((budget - fixed) / 4) & ~63u : 0u;
+    if (P.cells > 40000u) P.cells = 40000u & ~63u; // LDS word offsets of the windows must stay below 65 536
     if (!tune.hot) P.cells = 0;
-    const size_t ntiles = (n + V2_TILE - 1) / V2_TILE;
-    size_t g1 = (size_t)num_cus; // one 1 024-thread workgroup per CU (it owns the CU's LDS)
+    const size_t ntiles = (n + P.tile - 1) / P.tile;
+    size_t g1 = (size_t)num_cus * wgs_per_cu; // the workgroups of a CU own its LDS between them
     if (g1 > (ntiles + 3) / 4) g1 = (ntiles + 3) / 4;
     if (g1 < 1) g1 = 1;
     P.g1 = (uint32_t)g1;
     const size_t tiles_per_wg = (ntiles + g1 - 1) / g1;
-    P.chunks_per_wg = (uint32_t)(tiles_per_wg * (V2_TILE / CHUNK) + P.np + 1);
+    P.chunks_per_wg = (uint32_t)(tiles_per_wg * (P.tile / CHUNK) + P.np + 1);
     P.nchunks = P.g1 * P.chunks_per_wg;
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~size_t(255); return at; };
-    P.off_rec = take((size_t)P.nchunks * CHUNK * sizeof(rec16_t));
-    P.off_cd = take((size_t)P.nchunks * sizeof(uint32_t));
-    P.off_sorted = take((size_t)P.nchunks * sizeof(uint32_t));
-    P.off_small = take(small_words(P.np, SLOT_EXTRA) * sizeof(uint32_t));
-    P.off_stat = take((size_t)nmetrics * 20);
+    // the survey's tables come first: their offsets depend on the name count only, so the sub-launches of one
+    // call (whose other regions shrink with n) all find the survey of the first one
+    P.off_stat = take((size_t)nmetrics * 20 + 8);
     P.off_nt = take((size_t)nmetrics * sizeof(NameEntry));
     P.off_hs = take((size_t)V2_MAX_SLOTS * sizeof(pu4_t));
     P.off_hdr = take(64);
+    P.off_rec = take((size_t)P.nchunks * CHUNK * sizeof(rec16_t));
+    P.off_cd = take((size_t)P.nchunks * sizeof(uint32_t));
+    P.off_sorted = take((size_t)P.nchunks * sizeof(uint32_t));
+    P.off_small = take(small_words(P.np, P2V2_SLOT_EXTRA) * sizeof(uint32_t));
     P.total = o;
     return true;
 }
@@ -665,24 +787,28 @@ size_t part2_scratch_bytes(size_t n, uint32_t nmetrics, int num_cus, const PartT
     return make_plan2(n, nmetrics, num_cus, tune, P) ? P.total : 0;
 }
 
-hipError_t launch_ingest_pairs_part2(const uint32_t *d_ids, const double *d_v, size_t n, uint64_t *counts,
-                                     uint32_t *ranges, uint32_t nmetrics, const double *d_Tx, uint32_t *d_err,
-                                     void *scratch, size_t scratch_bytes, int num_cus, const PartTuning &tune,
-                                     hipStream_t s)
+// survey_n > 0: first sub-launch of a call -- survey pairs [0, survey_n) of the same arrays (the whole call) before
+// the scatter; survey_n == 0: a later sub-launch, the tables of the first one are still in the scratch block.
+hipError_t launch_ingest_pairs_part2(const uint32_t *d_ids, const double *d_v, size_t n, size_t survey_n,
+                                     uint64_t *counts, uint32_t *ranges, uint32_t nmetrics, const double *d_Tx,
+                                     uint32_t *d_err, void *scratch, size_t scratch_bytes, int num_cus,
+                                     const PartTuning &tune, hipStream_t s)
 {
     Part2Plan P;
     if (!make_plan2(n, nmetrics, num_cus, tune, P) || scratch_bytes < P.total || !scratch) return hipErrorInvalidValue;
     if (!part_aligned(d_ids, d_v)) return hipErrorInvalidValue;
-    const size_t p1_dyn = (size_t)nmetrics * sizeof(NameEntry) + (size_t)P.cells * 4;
+    const size_t p1_dyn = P.lds_fixed + (size_t)nmetrics * sizeof(NameEntry) + (size_t)P.cells * 4;
     const size_t sv_dyn = (size_t)nmetrics * 16;
     static std::atomic<bool> attr_set{false}; // benign if two threads race: both set the same attributes
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_part_hist2),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)P2V2_LDS_BYTES);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter2),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(V2_LDS_TOTAL - sizeof(Scatter2Lds)));
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter2<1024, 256>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)V2_LDS_TOTAL);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter2<512, 128>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(V2_LDS_TOTAL / 2));
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_survey_count),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(V2_MAX_NAMES * 16));
@@ -701,7 +827,7 @@ hipError_t launch_ingest_pairs_part2(const uint32_t *d_ids, const double *d_v, s
     const uint32_t dbg = 0;
 #endif
     unsigned char *base = static_cast<unsigned char *>(scratch);
-    LevelPtrs L1 = level_ptrs(base, P.off_rec, P.off_cd, P.off_sorted, P.off_small, P.np, SLOT_EXTRA);
+    LevelPtrs L1 = level_ptrs(base, P.off_rec, P.off_cd, P.off_sorted, P.off_small, P.np, P2V2_SLOT_EXTRA);
     rec16_t *records = reinterpret_cast<rec16_t *>(base + P.off_rec);
     uint32_t *g_cnt = reinterpret_cast<uint32_t *>(base + P.off_stat);
     uint32_t *g_mninv = g_cnt + nmetrics, *g_mx = g_mninv + nmetrics;
@@ -712,23 +838,30 @@ hipError_t launch_ingest_pairs_part2(const uint32_t *d_ids, const double *d_v, s
 
     hipError_t e = hipMemsetAsync(L1.cdesc, 0xff, (size_t)P.nchunks * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(L1.pc, 0, small_words(P.np, SLOT_EXTRA) * sizeof(uint32_t), s);
+    e = hipMemsetAsync(L1.pc, 0, small_words(P.np, P2V2_SLOT_EXTRA) * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(g_cnt, 0, (size_t)nmetrics * 20 + 8, s);
-    if (e != hipSuccess) return e;
-    const size_t sv_tiles = (n / 2 + 2047) / 2048;
-    const unsigned sv_grid = (unsigned)std::min<size_t>(SV_GRID, std::max<size_t>(1, sv_tiles));
-    hipLaunchKernelGGL(k_survey_count, dim3(sv_grid), dim3(V2_BLOCK), sv_dyn, s, d_ids, d_v, n, nmetrics, d_Tx, g_cnt,
-                       g_mninv, g_mx, g_sum);
-    hipLaunchKernelGGL(k_survey_plan, dim3(1), dim3(V2_BLOCK), 0, s, g_cnt, g_mninv, g_mx, g_sum, nmetrics, P.log_w,
-                       P.cells, g_nt, g_hs, g_hdr);
-    hipLaunchKernelGGL(k_scatter2, dim3(P.g1), dim3(V2_BLOCK), p1_dyn, s, d_ids, d_v, n, nmetrics, P.log_np, P.log_w,
-                       d_Tx, g_nt, g_hs, g_hdr, P.cells, records, L1.cdesc, P.chunks_per_wg, counts, ranges, d_err,
-                       dbg);
-    e = run_plan(L1, P.nchunks, P.np, 0u, SLOT_EXTRA, s);
+    if (survey_n) {
+        e = hipMemsetAsync(g_cnt, 0, (size_t)nmetrics * 20 + 8, s);
+        if (e != hipSuccess) return e;
+        const size_t sv_tiles = (survey_n / 2 + 2047) / 2048;
+        const unsigned sv_grid = (unsigned)std::min<size_t>(SV_GRID, std::max<size_t>(1, sv_tiles));
+        hipLaunchKernelGGL(k_survey_count, dim3(sv_grid), dim3(V2_BLOCK), sv_dyn, s, d_ids, d_v, survey_n, nmetrics,
+                           d_Tx, g_cnt, g_mninv, g_mx, g_sum);
+        hipLaunchKernelGGL(k_survey_plan, dim3(1), dim3(V2_BLOCK), 0, s, g_cnt, g_mninv, g_mx, g_sum, nmetrics,
+                           P.log_w, P.cells, g_nt, g_hs, g_hdr);
+    }
+    if (P.shape)
+        hipLaunchKernelGGL((k_scatter2<512, 128>), dim3(P.g1), dim3(512), p1_dyn, s, d_ids, d_v, n, nmetrics, P.log_np,
+                           P.log_w, d_Tx, g_nt, g_hs, g_hdr, P.cells, records, L1.cdesc, P.chunks_per_wg, counts,
+                           ranges, d_err, dbg);
+    else
+        hipLaunchKernelGGL((k_scatter2<1024, 256>), dim3(P.g1), dim3(1024), p1_dyn, s, d_ids, d_v, n, nmetrics,
+                           P.log_np, P.log_w, d_Tx, g_nt, g_hs, g_hdr, P.cells, records, L1.cdesc, P.chunks_per_wg,
+                           counts, ranges, d_err, dbg);
+    e = run_plan(L1, P.nchunks, P.np, 0u, P2V2_SLOT_EXTRA, s);
     if (e != hipSuccess) return e;
     if (!(dbg & 4u))
-        hipLaunchKernelGGL(k_part_hist2, dim3(P.np + SLOT_EXTRA), dim3(P2_BLOCK), P2V2_LDS_BYTES, s, records, L1.cdesc,
+        hipLaunchKernelGGL(k_part_hist2, dim3(P.np + P2V2_SLOT_EXTRA), dim3(P2_BLOCK), P2V2_LDS_BYTES, s, records, L1.cdesc,
                            L1.sorted, L1.part_start, L1.slots, L1.nslots, P.log_np, P.mpp, P.log_w, nmetrics, g_nt,
                            counts, ranges);
     return hipGetLastError();

@@ -92,8 +92,9 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("shape", [0, 1], ids=["1024x256", "512x128"])
 @pytest.mark.parametrize("M,n,kind,skew", CASES)
-def test_survey_path_is_exact(native_lib, torch_cuda, M, n, kind, skew):
+def test_survey_path_is_exact(native_lib, torch_cuda, M, n, kind, skew, shape):
     import loghisto_amd
     rng = np.random.default_rng(M * 13 + n)
     ids = _ids(rng, M, n, skew)
@@ -101,6 +102,7 @@ def test_survey_path_is_exact(native_lib, torch_cuda, M, n, kind, skew):
     d_ids, d_v = _dev(torch_cuda, ids), _dev(torch_cuda, v)
     with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
         e.set_option(N.OPT_PART_V2_MIN_PAIRS, 1 << 17)
+        e.set_option(N.OPT_PART_V2_SHAPE, shape)
         for rep in range(2):                     # scratch, survey tables and ranges are reused across launches / epochs
             e.submit_pairs_device(d_ids, d_v)
             e.sync()
@@ -111,7 +113,8 @@ def test_survey_path_is_exact(native_lib, torch_cuda, M, n, kind, skew):
                 _check(snap, ids, v, M, got)
 
 
-def test_survey_path_bad_ids_sublaunches_and_two_launches_per_epoch(native_lib, torch_cuda):
+@pytest.mark.parametrize("shape", [0, 1], ids=["1024x256", "512x128"])
+def test_survey_path_bad_ids_sublaunches_and_two_launches_per_epoch(native_lib, torch_cuda, shape):
     import loghisto_amd
     rng = np.random.default_rng(77)
     M, n = 512, 9_000_001
@@ -124,7 +127,8 @@ def test_survey_path_bad_ids_sublaunches_and_two_launches_per_epoch(native_lib, 
     keep[where] = False
     with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
         e.set_option(N.OPT_PART_V2_MIN_PAIRS, 1 << 17)
-        e.set_option(N.OPT_SUBLAUNCH_PAIRS, 1 << 22)       # 3 sub-launches per call, each with its own survey
+        e.set_option(N.OPT_PART_V2_SHAPE, shape)
+        e.set_option(N.OPT_SUBLAUNCH_PAIRS, 1 << 22)       # 3 sub-launches per call, one survey per call
         e.submit_pairs_device(_dev(torch_cuda, ids), _dev(torch_cuda, v))
         e.submit_pairs_device(_dev(torch_cuda, bad), _dev(torch_cuda, v))
         with pytest.raises(loghisto_amd.LhError) as ei:
