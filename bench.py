@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- loghisto hot path on MI355X: float64 samples/s bucketed.
 
-A "step" is one pass of the hot path over one resident batch: ingest kernel over
-n float64 samples of one metric (K1), epoch flip, [N>1: RCCL merge of the bucket
-row], percentile/sum/count scan (K2), results on the host, buffer recycled (K3).
-Workload at N=1 = BASELINE.json configs[1]: "Single-metric 1B float64 samples,
-1xMI355X, one ingest kernel + one percentile scan" (SURVEY.md 8d "C2":
-lognormal(mu=ln 1e5, sigma=1), seeded, generated on device).
+A "step" is one pass of the hot path over one resident batch: ingest, epoch flip, [N>1: merge], percentile /
+sum / count scan, results on the host, buffer recycled.
 
-N>1: one process per GPU (torch.distributed / RCCL), weak scaling: every rank
-ingests its own n samples, the only exchange is the all-reduce of the uint64
-bucket row at the flip.  value = N*n*K / max-over-ranks wall time.
+N = 1 (the headline): BASELINE.json configs[1] "Single-metric 1B float64 samples, 1xMI355X, one ingest kernel
++ one percentile scan" (SURVEY.md 8d "C2": lognormal(mu = ln 1e5, sigma = 1), seeded, generated on device).
+The same JSON line carries, under "secondary", the other configurations measured in the same process --
+C3 (1e9 pairs over 1 024 Zipf names), one rank's slice of C4 (65 536 names, reduce-scatter merge through the
+C ABI), the host-fed lh_submit_pairs rate and a short C5 burst -- each with its own roofline and parity flag
+(VERDICT r1 next #4), and "parity": the GPU row against the oracle over ALL 1e9 samples of the step.
+
+N > 1: one process per GPU (torch.distributed launches and rendezvous), weak scaling of BASELINE configs[3]
+"65536 histogram names sharded across the GPUs, RCCL merge of bucket arrays": every rank buckets ITS slice of a
+Zipf stream over ALL 65 536 names, and at the flip lh_snapshot_merge reduce-scatters the per-row merged windows
+over RCCL/xGMI so that rank r ends with the rows of the names it owns, which it extracts.  The only collective
+is that merge.  value = N * n * K / max-over-ranks wall time.  (The N = 1 line's secondary.c4_one_rank is the
+single-rank point of this series.)
 
 Prints ONE JSON line on rank 0.
 """
@@ -20,7 +26,9 @@ import argparse
 import json
 import math
 import os
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -31,7 +39,10 @@ sys.path.insert(0, ROOT)
 
 PCTS = [0.0, .5, .75, .9, .95, .99, .999, .9999, 1.0]   # metrics.go:145-155
 HBM_PEAK_GBS = 8000.0                                    # MI355X_MICROARCH.md: 8.0 TB/s spec
-BYTES_PER_SAMPLE = 8                                     # one float64 read
+PCIE_GBS = 63.0                                          # PCIe Gen5 x16 (spec)
+BYTES_SINGLE, BYTES_PAIR = 8, 12                         # float64 / float64 + uint32 id
+METRIC = "float64 samples/sec bucketed (1 GPU) + % HBM roofline; p99 extract latency"
+K1_PMC = os.path.join("profiles", "r02_k1_pmc.json")
 
 
 def parse():
@@ -39,15 +50,19 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--samples", type=float, default=1e9, help="float64 samples per GPU per step")
+    ap.add_argument("--samples", type=float, default=1e9, help="float64 samples per GPU per step (c2 / c3)")
     ap.add_argument("--dist", default="lognormal", choices=["lognormal", "constant", "uniform", "exponential",
                                                             "normal", "loguniform", "lognormal25"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="N = 1: only the C2 headline")
+    ap.add_argument("--no-parity", action="store_true", help="skip the full-stream oracle checks (profiling runs)")
     ap.add_argument("--latency-flips", type=int, default=1000)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3"],
-                    help="c2 (default, the headline): one metric; c3: 1024 Zipf names, (id, value) stream")
-    ap.add_argument("--names", type=int, default=1024, help="histogram names for --workload c3")
+    ap.add_argument("--workload", default="auto", choices=["auto", "c2", "c3", "c4"],
+                    help="auto: c2 (+ secondary) on one GPU, c4 on several; c3: 1024 Zipf names; c4: 65536 names "
+                         "+ reduce-scatter merge")
+    ap.add_argument("--names", type=int, default=0, help="histogram names (default 1024 for c3, 65536 for c4)")
+    ap.add_argument("--c4-slice", type=float, default=1.25e8, help="pairs per rank per step of the C4 stream")
     return ap.parse_args()
 
 
@@ -71,49 +86,53 @@ def make_samples(n: int, kind: str, seed: int) -> torch.Tensor:
     return v.mul_(sigma).add_(math.log(1e5)).exp_()
 
 
+def zipf_ids(n: int, M: int, seed: int) -> torch.Tensor:
+    """id ~ Zipf(1.0) over ranks by inverse CDF (chunked: searchsorted needs int64 scratch)."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    w = 1.0 / torch.arange(1, M + 1, dtype=torch.float64, device="cuda")
+    cdf = torch.cumsum(w / w.sum(), 0)
+    ids = torch.empty(n, dtype=torch.int32, device="cuda")
+    step = 1 << 27
+    for lo in range(0, n, step):
+        u = torch.rand(min(step, n - lo), device="cuda", dtype=torch.float64, generator=g)
+        ids[lo:lo + step] = torch.searchsorted(cdf, u).clamp_(max=M - 1).to(torch.int32)
+    return ids
+
+
 def effective_cores() -> int:
-    """Cores this process may actually use: min(cpu_count, affinity mask, cgroup CPU quota).
-    (The MI355X box reports 256 CPUs but its cgroup grants 16: threads beyond that only time-slice.)"""
-    n = os.cpu_count() or 1
-    try:
-        n = min(n, len(os.sched_getaffinity(0)))
-    except (AttributeError, OSError):
-        pass
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]       # cgroup v2
-        if quota != "max":
-            n = min(n, max(1, int(math.ceil(int(quota) / int(period)))))
-    except (OSError, ValueError):
-        try:
-            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())             # cgroup v1
-            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0 and p > 0:
-                n = min(n, max(1, int(math.ceil(q / p))))
-        except (OSError, ValueError):
-            pass
-    return n
+    import oracle
+    return oracle.granted_cores()
 
 
-def cpu_baseline(samples: torch.Tensor, target_s: float):
+def roofline(n_bytes: float, avg_ms: float, kernel: str, peak=HBM_PEAK_GBS, bound="hbm", traffic=None, **extra):
+    achieved = n_bytes / (avg_ms * 1e-3) / 1e9
+    r = {"bound": bound, "kernel": kernel, "achieved": achieved, "peak": peak, "unit": "GB/s",
+         "frac": achieved / peak, "traffic": traffic, "algorithmic_bytes_per_launch": n_bytes,
+         "avg_launch_ms": avg_ms}
+    r.update(extra)
+    return r
+
+
+def cpu_baseline(host: np.ndarray, target_s: float):
     """Oracle timed on this box's host cores (bounded sample of the same workload)."""
     import oracle
     cores = effective_cores()
-    probe = samples[: 1 << 21].cpu().numpy()
+    probe = host[: 1 << 21]
     t1, _ = oracle.bench_dense(probe, 1)
     rate1 = probe.size / max(t1, 1e-9)                       # one core
-    n = int(min(samples.numel(), 1 << 27))                   # 1 GiB of host samples
-    host = samples[:n].cpu().numpy()
+    n = int(min(host.size, 1 << 27))                         # 1 GiB of host samples
+    part = host[:n]
     # every thread passes `reps` times over its slice so that thread start-up and the final merge do not
     # dominate on a many-core host: about target_s seconds of wall time if the cores scaled perfectly / 4
     reps = int(max(1, min(256, target_s * rate1 * cores / 2 / n)))
-    t, counts = oracle.bench_dense_reps(host, cores, reps)
+    t, counts = oracle.bench_dense_reps(part, cores, reps)
     assert int(counts.sum()) == n * reps and not (counts % reps).any()
-    counts = counts // reps
     n_timed = n * reps
     # form A (the reference's cost shape: lock + 4 map probes + atomic per sample), small sample
     na = int(min(n, 1 << 22))
-    ta, _ = oracle.bench_faithful(host[:na], cores)
-    ta1, _ = oracle.bench_faithful(host[: na // 4], 1)
+    ta, _ = oracle.bench_faithful(part[:na], cores)
+    ta1, _ = oracle.bench_faithful(part[: na // 4], 1)
     return {
         "value": n_timed / t, "unit": "samples/s", "cores": cores, "kind": "port",
         "sample": f"first {n} samples of the step's stream, {reps} passes per thread ({t:.2f} s wall); C oracle "
@@ -123,90 +142,57 @@ def cpu_baseline(samples: torch.Tensor, target_s: float):
         "faithful_form": {"value": na / ta, "cores": cores, "value_1thread": (na // 4) / ta1,
                           "sample": f"{na} samples; shared lock + map[name][int16] + atomic per call "
                                     "(cost shape of metrics.go:273-295, BASELINE.md form A)"},
-    }, counts, n
+    }
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X; there is no CPU path")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+def timed_steps(step, steps, warmup, fence):
+    for _ in range(warmup):
+        out = step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step(True)
+    fence()
+    return time.perf_counter() - t0, out
 
-    import loghisto_amd
-    from loghisto_amd import merge
 
+def dense_from_csr(off, keys, counts, M):
+    import oracle
+    dense = np.zeros((M, 65536), dtype=np.uint64)
+    rows = np.repeat(np.arange(M), np.diff(off.astype(np.int64)))
+    dense[rows, oracle.key_to_bin(keys)] = counts
+    return dense
+
+
+# ---------------------------------------------------------------------------------------------------------
+# C2: single metric (the headline)
+# ---------------------------------------------------------------------------------------------------------
+def run_c2(args, la, stream, rank):
     n = int(args.samples)
-    c3 = args.workload == "c3"
-    M = args.names if c3 else 1
-    bytes_per_sample = 12 if c3 else BYTES_PER_SAMPLE       # float64 + uint32 id for mixed streams
-    eng = loghisto_amd.Engine(device=local_rank, max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16)
-    data = make_samples(n, args.dist, seed=(3 if c3 else 2) + rank)
-    ids = None
-    if c3:  # id ~ Zipf(1.0) over ranks, value ~ lognormal(ln 1e5 + 0.002*id, 1)
-        g = torch.Generator(device="cuda")
-        g.manual_seed(1003 + rank)
-        w = 1.0 / torch.arange(1, M + 1, dtype=torch.float64, device="cuda")
-        ids = torch.multinomial(w / w.sum(), n, replacement=True, generator=g).to(torch.int32)
-        data.mul_(torch.exp(0.002 * ids.to(torch.float64)))
+    eng = la.Engine(device=torch.cuda.current_device(), max_metrics=1, num_buffers=2, num_lanes=1, lane_samples=1 << 16)
+    data = make_samples(n, args.dist, seed=2 + rank)
     torch.cuda.synchronize()
-    # a non-default stream: the default stream's handle is 0, which the C ABI reads as
-    # "use the engine's own stream" and torch events would then not bracket the kernel
-    stream = torch.cuda.Stream()
-    torch.cuda.set_stream(stream)
+    events = []
 
-    k1_events = []
-
-    def step(timed: bool):
+    def step(timed):
         if timed:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(stream)
-        if c3:
-            eng.submit_pairs_device(ids, data, n, stream=stream)   # P1 + plan + P2 on torch's current stream
-        else:
-            eng.submit_device(0, data, n, stream=stream)       # K1 on torch's current stream
+        eng.submit_device(0, data, n, stream=stream)               # K1 on torch's current stream
         if timed:
             b.record(stream)
-            k1_events.append((a, b))
+            events.append((a, b))
         snap = eng.flip()
-        if world > 1:
-            merge.merge_snapshot(snap, M, plan="allreduce")
-        out = snap.extract(PCTS, M)                            # K2 + D2H + sync
-        snap.release()                                         # K3 (async)
+        out = snap.extract(PCTS, 1)                                # K2 + results on the host
+        snap.release()                                             # K3 (async)
         return out
 
     def fence():
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = step(False)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step(True)
-    fence()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
-    assert int(out["count"].sum()) == n * world, (int(out["count"].sum()), n, world)
-    k1_ms = [a.elapsed_time(b) for a, b in k1_events]
-    k1_avg_ms = sum(k1_ms) / len(k1_ms)
-    achieved = n * bytes_per_sample / (k1_avg_ms * 1e-3) / 1e9
+    dt, out = timed_steps(step, args.steps, args.warmup, fence)
+    assert int(out["count"].sum()) == n
+    k1_ms = sum(a.elapsed_time(b) for a, b in events) / len(events)
 
     # p99 extract latency: flip -> stats on host (BASELINE.json metric, part 2)
     lat = []
@@ -216,55 +202,365 @@ def main():
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         snap = eng.flip()
-        snap.extract(PCTS, M)
+        snap.extract(PCTS, 1)
         lat.append(time.perf_counter() - t1)
         snap.release()
     lat_us = np.array(lat) * 1e6 if lat else np.array([float("nan")])
 
-    result = None
-    if rank == 0:
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_k1_pmc.json")
-        if os.path.exists(pmc):
-            try:
-                # PMC passes cannot run inside this process: the committed rocprofv3 --pmc summary
-                # of this same command supplies HBM bytes per K1 launch (read + write, corrected
-                # as the microarch guide prescribes; see the JSON's "corrections").  It only
-                # applies to the workload it was measured on.
-                j = json.load(open(pmc))
-                if not c3 and n * BYTES_PER_SAMPLE == int(j["algorithmic_bytes_per_launch"]) and args.dist == "lognormal":
-                    traffic = j["hbm_read_bytes_per_launch"] + j["hbm_write_bytes_per_launch"]
-            except Exception:
-                traffic = None
-        result = {
-            "metric": "float64 samples/sec bucketed (1 GPU) + % HBM roofline; p99 extract latency",
-            "value": world * n * args.steps / dt, "unit": "samples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("C3 mixed (uint32 id, float64 value) stream over Zipf(1.0) names, partitioned ingest + "
-                                    "one percentile scan per name per step") if c3 else
-                                   "C2 single-metric float64 stream, one ingest kernel + one percentile scan per step",
-                       "samples_per_gpu_per_step": n, "distribution": args.dist, "metrics": M,
-                       "percentiles": PCTS, "merge": "allreduce(uint64 row) at flip" if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "kernel": "k_scatter_samples+k_plan_*+k_part_hist" if c3 else "k_ingest_single",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": n * bytes_per_sample, "avg_launch_ms": k1_avg_ms,
-                         "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},
-            "extract_latency_us": {"p50": float(np.percentile(lat_us, 50)), "p99": float(np.percentile(lat_us, 99)),
-                                   "flips": len(lat)},
-        }
-        if world == 1 and not args.no_cpu_baseline and not c3:
-            cb, cpu_counts, ncpu = cpu_baseline(data, args.cpu_seconds)
-            # the same samples through the GPU path must give the same row
-            eng.submit_device(0, data[:ncpu], ncpu, stream=stream)
-            with eng.flip() as snap:
-                gpu_row = snap.dense_row(0)
-            assert np.array_equal(gpu_row, cpu_counts), "GPU row differs from the oracle on the baseline sample"
-            result["cpu_baseline"] = cb
-        print(json.dumps(result), flush=True)
+    traffic, traffic_source = None, None
+    pmc = os.path.join(ROOT, K1_PMC)
+    if os.path.exists(pmc):
+        try:
+            # PMC passes cannot run inside this process: the committed rocprofv3 --pmc summary of this same
+            # command supplies HBM bytes per K1 launch (read + write, corrected as the microarch guide
+            # prescribes; see the JSON's "corrections").  It only applies to the workload it was measured on.
+            j = json.load(open(pmc))
+            if n * BYTES_SINGLE == int(j["algorithmic_bytes_per_launch"]) and args.dist == "lognormal":
+                traffic = j["hbm_read_bytes_per_launch"] + j["hbm_write_bytes_per_launch"]
+                traffic_source = f"{K1_PMC} (committed rocprofv3 --pmc summary of this command, not measured in this run)"
+        except Exception:
+            traffic = None
+    res = {
+        "value": n * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+        "config": {"workload": "C2 single-metric float64 stream, one ingest kernel + one percentile scan per step",
+                   "samples_per_gpu_per_step": n, "distribution": args.dist, "metrics": 1, "percentiles": PCTS,
+                   "merge": "none"},
+        "roofline": roofline(n * BYTES_SINGLE, k1_ms, "k_ingest_single", traffic=traffic,
+                             traffic_source=traffic_source, frac_of_measured_copy_ceiling_6290=n * BYTES_SINGLE / (k1_ms * 1e-3) / 1e9 / 6290.0),
+        "extract_latency_us": {"p50": float(np.percentile(lat_us, 50)), "p99": float(np.percentile(lat_us, 99)),
+                               "flips": len(lat), "names": 1},
+    }
+    host = None
+    if not args.no_parity:
+        # the whole step's stream through the oracle on every granted host core: bit-exact bucket counts
+        import oracle
+        eng.submit_device(0, data, n, stream=stream)
+        with eng.flip() as snap:
+            gpu_row = snap.dense_row(0)
+        t0 = time.perf_counter()
+        host = data.cpu().numpy()
+        t_copy = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        want = oracle.histogram_dense_mt(host)
+        t_cpu = time.perf_counter() - t0
+        res["parity"] = {"samples_checked": int(want.sum()), "exact": bool(np.array_equal(gpu_row, want)),
+                         "checker": f"oracle/ (C restatement of metrics.go:316-322 + Go math.Log), {effective_cores()} "
+                                    f"threads, {t_cpu:.2f} s (+ {t_copy:.2f} s for the 8 GB device-to-host copy)"}
+        assert res["parity"]["exact"], "GPU row differs from the oracle over the full stream"
+    if not args.no_cpu_baseline:
+        if host is None:
+            host = data[: 1 << 27].cpu().numpy()
+        res["cpu_baseline"] = cpu_baseline(host, args.cpu_seconds)
+    del host
     eng.close()
+    del data
+    torch.cuda.empty_cache()
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------------
+# C3: 1 024 Zipf names, (id, value) stream
+# ---------------------------------------------------------------------------------------------------------
+def run_c3(args, la, stream, rank, steps, warmup, latency_flips=0):
+    n = int(args.samples)
+    M = args.names or 1024
+    eng = la.Engine(device=torch.cuda.current_device(), max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16)
+    ids = zipf_ids(n, M, 1003 + rank)
+    data = make_samples(n, args.dist, seed=3 + rank)
+    chunk = 1 << 27
+    for lo in range(0, n, chunk):      # value ~ lognormal(ln 1e5 + 0.002*id, 1): every name its own
+        data[lo:lo + chunk].mul_(torch.exp(0.002 * ids[lo:lo + chunk].to(torch.float64)))
+    torch.cuda.synchronize()
+    events = []
+
+    def step(timed):
+        if timed:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+        eng.submit_pairs_device(ids, data, n, stream=stream)       # survey + scatter + plan + P2 on this stream
+        if timed:
+            b.record(stream)
+            events.append((a, b))
+        snap = eng.flip()
+        out = snap.extract(PCTS, M)
+        snap.release()
+        return out
+
+    dt, out = timed_steps(step, steps, warmup, torch.cuda.synchronize)
+    assert int(out["count"].sum()) == n
+    ing_ms = sum(a.elapsed_time(b) for a, b in events) / len(events)
+    c = eng.counters()
+    res = {"value": n * steps / dt, "unit": "samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+           "config": {"workload": "C3 mixed (uint32 id, float64 value) stream over Zipf(1.0) names, one percentile "
+                                  "scan per name per step", "samples_per_step": n, "metrics": M,
+                      "distribution": args.dist, "path": "survey + 2-byte-record scatter + LDS reduce"
+                      if c["samples_partitioned_v2"] else "partitioned (first generation)"},
+           "roofline": roofline(n * BYTES_PAIR, ing_ms,
+                                "k_survey_* + k_scatter2 + k_plan_* + k_part_hist2 (all launches of one lh_submit_pairs_device)"),
+           "scratch_bytes": c["scratch_bytes"], "sublaunches_per_step": c["sublaunches"] // max(1, steps + warmup)}
+    if latency_flips:
+        lat = []
+        sl_i, sl_v = ids[: 1 << 22], data[: 1 << 22]
+        for _ in range(latency_flips):
+            eng.submit_pairs_device(sl_i, sl_v, sl_v.numel(), stream=stream)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            snap = eng.flip()
+            snap.extract(PCTS, M)
+            lat.append(time.perf_counter() - t1)
+            snap.release()
+        lu = np.array(lat) * 1e6
+        res["extract_latency_us"] = {"p50": float(np.percentile(lu, 50)), "p99": float(np.percentile(lu, 99)),
+                                     "flips": len(lat), "names": M}
+    if not args.no_parity:
+        import oracle
+        eng.submit_pairs_device(ids, data, n, stream=stream)
+        with eng.flip() as snap:
+            off, keys, counts = snap.buckets_all(M)
+        t0 = time.perf_counter()
+        want = oracle.histogram_pairs_mt(ids.cpu().numpy().view(np.uint32), data.cpu().numpy(), M)
+        t_cpu = time.perf_counter() - t0
+        exact = bool(np.array_equal(dense_from_csr(off, keys, counts, M), want))
+        res["parity"] = {"samples_checked": int(want.sum()), "rows_checked": M, "exact": exact,
+                         "checker": f"oracle/ over every pair, {effective_cores()} threads, {t_cpu:.1f} s incl. the copy"}
+        assert exact, "GPU cells differ from the oracle over the full C3 stream"
+        del want
+    eng.close()
+    del ids, data
+    torch.cuda.empty_cache()
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------------
+# C4: 65 536 names, data-parallel ingest, reduce-scatter merge through the C ABI
+# ---------------------------------------------------------------------------------------------------------
+def run_c4(args, la, stream, rank, world, dist, steps, warmup):
+    from loghisto_amd import merge as tmerge
+    from loghisto_amd import rccl
+    M = args.names or 65536
+    n = int(args.c4_slice)
+    dev = torch.cuda.current_device()
+    eng = la.Engine(device=dev, max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16)
+    ids = zipf_ids(n, M, 4000 + rank)                       # this rank's slice of a Zipf stream over ALL names
+    data = make_samples(n, "lognormal", seed=40 + rank)
+    data.mul_(torch.exp(3e-5 * ids.to(torch.float64)))
+    torch.cuda.synchronize()
+    # communicator for the C-ABI front-end (what a cgo caller would hold); torch.distributed only carries the id
+    comm, frontend, why = 0, "c-abi: lh_snapshot_merge -> RCCL ncclReduceScatter", ""
+    try:
+        if world > 1:
+            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(rccl.unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, 0)
+            comm = rccl.comm_init_rank(world, bytes(uid.cpu().numpy().tobytes()), rank)
+        else:
+            comm = rccl.comm_init_rank(1, rccl.unique_id(), 0)
+    except Exception as exc:  # noqa: BLE001 -- keep the scaling run alive through the torch.distributed front-end
+        comm, frontend, why = 0, "torch.distributed: loghisto_amd.merge.merge_snapshot (reduce_scatter_tensor)", repr(exc)
+    per = -(-M // world)
+    own = (min(rank * per, M), min((rank + 1) * per, M))
+    t_ing, t_merge, t_ext = [], [], []
+    info = {}
+
+    def step(timed):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        eng.submit_pairs_device(ids, data, n, stream=stream)
+        b.record(stream)
+        snap = eng.flip()
+        if timed:
+            torch.cuda.synchronize()                                 # merge ms below = the merge alone, not the ingest tail
+        t0 = time.perf_counter()
+        if comm:
+            first, last = snap.merge_rccl(comm, world, rank, M, plan="reduce_scatter")
+        elif world > 1:
+            first, last = tmerge.merge_snapshot(snap, M, plan="reduce_scatter")
+        else:
+            first, last = 0, M
+        t1 = time.perf_counter()
+        out = snap.extract(PCTS, last - first, first=first)      # the names this rank owns
+        t2 = time.perf_counter()
+        if timed:
+            info.update(snap.merge_info() if comm else dict(tmerge.last_info))
+        snap.release()
+        if timed:
+            torch.cuda.synchronize()
+            t_ing.append(a.elapsed_time(b))
+            t_merge.append((t1 - t0) * 1e3)
+            t_ext.append((t2 - t1) * 1e3)
+        return out, (first, last)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    dt, (out, (first, last)) = timed_steps(step, steps, warmup, fence)
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert (first, last) == own, ((first, last), own)
+    # parity: every sample of every rank is in exactly one owned row (conservation), per-name counts of the owned
+    # rows equal the all-reduced bincount of the ids
+    per_name = torch.bincount(ids, minlength=M).to(torch.int64)
+    if dist is not None:
+        dist.all_reduce(per_name)
+    counts_ok = bool(np.array_equal(out["count"].astype(np.int64), per_name[first:last].cpu().numpy()))
+    owned_total = torch.tensor([int(out["count"].sum())], dtype=torch.int64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(owned_total)
+    conserved = int(owned_total.item()) == n * world
+    parity = {"per_name_counts_exact": counts_ok, "samples_conserved": conserved, "exact": counts_ok and conserved}
+    if world == 1 and not args.no_parity:
+        # single rank: a sample of rows cell by cell against the oracle (dense matrices of 65 536 names do not fit a test)
+        import oracle
+        eng.submit_pairs_device(ids, data, n, stream=stream)
+        with eng.flip() as snap:
+            probe = sorted({0, 1, 2, 7, 63, 64, 255, 1023, 4095, M // 2, M - 2, M - 1} | set(range(100, 100 + 20)))
+            probe = [m for m in probe if m < M]
+            ok = True
+            for m in probe:
+                sel = data[ids == m].cpu().numpy()
+                ok = ok and np.array_equal(snap.dense_row(m), oracle.histogram_dense(sel))
+        parity.update(rows_checked_cell_by_cell=len(probe), exact=parity["exact"] and bool(ok))
+    assert parity["exact"], parity
+    c = eng.counters()
+    res = {
+        "value": world * n * steps / dt, "unit": "samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+        "config": {"workload": "C4 65536 histogram names, every rank ingests its slice of a Zipf(1.0) stream over ALL "
+                               "names, reduce-scatter merge of the per-row windows at the flip, extract of the owned names",
+                   "names": M, "pairs_per_gpu_per_step": n, "ranks": world, "owned_rows": [first, last],
+                   "merge": frontend, "percentiles": PCTS},
+        "roofline": roofline(n * BYTES_PAIR, sum(t_ing) / len(t_ing),
+                             "k_scatter_samples<hot> + k_scatter_records + k_part_hist (two-level partitioned ingest, "
+                             "all launches of one lh_submit_pairs_device)"),
+        "merge": {"ms": sum(t_merge) / len(t_merge), "packed_cells": info.get("packed_cells"),
+                  "send_bytes": info.get("send_bytes"), "recv_bytes": info.get("recv_bytes"),
+                  "widest_row": info.get("widest_row"), "occupied_rows": info.get("occupied_rows"),
+                  "note": "host wall time of lh_snapshot_merge (range all-reduce, device-side window plan, pack, "
+                          "reduce-scatter, unpack are enqueued; the plan totals come back through pinned memory)"},
+        "extract_owned_ms": sum(t_ext) / len(t_ext), "parity": parity, "scratch_bytes": c["scratch_bytes"],
+    }
+    if why:
+        res["merge_frontend_fallback_reason"] = why
+    if comm:
+        rccl.comm_destroy(comm)
+    eng.close()
+    del ids, data
+    torch.cuda.empty_cache()
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------------
+# host-fed (PCIe-inclusive) and the C5 burst
+# ---------------------------------------------------------------------------------------------------------
+def run_hostfed(la, M=1024, total=int(3e8)):
+    cores = effective_cores()
+    T = max(1, min(16, cores))
+    rng = np.random.default_rng(1)
+    src = rng.lognormal(np.log(1e5), 1.0, 1 << 23)
+    w = 1.0 / np.arange(1, M + 1)
+    ids = rng.choice(M, size=src.size, p=w / w.sum()).astype(np.uint32)
+    batch = 1 << 20
+    eng = la.Engine(device=torch.cuda.current_device(), max_metrics=M, num_buffers=2, num_lanes=T, lane_samples=1 << 21)
+    per = total // T
+
+    def work(t):
+        done, off = 0, (t * 7919 * batch) % (src.size - batch)
+        while done < per:
+            k = min(batch, per - done)
+            eng.submit_pairs(ids[off:off + k], src[off:off + k])
+            done += k
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+    t0 = time.perf_counter()
+    [x.start() for x in th]
+    [x.join() for x in th]
+    eng.sync()
+    dt = time.perf_counter() - t0
+    with eng.flip() as snap:
+        cnt = int(snap.extract([0.5], M)["count"].sum())
+    eng.close()
+    rate = per * T / dt
+    return {"value": rate, "unit": "samples/s", "threads": T, "samples": per * T, "names": M,
+            "config": {"workload": "host arrays through lh_submit_pairs (memcpy into pinned lanes, hipMemcpyAsync, "
+                                   "mixed ingest per lane half-buffer): the path a cgo binding uses"},
+            "roofline": {"bound": "pcie", "achieved": rate * BYTES_PAIR / 1e9, "peak": PCIE_GBS, "unit": "GB/s",
+                         "frac": rate * BYTES_PAIR / 1e9 / PCIE_GBS, "bytes_per_sample": BYTES_PAIR},
+            "parity": {"samples_conserved": cnt == per * T, "exact": cnt == per * T}}
+
+
+def run_c5(seconds=3.0):
+    exe = os.path.join(ROOT, "loghisto_amd", "build", "c5_driver")
+    if not os.path.exists(exe):
+        return {"skipped": "loghisto_amd/build/c5_driver is not built"}
+    r = subprocess.run([exe, "--seconds", str(seconds), "--rate", "1e8", "--bulk", "1"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=120)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"failed": r.stdout[-400:]}
+    j = json.loads(lines[-1])
+    return {"value": j["events_per_s"], "unit": "events/s", "seconds": j["seconds"], "threads": j["threads"],
+            "config": {"workload": j["workload"] + ", 1 s ProcessedMetricSet emit to a Graphite TCP sink (tools/c5_driver.cc)"},
+            "target_events_per_s": j["target_events_per_s"], "dropped_intervals": j["dropped_intervals"],
+            "emit_latency_ms_p50": j.get("emit_latency_ms_p50"),
+            "parity": {"events_accounted": j["events_accounted"], "events_submitted": j["events_submitted"],
+                       "exact": bool(j["lossless"])}}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import loghisto_amd as la
+
+    # a non-default stream: the default stream's handle is 0, which the C ABI reads as "use the engine's own
+    # stream" and torch events would then not bracket the kernels
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    workload = args.workload
+    if workload == "auto":
+        workload = "c2" if world == 1 else "c4"
+    if world > 1 and workload != "c4":
+        raise SystemExit("several GPUs run the C4 workload (data-parallel ingest + merge); use --workload c4 or auto")
+
+    base = {"metric": METRIC, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
+    if workload == "c2":
+        res = run_c2(args, la, stream, rank)
+        if not args.no_secondary:
+            sec = {}
+            for name, fn in (("c3", lambda: run_c3(args, la, stream, rank, steps=5, warmup=2, latency_flips=200)),
+                             ("c4_one_rank", lambda: run_c4(args, la, stream, 0, 1, None, steps=5, warmup=2)),
+                             ("hostfed_pairs", lambda: run_hostfed(la)),
+                             ("c5", run_c5)):
+                try:
+                    sec[name] = fn()
+                except Exception as exc:  # noqa: BLE001 -- a secondary leg must not take the headline down
+                    sec[name] = {"failed": repr(exc)[:300]}
+            res["secondary"] = sec
+    elif workload == "c3":
+        res = run_c3(args, la, stream, rank, args.steps, args.warmup, latency_flips=min(args.latency_flips, 200))
+    else:
+        res = run_c4(args, la, stream, rank, world, dist, args.steps, args.warmup)
+    if rank == 0:
+        res.pop("unit", None)
+        res.pop("steps", None)
+        print(json.dumps({**base, **res}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -77,7 +77,7 @@ typedef struct lh_config {
     uint32_t max_metrics;   /* dense rows per epoch buffer (512 KiB each)     */
     uint32_t num_buffers;   /* epoch buffers, >= 2                            */
     uint32_t num_lanes;     /* host staging lanes (one HIP stream each)       */
-    uint32_t reserved0;
+    uint32_t max_counters;  /* counter names (metrics.go:115), 8 B each per epoch buffer; 0 = no counters */
     uint64_t lane_samples;  /* samples per pinned half-buffer of a lane       */
 } lh_config;
 
@@ -121,6 +121,28 @@ int lh_submit_pairs(lh_engine *e, const uint32_t *ids, const double *v, size_t n
  * caller-owned stream must outlive the next lh_flip, which records an event on it. */
 int lh_submit_device(lh_engine *e, uint32_t id, const double *d_v, size_t n, void *stream);
 int lh_submit_pairs_device(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t n, void *stream);
+/* Counters on the device.  Counter names have their own dense id space.
+ *   (*MetricSystem).Counter           /root/reference/metrics.go:251-269  -> lh_intern_counter + lh_submit_counts
+ *   collectRawMetrics, counter part   /root/reference/metrics.go:425-458  -> lh_flip (steals the interval's amounts
+ *                                     together with the histogram cells) + lh_counters_collect (Rates = the
+ *                                     interval's amounts of the names touched, Counters = lifetime totals of every
+ *                                     name ever touched; the fold into the lifetime store happens once per snapshot)
+ *   processMetrics / serializers      /root/reference/metrics.go:487-493  -> lh_serialize_counters ("<name>" and
+ *                                     "<name>_rate" lines, Go's %f of float64(count))
+ * Same conventions as the histogram ingest: lossless, thread-safe, the caller's buffers are copied. */
+int lh_intern_counter(lh_engine *e, const char *name, size_t len, uint32_t *id);
+int lh_num_counters(lh_engine *e, uint32_t *n);
+int lh_counter_name(lh_engine *e, uint32_t id, char *buf, size_t cap, size_t *len);
+/* Counter(name(ids[i]), amounts[i]) for i < n. */
+int lh_submit_counts(lh_engine *e, const uint32_t *ids, const uint64_t *amounts, size_t n);
+int lh_submit_counts_device(lh_engine *e, const uint32_t *d_ids, const uint64_t *d_amounts, size_t n, void *stream);
+/* Counters [first, first+n) of the snapshot: rate[i] = amount added this interval, present[i] = 1 iff the name was
+ * touched this interval (metrics.go:430-433), total[i] = lifetime total after this interval, known[i] = 1 iff the
+ * name has ever been touched (metrics.go:435-458).  Any output may be NULL. */
+int lh_counters_collect(lh_snapshot *s, uint32_t first, size_t n, uint64_t *rate, uint8_t *present, uint64_t *total,
+                        uint8_t *known);
+/* lh_serialize_counters (declared after lh_line_format below) writes them as wire lines. */
+
 /* Push partially filled staging buffers to the device (asynchronous). */
 int lh_flush(lh_engine *e);
 /* Wait until every sample submitted so far is in the bucket arrays. */
@@ -214,6 +236,11 @@ enum { LH_FMT_UNDERSCORE_TO_DOT = 1 };
 enum { LH_SER_AGGREGATES = 1 };
 int lh_serialize(lh_snapshot *s, uint32_t first, size_t nmetrics, const double *p, const char *const *labels,
                  size_t np, const lh_line_format *fmt, uint32_t flags, char *out, size_t cap, size_t *len);
+/* One line per exported key, counter-major: "<prefix><name><sep>%f<suffix>" for every known counter and
+ * "<prefix><name>_rate<sep>%f<suffix>" for those touched this interval (same lh_line_format and size-then-call
+ * protocol as lh_serialize). */
+int lh_serialize_counters(lh_snapshot *s, uint32_t first, size_t n, const lh_line_format *fmt, char *out, size_t cap,
+                          size_t *len);
 /* processHistograms' lifetime side effect (metrics.go:359-376) for every row of the snapshot, kept in
  * HBM: life_sum[m] += uint64(totalSum_m) (amd64 conversion, wrapping add), life_count[m] += count_m.
  * Applied at most once per snapshot; later calls return LH_OK without effect. */
@@ -246,6 +273,7 @@ typedef struct lh_counters {
     uint64_t scratch_bytes;        /* HBM scratch of the partitioned mixed ingest (one block per engine)  */
     uint64_t sublaunches;          /* partitioned sub-launches (a large launch is cut so the scratch stays bounded) */
     uint64_t samples_partitioned_v2; /* of samples_partitioned: through the survey + 2-byte-record path          */
+    uint64_t counter_events;         /* (id, amount) events through lh_submit_counts*                               */
 } lh_counters;
 int lh_get_counters(lh_engine *e, lh_counters *out);
 

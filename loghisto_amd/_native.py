@@ -21,7 +21,7 @@ OK, EINVAL, ENOMEM, EDEVICE, ENODEVICE, EBUSY, ERANGE, ESTATE = range(8)
 
 class LhConfig(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("max_metrics", C.c_uint32),
-                ("num_buffers", C.c_uint32), ("num_lanes", C.c_uint32), ("reserved0", C.c_uint32),
+                ("num_buffers", C.c_uint32), ("num_lanes", C.c_uint32), ("max_counters", C.c_uint32),
                 ("lane_samples", C.c_uint64)]
 
 
@@ -32,7 +32,8 @@ class LhCounters(C.Structure):
                                                                 ("reserved", C.c_uint32),
                                                                 ("scratch_bytes", C.c_uint64),
                                                                 ("sublaunches", C.c_uint64),
-                                                                ("samples_partitioned_v2", C.c_uint64)]
+                                                                ("samples_partitioned_v2", C.c_uint64),
+                                                                ("counter_events", C.c_uint64)]
 
 # lh_set_option keys (include/loghisto_gpu.h)
 OPT_TWO_LEVEL_ABOVE, OPT_HOT_MIN_TILES, OPT_HOT_WINDOWS, OPT_NAMES_PER_PARTITION = 1, 2, 3, 4
@@ -80,6 +81,13 @@ SIGNATURES = {
     "lh_submit_pairs": (C.c_int, [_vp, _vp, _vp, _sz]),
     "lh_submit_device": (C.c_int, [_vp, C.c_uint32, _vp, _sz, _vp]),
     "lh_submit_pairs_device": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
+    "lh_intern_counter": (C.c_int, [_vp, C.c_char_p, _sz, _u32p]),
+    "lh_num_counters": (C.c_int, [_vp, _u32p]),
+    "lh_counter_name": (C.c_int, [_vp, C.c_uint32, C.c_char_p, _sz, C.POINTER(_sz)]),
+    "lh_submit_counts": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "lh_submit_counts_device": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
+    "lh_counters_collect": (C.c_int, [_vp, C.c_uint32, _sz, _u64p, _u8p, _u64p, _u8p]),
+    "lh_serialize_counters": (C.c_int, [_vp, C.c_uint32, _sz, C.POINTER(LhLineFormat), _vp, _sz, C.POINTER(_sz)]),
     "lh_flush": (C.c_int, [_vp]),
     "lh_sync": (C.c_int, [_vp]),
     "lh_flip": (C.c_int, [_vp, C.POINTER(_vp)]),

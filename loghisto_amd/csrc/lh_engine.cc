@@ -60,11 +60,13 @@ enum BufState { BUF_FREE = 0, BUF_CURRENT = 1, BUF_SNAPSHOT = 2 };
 struct EpochBuffer {
     uint64_t *counts = nullptr;  // [max_metrics][65536]
     uint32_t *ranges = nullptr;  // [max_metrics][2]
+    uint64_t *ccur = nullptr;    // [max_counters] the interval's counter amounts (metrics.go:425-433)
+    uint32_t *cflag = nullptr;   // [max_counters] touched this interval
     hipEvent_t cleared = nullptr; // recorded on xstream after the last clear
     BufState state = BUF_FREE;
 };
 
-enum LaneMode { LANE_NONE = 0, LANE_SINGLE = 1, LANE_PAIRS = 2 };
+enum LaneMode { LANE_NONE = 0, LANE_SINGLE = 1, LANE_PAIRS = 2, LANE_COUNTS = 3 };
 
 struct Lane {
     std::mutex mu;
@@ -151,6 +153,19 @@ struct lh_engine {
     size_t mbuf_bytes = 0;
     lh_merge_info merge_info{};
 
+    // counters (metrics.go:112-117): their own name table, the lifetime store and the "ever touched" flags in HBM
+    std::shared_mutex cnames_mu;
+    std::unordered_map<std::string, uint32_t> cname2id;
+    std::vector<std::string> cnames;
+    std::string cname_blob;
+    std::vector<uint32_t> cname_off{0};
+    char *d_cnames = nullptr;
+    uint32_t *d_cname_off = nullptr;
+    size_t d_cnames_cap = 0, d_cname_off_cap = 0, cnames_uploaded = 0;
+    uint64_t *d_clife = nullptr;   // [max_counters] counterStore
+    uint32_t *d_cknown = nullptr;  // [max_counters]
+    std::atomic<uint64_t> c_counts{0};
+
     std::atomic<int> live_snapshots{0};
 
     // adaptive dispatch of mixed launches with few names: the single-pass kernel reports how many samples
@@ -185,7 +200,8 @@ struct lh_engine {
 struct lh_snapshot {
     lh_engine *e;
     int buf;
-    bool life_applied = false; // lh_snapshot_accumulate ran (xmu)
+    bool life_applied = false;    // lh_snapshot_accumulate ran (xmu)
+    bool counters_folded = false; // the interval's counter amounts are in the lifetime store (xmu)
 };
 
 namespace {
@@ -323,6 +339,15 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
     return LH_OK;
 }
 
+int launch_counts(lh_engine *e, const uint32_t *d_ids, const uint64_t *d_amounts, size_t n, hipStream_t s)
+{
+    EpochBuffer &b = e->bufs[(size_t)e->cur];
+    HIPCHK(lh::launch_count_add(d_ids, d_amounts, n, b.ccur, b.cflag, e->cfg.max_counters, e->d_err, e->num_cus, s));
+    e->c_counts.fetch_add(n, std::memory_order_relaxed);
+    e->c_launches.fetch_add(1, std::memory_order_relaxed);
+    return LH_OK;
+}
+
 // Lane mutex held, epoch lock held (shared or unique).
 int lane_launch(lh_engine *e, Lane &ln)
 {
@@ -335,6 +360,9 @@ int lane_launch(lh_engine *e, Lane &ln)
     if (ln.mode == LANE_PAIRS) {
         HIPCHK(hipMemcpyAsync(ln.d_ids[h], ln.h_ids[h], n * sizeof(uint32_t), hipMemcpyHostToDevice, ln.stream));
         rc = launch_pairs(e, ln.d_ids[h], ln.d_vals[h], n, ln.stream);
+    } else if (ln.mode == LANE_COUNTS) { // the value half-buffer carries uint64 amounts
+        HIPCHK(hipMemcpyAsync(ln.d_ids[h], ln.h_ids[h], n * sizeof(uint32_t), hipMemcpyHostToDevice, ln.stream));
+        rc = launch_counts(e, ln.d_ids[h], reinterpret_cast<const uint64_t *>(ln.d_vals[h]), n, ln.stream);
     } else {
         rc = launch_single(e, ln.single_id, ln.d_vals[h], n, ln.stream);
     }
@@ -387,6 +415,8 @@ void free_engine(lh_engine *e)
     for (auto &b : e->bufs) {
         if (b.counts) (void)hipFree(b.counts);
         if (b.ranges) (void)hipFree(b.ranges);
+        if (b.ccur) (void)hipFree(b.ccur);
+        if (b.cflag) (void)hipFree(b.cflag);
         if (b.cleared) (void)hipEventDestroy(b.cleared);
     }
     for (hipEvent_t ev : e->flip_events) (void)hipEventDestroy(ev);
@@ -403,6 +433,10 @@ void free_engine(lh_engine *e)
     if (e->d_text) (void)hipFree(e->d_text);
     if (e->d_blob) (void)hipFree(e->d_blob);
     if (e->d_mplan) (void)hipFree(e->d_mplan);
+    if (e->d_cnames) (void)hipFree(e->d_cnames);
+    if (e->d_cname_off) (void)hipFree(e->d_cname_off);
+    if (e->d_clife) (void)hipFree(e->d_clife);
+    if (e->d_cknown) (void)hipFree(e->d_cknown);
     if (e->d_mbuf) (void)hipFree(e->d_mbuf);
     if (e->main_stream) (void)hipStreamDestroy(e->main_stream);
     if (e->xstream) (void)hipStreamDestroy(e->xstream);
@@ -463,8 +497,21 @@ int create_impl(const lh_config *cfg_in, lh_engine *e)
     HIPCHK(hipMalloc((void **)&e->d_life, M * 2 * sizeof(uint64_t)));
     HIPCHK(hipMemsetAsync(e->d_life, 0, M * 2 * sizeof(uint64_t), e->xstream));
     HIPCHK(hipMalloc((void **)&e->d_blob, lh::SER_BLOB_MAX));
+    const size_t NC = e->cfg.max_counters;
+    if (NC) {
+        HIPCHK(hipMalloc((void **)&e->d_clife, NC * sizeof(uint64_t)));
+        HIPCHK(hipMalloc((void **)&e->d_cknown, NC * sizeof(uint32_t)));
+        HIPCHK(hipMemsetAsync(e->d_clife, 0, NC * sizeof(uint64_t), e->xstream));
+        HIPCHK(hipMemsetAsync(e->d_cknown, 0, NC * sizeof(uint32_t), e->xstream));
+    }
     e->bufs.resize(e->cfg.num_buffers);
     for (auto &b : e->bufs) {
+        if (NC) {
+            HIPCHK(hipMalloc((void **)&b.ccur, NC * sizeof(uint64_t)));
+            HIPCHK(hipMalloc((void **)&b.cflag, NC * sizeof(uint32_t)));
+            HIPCHK(hipMemsetAsync(b.ccur, 0, NC * sizeof(uint64_t), e->xstream));
+            HIPCHK(hipMemsetAsync(b.cflag, 0, NC * sizeof(uint32_t), e->xstream));
+        }
         HIPCHK(hipMalloc((void **)&b.counts, M * LH_NKEYS * sizeof(uint64_t)));
         HIPCHK(hipMalloc((void **)&b.ranges, M * 2 * sizeof(uint32_t)));
         HIPCHK(hipMemsetAsync(b.counts, 0, M * LH_NKEYS * sizeof(uint64_t), e->xstream));
@@ -525,6 +572,7 @@ int lh_default_config(lh_config *cfg)
     cfg->max_metrics = 1024;
     cfg->num_buffers = 2;
     cfg->num_lanes = 4;
+    cfg->max_counters = 1024;
     cfg->lane_samples = 1u << 20; // 8 MiB of float64 per half-buffer
     return LH_OK;
 }
@@ -535,7 +583,8 @@ int lh_create(const lh_config *cfg, lh_engine **out)
     *out = nullptr;
     if (cfg->struct_size != sizeof(lh_config)) return LH_EINVAL;
     if (cfg->max_metrics == 0 || cfg->num_buffers < 2 || cfg->num_buffers > 16 || cfg->num_lanes == 0 ||
-        cfg->num_lanes > 256 || cfg->lane_samples < 2 || cfg->lane_samples > (1ull << 28))
+        cfg->num_lanes > 256 || cfg->lane_samples < 2 || cfg->lane_samples > (1ull << 28) ||
+        cfg->max_counters > (1u << 24))
         return LH_EINVAL;
     lh_engine *e = new (std::nothrow) lh_engine();
     if (!e) return LH_ENOMEM;
@@ -710,6 +759,96 @@ int lh_submit_pairs_device(lh_engine *e, const uint32_t *d_ids, const double *d_
     rc = epoch_touch_stream(e, s);
     if (rc) return rc;
     return launch_pairs(e, d_ids, d_v, n, s);
+}
+
+int lh_intern_counter(lh_engine *e, const char *name, size_t len, uint32_t *id)
+{
+    if (!e || (!name && len) || !id) return LH_EINVAL;
+    std::string key(name ? name : "", len);
+    {
+        std::shared_lock<std::shared_mutex> g(e->cnames_mu);
+        auto it = e->cname2id.find(key);
+        if (it != e->cname2id.end()) { *id = it->second; return LH_OK; }
+    }
+    std::unique_lock<std::shared_mutex> g(e->cnames_mu);
+    auto it = e->cname2id.find(key);
+    if (it != e->cname2id.end()) { *id = it->second; return LH_OK; }
+    if (e->cnames.size() >= e->cfg.max_counters) return LH_ERANGE;
+    if (e->cname_blob.size() + key.size() > (size_t(1) << 31)) return LH_ERANGE;
+    const uint32_t nid = (uint32_t)e->cnames.size();
+    e->cnames.push_back(key);
+    e->cname_blob += key;
+    e->cname_off.push_back((uint32_t)e->cname_blob.size());
+    e->cname2id.emplace(std::move(key), nid);
+    *id = nid;
+    return LH_OK;
+}
+
+int lh_num_counters(lh_engine *e, uint32_t *n)
+{
+    if (!e || !n) return LH_EINVAL;
+    std::shared_lock<std::shared_mutex> g(e->cnames_mu);
+    *n = (uint32_t)e->cnames.size();
+    return LH_OK;
+}
+
+int lh_counter_name(lh_engine *e, uint32_t id, char *buf, size_t cap, size_t *len)
+{
+    if (!e || !len || (!buf && cap)) return LH_EINVAL;
+    std::shared_lock<std::shared_mutex> g(e->cnames_mu);
+    if (id >= e->cnames.size()) return LH_ERANGE;
+    const std::string &s = e->cnames[id];
+    *len = s.size();
+    if (cap) std::memcpy(buf, s.data(), s.size() < cap ? s.size() : cap);
+    return LH_OK;
+}
+
+int lh_submit_counts(lh_engine *e, const uint32_t *ids, const uint64_t *amounts, size_t n)
+{
+    if (!e || ((!ids || !amounts) && n)) return LH_EINVAL;
+    if (n == 0) return LH_OK;
+    for (size_t i = 0; i < n; i++)
+        if (ids[i] >= e->cfg.max_counters) return LH_ERANGE;
+    int rc = use_device(e);
+    if (rc) return rc;
+    std::shared_lock<std::shared_mutex> eg(e->epoch_mu);
+    Lane &ln = pick_lane(e);
+    std::lock_guard<std::mutex> g(ln.mu);
+    if (ln.fill && ln.mode != LANE_COUNTS) {
+        rc = lane_launch(e, ln);
+        if (rc) return rc;
+    }
+    const size_t cap = (size_t)e->cfg.lane_samples;
+    while (n) {
+        ln.mode = LANE_COUNTS;
+        const size_t take = (cap - ln.fill) < n ? (cap - ln.fill) : n;
+        std::memcpy(ln.h_vals[ln.cur] + ln.fill, amounts, take * sizeof(uint64_t)); // same 8-byte slots as float64
+        std::memcpy(ln.h_ids[ln.cur] + ln.fill, ids, take * sizeof(uint32_t));
+        ln.fill += take;
+        amounts += take;
+        ids += take;
+        n -= take;
+        if (ln.fill == cap) {
+            rc = lane_launch(e, ln);
+            if (rc) return rc;
+        }
+    }
+    return LH_OK;
+}
+
+int lh_submit_counts_device(lh_engine *e, const uint32_t *d_ids, const uint64_t *d_amounts, size_t n, void *stream)
+{
+    if (!e || ((!d_ids || !d_amounts) && n)) return LH_EINVAL;
+    if (((uintptr_t)d_amounts & 7) != 0 || ((uintptr_t)d_ids & 3) != 0) return LH_EINVAL;
+    if (e->cfg.max_counters == 0) return LH_ERANGE;
+    if (n == 0) return LH_OK;
+    int rc = use_device(e);
+    if (rc) return rc;
+    hipStream_t s = stream ? (hipStream_t)stream : e->main_stream;
+    std::shared_lock<std::shared_mutex> eg(e->epoch_mu);
+    rc = epoch_touch_stream(e, s);
+    if (rc) return rc;
+    return launch_counts(e, d_ids, d_amounts, n, s);
 }
 
 int lh_flush(lh_engine *e)
@@ -1410,6 +1549,147 @@ int lh_format_f(lh_engine *e, const double *v, size_t n, char *out, size_t slot,
     return LH_OK;
 }
 
+namespace {
+// the interval's counter amounts go into the lifetime store exactly once per snapshot (xmu held)
+int fold_counters(lh_snapshot *s)
+{
+    lh_engine *e = s->e;
+    if (s->counters_folded || !e->cfg.max_counters) return LH_OK;
+    EpochBuffer &b = e->bufs[(size_t)s->buf];
+    HIPCHK(lh::launch_count_fold(b.ccur, b.cflag, e->d_clife, e->d_cknown, e->cfg.max_counters, e->xstream));
+    s->counters_folded = true;
+    return LH_OK;
+}
+} // namespace
+
+int lh_counters_collect(lh_snapshot *s, uint32_t first, size_t n, uint64_t *rate, uint8_t *present, uint64_t *total,
+                        uint8_t *known)
+{
+    if (!s) return LH_EINVAL;
+    lh_engine *e = s->e;
+    if ((uint64_t)first + n > e->cfg.max_counters) return LH_EINVAL;
+    int rc = use_device(e);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(e->xmu);
+    rc = fold_counters(s);
+    if (rc || n == 0) return rc;
+    EpochBuffer &b = e->bufs[(size_t)s->buf];
+    const size_t o_rate = 0, o_total = n * 8, o_flag = 2 * n * 8, o_known = o_flag + n * 4, bytes = o_known + n * 4;
+    rc = ensure_xbuf(e, bytes);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(e->h_xbuf + o_rate, b.ccur + first, n * 8, hipMemcpyDeviceToHost, e->xstream));
+    HIPCHK(hipMemcpyAsync(e->h_xbuf + o_total, e->d_clife + first, n * 8, hipMemcpyDeviceToHost, e->xstream));
+    HIPCHK(hipMemcpyAsync(e->h_xbuf + o_flag, b.cflag + first, n * 4, hipMemcpyDeviceToHost, e->xstream));
+    HIPCHK(hipMemcpyAsync(e->h_xbuf + o_known, e->d_cknown + first, n * 4, hipMemcpyDeviceToHost, e->xstream));
+    HIPCHK(hipStreamSynchronize(e->xstream));
+    if (rate) std::memcpy(rate, e->h_xbuf + o_rate, n * 8);
+    if (total) std::memcpy(total, e->h_xbuf + o_total, n * 8);
+    const uint32_t *hf = reinterpret_cast<const uint32_t *>(e->h_xbuf + o_flag);
+    const uint32_t *hk = reinterpret_cast<const uint32_t *>(e->h_xbuf + o_known);
+    for (size_t i = 0; i < n; i++) {
+        if (present) present[i] = hf[i] ? 1 : 0;
+        if (known) known[i] = hk[i] ? 1 : 0;
+    }
+    return LH_OK;
+}
+
+int lh_serialize_counters(lh_snapshot *s, uint32_t first, size_t n, const lh_line_format *fmt, char *out, size_t cap,
+                          size_t *len)
+{
+    if (!s || !fmt || !len || (cap && !out)) return LH_EINVAL;
+    if (!fmt->prefix || !fmt->sep || !fmt->suffix) return LH_EINVAL;
+    *len = 0;
+    lh_engine *e = s->e;
+    if ((uint64_t)first + n > e->cfg.max_counters) return LH_EINVAL;
+    if (n == 0) return LH_OK;
+    int rc = use_device(e);
+    if (rc) return rc;
+    lh::SerArgs a{};
+    BlobBuilder bb;
+    bb.dots = (fmt->flags & LH_FMT_UNDERSCORE_TO_DOT) != 0;
+    bb.put(fmt->prefix, false, &a.prefix_off, &a.prefix_len);
+    bb.put(fmt->sep, false, &a.sep_off, &a.sep_len);
+    bb.put(fmt->suffix, false, &a.suffix_off, &a.suffix_len);
+    bb.key("", "", &a.keys[0]);      // metrics.go:487-489: the counter's name is the key
+    bb.key("", "_rate", &a.keys[1]); // metrics.go:491-493
+    if (!bb.ok) return LH_EINVAL;
+    std::lock_guard<std::mutex> g(e->xmu);
+    rc = fold_counters(s);
+    if (rc) return rc;
+    size_t nnames = 0;
+    {   // counter names interned since the last call go to HBM
+        std::shared_lock<std::shared_mutex> ng(e->cnames_mu);
+        nnames = e->cnames.size();
+        if (e->cnames_uploaded != nnames || !e->d_cname_off) {
+            const size_t nbytes = e->cname_blob.size();
+            if (nbytes + 1 > e->d_cnames_cap) {
+                if (e->d_cnames) (void)hipFree(e->d_cnames);
+                e->d_cnames = nullptr;
+                e->d_cnames_cap = 0;
+                HIPCHK(hipMalloc((void **)&e->d_cnames, 2 * nbytes + 4096));
+                e->d_cnames_cap = 2 * nbytes + 4096;
+            }
+            if (nnames + 1 > e->d_cname_off_cap) {
+                if (e->d_cname_off) (void)hipFree(e->d_cname_off);
+                e->d_cname_off = nullptr;
+                e->d_cname_off_cap = 0;
+                HIPCHK(hipMalloc((void **)&e->d_cname_off, (2 * (nnames + 1) + 1024) * sizeof(uint32_t)));
+                e->d_cname_off_cap = 2 * (nnames + 1) + 1024;
+            }
+            if (nbytes) HIPCHK(hipMemcpyAsync(e->d_cnames, e->cname_blob.data(), nbytes, hipMemcpyHostToDevice, e->xstream));
+            HIPCHK(hipMemcpyAsync(e->d_cname_off, e->cname_off.data(), (nnames + 1) * sizeof(uint32_t),
+                                  hipMemcpyHostToDevice, e->xstream));
+            HIPCHK(hipStreamSynchronize(e->xstream));
+            e->cnames_uploaded = nnames;
+        }
+    }
+    if ((uint64_t)first + n > nnames) return LH_EINVAL; // every counter in the range must have a name
+    EpochBuffer &b = e->bufs[(size_t)s->buf];
+    const uint64_t nlines = (uint64_t)n * 2;
+    const uint32_t nb = lh::ser_blocks(nlines);
+    const size_t off_lens = 0;
+    const size_t off_bsum = (nlines * 4 + 15) & ~size_t(15);
+    const size_t off_boff = off_bsum + (((size_t)nb * 4 + 15) & ~size_t(15));
+    rc = ensure_xbuf(e, off_boff + ((size_t)nb + 1) * 8);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(e->d_blob, bb.bytes.data(), bb.bytes.size(), hipMemcpyHostToDevice, e->xstream));
+    a.c_total = e->d_clife;
+    a.c_rate = b.ccur;
+    a.c_known = e->d_cknown;
+    a.c_present = b.cflag;
+    a.names = e->d_cnames;
+    a.name_off = e->d_cname_off;
+    a.blob = e->d_blob;
+    a.blob_len = (uint32_t)bb.bytes.size();
+    a.first = first;
+    a.nmetrics = (uint32_t)n;
+    a.np = 0;
+    a.nkeys = 2;
+    a.flags = (bb.dots ? lh::SER_DOTS : 0u) | lh::SER_COUNTERS;
+    uint32_t *d_lens = reinterpret_cast<uint32_t *>(e->d_xbuf + off_lens);
+    uint32_t *d_bsum = reinterpret_cast<uint32_t *>(e->d_xbuf + off_bsum);
+    uint64_t *d_boff = reinterpret_cast<uint64_t *>(e->d_xbuf + off_boff);
+    HIPCHK(lh::launch_ser_len(a, d_lens, d_bsum, d_boff, e->xstream));
+    HIPCHK(hipMemcpyAsync(e->h_xbuf, d_boff + nb, 8, hipMemcpyDeviceToHost, e->xstream));
+    HIPCHK(hipStreamSynchronize(e->xstream)); // also keeps bb.bytes alive until the blob copy is done
+    uint64_t total = 0;
+    std::memcpy(&total, e->h_xbuf, 8);
+    *len = (size_t)total;
+    if (total == 0 || total > cap) return LH_OK;
+    if (total + 16 > e->d_text_cap) {
+        if (e->d_text) (void)hipFree(e->d_text);
+        e->d_text = nullptr;
+        e->d_text_cap = 0;
+        const size_t want = (size_t)total + (size_t)total / 4 + 4096;
+        HIPCHK(hipMalloc((void **)&e->d_text, want));
+        e->d_text_cap = want;
+    }
+    HIPCHK(lh::launch_ser_write(a, d_lens, d_boff, e->d_text, e->xstream));
+    HIPCHK(hipMemcpyAsync(out, e->d_text, (size_t)total, hipMemcpyDeviceToHost, e->xstream));
+    HIPCHK(hipStreamSynchronize(e->xstream));
+    return LH_OK;
+}
+
 int lh_snapshot_stream(lh_snapshot *s, void **stream)
 {
     if (!s || !stream) return LH_EINVAL;
@@ -1427,6 +1707,10 @@ int lh_release(lh_snapshot *s)
     {
         std::lock_guard<std::mutex> g(e->xmu);
         HIPCHK(lh::launch_clear(b.counts, b.ranges, e->cfg.max_metrics, e->xstream));
+        if (e->cfg.max_counters) {
+            HIPCHK(hipMemsetAsync(b.ccur, 0, (size_t)e->cfg.max_counters * sizeof(uint64_t), e->xstream));
+            HIPCHK(hipMemsetAsync(b.cflag, 0, (size_t)e->cfg.max_counters * sizeof(uint32_t), e->xstream));
+        }
         HIPCHK(hipEventRecord(b.cleared, e->xstream));
     }
     {
@@ -1456,6 +1740,7 @@ int lh_get_counters(lh_engine *e, lh_counters *out)
     out->scratch_bytes = e->c_scratch.load();
     out->sublaunches = e->c_sublaunches.load();
     out->samples_partitioned_v2 = e->c_part2.load();
+    out->counter_events = e->c_counts.load();
     return LH_OK;
 }
 

@@ -56,6 +56,13 @@ hipError_t launch_ingest_pairs_part(const uint32_t *d_ids, const double *d_v, si
                                     void *scratch, size_t scratch_bytes, int num_cus, const PartTuning &tune,
                                     hipStream_t s);
 
+// Counters (metrics.go:251-269): cur[id] += amount, flag[id] = touched; the fold adds the interval into the lifetime
+// store (metrics.go:435-458).
+hipError_t launch_count_add(const uint32_t *d_ids, const uint64_t *d_amounts, size_t n, uint64_t *cur, uint32_t *flag,
+                            uint32_t ncounters, uint32_t *d_err, int num_cus, hipStream_t s);
+hipError_t launch_count_fold(const uint64_t *cur, const uint32_t *flag, uint64_t *life, uint32_t *known,
+                             uint32_t ncounters, hipStream_t s);
+
 // Second generation (lh_kernels_part2.h): one survey per launch, 2-byte records, line-granular copy-out.
 // part2_scratch_bytes returns 0 when the launch should take the first-generation path.
 size_t part2_scratch_bytes(size_t n, uint32_t nmetrics, int num_cus, const PartTuning &tune);
@@ -99,6 +106,7 @@ hipError_t launch_unpack_rows(uint64_t *counts, const uint32_t *ranges, const ui
 // K6 (lh_kernels_fmt.hip): ProcessedMetricSet keys + Go "%f" + wire lines, one thread per (metric, key).
 struct SerKey { uint16_t pre_off, pre_len, post_off, post_len; }; // key = pre + name + post, strings in the blob
 constexpr uint32_t SER_DOTS = 1u;                                 // '_' -> '.' in the name (graphite.go:42)
+constexpr uint32_t SER_COUNTERS = 2u;                             // counter mode: keys "<name>" and "<name>_rate"
 constexpr uint32_t SER_MAX_KEYS = 3 + 32 + 3;                     // _count _sum _avg, percentiles, _agg_*
 constexpr uint32_t SER_BLOB_MAX = 2048;
 constexpr uint32_t SER_FMT_SLOT = 336;                            // longest "%f" of a float64 is 317 bytes
@@ -110,6 +118,12 @@ struct SerArgs {
     const char *names;        // name bytes of every interned metric, back to back
     const uint32_t *name_off; // [num_names + 1]
     const char *blob;         // prefix | sep | suffix | key strings
+    // counter mode (SER_COUNTERS): key 0 = lifetime total of a known counter (metrics.go:487-489), key 1 = the
+    // interval's amount of a counter touched this interval (metrics.go:491-493)
+    const uint64_t *c_total;
+    const uint64_t *c_rate;
+    const uint32_t *c_known;
+    const uint32_t *c_present;
     uint32_t blob_len, first, nmetrics, np, nkeys, flags;
     uint32_t prefix_off, prefix_len, sep_off, sep_len, suffix_off, suffix_len;
     SerKey keys[SER_MAX_KEYS];

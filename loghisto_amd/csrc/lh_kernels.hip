@@ -18,6 +18,7 @@
 #include "lh_kernels.h"
 #include "lh_codec.h"
 
+#include <algorithm>
 #include <atomic>
 
 namespace lh {
@@ -266,6 +267,90 @@ hipError_t launch_ingest_pairs(const uint32_t *d_ids, const double *d_v, size_t 
     if (grid == 0) grid = 1;
     hipLaunchKernelGGL(k_ingest_pairs, dim3(grid), dim3(KP_BLOCK), 0, s, d_ids, d_v, n, counts, ranges,
                        nmetrics, d_Tx, d_err, vec);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Counters: counterCache[name] += amount (metrics.go:251-269) for a batch of (id, amount) events.
+// cur[id] collects the interval's amounts (the reference's Rates, metrics.go:430-433); flag[id] records that
+// the name was touched this interval (Counter(name, 0) still creates the entry and exports a rate of 0).
+// Up to CNT_LDS_NAMES counters are first summed in LDS (uint64 LDS atomics), one global atomic per touched
+// name per workgroup; beyond that every event is one global atomic.
+// ---------------------------------------------------------------------------
+constexpr int CNT_BLOCK = 256;
+constexpr uint32_t CNT_LDS_NAMES = 4096;
+
+__global__ __launch_bounds__(CNT_BLOCK) void k_count_add(const uint32_t *__restrict__ ids,
+                                                         const unsigned long long *__restrict__ amounts, size_t n,
+                                                         unsigned long long *__restrict__ cur,
+                                                         uint32_t *__restrict__ flag, uint32_t ncounters,
+                                                         uint32_t *__restrict__ err)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char cnt_smem[];
+    unsigned long long *s_sum = reinterpret_cast<unsigned long long *>(cnt_smem);
+    uint32_t *s_flag = reinterpret_cast<uint32_t *>(s_sum + CNT_LDS_NAMES);
+    const bool lds = ncounters <= CNT_LDS_NAMES;
+    if (lds) {
+        for (uint32_t i = threadIdx.x; i < ncounters; i += CNT_BLOCK) { s_sum[i] = 0; s_flag[i] = 0; }
+        __syncthreads();
+    }
+    const size_t gsz = (size_t)gridDim.x * CNT_BLOCK;
+    for (size_t i = (size_t)blockIdx.x * CNT_BLOCK + threadIdx.x; i < n; i += gsz) {
+        const uint32_t id = ids[i];
+        if (id >= ncounters) { atomicOr(err, 1u); continue; }
+        const unsigned long long a = amounts[i];
+        if (lds) {
+            atomicAdd(&s_sum[id], a);
+            s_flag[id] = 1u;
+        } else {
+            atomicAdd(&cur[id], a);
+            if (!flag[id]) atomicOr(&flag[id], 1u);
+        }
+    }
+    if (lds) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < ncounters; i += CNT_BLOCK) {
+            if (s_flag[i]) {
+                if (s_sum[i]) atomicAdd(&cur[i], s_sum[i]);
+                if (!flag[i]) atomicOr(&flag[i], 1u);
+            }
+        }
+    }
+}
+
+// The fold at the epoch boundary (metrics.go:435-458): counterStore[name] += the interval's amount for every
+// name touched this interval; flag bit 1 = the name exists in the store.  Applied once per snapshot.
+__global__ void k_count_fold(const unsigned long long *__restrict__ cur, const uint32_t *__restrict__ flag,
+                             unsigned long long *__restrict__ life, uint32_t *__restrict__ known, uint32_t ncounters)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ncounters && flag[i]) {
+        life[i] += cur[i];
+        known[i] = 1u;
+    }
+}
+
+hipError_t launch_count_add(const uint32_t *d_ids, const uint64_t *d_amounts, size_t n, uint64_t *cur, uint32_t *flag,
+                            uint32_t ncounters, uint32_t *d_err, int num_cus, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    const size_t lds = ncounters <= CNT_LDS_NAMES ? (size_t)CNT_LDS_NAMES * 12 : 0;
+    size_t want = (n + CNT_BLOCK * 8 - 1) / (CNT_BLOCK * 8);
+    const size_t cap = (size_t)num_cus * 4;
+    const unsigned grid = (unsigned)std::max<size_t>(1, std::min(want, cap));
+    hipLaunchKernelGGL(k_count_add, dim3(grid), dim3(CNT_BLOCK), lds, s, d_ids,
+                       reinterpret_cast<const unsigned long long *>(d_amounts), n,
+                       reinterpret_cast<unsigned long long *>(cur), flag, ncounters, d_err);
+    return hipGetLastError();
+}
+
+hipError_t launch_count_fold(const uint64_t *cur, const uint32_t *flag, uint64_t *life, uint32_t *known,
+                             uint32_t ncounters, hipStream_t s)
+{
+    if (!ncounters) return hipSuccess;
+    hipLaunchKernelGGL(k_count_fold, dim3((ncounters + 255) / 256), dim3(256), 0, s,
+                       reinterpret_cast<const unsigned long long *>(cur), flag,
+                       reinterpret_cast<unsigned long long *>(life), known, ncounters);
     return hipGetLastError();
 }
 

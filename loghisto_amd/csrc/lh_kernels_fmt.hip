@@ -172,6 +172,12 @@ template <bool WRITE> __device__ __forceinline__ uint32_t fmt_f(double v, char *
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ bool line_value(const SerArgs &a, uint32_t m, uint32_t j, double *v)
 {
+    if (a.flags & SER_COUNTERS) { // float64(count), metrics.go:488, 492
+        const size_t c = (size_t)a.first + m;
+        if (j == 0) { *v = (double)a.c_total[c]; return a.c_known[c] != 0; }
+        *v = (double)a.c_rate[c];
+        return a.c_present[c] != 0;
+    }
     const ExtractOut &st = a.stats[m];
     if (!st.present) return false;
     if (j == 0) { *v = (double)st.count; return true; }  // metrics.go:349

@@ -119,6 +119,36 @@ class Snapshot:
             N.check(rc, "lh_serialize")
         return buf.raw[:n.value]
 
+    def counter_values(self, n: Optional[int] = None, first: int = 0):
+        """Counters [first, first+n) of the interval (lh_counters_collect): dict(rate, present, total, known).
+        rate = the interval's amounts of the names touched (metrics.go:430-433), total = lifetime store
+        after the fold (metrics.go:435-458)."""
+        if n is None:
+            n = self.engine.num_counters() - first
+        rate, total = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+        present, known = np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+        u64p, u8p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint8)
+        N.check(N.lib().lh_counters_collect(self._h, first, n, rate.ctypes.data_as(u64p), present.ctypes.data_as(u8p),
+                                            total.ctypes.data_as(u64p), known.ctypes.data_as(u8p)), "lh_counters_collect")
+        return dict(rate=rate, present=present.astype(bool), total=total, known=known.astype(bool))
+
+    def serialize_counters(self, prefix: str, sep: str, suffix: str, underscore_to_dot: bool = False,
+                           n: Optional[int] = None, first: int = 0) -> bytes:
+        """"<name>" / "<name>_rate" wire lines of the counters, formatted on the device (lh_serialize_counters)."""
+        L = N.lib()
+        if n is None:
+            n = self.engine.num_counters() - first
+        fmt = N.LhLineFormat(prefix.encode(), sep.encode(), suffix.encode(),
+                             N.FMT_UNDERSCORE_TO_DOT if underscore_to_dot else 0, 0)
+        ln = C.c_size_t(0)
+        N.check(L.lh_serialize_counters(self._h, first, n, C.byref(fmt), None, 0, C.byref(ln)), "lh_serialize_counters")
+        if ln.value == 0:
+            return b""
+        buf = C.create_string_buffer(ln.value)
+        N.check(L.lh_serialize_counters(self._h, first, n, C.byref(fmt), buf, ln.value, C.byref(ln)),
+                "lh_serialize_counters")
+        return buf.raw[:ln.value]
+
     def accumulate(self):
         """processHistograms' lifetime side effect (metrics.go:359-376), once per snapshot, in HBM."""
         N.check(N.lib().lh_snapshot_accumulate(self._h), "lh_snapshot_accumulate")
@@ -178,12 +208,12 @@ class Snapshot:
 
 class Engine:
     def __init__(self, device: int = 0, max_metrics: int = 1024, num_buffers: int = 2, num_lanes: int = 4,
-                 lane_samples: int = 1 << 20):
+                 lane_samples: int = 1 << 20, max_counters: int = 1024):
         L = N.lib()
         cfg = N.LhConfig()
         N.check(L.lh_default_config(C.byref(cfg)), "lh_default_config")
         cfg.device, cfg.max_metrics, cfg.num_buffers = device, max_metrics, num_buffers
-        cfg.num_lanes, cfg.lane_samples = num_lanes, lane_samples
+        cfg.num_lanes, cfg.lane_samples, cfg.max_counters = num_lanes, lane_samples, max_counters
         h = C.c_void_p(0)
         N.check(L.lh_create(C.byref(cfg), C.byref(h)), "lh_create")
         self._h = h
@@ -237,6 +267,36 @@ class Engine:
         n = int(d_values.numel()) if n is None else n
         N.check(N.lib().lh_submit_pairs_device(self._h, _ptr(d_ids), _ptr(d_values), n, _stream_handle(stream)),
                 "lh_submit_pairs_device")
+
+    # -- counters (metrics.go:251-269) -----------------------------------------
+    def intern_counter(self, name: str) -> int:
+        b = name.encode()
+        out = C.c_uint32(0)
+        N.check(N.lib().lh_intern_counter(self._h, b, len(b), C.byref(out)), "lh_intern_counter")
+        return int(out.value)
+
+    def num_counters(self) -> int:
+        out = C.c_uint32(0)
+        N.check(N.lib().lh_num_counters(self._h, C.byref(out)), "lh_num_counters")
+        return int(out.value)
+
+    def counter_name(self, cid: int) -> str:
+        ln = C.c_size_t(0)
+        buf = C.create_string_buffer(4096)
+        N.check(N.lib().lh_counter_name(self._h, cid, buf, 4096, C.byref(ln)), "lh_counter_name")
+        return buf.raw[:min(ln.value, 4096)].decode()
+
+    def submit_counts(self, ids, amounts):
+        i = np.ascontiguousarray(ids, dtype=np.uint32)
+        a = np.ascontiguousarray(amounts, dtype=np.uint64)
+        if i.size != a.size:
+            raise ValueError("ids and amounts differ in length")
+        N.check(N.lib().lh_submit_counts(self._h, i.ctypes.data, a.ctypes.data, a.size), "lh_submit_counts")
+
+    def submit_counts_device(self, d_ids, d_amounts, n: Optional[int] = None, stream=None):
+        n = int(d_amounts.numel()) if n is None else n
+        N.check(N.lib().lh_submit_counts_device(self._h, _ptr(d_ids), _ptr(d_amounts), n, _stream_handle(stream)),
+                "lh_submit_counts_device")
 
     def flush(self):
         N.check(N.lib().lh_flush(self._h), "lh_flush")

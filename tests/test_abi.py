@@ -35,7 +35,7 @@ def test_struct_layouts_match_header(native_lib):
     from loghisto_amd import _native
     assert C.sizeof(_native.LhConfig) == 32
     assert C.sizeof(_native.LhStats) == 40
-    assert C.sizeof(_native.LhLineFormat) == 32 and C.sizeof(_native.LhCounters) == 112
+    assert C.sizeof(_native.LhLineFormat) == 32 and C.sizeof(_native.LhCounters) == 120
     cfg = _native.LhConfig()
     assert native_lib.lh_default_config(C.byref(cfg)) == 0
     assert cfg.struct_size == 32 and cfg.max_metrics >= 1 and cfg.num_buffers >= 2
@@ -59,6 +59,10 @@ def test_argument_validation_needs_no_gpu(native_lib):
     assert native_lib.lh_lifetime(None, 0, 1, None, None) == _native.EINVAL
     assert native_lib.lh_format_f(None, None, 1, None, 336, None) == _native.EINVAL
     assert native_lib.lh_set_option(None, 1, 0) == _native.EINVAL
+    assert native_lib.lh_intern_counter(None, b"c", 1, None) == _native.EINVAL
+    assert native_lib.lh_submit_counts(None, None, None, 1) == _native.EINVAL
+    assert native_lib.lh_counters_collect(None, 0, 1, None, None, None, None) == _native.EINVAL
+    assert native_lib.lh_serialize_counters(None, 0, 1, C.byref(fmt), None, 0, C.byref(n)) == _native.EINVAL
 
 
 def test_product_build_never_reads_the_environment(native_lib):
