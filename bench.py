@@ -379,7 +379,8 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup):
         else:
             first, last = 0, M
         t1 = time.perf_counter()
-        out = snap.extract(PCTS, last - first, first=first)      # the names this rank owns
+        out = snap.extract_view(PCTS, last - first, first=first) # the names this rank owns, results in place (pinned)
+        out = {k: v.copy() for k, v in out.items() if k in ("count",)}
         t2 = time.perf_counter()
         if timed:
             info.update(snap.merge_info() if comm else dict(tmerge.last_info))
@@ -427,6 +428,22 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup):
                 ok = ok and np.array_equal(snap.dense_row(m), oracle.histogram_dense(sel))
         parity.update(rows_checked_cell_by_cell=len(probe), exact=parity["exact"] and bool(ok))
     assert parity["exact"], parity
+    lat_c4 = None
+    if world == 1 and steps:
+        # flip -> results of ALL 65 536 names on the host (in place, lh_extract_rows_view), small intervals
+        lat = []
+        sl_i, sl_v = ids[: 1 << 22], data[: 1 << 22]
+        for _ in range(100):
+            eng.submit_pairs_device(sl_i, sl_v, sl_v.numel(), stream=stream)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            snap = eng.flip()
+            snap.extract_view(PCTS, M)
+            lat.append(time.perf_counter() - t1)
+            snap.release()
+        lu = np.array(lat[10:]) * 1e6
+        lat_c4 = {"p50": float(np.percentile(lu, 50)), "p99": float(np.percentile(lu, 99)), "flips": len(lu),
+                  "names": M, "api": "lh_extract_rows_view (results in place, pinned memory)"}
     c = eng.counters()
     res = {
         "value": world * n * steps / dt, "unit": "samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
@@ -444,6 +461,8 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup):
                           "reduce-scatter, unpack are enqueued; the plan totals come back through pinned memory)"},
         "extract_owned_ms": sum(t_ext) / len(t_ext), "parity": parity, "scratch_bytes": c["scratch_bytes"],
     }
+    if lat_c4:
+        res["extract_latency_us"] = lat_c4
     if why:
         res["merge_frontend_fallback_reason"] = why
     if comm:
@@ -457,11 +476,11 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup):
 # ---------------------------------------------------------------------------------------------------------
 # host-fed (PCIe-inclusive) and the C5 burst
 # ---------------------------------------------------------------------------------------------------------
-def run_hostfed(la, M=1024, total=int(3e8)):
+def run_hostfed(la, M=1024, total=int(8e8)):
     cores = effective_cores()
     T = max(1, min(16, cores))
     rng = np.random.default_rng(1)
-    src = rng.lognormal(np.log(1e5), 1.0, 1 << 23)
+    src = rng.lognormal(np.log(1e5), 1.0, 1 << 24)
     w = 1.0 / np.arange(1, M + 1)
     ids = rng.choice(M, size=src.size, p=w / w.sum()).astype(np.uint32)
     batch = 1 << 20
@@ -497,7 +516,8 @@ def run_c5(seconds=3.0):
     exe = os.path.join(ROOT, "loghisto_amd", "build", "c5_driver")
     if not os.path.exists(exe):
         return {"skipped": "loghisto_amd/build/c5_driver is not built"}
-    r = subprocess.run([exe, "--seconds", str(seconds), "--rate", "1e8", "--bulk", "1"], stdout=subprocess.PIPE,
+    r = subprocess.run([exe, "--seconds", str(seconds), "--rate", "1e8", "--bulk", "1", "--device-counters", "1"],
+                       stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=120)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if r.returncode != 0 or not lines:
@@ -506,7 +526,7 @@ def run_c5(seconds=3.0):
     return {"value": j["events_per_s"], "unit": "events/s", "seconds": j["seconds"], "threads": j["threads"],
             "config": {"workload": j["workload"] + ", 1 s ProcessedMetricSet emit to a Graphite TCP sink (tools/c5_driver.cc)"},
             "target_events_per_s": j["target_events_per_s"], "dropped_intervals": j["dropped_intervals"],
-            "emit_latency_ms_p50": j.get("emit_latency_ms_p50"),
+            "emit_latency_ms_p50": j.get("emit_latency_ms_p50"), "device_counters": j.get("device_counters"),
             "parity": {"events_accounted": j["events_accounted"], "events_submitted": j["events_submitted"],
                        "exact": bool(j["lossless"])}}
 
@@ -557,13 +577,20 @@ def main():
         res = run_c3(args, la, stream, rank, args.steps, args.warmup, latency_flips=min(args.latency_flips, 200))
     else:
         res = run_c4(args, la, stream, rank, world, dist, args.steps, args.warmup)
-    if rank == 0:
-        res.pop("unit", None)
-        res.pop("steps", None)
-        print(json.dumps({**base, **res}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        res.pop("unit", None)
+        res.pop("steps", None)
+        # RCCL prints its version banner through C stdio: push it out first so that the JSON line is the last one
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        sys.stdout.flush()
+        print(json.dumps({**base, **res}), flush=True)
 
 
 if __name__ == "__main__":

@@ -147,6 +147,12 @@ struct Options {
     uint32_t num_lanes = 8;       // staging lanes inside the engine
     uint32_t stage_samples = 4096; // per-thread (id,value) pairs per crossing into the library
     uint64_t lane_samples = 1u << 20;
+    // Counters on the device (lh_submit_counts / lh_counters_collect): every Counter() call is staged as an
+    // (id, amount) event next to the histogram samples and summed on the GPU; Rates / Counters of the interval
+    // come back from the snapshot.  Off: per-thread host maps merged at the flip (the reference's own shape,
+    // metrics.go:251-269, 425-458; also what runs when no device is present).
+    bool device_counters = false;
+    uint32_t max_counters = 4096;
 };
 
 class MetricSystem {
@@ -194,11 +200,12 @@ private:
     struct Stage;
     Stage *stage();
     void ship(Stage &s);
+    void ship_counts(Stage &s);
     bool ensure_engine();
     uint32_t intern(const std::string &name);
     void updateSubscribers();
     void reaper();
-    void note(int rc, const char *where);
+    int note(int rc, const char *where); // returns rc
     void serializeHistograms(RawMetricSet &raw, const std::vector<std::string> &labels, const std::vector<double> &ps,
                              WireFormat wf, std::string &text);
 
@@ -219,18 +226,20 @@ private:
     std::mutex stages_mu_;
     std::vector<std::unique_ptr<Stage>> stages_;
     alignas(64) std::atomic<bool> hist_used_{false}; // own cache line: written once, read by every producer
+    alignas(64) std::atomic<bool> counters_used_{false}; // device counters received an event
     alignas(64) uint64_t instance_id_;
 
     std::mutex names_mu_;
     std::vector<std::string> names_;
 
-    // counters (host side as in the reference, metrics.go:112-117)
+    // counters: host side as in the reference (metrics.go:112-117), or -- Options::device_counters -- a mirror of
+    // the lifetime store that lives in HBM (lh_counters_collect)
     std::mutex counter_store_mu_;
     std::unordered_map<std::string, uint64_t> counter_store_;
+    std::vector<std::string> counter_names_; // device counter id -> name (counter_store_mu_)
 
     // lifetime histogram aggregates (metrics.go:122-125)
-    std::mutex hist_count_mu_;
-    std::unordered_map<std::string, uint64_t> hist_count_store_;
+    // (histogramCountStore, metrics.go:122-127, lives in HBM: lh_snapshot_accumulate / lh_lifetime)
 
     std::mutex gauge_mu_;
     std::unordered_map<std::string, std::function<double()>> gauge_funcs_;

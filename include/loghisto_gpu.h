@@ -164,6 +164,19 @@ int lh_extract(lh_snapshot *s, const double *p, size_t np, lh_stats *stats,
  * reduce-scatter merge. */
 int lh_extract_rows(lh_snapshot *s, uint32_t first, size_t nmetrics, const double *p, size_t np,
                     lh_stats *stats, double *pvals, int16_t *pkeys, uint8_t *pvalid);
+/* The same without the last copy: the results are handed out IN PLACE, in the engine's pinned result buffer (a
+ * cgo caller wraps them as slices without copying; at 65 536 names the copy into caller arrays would cost more
+ * than the scan).  The pointers stay valid until the next lh_extract* / lh_buckets* / lh_serialize* / merge call
+ * on this engine or lh_release of the snapshot, whichever comes first. */
+typedef struct lh_extract_view {
+    const lh_stats *stats;   /* [nmetrics]      */
+    const double *pvals;     /* [nmetrics * np] */
+    const int16_t *pkeys;    /* [nmetrics * np] */
+    const uint8_t *pvalid;   /* [nmetrics * np] */
+    size_t nmetrics, np;
+} lh_extract_view;
+int lh_extract_rows_view(lh_snapshot *s, uint32_t first, size_t nmetrics, const double *p, size_t np,
+                         lh_extract_view *view);
 /* Occupied cells of one metric, ascending key. *n receives the number of
  * occupied cells even when it exceeds cap. */
 int lh_buckets(lh_snapshot *s, uint32_t id, int16_t *keys, uint64_t *counts, size_t cap, size_t *n);

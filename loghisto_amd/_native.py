@@ -41,6 +41,11 @@ OPT_EXTRACT_ZERO_COPY, OPT_SCRATCH_CAP_BYTES, OPT_SUBLAUNCH_PAIRS, OPT_SMALL_PAT
 OPT_PART_V2, OPT_PART_V2_MIN_PAIRS, OPT_PART_V2_SHAPE = 9, 10, 11
 
 
+class LhExtractView(C.Structure):
+    _fields_ = [("stats", C.c_void_p), ("pvals", C.c_void_p), ("pkeys", C.c_void_p), ("pvalid", C.c_void_p),
+                ("nmetrics", C.c_size_t), ("np", C.c_size_t)]
+
+
 class LhMergeInfo(C.Structure):
     _fields_ = [("packed_cells", C.c_uint64), ("send_bytes", C.c_uint64), ("recv_bytes", C.c_uint64),
                 ("widest_row", C.c_uint32), ("occupied_rows", C.c_uint32)]
@@ -93,6 +98,7 @@ SIGNATURES = {
     "lh_flip": (C.c_int, [_vp, C.POINTER(_vp)]),
     "lh_extract": (C.c_int, [_vp, _dp, _sz, C.POINTER(LhStats), _dp, _i16p, _u8p, _sz]),
     "lh_extract_rows": (C.c_int, [_vp, C.c_uint32, _sz, _dp, _sz, C.POINTER(LhStats), _dp, _i16p, _u8p]),
+    "lh_extract_rows_view": (C.c_int, [_vp, C.c_uint32, _sz, _dp, _sz, C.POINTER(LhExtractView)]),
     "lh_buckets": (C.c_int, [_vp, C.c_uint32, _i16p, _u64p, _sz, C.POINTER(_sz)]),
     "lh_buckets_all": (C.c_int, [_vp, C.c_uint32, _sz, _u64p, _i16p, _u64p, _sz, C.POINTER(_sz)]),
     "lh_snapshot_rows": (C.c_int, [_vp, C.POINTER(_vp), _u32p]),

@@ -83,7 +83,12 @@ struct MetricSystem::Stage {
     std::vector<double> vals;
     size_t n = 0;
     std::unordered_map<std::string, uint32_t> idcache;  // name -> dense id, thread private
-    std::unordered_map<std::string, uint64_t> counters; // counterCache share of this thread
+    std::unordered_map<std::string, uint64_t> counters; // counterCache share of this thread (host counters)
+    // device counters: (counter id, amount) events, shipped with lh_submit_counts
+    std::vector<uint32_t> cids;
+    std::vector<uint64_t> camts;
+    size_t cn = 0;
+    std::unordered_map<std::string, uint32_t> cidcache;
 };
 
 // ---------------------------------------------------------------------------
@@ -149,12 +154,13 @@ MetricSystem::~MetricSystem()
     }
 }
 
-void MetricSystem::note(int rc, const char *where)
+int MetricSystem::note(int rc, const char *where)
 {
-    if (rc == LH_OK) return;
+    if (rc == LH_OK) return rc;
     const int prev = last_status_.exchange(rc);
     if (prev != rc) // the reference logs through glog and carries on (metrics.go:379-384)
         std::fprintf(stderr, "loghisto: %s: %s [%s]\n", where, lh_strerror(rc), lh_last_error());
+    return rc;
 }
 
 bool MetricSystem::ensure_engine()
@@ -169,6 +175,7 @@ bool MetricSystem::ensure_engine()
     cfg.num_buffers = opt_.num_buffers;
     cfg.num_lanes = opt_.num_lanes;
     cfg.lane_samples = opt_.lane_samples;
+    cfg.max_counters = opt_.device_counters ? opt_.max_counters : 0;
     lh_engine *e = nullptr;
     const int rc = lh_create(&cfg, &e);
     if (rc != LH_OK) {
@@ -197,6 +204,10 @@ MetricSystem::Stage *MetricSystem::stage()
         auto st = std::make_unique<Stage>();
         st->ids.resize(opt_.stage_samples);
         st->vals.resize(opt_.stage_samples);
+        if (opt_.device_counters) {
+            st->cids.resize(opt_.stage_samples);
+            st->camts.resize(opt_.stage_samples);
+        }
         Stage *raw = st.get();
         {
             std::lock_guard<std::mutex> g(stages_mu_);
@@ -242,8 +253,36 @@ std::chrono::nanoseconds TimerToken::Stop()
     return d;
 }
 
+void MetricSystem::ship_counts(Stage &s)
+{
+    if (s.cn == 0) return;
+    note(lh_submit_counts(engine_, s.cids.data(), s.camts.data(), s.cn), "lh_submit_counts");
+    s.cn = 0;
+}
+
 void MetricSystem::Counter(const std::string &name, uint64_t amount)
 {
+    if (opt_.device_counters && (engine_ || ensure_engine())) {
+        Stage *st = stage();
+        std::lock_guard<std::mutex> g(st->mu);
+        uint32_t id;
+        auto it = st->cidcache.find(name);
+        if (it != st->cidcache.end()) {
+            id = it->second;
+        } else {
+            const int rc = lh_intern_counter(engine_, name.data(), name.size(), &id);
+            if (rc != LH_OK) {
+                note(rc, "lh_intern_counter");
+                return;
+            }
+            st->cidcache.emplace(name, id);
+        }
+        st->cids[st->cn] = id;
+        st->camts[st->cn] = amount; // the sum happens on the GPU
+        if (!counters_used_.load(std::memory_order_relaxed)) counters_used_.store(true, std::memory_order_relaxed);
+        if (++st->cn == st->cids.size()) ship_counts(*st);
+        return;
+    }
     Stage *st = stage();
     std::lock_guard<std::mutex> g(st->mu);
     st->counters[name] += amount;
@@ -316,8 +355,10 @@ std::shared_ptr<RawMetricSet> MetricSystem::collectRawMetrics()
             for (auto &kv : st->counters) fresh[kv.first] += kv.second;
             st->counters.clear();
         }
-        if (hist_used_.load() && engine_) {
+        if ((hist_used_.load() || counters_used_.load()) && engine_) {
             for (auto &st : stages_) ship(*st);
+            if (counters_used_.load())
+                for (auto &st : stages_) ship_counts(*st);
             lh_snapshot *snap = nullptr;
             const int rc = lh_flip(engine_, &snap);
             if (rc == LH_OK) raw->snapshot = snap;
@@ -329,8 +370,33 @@ std::shared_ptr<RawMetricSet> MetricSystem::collectRawMetrics()
         std::lock_guard<std::mutex> g(names_mu_);
         raw->names = names_;
     }
-    raw->Rates = fresh; // metrics.go:430-433
-    {
+    if (counters_used_.load() && raw->snapshot) {
+        // device counters: the interval's amounts and the lifetime store come back from the snapshot
+        // (metrics.go:430-458 ran on the GPU: sum per name, fold into the store at the epoch boundary)
+        uint32_t nc = 0;
+        note(lh_num_counters(engine_, &nc), "lh_num_counters");
+        std::vector<uint64_t> rate(nc), total(nc);
+        std::vector<uint8_t> present(nc), known(nc);
+        if (nc && note(lh_counters_collect(raw->snapshot, 0, nc, rate.data(), present.data(), total.data(), known.data()),
+                       "lh_counters_collect") == LH_OK) {
+            std::lock_guard<std::mutex> g(counter_store_mu_);
+            char buf[1024];
+            while (counter_names_.size() < nc) {
+                size_t len = 0;
+                const uint32_t id = (uint32_t)counter_names_.size();
+                if (lh_counter_name(engine_, id, buf, sizeof(buf), &len) != LH_OK) break;
+                counter_names_.emplace_back(buf, len < sizeof(buf) ? len : sizeof(buf));
+            }
+            for (uint32_t i = 0; i < nc && i < counter_names_.size(); i++) {
+                if (present[i]) fresh[counter_names_[i]] += rate[i];
+                if (known[i]) counter_store_[counter_names_[i]] = total[i];
+            }
+        }
+        raw->Rates = fresh;
+        std::lock_guard<std::mutex> g(counter_store_mu_);
+        raw->Counters = counter_store_;
+    } else {
+        raw->Rates = fresh; // metrics.go:430-433
         std::lock_guard<std::mutex> g(counter_store_mu_); // metrics.go:435-458
         for (auto &kv : fresh) counter_store_[kv.first] += kv.second;
         raw->Counters = counter_store_;
@@ -369,6 +435,11 @@ std::shared_ptr<ProcessedMetricSet> MetricSystem::processMetrics(const std::shar
         else n_map = n;
     }
     if (n_map) {
+        {   // processHistograms' lifetime side effect (metrics.go:359-376: uint64(totalSum), wrapping adds): applied
+            // once per snapshot to the ONE store there is -- in HBM -- whether the map path, the wire path or both run
+            std::lock_guard<std::mutex> g(raw->mu);
+            if (raw->snapshot) note(lh_snapshot_accumulate(raw->snapshot), "lh_snapshot_accumulate");
+        }
         std::vector<std::string> labels;
         std::vector<double> ps;
         {
@@ -393,11 +464,6 @@ std::shared_ptr<ProcessedMetricSet> MetricSystem::processMetrics(const std::shar
                 m[name + "_count"] = (double)st[id].count;
                 m[name + "_sum"] = st[id].sum;
                 m[name + "_avg"] = st[id].avg;
-                {
-                    std::lock_guard<std::mutex> g(hist_count_mu_); // metrics.go:359-376
-                    hist_count_store_[name + "_sum"] += st[id].agg_sum_add; // uint64(totalSum), wrapping add
-                    hist_count_store_[name + "_count"] += st[id].count;
-                }
                 for (size_t i = 0; i < np; i++) {
                     if (ok[id * np + i]) m[fmt_label(labels[i], name)] = pv[id * np + i];
                     else std::fprintf(stderr, "loghisto: unable to calculate percentile: Invalid percentile.  "
@@ -475,24 +541,18 @@ void MetricSystem::serializeHistograms(RawMetricSet &raw, const std::vector<std:
 
 void MetricSystem::addAggregates(const std::shared_ptr<RawMetricSet> &raw, ProcessedMetricSet &processed)
 {
-    for (const std::string &name : raw->names) { // metrics.go:590-608
-        if (!processed.Metrics.count(name + "_count")) continue;
-        uint64_t agg_count = 0, agg_sum = 0;
-        bool have = false;
-        {
-            std::lock_guard<std::mutex> g(hist_count_mu_);
-            auto c = hist_count_store_.find(name + "_count"), s = hist_count_store_.find(name + "_sum");
-            if (c != hist_count_store_.end() && s != hist_count_store_.end()) {
-                agg_count = c->second;
-                agg_sum = s->second;
-                have = true;
-            }
-        }
-        if (have && agg_count > 0) {
-            processed.Metrics[name + "_agg_avg"] = (double)(agg_sum / agg_count); // integer division
-            processed.Metrics[name + "_agg_count"] = (double)agg_count;
-            processed.Metrics[name + "_agg_sum"] = (double)agg_sum;
-        }
+    // metrics.go:590-608.  histogramCountStore lives in HBM (lh_snapshot_accumulate / lh_lifetime): the map keys
+    // and the wire text's _agg_* lines read the same store.
+    const size_t n = raw->names.size();
+    if (!n || !engine_) return;
+    std::vector<uint64_t> agg_count(n), agg_sum(n);
+    if (note(lh_lifetime(engine_, 0, n, agg_count.data(), agg_sum.data()), "lh_lifetime") != LH_OK) return;
+    for (size_t id = 0; id < n; id++) {
+        const std::string &name = raw->names[id];
+        if (!processed.Metrics.count(name + "_count") || agg_count[id] == 0) continue;
+        processed.Metrics[name + "_agg_avg"] = (double)(agg_sum[id] / agg_count[id]); // integer division
+        processed.Metrics[name + "_agg_count"] = (double)agg_count[id];
+        processed.Metrics[name + "_agg_sum"] = (double)agg_sum[id];
     }
 }
 

@@ -123,6 +123,7 @@ struct lh_engine {
     hipStream_t main_stream = nullptr; // device submits with stream == NULL
     hipStream_t xstream = nullptr;     // extract / clear
 
+
     std::vector<std::unique_ptr<Lane>> lanes;
 
     std::shared_mutex names_mu;
@@ -287,13 +288,17 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
             };
             bool v2 = false;
             size_t need = scratch_need(sub, &v2);
-            while (need > e->scratch_cap && sub > (size_t(1) << 22)) {
-                size_t half = size_t(1) << 22;
+            // Above 8 192 names the second scatter level carries ~1.2 GB of chunk pools whatever the launch size and
+            // ~0.35 ms of fixed work per sub-launch: cutting such launches finer costs more than the bytes it
+            // saves, so the cap only shapes sub-launches down to 2^28 pairs there (2^24 otherwise).
+            const size_t floor = e->cfg.max_metrics > 8192 ? (size_t(1) << 28) : (size_t(1) << 24);
+            while (need > e->scratch_cap && sub > floor) {
+                size_t half = floor;
                 while (half * 2 < sub) half *= 2;
                 sub = half;
                 need = scratch_need(sub, &v2);
             }
-            if (need == 0) return LH_EDEVICE; // cannot happen: sub >= 2^22 >= the partitioned path's minimum
+            if (need == 0) return LH_EDEVICE; // cannot happen: sub is above the partitioned path's minimum
             take = sub;
             std::lock_guard<std::mutex> g(e->scratch_mu);
             if (e->scratch_bytes < need) {
@@ -440,6 +445,7 @@ void free_engine(lh_engine *e)
     if (e->d_mbuf) (void)hipFree(e->d_mbuf);
     if (e->main_stream) (void)hipStreamDestroy(e->main_stream);
     if (e->xstream) (void)hipStreamDestroy(e->xstream);
+
     delete e;
 }
 
@@ -944,10 +950,55 @@ int lh_extract(lh_snapshot *s, const double *p, size_t np, lh_stats *stats, doub
     return lh_extract_rows(s, 0, nmetrics, p, np, stats, pvals, pkeys, pvalid);
 }
 
+namespace {
+// results on the host: copied into the caller's arrays, or (view) handed out in place
+int finish_extract(lh_engine *e, const ExtractLayout &L, size_t nmetrics, size_t np, lh_stats *stats, double *pvals,
+                   int16_t *pkeys, uint8_t *pvalid, lh_extract_view *view)
+{
+    if (view) {
+        view->stats = reinterpret_cast<const lh_stats *>(e->h_xbuf + L.off_stats);
+        view->pvals = reinterpret_cast<const double *>(e->h_xbuf + L.off_pvals);
+        view->pkeys = reinterpret_cast<const int16_t *>(e->h_xbuf + L.off_pkeys);
+        view->pvalid = e->h_xbuf + L.off_pvalid;
+        view->nmetrics = nmetrics;
+        view->np = np;
+    } else {
+        std::memcpy(stats, e->h_xbuf + L.off_stats, nmetrics * sizeof(lh_stats));
+        if (np) {
+            std::memcpy(pvals, e->h_xbuf + L.off_pvals, nmetrics * np * sizeof(double));
+            if (pkeys) std::memcpy(pkeys, e->h_xbuf + L.off_pkeys, nmetrics * np * sizeof(int16_t));
+            if (pvalid) std::memcpy(pvalid, e->h_xbuf + L.off_pvalid, nmetrics * np);
+        }
+    }
+    uint32_t err, nfall;
+    std::memcpy(&err, e->h_xbuf + L.off_err, 4);
+    std::memcpy(&nfall, e->h_xbuf + L.off_err + 4, 4);
+    return after_extract(e, err, nfall);
+}
+
+int extract_impl(lh_snapshot *s, uint32_t first, size_t nmetrics, const double *p, size_t np, lh_stats *stats,
+                 double *pvals, int16_t *pkeys, uint8_t *pvalid, lh_extract_view *view);
+} // namespace
+
 int lh_extract_rows(lh_snapshot *s, uint32_t first, size_t nmetrics, const double *p, size_t np, lh_stats *stats,
                     double *pvals, int16_t *pkeys, uint8_t *pvalid)
 {
     if (!s || (nmetrics && !stats) || (np && nmetrics && (!p || !pvals))) return LH_EINVAL;
+    return extract_impl(s, first, nmetrics, p, np, stats, pvals, pkeys, pvalid, nullptr);
+}
+
+int lh_extract_rows_view(lh_snapshot *s, uint32_t first, size_t nmetrics, const double *p, size_t np,
+                         lh_extract_view *view)
+{
+    if (!s || !view || (np && nmetrics && !p)) return LH_EINVAL;
+    std::memset(view, 0, sizeof(*view));
+    return extract_impl(s, first, nmetrics, p, np, nullptr, nullptr, nullptr, nullptr, view);
+}
+
+namespace {
+int extract_impl(lh_snapshot *s, uint32_t first, size_t nmetrics, const double *p, size_t np, lh_stats *stats,
+                 double *pvals, int16_t *pkeys, uint8_t *pvalid, lh_extract_view *view)
+{
     lh_engine *e = s->e;
     if (np > LH_MAX_PERCENTILES || (uint64_t)first + nmetrics > e->cfg.max_metrics) return LH_EINVAL;
     if (nmetrics == 0) return LH_OK;
@@ -961,7 +1012,10 @@ int lh_extract_rows(lh_snapshot *s, uint32_t first, size_t nmetrics, const doubl
     EpochBuffer &b = e->bufs[(size_t)s->buf];
     // Small results (the latency path: one or a few metrics) are written by the kernel straight into the pinned
     // host block through its device mapping: one launch + one sync, no separate copy.  Large ones go through
-    // HBM and one DMA (fine-grained stores over PCIe would be slower than the copy engine).
+    // HBM and one DMA (fine-grained stores over PCIe would be slower than the copy engine); from 2 048 names on the
+    // scan itself is the wave-per-metric kernel (65 536 names: ~290 -> ~60 us), so that the 9 MB transfer is what
+    // remains -- measured: cutting it into chunks pipelined behind the kernels gained nothing over one copy, and
+    // lh_extract_rows_view hands the pinned block out in place instead of copying it once more on the host.
     const bool zero_copy = e->d_hxbuf != nullptr && L.total <= 32768 && e->zero_copy_enabled;
     unsigned char *xb = zero_copy ? e->d_hxbuf : e->d_xbuf;
     lh::ExtractNotify nt;
@@ -996,17 +1050,9 @@ int lh_extract_rows(lh_snapshot *s, uint32_t first, size_t nmetrics, const doubl
         HIPCHK(hipMemcpyAsync(e->h_xbuf, e->d_xbuf, L.total, hipMemcpyDeviceToHost, e->xstream));
         HIPCHK(hipStreamSynchronize(e->xstream));
     }
-    std::memcpy(stats, e->h_xbuf + L.off_stats, nmetrics * sizeof(lh_stats));
-    if (np) {
-        std::memcpy(pvals, e->h_xbuf + L.off_pvals, nmetrics * np * sizeof(double));
-        if (pkeys) std::memcpy(pkeys, e->h_xbuf + L.off_pkeys, nmetrics * np * sizeof(int16_t));
-        if (pvalid) std::memcpy(pvalid, e->h_xbuf + L.off_pvalid, nmetrics * np);
-    }
-    uint32_t err, nfall;
-    std::memcpy(&err, e->h_xbuf + L.off_err, 4);
-    std::memcpy(&nfall, e->h_xbuf + L.off_err + 4, 4);
-    return after_extract(e, err, nfall);
+    return finish_extract(e, L, nmetrics, np, stats, pvals, pkeys, pvalid, view);
 }
+} // namespace
 
 // The sticky bad-id flag and the single-pass kernel's window-miss counter ride along with every extract.
 static int after_extract(lh_engine *e, uint32_t err, uint32_t nfall)

@@ -391,6 +391,17 @@ __device__ __forceinline__ uint64_t shfl_down_u64(uint64_t x, int d)
     hi = __shfl_down(hi, d, 64);
     return ((uint64_t)hi << 32) | lo;
 }
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t x, int src)
+{
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    lo = __shfl(lo, src, 64);
+    hi = __shfl(hi, src, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ double shfl_f64(double x, int src)
+{
+    return __longlong_as_double((long long)shfl_u64((uint64_t)__double_as_longlong(x), src));
+}
 __device__ __forceinline__ double shfl_down_f64(double x, int d)
 {
     return __longlong_as_double((long long)shfl_down_u64((uint64_t)__double_as_longlong(x), d));
@@ -543,6 +554,134 @@ __global__ __launch_bounds__(K2_BLOCK) void k_extract(const uint64_t *__restrict
     }
 }
 
+// The same, one WAVE per metric (four metrics per workgroup, no workgroup barriers): for thousands of names with
+// narrow spans the block-per-metric form is bound by workgroup dispatch and its six barriers, not by the scan
+// (65 536 names: ~290 us).  Results are BIT-IDENTICAL to k_extract, _sum included: every lane keeps the four
+// partial sums of the four k_extract threads it stands for (tid = lane, lane + 64, lane + 128, lane + 192, each
+// accumulating bins lo + tid, + 256, ... in the same order), reduces each with the same shuffle tree and adds the
+// four wave totals in the same order; counts and the percentile scan are integer arithmetic.
+__global__ __launch_bounds__(K2_BLOCK) void k_extract_wave(const uint64_t *__restrict__ counts,
+                                                           const uint32_t *__restrict__ ranges, uint32_t nmetrics,
+                                                           const PctArgs pa, uint32_t np,
+                                                           const double *__restrict__ D,
+                                                           ExtractOut *__restrict__ out,
+                                                           double *__restrict__ pvals, int16_t *__restrict__ pkeys,
+                                                           uint8_t *__restrict__ pvalid,
+                                                           const uint32_t *__restrict__ err_in,
+                                                           uint32_t *__restrict__ err_out)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t m = blockIdx.x * K2_WAVES + wave;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        err_out[0] = err_in[0];
+        err_out[1] = err_in[1];
+    }
+    if (m >= nmetrics) return; // wave-uniform
+    const uint64_t *row = counts + (size_t)m * LH_NKEYS;
+    const uint32_t lo = ranges[2 * (size_t)m], hi = ranges[2 * (size_t)m + 1];
+
+    // ---- pass 1 (metrics.go:342-347)
+    uint64_t cnt = 0;
+    double sum4[K2_WAVES] = {0, 0, 0, 0};
+    uint32_t nb = 0;
+    if (lo <= hi) {
+        for (uint32_t base = lo; base <= hi; base += K2_BLOCK) {
+#pragma unroll
+            for (int v = 0; v < K2_WAVES; v++) { // virtual thread v * 64 + lane of k_extract
+                const uint32_t b = base + (uint32_t)v * 64 + lane;
+                if (b <= hi) {
+                    const uint64_t c = row[b];
+                    if (c) {
+                        cnt += c;
+                        sum4[v] += D[b] * (double)c;
+                        nb++;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        cnt += shfl_down_u64(cnt, d);
+        nb += __shfl_down(nb, d, 64);
+#pragma unroll
+        for (int v = 0; v < K2_WAVES; v++) sum4[v] += shfl_down_f64(sum4[v], d);
+    }
+    const uint64_t total = shfl_u64(cnt, 0);
+    double tsum = 0;
+#pragma unroll
+    for (int v = 0; v < K2_WAVES; v++) tsum += shfl_f64(sum4[v], 0); // ((w0 + w1) + w2) + w3, as k_extract
+    const uint32_t tnb = __shfl(nb, 0, 64);
+    if (lane == 0) {
+        ExtractOut o;
+        o.count = total;
+        o.sum = tsum;
+        o.avg = tsum / (double)total;
+        o.agg_sum_add = d_f64_to_u64_amd64(tsum);
+        o.nbuckets = tnb;
+        o.present = total ? 1u : 0u;
+        out[m] = o;
+    }
+
+    // ---- pass 2 (metrics.go:406-418): lane i < np owns percentile i and keeps the first bin that reaches it
+    uint32_t found = 0xffffffffu;
+    if (total && np) {
+        const double ftotal = (double)total;
+        uint64_t carry = 0;
+        uint32_t open = np; // percentiles without a bin yet (wave-uniform)
+        for (uint32_t base = lo; base <= hi && open; base += K2_TILE / K2_WAVES) { // 256 bins per step
+            const uint32_t b0 = base + lane * K2_PER_THREAD;
+            uint64_t c[K2_PER_THREAD];
+#pragma unroll
+            for (int k = 0; k < K2_PER_THREAD; k++) c[k] = (b0 + k <= hi) ? row[b0 + k] : 0;
+            uint64_t tsumc = 0;
+#pragma unroll
+            for (int k = 0; k < K2_PER_THREAD; k++) tsumc += c[k];
+            uint64_t inc = tsumc;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint64_t y = shfl_up_u64(inc, d);
+                if ((int)lane >= d) inc += y;
+            }
+            uint64_t sofar = carry + (inc - tsumc);
+            double q[K2_PER_THREAD];
+#pragma unroll
+            for (int k = 0; k < K2_PER_THREAD; k++) {
+                sofar += c[k];
+                q[k] = c[k] ? (double)sofar / ftotal : -1.0;
+            }
+            for (uint32_t i = 0; i < np; i++) {
+                const uint32_t fi = __shfl(found, (int)i, 64);
+                if (fi != 0xffffffffu) continue; // settled by an earlier step (wave-uniform)
+                const double pi = pa.p[i];
+                uint32_t hit = 0xffffffffu;
+#pragma unroll
+                for (int k = K2_PER_THREAD - 1; k >= 0; k--)
+                    if (q[k] >= pi && q[k] >= 0.0) hit = b0 + k;
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit != 0xffffffffu);
+                if (mask) {
+                    const uint32_t first_hit = __shfl(hit, (int)__builtin_ctzll(mask), 64);
+                    if (lane == i) found = first_hit;
+                    open--;
+                }
+            }
+            carry += shfl_u64(inc, 63);
+        }
+    }
+    if (lane < np) {
+        const size_t o = (size_t)m * np + lane;
+        if (found != 0xffffffffu) {
+            pvals[o] = D[found];
+            pkeys[o] = (int16_t)bin_to_key(found);
+            pvalid[o] = 1;
+        } else {
+            pvals[o] = 0;
+            pkeys[o] = 0;
+            pvalid[o] = 0;
+        }
+    }
+}
+
 hipError_t launch_extract(const uint64_t *counts, const uint32_t *ranges, uint32_t nmetrics,
                           const double *h_p, uint32_t np, const double *d_D, ExtractOut *out,
                           double *pvals, int16_t *pkeys, uint8_t *pvalid, const uint32_t *err_in,
@@ -551,6 +690,12 @@ hipError_t launch_extract(const uint64_t *counts, const uint32_t *ranges, uint32
     if (nmetrics == 0) return hipSuccess;
     PctArgs pa;
     for (uint32_t i = 0; i < (uint32_t)K2_MAXP; i++) pa.p[i] = i < np ? h_p[i] : 2.0;
+    // many names: one wave per metric (bit-identical results; see k_extract_wave)
+    if (nmetrics >= 2048 && !notify.host_flag) {
+        hipLaunchKernelGGL(k_extract_wave, dim3((nmetrics + K2_WAVES - 1) / K2_WAVES), dim3(K2_BLOCK), 0, s, counts,
+                           ranges, nmetrics, pa, np, d_D, out, pvals, pkeys, pvalid, err_in, err_out);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_extract, dim3(nmetrics), dim3(K2_BLOCK), 0, s, counts, ranges, pa, np, d_D, out,
                        pvals, pkeys, pvalid, err_in, err_out, notify);
     return hipGetLastError();

@@ -64,6 +64,31 @@ class Snapshot:
         return dict(count=raw["count"], sum=raw["sum"], avg=raw["avg"], agg_sum_add=raw["agg_sum_add"],
                     nbuckets=raw["nbuckets"], present=raw["present"], pvals=pvals, pkeys=pkeys, pvalid=pvalid)
 
+    def extract_view(self, percentiles: Sequence[float], nmetrics: Optional[int] = None, first: int = 0):
+        """extract() without the last copy: numpy views of the engine's pinned result buffer (lh_extract_rows_view).
+        Valid until the next call that produces results on this engine, or release()."""
+        if nmetrics is None:
+            nmetrics = self.engine.num_metrics() - first
+        p = np.ascontiguousarray(percentiles, dtype=np.float64)
+        v = N.LhExtractView()
+        N.check(N.lib().lh_extract_rows_view(self._h, first, nmetrics, p.ctypes.data_as(C.POINTER(C.c_double)), int(p.size),
+                                             C.byref(v)), "lh_extract_rows_view")
+        dt = np.dtype([("count", "<u8"), ("sum", "<f8"), ("avg", "<f8"), ("agg_sum_add", "<u8"), ("nbuckets", "<u4"),
+                       ("present", "<u4")])
+        np_ = int(p.size)
+
+        def arr(ptr, ctype, count, dtype):
+            if not count:
+                return np.zeros(0, dtype=dtype)
+            return np.frombuffer((ctype * count).from_address(ptr), dtype=dtype, count=count)
+
+        raw = arr(v.stats, C.c_uint8 * 40, nmetrics, dt)
+        return dict(count=raw["count"], sum=raw["sum"], avg=raw["avg"], agg_sum_add=raw["agg_sum_add"],
+                    nbuckets=raw["nbuckets"], present=raw["present"],
+                    pvals=arr(v.pvals, C.c_double, nmetrics * np_, np.float64).reshape(nmetrics, np_),
+                    pkeys=arr(v.pkeys, C.c_int16, nmetrics * np_, np.int16).reshape(nmetrics, np_),
+                    pvalid=arr(v.pvalid, C.c_uint8, nmetrics * np_, np.uint8).reshape(nmetrics, np_))
+
     def buckets(self, metric_id: int):
         """Occupied (key, count) cells of one metric, ascending key."""
         L = N.lib()

@@ -24,6 +24,7 @@ No bucket arithmetic happens in this file.
 from __future__ import annotations
 
 import queue
+import sys
 import threading
 import time
 from dataclasses import dataclass, field
@@ -31,6 +32,7 @@ from typing import Callable, Dict, List, Optional
 
 import numpy as np
 
+from . import _native as N
 from .engine import Engine, Snapshot
 
 _U64 = (1 << 64) - 1
@@ -145,6 +147,7 @@ class MetricSystem:
         self.interval = float(interval)
         self._device, self._max_metrics, self._stage_cap = device, max_metrics, stage_samples
         self._engine = engine
+        self._owns_engine = engine is None   # Stop() closes only an engine this system created
         self._engine_lock = threading.Lock()
         self._ids: Dict[str, int] = {}
         self._names: List[str] = []
@@ -156,8 +159,7 @@ class MetricSystem:
         self.counterStore: Dict[str, int] = {}
         self.counterCache: Dict[str, int] = {}
         self.counterMu = threading.Lock()
-        self.histogramCountStore: Dict[str, int] = {}
-        self.histogramCountMu = threading.Lock()
+        # (histogramCountStore, metrics.go:122-127, lives in HBM: Snapshot.accumulate / Engine.lifetime)
         self.gaugeFuncs: Dict[str, Callable[[], float]] = {}
         self.gaugeFuncsMu = threading.Lock()
         # subscriptions
@@ -261,11 +263,20 @@ class MetricSystem:
         if self._hist_used:
             with self._stages_lock:
                 stages = list(self._stages)
-                names = list(self._names)
             for st in stages:       # every sample staged before the flip lands in this interval
                 with st.lock:
                     self._ship(st)
-            snap = self._eng().flip()  # epoch boundary, metrics.go:460-463
+            try:
+                snap = self._eng().flip()  # epoch boundary, metrics.go:460-463
+            except N.LhError as exc:
+                if exc.code != N.EBUSY:
+                    raise
+                snap = None         # every epoch buffer is still being read: the interval keeps accumulating
+            # AFTER the flip: _id() appends a name before its first sample is staged, so this copy covers every
+            # row that can hold data in the snapshot (a copy taken earlier could miss a name interned in between,
+            # and that name's first interval would be cleared without ever being reported)
+            with self._stages_lock:
+                names = list(self._names)
 
         with self.gaugeFuncsMu:
             gauges = {name: f() for name, f in self.gaugeFuncs.items()}
@@ -285,11 +296,6 @@ class MetricSystem:
             out[f"{name}_count"] = float(count)
             out[f"{name}_sum"] = float(res["sum"][mid])
             out[f"{name}_avg"] = float(res["avg"][mid])
-            with self.histogramCountMu:  # metrics.go:359-376: uint64(totalSum), wrapping adds
-                self.histogramCountStore[f"{name}_sum"] = (
-                    self.histogramCountStore.get(f"{name}_sum", 0) + int(res["agg_sum_add"][mid])) & _U64
-                self.histogramCountStore[f"{name}_count"] = (
-                    self.histogramCountStore.get(f"{name}_count", 0) + count) & _U64
             for i, label in enumerate(labels):
                 if res["pvalid"][mid][i]:
                     out[label % name] = float(res["pvals"][mid][i])
@@ -305,6 +311,10 @@ class MetricSystem:
         host_keys = dict(metrics)
         wf = self._wire_format
         wire = b""
+        if raw._snapshot is not None and raw._names:
+            # processHistograms' lifetime side effect (metrics.go:359-376: uint64(totalSum), wrapping adds), applied
+            # once per snapshot to the ONE store there is -- in HBM -- whichever of the map / wire paths runs
+            raw._snapshot.accumulate()
         if wf is not None and raw._snapshot is not None and raw._names:
             wire = self.serializeHistograms(raw, wf)
         if wf is None or self._wire_keep_map:
@@ -332,7 +342,6 @@ class MetricSystem:
     def serializeHistograms(self, raw: RawMetricSet, kind: str) -> bytes:
         """Histogram keys of the interval incl. _agg_* as wire text, formatted on the device."""
         host, ts = _hostname(), str(int(raw.Time))
-        raw._snapshot.accumulate()  # processHistograms' lifetime side effect, metrics.go:359-376
         if kind == "graphite":      # graphite.go:40
             return raw._snapshot.serialize(self.percentiles, f"cockroach.{host}.", " ", f" {ts}\n",
                                            underscore_to_dot=True, aggregates=True, nmetrics=len(raw._names))
@@ -340,16 +349,17 @@ class MetricSystem:
                                        aggregates=True, nmetrics=len(raw._names))
 
     def _add_aggregates(self, raw: RawMetricSet, processed: ProcessedMetricSet):  # metrics.go:590-608
-        for name in raw._names:
+        if raw._snapshot is None or not raw._names:
+            return
+        agg_count, agg_sum = self._eng().lifetime(len(raw._names))   # histogramCountStore lives in HBM (lh_lifetime)
+        for mid, name in enumerate(raw._names):
             if f"{name}_count" not in processed.Metrics:
                 continue
-            with self.histogramCountMu:
-                agg_count = self.histogramCountStore.get(f"{name}_count")
-                agg_sum = self.histogramCountStore.get(f"{name}_sum")
-            if agg_count is not None and agg_sum is not None and agg_count > 0:
-                processed.Metrics[f"{name}_agg_avg"] = float(agg_sum // agg_count)  # integer division
-                processed.Metrics[f"{name}_agg_count"] = float(agg_count)
-                processed.Metrics[f"{name}_agg_sum"] = float(agg_sum)
+            c, sm = int(agg_count[mid]), int(agg_sum[mid])
+            if c > 0:
+                processed.Metrics[f"{name}_agg_avg"] = float(sm // c)  # integer division
+                processed.Metrics[f"{name}_agg_count"] = float(c)
+                processed.Metrics[f"{name}_agg_sum"] = float(sm)
 
     # -- subscriptions (glue; metrics.go:203-228, 508-525) -----------------------------
     def SubscribeToRawMetrics(self, q: "queue.Queue"):
@@ -392,14 +402,16 @@ class MetricSystem:
 
     def _tick(self):
         raw = self.collectRawMetrics()
-        self.updateSubscribers()
-        with self._subs_mu:
-            if self._raw_subs:
-                _ = raw.Histograms  # materialise before the snapshot is released
-            self._broadcast(self._raw_subs, self._raw_bad, raw)
-        processed = self.processMetrics(raw)
-        self._add_aggregates(raw, processed)
-        raw.release()
+        try:
+            self.updateSubscribers()
+            with self._subs_mu:
+                if self._raw_subs:
+                    _ = raw.Histograms  # materialise before the snapshot is released
+                self._broadcast(self._raw_subs, self._raw_bad, raw)
+            processed = self.processMetrics(raw)
+            self._add_aggregates(raw, processed)
+        finally:
+            raw.release()           # a leaked snapshot would pin an epoch buffer: every later flip LH_EBUSY
         with self._subs_mu:
             self._broadcast(self._proc_subs, self._proc_bad, processed)
 
@@ -411,10 +423,14 @@ class MetricSystem:
             if self._shutdown.wait(tts):
                 self.reaping = False
                 return
-            self._tick()
+            try:
+                self._tick()
+            except Exception as exc:  # noqa: BLE001 -- the reference logs and carries on (metrics.go:379-384, 572-576)
+                print(f"loghisto: interval dropped: {exc!r}", file=sys.stderr)
 
     def Start(self):  # metrics.go:644
         if not self.reaping:
+            self._shutdown.clear()  # Start after Stop
             self.reaping = True
             self._reaper_thread = threading.Thread(target=self.reaper, daemon=True)
             self._reaper_thread.start()
@@ -424,6 +440,10 @@ class MetricSystem:
         if self._reaper_thread is not None:
             self._reaper_thread.join(timeout=5)
             self._reaper_thread = None
-        if self._engine is not None:
+        if self._engine is not None and self._owns_engine:
             self._engine.close()
             self._engine = None
+            with self._stages_lock:   # ids of a destroyed engine must not reach its successor
+                self._ids.clear()
+                self._names.clear()
+                self._hist_used = False

@@ -95,6 +95,81 @@ TEST(TestRawBroadcast) // metrics_test.go:321-346
     ms.Stop();
 }
 
+// ---- the same three tests with the counters on the device (Options::device_counters): every Counter() call is an
+// (id, amount) event summed by the GPU, Rates / Counters come back from the snapshot (lh_counters_collect)
+static Options device_counter_options()
+{
+    Options o;
+    o.device_counters = true;
+    o.max_counters = 64;
+    o.max_metrics = 8;
+    return o;
+}
+
+TEST(TestRateOnDevice) // metrics_test.go:202-223
+{
+    MetricSystem ms(1us, false, device_counter_options());
+    ms.Counter("rate1", 777);
+    auto m = ms.processMetrics(ms.collectRawMetrics())->Metrics;
+    CHECK(m["rate1_rate"] == 777);
+    ms.Counter("rate1", 1223);
+    m = ms.processMetrics(ms.collectRawMetrics())->Metrics;
+    CHECK(m["rate1_rate"] == 1223);
+    ms.Counter("rate1", 1223);
+    ms.Counter("rate1", 1223);
+    m = ms.processMetrics(ms.collectRawMetrics())->Metrics;
+    CHECK(m["rate1_rate"] == 2446 && m["rate1"] == 777 + 1223 + 2446);
+    m = ms.processMetrics(ms.collectRawMetrics())->Metrics; // an idle interval: no rate key, the total stays
+    CHECK(m.count("rate1_rate") == 0 && m["rate1"] == 4446);
+}
+
+TEST(TestCounterOnDevice) // metrics_test.go:225-240
+{
+    MetricSystem ms(1us, false, device_counter_options());
+    ms.Counter("counter1", 3290);
+    auto m = ms.processMetrics(ms.collectRawMetrics())->Metrics;
+    CHECK(m["counter1"] == 3290);
+    ms.Counter("counter1", 10000);
+    m = ms.processMetrics(ms.collectRawMetrics())->Metrics;
+    CHECK(m["counter1"] == 13290);
+}
+
+TEST(TestCounterManyThreadsOnDevice)
+{
+    MetricSystem ms(1us, false, device_counter_options());
+    std::vector<std::thread> th;
+    for (int t = 0; t < 8; t++)
+        th.emplace_back([&, t] {
+            for (int i = 0; i < 10000; i++) {
+                ms.Counter("c", 3);
+                if ((i & 1023) == 0) ms.Histogram("h", 1.0 + t); // counters and histograms share the epoch
+            }
+        });
+    for (auto &x : th) x.join();
+    auto raw = ms.collectRawMetrics();
+    CHECK(raw->Counters["c"] == 240000 && raw->Rates["c"] == 240000);
+    auto m = ms.processMetrics(raw)->Metrics;
+    CHECK(m["h_count"] == 80);
+}
+
+TEST(TestRawBroadcastOnDevice) // metrics_test.go:321-346
+{
+    auto ch = std::make_shared<RawCh>(128);
+    MetricSystem ms(1ms, false, device_counter_options());
+    ms.SubscribeToRawMetrics(ch);
+    ms.Counter("counter2", 10);
+    ms.Counter("counter2", 111);
+    ms.Start();
+    std::shared_ptr<RawMetricSet> raw;
+    CHECK(ch->Receive(raw, 2s));
+    if (raw) {
+        CHECK(raw->Counters["counter2"] == 121);
+        CHECK(raw->Rates["counter2"] == 121);
+    }
+    ms.UnsubscribeFromRawMetrics(ch);
+    ms.Stop();
+}
+
 TEST(TestUpdateSubscribers) // metrics_test.go:242-287
 {
     auto rc = std::make_shared<RawCh>(1);
@@ -477,6 +552,10 @@ int main(int argc, char **argv)
         RUN(TestProducersAreLosslessAcrossIntervals);
         RUN(TestBulkWireMatchesPerKeySerializer);
         RUN(TestPrintBenchmark);
+        RUN(TestRateOnDevice);
+        RUN(TestCounterOnDevice);
+        RUN(TestCounterManyThreadsOnDevice);
+        RUN(TestRawBroadcastOnDevice);
     }
     std::printf("%d checks, %d failed tests\n", g_checks, g_failed);
     return g_failed;

@@ -97,3 +97,34 @@ def test_option_validation(native_lib, torch_cuda):
         with e.flip() as snap:
             got = snap.extract([0.5], 1)
         assert int(got["count"][0]) == 3 and got["pvals"][0, 0] == oracle.decompress(409)
+
+
+@pytest.mark.parametrize("M", [300, 20000])          # block-per-metric kernel / wave-per-metric kernel
+def test_extract_view_equals_extract(native_lib, torch_cuda, M):
+    """lh_extract_rows_view hands the results out in place (pinned memory): same values as lh_extract_rows, for the
+    single-launch path and for the chunked path that large name counts take."""
+    import loghisto_amd
+    rng = np.random.default_rng(M)
+    n = 1_500_000
+    ids = rng.integers(0, M, n).astype(np.uint32)
+    ids[ids % 7 == 3] = 0                              # some names stay empty
+    v = rng.lognormal(8, 1.5, n)
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        e.submit_pairs_device(_dev(torch_cuda, ids), _dev(torch_cuda, v))
+        with e.flip() as snap:
+            a = snap.extract(PCTS, M)
+            b = {k: x.copy() for k, x in snap.extract_view(PCTS, M).items()}
+            c = {k: x.copy() for k, x in snap.extract_view(PCTS, M - 11, first=5).items()}
+            d = snap.extract(PCTS, min(1000, M - 5), first=5)   # < 2 048 names: the block-per-metric kernel
+    assert np.array_equal(a["count"].astype(np.int64), np.bincount(ids, minlength=M))
+
+    def bits(x):                                       # floats compared bit for bit
+        x = np.ascontiguousarray(x)
+        return x.view(np.uint64) if x.dtype.kind == "f" else x
+
+    hi = 5 + min(1000, M - 5)
+    for k in a:
+        assert np.array_equal(bits(a[k]), bits(b[k])), k
+        assert np.array_equal(bits(a[k][5:M - 6]), bits(c[k])), k
+        # the wave-per-metric kernel (>= 2 048 names) is bit-identical to the block-per-metric one, _sum included
+        assert np.array_equal(bits(a[k][5:hi]), bits(d[k])), k

@@ -121,6 +121,8 @@ int main(int argc, char **argv)
     opt.max_metrics = 2048;
     opt.num_lanes = (uint32_t)std::min(64, std::max(8, T / 2));
     opt.stage_samples = 8192;
+    // --device-counters 1: Counter() events are summed on the GPU (lh_submit_counts) instead of per-thread host maps
+    opt.device_counters = arg_d(argc, argv, "--device-counters", 0) != 0;
     MetricSystem ms(std::chrono::milliseconds(interval_ms), false, opt);
     // --bulk 1: the Graphite request is prepared on the GPU (K6, lh_serialize) instead of one %f per key; the map
     // is still filled because the event accounting below reads it
@@ -247,11 +249,12 @@ int main(int argc, char **argv)
                 "\"events_per_s\": %.4g, \"events_accounted\": %llu, \"lossless\": %s, \"intervals_emitted\": %llu, "
                 "\"dropped_intervals\": %llu, \"interval_ms\": %d, \"emit_latency_ms_p50\": %.2f, \"emit_latency_ms_max\": %.2f, "
                 "\"graphite_bytes\": %llu, \"graphite_lines\": %llu, \"keys_emitted\": %llu, \"submit_failures\": %llu, "
-                "\"last_status\": %d}\n",
+                "\"last_status\": %d, \"device_counters\": %s, \"bulk_wire\": %s}\n",
                 NH, NT, NC, T, elapsed, target, (unsigned long long)total, (double)total / elapsed,
                 (unsigned long long)accounted.load(), accounted.load() == total ? "true" : "false",
                 (unsigned long long)intervals.load(), (unsigned long long)ms.dropped_intervals(), interval_ms, p50, pmax,
                 (unsigned long long)sink.bytes.load(), (unsigned long long)sink.lines.load(),
-                (unsigned long long)keys_emitted.load(), (unsigned long long)submit_fail.load(), ms.last_status());
+                (unsigned long long)keys_emitted.load(), (unsigned long long)submit_fail.load(), ms.last_status(),
+                opt.device_counters ? "true" : "false", bulk ? "true" : "false");
     return accounted.load() == total ? 0 : 1;
 }
