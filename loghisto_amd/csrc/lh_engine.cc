@@ -190,7 +190,7 @@ struct lh_engine {
     bool scratch_used = false;
     std::atomic<uint64_t> c_scratch{0}, c_sublaunches{0}, c_part2{0};
     size_t scratch_cap = size_t(1536) << 20;     // 1.5 GiB
-    size_t sublaunch_pairs = size_t(1) << 28;
+    size_t sublaunch_pairs = size_t(1) << 29;
 
     lh::PartTuning tune;                  // lh_set_option; never the environment in the product build
     bool zero_copy_enabled = true;
@@ -1833,7 +1833,7 @@ int lh_set_option(lh_engine *e, int option, uint64_t value)
         e->tune.v2 = value != 0;
         return LH_OK;
     case LH_OPT_PART_V2_SHAPE:
-        if (value > 1) return LH_EINVAL;
+        if (value > 3) return LH_EINVAL;
         e->tune.v2_shape = (uint32_t)value;
         return LH_OK;
     case LH_OPT_PART_V2_MIN_PAIRS:

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__rest
         uint32_t sw = 0, sn = 0;
 #pragma unroll
         for (uint32_t e = 0; e < EMAX; e++)
-            if (want[e] && cnt[e] >= mid) { sw += want[e]; sn++; }
+            if (want[e] && cnt[e] >= mid) { sw += want[e] + 1u; sn++; }
         uint32_t tw, tn;
         block_sum2(sw, sn, s_a, s_b, tw, tn);
         if (tw <= cells && tn <= V2_MAX_SLOTS) fhi = mid; else flo = mid;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__rest
     uint32_t sw = 0, sn = 0, sc = 0;
 #pragma unroll
     for (uint32_t e = 0; e < EMAX; e++)
-        if (want[e] && cnt[e] >= tau) { sw += want[e]; sn++; sc += cnt[e]; }
+        if (want[e] && cnt[e] >= tau) { sw += want[e] + 1u; sn++; sc += cnt[e]; }
     // exclusive scans of (cells, slots) in name order
     uint32_t incw = sw, incn = sn;
     const uint32_t lane = tid & 63, wave = tid >> 6;
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__rest
                 ne.org |= o << 16;
                 ne.hot = cellpos | (w << 16);
                 hs[slot] = (pu4_t){m, o | (w << 16), cellpos, 0u};
-                cellpos += w;
+                cellpos += w + 1u; // one unused cell: windows of equal width do not start in the same LDS bank
                 slot++;
             }
             nt[m] = ne;
@@ -401,15 +401,20 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter2(const uint32_t *__restric
                 const bool ok = live && raw < nmetrics;
                 rare |= (live && !ok) ? 1u : 0u;
                 id[k] = ok ? raw : INVALID;
-                ne[k] = nt[ok ? raw : 0u];
+                ne[k] = nt[(ok && !(dbg & 64u)) ? raw : 0u]; // 64: every sample reads entry 0
             }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int j = h + k;
                 const double x = (j & 1) ? val[j >> 1].y : val[j >> 1].x;
                 bool u;
-                bin[k] = (dbg & 2u) ? (uint32_t)(__double2loint(x) & 0xffff) : lh_bin_fast(x, u);
-                if (!(dbg & 2u) && u) unc |= 1u << k;
+                if (dbg & 2u) { // ablation: no compress -- a pseudo-bin near the name's window origins
+                    bin[k] = (ne[k].org >> 16) + ((uint32_t)__double2loint(x) & 1023u);
+                    u = false;
+                } else {
+                    bin[k] = lh_bin_fast(x, u);
+                }
+                if (u) unc |= 1u << k;
             }
             if (unc) { // inside the guard band of a bucket threshold (1 sample in ~4 000): exact table compare
 #pragma unroll
@@ -432,7 +437,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter2(const uint32_t *__restric
                 if (valid && !hot && !cold) miss |= 1u << k;
             }
 #pragma unroll
-            for (int k = 0; k < 4; k++) rank[k] = atomicAdd(lds32 + where[k], 1u);
+            for (int k = 0; k < 4; k++) rank[k] = (dbg & 32u) ? 0u : atomicAdd(lds32 + where[k], 1u); // 32: no LDS atomics
 #pragma unroll
             for (int k = 0; k < 4; k++)
                 if (pr[h + k] != INVALID) pr[h + k] |= rank[k] << 8;
@@ -449,65 +454,91 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter2(const uint32_t *__restric
         }
         if (rare) atomicOr(err, 1u); // an id >= nmetrics: reported by lh_sync / lh_extract
         __syncthreads();                                   // barrier A: counts complete
+        if (dbg & 16u) { // ablation: phase 1 and the loads only
+            load_tile(tile + 2 * (size_t)gridDim.x, idv, val);
+            return;
+        }
         // this register set is free again: it receives the tile two steps ahead (a whole tile period in flight)
         load_tile(tile + 2 * (size_t)gridDim.x, idv, val);
 
-        // ---- phase 2: per-partition bookkeeping (threads 0..255).  sf / cnt are only READ here (other scanning
-        // waves sum them too); their new values are installed after barrier B.
+        // ---- phase 2: per-partition bookkeeping, four threads per partition (p = tid / 4, q = tid % 4).
+        // Every wave first scans the line counts of ALL partitions redundantly (K partitions per lane, one wave scan:
+        // no barrier, no waiting for other waves), publishes the bases of the 16 partitions its own threads handle and
+        // reads them back (same wave: LDS operations of one wave are ordered).  sf / cnt are only READ in this
+        // phase; their new values are installed after barrier B.
         if (tid == V2_BLOCK - 1) L.missn[par ^ 1u] = 0; // the other parity's queue was drained in the previous tile
-        if (tid < NPMAX) {
-            const uint32_t p = tid;
-            const uint32_t c = L.cnt[p], sf0 = L.sf[p];
-            const uint32_t total = sf0 + c, nfull = total / LINE2, out = nfull * LINE2;
-            // exclusive scan of the line counts: own wave by shuffles, earlier waves by re-summing their inputs
-            uint32_t inc = nfull;
+        {
+            constexpr int K = NPT / 64; // partitions per lane of the scan
+            uint32_t nf[K];
+            uint32_t lane_lines = 0;
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                nf[k] = (L.sf[lane * K + k] + L.cnt[lane * K + k]) / LINE2;
+                lane_lines += nf[k];
+            }
+            uint32_t inc = lane_lines;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
                 const uint32_t y = __shfl_up(inc, d, 64);
                 if ((int)lane >= d) inc += y;
             }
-            uint32_t wbase = 0;
-            for (uint32_t w = 0; w < wave; w++) { // wave-uniform trip count
-                uint32_t x = (L.sf[w * 64 + lane] + L.cnt[w * 64 + lane]) / LINE2;
+            uint32_t run = inc - lane_lines;
+            // this wave's threads handle partitions [16 * wave, 16 * wave + 16): lanes 16 * wave / K .. own them
+            const bool mine = lane >= 16u * wave / K && lane < (16u * wave + 16u) / K;
 #pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
-                wbase += x;
+            for (int k = 0; k < K; k++) {
+                if (mine) L.lbase[lane * K + k] = run;
+                run += nf[k];
             }
-            const uint32_t lb = wbase + inc - nfull;
-            if (tid == NPMAX - 1) L.nlines = wbase + inc;
-            L.lbase[p] = lb;
-            L.tA[p] = (pu2_t){sf0 | (out << 8), lb * LINE2};
-            L.newsf[p] = total - out;
-            if (nfull) {
-                const uint32_t tag = p << CD_SHIFT;
-                const uint32_t cf = L.cfill[p], cb = L.cbase[p];
-                const uint32_t room = CHUNK - cf; // multiple of LINE2 (0 when there is no open chunk)
-                uint32_t first = 0;
-                if (out > room) {
-                    const uint32_t over = out - room;
-                    const uint32_t k = (over + CHUNK - 1) / CHUNK;
-                    first = pool_base + atomicAdd(&L.pool_next, k);   // k consecutive chunks
-                    if (cb != INVALID) hidden_store_u32(cdesc + cb, tag | CHUNK);   // the old chunk is now full
+            if (tid == V2_BLOCK - 1) L.nlines = inc; // lane 63 of the last wave: the total
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            uint32_t t2 = tid;
+            asm volatile("" : "+v"(t2)); // keeps the address arithmetic below inside the loop (hoisted, it spills:
+                                         // and a scratch reload here waits for the prefetch that was just issued)
+            const uint32_t p = t2 >> 2, q = t2 & 3u;
+            const uint32_t c = L.cnt[p], sf0 = L.sf[p], lb = L.lbase[p];
+            const uint32_t total = sf0 + c, nfull = total / LINE2, out = nfull * LINE2;
+            if (q == 0) {
+                L.tA[p] = (pu2_t){sf0 | (out << 8), lb * LINE2};
+                L.newsf[p] = total - out;
+                if (nfull) {
+                    const uint32_t tag = p << CD_SHIFT;
+                    const uint32_t cf = L.cfill[p], cb = L.cbase[p];
+                    const uint32_t room = CHUNK - cf; // multiple of LINE2 (0 when there is no open chunk)
+                    uint32_t first = 0;
+                    if (out > room) {
+                        const uint32_t over = out - room;
+                        const uint32_t k = (over + CHUNK - 1) / CHUNK;
+                        first = pool_base + atomicAdd(&L.pool_next, k);   // k consecutive chunks
+                        if (cb != INVALID) hidden_store_u32(cdesc + cb, tag | CHUNK);   // the old chunk is now full
 #pragma nounroll
-                    for (uint32_t q = 0; q + 1 < k; q++) hidden_store_u32(cdesc + first + q, tag | CHUNK);
-                    L.cbase[p] = first + k - 1;
-                    L.cfill[p] = over - (k - 1) * CHUNK;
-                } else {
-                    L.cfill[p] = cf + out;
+                        for (uint32_t i = 0; i + 1 < k; i++) hidden_store_u32(cdesc + first + i, tag | CHUNK);
+                        L.cbase[p] = first + k - 1;
+                        L.cfill[p] = over - (k - 1) * CHUNK;
+                    } else {
+                        L.cfill[p] = cf + out;
+                    }
+                    L.dA[p] = cb * CHUNK + cf;
+                    L.dB[p] = first * CHUNK - room;
+                    L.room[p] = room;
                 }
-                L.dA[p] = cb * CHUNK + cf;
-                L.dB[p] = first * CHUNK - room;
-                L.room[p] = room;
+            }
+            if (nfull) {
 #pragma nounroll
-                for (uint32_t i = 0; i < nfull; i++) L.owner[lb + i] = (uint16_t)p;
-                // the staged leftovers open the partition's first line: aligned 16-byte LDS copies
-#pragma nounroll
-                for (uint32_t q = 0; q * 8 < sf0; q++)
+                for (uint32_t i = q; i < nfull; i += 4) L.owner[lb + i] = (uint16_t)p;
+                // the staged leftovers open the partition's first line: one aligned 16-byte LDS copy per thread
+                if (q * 8 < sf0)
                     *reinterpret_cast<pu4_t *>(&L.sorted[lb * LINE2 + q * 8]) =
                         *reinterpret_cast<const pu4_t *>(&L.stage[p * LINE2 + q * 8]);
             }
         }
         __syncthreads();                                   // barrier B: plan of the tile is visible
+        if (dbg & 128u) { // ablation: no placement, no copy-out
+            if (tid < NPMAX) { L.sf[tid] = L.newsf[tid]; L.cnt[tid] = 0; }
+            return;
+        }
 
         // ---- phase 3: place the records (again one form for every sample: eight table reads, eight stores)
         if (tid < NPMAX) { L.sf[tid] = L.newsf[tid]; L.cnt[tid] = 0; }
@@ -525,6 +556,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter2(const uint32_t *__restric
             }
         }
         __syncthreads();                                   // barrier C: lines complete
+        if (dbg & 256u) return; // ablation: no copy-out
 
         // ---- phase 4: copy whole lines out, 16 bytes per lane
         const uint32_t npieces = L.nlines * 4;
@@ -611,6 +643,341 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter2(const uint32_t *__restric
 }
 
 // ---------------------------------------------------------------------------
+// P1 v3: fixed per-partition regions -- a cold record is placed by the phase that classifies it
+// ---------------------------------------------------------------------------
+// k_scatter2 lays a tile's records out exactly (scan of the partitions' line counts, owner table, staged
+// leftovers), which takes two more phases and two more barriers per tile than the classification itself:
+// measured (profiles/r02 ablations) 0.55 ms bookkeeping + 0.58 ms placement + 0.18 ms copy-out on top of 2.6 ms
+// per 1e9 pairs, and 34 of the kernel's 67 VALU instructions per sample.
+//
+// Here every partition owns a fixed REGION of the workgroup's LDS, sized once per launch by the survey
+// (1.5 x the partition's expected records per tile + 40, in whole lines; k_survey_parts).  The partition counter
+// starts a tile at the number of records left over from the previous one, so the value the classification's LDS
+// atomic returns IS the record's slot in the region: the record is stored at once, in phase 1.  After the tile's
+// single counting barrier, four threads per partition copy the region's whole 64-byte lines to the partition's open
+// chunk, move the last partial line to the front of the region and reset the counter to its length.  Two barriers
+// per tile instead of three, no scan, no second pass over the samples.
+//
+// A record that finds its region full (a tile with several times the partition's expected share: a burst of one
+// cold name) is counted exactly through the out-of-window queue instead.  The survey's per-partition shares use
+// the names' TOTAL counts, hot samples included, so that a mispredicted hot window cannot cause that.
+//
+// The kernel handles whole tiles only; the launcher gives the last n % TILE pairs to k_ingest_pairs.
+template <int NPT> struct Scatter3LdsT {
+    uint32_t cnt[NPT];            // records in the partition's region (leftover + this tile's, may exceed cap)
+    uint32_t cfill[NPT], cbase[NPT]; // open chunk of the partition: records in it, its index (persistent)
+    pu2_t pt[NPT];                // {region base (LDS halfword index), capacity in records}
+    uint32_t ov_key[OV_SLOTS], ov_cnt[OV_SLOTS];
+    uint32_t missq[2][V2_MISSQ];
+    uint32_t missn[2];
+    uint32_t dummy[64];
+    uint32_t pool_next, pad[1];
+};
+
+#ifndef LH_SC3_BATCH
+#define LH_SC3_BATCH 4
+#endif
+constexpr int SC3_BATCH = LH_SC3_BATCH;              // samples classified together (4 or 8)
+constexpr uint32_t region_records(uint32_t tile, uint32_t np) { return 3u * tile / 2u + 72u * np; }
+
+// Region sizes from the survey: g_pt[p] = {first record of the region (relative to the region area), capacity}.
+// One workgroup of 256 threads, after k_survey_plan.
+__global__ __launch_bounds__(256) void k_survey_parts(const uint32_t *__restrict__ g_cnt, uint32_t nmetrics,
+                                                      uint32_t log_np, uint32_t tile, pu2_t *__restrict__ g_pt)
+{
+    __shared__ uint32_t s_pc[256], s_cap[256];
+    __shared__ uint32_t s_total;
+    const uint32_t tid = threadIdx.x, np = 1u << log_np;
+    s_pc[tid] = 0;
+    if (tid == 0) s_total = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t m = tid; m < nmetrics; m += 256) { // m & (np - 1) == tid & (np - 1): np divides 256
+        const uint32_t c = g_cnt[m];
+        mine += c;
+    }
+    atomicAdd(&s_pc[tid & (np - 1)], mine);
+    atomicAdd(&s_total, mine);
+    __syncthreads();
+    const uint32_t total = s_total;
+    uint32_t cap = 0;
+    if (tid < np) {
+        const uint32_t est = total ? (uint32_t)(((unsigned long long)s_pc[tid] * tile) / total) : tile / np;
+        cap = (est + est / 2 + 40u + 31u) & ~31u;
+        if (cap > tile + 32u) cap = tile + 32u; // leftover (< 32) + a whole tile
+    }
+    s_cap[tid] = cap;
+    __syncthreads();
+    if (tid < np) {
+        uint32_t base = 0;
+        for (uint32_t i = 0; i < tid; i++) base += s_cap[i];
+        g_pt[tid] = (pu2_t){base, cap};
+    }
+}
+
+template <int BLOCK, int NPT, int BATCH>
+__global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const uint32_t *__restrict__ ids,
+                                                       const double *__restrict__ v, size_t ntiles, uint32_t nmetrics,
+                                                       uint32_t log_np, uint32_t log_w,
+                                                       const double *__restrict__ Tx,
+                                                       const NameEntry *__restrict__ g_nt,
+                                                       const pu4_t *__restrict__ g_hs,
+                                                       const uint32_t *__restrict__ g_hdr,
+                                                       const pu2_t *__restrict__ g_pt, uint32_t region_recs,
+                                                       uint32_t cells, rec16_t *__restrict__ records,
+                                                       uint32_t *__restrict__ cdesc, uint32_t chunks_per_wg,
+                                                       uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
+                                                       uint32_t *__restrict__ err, uint32_t dbg_arg)
+{
+    const uint32_t dbg = LH_DBG(dbg_arg);
+    // ONE LDS allocation: [Scatter3Lds][name table][regions][hot windows]
+    typedef Scatter3LdsT<NPT> LdsT;
+    static_assert(sizeof(LdsT) % 16 == 0, "the name table follows the struct in LDS");
+    static_assert(BLOCK == 4 * NPT, "flush: four threads per partition");
+    constexpr int V3_TILE = BLOCK * V2_SPT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char v2_smem[];
+    LdsT &L = *reinterpret_cast<LdsT *>(v2_smem);
+    NameEntry *nt = reinterpret_cast<NameEntry *>(v2_smem + sizeof(LdsT));         // [nmetrics]
+    uint32_t *lds32 = reinterpret_cast<uint32_t *>(v2_smem);
+    rec16_t *lds16 = reinterpret_cast<rec16_t *>(v2_smem);
+    const uint32_t reg_h = (uint32_t)(sizeof(LdsT) / 2) + 4 * ((nmetrics + 1) & ~1u); // halfword offset of the regions (16-byte aligned)
+    const uint32_t win_w = (reg_h + region_recs) / 2;                              // word offset of the hot windows
+    uint32_t *win = lds32 + win_w;                                                 // [cells]
+    constexpr uint32_t CNT_W = offsetof(LdsT, cnt) / 4, DUMMY_W = offsetof(LdsT, dummy) / 4;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t np = 1u << log_np, pmask = np - 1, W = 1u << log_w;
+    const uint32_t pool_base = blockIdx.x * chunks_per_wg;
+
+    for (uint32_t i = tid; i < nmetrics; i += BLOCK) {
+        NameEntry ne = g_nt[i];
+        ne.hot += win_w; // hot base as a word offset from the LDS base (< 40 960: fits the low half)
+        nt[i] = ne;
+    }
+    for (uint32_t i = tid; i < cells; i += BLOCK) win[i] = 0;
+    if (tid < NPT) {
+        pu2_t e = tid < np ? g_pt[tid] : (pu2_t){0u, 0u};
+        e.x += reg_h;
+        L.pt[tid] = e;
+        L.cnt[tid] = 0;
+        L.cfill[tid] = CHUNK;
+        L.cbase[tid] = INVALID;
+    }
+    ov_init(L.ov_key, L.ov_cnt, tid, BLOCK);
+    if (tid == 0) { L.pool_next = 0; L.missn[0] = 0; L.missn[1] = 0; }
+    __syncthreads();
+    const pu2_t my_pt = L.pt[tid >> 2]; // the flush phase's partition (constant over the launch)
+
+    const pd2_t *vp = reinterpret_cast<const pd2_t *>(v);
+    const pu2_t *ip = reinterpret_cast<const pu2_t *>(ids);
+    constexpr int NPAIR = V2_SPT / 2;
+    // two register sets used by alternate tiles, loads issued a whole tile period ahead, stores hidden from the
+    // compiler's s_waitcnt bookkeeping: see k_scatter2
+    pu2_t ida[NPAIR], idb[NPAIR];
+    pd2_t vaa[NPAIR], vab[NPAIR];
+    auto load_tile = [&](size_t tile, pu2_t (&di)[NPAIR], pd2_t (&dv)[NPAIR]) {
+        if (tile >= ntiles) tile = ntiles - 1; // the two tiles past the end that the pipeline touches (uniform)
+        if (dbg & 512u) tile = blockIdx.x;     // ablation: every load hits L2 (the workgroup re-reads its first tile)
+        const pu2_t *it = ip + tile * (V3_TILE / 2) + tid;
+        const pd2_t *vt = vp + tile * (V3_TILE / 2) + tid;
+#pragma unroll
+        for (int j = 0; j < NPAIR; j++) {
+            di[j] = __builtin_nontemporal_load(it + j * BLOCK);
+            dv[j] = __builtin_nontemporal_load(vt + j * BLOCK);
+        }
+    };
+    load_tile(blockIdx.x, ida, vaa);
+    asm volatile("" : "+v"(ida[0]), "+v"(ida[1]), "+v"(ida[2]), "+v"(ida[3]), "+v"(vaa[0]), "+v"(vaa[1]), "+v"(vaa[2]),
+                      "+v"(vaa[3]));
+    static_assert(NPAIR == 4, "the asm above names four register pairs");
+    load_tile((size_t)blockIdx.x + gridDim.x, idb, vab);
+
+    auto process_tile = [&](size_t tile, pu2_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
+        uint32_t rare = 0;
+        // ---- phase 1: classify and place.  Straight-line code, four samples at a time: their table reads, then
+        // their LDS atomics, then their record stores are in flight together.
+#pragma unroll
+        for (int h = 0; h < V2_SPT; h += BATCH) {
+            uint32_t id[BATCH], bin[BATCH], where[BATCH], rank[BATCH], rec[BATCH];
+            NameEntry ne[BATCH];
+            pu2_t pe[BATCH];
+            uint32_t unc = 0, miss = 0, coldm = 0;
+#pragma unroll
+            for (int k = 0; k < BATCH; k++) {
+                const int j = h + k;
+                const uint32_t raw = (j & 1) ? idv[j >> 1].y : idv[j >> 1].x;
+                const bool ok = raw < nmetrics; // an id >= nmetrics is reported, the sample skipped
+                rare |= ok ? 0u : 1u;
+                id[k] = ok ? raw : INVALID;
+                ne[k] = nt[(ok && !(dbg & 64u)) ? raw : 0u];
+                pe[k] = L.pt[raw & pmask];
+            }
+#pragma unroll
+            for (int k = 0; k < BATCH; k++) {
+                const int j = h + k;
+                const double x = (j & 1) ? val[j >> 1].y : val[j >> 1].x;
+                bool u;
+                if (dbg & 2u) { // ablation: no compress -- a pseudo-bin near the name's window origins
+                    bin[k] = (ne[k].org >> 16) + ((uint32_t)__double2loint(x) & 1023u);
+                    u = false;
+                } else {
+                    bin[k] = lh_bin_fast(x, u);
+                }
+                if (u) unc |= 1u << k;
+            }
+            if (unc) { // inside the guard band of a bucket threshold (1 sample in ~4 000): exact table compare
+#pragma unroll
+                for (int k = 0; k < BATCH; k++) {
+                    const int j = h + k;
+                    if (unc & (1u << k)) bin[k] = lh_bin_of((j & 1) ? val[j >> 1].y : val[j >> 1].x, Tx);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < BATCH; k++) {
+                const uint32_t hrel = bin[k] - (ne[k].org >> 16), crel = bin[k] - (ne[k].org & 0xffffu);
+                const bool valid = id[k] != INVALID;
+                const bool hot = valid && hrel < (ne[k].hot >> 16);
+                const bool cold = valid && !hot && crel < W;
+                where[k] = hot ? (ne[k].hot & 0xffffu) + hrel : cold ? CNT_W + (id[k] & pmask) : DUMMY_W + lane;
+                rec[k] = ((id[k] >> log_np) << log_w) | crel;
+                if (cold) coldm |= 1u << k;
+                if (valid && !hot && !cold) miss |= 1u << k;
+            }
+#pragma unroll
+            for (int k = 0; k < BATCH; k++) rank[k] = (dbg & 32u) ? 0u : atomicAdd(lds32 + where[k], 1u); // 32: no LDS atomics
+#pragma unroll
+            for (int k = 0; k < BATCH; k++) {
+                const bool fits = (coldm & (1u << k)) && rank[k] < pe[k].y;
+                if ((coldm & (1u << k)) && !fits) miss |= 1u << k; // the region is full: counted exactly below
+                lds16[fits ? pe[k].x + rank[k] : 2 * DUMMY_W + lane] = (rec16_t)rec[k];
+            }
+            if (miss) { // outside the name's cold window, or no room: queued, counted exactly by the flush phase
+#pragma unroll
+                for (int k = 0; k < BATCH; k++)
+                    if (miss & (1u << k)) {
+                        const uint32_t key = (id[k] << 16) | bin[k];
+                        const uint32_t at = atomicAdd(&L.missn[par], 1u);
+                        if (at < V2_MISSQ) L.missq[par][at] = key;
+                        else if (!ov_add(L.ov_key, L.ov_cnt, key, 1u)) v2_global_add(counts, ranges, id[k], bin[k], 1);
+                    }
+            }
+        }
+        if (rare) atomicOr(err, 1u); // an id >= nmetrics: reported by lh_sync / lh_extract
+        __syncthreads();                                   // barrier A: the tile's records are in the regions
+        load_tile(tile + 2 * (size_t)gridDim.x, idv, val); // this register set is free: the tile two steps ahead
+
+        // ---- phase 2: flush.  Four threads per partition (p = tid / 4, q = tid % 4: the q-th 16 bytes of a line).
+        if (tid == BLOCK - 1) L.missn[par ^ 1u] = 0; // the other parity's queue was drained in the previous tile
+        if (!(dbg & 16u)) {
+            uint32_t t2 = tid;
+            asm volatile("" : "+v"(t2)); // keeps this phase's address arithmetic inside the loop (see k_scatter2)
+            const uint32_t p = t2 >> 2, q = t2 & 3u;
+            const pu2_t e = my_pt;
+            const uint32_t c = min(L.cnt[p], e.y), full = c / LINE2, left = c % LINE2;
+            if (full) {
+                const uint32_t cf = L.cfill[p], cb = L.cbase[p];
+                const uint32_t room = (CHUNK - cf) / LINE2; // lines left in the open chunk (0: none open)
+                uint32_t first = 0;
+                if (full > room && q == 0) {
+                    const uint32_t tag = p << CD_SHIFT;
+                    const uint32_t over = full - room;
+                    const uint32_t k = (over + CHUNK / LINE2 - 1) / (CHUNK / LINE2);
+                    first = pool_base + atomicAdd(&L.pool_next, k);   // k consecutive chunks
+                    if (cb != INVALID) hidden_store_u32(cdesc + cb, tag | CHUNK);   // the old chunk is now full
+#pragma nounroll
+                    for (uint32_t i = 0; i + 1 < k; i++) hidden_store_u32(cdesc + first + i, tag | CHUNK);
+                    L.cbase[p] = first + k - 1;
+                    L.cfill[p] = (over - (k - 1) * (CHUNK / LINE2)) * LINE2;
+                } else if (q == 0) {
+                    L.cfill[p] = cf + full * LINE2;
+                }
+                first = __builtin_amdgcn_mov_dpp(first, 0x00, 0xf, 0xf, false); // quad_perm [0,0,0,0]: q == 0's value
+                const uint32_t dA = cb * CHUNK + cf, dB = first * CHUNK - room * LINE2;
+                const rec16_t *src = lds16 + e.x + q * 8;
+#pragma nounroll
+                for (uint32_t l = 0; l < full; l++) {
+                    const pu4_t r4 = *reinterpret_cast<const pu4_t *>(src + l * LINE2);
+                    const uint32_t dst = (l < room ? dA : dB) + l * LINE2 + q * 8;
+                    if (!(dbg & 1u)) hidden_store_u4(records + dst, r4);
+                }
+                // the last partial line moves to the front of the region (its slots are this thread's own)
+                if (q * 8 < left)
+                    *reinterpret_cast<pu4_t *>(lds16 + e.x + q * 8) =
+                        *reinterpret_cast<const pu4_t *>(src + full * LINE2);
+            }
+            if (q == 0) L.cnt[p] = left;
+        } else if (tid < NPT) {
+            L.cnt[tid] = 0; // ablation: phase 1 and the loads only
+        }
+        // the tile's out-of-window samples, one per thread: aggregated in the small LDS table, else a global atomic
+        {
+            const uint32_t nq = min(L.missn[par], V2_MISSQ);
+            for (uint32_t i = tid; i < nq; i += BLOCK) {
+                const uint32_t key = L.missq[par][i];
+                if (!ov_add(L.ov_key, L.ov_cnt, key, 1u)) v2_global_add(counts, ranges, key >> 16, key & 0xffffu, 1);
+            }
+        }
+        __syncthreads();                                   // barrier B: counters and regions are ready for the next tile
+    };
+    for (size_t tile = blockIdx.x; tile < ntiles; tile += 2 * (size_t)gridDim.x) {
+        process_tile(tile, ida, vaa, 0u);
+        if (tile + gridDim.x < ntiles) process_tile(tile + gridDim.x, idb, vab, 1u); // workgroup-uniform
+    }
+
+    // ---- drain: the regions' leftovers (< one line each) and the open chunks' descriptors
+    {
+        const uint32_t p = tid >> 2, q = tid & 3u;
+        const uint32_t left = L.cnt[p]; // < LINE2 after a flush
+        uint32_t d = INVALID;
+        if (left && q == 0) {
+            uint32_t cf = L.cfill[p], cb = L.cbase[p];
+            if (cf == CHUNK) { // no open chunk, or it is exactly full
+                if (cb != INVALID) cdesc[cb] = (p << CD_SHIFT) | CHUNK;
+                cb = pool_base + atomicAdd(&L.pool_next, 1u);
+                cf = 0;
+                L.cbase[p] = cb;
+            }
+            d = cb * CHUNK + cf;
+            L.cfill[p] = cf + left;
+        }
+        d = __builtin_amdgcn_mov_dpp(d, 0x00, 0xf, 0xf, false);
+        if (left && q * 8 < left)
+            *reinterpret_cast<pu4_t *>(records + d + q * 8) = *reinterpret_cast<const pu4_t *>(lds16 + L.pt[p].x + q * 8);
+    }
+    __syncthreads();
+    if (tid < np && L.cbase[tid] != INVALID) cdesc[L.cbase[tid]] = (tid << CD_SHIFT) | L.cfill[tid];
+
+    // ---- flush the hot windows (one uint64 atomic per occupied bin) and the out-of-window table
+    const uint32_t nhot = g_hdr[0];
+    for (uint32_t s = wave; s < nhot; s += BLOCK / 64) {
+        const pu4_t h = g_hs[s];
+        const uint32_t name = h.x, org = h.y & 0xffffu, width = h.y >> 16, base = h.z;
+        uint32_t mn = INVALID, mx = 0;
+        for (uint32_t i = lane; i < width; i += 64) {
+            const uint32_t c = win[base + i];
+            if (c) {
+                const uint32_t b = org + i;
+                atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)name * LH_NKEYS + b]),
+                          (unsigned long long)c);
+                mn = min(mn, b);
+                mx = max(mx, b);
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            mn = min(mn, (uint32_t)__shfl_xor(mn, d, 64));
+            mx = max(mx, (uint32_t)__shfl_xor(mx, d, 64));
+        }
+        if (lane == 0 && mn != INVALID) {
+            uint32_t *r = ranges + 2 * (size_t)name;
+            if (mn < r[0]) atomicMin(&r[0], mn);
+            if (mx > r[1]) atomicMax(&r[1], mx);
+        }
+    }
+    for (uint32_t i = tid; i < OV_SLOTS; i += BLOCK)
+        if (L.ov_key[i] != OV_EMPTY) v2_global_add(counts, ranges, L.ov_key[i] >> 16, L.ov_key[i] & 0xffffu, L.ov_cnt[i]);
+}
+
+// ---------------------------------------------------------------------------
 // P2 v2: the record is the LDS index
 // ---------------------------------------------------------------------------
 constexpr size_t P2V2_LDS_BYTES = (P2V2_WINWORDS + 3 * PART_MAX_MPP) * sizeof(uint32_t) + 16;
@@ -676,31 +1043,29 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist2(const rec16_t *__restri
             }
         }
     };
-    constexpr uint32_t WSTEP = P2_BLOCK / 64;
-    u4_t bufA[2], bufB[2];
-    uint32_t j = wave;
-    uint32_t cnA = 0, cnB = 0;
-    if (j < cnt) {
-        const uint32_t cid = __builtin_amdgcn_readfirstlane(list[j]);
-        cnA = __builtin_amdgcn_readfirstlane(cdesc[cid] & CD_MASK);
-        load_chunk(cid, bufA);
-    }
-    while (j < cnt) {
-        if (j + WSTEP < cnt) {
-            const uint32_t cid = __builtin_amdgcn_readfirstlane(list[j + WSTEP]);
-            cnB = __builtin_amdgcn_readfirstlane(cdesc[cid] & CD_MASK);
-            load_chunk(cid, bufB);
+    // Each wave walks chunks wave, wave + 16, ...; DEPTH of them are in flight per wave (8 KiB per wave, 128 KiB per CU)
+    // while the oldest is reduced: with one workgroup per CU nothing else hides the load latency.
+    constexpr uint32_t WSTEP = P2_BLOCK / 64, DEPTH = 4;
+    u4_t buf[DEPTH][2];
+    uint32_t cn[DEPTH];
+    auto fetch = [&](uint32_t jj, uint32_t slot) {
+        cn[slot] = 0;
+        if (jj < cnt) {
+            const uint32_t cid = __builtin_amdgcn_readfirstlane(list[jj]);
+            cn[slot] = __builtin_amdgcn_readfirstlane(cdesc[cid] & CD_MASK);
+            load_chunk(cid, buf[slot]);
         }
-        reduce_chunk(bufA, cnA);
-        j += WSTEP;
-        if (j >= cnt) break;
-        if (j + WSTEP < cnt) {
-            const uint32_t cid = __builtin_amdgcn_readfirstlane(list[j + WSTEP]);
-            cnA = __builtin_amdgcn_readfirstlane(cdesc[cid] & CD_MASK);
-            load_chunk(cid, bufA);
+    };
+#pragma unroll
+    for (uint32_t d = 0; d < DEPTH; d++) fetch(wave + d * WSTEP, d);
+    for (uint32_t j = wave; j < cnt; j += DEPTH * WSTEP) {
+#pragma unroll
+        for (uint32_t d = 0; d < DEPTH; d++) { // fully unrolled: the slot index is a compile-time constant
+            if (j + d * WSTEP < cnt) {           // wave-uniform
+                reduce_chunk(buf[d], cn[d]);
+                fetch(j + (d + DEPTH) * WSTEP, d);
+            }
         }
-        reduce_chunk(bufB, cnB);
-        j += WSTEP;
     }
     __syncthreads();
 
@@ -727,22 +1092,28 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist2(const rec16_t *__restri
 // plan + launcher
 // ---------------------------------------------------------------------------
 struct Part2Plan {
-    uint32_t shape;            // 0 = <1024, 256>, 1 = <512, 128>
+    uint32_t shape;            // bit 0: 0 = <1024, 256>, 1 = <512, 128>; bit 1: direct record stores (k_scatter3)
     uint32_t block, tile, lds_fixed;
     uint32_t log_np, np, mpp, log_w, cells, g1, chunks_per_wg, nchunks;
-    size_t off_rec, off_cd, off_sorted, off_small, off_stat, off_nt, off_hs, off_hdr, total;
+    uint32_t region_recs;      // shapes 2, 3: records of LDS the partitions' regions take
+    size_t lds_dyn;            // dynamic LDS of the scatter kernel
+    size_t off_rec, off_cd, off_sorted, off_small, off_stat, off_nt, off_hs, off_hdr, off_pt, total;
 };
 
 static bool make_plan2(size_t n, uint32_t nmetrics, int num_cus, const PartTuning &tune, Part2Plan &P)
 {
     if (!tune.v2 || n < (tune.v2_min_samples ? tune.v2_min_samples : V2_MIN_SAMPLES) || n > (size_t(1) << 31)) return false;
     if (nmetrics < 2 || nmetrics > V2_MAX_NAMES) return false;
-    P.shape = tune.v2_shape ? 1u : 0u;
-    const uint32_t npt = P.shape ? 128u : 256u, wgs_per_cu = P.shape ? 2u : 1u;
-    P.block = P.shape ? 512u : 1024u;
+    P.shape = tune.v2_shape & 3u;
+    const bool half = P.shape & 1u, direct = P.shape & 2u;
+    const uint32_t npt = half ? 128u : 256u, wgs_per_cu = half ? 2u : 1u;
+    P.block = half ? 512u : 1024u;
     P.tile = P.block * V2_SPT;
-    P.lds_fixed = (uint32_t)(P.shape ? sizeof(Scatter2LdsT<512, 128>) : sizeof(Scatter2LdsT<1024, 256>));
-    const uint32_t names_per_part = P.shape ? 8u : 4u;
+    if (direct)
+        P.lds_fixed = (uint32_t)(half ? sizeof(Scatter3LdsT<128>) : sizeof(Scatter3LdsT<256>));
+    else
+        P.lds_fixed = (uint32_t)(half ? sizeof(Scatter2LdsT<512, 128>) : sizeof(Scatter2LdsT<1024, 256>));
+    const uint32_t names_per_part = half ? 8u : 4u;
     const uint32_t want_np = (nmetrics + names_per_part - 1) / names_per_part;
     P.log_np = std::min(ilog2_ceil(npt), ilog2_ceil(want_np));
     P.np = 1u << P.log_np;
@@ -753,10 +1124,13 @@ static bool make_plan2(size_t n, uint32_t nmetrics, int num_cus, const PartTunin
     P.log_w = lw; // cold window = 2^log_w bins per name; the record (local << log_w | offset) is < 32 768
     // hot windows: whatever LDS is left beside the scatter structures and the per-name table
     const size_t budget = V2_LDS_TOTAL / wgs_per_cu;
-    const size_t fixed = P.lds_fixed + (size_t)nmetrics * sizeof(NameEntry) + 256;
+    P.region_recs = direct ? region_records(P.tile, P.np) : 0u;
+    const size_t nt_bytes = (size_t)(direct ? (nmetrics + 1) & ~1u : nmetrics) * sizeof(NameEntry);
+    const size_t fixed = P.lds_fixed + nt_bytes + (size_t)P.region_recs * sizeof(rec16_t) + 256;
     P.cells = fixed + 4096 <= budget ? (uint32_t)((budget - fixed) / 4) & ~63u : 0u;
     if (P.cells > 40000u) P.cells = 40000u & ~63u; // LDS word offsets of the windows must stay below 65 536
     if (!tune.hot) P.cells = 0;
+    P.lds_dyn = fixed - 256 + (size_t)P.cells * 4;
     const size_t ntiles = (n + P.tile - 1) / P.tile;
     size_t g1 = (size_t)num_cus * wgs_per_cu; // the workgroups of a CU own its LDS between them
     if (g1 > (ntiles + 3) / 4) g1 = (ntiles + 3) / 4;
@@ -773,6 +1147,7 @@ static bool make_plan2(size_t n, uint32_t nmetrics, int num_cus, const PartTunin
     P.off_nt = take((size_t)nmetrics * sizeof(NameEntry));
     P.off_hs = take((size_t)V2_MAX_SLOTS * sizeof(pu4_t));
     P.off_hdr = take(64);
+    P.off_pt = take(256 * sizeof(pu2_t));
     P.off_rec = take((size_t)P.nchunks * CHUNK * sizeof(rec16_t));
     P.off_cd = take((size_t)P.nchunks * sizeof(uint32_t));
     P.off_sorted = take((size_t)P.nchunks * sizeof(uint32_t));
@@ -797,7 +1172,7 @@ hipError_t launch_ingest_pairs_part2(const uint32_t *d_ids, const double *d_v, s
     Part2Plan P;
     if (!make_plan2(n, nmetrics, num_cus, tune, P) || scratch_bytes < P.total || !scratch) return hipErrorInvalidValue;
     if (!part_aligned(d_ids, d_v)) return hipErrorInvalidValue;
-    const size_t p1_dyn = P.lds_fixed + (size_t)nmetrics * sizeof(NameEntry) + (size_t)P.cells * 4;
+    const size_t p1_dyn = P.lds_dyn;
     const size_t sv_dyn = (size_t)nmetrics * 16;
     static std::atomic<bool> attr_set{false}; // benign if two threads race: both set the same attributes
     if (!attr_set) {
@@ -808,6 +1183,12 @@ hipError_t launch_ingest_pairs_part2(const uint32_t *d_ids, const double *d_v, s
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)V2_LDS_TOTAL);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter2<512, 128>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(V2_LDS_TOTAL / 2));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter3<1024, 256, SC3_BATCH>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)V2_LDS_TOTAL);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter3<512, 128, SC3_BATCH>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(V2_LDS_TOTAL / 2));
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_survey_count),
@@ -835,6 +1216,7 @@ hipError_t launch_ingest_pairs_part2(const uint32_t *d_ids, const double *d_v, s
     NameEntry *g_nt = reinterpret_cast<NameEntry *>(base + P.off_nt);
     pu4_t *g_hs = reinterpret_cast<pu4_t *>(base + P.off_hs);
     uint32_t *g_hdr = reinterpret_cast<uint32_t *>(base + P.off_hdr);
+    pu2_t *g_pt = reinterpret_cast<pu2_t *>(base + P.off_pt);
 
     hipError_t e = hipMemsetAsync(L1.cdesc, 0xff, (size_t)P.nchunks * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
@@ -849,8 +1231,25 @@ hipError_t launch_ingest_pairs_part2(const uint32_t *d_ids, const double *d_v, s
                            d_Tx, g_cnt, g_mninv, g_mx, g_sum);
         hipLaunchKernelGGL(k_survey_plan, dim3(1), dim3(V2_BLOCK), 0, s, g_cnt, g_mninv, g_mx, g_sum, nmetrics,
                            P.log_w, P.cells, g_nt, g_hs, g_hdr);
+        if (P.shape & 2u)
+            hipLaunchKernelGGL(k_survey_parts, dim3(1), dim3(256), 0, s, g_cnt, nmetrics, P.log_np, P.tile, g_pt);
     }
-    if (P.shape)
+    if (P.shape & 2u) { // whole tiles through the region kernel, the last n % tile pairs through the plain kernel
+        const size_t nt_full = n / P.tile, done = nt_full * P.tile;
+        if (P.shape == 3)
+            hipLaunchKernelGGL((k_scatter3<512, 128, SC3_BATCH>), dim3(P.g1), dim3(512), p1_dyn, s, d_ids, d_v, nt_full, nmetrics,
+                               P.log_np, P.log_w, d_Tx, g_nt, g_hs, g_hdr, g_pt, P.region_recs, P.cells, records,
+                               L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, dbg);
+        else
+            hipLaunchKernelGGL((k_scatter3<1024, 256, SC3_BATCH>), dim3(P.g1), dim3(1024), p1_dyn, s, d_ids, d_v, nt_full,
+                               nmetrics, P.log_np, P.log_w, d_Tx, g_nt, g_hs, g_hdr, g_pt, P.region_recs, P.cells,
+                               records, L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, dbg);
+        if (done < n) {
+            e = launch_ingest_pairs(d_ids + done, d_v + done, n - done, counts, ranges, nmetrics, d_Tx, d_err, num_cus, s);
+            if (e != hipSuccess) return e;
+        }
+    }
+    else if (P.shape == 1)
         hipLaunchKernelGGL((k_scatter2<512, 128>), dim3(P.g1), dim3(512), p1_dyn, s, d_ids, d_v, n, nmetrics, P.log_np,
                            P.log_w, d_Tx, g_nt, g_hs, g_hdr, P.cells, records, L1.cdesc, P.chunks_per_wg, counts,
                            ranges, d_err, dbg);

@@ -92,7 +92,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("shape", [0, 1], ids=["1024x256", "512x128"])
+@pytest.mark.parametrize("shape", [0, 1, 2, 3], ids=["1024x256", "512x128", "1024x256-direct", "512x128-direct"])
 @pytest.mark.parametrize("M,n,kind,skew", CASES)
 def test_survey_path_is_exact(native_lib, torch_cuda, M, n, kind, skew, shape):
     import loghisto_amd
@@ -113,7 +113,7 @@ def test_survey_path_is_exact(native_lib, torch_cuda, M, n, kind, skew, shape):
                 _check(snap, ids, v, M, got)
 
 
-@pytest.mark.parametrize("shape", [0, 1], ids=["1024x256", "512x128"])
+@pytest.mark.parametrize("shape", [0, 1, 2, 3], ids=["1024x256", "512x128", "1024x256-direct", "512x128-direct"])
 def test_survey_path_bad_ids_sublaunches_and_two_launches_per_epoch(native_lib, torch_cuda, shape):
     import loghisto_amd
     rng = np.random.default_rng(77)

@@ -14,8 +14,8 @@ timeout 300 python tools/sweep.py --samples 1e9 --pairs 1024 --reps 3 --opt 9=1 
 for M in 64 256 4096 8192; do
   timeout 300 python tools/sweep.py --samples 1e9 --pairs $M --reps 3 --opt 9=1 --opt 11=$SH --dists lognormal 2>/dev/null | cut -c1-200 | tee -a $OUT/sweep_names.jsonl
 done; done
-echo "== ablations (tuning build; results wrong by design): bit 1 = no record stores, 2 = no compress, 4 = no P2"
-for D in 0 4; do
+echo "== ablations (tuning build; results wrong by design): 1 no record stores, 2 no compress, 4 no P2, 16 phase 1 only, 32 no LDS atomics, 64 no name-table gather"
+for D in 0 4 16 18 48 112 114; do
   timeout 300 python tools/sweep.py --lib loghisto_amd/build/liblhgpu_tuning.so --samples 1e9 --pairs 1024 --reps 3 --opt 9=1 --opt 100=$D --dists lognormal 2>/dev/null | cut -c1-200 | tee -a $OUT/ablate_v2.jsonl
 done
 cd /tmp; export TMPDIR=/tmp
