@@ -282,11 +282,12 @@ typedef struct lh_counters {
     uint64_t backpressure_waits;   /* submitters that had to wait for a staging half-buffer */
     uint64_t window_misses;        /* samples the single-pass kernel sent to global atomics */
     uint32_t small_path_disabled;  /* 1 while adaptive dispatch routes few-name streams through the partitioned path */
-    uint32_t reserved;
+    uint32_t regions_disabled;     /* 1 while a name-clustered stream keeps the mixed ingest on the exact-layout scatter */
     uint64_t scratch_bytes;        /* HBM scratch of the partitioned mixed ingest (one block per engine)  */
     uint64_t sublaunches;          /* partitioned sub-launches (a large launch is cut so the scratch stays bounded) */
     uint64_t samples_partitioned_v2; /* of samples_partitioned: through the survey + 2-byte-record path          */
     uint64_t counter_events;         /* (id, amount) events through lh_submit_counts*                               */
+    uint64_t region_overflows;       /* records the region scatter counted through the exact out-of-window path     */
 } lh_counters;
 int lh_get_counters(lh_engine *e, lh_counters *out);
 
@@ -306,8 +307,12 @@ int lh_get_counters(lh_engine *e, lh_counters *out);
  *   LH_OPT_PART_V2            0 / 1: the survey + 2-byte-record generation of the partitioned path (default 1;
  *                             used for 33 .. 8 192 names)
  *   LH_OPT_PART_V2_MIN_PAIRS  smallest launch that takes it (default 2^24; >= 2^17: tests exercise it on small inputs)
- *   LH_OPT_PART_V2_SHAPE      0: one 1 024-thread scatter workgroup per CU over <= 256 partitions; 1: two
- *                             512-thread workgroups per CU over <= 128 partitions
+ *   LH_OPT_PART_V2_SHAPE      bit 0: two 512-thread scatter workgroups per CU over <= 128 partitions instead of one
+ *                             1 024-thread workgroup over <= 256; bit 1: fixed per-partition LDS regions (records
+ *                             placed by the classifying phase) instead of the exact per-tile layout.  Default 2.
+ *                             With bit 1 set the engine falls back to the exact layout while more than 2 % of an
+ *                             interval's samples overflow their regions (a stream clustered by name), see
+ *                             lh_counters.regions_disabled
  *   LH_OPT_SMALL_PATH         0 / 1: the single-pass kernel for <= 32 names (1 also re-arms it after adaptive
  *                             dispatch turned it off) */
 enum {

@@ -29,11 +29,12 @@ class LhCounters(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("samples_single", "samples_small", "samples_partitioned", "samples_direct",
                                            "launches", "flips", "flips_busy", "extracts", "backpressure_waits",
                                            "window_misses")] + [("small_path_disabled", C.c_uint32),
-                                                                ("reserved", C.c_uint32),
+                                                                ("regions_disabled", C.c_uint32),
                                                                 ("scratch_bytes", C.c_uint64),
                                                                 ("sublaunches", C.c_uint64),
                                                                 ("samples_partitioned_v2", C.c_uint64),
-                                                                ("counter_events", C.c_uint64)]
+                                                                ("counter_events", C.c_uint64),
+                                                                ("region_overflows", C.c_uint64)]
 
 # lh_set_option keys (include/loghisto_gpu.h)
 OPT_TWO_LEVEL_ABOVE, OPT_HOT_MIN_TILES, OPT_HOT_WINDOWS, OPT_NAMES_PER_PARTITION = 1, 2, 3, 4

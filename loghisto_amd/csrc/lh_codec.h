@@ -147,22 +147,22 @@ __device__ __forceinline__ uint32_t lh_bin_of(double v, const double *__restrict
 }
 
 // The same index in two steps, for kernels that classify several samples in straight-line code: the fast
-// part is branch-free (kext from the hardware log2; NaN / Inf give 0 as in lh_bin_of) and reports whether the
-// sample lies inside the guard band of a threshold; only then (about 1 sample in 4 000) must the caller take
-// lh_bin_of's exact table compare.
+// part is branch-free (kext from the hardware log2) and reports whether the sample lies inside the guard band of
+// a threshold or is not finite; only then (about 1 sample in 4 000) must the caller take lh_bin_of's exact path.
 __device__ __forceinline__ uint32_t lh_bin_fast(double v, bool &uncertain)
 {
     const double x = 1.0 + fabs(v);
     const uint32_t hi = (uint32_t)__double2hiint(x), lo = (uint32_t)__double2loint(x);
-    const uint32_t eb = hi >> 20;
-    const int e = (int)eb - 1023;
     const float m = __uint_as_float(0x3f800000u | ((hi & 0xfffffu) << 3) | (lo >> 29));
     const float l2 = __builtin_amdgcn_logf(m);
-    const double uq = __builtin_fma((double)e + (double)l2, 69.314718055994530942 * 16384.0, 8192.0);
+    // (biased exponent + log2 m) * C + (8192 - 1023 C): the bias folded into the constant.  The sum is exact
+    // (an integer below 2 048 plus a float), the constant's rounding (2.4e-7 of a Q14 unit) is far inside the guard.
+    constexpr double C = 69.314718055994530942 * 16384.0;
+    const double uq = __builtin_fma((double)(hi >> 20) + (double)l2, C, 8192.0 - 1023.0 * C);
     const int u = (int)uq;
-    const bool finite = eb < 0x7ffu;
-    uncertain = finite && ((((uint32_t)u + LH_GUARD_Q14) & 16383u) < 2u * LH_GUARD_Q14);
-    return bin_from_kext(finite ? (u >> 14) : 0, v);
+    // NaN / Inf (x's exponent field all ones) take the exact path too: lh_bin_of gives them bucket 0
+    uncertain = hi >= 0x7ff00000u || ((((uint32_t)u + LH_GUARD_Q14) & 16383u) < 2u * LH_GUARD_Q14);
+    return bin_from_kext(u >> 14, v);
 }
 
 } // namespace lh

@@ -173,6 +173,13 @@ struct lh_engine {
     // missed its LDS windows; when that exceeds 2 % the engine uses the partitioned path (wider windows)
     std::atomic<uint64_t> small_samples{0};
     std::atomic<bool> small_disabled{false};
+    // the region scatter reports records that found their LDS region full (a stream clustered by name); above 2 % of
+    // an interval's samples later calls take the exact-layout scatter, and the regions get another try every 64 flips
+    unsigned long long *h_rstat = nullptr, *d_rstat = nullptr; // pinned, device-visible
+    std::atomic<bool> regions_disabled{false};
+    std::atomic<uint64_t> region_samples{0}, c_region_ovf{0};
+    uint64_t rstat_seen = 0;
+    int flips_since_regions_off = 0;
 
     // self-metrics (lh_get_counters)
     std::atomic<uint64_t> c_single{0}, c_small{0}, c_part{0}, c_direct{0}, c_launches{0}, c_flips{0}, c_busy{0},
@@ -280,11 +287,13 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
             // block bounded: at most `sublaunch_pairs` pairs each, halved until the block fits `scratch_cap`
             // (power-of-two cuts keep both arrays on their vector alignment).
             size_t sub = take < e->sublaunch_pairs ? take : e->sublaunch_pairs;
+            lh::PartTuning tune = e->tune;
+            if (e->regions_disabled.load(std::memory_order_relaxed)) tune.v2_shape &= ~2u; // clustered stream: exact layout
             // second generation (survey + 2-byte records) when the launch is large enough and has <= 8 192 names
             auto scratch_need = [&](size_t m, bool *v2) {
-                size_t b = lh::part2_scratch_bytes(m, e->cfg.max_metrics, e->num_cus, e->tune);
+                size_t b = lh::part2_scratch_bytes(m, e->cfg.max_metrics, e->num_cus, tune);
                 *v2 = b != 0;
-                return b ? b : lh::part_scratch_bytes(m, e->cfg.max_metrics, e->num_cus, e->tune);
+                return b ? b : lh::part_scratch_bytes(m, e->cfg.max_metrics, e->num_cus, tune);
             };
             bool v2 = false;
             size_t need = scratch_need(sub, &v2);
@@ -318,13 +327,13 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
                 // one survey per call: the first sub-launch samples everything that is left of the call (n pairs)
                 HIPCHK(lh::launch_ingest_pairs_part2(d_ids, d_v, take, surveyed ? 0 : n, b.counts, b.ranges,
                                                      e->cfg.max_metrics, e->d_Tx, e->d_err, e->scratch_p,
-                                                     e->scratch_bytes, e->num_cus, e->tune, s));
+                                                     e->scratch_bytes, e->num_cus, tune, e->d_rstat, s));
                 surveyed = true;
+                if (tune.v2_shape & 2u) e->region_samples.fetch_add(take, std::memory_order_relaxed);
                 e->c_part2.fetch_add(take, std::memory_order_relaxed);
             } else {
                 HIPCHK(lh::launch_ingest_pairs_part(d_ids, d_v, take, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx,
-                                                    e->d_err, e->scratch_p, e->scratch_bytes, e->num_cus, e->tune,
-                                                    s));
+                                                    e->d_err, e->scratch_p, e->scratch_bytes, e->num_cus, tune, s));
             }
             HIPCHK(hipEventRecord(e->scratch_done, s));
             e->scratch_stream = s;
@@ -430,6 +439,7 @@ void free_engine(lh_engine *e)
     if (e->d_Tx) (void)hipFree(e->d_Tx);
     if (e->d_D) (void)hipFree(e->d_D);
     if (e->d_err) (void)hipFree(e->d_err);
+    if (e->h_rstat) (void)hipHostFree(e->h_rstat);
     if (e->d_xbuf) (void)hipFree(e->d_xbuf);
     if (e->h_xbuf) (void)hipHostFree(e->h_xbuf);
     if (e->d_names) (void)hipFree(e->d_names);
@@ -495,6 +505,13 @@ int create_impl(const lh_config *cfg_in, lh_engine *e)
 
     HIPCHK(hipMalloc((void **)&e->d_Tx, sizeof(double) * LH_NTHRESH));
     HIPCHK(hipMalloc((void **)&e->d_D, sizeof(double) * LH_NKEYS));
+    HIPCHK(hipHostMalloc((void **)&e->h_rstat, 16, hipHostMallocDefault));
+    e->h_rstat[0] = 0;
+    {
+        void *dp = nullptr;
+        HIPCHK(hipHostGetDevicePointer(&dp, e->h_rstat, 0));
+        e->d_rstat = static_cast<unsigned long long *>(dp);
+    }
     HIPCHK(hipMalloc((void **)&e->d_err, 16)); // [0] bad id flag, [1] window misses, [2] extract done counter
     HIPCHK(hipMemsetAsync(e->d_err, 0, 16, e->xstream));
     HIPCHK(lh::launch_gen_tables(e->d_Tx, e->d_D, e->xstream));
@@ -929,6 +946,21 @@ int lh_flip(lh_engine *e, lh_snapshot **out)
     e->bufs[(size_t)next].state = BUF_CURRENT;
     e->live_snapshots.fetch_add(1);
     e->c_flips.fetch_add(1, std::memory_order_relaxed);
+    {
+        // region overflows of the launches that have completed so far (the kernels add to pinned memory)
+        const uint64_t now = __atomic_load_n(e->h_rstat, __ATOMIC_RELAXED);
+        const uint64_t ov = now - e->rstat_seen;
+        e->rstat_seen = now;
+        const uint64_t seen = e->region_samples.exchange(0);
+        if (ov) e->c_region_ovf.fetch_add(ov, std::memory_order_relaxed);
+        if (ov && ov * 50 > seen) {
+            e->regions_disabled.store(true);
+            e->flips_since_regions_off = 0;
+        } else if (e->regions_disabled.load(std::memory_order_relaxed) && ++e->flips_since_regions_off >= 64) {
+            e->flips_since_regions_off = 0;
+            e->regions_disabled.store(false);
+        }
+    }
     // adaptive dispatch is not one-way: the few-name single-pass kernel gets another interval every 64 flips
     // (its window-miss counter turns it off again if the stream is still too wide for it)
     if (e->small_disabled.load(std::memory_order_relaxed) && !e->small_forced_off) {
@@ -1782,11 +1814,12 @@ int lh_get_counters(lh_engine *e, lh_counters *out)
     out->backpressure_waits = e->c_waits.load();
     out->window_misses = e->c_misses.load();
     out->small_path_disabled = e->small_disabled.load() ? 1u : 0u;
-    out->reserved = 0;
+    out->regions_disabled = e->regions_disabled.load() ? 1u : 0u;
     out->scratch_bytes = e->c_scratch.load();
     out->sublaunches = e->c_sublaunches.load();
     out->samples_partitioned_v2 = e->c_part2.load();
     out->counter_events = e->c_counts.load();
+    out->region_overflows = e->c_region_ovf.load();
     return LH_OK;
 }
 

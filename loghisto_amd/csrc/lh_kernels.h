@@ -37,7 +37,8 @@ struct PartTuning {
     bool hot = true;                // hot-name windows allowed at all
     bool v2 = true;                 // survey + 2-byte-record path (lh_kernels_part2.h) for <= 8 192 names
     size_t v2_min_samples = 0;      // 0 = default (2^24): smaller launches do not amortise the survey
-    uint32_t v2_shape = 0;          // 0: one 1 024-thread workgroup per CU, 256 partitions; 1: two 512-thread, 128
+    uint32_t v2_shape = 2;          // bit 0: two 512-thread workgroups per CU (128 partitions) instead of one 1 024-thread (256);
+                                    // bit 1: fixed per-partition regions (k_scatter3) instead of the exact per-tile layout
     uint32_t dbg = 0;               // -DLH_TUNING builds only: timing ablations (results are wrong); ignored otherwise
 };
 
@@ -67,10 +68,11 @@ hipError_t launch_count_fold(const uint64_t *cur, const uint32_t *flag, uint64_t
 // part2_scratch_bytes returns 0 when the launch should take the first-generation path.
 size_t part2_scratch_bytes(size_t n, uint32_t nmetrics, int num_cus, const PartTuning &tune);
 // survey_n: pairs of [d_ids, d_v) to survey before the scatter (the whole call), 0 = reuse the scratch block's tables
+// region_stat: device-visible counter (pinned host memory) the region kernel adds its overflowed records to, or null
 hipError_t launch_ingest_pairs_part2(const uint32_t *d_ids, const double *d_v, size_t n, size_t survey_n,
                                      uint64_t *counts, uint32_t *ranges, uint32_t nmetrics, const double *d_Tx,
                                      uint32_t *d_err, void *scratch, size_t scratch_bytes, int num_cus,
-                                     const PartTuning &tune, hipStream_t s);
+                                     const PartTuning &tune, unsigned long long *region_stat, hipStream_t s);
 
 // K2: extract.  One workgroup per metric.
 // ExtractNotify (optional): when the outputs live in host-mapped memory the last workgroup to finish stores

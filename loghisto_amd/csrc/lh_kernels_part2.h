@@ -671,7 +671,7 @@ template <int NPT> struct Scatter3LdsT {
     uint32_t missq[2][V2_MISSQ];
     uint32_t missn[2];
     uint32_t dummy[64];
-    uint32_t pool_next, pad[1];
+    uint32_t pool_next, ovn; // ovn: records that found their region full (reported to the engine)
 };
 
 #ifndef LH_SC3_BATCH
@@ -727,7 +727,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const uint32_t *__restric
                                                        uint32_t cells, rec16_t *__restrict__ records,
                                                        uint32_t *__restrict__ cdesc, uint32_t chunks_per_wg,
                                                        uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
-                                                       uint32_t *__restrict__ err, uint32_t dbg_arg)
+                                                       uint32_t *__restrict__ err,
+                                                       unsigned long long *__restrict__ rstat, uint32_t dbg_arg)
 {
     const uint32_t dbg = LH_DBG(dbg_arg);
     // ONE LDS allocation: [Scatter3Lds][name table][regions][hot windows]
@@ -763,7 +764,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const uint32_t *__restric
         L.cbase[tid] = INVALID;
     }
     ov_init(L.ov_key, L.ov_cnt, tid, BLOCK);
-    if (tid == 0) { L.pool_next = 0; L.missn[0] = 0; L.missn[1] = 0; }
+    if (tid == 0) { L.pool_next = 0; L.ovn = 0; L.missn[0] = 0; L.missn[1] = 0; }
     __syncthreads();
     const pu2_t my_pt = L.pt[tid >> 2]; // the flush phase's partition (constant over the launch)
 
@@ -800,7 +801,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const uint32_t *__restric
             uint32_t id[BATCH], bin[BATCH], where[BATCH], rank[BATCH], rec[BATCH];
             NameEntry ne[BATCH];
             pu2_t pe[BATCH];
-            uint32_t unc = 0, miss = 0, coldm = 0;
+            uint32_t unc = 0, miss = 0, coldm = 0, full = 0;
 #pragma unroll
             for (int k = 0; k < BATCH; k++) {
                 const int j = h + k;
@@ -824,7 +825,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const uint32_t *__restric
                 }
                 if (u) unc |= 1u << k;
             }
-            if (unc) { // inside the guard band of a bucket threshold (1 sample in ~4 000): exact table compare
+            if (unc && !(dbg & 1024u)) { // inside the guard band of a bucket threshold (1 sample in ~4 000): exact table compare
 #pragma unroll
                 for (int k = 0; k < BATCH; k++) {
                     const int j = h + k;
@@ -847,9 +848,10 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const uint32_t *__restric
 #pragma unroll
             for (int k = 0; k < BATCH; k++) {
                 const bool fits = (coldm & (1u << k)) && rank[k] < pe[k].y;
-                if ((coldm & (1u << k)) && !fits) miss |= 1u << k; // the region is full: counted exactly below
+                if ((coldm & (1u << k)) && !fits) full |= 1u << k; // the region is full: counted exactly below
                 lds16[fits ? pe[k].x + rank[k] : 2 * DUMMY_W + lane] = (rec16_t)rec[k];
             }
+            if (full) { atomicAdd(&L.ovn, (uint32_t)__popc(full)); miss |= full; }
             if (miss) { // outside the name's cold window, or no room: queued, counted exactly by the flush phase
 #pragma unroll
                 for (int k = 0; k < BATCH; k++)
@@ -945,6 +947,10 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const uint32_t *__restric
     }
     __syncthreads();
     if (tid < np && L.cbase[tid] != INVALID) cdesc[L.cbase[tid]] = (tid << CD_SHIFT) | L.cfill[tid];
+    // the engine watches this count (pinned host memory): a stream whose tiles overflow the regions is clustered by
+    // name, and later calls take the exact-layout kernel instead
+    if (tid == 0 && L.ovn && rstat)
+        __hip_atomic_fetch_add(rstat, (unsigned long long)L.ovn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 
     // ---- flush the hot windows (one uint64 atomic per occupied bin) and the out-of-window table
     const uint32_t nhot = g_hdr[0];
@@ -1043,27 +1049,38 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist2(const rec16_t *__restri
             }
         }
     };
-    // Each wave walks chunks wave, wave + 16, ...; DEPTH of them are in flight per wave (8 KiB per wave, 128 KiB per CU)
-    // while the oldest is reduced: with one workgroup per CU nothing else hides the load latency.
+    // Each wave walks chunks wave, wave + 16, ...  Their indices and descriptors are fetched 64 at a time (lane l
+    // holds the wave's l-th chunk of the batch: two dependent loads per 64 chunks instead of two per chunk), and
+    // DEPTH chunks are in flight per wave (8 KiB per wave, 128 KiB per CU) while the oldest is reduced: with one
+    // workgroup per CU nothing else hides the load latency.
     constexpr uint32_t WSTEP = P2_BLOCK / 64, DEPTH = 4;
     u4_t buf[DEPTH][2];
     uint32_t cn[DEPTH];
-    auto fetch = [&](uint32_t jj, uint32_t slot) {
-        cn[slot] = 0;
-        if (jj < cnt) {
-            const uint32_t cid = __builtin_amdgcn_readfirstlane(list[jj]);
-            cn[slot] = __builtin_amdgcn_readfirstlane(cdesc[cid] & CD_MASK);
-            load_chunk(cid, buf[slot]);
+    const uint32_t mine = cnt > wave ? (cnt - wave + WSTEP - 1) / WSTEP : 0u; // chunks of this wave
+    for (uint32_t b0 = 0; b0 < mine; b0 += 64) {
+        const uint32_t nb = min(mine - b0, 64u);
+        uint32_t my_cid = 0, my_cn = 0;
+        if (lane < nb) {
+            my_cid = list[wave + (b0 + lane) * WSTEP];
+            my_cn = cdesc[my_cid] & CD_MASK;
         }
-    };
+        auto fetch = [&](uint32_t k, uint32_t slot) { // k: position in the batch (wave-uniform)
+            cn[slot] = 0;
+            if (k < nb) {
+                const uint32_t cid = __builtin_amdgcn_readlane(my_cid, k);
+                cn[slot] = __builtin_amdgcn_readlane(my_cn, k);
+                load_chunk(cid, buf[slot]);
+            }
+        };
 #pragma unroll
-    for (uint32_t d = 0; d < DEPTH; d++) fetch(wave + d * WSTEP, d);
-    for (uint32_t j = wave; j < cnt; j += DEPTH * WSTEP) {
+        for (uint32_t d = 0; d < DEPTH; d++) fetch(d, d);
+        for (uint32_t k = 0; k < nb; k += DEPTH) {
 #pragma unroll
-        for (uint32_t d = 0; d < DEPTH; d++) { // fully unrolled: the slot index is a compile-time constant
-            if (j + d * WSTEP < cnt) {           // wave-uniform
-                reduce_chunk(buf[d], cn[d]);
-                fetch(j + (d + DEPTH) * WSTEP, d);
+            for (uint32_t d = 0; d < DEPTH; d++) { // fully unrolled: the slot index is a compile-time constant
+                if (k + d < nb) {                  // wave-uniform
+                    reduce_chunk(buf[d], cn[d]);
+                    fetch(k + d + DEPTH, d);
+                }
             }
         }
     }
@@ -1167,7 +1184,7 @@ size_t part2_scratch_bytes(size_t n, uint32_t nmetrics, int num_cus, const PartT
 hipError_t launch_ingest_pairs_part2(const uint32_t *d_ids, const double *d_v, size_t n, size_t survey_n,
                                      uint64_t *counts, uint32_t *ranges, uint32_t nmetrics, const double *d_Tx,
                                      uint32_t *d_err, void *scratch, size_t scratch_bytes, int num_cus,
-                                     const PartTuning &tune, hipStream_t s)
+                                     const PartTuning &tune, unsigned long long *region_stat, hipStream_t s)
 {
     Part2Plan P;
     if (!make_plan2(n, nmetrics, num_cus, tune, P) || scratch_bytes < P.total || !scratch) return hipErrorInvalidValue;
@@ -1239,11 +1256,11 @@ hipError_t launch_ingest_pairs_part2(const uint32_t *d_ids, const double *d_v, s
         if (P.shape == 3)
             hipLaunchKernelGGL((k_scatter3<512, 128, SC3_BATCH>), dim3(P.g1), dim3(512), p1_dyn, s, d_ids, d_v, nt_full, nmetrics,
                                P.log_np, P.log_w, d_Tx, g_nt, g_hs, g_hdr, g_pt, P.region_recs, P.cells, records,
-                               L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, dbg);
+                               L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, region_stat, dbg);
         else
             hipLaunchKernelGGL((k_scatter3<1024, 256, SC3_BATCH>), dim3(P.g1), dim3(1024), p1_dyn, s, d_ids, d_v, nt_full,
                                nmetrics, P.log_np, P.log_w, d_Tx, g_nt, g_hs, g_hdr, g_pt, P.region_recs, P.cells,
-                               records, L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, dbg);
+                               records, L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, region_stat, dbg);
         if (done < n) {
             e = launch_ingest_pairs(d_ids + done, d_v + done, n - done, counts, ranges, nmetrics, d_Tx, d_err, num_cus, s);
             if (e != hipSuccess) return e;

@@ -143,6 +143,56 @@ def test_survey_path_bad_ids_sublaunches_and_two_launches_per_epoch(native_lib, 
             _check(snap, np.concatenate([ids, ids[keep]]), np.concatenate([v, v[keep]]), M, got)
 
 
+@pytest.mark.parametrize("shape", [0, 2], ids=["1024x256", "1024x256-direct"])
+def test_threshold_fixture_through_the_survey_path(native_lib, torch_cuda, shape):
+    """Every bucket threshold, the double below and the double above it (tests/golden/thresholds_x.bin, the file
+    real Go is checked against), both signs, through the scatter pass's branch-free bucket index: the guard band
+    must hand exactly the right samples to the exact compare."""
+    import os
+    import sys
+    import loghisto_amd
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_thresholds as mt
+    x, _, _ = mt.read()
+    v = np.concatenate([x, -x, x[::-1]])
+    M = 64
+    ids = (np.arange(v.size, dtype=np.uint32) * 7) % M
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        e.set_option(N.OPT_PART_V2_MIN_PAIRS, 1 << 17)
+        e.set_option(N.OPT_PART_V2_SHAPE, shape)
+        e.submit_pairs_device(_dev(torch_cuda, ids), _dev(torch_cuda, v))
+        e.sync()
+        assert e.counters()["samples_partitioned_v2"] == v.size
+        with e.flip() as snap:
+            _check(snap, ids, v, M, snap.extract(PCTS, M))
+
+
+def test_clustered_stream_falls_back_to_exact_layout(native_lib, torch_cuda):
+    """A stream sorted by name: every tile belongs to one or two names, so a cold name's records overflow the LDS
+    region the survey sized for its share.  They are still counted exactly (out-of-window path); the engine sees
+    the overflow count at the next flip and sends later calls through the exact-layout scatter."""
+    import loghisto_amd
+    rng = np.random.default_rng(11)
+    M, n = 512, 3_000_000
+    ids = np.sort(_ids(rng, M, n, 1.0))
+    v = rng.lognormal(10, 2.5, n)
+    d_ids, d_v = _dev(torch_cuda, ids), _dev(torch_cuda, v)
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        e.set_option(N.OPT_PART_V2_MIN_PAIRS, 1 << 17)
+        e.submit_pairs_device(d_ids, d_v)
+        e.sync()
+        with e.flip() as snap:
+            _check(snap, ids, v, M, snap.extract(PCTS, M))
+        c = e.counters()
+        assert c["region_overflows"] * 50 > n and c["regions_disabled"] == 1, c
+        e.submit_pairs_device(d_ids, d_v)
+        e.sync()
+        with e.flip() as snap:
+            _check(snap, ids, v, M, snap.extract(PCTS, M))
+        c2 = e.counters()
+        assert c2["region_overflows"] == c["region_overflows"] and c2["samples_partitioned_v2"] == 2 * n, c2
+
+
 def test_old_and_new_generation_agree(native_lib, torch_cuda):
     """The same stream through both generations of the partitioned path: identical cells."""
     import loghisto_amd
