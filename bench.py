@@ -43,6 +43,7 @@ PCIE_GBS = 63.0                                          # PCIe Gen5 x16 (spec)
 BYTES_SINGLE, BYTES_PAIR = 8, 12                         # float64 / float64 + uint32 id
 METRIC = "float64 samples/sec bucketed (1 GPU) + % HBM roofline; p99 extract latency"
 K1_PMC = os.path.join("profiles", "r02_k1_pmc.json")
+C3_PMC = os.path.join("profiles", "r02_c3_pmc.json")
 
 
 def parse():
@@ -261,6 +262,21 @@ def run_c2(args, la, stream, rank):
 # ---------------------------------------------------------------------------------------------------------
 # C3: 1 024 Zipf names, (id, value) stream
 # ---------------------------------------------------------------------------------------------------------
+def c3_traffic(n, names):
+    """HBM bytes of one 1e9-pair call from the committed rocprofv3 --pmc summary of the same stream (PMC passes
+    cannot run inside this process); None when the run is not that configuration."""
+    path = os.path.join(ROOT, C3_PMC)
+    try:
+        j = json.load(open(path))
+        if j["pairs_per_call"] == n and j["names"] == names:
+            return {"traffic": j["hbm_bytes_per_call"],
+                    "traffic_source": f"{C3_PMC} (committed rocprofv3 --pmc summary of the same stream through "
+                                      "tools/sweep.py, not measured in this run)"}
+    except (OSError, ValueError, KeyError):
+        pass
+    return {"traffic": None, "traffic_source": None}
+
+
 def run_c3(args, la, stream, rank, steps, warmup, latency_flips=0):
     n = int(args.samples)
     M = args.names or 1024
@@ -296,7 +312,8 @@ def run_c3(args, la, stream, rank, steps, warmup, latency_flips=0):
                       "distribution": args.dist, "path": "survey + 2-byte-record scatter + LDS reduce"
                       if c["samples_partitioned_v2"] else "partitioned (first generation)"},
            "roofline": roofline(n * BYTES_PAIR, ing_ms,
-                                "k_survey_* + k_scatter2 + k_plan_* + k_part_hist2 (all launches of one lh_submit_pairs_device)"),
+                                "k_survey_* + k_scatter3 + k_plan_* + k_part_hist2 (all launches of one lh_submit_pairs_device)",
+                                **c3_traffic(n, M)),
            "scratch_bytes": c["scratch_bytes"], "sublaunches_per_step": c["sublaunches"] // max(1, steps + warmup)}
     if latency_flips:
         lat = []

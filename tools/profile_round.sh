@@ -1,29 +1,62 @@
-# Produces the per-round evidence under gpurun_out/round/ (copy into profiles/ afterwards):
-#   bench.json            python bench.py (default flags)
-#   kernel_trace.txt      rocprofv3 --kernel-trace of the same command (no cpu baseline), summarised
-#   k1_pmc.json           FETCH_SIZE / WRITE_SIZE passes for k_ingest_single, corrected per MI355X_MICROARCH.md
+# Per-round evidence under gpurun_out/round/ (copy into profiles/ as r02_* afterwards).  One gpurun call.
+#   bench.json              python bench.py (default flags: headline C2 + secondary C3 / C4 / host-fed / C5)
+#   kernel_trace.txt        rocprofv3 --kernel-trace of the C2 bench command (no cpu baseline), summarised
+#   k1_pmc.json             FETCH_SIZE / WRITE_SIZE passes for k_ingest_single, corrected per MI355X_MICROARCH.md
+#   c3_kernel_trace.txt     rocprofv3 --kernel-trace of bench.py --workload c3
+#   c3_pmc.json             FETCH_SIZE / WRITE_SIZE passes of the same command, every kernel of the call summed
+#   c4_bench.json           bench.py --workload c4 (one rank)
+# PMC passes are separate runs with no tracing domain mixed in.
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/round; mkdir -p $OUT; cd $R
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+python bench.py --workload c4 > $OUT/c4_bench.json 2> $OUT/c4_bench.err
 cd /tmp; export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --latency-flips 50"
-rocprofv3 --kernel-trace -d /tmp/pr_trace -o t -- $CMD > $OUT/bench_under_trace.json 2>/dev/null
+CMD="python $R/bench.py --workload c2 --steps 10 --warmup 2 --no-cpu-baseline --no-parity --latency-flips 50"
+rm -rf /tmp/pr_trace; rocprofv3 --kernel-trace -d /tmp/pr_trace -o t -- $CMD > $OUT/bench_under_trace.json 2>/dev/null
 { echo "# rocprofv3 --kernel-trace -- $CMD"; python $R/profiles/summarize_rocpd.py stats /tmp/pr_trace/t_results.db | cut -c1-170
   echo; echo "## full-size launches only (duration >= 0.5 ms)"; python $R/profiles/summarize_rocpd.py stats /tmp/pr_trace/t_results.db --min-ns 500000 | cut -c1-170; } > $OUT/kernel_trace.txt
-CMD2="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --latency-flips 0"
+CMD2="python $R/bench.py --workload c2 --steps 3 --warmup 1 --no-cpu-baseline --no-parity --latency-flips 0"
+rm -rf /tmp/pr_fetch /tmp/pr_write
 rocprofv3 --pmc FETCH_SIZE -d /tmp/pr_fetch -o t -- $CMD2 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE -d /tmp/pr_write -o t -- $CMD2 > /dev/null 2>&1
+CMD3="python $R/bench.py --workload c3 --steps 3 --warmup 1 --no-cpu-baseline --no-parity --latency-flips 0"
+rm -rf /tmp/pr_c3t /tmp/pr_c3f /tmp/pr_c3w
+rocprofv3 --kernel-trace -d /tmp/pr_c3t -o t -- $CMD3 > $OUT/c3_under_trace.json 2>/dev/null
+{ echo "# rocprofv3 --kernel-trace -- $CMD3"; python $R/profiles/summarize_rocpd.py stats /tmp/pr_c3t/t_results.db | grep -E "^#|^kernel|lh::" | cut -c1-170; } > $OUT/c3_kernel_trace.txt
+rocprofv3 --pmc FETCH_SIZE -d /tmp/pr_c3f -o t -- $CMD3 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE -d /tmp/pr_c3w -o t -- $CMD3 > /dev/null 2>&1
 python - <<PY
 import json, subprocess
 R="$R"
-def pmc(db): return json.loads(subprocess.check_output(["python", R+"/profiles/summarize_rocpd.py", "pmc", db, "k_ingest_single", "--min-ns", "500000"]))
-f=pmc("/tmp/pr_fetch/t_results.db")["counters"]["FETCH_SIZE"]; w=pmc("/tmp/pr_write/t_results.db")["counters"]["WRITE_SIZE"]
+def pmc(db, k, min_ns=0):
+    return json.loads(subprocess.check_output(["python", R+"/profiles/summarize_rocpd.py", "pmc", db, k, "--min-ns", str(min_ns)]))["counters"]
+CORR = ("FETCH_SIZE is in KiB and on gfx950 counts the 128-B requests of a 16-B/lane coalesced stream as 64 B: read "
+        "bytes = FETCH_SIZE*1024*2 (MI355X_MICROARCH.md 'HBM'). WRITE_SIZE*1024, uncalibrated.")
+f=pmc("/tmp/pr_fetch/t_results.db","k_ingest_single",500000)["FETCH_SIZE"]; w=pmc("/tmp/pr_write/t_results.db","k_ingest_single",500000)["WRITE_SIZE"]
 out={"kernel":"lh::k_ingest_single","workload":"1e9 float64 samples, lognormal(ln 1e5, 1), one metric",
  "commands":["rocprofv3 --pmc FETCH_SIZE -- $CMD2","rocprofv3 --pmc WRITE_SIZE -- $CMD2"],
  "FETCH_SIZE_KiB_per_launch":f["avg"],"WRITE_SIZE_KiB_per_launch":w["avg"],"launches":f["launches"],
- "corrections":"FETCH_SIZE is in KiB and on gfx950 counts the 128-B requests of a 16-B/lane coalesced stream as 64 B: read bytes = FETCH_SIZE*1024*2 (MI355X_MICROARCH.md 'HBM'). WRITE_SIZE*1024, uncalibrated (flush atomics), 3 orders of magnitude below the read side.",
+ "corrections":CORR,
  "hbm_read_bytes_per_launch":f["avg"]*2048,"hbm_write_bytes_per_launch":w["avg"]*1024,"algorithmic_bytes_per_launch":8e9,
  "read_over_algorithmic":f["avg"]*2048/8e9,
  "avg_duration_us_under_pmc":{"FETCH_SIZE pass":f["avg_duration_us_profiled"],"WRITE_SIZE pass":w["avg_duration_us_profiled"]}}
 json.dump(out, open("$OUT/k1_pmc.json","w"), indent=1)
+# C3: every kernel of one lh_submit_pairs_device call (4 calls in the run: 1 warmup + 3 timed)
+calls = 4
+kernels = ["k_survey_count", "k_survey_plan", "k_survey_parts", "k_scatter3", "k_scatter2", "k_plan_count", "k_plan_scan",
+           "k_plan_scatter", "k_part_hist2", "k_ingest_pairs"]
+per = {}; rd = wr = 0.0
+for k in kernels:
+    cf = pmc("/tmp/pr_c3f/t_results.db", k).get("FETCH_SIZE"); cw = pmc("/tmp/pr_c3w/t_results.db", k).get("WRITE_SIZE")
+    if not cf: continue
+    r = cf["avg"]*cf["launches"]*2048/calls; ww = (cw["avg"]*cw["launches"]*1024/calls) if cw else 0.0
+    per[k] = {"launches_per_call": cf["launches"]/calls, "read_bytes_per_call": r, "write_bytes_per_call": ww,
+              "avg_duration_us_under_pmc": cf["avg_duration_us_profiled"]}
+    rd += r; wr += ww
+json.dump({"workload":"C3: 1e9 (uint32 id, float64 value) pairs over 1 024 Zipf(1.0) names, lognormal values",
+ "pairs_per_call": 1000000000, "names": 1024,
+ "commands":["rocprofv3 --pmc FETCH_SIZE -- $CMD3","rocprofv3 --pmc WRITE_SIZE -- $CMD3"], "corrections": CORR,
+ "kernels": per, "hbm_read_bytes_per_call": rd, "hbm_write_bytes_per_call": wr, "hbm_bytes_per_call": rd+wr,
+ "algorithmic_bytes_per_call": 12e9, "traffic_over_algorithmic": (rd+wr)/12e9}, open("$OUT/c3_pmc.json","w"), indent=1)
 PY
-ls -la $OUT; tail -c 1200 $OUT/bench.json; grep -E "k_ingest_single" $OUT/kernel_trace.txt | cut -c1-140
+ls -la $OUT; tail -c 1500 $OUT/bench.json; grep -E "k_ingest_single" $OUT/kernel_trace.txt | cut -c1-140; cat $OUT/c3_kernel_trace.txt | cut -c1-150; python -c "
+import json; j=json.load(open('$OUT/c3_pmc.json')); print({k:j[k] for k in ('hbm_read_bytes_per_call','hbm_write_bytes_per_call','traffic_over_algorithmic')})"
