@@ -209,3 +209,66 @@ func (ms *MetricSystem) graphiteRequest(raw *RawMetricSet, host string) []byte {
 		C.LH_MERGE_REDUCE_SCATTER, C.uint32_t(len(ms.gpu.names)), &first, &last)
 	// this rank now holds the merged cells of names [first, last): extract only those
 	C.lh_extract_rows(snap, first, C.size_t(last-first), &ps[0], C.size_t(len(ps)), &stats[0], &pvals[0], nil, &pvalid[0])
+
+// ---- round 2 (ABI version 2) -------------------------------------------------------------------------------------
+
+// Counter on the device (optional; replaces metrics.go:251-269 and the counter half of collectRawMetrics,
+// metrics.go:425-458).  The per-P stage gains cids / camts / cn beside ids / vals / n.
+func (ms *MetricSystem) counterGPU(name string, amount uint64) {
+	g := ms.gpu
+	id := g.counterID(name) // cache over lh_intern_counter: counters have their own dense id space
+	ms.counterMu.RLock()
+	s := g.pool.Get().(*stage)
+	s.cids[s.cn] = C.uint32_t(id)
+	s.camts[s.cn] = C.uint64_t(amount)
+	s.cn++
+	if s.cn == stageCap {
+		C.lh_submit_counts(g.e, &s.cids[0], &s.camts[0], C.size_t(s.cn)) // copies before returning
+		s.cn = 0
+	}
+	g.pool.Put(s)
+	ms.counterMu.RUnlock()
+}
+
+func (raw *RawMetricSet) fillCounters(g *gpuEngine) {
+	n := len(g.counterNames)
+	if n == 0 {
+		return
+	}
+	rate := make([]C.uint64_t, n)
+	total := make([]C.uint64_t, n)
+	present := make([]C.uint8_t, n)
+	known := make([]C.uint8_t, n)
+	C.lh_counters_collect(raw.snap, 0, C.size_t(n), &rate[0], &present[0], &total[0], &known[0])
+	for id, name := range g.counterNames {
+		if present[id] != 0 {
+			raw.Rates[name] = uint64(rate[id]) // metrics.go:430-433
+		}
+		if known[id] != 0 {
+			raw.Counters[name] = uint64(total[id]) // metrics.go:435-458
+		}
+	}
+}
+
+// Results in place for large name spaces: the library's own pinned arrays, valid until the next extract.
+func (ms *MetricSystem) extractView(raw *RawMetricSet, ps []C.double) (stats []C.lh_stats, pvals []C.double) {
+	n := len(ms.gpu.names)
+	var v C.lh_extract_view
+	if rc := C.lh_extract_rows_view(raw.snap, 0, C.size_t(n), &ps[0], C.size_t(len(ps)), &v); rc != C.LH_OK {
+		glog.Errorf("lh_extract_rows_view: %s", C.GoString(C.lh_strerror(rc)))
+		return nil, nil
+	}
+	return unsafe.Slice(v.stats, n), unsafe.Slice(v.pvals, n*len(ps))
+}
+
+// Self-metrics of the engine as gauges (RegisterGaugeFunc, metrics.go:299).
+func (ms *MetricSystem) registerEngineGauges() {
+	get := func(f func(c *C.lh_counters) float64) func() float64 {
+		return func() float64 { var c C.lh_counters; C.lh_get_counters(ms.gpu.e, &c); return f(&c) }
+	}
+	ms.RegisterGaugeFunc("lhgpu.samples_partitioned", get(func(c *C.lh_counters) float64 { return float64(c.samples_partitioned) }))
+	ms.RegisterGaugeFunc("lhgpu.scratch_bytes", get(func(c *C.lh_counters) float64 { return float64(c.scratch_bytes) }))
+	ms.RegisterGaugeFunc("lhgpu.region_overflows", get(func(c *C.lh_counters) float64 { return float64(c.region_overflows) }))
+	ms.RegisterGaugeFunc("lhgpu.flips_busy", get(func(c *C.lh_counters) float64 { return float64(c.flips_busy) }))
+}
+
