@@ -678,7 +678,20 @@ template <int NPT> struct Scatter3LdsT {
 #define LH_SC3_BATCH 4
 #endif
 constexpr int SC3_BATCH = LH_SC3_BATCH;              // samples classified together (4 or 8)
-constexpr uint32_t region_records(uint32_t tile, uint32_t np) { return 3u * tile / 2u + 72u * np; }
+#ifndef LH_SC3_FLUSH_TPP
+#define LH_SC3_FLUSH_TPP 4
+#endif
+constexpr uint32_t SC3_FLUSH_TPP = LH_SC3_FLUSH_TPP; // flush-phase threads per partition (1, 2 or 4)
+#ifndef LH_SC3_TILES_PER_FLUSH
+#define LH_SC3_TILES_PER_FLUSH 1
+#endif
+constexpr uint32_t SC3_TILES_PER_FLUSH = LH_SC3_TILES_PER_FLUSH; // tiles classified between two flushes (1 or 2)
+#ifndef LH_SC3_CAP_NUM
+#define LH_SC3_CAP_NUM 6
+#endif
+constexpr uint32_t SC3_CAP_NUM = LH_SC3_CAP_NUM; // region capacity = expected records * CAP_NUM / 4 + 40 (6: 1.5 x)
+// upper bound of the sum of the partitions' capacities; `tile` = samples between two flushes
+constexpr uint32_t region_records(uint32_t tile, uint32_t np) { return SC3_CAP_NUM * tile / 4u + 72u * np; }
 
 // Region sizes from the survey: g_pt[p] = {first record of the region (relative to the region area), capacity}.
 // One workgroup of 256 threads, after k_survey_plan.
@@ -703,7 +716,7 @@ __global__ __launch_bounds__(256) void k_survey_parts(const uint32_t *__restrict
     uint32_t cap = 0;
     if (tid < np) {
         const uint32_t est = total ? (uint32_t)(((unsigned long long)s_pc[tid] * tile) / total) : tile / np;
-        cap = (est + est / 2 + 40u + 31u) & ~31u;
+        cap = (est * SC3_CAP_NUM / 4u + 40u + 31u) & ~31u;
         if (cap > tile + 32u) cap = tile + 32u; // leftover (< 32) + a whole tile
     }
     s_cap[tid] = cap;
@@ -792,7 +805,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const uint32_t *__restric
     static_assert(NPAIR == 4, "the asm above names four register pairs");
     load_tile((size_t)blockIdx.x + gridDim.x, idb, vab);
 
-    auto process_tile = [&](size_t tile, pu2_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
+    auto classify = [&](pu2_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
         uint32_t rare = 0;
         // ---- phase 1: classify and place.  Straight-line code, four samples at a time: their table reads, then
         // their LDS atomics, then their record stores are in flight together.
@@ -844,7 +857,9 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const uint32_t *__restric
                 if (valid && !hot && !cold) miss |= 1u << k;
             }
 #pragma unroll
-            for (int k = 0; k < BATCH; k++) rank[k] = (dbg & 32u) ? 0u : atomicAdd(lds32 + where[k], 1u); // 32: no LDS atomics
+            for (int k = 0; k < BATCH; k++) {
+                rank[k] = (dbg & 32u) ? 0u : atomicAdd(lds32 + where[k], 1u); // 32: no LDS atomics
+            }
 #pragma unroll
             for (int k = 0; k < BATCH; k++) {
                 const bool fits = (coldm & (1u << k)) && rank[k] < pe[k].y;
@@ -864,16 +879,21 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const uint32_t *__restric
             }
         }
         if (rare) atomicOr(err, 1u); // an id >= nmetrics: reported by lh_sync / lh_extract
-        __syncthreads();                                   // barrier A: the tile's records are in the regions
-        load_tile(tile + 2 * (size_t)gridDim.x, idv, val); // this register set is free: the tile two steps ahead
-
-        // ---- phase 2: flush.  Four threads per partition (p = tid / 4, q = tid % 4: the q-th 16 bytes of a line).
+    };
+    auto flush = [&](const uint32_t par) {
+        __syncthreads();                                   // barrier A: the records of the tile(s) are in the regions
+        // ---- phase 2: flush.  TPP threads per partition (p = tid / TPP; thread q copies the 16-byte pieces q, q + TPP,
+        // .. of every line).  With TPP = 1 only the first NPT threads -- one wave per SIMD -- run this phase and the
+        // other waves go straight to the barrier.
         if (tid == BLOCK - 1) L.missn[par ^ 1u] = 0; // the other parity's queue was drained in the previous tile
+        constexpr uint32_t TPP = SC3_FLUSH_TPP;
+        static_assert(TPP == 1 || TPP == 2 || TPP == 4, "pieces of a 64-byte line per thread: 4 / TPP");
         if (!(dbg & 16u)) {
+          if (tid < NPT * TPP) {
             uint32_t t2 = tid;
             asm volatile("" : "+v"(t2)); // keeps this phase's address arithmetic inside the loop (see k_scatter2)
-            const uint32_t p = t2 >> 2, q = t2 & 3u;
-            const pu2_t e = my_pt;
+            const uint32_t p = t2 / TPP, q = t2 % TPP;
+            const pu2_t e = TPP == 4 ? my_pt : L.pt[p];
             const uint32_t c = min(L.cnt[p], e.y), full = c / LINE2, left = c % LINE2;
             if (full) {
                 const uint32_t cf = L.cfill[p], cb = L.cbase[p];
@@ -892,21 +912,33 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const uint32_t *__restric
                 } else if (q == 0) {
                     L.cfill[p] = cf + full * LINE2;
                 }
-                first = __builtin_amdgcn_mov_dpp(first, 0x00, 0xf, 0xf, false); // quad_perm [0,0,0,0]: q == 0's value
+                if (TPP == 4) first = __builtin_amdgcn_mov_dpp(first, 0x00, 0xf, 0xf, false); // quad_perm [0,0,0,0]: q == 0's value
+                if (TPP == 2) first = __builtin_amdgcn_mov_dpp(first, 0xa0, 0xf, 0xf, false); // quad_perm [0,0,2,2]
                 const uint32_t dA = cb * CHUNK + cf, dB = first * CHUNK - room * LINE2;
-                const rec16_t *src = lds16 + e.x + q * 8;
+                const rec16_t *src = lds16 + e.x;
 #pragma nounroll
                 for (uint32_t l = 0; l < full; l++) {
-                    const pu4_t r4 = *reinterpret_cast<const pu4_t *>(src + l * LINE2);
-                    const uint32_t dst = (l < room ? dA : dB) + l * LINE2 + q * 8;
-                    if (!(dbg & 1u)) hidden_store_u4(records + dst, r4);
+                    const uint32_t dst = (l < room ? dA : dB) + l * LINE2;
+                    pu4_t r4[4 / TPP];
+#pragma unroll
+                    for (uint32_t i = 0; i < 4 / TPP; i++)
+                        r4[i] = *reinterpret_cast<const pu4_t *>(src + l * LINE2 + (q + i * TPP) * 8);
+                    if (!(dbg & 1u)) {
+#pragma unroll
+                        for (uint32_t i = 0; i < 4 / TPP; i++) hidden_store_u4(records + dst + (q + i * TPP) * 8, r4[i]);
+                    }
                 }
                 // the last partial line moves to the front of the region (its slots are this thread's own)
-                if (q * 8 < left)
-                    *reinterpret_cast<pu4_t *>(lds16 + e.x + q * 8) =
-                        *reinterpret_cast<const pu4_t *>(src + full * LINE2);
+#pragma unroll
+                for (uint32_t i = 0; i < 4 / TPP; i++) {
+                    const uint32_t piece = q + i * TPP;
+                    if (piece * 8 < left)
+                        *reinterpret_cast<pu4_t *>(lds16 + e.x + piece * 8) =
+                            *reinterpret_cast<const pu4_t *>(src + full * LINE2 + piece * 8);
+                }
             }
             if (q == 0) L.cnt[p] = left;
+          }
         } else if (tid < NPT) {
             L.cnt[tid] = 0; // ablation: phase 1 and the loads only
         }
@@ -920,9 +952,20 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const uint32_t *__restric
         }
         __syncthreads();                                   // barrier B: counters and regions are ready for the next tile
     };
+    // Each register set receives the tile two steps ahead as soon as its samples are classified.  With
+    // SC3_TILES_PER_FLUSH = 2 both tiles of an iteration are classified back to back (no barrier between them: the
+    // LDS atomics and record stores of the second simply continue the first) and flushed together.
+    uint32_t par = 0; // out-of-window queue of this flush group (the flush resets the other one)
     for (size_t tile = blockIdx.x; tile < ntiles; tile += 2 * (size_t)gridDim.x) {
-        process_tile(tile, ida, vaa, 0u);
-        if (tile + gridDim.x < ntiles) process_tile(tile + gridDim.x, idb, vab, 1u); // workgroup-uniform
+        classify(ida, vaa, par);
+        load_tile(tile + 2 * (size_t)gridDim.x, ida, vaa);
+        if (SC3_TILES_PER_FLUSH == 1) { flush(par); par ^= 1u; }
+        if (tile + gridDim.x < ntiles) { // workgroup-uniform
+            classify(idb, vab, par);
+            load_tile(tile + 3 * (size_t)gridDim.x, idb, vab);
+        }
+        flush(par); // (with one tile per flush and no second tile: finds nothing new, harmless)
+        par ^= 1u;
     }
 
     // ---- drain: the regions' leftovers (< one line each) and the open chunks' descriptors
@@ -1141,7 +1184,7 @@ static bool make_plan2(size_t n, uint32_t nmetrics, int num_cus, const PartTunin
     P.log_w = lw; // cold window = 2^log_w bins per name; the record (local << log_w | offset) is < 32 768
     // hot windows: whatever LDS is left beside the scatter structures and the per-name table
     const size_t budget = V2_LDS_TOTAL / wgs_per_cu;
-    P.region_recs = direct ? region_records(P.tile, P.np) : 0u;
+    P.region_recs = direct ? region_records(P.tile * SC3_TILES_PER_FLUSH, P.np) : 0u;
     const size_t nt_bytes = (size_t)(direct ? (nmetrics + 1) & ~1u : nmetrics) * sizeof(NameEntry);
     const size_t fixed = P.lds_fixed + nt_bytes + (size_t)P.region_recs * sizeof(rec16_t) + 256;
     P.cells = fixed + 4096 <= budget ? (uint32_t)((budget - fixed) / 4) & ~63u : 0u;
@@ -1249,7 +1292,8 @@ hipError_t launch_ingest_pairs_part2(const uint32_t *d_ids, const double *d_v, s
         hipLaunchKernelGGL(k_survey_plan, dim3(1), dim3(V2_BLOCK), 0, s, g_cnt, g_mninv, g_mx, g_sum, nmetrics,
                            P.log_w, P.cells, g_nt, g_hs, g_hdr);
         if (P.shape & 2u)
-            hipLaunchKernelGGL(k_survey_parts, dim3(1), dim3(256), 0, s, g_cnt, nmetrics, P.log_np, P.tile, g_pt);
+            hipLaunchKernelGGL(k_survey_parts, dim3(1), dim3(256), 0, s, g_cnt, nmetrics, P.log_np,
+                               P.tile * SC3_TILES_PER_FLUSH, g_pt);
     }
     if (P.shape & 2u) { // whole tiles through the region kernel, the last n % tile pairs through the plain kernel
         const size_t nt_full = n / P.tile, done = nt_full * P.tile;

@@ -1,0 +1,12 @@
+"""Runs the survey-path parity tests against another build of the library (a tuning variant under evaluation):
+    python tools/test_with_lib.py loghisto_amd/build/liblhgpu_tuning_x.so [pytest args...]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from loghisto_amd import _native  # noqa: E402
+
+_native.LIB_PATH = os.path.abspath(sys.argv[1])
+import pytest  # noqa: E402
+
+sys.exit(pytest.main(["tests/test_gpu_part2.py", "-x", "-q", "-k", "direct or clustered or threshold"] + sys.argv[2:]))
