@@ -593,7 +593,23 @@ def main():
     elif workload == "c3":
         res = run_c3(args, la, stream, rank, args.steps, args.warmup, latency_flips=min(args.latency_flips, 200))
     else:
+        ref = None
+        if world > 1:
+            # the same workload on this GPU alone (1-rank communicator, no exchange): the N = 1 line of the driver is the
+            # C2 headline, so the N-rank line carries its own one-rank reference for this workload
+            saved = args.no_parity
+            args.no_parity = True
+            try:
+                one = run_c4(args, la, stream, 0, 1, None, steps=5, warmup=2)
+                ref = {"value": one["value"], "ms_per_step": one["ms_per_step"], "ranks": 1,
+                       "note": "same C4 slice on rank 0's GPU alone, measured in this process before the N-rank steps"}
+            except Exception as exc:  # noqa: BLE001
+                ref = {"failed": repr(exc)[:300]}
+            args.no_parity = saved
+            dist.barrier()
         res = run_c4(args, la, stream, rank, world, dist, args.steps, args.warmup)
+        if ref is not None:
+            res["one_rank_reference"] = ref
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

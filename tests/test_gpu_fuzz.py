@@ -63,9 +63,9 @@ def test_mixed_ingest_fuzz(native_lib, torch_cuda, case, monkeypatch):
         if case % 2:
             e.set_option(N.OPT_HOT_MIN_TILES, 1)
             e.set_option(N.OPT_TWO_LEVEL_ABOVE, two_level_above)
-        if case % 3:                         # second generation of the partitioned path, either shape
+        if case % 3:                         # survey + 2-byte records: region scatter (2, 3) or exact layout (0, 1)
             e.set_option(N.OPT_PART_V2_MIN_PAIRS, 1 << 17)
-            e.set_option(N.OPT_PART_V2_SHAPE, case % 3 - 1)
+            e.set_option(N.OPT_PART_V2_SHAPE, [2, 3, 0, 1][(case // 3) % 4])
         for a, b in zip(cuts[:-1], cuts[1:]):
             if rng.random() < 0.25 and b - a < 600_000:
                 e.submit_pairs(ids[a:b], v[a:b])
