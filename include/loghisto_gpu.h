@@ -303,7 +303,11 @@ int lh_get_counters(lh_engine *e, lh_counters *out);
  *   LH_OPT_EXTRACT_ZERO_COPY  0 / 1: small extract results are stored straight into pinned host memory (default 1)
  *   LH_OPT_SCRATCH_CAP_BYTES  upper bound of the mixed ingest's scratch block (default 1.5 GiB, >= 64 MiB)
  *   LH_OPT_SUBLAUNCH_PAIRS    largest partitioned sub-launch, 2^22 .. 2^30 pairs, rounded down to a power of two
- *                             (default 2^29; a sub-launch is halved until its scratch fits the cap)
+ *                             (default 2^29; a sub-launch is halved until its scratch fits the cap).
+ *                             Engines with more than 8 192 names (two scatter levels: ~1.2 GB of chunk pools and
+ *                             ~0.35 ms of fixed work per launch) are NOT cut by default -- a 1e9-pair launch over
+ *                             65 536 names takes a 9 GB block -- unless one of these two options was set, and then
+ *                             not below 2^28 pairs
  *   LH_OPT_PART_V2            0 / 1: the survey + 2-byte-record generation of the partitioned path (default 1;
  *                             used for 33 .. 8 192 names)
  *   LH_OPT_PART_V2_MIN_PAIRS  smallest launch that takes it (default 2^24; >= 2^17: tests exercise it on small inputs)

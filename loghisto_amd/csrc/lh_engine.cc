@@ -197,6 +197,7 @@ struct lh_engine {
     bool scratch_used = false;
     std::atomic<uint64_t> c_scratch{0}, c_sublaunches{0}, c_part2{0};
     size_t scratch_cap = size_t(1536) << 20;     // 1.5 GiB
+    bool scratch_cap_set = false, sublaunch_set = false; // lh_set_option was called: the caller's bound wins
     size_t sublaunch_pairs = size_t(1) << 29;
 
     lh::PartTuning tune;                  // lh_set_option; never the environment in the product build
@@ -286,7 +287,13 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
             // large launch over many names: partition by name, then reduce in LDS.  Sub-launches keep the scratch
             // block bounded: at most `sublaunch_pairs` pairs each, halved until the block fits `scratch_cap`
             // (power-of-two cuts keep both arrays on their vector alignment).
-            size_t sub = take < e->sublaunch_pairs ? take : e->sublaunch_pairs;
+            // Above 8 192 names the second scatter level carries ~1.2 GB of chunk pools whatever the launch size and
+            // ~0.35 ms of fixed work per launch, so cutting costs more than the bytes it saves (65 536 names: 9.1 ms
+            // in four sub-launches against 7.3 ms in one, per 1e9 pairs).  Such launches are cut only when the caller
+            // asked for a bound (LH_OPT_SCRATCH_CAP_BYTES / LH_OPT_SUBLAUNCH_PAIRS), and then not below 2^28 pairs.
+            const bool two_level = e->cfg.max_metrics > 8192;
+            const bool bounded = !two_level || e->scratch_cap_set || e->sublaunch_set;
+            size_t sub = (bounded && take > e->sublaunch_pairs) ? e->sublaunch_pairs : take;
             lh::PartTuning tune = e->tune;
             if (e->regions_disabled.load(std::memory_order_relaxed)) tune.v2_shape &= ~2u; // clustered stream: exact layout
             // second generation (survey + 2-byte records) when the launch is large enough and has <= 8 192 names
@@ -297,11 +304,8 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
             };
             bool v2 = false;
             size_t need = scratch_need(sub, &v2);
-            // Above 8 192 names the second scatter level carries ~1.2 GB of chunk pools whatever the launch size and
-            // ~0.35 ms of fixed work per sub-launch: cutting such launches finer costs more than the bytes it
-            // saves, so the cap only shapes sub-launches down to 2^28 pairs there (2^24 otherwise).
-            const size_t floor = e->cfg.max_metrics > 8192 ? (size_t(1) << 28) : (size_t(1) << 24);
-            while (need > e->scratch_cap && sub > floor) {
+            const size_t floor = two_level ? (size_t(1) << 28) : (size_t(1) << 24);
+            while (bounded && need > e->scratch_cap && sub > floor) {
                 size_t half = floor;
                 while (half * 2 < sub) half *= 2;
                 sub = half;
@@ -1851,6 +1855,7 @@ int lh_set_option(lh_engine *e, int option, uint64_t value)
         if (value < (uint64_t(64) << 20)) return LH_EINVAL;
         std::lock_guard<std::mutex> g(e->scratch_mu);
         e->scratch_cap = (size_t)value;
+        e->scratch_cap_set = true;
         return LH_OK;
     }
     case LH_OPT_SUBLAUNCH_PAIRS: {
@@ -1859,6 +1864,7 @@ int lh_set_option(lh_engine *e, int option, uint64_t value)
         while (p2 * 2 <= value) p2 *= 2;
         std::lock_guard<std::mutex> g(e->scratch_mu);
         e->sublaunch_pairs = p2;
+        e->sublaunch_set = true;
         return LH_OK;
     }
     case LH_OPT_PART_V2:

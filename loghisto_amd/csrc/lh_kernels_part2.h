@@ -1107,23 +1107,23 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist2(const rec16_t *__restri
             my_cid = list[wave + (b0 + lane) * WSTEP];
             my_cn = cdesc[my_cid] & CD_MASK;
         }
+        // Loads are issued unconditionally (positions past the batch re-read its last chunk; the data is ignored) and
+        // only the LDS work is conditional: with a load inside a branch the compiler cannot count the loads in
+        // flight at the join and falls back to s_waitcnt vmcnt(0) before every chunk, which serialises the four
+        // chunks this loop keeps in flight.
         auto fetch = [&](uint32_t k, uint32_t slot) { // k: position in the batch (wave-uniform)
-            cn[slot] = 0;
-            if (k < nb) {
-                const uint32_t cid = __builtin_amdgcn_readlane(my_cid, k);
-                cn[slot] = __builtin_amdgcn_readlane(my_cn, k);
-                load_chunk(cid, buf[slot]);
-            }
+            const uint32_t kk = min(k, nb - 1u);
+            const uint32_t cid = __builtin_amdgcn_readlane(my_cid, kk);
+            cn[slot] = __builtin_amdgcn_readlane(my_cn, kk);
+            load_chunk(cid, buf[slot]);
         };
 #pragma unroll
         for (uint32_t d = 0; d < DEPTH; d++) fetch(d, d);
         for (uint32_t k = 0; k < nb; k += DEPTH) {
 #pragma unroll
             for (uint32_t d = 0; d < DEPTH; d++) { // fully unrolled: the slot index is a compile-time constant
-                if (k + d < nb) {                  // wave-uniform
-                    reduce_chunk(buf[d], cn[d]);
-                    fetch(k + d + DEPTH, d);
-                }
+                if (k + d < nb) reduce_chunk(buf[d], cn[d]); // wave-uniform
+                fetch(k + d + DEPTH, d);
             }
         }
     }
