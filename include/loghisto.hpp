@@ -278,9 +278,12 @@ public:
     std::string DestinationNetwork, DestinationAddress;
     uint64_t sent_requests() const { return sent_.load(); }
     uint64_t evicted_requests() const { return evicted_.load(); }
+    uint64_t connections() const { return connects_.load(); } // dials so far (tcp: one while the peer stays up)
 
 private:
-    bool submit(const std::string &request);
+    bool connectIfNeeded();
+    void disconnect();
+    bool submitBatch(const std::shared_ptr<const std::string> *requests, size_t n);
     bool retryBacklog();
     void appendToBacklog(std::string request);
     MetricSystem *ms_;
@@ -288,10 +291,12 @@ private:
     std::chrono::nanoseconds interval_;
     std::shared_ptr<Channel<std::shared_ptr<ProcessedMetricSet>>> chan_;
     std::mutex backlog_mu_;
-    std::string backlog_[60];
+    std::shared_ptr<const std::string> backlog_[60];
     int head_ = 0, tail_ = 0;
+    uint64_t head_seq_ = 0; // sequence number of the entry at head_ (evictions and sends both advance it)
     std::atomic<bool> shutdown_{false};
-    std::atomic<uint64_t> sent_{0}, evicted_{0};
+    std::atomic<uint64_t> sent_{0}, evicted_{0}, connects_{0};
+    int fd_ = -1; // send thread only
     std::thread recv_thread_, send_thread_;
 };
 

@@ -704,8 +704,13 @@ Submitter::Submitter(MetricSystem *ms, Serializer serializer, std::string networ
 
 Submitter::~Submitter() { Shutdown(); }
 
-bool Submitter::submit(const std::string &request) // submitter.go:106-116
+// submitter.go:106-116 dials, writes one request and closes, once per backlog entry per interval.  Here the
+// connection is kept (re-dialled only after an error) and everything the backlog holds leaves in ONE writev per
+// interval: same bytes in the same order, same 5 s deadline, same "retry next interval" on failure.  UDP keeps one
+// datagram per request.
+bool Submitter::connectIfNeeded()
 {
+    if (fd_ >= 0) return true;
     const size_t colon = DestinationAddress.rfind(':');
     if (colon == std::string::npos) return false;
     const std::string host = DestinationAddress.substr(0, colon), port = DestinationAddress.substr(colon + 1);
@@ -713,50 +718,99 @@ bool Submitter::submit(const std::string &request) // submitter.go:106-116
     hints.ai_family = AF_UNSPEC;
     hints.ai_socktype = DestinationNetwork == "udp" ? SOCK_DGRAM : SOCK_STREAM;
     if (getaddrinfo(host.c_str(), port.c_str(), &hints, &res) != 0 || !res) return false;
-    bool ok = false;
     const int fd = socket(res->ai_family, res->ai_socktype, res->ai_protocol);
     if (fd >= 0) {
         timeval tv{5, 0}; // 5 s deadline
         setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof tv);
         setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
         if (connect(fd, res->ai_addr, res->ai_addrlen) == 0) {
-            size_t off = 0;
-            ok = true;
-            while (off < request.size()) {
-                const ssize_t n = ::send(fd, request.data() + off, request.size() - off, MSG_NOSIGNAL);
-                if (n <= 0) { ok = false; break; }
-                off += (size_t)n;
-            }
+            fd_ = fd;
+            connects_.fetch_add(1);
+        } else {
+            close(fd);
         }
-        close(fd);
     }
     freeaddrinfo(res);
-    return ok;
+    return fd_ >= 0;
+}
+
+void Submitter::disconnect()
+{
+    if (fd_ >= 0) close(fd_);
+    fd_ = -1;
+}
+
+bool Submitter::submitBatch(const std::shared_ptr<const std::string> *requests, size_t n)
+{
+    if (!connectIfNeeded()) return false;
+    if (DestinationNetwork == "udp") {
+        for (size_t i = 0; i < n; i++)
+            if (::send(fd_, requests[i]->data(), requests[i]->size(), MSG_NOSIGNAL) != (ssize_t)requests[i]->size()) {
+                disconnect();
+                return false;
+            }
+        return true;
+    }
+    iovec iov[60];
+    size_t cnt = 0;
+    for (size_t i = 0; i < n && cnt < 60; i++)
+        if (!requests[i]->empty()) iov[cnt++] = iovec{const_cast<char *>(requests[i]->data()), requests[i]->size()};
+    size_t first = 0;
+    while (first < cnt) {
+        msghdr mh{};
+        mh.msg_iov = iov + first;
+        mh.msg_iovlen = cnt - first;
+        ssize_t w = ::sendmsg(fd_, &mh, MSG_NOSIGNAL); // writev with MSG_NOSIGNAL
+        if (w <= 0) {
+            disconnect(); // the peer went away or the deadline passed: re-dial at the next interval
+            return false;
+        }
+        while (w > 0 && first < cnt) { // partial write: drop what has left
+            if ((size_t)w >= iov[first].iov_len) {
+                w -= (ssize_t)iov[first].iov_len;
+                first++;
+            } else {
+                iov[first].iov_base = static_cast<char *>(iov[first].iov_base) + w;
+                iov[first].iov_len -= (size_t)w;
+                w = 0;
+            }
+        }
+    }
+    return true;
 }
 
 bool Submitter::retryBacklog() // submitter.go:70-93
 {
-    while (true) {
-        std::string request;
-        {
-            std::lock_guard<std::mutex> g(backlog_mu_);
-            if (head_ == tail_) return true;
-            request = backlog_[head_];
-        }
-        if (!submit(request)) return false;
-        sent_.fetch_add(1);
+    std::shared_ptr<const std::string> batch[60];
+    size_t n = 0;
+    uint64_t seq0;
+    {
         std::lock_guard<std::mutex> g(backlog_mu_);
+        seq0 = head_seq_;
+        for (int i = head_; i != tail_; i = (i + 1) % 60) batch[n++] = backlog_[i];
+    }
+    if (n == 0) return true;
+    if (!submitBatch(batch, n)) return false;
+    sent_.fetch_add(n);
+    std::lock_guard<std::mutex> g(backlog_mu_);
+    // entries evicted while the batch was on the wire already moved the head past some of what was sent
+    for (uint64_t end = seq0 + n; head_seq_ < end; head_seq_++) {
+        backlog_[head_].reset();
         head_ = (head_ + 1) % 60;
     }
+    return true;
 }
 
 void Submitter::appendToBacklog(std::string request) // submitter.go:95-104
 {
+    auto entry = std::make_shared<const std::string>(std::move(request));
     std::lock_guard<std::mutex> g(backlog_mu_);
-    backlog_[tail_] = std::move(request);
+    backlog_[tail_] = std::move(entry);
     tail_ = (tail_ + 1) % 60;
     if (head_ == tail_) { // ran into the head: evict it
+        backlog_[head_].reset();
         head_ = (head_ + 1) % 60;
+        head_seq_++;
         evicted_.fetch_add(1);
     }
 }
@@ -791,6 +845,7 @@ void Submitter::Shutdown() // submitter.go:152-159
     if (shutdown_.exchange(true)) return;
     if (recv_thread_.joinable()) recv_thread_.join();
     if (send_thread_.joinable()) send_thread_.join();
+    disconnect();
 }
 
 // ---------------------------------------------------------------------------

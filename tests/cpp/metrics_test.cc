@@ -267,6 +267,7 @@ TEST(TestSubmitterGraphite)
         s.Shutdown();
         ms.Stop();
         CHECK(s.sent_requests() >= 2);
+        CHECK(s.connections() == 1); // persistent: every interval's requests over the one connection
         CHECK(s.DestinationNetwork == "tcp");
     }
     stop.store(true);
@@ -275,6 +276,51 @@ TEST(TestSubmitterGraphite)
     CHECK(received.find(".requests.total 7.000000 ") != std::string::npos);      // lifetime counter, '_' -> '.'
     CHECK(received.find(".requests.total.rate 7.000000 ") != std::string::npos); // first interval's rate
     CHECK(received.rfind("cockroach.", 0) == 0);
+}
+
+
+// submitter.go:70-104: requests that cannot be delivered wait in the backlog and leave, oldest first, once the
+// destination answers -- here in one batch over one connection (no reference test covers the backlog).
+TEST(TestSubmitterBacklogDrainsAfterTheSinkComesUp)
+{
+    // reserve a port, then close the listener: nothing answers at first
+    int lfd = socket(AF_INET, SOCK_STREAM, 0);
+    int one = 1;
+    setsockopt(lfd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
+    sockaddr_in a{};
+    a.sin_family = AF_INET;
+    a.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
+    CHECK(bind(lfd, (sockaddr *)&a, sizeof a) == 0);
+    socklen_t l = sizeof a;
+    getsockname(lfd, (sockaddr *)&a, &l);
+    close(lfd);
+    MetricSystem ms(5ms, false);
+    Submitter s(&ms, GraphiteProtocol, "tcp", "127.0.0.1:" + std::to_string(ntohs(a.sin_port)), 5ms);
+    s.Start();
+    ms.Counter("queued_total", 3);
+    ms.Start();
+    std::this_thread::sleep_for(80ms);
+    CHECK(s.sent_requests() == 0 && s.connections() == 0); // every interval's request is waiting
+    lfd = socket(AF_INET, SOCK_STREAM, 0);
+    setsockopt(lfd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
+    CHECK(bind(lfd, (sockaddr *)&a, sizeof a) == 0 && listen(lfd, 16) == 0);
+    std::string received;
+    std::thread sink([&] {
+        char buf[65536];
+        int c = accept(lfd, nullptr, nullptr);
+        ssize_t n;
+        while ((n = read(c, buf, sizeof buf)) > 0) received.append(buf, (size_t)n);
+        close(c);
+    });
+    std::this_thread::sleep_for(80ms);
+    s.Shutdown(); // closes the connection: the sink sees EOF
+    ms.Stop();
+    sink.join();
+    close(lfd);
+    CHECK(s.connections() == 1 && s.sent_requests() >= 10 && s.evicted_requests() == 0);
+    // the first interval's request (the only one with a rate line for the counter) arrived, and arrived first
+    const size_t first_rate = received.find(".queued.total.rate 3.000000 ");
+    CHECK(first_rate != std::string::npos && first_rate < 200);
 }
 
 // ---- histogram paths: need the GPU ---------------------------------------------------------------
@@ -543,6 +589,7 @@ int main(int argc, char **argv)
     RUN(TestMetricSystemStop);
     RUN(TestSerializers);
     RUN(TestSubmitterGraphite);
+    RUN(TestSubmitterBacklogDrainsAfterTheSinkComesUp);
     RUN(TestFormatGoV);
     if (!cpu_only) {
         RUN(TestTimer);
