@@ -506,12 +506,13 @@ TEST(TestPrintBenchmark) // print_benchmark.go:49-106
     CHECK(text.find("raft_AppendLogEntries_agg_count: ") != std::string::npos);
     CHECK(text.find("raft_AppendLogEntries_max:\t ") != std::string::npos);
     CHECK(text.find("sys.NumGC:\t\t\t 0\n") != std::string::npos);
-    // a sleep of 200 us is timed at >= 200 000 ns: the median prints in Go's %v form
+    // a sleep of 200 us is timed at >= 200 000 ns, reported as its bucket's value (within 1 % below or above); a loaded
+    // box may stretch the sleeps, hence the loose upper bound: the median prints in Go's %v form
     const size_t p50 = text.find("raft_AppendLogEntries_50:");
     CHECK(p50 != std::string::npos);
     if (p50 != std::string::npos) {
         const double v = std::atof(text.c_str() + text.find(' ', p50));
-        CHECK(v >= 200000.0 && v < 5e7);
+        CHECK(v >= 197000.0 && v < 5e8);
     }
 }
 
