@@ -202,6 +202,7 @@ struct lh_engine {
 
     lh::PartTuning tune;                  // lh_set_option; never the environment in the product build
     bool zero_copy_enabled = true;
+    size_t zero_copy_max = 32768; // results up to this size are stored by the kernel straight into pinned memory
     uint32_t flips_since_small_off = 0;   // adaptive dispatch re-arms the single-pass path every 64 flips (epoch_mu)
     bool small_forced_off = false;        // LH_OPT_SMALL_PATH = 0: never re-armed
 };
@@ -1052,7 +1053,7 @@ int extract_impl(lh_snapshot *s, uint32_t first, size_t nmetrics, const double *
     // scan itself is the wave-per-metric kernel (65 536 names: ~290 -> ~60 us), so that the 9 MB transfer is what
     // remains -- measured: cutting it into chunks pipelined behind the kernels gained nothing over one copy, and
     // lh_extract_rows_view hands the pinned block out in place instead of copying it once more on the host.
-    const bool zero_copy = e->d_hxbuf != nullptr && L.total <= 32768 && e->zero_copy_enabled;
+    const bool zero_copy = e->d_hxbuf != nullptr && L.total <= e->zero_copy_max && e->zero_copy_enabled;
     unsigned char *xb = zero_copy ? e->d_hxbuf : e->d_xbuf;
     lh::ExtractNotify nt;
     volatile uint32_t *flag = reinterpret_cast<volatile uint32_t *>(e->h_xbuf + L.total);
@@ -1848,8 +1849,9 @@ int lh_set_option(lh_engine *e, int option, uint64_t value)
         e->tune.names_per_part = (uint32_t)value;
         return LH_OK;
     case LH_OPT_EXTRACT_ZERO_COPY:
-        if (value > 1) return LH_EINVAL;
+        if (value > 1 && (value < 4096 || value > (uint64_t(64) << 20))) return LH_EINVAL;
         e->zero_copy_enabled = value != 0;
+        if (value > 1) e->zero_copy_max = (size_t)value;
         return LH_OK;
     case LH_OPT_SCRATCH_CAP_BYTES: {
         if (value < (uint64_t(64) << 20)) return LH_EINVAL;

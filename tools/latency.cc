@@ -21,6 +21,7 @@ int main(int argc, char **argv)
     const size_t n = argc > 2 ? (size_t)std::atoll(argv[2]) : (size_t)1 << 20;
     const uint32_t names = argc > 3 ? (uint32_t)std::atoi(argv[3]) : 1u;
     const bool use_view = argc > 4 && std::atoi(argv[4]) != 0; // lh_extract_rows_view instead of lh_extract
+    const long long zc = argc > 5 ? std::atoll(argv[5]) : -1;  // LH_OPT_EXTRACT_ZERO_COPY (0 off, 1 default, >= 4096: limit)
     lh_config cfg;
     lh_default_config(&cfg);
     cfg.max_metrics = names;
@@ -29,6 +30,7 @@ int main(int argc, char **argv)
     lh_engine *e = nullptr;
     int rc = lh_create(&cfg, &e);
     if (rc != LH_OK) { std::fprintf(stderr, "lh_create: %s [%s]\n", lh_strerror(rc), lh_last_error()); return 2; }
+    if (zc >= 0 && lh_set_option(e, LH_OPT_EXTRACT_ZERO_COPY, (uint64_t)zc) != LH_OK) { std::fprintf(stderr, "bad zero-copy value\n"); return 2; }
     uint32_t id = 0;
     for (uint32_t m = 0; m < names; m++) {
         char nm[32];
@@ -79,9 +81,9 @@ int main(int argc, char **argv)
         if (i >= 20) lat.push_back(std::chrono::duration<double, std::micro>(t1 - t0).count());
     }
     std::sort(lat.begin(), lat.end());
-    std::printf("{\"what\": \"lh_flip -> lh_extract results on host, C ABI\", \"names\": %u, \"view\": %d, \"flips\": %d, \"samples_per_interval\": %zu, "
+    std::printf("{\"what\": \"lh_flip -> lh_extract results on host, C ABI\", \"names\": %u, \"view\": %d, \"zero_copy\": %lld, \"flips\": %d, \"samples_per_interval\": %zu, "
                 "\"p50_us\": %.2f, \"p90_us\": %.2f, \"p99_us\": %.2f, \"max_us\": %.2f, \"samples_total\": %llu}\n",
-                names, (int)use_view, flips, n, lat[lat.size() / 2], lat[lat.size() * 9 / 10], lat[lat.size() * 99 / 100], lat.back(),
+                names, (int)use_view, zc, flips, n, lat[lat.size() / 2], lat[lat.size() * 9 / 10], lat[lat.size() * 99 / 100], lat.back(),
                 (unsigned long long)total);
     lh_destroy(e);
     return 0;
