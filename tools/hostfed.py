@@ -19,12 +19,16 @@ import loghisto_amd  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--lib", default=None, help="path of another build of liblhgpu.so (A/B runs)")
     ap.add_argument("--samples", type=float, default=4e8)
     ap.add_argument("--threads", default="1,4,16,64")
     ap.add_argument("--batch", type=int, default=1 << 20)
     ap.add_argument("--lane-samples", type=int, default=1 << 21)
     ap.add_argument("--pairs", type=int, default=0, help="if >0: lh_submit_pairs over this many Zipf(1.0) names (12 B/sample)")
     a = ap.parse_args()
+    if a.lib:
+        from loghisto_amd import _native
+        _native.LIB_PATH = os.path.abspath(a.lib)
     n = int(a.samples)
     rng = np.random.default_rng(1)
     src = rng.lognormal(np.log(1e5), 1.0, 1 << 24)  # 128 MiB of host samples, reused

@@ -10,11 +10,11 @@ R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/round; mkdir -p $OUT; cd $R
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 python bench.py --workload c4 > $OUT/c4_bench.json 2> $OUT/c4_bench.err
 cd /tmp; export TMPDIR=/tmp
-CMD="python $R/bench.py --workload c2 --steps 10 --warmup 2 --no-cpu-baseline --no-parity --latency-flips 50"
+CMD="python $R/bench.py --workload c2 --no-secondary --steps 10 --warmup 2 --no-cpu-baseline --no-parity --latency-flips 50"
 rm -rf /tmp/pr_trace; rocprofv3 --kernel-trace -d /tmp/pr_trace -o t -- $CMD > $OUT/bench_under_trace.json 2>/dev/null
 { echo "# rocprofv3 --kernel-trace -- $CMD"; python $R/profiles/summarize_rocpd.py stats /tmp/pr_trace/t_results.db | cut -c1-170
   echo; echo "## full-size launches only (duration >= 0.5 ms)"; python $R/profiles/summarize_rocpd.py stats /tmp/pr_trace/t_results.db --min-ns 500000 | cut -c1-170; } > $OUT/kernel_trace.txt
-CMD2="python $R/bench.py --workload c2 --steps 3 --warmup 1 --no-cpu-baseline --no-parity --latency-flips 0"
+CMD2="python $R/bench.py --workload c2 --no-secondary --steps 3 --warmup 1 --no-cpu-baseline --no-parity --latency-flips 0"
 rm -rf /tmp/pr_fetch /tmp/pr_write
 rocprofv3 --pmc FETCH_SIZE -d /tmp/pr_fetch -o t -- $CMD2 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE -d /tmp/pr_write -o t -- $CMD2 > /dev/null 2>&1
