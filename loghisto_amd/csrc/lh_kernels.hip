@@ -151,7 +151,11 @@ __global__ __launch_bounds__(K1_BLOCK) void k_ingest_single(const double *__rest
     }
 #else
     for (size_t t = blockIdx.x; t < nfull; t += gridDim.x) {
+#ifdef LH_K1_L2TEST // tuning builds only: every workgroup re-reads its first tile (L2 hits): compute time without HBM
+        const d2_t *p = vp + (size_t)blockIdx.x * tile + tid;
+#else
         const d2_t *p = vp + t * tile + tid;
+#endif
         d2_t r[K1_UNROLL];
 #pragma unroll
         for (int u = 0; u < K1_UNROLL; u++) r[u] = __builtin_nontemporal_load(p + u * K1_BLOCK);
