@@ -312,7 +312,8 @@ int lh_get_counters(lh_engine *e, lh_counters *out);
  *                             not below 2^28 pairs
  *   LH_OPT_PART_V2            0 / 1: the survey + 2-byte-record generation of the partitioned path (default 1;
  *                             used for 33 .. 8 192 names)
- *   LH_OPT_PART_V2_MIN_PAIRS  smallest launch that takes it (default 2^24; >= 2^17: tests exercise it on small inputs)
+ *   LH_OPT_PART_V2_MIN_PAIRS  smallest launch that takes it (default 2^25, the measured crossover with the first generation; >= 2^17: tests
+ *                             exercise it on small inputs)
  *   LH_OPT_PART_V2_SHAPE      bit 0: two 512-thread scatter workgroups per CU over <= 128 partitions instead of one
  *                             1 024-thread workgroup over <= 256; bit 1: fixed per-partition LDS regions (records
  *                             placed by the classifying phase) instead of the exact per-tile layout.  Default 2.

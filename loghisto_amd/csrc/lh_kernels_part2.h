@@ -30,7 +30,7 @@ constexpr int V2_SPT = 8;                              // samples per thread per
 constexpr uint32_t LINE2 = 32;                         // records per line (64 B)
 constexpr uint32_t V2_MAX_NAMES = 8192;
 constexpr uint32_t V2_MAX_SLOTS = 512;                 // hot names
-constexpr size_t V2_MIN_SAMPLES = size_t(1) << 24;
+constexpr size_t V2_MIN_SAMPLES = size_t(1) << 25; // measured crossover with the first-generation path: profiles/r02_c3_sizes.txt
 constexpr uint32_t V2_LDS_TOTAL = 160 * 1024;
 constexpr uint32_t SV_GRID = 256;                      // survey workgroups (one 4 096-sample tile each)
 constexpr uint32_t P2V2_WINWORDS = 32768;              // 128 KiB of uint32 windows per P2 workgroup

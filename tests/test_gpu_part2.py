@@ -3,7 +3,7 @@ launch, hot windows sized from the measured spread, 2-byte records, line-granula
 
 The survey only decides WHERE a sample is counted (hot LDS window, 2-byte record into a 4 096-bin cold window,
 or the exact out-of-window path); every cell must equal the oracle's whatever it estimates.  The engine takes
-this path for launches of >= 2^24 pairs over 33 .. 8 192 names; lh_set_option(LH_OPT_PART_V2_MIN_PAIRS) lowers
+this path for launches of >= 2^25 pairs over 33 .. 8 192 names; lh_set_option(LH_OPT_PART_V2_MIN_PAIRS) lowers
 the bar so that the cases below (a few million pairs, seconds of oracle time) run through it.  Every row of
 every case is compared, cell by cell."""
 import math
