@@ -23,8 +23,8 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--pairs", type=int, default=0, help="if >0: mixed stream over this many names, Zipf(1.0) ids")
     ap.add_argument("--dists", default="lognormal,constant,uniform,exponential,normal,loguniform,lognormal25")
-    ap.add_argument("--ids", default="zipf", choices=["zipf", "uniform", "zipf0.5", "sorted"],
-                    help="name distribution of --pairs (sorted: Zipf(1.0) counts, the stream ordered by name)")
+    ap.add_argument("--ids", default="zipf", choices=["zipf", "uniform", "zipf0.5", "sorted", "drift"],
+                    help="name distribution of --pairs (sorted: Zipf(1.0) counts, the stream ordered by name; drift: the ranking of the names is reversed half way through the launch)")
     ap.add_argument("--lib", default=None, help="path of an alternative liblhgpu.so (a -DLH_TUNING build)")
     ap.add_argument("--opt", action="append", default=[], help="lh_set_option as ID=VALUE (repeatable), e.g. 9=0 turns "
                                                                "the survey + 2-byte-record path off")
@@ -42,10 +42,12 @@ def main():
         ids = None
         if a.pairs:
             w = torch.arange(1, a.pairs + 1, dtype=torch.float64, device="cuda") ** {"zipf": -1.0, "uniform": 0.0,
-                                                                                      "zipf0.5": -0.5, "sorted": -1.0}[a.ids]
+                                                                                      "zipf0.5": -0.5, "sorted": -1.0, "drift": -1.0}[a.ids]
             ids = torch.multinomial(w / w.sum(), n, replacement=True).to(torch.int32)
             if a.ids == "sorted":
                 ids = torch.sort(ids).values.contiguous()
+            if a.ids == "drift":
+                ids[n // 2:] = (a.pairs - 1) - ids[n // 2:]
         ms = []
         for r in range(a.reps + 2):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
