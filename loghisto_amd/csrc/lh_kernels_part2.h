@@ -24,6 +24,13 @@
 //   4. 8 192-sample tiles on 1 024 threads: half the barriers per sample.
 //
 // Everything stays exact whatever the survey estimates: windows only decide where a sample is counted.
+//
+// Two scatter kernels share the survey, the record format and P2:
+//   k_scatter3  (default, shapes 2 / 3)  fixed per-partition LDS regions sized by the survey; a record is placed by the
+//               phase that classifies it (the LDS atomic's return value is its slot): two barriers per tile
+//   k_scatter2  (shapes 0 / 1)           exact per-tile layout (scan of the partitions' line counts, points 3 and 4
+//               above): any distribution of a tile over the partitions at full speed; the engine falls back to it
+//               while a stream is clustered by name (lh_engine.cc, regions_disabled)
 
 constexpr int V2_BLOCK = 1024;                         // survey kernels
 constexpr int V2_SPT = 8;                              // samples per thread per tile
