@@ -178,7 +178,7 @@ struct lh_engine {
     unsigned long long *h_rstat = nullptr, *d_rstat = nullptr; // pinned, device-visible
     std::atomic<bool> regions_disabled{false};
     std::atomic<uint64_t> region_samples{0}, c_region_ovf{0};
-    uint64_t rstat_seen = 0;
+    uint64_t rstat_seen = 0, win_ovf = 0, win_samples = 0; // lh_flip only (under the epoch lock)
     int flips_since_regions_off = 0;
 
     // self-metrics (lh_get_counters)
@@ -952,16 +952,25 @@ int lh_flip(lh_engine *e, lh_snapshot **out)
     e->live_snapshots.fetch_add(1);
     e->c_flips.fetch_add(1, std::memory_order_relaxed);
     {
-        // region overflows of the launches that have completed so far (the kernels add to pinned memory)
+        // Region overflows of the launches that have completed so far (the kernels add to pinned memory).  A
+        // launch's overflows can arrive one flip after its samples were counted, so both are accumulated and the ratio
+        // is judged only over windows of at least 2^21 region-path samples: an idle interval that merely collects a
+        // late count must not switch the path.
         const uint64_t now = __atomic_load_n(e->h_rstat, __ATOMIC_RELAXED);
         const uint64_t ov = now - e->rstat_seen;
         e->rstat_seen = now;
-        const uint64_t seen = e->region_samples.exchange(0);
         if (ov) e->c_region_ovf.fetch_add(ov, std::memory_order_relaxed);
-        if (ov && ov * 50 > seen) {
-            e->regions_disabled.store(true);
-            e->flips_since_regions_off = 0;
-        } else if (e->regions_disabled.load(std::memory_order_relaxed) && ++e->flips_since_regions_off >= 64) {
+        e->win_ovf += ov;
+        e->win_samples += e->region_samples.exchange(0);
+        if (e->win_samples >= (uint64_t(1) << 21)) {
+            if (e->win_ovf * 50 > e->win_samples) {
+                e->regions_disabled.store(true);
+                e->flips_since_regions_off = 0;
+            }
+            e->win_ovf = 0;
+            e->win_samples = 0;
+        }
+        if (e->regions_disabled.load(std::memory_order_relaxed) && ++e->flips_since_regions_off > 64) {
             e->flips_since_regions_off = 0;
             e->regions_disabled.store(false);
         }

@@ -193,6 +193,27 @@ def test_clustered_stream_falls_back_to_exact_layout(native_lib, torch_cuda):
         assert c2["region_overflows"] == c["region_overflows"] and c2["samples_partitioned_v2"] == 2 * n, c2
 
 
+def test_idle_intervals_do_not_switch_the_scatter(native_lib, torch_cuda):
+    """A random stream leaves a few hundred statistical-tail overflows per launch, and they can be seen one flip after
+    the launch's samples were counted: intervals without region-path traffic must not turn the regions off."""
+    import loghisto_amd
+    rng = np.random.default_rng(12)
+    M, n = 512, 3_000_000
+    ids = _ids(rng, M, n, 1.0)
+    v = rng.lognormal(10, 2.5, n)
+    d_ids, d_v = _dev(torch_cuda, ids), _dev(torch_cuda, v)
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        e.set_option(N.OPT_PART_V2_MIN_PAIRS, 1 << 17)
+        for _ in range(3):
+            e.submit_pairs_device(d_ids, d_v)      # not synchronised: the flip comes before the kernel's count
+            with e.flip() as snap:
+                snap.extract(PCTS, M)
+            for _ in range(3):                     # idle intervals collect the late counts
+                with e.flip() as snap:
+                    snap.extract(PCTS, M)
+            assert e.counters()["regions_disabled"] == 0, e.counters()
+
+
 def test_old_and_new_generation_agree(native_lib, torch_cuda):
     """The same stream through both generations of the partitioned path: identical cells."""
     import loghisto_amd
