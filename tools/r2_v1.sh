@@ -3,6 +3,7 @@
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/${1:-r2v1}; mkdir -p $OUT; cd $R
 (timeout 900 python -m pytest tests/test_gpu_twolevel.py tests/test_gpu_hot.py tests/test_gpu_fuzz.py tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q) > $OUT/pytest_v1.log 2>&1
 tail -2 $OUT/pytest_v1.log
+if ! grep -q " passed" $OUT/pytest_v1.log || grep -q "failed\|Aborted\|Fatal" $OUT/pytest_v1.log; then echo "TESTS FAILED: no timings"; exit 1; fi
 run() { timeout 300 python tools/sweep.py --samples $1 --pairs $2 --reps 5 --dists lognormal $3 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
