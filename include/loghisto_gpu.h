@@ -288,6 +288,8 @@ typedef struct lh_counters {
     uint64_t samples_partitioned_v2; /* of samples_partitioned: through the survey + 2-byte-record path          */
     uint64_t counter_events;         /* (id, amount) events through lh_submit_counts*                               */
     uint64_t region_overflows;       /* records the region scatter counted through the exact out-of-window path     */
+    uint64_t samples_partitioned_v3; /* of samples_partitioned: through the 8 193 .. 65 536-name path               */
+    uint64_t window_log2;            /* that path's second-level window width (log2 bins) for the next call         */
 } lh_counters;
 int lh_get_counters(lh_engine *e, lh_counters *out);
 
@@ -321,7 +323,14 @@ int lh_get_counters(lh_engine *e, lh_counters *out);
  *                             interval's samples overflow their regions (a stream clustered by name), see
  *                             lh_counters.regions_disabled
  *   LH_OPT_SMALL_PATH         0 / 1: the single-pass kernel for <= 32 names (1 also re-arms it after adaptive
- *                             dispatch turned it off) */
+ *                             dispatch turned it off)
+ *   LH_OPT_PART_V3            0 / 1: the third generation of the partitioned path (hashed survey, region scatter of
+ *                             4-byte records, a second level that counts each partition's frequent names in place;
+ *                             default 1; used for 8 193 .. 65 536 names -- BASELINE config 4's name count)
+ *   LH_OPT_PART_V3_MIN_PAIRS  smallest launch that takes it (default 2^24; >= 2^17: tests exercise it on small inputs)
+ *   LH_OPT_PART_V3_LOG_W      log2 of its second-level window width, 10 .. 13 (32 .. 4 names per fine partition);
+ *                             0 (default) = follow the survey: every call's survey reports the width that covers
+ *                             95 % of the sampled mass and the following calls use it (lh_counters.window_log2) */
 enum {
     LH_OPT_TWO_LEVEL_ABOVE = 1,
     LH_OPT_HOT_MIN_TILES = 2,
@@ -333,7 +342,10 @@ enum {
     LH_OPT_SMALL_PATH = 8,
     LH_OPT_PART_V2 = 9,
     LH_OPT_PART_V2_MIN_PAIRS = 10,
-    LH_OPT_PART_V2_SHAPE = 11
+    LH_OPT_PART_V2_SHAPE = 11,
+    LH_OPT_PART_V3 = 12,
+    LH_OPT_PART_V3_MIN_PAIRS = 13,
+    LH_OPT_PART_V3_LOG_W = 14
 };
 int lh_set_option(lh_engine *e, int option, uint64_t value);
 

@@ -34,12 +34,15 @@ class LhCounters(C.Structure):
                                                                 ("sublaunches", C.c_uint64),
                                                                 ("samples_partitioned_v2", C.c_uint64),
                                                                 ("counter_events", C.c_uint64),
-                                                                ("region_overflows", C.c_uint64)]
+                                                                ("region_overflows", C.c_uint64),
+                                                                ("samples_partitioned_v3", C.c_uint64),
+                                                                ("window_log2", C.c_uint64)]
 
 # lh_set_option keys (include/loghisto_gpu.h)
 OPT_TWO_LEVEL_ABOVE, OPT_HOT_MIN_TILES, OPT_HOT_WINDOWS, OPT_NAMES_PER_PARTITION = 1, 2, 3, 4
 OPT_EXTRACT_ZERO_COPY, OPT_SCRATCH_CAP_BYTES, OPT_SUBLAUNCH_PAIRS, OPT_SMALL_PATH = 5, 6, 7, 8
 OPT_PART_V2, OPT_PART_V2_MIN_PAIRS, OPT_PART_V2_SHAPE = 9, 10, 11
+OPT_PART_V3, OPT_PART_V3_MIN_PAIRS, OPT_PART_V3_LOG_W = 12, 13, 14
 
 
 class LhExtractView(C.Structure):

@@ -195,7 +195,11 @@ struct lh_engine {
     hipEvent_t scratch_done = nullptr;
     hipStream_t scratch_stream = nullptr; // stream of the last launch that used the block
     bool scratch_used = false;
-    std::atomic<uint64_t> c_scratch{0}, c_sublaunches{0}, c_part2{0};
+    int scratch_gen = 0;                  // generation of the last partitioned launch that used the block (scratch_mu)
+    std::atomic<uint64_t> c_scratch{0}, c_sublaunches{0}, c_part2{0}, c_part3{0};
+    // Third generation (8 193 .. 65 536 names): the survey reports the window width that covers the stream's spans
+    // (h_rstat[1], pinned); later calls use it.  A width that is too small only costs speed.
+    bool v3_log_w_fixed = false;             // lh_set_option(LH_OPT_PART_V3_LOG_W) pinned it
     size_t scratch_cap = size_t(1536) << 20;     // 1.5 GiB
     bool scratch_cap_set = false, sublaunch_set = false; // lh_set_option was called: the caller's bound wins
     size_t sublaunch_pairs = size_t(1) << 29;
@@ -268,7 +272,12 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
         d_v++;
         n--;
     }
-    bool surveyed = false; // the second-generation path surveys once per call, not once per sub-launch
+    // One survey per call, not one per sub-launch (second and third generation).  The survey's tables live in the
+    // scratch block, which every stream of the engine shares: the block's lock is held from the call's first
+    // partitioned sub-launch to its last, so that no other stream's launch can overwrite them in between (enqueueing
+    // is all that happens under the lock; the kernels run later, in stream order behind `scratch_done`).
+    bool surveyed = false;
+    std::unique_lock<std::mutex> scratch_lock(e->scratch_mu, std::defer_lock);
     while (n) {
         size_t take = n < kMaxLaunch ? n : kMaxLaunch;
         if (!e->small_disabled.load(std::memory_order_relaxed) &&
@@ -288,33 +297,41 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
             // large launch over many names: partition by name, then reduce in LDS.  Sub-launches keep the scratch
             // block bounded: at most `sublaunch_pairs` pairs each, halved until the block fits `scratch_cap`
             // (power-of-two cuts keep both arrays on their vector alignment).
-            // Above 8 192 names the second scatter level carries ~1.2 GB of chunk pools whatever the launch size and
-            // ~0.35 ms of fixed work per launch, so cutting costs more than the bytes it saves (65 536 names: 9.1 ms
-            // in four sub-launches against 7.3 ms in one, per 1e9 pairs).  Such launches are cut only when the caller
-            // asked for a bound (LH_OPT_SCRATCH_CAP_BYTES / LH_OPT_SUBLAUNCH_PAIRS), and then not below 2^28 pairs.
+            // Above 8 192 names the second scatter level carries its chunk pools and ~0.2 ms of fixed work per launch
+            // whatever the launch size, so cutting costs more than the bytes it saves.  Such launches are cut only
+            // when the caller asked for a bound (LH_OPT_SCRATCH_CAP_BYTES / LH_OPT_SUBLAUNCH_PAIRS), and then not
+            // below 2^28 pairs.
             const bool two_level = e->cfg.max_metrics > 8192;
             const bool bounded = !two_level || e->scratch_cap_set || e->sublaunch_set;
+            if (!scratch_lock.owns_lock()) scratch_lock.lock();
             size_t sub = (bounded && take > e->sublaunch_pairs) ? e->sublaunch_pairs : take;
             lh::PartTuning tune = e->tune;
             if (e->regions_disabled.load(std::memory_order_relaxed)) tune.v2_shape &= ~2u; // clustered stream: exact layout
-            // second generation (survey + 2-byte records) when the launch is large enough and has <= 8 192 names
-            auto scratch_need = [&](size_t m, bool *v2) {
-                size_t b = lh::part2_scratch_bytes(m, e->cfg.max_metrics, e->num_cus, tune);
-                *v2 = b != 0;
-                return b ? b : lh::part_scratch_bytes(m, e->cfg.max_metrics, e->num_cus, tune);
+            if (two_level && !e->v3_log_w_fixed) {
+                // what the last completed survey saw (0 until one has run)
+                const uint32_t lw = (uint32_t)__atomic_load_n(&e->h_rstat[1], __ATOMIC_RELAXED);
+                if (lw >= 10 && lw <= 13) tune.v3_log_w = lw;
+            }
+            // generation 2 (survey + 2-byte records) for <= 8 192 names, generation 3 above, when the launch is large
+            // enough; otherwise the first generation
+            auto scratch_need = [&](size_t m, int *gen) {
+                size_t bytes = lh::part2_scratch_bytes(m, e->cfg.max_metrics, e->num_cus, tune);
+                *gen = 2;
+                if (!bytes) { bytes = lh::part3_scratch_bytes(m, e->cfg.max_metrics, e->num_cus, tune); *gen = 3; }
+                if (!bytes) { bytes = lh::part_scratch_bytes(m, e->cfg.max_metrics, e->num_cus, tune); *gen = 1; }
+                return bytes;
             };
-            bool v2 = false;
-            size_t need = scratch_need(sub, &v2);
+            int gen = 1;
+            size_t need = scratch_need(sub, &gen);
             const size_t floor = two_level ? (size_t(1) << 28) : (size_t(1) << 24);
             while (bounded && need > e->scratch_cap && sub > floor) {
                 size_t half = floor;
                 while (half * 2 < sub) half *= 2;
                 sub = half;
-                need = scratch_need(sub, &v2);
+                need = scratch_need(sub, &gen);
             }
             if (need == 0) return LH_EDEVICE; // cannot happen: sub is above the partitioned path's minimum
             take = sub;
-            std::lock_guard<std::mutex> g(e->scratch_mu);
             if (e->scratch_bytes < need) {
                 if (e->scratch_p) {
                     if (e->scratch_used) HIPCHK(hipEventSynchronize(e->scratch_done)); // earlier launches still read it
@@ -326,20 +343,33 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
                 HIPCHK(hipMalloc(&e->scratch_p, need));
                 e->scratch_bytes = need;
                 e->c_scratch.store(need, std::memory_order_relaxed);
+                surveyed = false; // a new block: the tables of this call's earlier sub-launches went with the old one
             }
             if (e->scratch_used && e->scratch_stream != s) HIPCHK(hipStreamWaitEvent(s, e->scratch_done, 0));
-            if (v2) {
-                // one survey per call: the first sub-launch samples everything that is left of the call (n pairs)
+            if (gen != e->scratch_gen) surveyed = false; // the generations lay their tables out differently
+            if (gen == 2) {
+                // the first sub-launch samples everything that is left of the call (n pairs)
                 HIPCHK(lh::launch_ingest_pairs_part2(d_ids, d_v, take, surveyed ? 0 : n, b.counts, b.ranges,
                                                      e->cfg.max_metrics, e->d_Tx, e->d_err, e->scratch_p,
                                                      e->scratch_bytes, e->num_cus, tune, e->d_rstat, s));
                 surveyed = true;
                 if (tune.v2_shape & 2u) e->region_samples.fetch_add(take, std::memory_order_relaxed);
                 e->c_part2.fetch_add(take, std::memory_order_relaxed);
+            } else if (gen == 3) {
+                HIPCHK(lh::launch_ingest_pairs_part3(d_ids, d_v, take, surveyed ? 0 : n, b.counts, b.ranges,
+                                                     e->cfg.max_metrics, e->d_Tx, e->d_err, e->scratch_p,
+                                                     e->scratch_bytes, e->num_cus, tune, e->d_rstat,
+                                                     e->d_rstat ? reinterpret_cast<uint32_t *>(e->d_rstat + 1) : nullptr,
+                                                     s));
+                surveyed = true;
+                e->region_samples.fetch_add(take, std::memory_order_relaxed);
+                e->c_part3.fetch_add(take, std::memory_order_relaxed);
             } else {
                 HIPCHK(lh::launch_ingest_pairs_part(d_ids, d_v, take, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx,
                                                     e->d_err, e->scratch_p, e->scratch_bytes, e->num_cus, tune, s));
+                surveyed = false; // its records start at offset 0 of the block: the survey's tables are gone
             }
+            e->scratch_gen = gen;
             HIPCHK(hipEventRecord(e->scratch_done, s));
             e->scratch_stream = s;
             e->scratch_used = true;
@@ -512,6 +542,7 @@ int create_impl(const lh_config *cfg_in, lh_engine *e)
     HIPCHK(hipMalloc((void **)&e->d_D, sizeof(double) * LH_NKEYS));
     HIPCHK(hipHostMalloc((void **)&e->h_rstat, 16, hipHostMallocDefault));
     e->h_rstat[0] = 0;
+    e->h_rstat[1] = 0;
     {
         void *dp = nullptr;
         HIPCHK(hipHostGetDevicePointer(&dp, e->h_rstat, 0));
@@ -1834,6 +1865,11 @@ int lh_get_counters(lh_engine *e, lh_counters *out)
     out->samples_partitioned_v2 = e->c_part2.load();
     out->counter_events = e->c_counts.load();
     out->region_overflows = e->c_region_ovf.load();
+    out->samples_partitioned_v3 = e->c_part3.load();
+    {
+        const uint64_t lw = __atomic_load_n(&e->h_rstat[1], __ATOMIC_RELAXED);
+        out->window_log2 = e->v3_log_w_fixed ? e->tune.v3_log_w : (lw >= 10 && lw <= 13 ? lw : e->tune.v3_log_w);
+    }
     return LH_OK;
 }
 
@@ -1889,6 +1925,19 @@ int lh_set_option(lh_engine *e, int option, uint64_t value)
     case LH_OPT_PART_V2_MIN_PAIRS:
         if (value < (1u << 17) || value > (uint64_t(1) << 31)) return LH_EINVAL;
         e->tune.v2_min_samples = (size_t)value;
+        return LH_OK;
+    case LH_OPT_PART_V3:
+        if (value > 1) return LH_EINVAL;
+        e->tune.v3 = value != 0;
+        return LH_OK;
+    case LH_OPT_PART_V3_MIN_PAIRS:
+        if (value < (1u << 17) || value > (uint64_t(1) << 31)) return LH_EINVAL;
+        e->tune.v3_min_samples = (size_t)value;
+        return LH_OK;
+    case LH_OPT_PART_V3_LOG_W:
+        if (value != 0 && (value < 10 || value > 13)) return LH_EINVAL;
+        e->v3_log_w_fixed = value != 0;
+        e->tune.v3_log_w = value ? (uint32_t)value : 10u;
         return LH_OK;
     case LH_OPT_SMALL_PATH:
         if (value > 1) return LH_EINVAL;

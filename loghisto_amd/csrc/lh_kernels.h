@@ -39,6 +39,9 @@ struct PartTuning {
     size_t v2_min_samples = 0;      // 0 = default (2^24): smaller launches do not amortise the survey
     uint32_t v2_shape = 2;          // bit 0: two 512-thread workgroups per CU (128 partitions) instead of one 1 024-thread (256);
                                     // bit 1: fixed per-partition regions (k_scatter3) instead of the exact per-tile layout
+    bool v3 = true;                 // hashed survey + region scatter + in-place second level (lh_kernels_part3.h) for 8 193 .. 65 536 names
+    size_t v3_min_samples = 0;      // 0 = default (2^24)
+    uint32_t v3_log_w = 10;         // log2 of the second level's window width, 10 .. 13: the engine follows the survey's report
     uint32_t dbg = 0;               // -DLH_TUNING builds only: timing ablations (results are wrong); ignored otherwise
 };
 
@@ -73,6 +76,15 @@ hipError_t launch_ingest_pairs_part2(const uint32_t *d_ids, const double *d_v, s
                                      uint64_t *counts, uint32_t *ranges, uint32_t nmetrics, const double *d_Tx,
                                      uint32_t *d_err, void *scratch, size_t scratch_bytes, int num_cus,
                                      const PartTuning &tune, unsigned long long *region_stat, hipStream_t s);
+
+// Third generation (lh_kernels_part3.h): 8 193 .. 65 536 names.  part3_scratch_bytes returns 0 when the launch should
+// take another path.  span_stat: device-visible word (pinned host memory) that receives the survey's window class.
+size_t part3_scratch_bytes(size_t n, uint32_t nmetrics, int num_cus, const PartTuning &tune);
+hipError_t launch_ingest_pairs_part3(const uint32_t *d_ids, const double *d_v, size_t n, size_t survey_n,
+                                     uint64_t *counts, uint32_t *ranges, uint32_t nmetrics, const double *d_Tx,
+                                     uint32_t *d_err, void *scratch, size_t scratch_bytes, int num_cus,
+                                     const PartTuning &tune, unsigned long long *region_stat, uint32_t *span_stat,
+                                     hipStream_t s);
 
 // K2: extract.  One workgroup per metric.
 // ExtractNotify (optional): when the outputs live in host-mapped memory the last workgroup to finish stores

@@ -1097,5 +1097,6 @@ hipError_t launch_ingest_pairs_part(const uint32_t *d_ids, const double *d_v, si
 }
 
 #include "lh_kernels_part2.h"
+#include "lh_kernels_part3.h"
 
 } // namespace lh

@@ -1,0 +1,1219 @@
+// lh_kernels_part3.h -- third generation of the partitioned mixed (id, value) ingest: 8 193 .. 65 536 names, gfx950.
+// Included at the end of lh_kernels_part.hip after lh_kernels_part2.h (same translation unit: it reuses the plan
+// kernels, the chunk descriptor format, the survey's g_stat layout, hidden_store_* and lh_bin_fast).
+// Reference semantics are unchanged: Histogram(name, v) = histogramCache[name][compress(v)] += 1
+// (metrics.go:273-295, 316-322).
+//
+// Config 4 of BASELINE.json runs 65 536 names per GPU.  Round 2 left that name count on the first-generation
+// two-level path (k_scatter_samples -> k_scatter_records -> k_part_hist): 7.3 ms per 1e9 pairs, 20 % of the HBM
+// roofline, 28 B of traffic per sample.  What the survey path (lh_kernels_part2.h) changed for <= 8 192 names does
+// not carry over as it is -- its per-name LDS table is 8 B per name (512 KiB at 65 536 names) and its 2-byte record
+// needs name-in-partition and bin offset in 15 bits -- so this file rebuilds the three passes around what does:
+//
+//   survey   k_survey_count_h     the same ~1 M sampled pairs, counted per workgroup in an LDS HASH table (a
+//                                 workgroup sees <= 2 048 distinct names whatever the name space) and merged into the
+//                                 per-name tables with one global atomic per (workgroup, name)
+//            k_survey_pick/plan_h hot names claim one slot of a 1 024-entry hash table (the more frequent name wins a
+//                                 collision); the plan gives the winners LDS windows exactly as k_survey_plan does
+//            k_survey_remap       per level-1 partition (id & 255): its 256 names ranked by sampled count.  Rank r is
+//                                 the name's index in the second level: ranks < Kp are counted in place there, rank
+//                                 r >= Kp goes on to fine partition r / mpp2
+//   level 1  k_scatter4           k_scatter3's region scatter with a HASHED hot-name lookup (8 KiB of LDS instead of
+//                                 8 B per name) and 4-byte records (partition | local name | bin: no per-name cold
+//                                 window, so no per-name table at all).  One LDS gather + one returning LDS atomic +
+//                                 one LDS store per sample, two barriers per 8 192-sample tile
+//   level 2  k_split_records      one workgroup per level-1 work slot.  Names are skewed inside a partition too: the Kp
+//                                 most frequent of its 256 names get LDS windows here (96 KiB) and their records end
+//                                 in this pass (under Zipf(1) they are ~70 % of the partition's records); the rest is
+//                                 split into ns fine partitions through LDS regions, exactly like level 1
+//   reduce   k_part_hist3         one workgroup per fine-partition work slot: mpp2 names x W bins of uint32 windows
+//                                 (128 KiB), windows placed from the slot's own first chunk and the survey
+//
+// Window width W (1 024 .. 8 192 bins, names per fine partition 32 .. 4) follows the stream: the survey reports
+// the span that covers 95 % of the sampled mass (k_survey_plan_h -> pinned host word) and the engine uses it for
+// the following calls.  A wrong W only costs speed: every record outside a window is counted through the small LDS
+// overflow tables and global atomics; a record that finds an LDS region full likewise.  Everything stays exact.
+//
+// HBM traffic per sample at 65 536 Zipf names: 12 B read + (cold share ~0.65) x (4 B written + 4 B read) +
+// (forwarded share ~0.2) x (4 B + 4 B) = ~19 B against 28 B before.
+
+constexpr uint32_t V3_MAX_NAMES = 65536;
+constexpr uint32_t V3_LOG_NP = 8, V3_NP = 256;          // level-1 partitions: id & 255
+constexpr uint32_t V3_HN = 1024;                        // hot-name hash entries (8 B each)
+constexpr uint32_t V3_TILE = 8192;                      // samples per level-1 tile
+constexpr uint32_t LINE4 = 16;                          // 4-byte records per 64-byte line
+constexpr uint32_t V3_MISSQ = 512;                      // records a tile can queue for the exact path (per parity)
+constexpr size_t V3_MIN_SAMPLES = size_t(1) << 24;
+constexpr uint32_t SVH_GRID = 512, SVH_SLOTS = 4096;    // hashed survey: 512 workgroups x 2 048 samples
+constexpr uint32_t V3_EXTRA1 = 768;                     // level-1 work slots beyond one per partition
+constexpr uint32_t V3_EXTRA2 = 1024;                    // fine work slots beyond one per fine partition
+constexpr uint32_t V3_MAX_NS = 64;                      // fine partitions per level-1 partition (at most)
+constexpr uint32_t PEEL_WORDS = 24576;                  // level 2: 96 KiB of windows for the partition's top names
+constexpr uint32_t P3_WINWORDS = 32768;                 // reduce: 128 KiB of windows
+constexpr uint32_t SPLIT_TILE = 8192;                   // records per level-2 tile
+constexpr uint32_t SPLIT_REG_WORDS = 12800;             // level 2: LDS regions (>= 5/4 tile + 28 per fine partition)
+
+__device__ __forceinline__ uint32_t v3_hash(uint32_t id) { return (id * 0x9E3779B1u) >> 22; } // 10 bits
+
+// ---------------------------------------------------------------------------
+// Survey for large name spaces
+// ---------------------------------------------------------------------------
+// LDS hash table: key[SVH_SLOTS] (id + 1, 0 = free) | cnt | sum | mninv | mx.  A workgroup inserts <= 2 048 samples
+// into 4 096 slots, so linear probing always terminates.
+__global__ __launch_bounds__(1024) void k_survey_count_h(const uint32_t *__restrict__ ids, const double *__restrict__ v,
+                                                         size_t n, uint32_t nmetrics, const double *__restrict__ Tx,
+                                                         uint32_t *__restrict__ g_cnt, uint32_t *__restrict__ g_mninv,
+                                                         uint32_t *__restrict__ g_mx,
+                                                         unsigned long long *__restrict__ g_sum)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char svh_smem[];
+    uint32_t *s_key = reinterpret_cast<uint32_t *>(svh_smem);
+    uint32_t *s_cnt = s_key + SVH_SLOTS, *s_sum = s_cnt + SVH_SLOTS, *s_mninv = s_sum + SVH_SLOTS,
+             *s_mx = s_mninv + SVH_SLOTS;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < 5 * SVH_SLOTS; i += 1024) s_key[i] = 0;
+    __syncthreads();
+    const size_t npairs = n / 2; // an odd last sample is not surveyed
+    const size_t stride = npairs / gridDim.x;
+    const size_t i = (size_t)blockIdx.x * stride + tid;
+    if (i < npairs && tid < (stride ? stride : npairs)) {
+        const pu2_t id2 = reinterpret_cast<const pu2_t *>(ids)[i];
+        const pd2_t x2 = reinterpret_cast<const pd2_t *>(v)[i];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t id = h ? id2.y : id2.x;
+            if (id < nmetrics) {
+                const uint32_t bin = lh_bin_of(h ? x2.y : x2.x, Tx);
+                uint32_t s = (id * 2654435761u) >> 20;
+                for (;;) {
+                    const uint32_t prev = atomicCAS(&s_key[s], 0u, id + 1u);
+                    if (prev == 0u || prev == id + 1u) break;
+                    s = (s + 1u) & (SVH_SLOTS - 1u);
+                }
+                atomicAdd(&s_cnt[s], 1u);
+                atomicAdd(&s_sum[s], bin);
+                atomicMax(&s_mninv[s], 65535u - bin);
+                atomicMax(&s_mx[s], bin);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t s = tid; s < SVH_SLOTS; s += 1024) {
+        const uint32_t k = s_key[s];
+        if (k) {
+            const uint32_t m = k - 1u;
+            atomicAdd(&g_cnt[m], s_cnt[s]);
+            atomicAdd(&g_sum[m], (unsigned long long)s_sum[s]);
+            atomicMax(&g_mninv[m], s_mninv[s]);
+            atomicMax(&g_mx[m], s_mx[s]);
+        }
+    }
+}
+
+// g_aux (zero-initialised with the statistics): claim[V3_HN] | pc[V3_NP] | cls[17] (sampled mass by ceil(log2 span))
+constexpr uint32_t AUX_CLAIM = 0, AUX_PC = V3_HN, AUX_CLS = V3_HN + V3_NP, AUX_WORDS = V3_HN + V3_NP + 32;
+
+// One thread per name: a name with >= 16 sampled values claims its hash slot (the larger count wins); per-partition
+// sample counts; the sampled mass by span class.
+__global__ __launch_bounds__(1024) void k_survey_pick(const uint32_t *__restrict__ g_cnt,
+                                                      const uint32_t *__restrict__ g_mninv,
+                                                      const uint32_t *__restrict__ g_mx, uint32_t nmetrics,
+                                                      uint32_t *__restrict__ g_aux)
+{
+    __shared__ uint32_t s_pc[V3_NP], s_cls[17];
+    const uint32_t tid = threadIdx.x;
+    if (tid < V3_NP) s_pc[tid] = 0;
+    if (tid < 17) s_cls[tid] = 0;
+    __syncthreads();
+    const uint32_t m = blockIdx.x * 1024u + tid;
+    const uint32_t c = m < nmetrics ? g_cnt[m] : 0u;
+    if (c) {
+        atomicAdd(&s_pc[m & (V3_NP - 1u)], c);
+        const uint32_t span = g_mx[m] - (65535u - g_mninv[m]) + 1u;
+        if (c >= 16u) atomicMax(&g_aux[AUX_CLAIM + v3_hash(m)], (min(c, 65535u) << 16) | m);
+        if (c >= 32u) { // class k: spans in (2^(k-1), 2^k]
+            const uint32_t k = span <= 1u ? 0u : 32u - (uint32_t)__clz(span - 1u);
+            atomicAdd(&s_cls[k > 16u ? 16u : k], c);
+        }
+    }
+    __syncthreads();
+    if (tid < V3_NP && s_pc[tid]) atomicAdd(&g_aux[AUX_PC + tid], s_pc[tid]);
+    if (tid < 17 && s_cls[tid]) atomicAdd(&g_aux[AUX_CLS + tid], s_cls[tid]);
+}
+
+// One workgroup, thread t owns hash slot t.  Output:
+//   g_hk[t]   hot entry {name | width << 20, LDS base (relative to the window area) | origin << 16}, x = ~0 when free
+//   g_hs[s]   the same windows as a list for the flush {name, origin | width << 16, base, 0}
+//   g_pt[p]   level-1 region of partition p {first record relative to the region area, capacity}
+//   hdr       [0] hot names [1] cells used [2] surveyed samples [3] surveyed samples of hot names [4] log2 of the
+//             window width that covers 95 % of the sampled mass (10 .. 13), also stored to *span_out (pinned)
+__global__ __launch_bounds__(V2_BLOCK) void k_survey_plan_h(const uint32_t *__restrict__ g_cnt,
+                                                            const uint32_t *__restrict__ g_mninv,
+                                                            const uint32_t *__restrict__ g_mx,
+                                                            const unsigned long long *__restrict__ g_sum,
+                                                            const uint32_t *__restrict__ g_aux, uint32_t cells,
+                                                            uint32_t tile, pu2_t *__restrict__ g_hk,
+                                                            pu4_t *__restrict__ g_hs, pu2_t *__restrict__ g_pt,
+                                                            uint32_t *__restrict__ hdr, uint32_t *span_out)
+{
+    __shared__ uint32_t s_a[V2_BLOCK / 64], s_b[V2_BLOCK / 64];
+    __shared__ uint32_t s_cap[V3_NP];
+    static_assert(V3_HN == V2_BLOCK, "one thread per hash slot");
+    const uint32_t tid = threadIdx.x;
+    const uint32_t claim = g_aux[AUX_CLAIM + tid];
+    uint32_t name = 0, cnt = 0, want = 0, mean = 32768u;
+    if (claim) {
+        name = claim & 0xffffu;
+        cnt = g_cnt[name];
+        const uint32_t mn = 65535u - g_mninv[name], mx = g_mx[name];
+        mean = (uint32_t)(g_sum[name] / cnt);
+        const uint32_t w = (((mx - mn + 1u) * 3u / 4u) + 63u) & ~63u; // as k_survey_plan: 3/4 of the sampled span
+        want = w < 64u ? 64u : w;
+    }
+    const uint32_t pc = tid < V3_NP ? g_aux[AUX_PC + tid] : 0u;
+    uint32_t total_cnt, dummy;
+    block_sum2(pc, 0, s_a, s_b, total_cnt, dummy);
+    const uint32_t big = total_cnt / 64u;
+    if (want) {
+        const uint32_t cap = cnt >= big ? 512u : 256u;
+        if (want > cap) want = cap;
+    }
+    uint32_t flo = 15, fhi = (1u << 21) + 1;
+    if (cells < 64) flo = fhi - 1;
+    while (fhi - flo > 1) {
+        const uint32_t mid = flo + (fhi - flo) / 2;
+        const bool in = want && cnt >= mid;
+        uint32_t tw, tn;
+        block_sum2(in ? want + 1u : 0u, in ? 1u : 0u, s_a, s_b, tw, tn);
+        if (tw <= cells && tn <= V2_MAX_SLOTS) fhi = mid; else flo = mid;
+    }
+    const uint32_t tau = fhi;
+    const bool hot = want && cnt >= tau;
+    const uint32_t sw = hot ? want + 1u : 0u, sn = hot ? 1u : 0u;
+    uint32_t incw = sw, incn = sn;
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t yw = __shfl_up(incw, d, 64), yn = __shfl_up(incn, d, 64);
+        if ((int)lane >= d) { incw += yw; incn += yn; }
+    }
+    __syncthreads();
+    if (lane == 63) { s_a[wave] = incw; s_b[wave] = incn; }
+    __syncthreads();
+    uint32_t basew = 0, basen = 0, totw = 0, totn = 0;
+#pragma unroll
+    for (int w = 0; w < V2_BLOCK / 64; w++) {
+        if (w < (int)wave) { basew += s_a[w]; basen += s_b[w]; }
+        totw += s_a[w];
+        totn += s_b[w];
+    }
+    const uint32_t cellpos = basew + incw - sw, slot = basen + incn - sn;
+    uint32_t hot_cnt_total, dummy2;
+    block_sum2(hot ? cnt : 0u, 0, s_a, s_b, hot_cnt_total, dummy2);
+    pu2_t e = (pu2_t){0xffffffffu, 0u};
+    if (hot) {
+        uint32_t o = mean > want / 2 ? mean - want / 2 : 0u;
+        if (o > 65536u - want) o = 65536u - want;
+        e = (pu2_t){name | (want << 20), cellpos | (o << 16)};
+        g_hs[slot] = (pu4_t){name, o | (want << 16), cellpos, 0u};
+    }
+    g_hk[tid] = e;
+    // level-1 regions: 1.5 x the partition's expected records per tile + 24 (leftover < 16 and some air), the
+    // names' TOTAL counts (hot samples included: a mispredicted hot window must not overflow a region)
+    uint32_t cap = 0;
+    if (tid < V3_NP) {
+        const uint32_t est = total_cnt ? (uint32_t)(((unsigned long long)pc * tile) / total_cnt) : tile / V3_NP;
+        cap = (est * 6u / 4u + 24u + 3u) & ~3u;
+        if (cap > tile + 16u) cap = tile + 16u;
+        s_cap[tid] = cap;
+    }
+    __syncthreads();
+    if (tid < V3_NP) {
+        uint32_t base = 0;
+        for (uint32_t i = 0; i < tid; i++) base += s_cap[i];
+        g_pt[tid] = (pu2_t){base, cap};
+    }
+    if (tid == 0) {
+        hdr[0] = totn;
+        hdr[1] = totw;
+        hdr[2] = total_cnt;
+        hdr[3] = hot_cnt_total;
+        // the smallest window (as log2, 10 .. 13) that covers the span of 95 % of the sampled mass with 1/8 to spare
+        uint32_t mass = 0, lw = 10;
+        for (uint32_t k = 0; k <= 16; k++) mass += g_aux[AUX_CLS + k];
+        uint32_t run = 0;
+        for (uint32_t k = 0; k <= 16; k++) {
+            run += g_aux[AUX_CLS + k];
+            if ((unsigned long long)run * 20u >= (unsigned long long)mass * 19u) { lw = k; break; }
+        }
+        // class k holds spans in (2^(k-1), 2^k]: such a name wants a window of 2^k bins, and one class more when the
+        // sample is small (the span of a few dozen samples underestimates the name's real span)
+        lw = lw < 10u ? 10u : (lw > 13u ? 13u : lw);
+        hdr[4] = lw;
+        if (span_out && mass) __hip_atomic_store(span_out, lw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// One workgroup per level-1 partition p, thread l = old local name (id = l << 8 | p).  Ranks the partition's names by
+// sampled count (ties by l, so that names beyond nmetrics rank last) and lays out the level-2 regions of the partition:
+//   g_remap[p * 256 + l] = rank, g_inv[p * 256 + rank] = l
+//   g_pt2[p * V3_MAX_NS + s] = {first record of fine partition s's region (relative to the region area), capacity}
+__global__ __launch_bounds__(256) void k_survey_remap(const uint32_t *__restrict__ g_cnt, uint32_t nmetrics,
+                                                      uint32_t kp, uint32_t log_mpp2, uint32_t ns,
+                                                      uint8_t *__restrict__ g_remap, uint8_t *__restrict__ g_inv,
+                                                      pu2_t *__restrict__ g_pt2)
+{
+    __shared__ uint32_t s_c[256], s_w[V3_MAX_NS], s_cap[V3_MAX_NS];
+    __shared__ uint32_t s_tot;
+    const uint32_t p = blockIdx.x, l = threadIdx.x;
+    const uint32_t m = (l << V3_LOG_NP) | p;
+    const uint32_t c = m < nmetrics ? g_cnt[m] : 0u;
+    s_c[l] = c;
+    if (l < V3_MAX_NS) s_w[l] = 0;
+    if (l == 0) s_tot = 0;
+    __syncthreads();
+    uint32_t rank = 0;
+    for (uint32_t k = 0; k < 256; k++) {
+        const uint32_t ck = s_c[k];
+        rank += (ck > c || (ck == c && k < l)) ? 1u : 0u;
+    }
+    g_remap[p * 256u + l] = (uint8_t)rank;
+    g_inv[p * 256u + rank] = (uint8_t)l;
+    if (c) {
+        // expected share of the records this partition forwards: a name counted in place leaves half of its records
+        // at worst (its window is placed on the same survey)
+        const uint32_t s = rank >> log_mpp2;
+        atomicAdd(&s_w[s < ns ? s : ns - 1u], rank < kp ? (c + 1u) / 2u : c);
+        atomicAdd(&s_tot, c);
+    }
+    __syncthreads();
+    if (l < ns) {
+        const uint32_t tot = s_tot;
+        const uint32_t est = tot ? (uint32_t)(((unsigned long long)s_w[l] * SPLIT_TILE) / tot) : SPLIT_TILE / ns;
+        s_cap[l] = (est * 5u / 4u + 24u + 3u) & ~3u;
+    }
+    __syncthreads();
+    if (l < ns) {
+        uint32_t base = 0;
+        for (uint32_t i = 0; i < l; i++) base += s_cap[i];
+        g_pt2[p * V3_MAX_NS + l] = (pu2_t){base, s_cap[l]};
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Level 1: compress + hashed hot windows + region scatter of 4-byte records
+// Record: partition << 24 | local name (id >> 8) << 16 | bin  (the first generation's format).
+// The kernel handles whole tiles only; the launcher gives the last n % V3_TILE pairs to k_ingest_pairs.
+// ---------------------------------------------------------------------------
+struct Scatter4Lds {
+    uint32_t cnt[V3_NP];                 // records in the partition's region (leftover + this tile's, may exceed cap)
+    uint32_t cfill[V3_NP], cbase[V3_NP]; // open chunk of the partition: records in it, its index
+    pu2_t pt[V3_NP];                     // {region base (LDS word index), capacity in records}
+    uint32_t ov_key[OV_SLOTS], ov_cnt[OV_SLOTS];
+    uint32_t missq[2][V3_MISSQ];
+    uint32_t missn[2];
+    uint32_t dummy[64];
+    uint32_t pool_next, ovn;
+    pu2_t hk[V3_HN];                     // hot-name hash table
+};
+static_assert(sizeof(Scatter4Lds) % 16 == 0, "the regions follow the struct in LDS");
+// upper bound of the sum of the level-1 region capacities (k_survey_plan_h)
+constexpr uint32_t v3_region_words(uint32_t tile) { return 6u * tile / 4u + 28u * V3_NP; }
+
+template <int BATCH>
+__global__ __launch_bounds__(1024, 4) void k_scatter4(const uint32_t *__restrict__ ids, const double *__restrict__ v,
+                                                      size_t ntiles, uint32_t nmetrics, const double *__restrict__ Tx,
+                                                      const pu2_t *__restrict__ g_hk, const pu4_t *__restrict__ g_hs,
+                                                      const uint32_t *__restrict__ g_hdr,
+                                                      const pu2_t *__restrict__ g_pt, uint32_t region_words,
+                                                      uint32_t cells, uint32_t *__restrict__ records,
+                                                      uint32_t *__restrict__ cdesc, uint32_t chunks_per_wg,
+                                                      uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
+                                                      uint32_t *__restrict__ err,
+                                                      unsigned long long *__restrict__ rstat)
+{
+    constexpr int BLOCK = 1024, NPT = V3_NP;
+    static_assert(BLOCK == 4 * NPT, "flush: four threads per partition");
+    static_assert(BLOCK * V2_SPT == (int)V3_TILE, "eight samples per thread per tile");
+    // ONE LDS allocation: [Scatter4Lds][regions][hot windows]
+    extern __shared__ __attribute__((aligned(16))) unsigned char v3_smem[];
+    Scatter4Lds &L = *reinterpret_cast<Scatter4Lds *>(v3_smem);
+    uint32_t *lds32 = reinterpret_cast<uint32_t *>(v3_smem);
+    constexpr uint32_t REG_W = sizeof(Scatter4Lds) / 4;                 // word offset of the regions
+    const uint32_t win_w = REG_W + region_words;                        // word offset of the hot windows
+    uint32_t *win = lds32 + win_w;                                      // [cells]
+    constexpr uint32_t CNT_W = offsetof(Scatter4Lds, cnt) / 4, DUMMY_W = offsetof(Scatter4Lds, dummy) / 4;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t pool_base = blockIdx.x * chunks_per_wg;
+
+    for (uint32_t i = tid; i < V3_HN; i += BLOCK) {
+        pu2_t e = g_hk[i];
+        e.y += win_w; // hot base as a word offset from the LDS base (< 40 960: fits the low half)
+        L.hk[i] = e;
+    }
+    for (uint32_t i = tid; i < cells; i += BLOCK) win[i] = 0;
+    if (tid < NPT) {
+        pu2_t e = g_pt[tid];
+        e.x += REG_W;
+        L.pt[tid] = e;
+        L.cnt[tid] = 0;
+        L.cfill[tid] = CHUNK;
+        L.cbase[tid] = INVALID;
+    }
+    ov_init(L.ov_key, L.ov_cnt, tid, BLOCK);
+    if (tid == 0) { L.pool_next = 0; L.ovn = 0; L.missn[0] = 0; L.missn[1] = 0; }
+    __syncthreads();
+    const pu2_t my_pt = L.pt[tid >> 2]; // the flush phase's partition (constant over the launch)
+
+    const pd2_t *vp = reinterpret_cast<const pd2_t *>(v);
+    const pu2_t *ip = reinterpret_cast<const pu2_t *>(ids);
+    constexpr int NPAIR = V2_SPT / 2;
+    // two register sets used by alternate tiles, loads issued a whole tile period ahead, the loop's global stores
+    // hidden from the compiler's s_waitcnt bookkeeping: see k_scatter2 in lh_kernels_part2.h
+    pu2_t ida[NPAIR], idb[NPAIR];
+    pd2_t vaa[NPAIR], vab[NPAIR];
+    auto load_tile = [&](size_t tile, pu2_t (&di)[NPAIR], pd2_t (&dv)[NPAIR]) {
+        if (tile >= ntiles) tile = ntiles - 1; // the two tiles past the end that the pipeline touches (uniform)
+        const pu2_t *it = ip + tile * (V3_TILE / 2) + tid;
+        const pd2_t *vt = vp + tile * (V3_TILE / 2) + tid;
+#pragma unroll
+        for (int j = 0; j < NPAIR; j++) {
+            di[j] = __builtin_nontemporal_load(it + j * BLOCK);
+            dv[j] = __builtin_nontemporal_load(vt + j * BLOCK);
+        }
+    };
+    load_tile(blockIdx.x, ida, vaa);
+    asm volatile("" : "+v"(ida[0]), "+v"(ida[1]), "+v"(ida[2]), "+v"(ida[3]), "+v"(vaa[0]), "+v"(vaa[1]), "+v"(vaa[2]),
+                      "+v"(vaa[3]));
+    static_assert(NPAIR == 4, "the asm above names four register pairs");
+    load_tile((size_t)blockIdx.x + gridDim.x, idb, vab);
+
+    auto classify = [&](pu2_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
+        uint32_t rare = 0;
+        // ---- phase 1: classify and place.  Straight-line code, BATCH samples at a time: their table reads, then
+        // their LDS atomics, then their record stores are in flight together.
+#pragma unroll
+        for (int h = 0; h < V2_SPT; h += BATCH) {
+            uint32_t id[BATCH], bin[BATCH], where[BATCH], rank[BATCH], rec[BATCH];
+            pu2_t he[BATCH], pe[BATCH];
+            uint32_t unc = 0, coldm = 0, full = 0;
+#pragma unroll
+            for (int k = 0; k < BATCH; k++) {
+                const int j = h + k;
+                const uint32_t raw = (j & 1) ? idv[j >> 1].y : idv[j >> 1].x;
+                const bool ok = raw < nmetrics; // an id >= nmetrics is reported, the sample skipped
+                rare |= ok ? 0u : 1u;
+                id[k] = ok ? raw : INVALID;
+                he[k] = L.hk[v3_hash(raw)];
+                pe[k] = L.pt[raw & (NPT - 1u)];
+            }
+#pragma unroll
+            for (int k = 0; k < BATCH; k++) {
+                const int j = h + k;
+                bool u;
+                bin[k] = lh_bin_fast((j & 1) ? val[j >> 1].y : val[j >> 1].x, u);
+                if (u) unc |= 1u << k;
+            }
+            if (unc) { // inside the guard band of a bucket threshold (1 sample in ~4 000): exact table compare
+#pragma unroll
+                for (int k = 0; k < BATCH; k++) {
+                    const int j = h + k;
+                    if (unc & (1u << k)) bin[k] = lh_bin_of((j & 1) ? val[j >> 1].y : val[j >> 1].x, Tx);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < BATCH; k++) {
+                const bool valid = id[k] != INVALID;
+                const uint32_t hrel = bin[k] - (he[k].y >> 16);
+                const bool hot = valid && (he[k].x & 0xfffffu) == id[k] && hrel < (he[k].x >> 20);
+                const bool cold = valid && !hot;
+                const uint32_t p = id[k] & (NPT - 1u);
+                where[k] = hot ? (he[k].y & 0xffffu) + hrel : cold ? CNT_W + p : DUMMY_W + lane;
+                rec[k] = (p << 24) | (((id[k] >> V3_LOG_NP) & 0xffu) << 16) | bin[k];
+                if (cold) coldm |= 1u << k;
+            }
+#pragma unroll
+            for (int k = 0; k < BATCH; k++) rank[k] = atomicAdd(lds32 + where[k], 1u);
+#pragma unroll
+            for (int k = 0; k < BATCH; k++) {
+                const bool fits = (coldm & (1u << k)) && rank[k] < pe[k].y;
+                if ((coldm & (1u << k)) && !fits) full |= 1u << k; // the region is full: counted exactly below
+                lds32[fits ? pe[k].x + rank[k] : DUMMY_W + lane] = rec[k];
+            }
+            if (full) { // no room: queued, counted exactly by the flush phase
+                atomicAdd(&L.ovn, (uint32_t)__popc(full));
+#pragma unroll
+                for (int k = 0; k < BATCH; k++)
+                    if (full & (1u << k)) {
+                        const uint32_t key = (id[k] << 16) | bin[k];
+                        const uint32_t at = atomicAdd(&L.missn[par], 1u);
+                        if (at < V3_MISSQ) L.missq[par][at] = key;
+                        else if (!ov_add(L.ov_key, L.ov_cnt, key, 1u)) v2_global_add(counts, ranges, id[k], bin[k], 1);
+                    }
+            }
+        }
+        if (rare) atomicOr(err, 1u); // an id >= nmetrics: reported by lh_sync / lh_extract
+    };
+    auto flush = [&](const uint32_t par) {
+        __syncthreads();                                   // barrier A: the tile's records are in the regions
+        // ---- phase 2: four threads per partition (p = tid / 4; thread q copies 16-byte piece q of every line)
+        if (tid == BLOCK - 1) L.missn[par ^ 1u] = 0; // the other parity's queue was drained in the previous tile
+        {
+            uint32_t t2 = tid;
+            asm volatile("" : "+v"(t2)); // keeps this phase's address arithmetic inside the loop (see k_scatter2)
+            const uint32_t p = t2 >> 2, q = t2 & 3u;
+            const pu2_t e = my_pt;
+            const uint32_t c = min(L.cnt[p], e.y), full = c / LINE4, left = c % LINE4;
+            if (full) {
+                const uint32_t cf = L.cfill[p], cb = L.cbase[p];
+                const uint32_t room = (CHUNK - cf) / LINE4; // lines left in the open chunk (0: none open)
+                uint32_t first = 0;
+                if (full > room && q == 0) {
+                    const uint32_t tag = p << CD_SHIFT;
+                    const uint32_t over = full - room;
+                    const uint32_t k = (over + CHUNK / LINE4 - 1) / (CHUNK / LINE4);
+                    first = pool_base + atomicAdd(&L.pool_next, k);   // k consecutive chunks
+                    if (cb != INVALID) hidden_store_u32(cdesc + cb, tag | CHUNK);   // the old chunk is now full
+#pragma nounroll
+                    for (uint32_t i = 0; i + 1 < k; i++) hidden_store_u32(cdesc + first + i, tag | CHUNK);
+                    L.cbase[p] = first + k - 1;
+                    L.cfill[p] = (over - (k - 1) * (CHUNK / LINE4)) * LINE4;
+                } else if (q == 0) {
+                    L.cfill[p] = cf + full * LINE4;
+                }
+                first = __builtin_amdgcn_mov_dpp(first, 0x00, 0xf, 0xf, false); // quad_perm [0,0,0,0]: q == 0's value
+                const uint32_t dA = cb * CHUNK + cf, dB = first * CHUNK - room * LINE4;
+                const uint32_t *src = lds32 + e.x;
+#pragma nounroll
+                for (uint32_t l = 0; l < full; l++) {
+                    const uint32_t dst = (l < room ? dA : dB) + l * LINE4;
+                    const pu4_t r4 = *reinterpret_cast<const pu4_t *>(src + l * LINE4 + q * 4);
+                    hidden_store_u4(records + dst + q * 4, r4);
+                }
+                // the last partial line moves to the front of the region (its slots are this thread's own)
+                if (q * 4 < left)
+                    *reinterpret_cast<pu4_t *>(lds32 + e.x + q * 4) =
+                        *reinterpret_cast<const pu4_t *>(src + full * LINE4 + q * 4);
+            }
+            if (q == 0) L.cnt[p] = left;
+        }
+        // the tile's overflowed records, one per thread: aggregated in the small LDS table, else a global atomic
+        {
+            const uint32_t nq = min(L.missn[par], V3_MISSQ);
+            for (uint32_t i = tid; i < nq; i += BLOCK) {
+                const uint32_t key = L.missq[par][i];
+                if (!ov_add(L.ov_key, L.ov_cnt, key, 1u)) v2_global_add(counts, ranges, key >> 16, key & 0xffffu, 1);
+            }
+        }
+        __syncthreads();                                   // barrier B: counters and regions are ready for the next tile
+    };
+    uint32_t par = 0;
+    for (size_t tile = blockIdx.x; tile < ntiles; tile += 2 * (size_t)gridDim.x) {
+        classify(ida, vaa, par);
+        load_tile(tile + 2 * (size_t)gridDim.x, ida, vaa);
+        flush(par);
+        par ^= 1u;
+        if (tile + gridDim.x < ntiles) { // workgroup-uniform
+            classify(idb, vab, par);
+            load_tile(tile + 3 * (size_t)gridDim.x, idb, vab);
+        }
+        flush(par); // (without a second tile: finds nothing new, harmless)
+        par ^= 1u;
+    }
+
+    // ---- drain: the regions' leftovers (< one line each) and the open chunks' descriptors
+    {
+        const uint32_t p = tid >> 2, q = tid & 3u;
+        const uint32_t left = L.cnt[p]; // < LINE4 after a flush
+        uint32_t d = INVALID;
+        if (left && q == 0) {
+            uint32_t cf = L.cfill[p], cb = L.cbase[p];
+            if (cf == CHUNK) { // no open chunk, or it is exactly full
+                if (cb != INVALID) cdesc[cb] = (p << CD_SHIFT) | CHUNK;
+                cb = pool_base + atomicAdd(&L.pool_next, 1u);
+                cf = 0;
+                L.cbase[p] = cb;
+            }
+            d = cb * CHUNK + cf;
+            L.cfill[p] = cf + left;
+        }
+        d = __builtin_amdgcn_mov_dpp(d, 0x00, 0xf, 0xf, false);
+        if (left && q * 4 < left)
+            *reinterpret_cast<pu4_t *>(records + d + q * 4) = *reinterpret_cast<const pu4_t *>(lds32 + L.pt[p].x + q * 4);
+    }
+    __syncthreads();
+    if (tid < NPT && L.cbase[tid] != INVALID) cdesc[L.cbase[tid]] = (tid << CD_SHIFT) | L.cfill[tid];
+    // the engine watches this count (pinned host memory): a stream whose tiles overflow the regions is clustered by
+    // name, and later calls take the first-generation (exact-layout) scatter instead
+    if (tid == 0 && L.ovn && rstat)
+        __hip_atomic_fetch_add(rstat, (unsigned long long)L.ovn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+
+    // ---- flush the hot windows (one uint64 atomic per occupied bin) and the overflow table
+    const uint32_t nhot = g_hdr[0];
+    for (uint32_t s = wave; s < nhot; s += BLOCK / 64) {
+        const pu4_t h = g_hs[s];
+        const uint32_t name = h.x, org = h.y & 0xffffu, width = h.y >> 16, base = h.z;
+        uint32_t mn = INVALID, mx = 0;
+        for (uint32_t i = lane; i < width; i += 64) {
+            const uint32_t c = win[base + i];
+            if (c) {
+                const uint32_t b = org + i;
+                atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)name * LH_NKEYS + b]),
+                          (unsigned long long)c);
+                mn = min(mn, b);
+                mx = max(mx, b);
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            mn = min(mn, (uint32_t)__shfl_xor(mn, d, 64));
+            mx = max(mx, (uint32_t)__shfl_xor(mx, d, 64));
+        }
+        if (lane == 0 && mn != INVALID) {
+            uint32_t *r = ranges + 2 * (size_t)name;
+            if (mn < r[0]) atomicMin(&r[0], mn);
+            if (mx > r[1]) atomicMax(&r[1], mx);
+        }
+    }
+    for (uint32_t i = tid; i < OV_SLOTS; i += BLOCK)
+        if (L.ov_key[i] != OV_EMPTY) v2_global_add(counts, ranges, L.ov_key[i] >> 16, L.ov_key[i] & 0xffffu, L.ov_cnt[i]);
+}
+
+// ---------------------------------------------------------------------------
+// Window placement shared by level 2 and the reduce pass: the union of what the survey saw of the name and of what
+// the slot's first chunk holds; centred on the span when it fits, on the survey's mean bin otherwise.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t v3_place(uint32_t mn, uint32_t mx, uint32_t sv_cnt, uint32_t sv_mean, uint32_t W)
+{
+    uint32_t centre = 32768u; // nothing known about the name: key 0
+    if (mn != INVALID) centre = (mx - mn < W || !sv_cnt) ? (mn + mx + 1u) >> 1 : sv_mean;
+    uint32_t org = centre > W / 2 ? centre - W / 2 : 0u;
+    if (org > 65536u - W) org = 65536u - W;
+    return org;
+}
+
+// ---------------------------------------------------------------------------
+// Level 2: one workgroup per level-1 work slot (all records of one partition p1).
+//   tbl[old local] = rank | window origin << 8   (rank: k_survey_remap)
+//   rank < kp            counted here: LDS window rank x W (the record ends in this pass)
+//   otherwise / outside  4-byte record  fine << 24 | rank % mpp2 << 16 | bin  into fine partition rank / mpp2
+// Output chunk tag q = fine << 8 | p1.
+// ---------------------------------------------------------------------------
+struct SplitLds {
+    uint32_t cnt[V3_MAX_NS], cfill[V3_MAX_NS], cbase[V3_MAX_NS];
+    pu2_t pt[V3_MAX_NS];
+    uint32_t ov_key[OV_SLOTS], ov_cnt[OV_SLOTS];
+    uint32_t missq[2][V3_MISSQ];
+    uint32_t missn[2];
+    uint32_t dummy[64];
+    uint32_t pool_next, pad0;
+    uint32_t tbl[256];
+    uint32_t name[32], mn[32], mx[32], svc[32], svm[32], org[32]; // the names counted here
+};
+static_assert(sizeof(SplitLds) % 16 == 0, "the regions follow the struct in LDS");
+constexpr size_t SPLIT_LDS_BYTES = sizeof(SplitLds) + (size_t)(SPLIT_REG_WORDS + PEEL_WORDS) * 4;
+static_assert(SPLIT_LDS_BYTES <= 160 * 1024, "level 2 must fit one CU's LDS");
+static_assert(5 * SPLIT_TILE / 4 + 28 * V3_MAX_NS <= SPLIT_REG_WORDS, "k_survey_remap's capacities fit the region area");
+
+__global__ __launch_bounds__(1024, 4) void k_split_records(const uint32_t *__restrict__ in_records,
+                                                           const uint32_t *__restrict__ in_cdesc,
+                                                           const uint32_t *__restrict__ in_sorted,
+                                                           const uint32_t *__restrict__ in_part_start,
+                                                           const uint32_t *__restrict__ in_slots,
+                                                           const uint32_t *__restrict__ in_nslots,
+                                                           const uint32_t *__restrict__ pool_start, uint32_t nmetrics,
+                                                           uint32_t kp, uint32_t log_mpp2, uint32_t log_w, uint32_t ns,
+                                                           const uint8_t *__restrict__ g_remap,
+                                                           const uint8_t *__restrict__ g_inv,
+                                                           const pu2_t *__restrict__ g_pt2,
+                                                           const uint32_t *__restrict__ g_cnt,
+                                                           const uint32_t *__restrict__ g_mninv,
+                                                           const uint32_t *__restrict__ g_mx,
+                                                           const unsigned long long *__restrict__ g_sum,
+                                                           uint32_t *__restrict__ records, uint32_t *__restrict__ cdesc,
+                                                           uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
+                                                           uint32_t dbg_arg)
+{
+    const uint32_t dbg = LH_DBG(dbg_arg);
+    constexpr int BLOCK = 1024;
+    extern __shared__ __attribute__((aligned(16))) unsigned char v3_smem[];
+    SplitLds &L = *reinterpret_cast<SplitLds *>(v3_smem);
+    uint32_t *lds32 = reinterpret_cast<uint32_t *>(v3_smem);
+    constexpr uint32_t REG_W = sizeof(SplitLds) / 4, WIN_W = REG_W + SPLIT_REG_WORDS;
+    constexpr uint32_t CNT_W = offsetof(SplitLds, cnt) / 4, DUMMY_W = offsetof(SplitLds, dummy) / 4;
+    uint32_t *win = lds32 + WIN_W;
+    const uint32_t slot = blockIdx.x;
+    if (slot >= *in_nslots) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t p1 = in_slots[3 * slot], first = in_slots[3 * slot + 1], cnt = in_slots[3 * slot + 2];
+    const uint32_t *list = in_sorted + in_part_start[p1] + first;
+    const uint32_t pool_base = pool_start[slot];
+    const uint32_t W = 1u << log_w, mmask = (1u << log_mpp2) - 1u;
+
+    // ---- setup: the partition's rank table, the survey's view of the names counted here, the slot's first chunk
+    const uint32_t c0 = list[0];
+    const uint32_t n0 = in_cdesc[c0] & CD_MASK;
+    const uint32_t srec = tid < n0 ? in_records[(size_t)c0 * CHUNK + tid] : 0u;
+    if (tid < 256) L.tbl[tid] = g_remap[p1 * 256u + tid];
+    if (tid < 32) {
+        uint32_t name = INVALID, mn = INVALID, mx = 0, svc = 0, svm = 0;
+        if (tid < kp) {
+            const uint32_t m = ((uint32_t)g_inv[p1 * 256u + tid] << V3_LOG_NP) | p1;
+            if (m < nmetrics) {
+                name = m;
+                svc = g_cnt[m];
+                if (svc) {
+                    mn = 65535u - g_mninv[m];
+                    mx = g_mx[m];
+                    svm = (uint32_t)(g_sum[m] / svc);
+                }
+            }
+        }
+        L.name[tid] = name;
+        L.mn[tid] = mn;
+        L.mx[tid] = mx;
+        L.svc[tid] = svc;
+        L.svm[tid] = svm;
+    }
+    for (uint32_t i = tid; i < kp << log_w; i += BLOCK) win[i] = 0;
+    if (tid < V3_MAX_NS) {
+        pu2_t e = tid < ns ? g_pt2[p1 * V3_MAX_NS + tid] : (pu2_t){0u, 0u};
+        e.x += REG_W;
+        L.pt[tid] = e;
+        L.cnt[tid] = 0;
+        L.cfill[tid] = CHUNK;
+        L.cbase[tid] = INVALID;
+    }
+    ov_init(L.ov_key, L.ov_cnt, tid, BLOCK);
+    if (tid == 0) { L.pool_next = 0; L.missn[0] = 0; L.missn[1] = 0; }
+    __syncthreads();
+    if (tid < n0) {
+        const uint32_t r = L.tbl[(srec >> 16) & 0xffu], b = srec & 0xffffu;
+        if (r < kp) {
+            if (b < L.mn[r]) atomicMin(&L.mn[r], b);
+            if (b > L.mx[r]) atomicMax(&L.mx[r], b);
+        }
+    }
+    __syncthreads();
+    if (tid < 32) L.org[tid] = v3_place(L.mn[tid], L.mx[tid], L.svc[tid], L.svm[tid], W);
+    __syncthreads();
+    if (tid < 256) {
+        const uint32_t r = L.tbl[tid];
+        L.tbl[tid] = r | ((r < kp ? L.org[r] : 0u) << 8);
+    }
+    __syncthreads();
+
+    // ---- main loop: tiles of 8 chunks (8 192 records), two 16-byte loads per thread, two register sets
+    constexpr uint32_t CPT = SPLIT_TILE / CHUNK;
+    const uint32_t ntiles = (cnt + CPT - 1) / CPT;
+    pu4_t ra[2], rb[2];
+    uint32_t cna[2], cnb[2]; // records of the chunk each load came from
+    // The chunk a load reads comes out of two dependent loads (slot list -> descriptor).  Issued per tile they would
+    // stall every wave of the workgroup at the same point; instead lane l of a wave holds them for tile tb + l / 2, load
+    // l % 2, fetched 32 tiles at a time (tiles are requested in increasing order).
+    uint32_t my_cid = 0, my_cn = 0, batch = 0xffffffffu;
+    auto load_tile = [&](uint32_t tile, pu4_t (&r)[2], uint32_t (&cn)[2]) {
+        if ((tile >> 5) != batch) { // workgroup-uniform
+            batch = tile >> 5;
+            const uint32_t t = (batch << 5) + (lane >> 1);
+            uint32_t ci = t * CPT + (lane & 1u) * 4u + (wave >> 2); // 256 threads (4 waves) per chunk
+            const bool in = t < ntiles && ci < cnt;
+            ci = in ? ci : 0u;
+            my_cid = list[ci];
+            my_cn = in ? (in_cdesc[my_cid] & CD_MASK) : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const uint32_t idx = (tile & 31u) * 2u + (uint32_t)j;
+            const uint32_t cid = __builtin_amdgcn_readlane(my_cid, idx);
+            cn[j] = __builtin_amdgcn_readlane(my_cn, idx);
+            r[j] = __builtin_nontemporal_load(reinterpret_cast<const pu4_t *>(in_records + (size_t)cid * CHUNK) + (tid & 255u));
+        }
+    };
+    auto classify = [&](const pu4_t (&r)[2], const uint32_t (&cn)[2], const uint32_t par) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const uint32_t rr[4] = {r[j].x, r[j].y, r[j].z, r[j].w};
+            uint32_t t[4], where[4], rank[4], rec[4];
+            pu2_t pe[4];
+            uint32_t fwd = 0, full = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) t[k] = L.tbl[(rr[k] >> 16) & 0xffu];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool valid = (tid & 255u) * 4u + (uint32_t)k < cn[j];
+                const uint32_t nw = t[k] & 0xffu, bin = rr[k] & 0xffffu, rel = bin - (t[k] >> 8);
+                const bool here = valid && nw < kp && rel < W;
+                const uint32_t fine = nw >> log_mpp2;
+                where[k] = here ? WIN_W + (nw << log_w) + rel : valid ? CNT_W + fine : DUMMY_W + lane;
+                rec[k] = (fine << 24) | ((nw & mmask) << 16) | bin;
+                pe[k] = L.pt[fine];
+                if (valid && !here) fwd |= 1u << k;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) rank[k] = atomicAdd(lds32 + where[k], 1u);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool fits = (fwd & (1u << k)) && rank[k] < pe[k].y;
+                if ((fwd & (1u << k)) && !fits) full |= 1u << k;
+                lds32[fits ? pe[k].x + rank[k] : DUMMY_W + lane] = rec[k];
+            }
+            if (full) { // the fine partition's region is full: the record is counted exactly by the flush phase
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (full & (1u << k)) {
+                        const uint32_t old = (rr[k] >> 16) & 0xffu, bin = rr[k] & 0xffffu;
+                        const uint32_t key = (((old << V3_LOG_NP) | p1) << 16) | bin;
+                        const uint32_t at = atomicAdd(&L.missn[par], 1u);
+                        if (at < V3_MISSQ) L.missq[par][at] = key;
+                        else if (!ov_add(L.ov_key, L.ov_cnt, key, 1u))
+                            v2_global_add(counts, ranges, key >> 16, bin, 1);
+                    }
+            }
+        }
+    };
+    // one wave per fine partition: 16 lines (64 lanes x 16 bytes) per step
+    auto flush = [&](const uint32_t par) {
+        __syncthreads();
+        if (tid == BLOCK - 1) L.missn[par ^ 1u] = 0;
+        for (uint32_t s = wave; s < ns; s += BLOCK / 64) {
+            const pu2_t e = L.pt[s];
+            const uint32_t c = min(L.cnt[s], e.y), full = c / LINE4, left = c % LINE4;
+            if (full) { // wave-uniform
+                const uint32_t cf = L.cfill[s], cb = L.cbase[s];
+                const uint32_t room = (CHUNK - cf) / LINE4;
+                uint32_t firstc = 0;
+                if (full > room) {
+                    const uint32_t tag = ((s << V3_LOG_NP) | p1) << CD_SHIFT;
+                    const uint32_t over = full - room;
+                    const uint32_t k = (over + CHUNK / LINE4 - 1) / (CHUNK / LINE4);
+                    if (lane == 0) {
+                        firstc = pool_base + atomicAdd(&L.pool_next, k);
+                        if (cb != INVALID) hidden_store_u32(cdesc + cb, tag | CHUNK);
+#pragma nounroll
+                        for (uint32_t i = 0; i + 1 < k; i++) hidden_store_u32(cdesc + firstc + i, tag | CHUNK);
+                        L.cbase[s] = firstc + k - 1;
+                        L.cfill[s] = (over - (k - 1) * (CHUNK / LINE4)) * LINE4;
+                    }
+                    firstc = __builtin_amdgcn_readfirstlane(firstc);
+                } else if (lane == 0) {
+                    L.cfill[s] = cf + full * LINE4;
+                }
+                const uint32_t dA = cb * CHUNK + cf, dB = firstc * CHUNK - room * LINE4;
+                const uint32_t *src = lds32 + e.x;
+                const uint32_t q = lane & 3u;
+#pragma nounroll
+                for (uint32_t l = lane >> 2; l < full; l += 16) {
+                    const uint32_t dst = (l < room ? dA : dB) + l * LINE4;
+                    const pu4_t r4 = *reinterpret_cast<const pu4_t *>(src + l * LINE4 + q * 4);
+                    hidden_store_u4(records + dst + q * 4, r4);
+                }
+                // the last partial line moves to the front (LDS operations of one wave execute in order: the reads of
+                // line 0 above are done)
+                if (lane < 4 && lane * 4 < left)
+                    *reinterpret_cast<pu4_t *>(lds32 + e.x + lane * 4) =
+                        *reinterpret_cast<const pu4_t *>(src + full * LINE4 + lane * 4);
+            }
+            if (lane == 0) L.cnt[s] = left;
+        }
+        {
+            const uint32_t nq = min(L.missn[par], V3_MISSQ);
+            for (uint32_t i = tid; i < nq; i += BLOCK) {
+                const uint32_t key = L.missq[par][i];
+                if (!ov_add(L.ov_key, L.ov_cnt, key, 1u)) v2_global_add(counts, ranges, key >> 16, key & 0xffffu, 1);
+            }
+        }
+        __syncthreads();
+    };
+    load_tile(0, ra, cna);
+    asm volatile("" : "+v"(ra[0]), "+v"(ra[1]));
+    load_tile(1, rb, cnb);
+    uint32_t par = 0;
+    for (uint32_t tile = 0; tile < ((dbg & 1u) ? 0u : ntiles); tile += 2) {
+        if (!(dbg & 8u)) classify(ra, cna, par);
+        load_tile(tile + 2, ra, cna);
+        if (!(dbg & 4u)) flush(par);
+        par ^= 1u;
+        if (tile + 1 < ntiles) {
+            if (!(dbg & 8u)) classify(rb, cnb, par);
+            load_tile(tile + 3, rb, cnb);
+            if (!(dbg & 4u)) flush(par);
+            par ^= 1u;
+        }
+    }
+    if (dbg & 2u) return;
+
+    // ---- drain: leftovers (< one line per fine partition) and the open chunks' descriptors
+    if (tid < ns) {
+        const uint32_t s = tid, left = L.cnt[s];
+        if (left) {
+            uint32_t cf = L.cfill[s], cb = L.cbase[s];
+            const uint32_t tag = ((s << V3_LOG_NP) | p1) << CD_SHIFT;
+            if (cf == CHUNK) {
+                if (cb != INVALID) cdesc[cb] = tag | CHUNK;
+                cb = pool_base + atomicAdd(&L.pool_next, 1u);
+                cf = 0;
+                L.cbase[s] = cb;
+            }
+            const uint32_t *src = lds32 + L.pt[s].x;
+            for (uint32_t i = 0; i < left; i++) records[(size_t)cb * CHUNK + cf + i] = src[i];
+            L.cfill[s] = cf + left;
+        }
+    }
+    __syncthreads();
+    if (tid < ns && L.cbase[tid] != INVALID) cdesc[L.cbase[tid]] = (((tid << V3_LOG_NP) | p1) << CD_SHIFT) | L.cfill[tid];
+
+    // ---- flush the windows of the names counted here and the overflow table
+    for (uint32_t r = wave; r < kp; r += BLOCK / 64) {
+        const uint32_t name = L.name[r];
+        if (name == INVALID) continue;
+        const uint32_t org = L.org[r];
+        uint32_t mn = INVALID, mx = 0;
+        for (uint32_t i = lane; i < W; i += 64) {
+            const uint32_t c = win[(r << log_w) + i];
+            if (c) {
+                const uint32_t b = org + i;
+                atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)name * LH_NKEYS + b]),
+                          (unsigned long long)c);
+                mn = min(mn, b);
+                mx = max(mx, b);
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            mn = min(mn, (uint32_t)__shfl_xor(mn, d, 64));
+            mx = max(mx, (uint32_t)__shfl_xor(mx, d, 64));
+        }
+        if (lane == 0 && mn != INVALID) {
+            uint32_t *rg = ranges + 2 * (size_t)name;
+            if (mn < rg[0]) atomicMin(&rg[0], mn);
+            if (mx > rg[1]) atomicMax(&rg[1], mx);
+        }
+    }
+    for (uint32_t i = tid; i < OV_SLOTS; i += BLOCK)
+        if (L.ov_key[i] != OV_EMPTY) v2_global_add(counts, ranges, L.ov_key[i] >> 16, L.ov_key[i] & 0xffffu, L.ov_cnt[i]);
+}
+
+// ---------------------------------------------------------------------------
+// Reduce: one workgroup per fine-partition work slot.  Fine partition q = fine << 8 | p1 holds the names of ranks
+// fine * mpp2 .. + mpp2 - 1 of level-1 partition p1; record = fine << 24 | rank % mpp2 << 16 | bin.
+// ---------------------------------------------------------------------------
+constexpr size_t P3_LDS_BYTES = (P3_WINWORDS + 6 * 32 + 2 * OV_SLOTS) * sizeof(uint32_t) + 16;
+
+__global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restrict__ records,
+                                                         const uint32_t *__restrict__ cdesc,
+                                                         const uint32_t *__restrict__ sorted,
+                                                         const uint32_t *__restrict__ part_start,
+                                                         const uint32_t *__restrict__ slots,
+                                                         const uint32_t *__restrict__ nslots, uint32_t nmetrics,
+                                                         uint32_t log_mpp2, uint32_t log_w,
+                                                         const uint8_t *__restrict__ g_inv,
+                                                         const uint32_t *__restrict__ g_cnt,
+                                                         const uint32_t *__restrict__ g_mninv,
+                                                         const uint32_t *__restrict__ g_mx,
+                                                         const unsigned long long *__restrict__ g_sum,
+                                                         uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *h = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *s_org = h + P3_WINWORDS, *s_mn = s_org + 32, *s_mx = s_mn + 32, *s_name = s_mx + 32, *s_svc = s_name + 32,
+             *s_svm = s_svc + 32;
+    uint32_t *ov_key = s_svm + 32, *ov_cnt = ov_key + OV_SLOTS;
+    const uint32_t slot = blockIdx.x;
+    if (slot >= *nslots) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t q = slots[3 * slot], first = slots[3 * slot + 1], cnt = slots[3 * slot + 2];
+    const uint32_t p1 = q & (V3_NP - 1u), fine = q >> V3_LOG_NP;
+    const uint32_t *list = sorted + part_start[q] + first;
+    const uint32_t mpp2 = 1u << log_mpp2, W = 1u << log_w, words = mpp2 << log_w;
+
+    const uint32_t c0 = list[0];
+    const uint32_t n0 = cdesc[c0] & CD_MASK;
+    const uint32_t srec = tid < n0 ? records[(size_t)c0 * CHUNK + tid] : 0u;
+    for (uint32_t i = tid; i < words; i += P2_BLOCK) h[i] = 0;
+    ov_init(ov_key, ov_cnt, tid, P2_BLOCK);
+    if (tid < mpp2) {
+        const uint32_t m = ((uint32_t)g_inv[p1 * 256u + (fine << log_mpp2) + tid] << V3_LOG_NP) | p1;
+        uint32_t svc = 0, svm = 0;
+        if (m < nmetrics) {
+            svc = g_cnt[m];
+            if (svc) svm = (uint32_t)(g_sum[m] / svc);
+        }
+        s_name[tid] = m < nmetrics ? m : INVALID;
+        s_svc[tid] = svc;
+        s_svm[tid] = svm;
+        s_mn[tid] = INVALID;
+        s_mx[tid] = 0;
+    }
+    __syncthreads();
+    // windows from the slot's own records (what reaches this pass may be the tail that a level-2 window left over);
+    // a name the first chunk does not hold falls back to what the survey saw of it
+    if (tid < n0) {
+        const uint32_t l = (srec >> 16) & 0xffu, b = srec & 0xffffu;
+        if (b < s_mn[l]) atomicMin(&s_mn[l], b);
+        if (b > s_mx[l]) atomicMax(&s_mx[l], b);
+    }
+    __syncthreads();
+    if (tid < mpp2) {
+        uint32_t mn = s_mn[tid], mx = s_mx[tid];
+        const uint32_t m = s_name[tid];
+        if (mn == INVALID && m != INVALID && s_svc[tid]) {
+            mn = 65535u - g_mninv[m];
+            mx = g_mx[m];
+        }
+        s_org[tid] = v3_place(mn, mx, s_svc[tid], s_svm[tid], W);
+        s_mn[tid] = INVALID; // reused as the flush ranges
+        s_mx[tid] = 0;
+    }
+    __syncthreads();
+
+    auto load_chunk = [&](uint32_t cidx, u4_t (&dst)[CHUNK / 256]) {
+        const u4_t *src = reinterpret_cast<const u4_t *>(records + (size_t)cidx * CHUNK) + lane;
+#pragma unroll
+        for (uint32_t k = 0; k < CHUNK / 256; k++) dst[k] = __builtin_nontemporal_load(src + k * 64);
+    };
+    auto add_one = [&](uint32_t rec, uint32_t c) {
+        const uint32_t l = (rec >> 16) & 0xffu, b = rec & 0xffffu;
+        const uint32_t rel = b - s_org[l];
+        if (rel < W) atomicAdd(&h[(l << log_w) + rel], c);
+        else if (!ov_add(ov_key, ov_cnt, (l << 16) | b, c)) p2_global_add(counts, ranges, s_name[l], b, c);
+    };
+    auto reduce_chunk = [&](const u4_t (&r4)[CHUNK / 256], uint32_t cn) {
+        const bool full = cn == CHUNK; // wave-uniform
+#pragma unroll
+        for (uint32_t k = 0; k < CHUNK / 256; k++) {
+            const uint32_t rr[4] = {r4[k].x, r4[k].y, r4[k].z, r4[k].w};
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                if (full) {
+                    // constant streams: the whole wave carries one record value -> one lane adds 64
+                    const uint32_t f0 = __builtin_amdgcn_readfirstlane(rr[t]);
+                    if (__builtin_amdgcn_ballot_w64(rr[t] != f0) == 0ull) {
+                        if (lane == 0) add_one(rr[t], 64u);
+                    } else {
+                        add_one(rr[t], 1u);
+                    }
+                } else if (k * 256 + lane * 4 + t < cn) {
+                    add_one(rr[t], 1u);
+                }
+            }
+        }
+    };
+    // Each wave walks chunks wave, wave + 16, ...; their indices and descriptors are fetched 64 at a time (lane l holds
+    // the wave's l-th chunk of the batch) and two chunks (8 KiB per wave) are in flight while the older is reduced:
+    // see k_part_hist2.
+    constexpr uint32_t WSTEP = P2_BLOCK / 64, DEPTH = 2;
+    u4_t buf[DEPTH][CHUNK / 256];
+    uint32_t cn[DEPTH];
+    const uint32_t mine = cnt > wave ? (cnt - wave + WSTEP - 1) / WSTEP : 0u; // chunks of this wave
+    for (uint32_t b0 = 0; b0 < mine; b0 += 64) {
+        const uint32_t nb = min(mine - b0, 64u);
+        uint32_t my_cid = 0, my_cn = 0;
+        if (lane < nb) {
+            my_cid = list[wave + (b0 + lane) * WSTEP];
+            my_cn = cdesc[my_cid] & CD_MASK;
+        }
+        auto fetch = [&](uint32_t k, uint32_t at) { // k: position in the batch (wave-uniform)
+            const uint32_t kk = min(k, nb - 1u);
+            const uint32_t cid = __builtin_amdgcn_readlane(my_cid, kk);
+            cn[at] = __builtin_amdgcn_readlane(my_cn, kk);
+            load_chunk(cid, buf[at]);
+        };
+#pragma unroll
+        for (uint32_t d = 0; d < DEPTH; d++) fetch(d, d);
+        for (uint32_t k = 0; k < nb; k += DEPTH) {
+#pragma unroll
+            for (uint32_t d = 0; d < DEPTH; d++) {
+                if (k + d < nb) reduce_chunk(buf[d], cn[d]); // wave-uniform
+                fetch(k + d + DEPTH, d);
+            }
+        }
+    }
+    __syncthreads();
+
+    for (uint32_t i = tid; i < words; i += P2_BLOCK) {
+        const uint32_t c = h[i];
+        if (c) {
+            const uint32_t l = i >> log_w, b = s_org[l] + (i & (W - 1));
+            atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)s_name[l] * LH_NKEYS + b]),
+                      (unsigned long long)c);
+            atomicMin(&s_mn[l], b);
+            atomicMax(&s_mx[l], b);
+        }
+    }
+    for (uint32_t i = tid; i < OV_SLOTS; i += P2_BLOCK)
+        if (ov_key[i] != OV_EMPTY) p2_global_add(counts, ranges, s_name[ov_key[i] >> 16], ov_key[i] & 0xffffu, ov_cnt[i]);
+    __syncthreads();
+    if (tid < mpp2 && s_mn[tid] != INVALID) {
+        uint32_t *r = ranges + 2 * (size_t)s_name[tid];
+        if (s_mn[tid] < r[0]) atomicMin(&r[0], s_mn[tid]);
+        if (s_mx[tid] > r[1]) atomicMax(&r[1], s_mx[tid]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// plan + launcher
+// ---------------------------------------------------------------------------
+struct Part3Plan {
+    uint32_t log_w, log_mpp2, mpp2, kp, mpp, ns, nq;
+    uint32_t region_words, cells, g1, chunks_per_wg, nchunks1, nchunks2;
+    size_t lds_dyn;
+    size_t off_stat, off_aux, off_hk, off_hs, off_hdr, off_pt, off_remap, off_inv, off_pt2;
+    size_t off_rec1, off_cd1, off_sorted1, off_small1, off_rec2, off_cd2, off_sorted2, off_small2, total;
+};
+
+static bool make_plan3(size_t n, uint32_t nmetrics, int num_cus, const PartTuning &tune, Part3Plan &P)
+{
+    if (!tune.v3 || !(tune.v2_shape & 2u)) return false; // shape bit 1 clear: the engine asked for the exact layout
+    if (n < (tune.v3_min_samples ? tune.v3_min_samples : V3_MIN_SAMPLES) || n > (size_t(1) << 31)) return false;
+    if (nmetrics <= V2_MAX_NAMES || nmetrics > V3_MAX_NAMES) return false;
+    P.log_w = std::min(13u, std::max(10u, tune.v3_log_w));
+    P.log_mpp2 = 15u - P.log_w;                  // mpp2 x W = 32 768 window words in the reduce pass
+    P.mpp2 = 1u << P.log_mpp2;
+    P.kp = PEEL_WORDS >> P.log_w;                // names counted in place by level 2: 24, 12, 6, 3
+    P.mpp = (nmetrics + V3_NP - 1) >> V3_LOG_NP; // names per level-1 partition: 33 .. 256
+    P.ns = 1;
+    while (P.ns * P.mpp2 < P.mpp) P.ns *= 2;     // fine partitions per level-1 partition: <= 64
+    P.nq = V3_NP * P.ns;
+    P.region_words = v3_region_words(V3_TILE);
+    const size_t fixed = sizeof(Scatter4Lds) + (size_t)P.region_words * 4;
+    P.cells = (uint32_t)((V2_LDS_TOTAL - fixed) / 4) & ~63u;
+    if (!tune.hot) P.cells = 0;
+    P.lds_dyn = fixed + (size_t)P.cells * 4;
+    const size_t ntiles = n / V3_TILE; // whole tiles; the rest goes through the direct kernel
+    if (ntiles == 0) return false;
+    size_t g1 = (size_t)num_cus;
+    if (g1 > (ntiles + 3) / 4) g1 = (ntiles + 3) / 4;
+    if (g1 < 1) g1 = 1;
+    P.g1 = (uint32_t)g1;
+    const size_t tiles_per_wg = (ntiles + g1 - 1) / g1;
+    P.chunks_per_wg = (uint32_t)(tiles_per_wg * (V3_TILE / CHUNK) + V3_NP + 1);
+    P.nchunks1 = P.g1 * P.chunks_per_wg;
+    // level 2: every level-1 slot re-scatters its chunks into <= cnt + ns + 1 chunks of its own pool
+    P.nchunks2 = P.nchunks1 + (V3_NP + V3_EXTRA1) * (P.ns + 1);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~size_t(255); return at; };
+    // the survey's tables first: their offsets depend on the name count only, so every sub-launch of a call finds them
+    P.off_stat = take((size_t)nmetrics * 20 + 8);
+    P.off_aux = take((size_t)AUX_WORDS * 4);
+    P.off_hk = take((size_t)V3_HN * sizeof(pu2_t));
+    P.off_hs = take((size_t)V2_MAX_SLOTS * sizeof(pu4_t));
+    P.off_hdr = take(64);
+    P.off_pt = take((size_t)V3_NP * sizeof(pu2_t));
+    P.off_remap = take(65536);
+    P.off_inv = take(65536);
+    P.off_pt2 = take((size_t)V3_NP * V3_MAX_NS * sizeof(pu2_t));
+    P.off_rec1 = take((size_t)P.nchunks1 * CHUNK * sizeof(uint32_t));
+    P.off_cd1 = take((size_t)P.nchunks1 * sizeof(uint32_t));
+    P.off_sorted1 = take((size_t)P.nchunks1 * sizeof(uint32_t));
+    P.off_small1 = take(small_words(V3_NP, V3_EXTRA1) * sizeof(uint32_t));
+    P.off_rec2 = take((size_t)P.nchunks2 * CHUNK * sizeof(uint32_t));
+    P.off_cd2 = take((size_t)P.nchunks2 * sizeof(uint32_t));
+    P.off_sorted2 = take((size_t)P.nchunks2 * sizeof(uint32_t));
+    P.off_small2 = take(small_words(P.nq, V3_EXTRA2) * sizeof(uint32_t));
+    P.total = o;
+    return true;
+}
+
+size_t part3_scratch_bytes(size_t n, uint32_t nmetrics, int num_cus, const PartTuning &tune)
+{
+    Part3Plan P;
+    return make_plan3(n, nmetrics, num_cus, tune, P) ? P.total : 0;
+}
+
+// survey_n / region_stat: as launch_ingest_pairs_part2.  span_stat: device-visible word (pinned host memory) that
+// receives the survey's window-width class, or null.
+hipError_t launch_ingest_pairs_part3(const uint32_t *d_ids, const double *d_v, size_t n, size_t survey_n,
+                                     uint64_t *counts, uint32_t *ranges, uint32_t nmetrics, const double *d_Tx,
+                                     uint32_t *d_err, void *scratch, size_t scratch_bytes, int num_cus,
+                                     const PartTuning &tune, unsigned long long *region_stat, uint32_t *span_stat,
+                                     hipStream_t s)
+{
+    Part3Plan P;
+    if (!make_plan3(n, nmetrics, num_cus, tune, P) || scratch_bytes < P.total || !scratch) return hipErrorInvalidValue;
+    if (!part_aligned(d_ids, d_v)) return hipErrorInvalidValue;
+    static std::atomic<bool> attr_set{false}; // benign if two threads race: both set the same attributes
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter4<4>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)V2_LDS_TOTAL);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_split_records),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPLIT_LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_part_hist3),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)P3_LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_survey_count_h),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(5 * SVH_SLOTS * 4));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_plan_count),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NQMAX * sizeof(uint32_t)));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_plan_scatter),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NQMAX * sizeof(uint32_t)));
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+#ifdef LH_TUNING
+    const uint32_t dbg = tune.dbg;
+#else
+    const uint32_t dbg = 0;
+#endif
+    unsigned char *base = static_cast<unsigned char *>(scratch);
+    const LevelPtrs L1 = level_ptrs(base, P.off_rec1, P.off_cd1, P.off_sorted1, P.off_small1, V3_NP, V3_EXTRA1);
+    const LevelPtrs L2 = level_ptrs(base, P.off_rec2, P.off_cd2, P.off_sorted2, P.off_small2, P.nq, V3_EXTRA2);
+    uint32_t *g_cnt = reinterpret_cast<uint32_t *>(base + P.off_stat);
+    uint32_t *g_mninv = g_cnt + nmetrics, *g_mx = g_mninv + nmetrics;
+    unsigned long long *g_sum = reinterpret_cast<unsigned long long *>(g_mx + nmetrics + (nmetrics & 1u));
+    uint32_t *g_aux = reinterpret_cast<uint32_t *>(base + P.off_aux);
+    pu2_t *g_hk = reinterpret_cast<pu2_t *>(base + P.off_hk);
+    pu4_t *g_hs = reinterpret_cast<pu4_t *>(base + P.off_hs);
+    uint32_t *g_hdr = reinterpret_cast<uint32_t *>(base + P.off_hdr);
+    pu2_t *g_pt = reinterpret_cast<pu2_t *>(base + P.off_pt);
+    uint8_t *g_remap = base + P.off_remap, *g_inv = base + P.off_inv;
+    pu2_t *g_pt2 = reinterpret_cast<pu2_t *>(base + P.off_pt2);
+
+    hipError_t e = hipMemsetAsync(L1.cdesc, 0xff, (size_t)P.nchunks1 * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(L1.pc, 0, small_words(V3_NP, V3_EXTRA1) * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(L2.cdesc, 0xff, (size_t)P.nchunks2 * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(L2.pc, 0, small_words(P.nq, V3_EXTRA2) * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    if (survey_n) {
+        // stat and aux are adjacent (both multiples of 256 bytes apart): one memset
+        e = hipMemsetAsync(base + P.off_stat, 0, P.off_hk - P.off_stat, s);
+        if (e != hipSuccess) return e;
+        const size_t sv_tiles = (survey_n / 2 + 1023) / 1024;
+        const unsigned sv_grid = (unsigned)std::min<size_t>(SVH_GRID, std::max<size_t>(1, sv_tiles));
+        hipLaunchKernelGGL(k_survey_count_h, dim3(sv_grid), dim3(1024), 5 * SVH_SLOTS * 4, s, d_ids, d_v, survey_n,
+                           nmetrics, d_Tx, g_cnt, g_mninv, g_mx, g_sum);
+        hipLaunchKernelGGL(k_survey_pick, dim3((nmetrics + 1023) / 1024), dim3(1024), 0, s, g_cnt, g_mninv, g_mx,
+                           nmetrics, g_aux);
+        hipLaunchKernelGGL(k_survey_plan_h, dim3(1), dim3(V2_BLOCK), 0, s, g_cnt, g_mninv, g_mx, g_sum, g_aux, P.cells,
+                           V3_TILE, g_hk, g_hs, g_pt, g_hdr, span_stat);
+        hipLaunchKernelGGL(k_survey_remap, dim3(V3_NP), dim3(256), 0, s, g_cnt, nmetrics, P.kp, P.log_mpp2, P.ns,
+                           g_remap, g_inv, g_pt2);
+    }
+    const size_t nt_full = n / V3_TILE, done = nt_full * V3_TILE;
+    hipLaunchKernelGGL(k_scatter4<4>, dim3(P.g1), dim3(1024), P.lds_dyn, s, d_ids, d_v, nt_full, nmetrics, d_Tx, g_hk,
+                       g_hs, g_hdr, g_pt, P.region_words, P.cells, L1.records, L1.cdesc, P.chunks_per_wg, counts, ranges,
+                       d_err, region_stat);
+    if (done < n) {
+        e = launch_ingest_pairs(d_ids + done, d_v + done, n - done, counts, ranges, nmetrics, d_Tx, d_err, num_cus, s);
+        if (e != hipSuccess) return e;
+    }
+    e = run_plan(L1, P.nchunks1, V3_NP, P.ns + 1, V3_EXTRA1, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_split_records, dim3(V3_NP + V3_EXTRA1), dim3(1024), SPLIT_LDS_BYTES, s, L1.records, L1.cdesc,
+                       L1.sorted, L1.part_start, L1.slots, L1.nslots, L1.pool_start, nmetrics, P.kp, P.log_mpp2,
+                       P.log_w, P.ns, g_remap, g_inv, g_pt2, g_cnt, g_mninv, g_mx, g_sum, L2.records, L2.cdesc, counts,
+                       ranges, dbg);
+    e = run_plan(L2, P.nchunks2, P.nq, 0u, V3_EXTRA2, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_part_hist3, dim3(P.nq + V3_EXTRA2), dim3(P2_BLOCK), P3_LDS_BYTES, s, L2.records, L2.cdesc,
+                       L2.sorted, L2.part_start, L2.slots, L2.nslots, nmetrics, P.log_mpp2, P.log_w, g_inv, g_cnt,
+                       g_mninv, g_mx, g_sum, counts, ranges);
+    return hipGetLastError();
+}

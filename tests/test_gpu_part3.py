@@ -1,0 +1,224 @@
+"""Third generation of the partitioned mixed ingest (loghisto_amd/csrc/lh_kernels_part3.h): 8 193 .. 65 536 names
+-- BASELINE config 4's name count -- through the hashed survey, the region scatter of 4-byte records
+(k_scatter4), the second level that counts each partition's frequent names in place (k_split_records) and the
+reduce pass (k_part_hist3).
+
+The survey, the hot-name hash, the per-partition ranking and the window width only decide WHERE a sample is
+counted; every cell of every row must equal the oracle's whatever they estimate.  A dense oracle matrix would be
+32 GiB at 65 536 names, so both sides are compared as sorted (name << 16 | bin, count) lists: the oracle's from
+compress_many + unique, the engine's from lh_buckets_all (device-compacted CSR of all occupied cells).
+Reference semantics: metrics.go:273-295 (fan-in), 316-322 (compress)."""
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+from loghisto_amd import _native as N
+
+pytestmark = pytest.mark.gpu
+PCTS = [0.0, .5, .9, .99, .999, 1.0]
+
+
+def _dev(torch, a):
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.uint32:
+        a = a.view(np.int32)
+    return torch.from_numpy(a).cuda()
+
+
+def _ids(rng, M, n, skew, permute=True):
+    w = np.arange(1, M + 1, dtype=np.float64) ** -skew
+    perm = rng.permutation(M) if permute else np.arange(M)
+    return perm[rng.choice(M, size=n, p=w / w.sum())].astype(np.uint32)
+
+
+def _values(rng, kind, ids, n):
+    if kind == "lognormal":
+        return rng.lognormal(math.log(1e5) + 2e-3 * (ids % 4096), 1.0)
+    if kind == "constant":
+        return 1000.0 + (ids % 5)
+    if kind == "allsame":
+        return np.full(n, 123.0)
+    if kind == "signed":                         # two lobes of bins per name, the mean bin between them
+        return rng.normal(0, 1e4, n)
+    if kind == "loguniform":                     # 4 147 occupied buckets per name
+        return 10.0 ** rng.uniform(-3, 18, n)
+    if kind == "huge":                           # spans the whole key space: most samples miss every window
+        return 10.0 ** rng.uniform(-6, 140, n) * np.where(rng.random(n) < 0.5, -1.0, 1.0)
+    if kind == "sigma25":
+        return rng.lognormal(math.log(1e5), 2.5, n)
+    if kind == "drift":                          # the distribution moves during the launch: windows go stale
+        return rng.lognormal(math.log(1e3) + 9.0 * np.arange(n) / n, 0.5)
+    assert kind == "edge"
+    v = rng.lognormal(math.log(1e5), 1.0, n)
+    hot = int(np.bincount(ids).argmax())
+    sel = np.nonzero(ids == hot)[0]
+    v[sel[:3000]] = 2.0196e142                   # key +32767 on a hot name
+    v[sel[3000:6000]] = -2.0196e142
+    v[sel[6000:6100]] = float("nan")
+    v[sel[6100:6200]] = float("inf")
+    v[sel[6200:6300]] = 0.0
+    v[sel[6300:6400]] = 3e142                    # beyond the int16 domain: amd64 wrap
+    last = int(ids.max())                        # the record 0xffffffff when the last name is 65 535
+    v[ids == last] = 2.0196e142
+    return v
+
+
+def oracle_cells(ids, v):
+    """Sorted (name << 16 | bin) of every occupied cell and its count, from the oracle's compress."""
+    bins = oracle.key_to_bin(oracle.compress_many(v)).astype(np.uint64)
+    return np.unique((ids.astype(np.uint64) << np.uint64(16)) | bins, return_counts=True)
+
+
+def engine_cells(snap, M):
+    off, keys, counts = snap.buckets_all(M)
+    rows = np.repeat(np.arange(M, dtype=np.uint64), np.diff(off.astype(np.int64)))
+    cells = (rows << np.uint64(16)) | oracle.key_to_bin(keys).astype(np.uint64)
+    return cells, counts.astype(np.int64)
+
+
+def check(snap, ids, v, M, got):
+    want_cells, want_counts = oracle_cells(ids, v)
+    cells, counts = engine_cells(snap, M)
+    if not (np.array_equal(cells, want_cells) and np.array_equal(counts, want_counts)):
+        a = dict(zip(cells.tolist(), counts.tolist()))
+        b = dict(zip(want_cells.tolist(), want_counts.tolist()))
+        bad = sorted(k for k in set(a) | set(b) if a.get(k) != b.get(k))
+        names = sorted({k >> 16 for k in bad})
+        raise AssertionError(f"{len(bad)} cells of {len(names)} names differ, e.g. " +
+                             ", ".join(f"name {k >> 16} bin {k & 0xffff}: {a.get(k)} != {b.get(k)}" for k in bad[:6]))
+    per_name = np.bincount(ids, minlength=M)
+    assert np.array_equal(got["count"].astype(np.int64), per_name)
+    for m in np.nonzero(per_name)[0][:: max(1, M // 48)]:
+        ref = oracle.process_dense(oracle.histogram_dense(v[ids == m]), PCTS)
+        assert np.array_equal(got["pvals"][m].view(np.uint64), ref["pvals"].view(np.uint64)), m
+        assert np.array_equal(got["pkeys"][m], ref["pkeys"]), m
+
+
+CASES = [
+    # names, pairs, values, Zipf exponent, permuted ids, window (0 = follow the survey)
+    (65536, 3_000_001, "lognormal", 1.0, False, 0),   # config 4's shape (id = rank); odd length
+    (65536, 2_500_000, "lognormal", 1.0, True, 0),    # the same with names in arbitrary order
+    (65536, 2_000_000, "lognormal", 0.0, True, 10),   # no skew: nothing is hot, nothing is frequent in its partition
+    (65536, 2_000_000, "edge", 1.0, False, 10),       # key +-32767, NaN, Inf, wrap; the last name; record 0xffffffff
+    (65536, 1_500_000, "loguniform", 1.0, True, 10),  # 4 147 buckets per name against 1 024-bin windows: overflow paths
+    (65536, 1_500_000, "loguniform", 1.0, True, 0),   # ... and with the width the survey reports
+    (65536, 1_500_000, "huge", 1.5, True, 13),
+    (65536, 2_000_000, "constant", 1.0, True, 11),
+    (40000, 2_200_000, "allsame", 1.0, True, 12),     # ragged: 157 names per partition, fine partitions partly empty
+    (16384, 2_600_000, "sigma25", 1.0, True, 0),      # 64 names per partition
+    (8193, 2_000_000, "signed", 1.5, True, 0),        # the smallest name count of this path: 33 names per partition
+    (20000, 1_800_000, "drift", 0.5, False, 0),
+]
+
+
+@pytest.mark.parametrize("M,n,kind,skew,permute,log_w", CASES)
+def test_third_generation_is_exact(native_lib, torch_cuda, M, n, kind, skew, permute, log_w):
+    import loghisto_amd
+    rng = np.random.default_rng(M * 7 + n)
+    ids = _ids(rng, M, n, skew, permute)
+    v = _values(rng, kind, ids, n)
+    d_ids, d_v = _dev(torch_cuda, ids), _dev(torch_cuda, v)
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        e.set_option(N.OPT_PART_V3_MIN_PAIRS, 1 << 17)
+        e.set_option(N.OPT_PART_V3_LOG_W, log_w)
+        for rep in range(2):                     # scratch and survey tables are reused; rep 1 runs with rep 0's window report
+            e.submit_pairs_device(d_ids, d_v)
+            e.sync()
+            c = e.counters()
+            assert c["samples_partitioned_v3"] == n * (rep + 1), c
+            assert 10 <= c["window_log2"] <= 13
+            with e.flip() as snap:
+                got = snap.extract(PCTS, M)
+                check(snap, ids, v, M, got)
+
+
+def test_window_width_follows_the_stream(native_lib, torch_cuda):
+    """The survey's report: lognormal sigma = 1 spans ~900 bins (1 024-bin windows), 21 decades span 4 147 (8 192)."""
+    import loghisto_amd
+    rng = np.random.default_rng(5)
+    M, n = 65536, 1_000_000
+    ids = _ids(rng, M, n, 1.0)
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        e.set_option(N.OPT_PART_V3_MIN_PAIRS, 1 << 17)
+        for kind, want in (("lognormal", 10), ("loguniform", 13), ("sigma25", 12), ("lognormal", 10)):
+            e.submit_pairs_device(_dev(torch_cuda, ids), _dev(torch_cuda, _values(rng, kind, ids, n)))
+            e.sync()
+            assert e.counters()["window_log2"] == want, (kind, e.counters())
+            e.flip().release()
+
+
+def test_bad_ids_sublaunches_and_two_launches_per_epoch(native_lib, torch_cuda):
+    import loghisto_amd
+    rng = np.random.default_rng(78)
+    M, n = 30000, 9_000_001
+    ids = _ids(rng, M, n, 1.0)
+    v = rng.lognormal(10, 1.2, n)
+    bad = ids.copy()
+    where = [3, 4_200_000, n - 1]
+    bad[where] = [M, 0xFFFFFFFF, M + 5]
+    keep = np.ones(n, dtype=bool)
+    keep[where] = False
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        e.set_option(N.OPT_PART_V3_MIN_PAIRS, 1 << 17)
+        e.set_option(N.OPT_SUBLAUNCH_PAIRS, 1 << 22)       # 3 sub-launches per call, one survey per call
+        e.submit_pairs_device(_dev(torch_cuda, ids), _dev(torch_cuda, v))
+        e.submit_pairs_device(_dev(torch_cuda, bad), _dev(torch_cuda, v))
+        with pytest.raises(loghisto_amd.LhError) as ei:
+            e.sync()
+        assert ei.value.code == 6
+        assert e.counters()["sublaunches"] == 6 and e.counters()["samples_partitioned_v3"] == 2 * n
+        with e.flip() as snap:
+            try:
+                got = snap.extract(PCTS, M)
+            except loghisto_amd.LhError:
+                got = snap.extract(PCTS, M)
+            check(snap, np.concatenate([ids, ids[keep]]), np.concatenate([v, v[keep]]), M, got)
+
+
+def test_threshold_fixture_through_the_hashed_scatter(native_lib, torch_cuda):
+    """Every bucket threshold, the double below and the double above it (tests/golden/thresholds_x.bin, the file real
+    Go is checked against), both signs, through k_scatter4's branch-free bucket index."""
+    import os
+    import sys
+    import loghisto_amd
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_thresholds as mt
+    x, _, _ = mt.read()
+    v = np.concatenate([x, -x, x[::-1]])
+    M = 9000
+    ids = ((np.arange(v.size, dtype=np.uint64) * 7919) % M).astype(np.uint32)
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        e.set_option(N.OPT_PART_V3_MIN_PAIRS, 1 << 17)
+        e.submit_pairs_device(_dev(torch_cuda, ids), _dev(torch_cuda, v))
+        e.sync()
+        assert e.counters()["samples_partitioned_v3"] == v.size
+        with e.flip() as snap:
+            check(snap, ids, v, M, snap.extract(PCTS, M))
+
+
+def test_clustered_stream_falls_back_to_the_first_generation(native_lib, torch_cuda):
+    """A stream sorted by name puts whole tiles into one level-1 partition: the regions overflow, the kernel reports
+    it, and the engine takes the exact-layout scatter for the following intervals.  Exact either way."""
+    import loghisto_amd
+    rng = np.random.default_rng(9)
+    M, n = 65536, 4_194_304
+    ids = np.sort(_ids(rng, M, n, 0.0))
+    v = rng.lognormal(10, 1.0, n)
+    d_ids, d_v = _dev(torch_cuda, ids), _dev(torch_cuda, v)
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=3, num_lanes=1, lane_samples=1 << 16) as e:
+        e.set_option(N.OPT_PART_V3_MIN_PAIRS, 1 << 17)
+        seen_v3 = 0
+        for rep in range(3):
+            e.submit_pairs_device(d_ids, d_v)
+            e.sync()
+            c = e.counters()
+            with e.flip() as snap:
+                check(snap, ids, v, M, snap.extract(PCTS, M))
+            if rep == 0:
+                assert c["samples_partitioned_v3"] == n
+                seen_v3 = c["samples_partitioned_v3"]
+        c = e.counters()
+        assert c["region_overflows"] > n // 50 and c["regions_disabled"] == 1, c
+        assert c["samples_partitioned_v3"] < 3 * n and c["samples_partitioned"] == 3 * n, (c, seen_v3)
