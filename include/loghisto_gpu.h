@@ -290,6 +290,10 @@ typedef struct lh_counters {
     uint64_t region_overflows;       /* records the region scatter counted through the exact out-of-window path     */
     uint64_t samples_partitioned_v3; /* of samples_partitioned: through the 8 193 .. 65 536-name path               */
     uint64_t window_log2;            /* that path's second-level window width (log2 bins) for the next call         */
+    uint64_t records_level1;         /* that path: 4-byte records its first level wrote (samples no hot window took)  */
+    uint64_t records_level2;         /* ... records its second level forwarded to the reduce pass                     */
+    uint64_t level2_overflows;       /* ... records that found a second-level region full (exact path)                */
+    uint64_t reduce_window_misses;   /* ... records outside their window in the reduce pass (exact path)              */
 } lh_counters;
 int lh_get_counters(lh_engine *e, lh_counters *out);
 

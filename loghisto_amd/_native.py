@@ -36,7 +36,11 @@ class LhCounters(C.Structure):
                                                                 ("counter_events", C.c_uint64),
                                                                 ("region_overflows", C.c_uint64),
                                                                 ("samples_partitioned_v3", C.c_uint64),
-                                                                ("window_log2", C.c_uint64)]
+                                                                ("window_log2", C.c_uint64),
+                                                                ("records_level1", C.c_uint64),
+                                                                ("records_level2", C.c_uint64),
+                                                                ("level2_overflows", C.c_uint64),
+                                                                ("reduce_window_misses", C.c_uint64)]
 
 # lh_set_option keys (include/loghisto_gpu.h)
 OPT_TWO_LEVEL_ABOVE, OPT_HOT_MIN_TILES, OPT_HOT_WINDOWS, OPT_NAMES_PER_PARTITION = 1, 2, 3, 4

@@ -278,6 +278,14 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
     // is all that happens under the lock; the kernels run later, in stream order behind `scratch_done`).
     bool surveyed = false;
     std::unique_lock<std::mutex> scratch_lock(e->scratch_mu, std::defer_lock);
+    // Third generation: the window width the last completed survey reported (0 until one has run).  Read ONCE per
+    // call: the sub-launches of a call share the survey's per-partition tables, which are laid out for one width,
+    // and the call's own survey stores its report while later sub-launches are still being enqueued.
+    uint32_t call_log_w = e->tune.v3_log_w;
+    if (!e->v3_log_w_fixed) {
+        const uint32_t lw = (uint32_t)__atomic_load_n(&e->h_rstat[1], __ATOMIC_RELAXED);
+        if (lw >= 10 && lw <= 13) call_log_w = lw;
+    }
     while (n) {
         size_t take = n < kMaxLaunch ? n : kMaxLaunch;
         if (!e->small_disabled.load(std::memory_order_relaxed) &&
@@ -307,11 +315,7 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
             size_t sub = (bounded && take > e->sublaunch_pairs) ? e->sublaunch_pairs : take;
             lh::PartTuning tune = e->tune;
             if (e->regions_disabled.load(std::memory_order_relaxed)) tune.v2_shape &= ~2u; // clustered stream: exact layout
-            if (two_level && !e->v3_log_w_fixed) {
-                // what the last completed survey saw (0 until one has run)
-                const uint32_t lw = (uint32_t)__atomic_load_n(&e->h_rstat[1], __ATOMIC_RELAXED);
-                if (lw >= 10 && lw <= 13) tune.v3_log_w = lw;
-            }
+            tune.v3_log_w = call_log_w;
             // generation 2 (survey + 2-byte records) for <= 8 192 names, generation 3 above, when the launch is large
             // enough; otherwise the first generation
             auto scratch_need = [&](size_t m, int *gen) {
@@ -540,9 +544,8 @@ int create_impl(const lh_config *cfg_in, lh_engine *e)
 
     HIPCHK(hipMalloc((void **)&e->d_Tx, sizeof(double) * LH_NTHRESH));
     HIPCHK(hipMalloc((void **)&e->d_D, sizeof(double) * LH_NKEYS));
-    HIPCHK(hipHostMalloc((void **)&e->h_rstat, 16, hipHostMallocDefault));
-    e->h_rstat[0] = 0;
-    e->h_rstat[1] = 0;
+    HIPCHK(hipHostMalloc((void **)&e->h_rstat, 64, hipHostMallocDefault));
+    for (int i = 0; i < 8; i++) e->h_rstat[i] = 0; // [0] level-1 region overflows [1] window class [2..5] part3 self-metrics
     {
         void *dp = nullptr;
         HIPCHK(hipHostGetDevicePointer(&dp, e->h_rstat, 0));
@@ -1866,6 +1869,10 @@ int lh_get_counters(lh_engine *e, lh_counters *out)
     out->counter_events = e->c_counts.load();
     out->region_overflows = e->c_region_ovf.load();
     out->samples_partitioned_v3 = e->c_part3.load();
+    out->records_level1 = __atomic_load_n(&e->h_rstat[2], __ATOMIC_RELAXED);
+    out->records_level2 = __atomic_load_n(&e->h_rstat[3], __ATOMIC_RELAXED);
+    out->level2_overflows = __atomic_load_n(&e->h_rstat[4], __ATOMIC_RELAXED);
+    out->reduce_window_misses = __atomic_load_n(&e->h_rstat[5], __ATOMIC_RELAXED);
     {
         const uint64_t lw = __atomic_load_n(&e->h_rstat[1], __ATOMIC_RELAXED);
         out->window_log2 = e->v3_log_w_fixed ? e->tune.v3_log_w : (lw >= 10 && lw <= 13 ? lw : e->tune.v3_log_w);

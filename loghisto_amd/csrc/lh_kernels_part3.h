@@ -44,7 +44,7 @@ constexpr uint32_t V3_TILE = 8192;                      // samples per level-1 t
 constexpr uint32_t LINE4 = 16;                          // 4-byte records per 64-byte line
 constexpr uint32_t V3_MISSQ = 512;                      // records a tile can queue for the exact path (per parity)
 constexpr size_t V3_MIN_SAMPLES = size_t(1) << 24;
-constexpr uint32_t SVH_GRID = 512, SVH_SLOTS = 4096;    // hashed survey: 512 workgroups x 2 048 samples
+constexpr uint32_t SVH_GRID = 256, SVH_SLOTS = 4096;    // hashed survey: 256 workgroups x 2 048 samples
 constexpr uint32_t V3_EXTRA1 = 768;                     // level-1 work slots beyond one per partition
 constexpr uint32_t V3_EXTRA2 = 1024;                    // fine work slots beyond one per fine partition
 constexpr uint32_t V3_MAX_NS = 64;                      // fine partitions per level-1 partition (at most)
@@ -55,6 +55,19 @@ constexpr uint32_t SPLIT_REG_WORDS = 12800;             // level 2: LDS regions 
 
 __device__ __forceinline__ uint32_t v3_hash(uint32_t id) { return (id * 0x9E3779B1u) >> 22; } // 10 bits
 
+// Per-name survey statistics (zero-initialised): cs[M] u64 = sampled count (24 bits) | sum of the sampled bins << 24,
+// then mninv[M] u32 (max of 65535 - bin) and mx[M] u32.  Count and sum share a word so that a workgroup merges a name
+// with ONE global atomic: atomics to scattered addresses sustain only ~9 G/s on this part (measured: four per name
+// took 250 us for 2 M of them).
+struct SurveyStat { const unsigned long long *cs; const uint32_t *mninv; const uint32_t *mx; };
+__device__ __forceinline__ uint32_t sv_count(const SurveyStat &S, uint32_t m) { return (uint32_t)(S.cs[m] & 0xffffffull); }
+__device__ __forceinline__ uint32_t sv_mean(const SurveyStat &S, uint32_t m)
+{
+    const unsigned long long w = S.cs[m];
+    const uint32_t c = (uint32_t)(w & 0xffffffull);
+    return c ? (uint32_t)((w >> 24) / c) : 32768u;
+}
+
 // ---------------------------------------------------------------------------
 // Survey for large name spaces
 // ---------------------------------------------------------------------------
@@ -62,9 +75,8 @@ __device__ __forceinline__ uint32_t v3_hash(uint32_t id) { return (id * 0x9E3779
 // into 4 096 slots, so linear probing always terminates.
 __global__ __launch_bounds__(1024) void k_survey_count_h(const uint32_t *__restrict__ ids, const double *__restrict__ v,
                                                          size_t n, uint32_t nmetrics, const double *__restrict__ Tx,
-                                                         uint32_t *__restrict__ g_cnt, uint32_t *__restrict__ g_mninv,
-                                                         uint32_t *__restrict__ g_mx,
-                                                         unsigned long long *__restrict__ g_sum)
+                                                         unsigned long long *__restrict__ g_cs,
+                                                         uint32_t *__restrict__ g_mninv, uint32_t *__restrict__ g_mx)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char svh_smem[];
     uint32_t *s_key = reinterpret_cast<uint32_t *>(svh_smem);
@@ -102,10 +114,10 @@ __global__ __launch_bounds__(1024) void k_survey_count_h(const uint32_t *__restr
         const uint32_t k = s_key[s];
         if (k) {
             const uint32_t m = k - 1u;
-            atomicAdd(&g_cnt[m], s_cnt[s]);
-            atomicAdd(&g_sum[m], (unsigned long long)s_sum[s]);
-            atomicMax(&g_mninv[m], s_mninv[s]);
-            atomicMax(&g_mx[m], s_mx[s]);
+            atomicAdd(&g_cs[m], (unsigned long long)s_cnt[s] | ((unsigned long long)s_sum[s] << 24));
+            // (a stale read only costs an atomic that changes nothing)
+            if (s_mninv[s] > g_mninv[m]) atomicMax(&g_mninv[m], s_mninv[s]);
+            if (s_mx[s] > g_mx[m]) atomicMax(&g_mx[m], s_mx[s]);
         }
     }
 }
@@ -115,9 +127,7 @@ constexpr uint32_t AUX_CLAIM = 0, AUX_PC = V3_HN, AUX_CLS = V3_HN + V3_NP, AUX_W
 
 // One thread per name: a name with >= 16 sampled values claims its hash slot (the larger count wins); per-partition
 // sample counts; the sampled mass by span class.
-__global__ __launch_bounds__(1024) void k_survey_pick(const uint32_t *__restrict__ g_cnt,
-                                                      const uint32_t *__restrict__ g_mninv,
-                                                      const uint32_t *__restrict__ g_mx, uint32_t nmetrics,
+__global__ __launch_bounds__(1024) void k_survey_pick(const SurveyStat S, uint32_t nmetrics,
                                                       uint32_t *__restrict__ g_aux)
 {
     __shared__ uint32_t s_pc[V3_NP], s_cls[17];
@@ -126,10 +136,10 @@ __global__ __launch_bounds__(1024) void k_survey_pick(const uint32_t *__restrict
     if (tid < 17) s_cls[tid] = 0;
     __syncthreads();
     const uint32_t m = blockIdx.x * 1024u + tid;
-    const uint32_t c = m < nmetrics ? g_cnt[m] : 0u;
+    const uint32_t c = m < nmetrics ? sv_count(S, m) : 0u;
     if (c) {
         atomicAdd(&s_pc[m & (V3_NP - 1u)], c);
-        const uint32_t span = g_mx[m] - (65535u - g_mninv[m]) + 1u;
+        const uint32_t span = S.mx[m] - (65535u - S.mninv[m]) + 1u;
         if (c >= 16u) atomicMax(&g_aux[AUX_CLAIM + v3_hash(m)], (min(c, 65535u) << 16) | m);
         if (c >= 32u) { // class k: spans in (2^(k-1), 2^k]
             const uint32_t k = span <= 1u ? 0u : 32u - (uint32_t)__clz(span - 1u);
@@ -147,10 +157,7 @@ __global__ __launch_bounds__(1024) void k_survey_pick(const uint32_t *__restrict
 //   g_pt[p]   level-1 region of partition p {first record relative to the region area, capacity}
 //   hdr       [0] hot names [1] cells used [2] surveyed samples [3] surveyed samples of hot names [4] log2 of the
 //             window width that covers 95 % of the sampled mass (10 .. 13), also stored to *span_out (pinned)
-__global__ __launch_bounds__(V2_BLOCK) void k_survey_plan_h(const uint32_t *__restrict__ g_cnt,
-                                                            const uint32_t *__restrict__ g_mninv,
-                                                            const uint32_t *__restrict__ g_mx,
-                                                            const unsigned long long *__restrict__ g_sum,
+__global__ __launch_bounds__(V2_BLOCK) void k_survey_plan_h(const SurveyStat S,
                                                             const uint32_t *__restrict__ g_aux, uint32_t cells,
                                                             uint32_t tile, pu2_t *__restrict__ g_hk,
                                                             pu4_t *__restrict__ g_hs, pu2_t *__restrict__ g_pt,
@@ -164,9 +171,9 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan_h(const uint32_t *__re
     uint32_t name = 0, cnt = 0, want = 0, mean = 32768u;
     if (claim) {
         name = claim & 0xffffu;
-        cnt = g_cnt[name];
-        const uint32_t mn = 65535u - g_mninv[name], mx = g_mx[name];
-        mean = (uint32_t)(g_sum[name] / cnt);
+        cnt = sv_count(S, name);
+        const uint32_t mn = 65535u - S.mninv[name], mx = S.mx[name];
+        mean = sv_mean(S, name);
         const uint32_t w = (((mx - mn + 1u) * 3u / 4u) + 63u) & ~63u; // as k_survey_plan: 3/4 of the sampled span
         want = w < 64u ? 64u : w;
     }
@@ -258,8 +265,8 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan_h(const uint32_t *__re
 // sampled count (ties by l, so that names beyond nmetrics rank last) and lays out the level-2 regions of the partition:
 //   g_remap[p * 256 + l] = rank, g_inv[p * 256 + rank] = l
 //   g_pt2[p * V3_MAX_NS + s] = {first record of fine partition s's region (relative to the region area), capacity}
-__global__ __launch_bounds__(256) void k_survey_remap(const uint32_t *__restrict__ g_cnt, uint32_t nmetrics,
-                                                      uint32_t kp, uint32_t log_mpp2, uint32_t ns,
+__global__ __launch_bounds__(256) void k_survey_remap(const SurveyStat S, const pu2_t *__restrict__ g_hk,
+                                                      uint32_t nmetrics, uint32_t kp, uint32_t log_mpp2, uint32_t ns,
                                                       uint8_t *__restrict__ g_remap, uint8_t *__restrict__ g_inv,
                                                       pu2_t *__restrict__ g_pt2)
 {
@@ -267,7 +274,9 @@ __global__ __launch_bounds__(256) void k_survey_remap(const uint32_t *__restrict
     __shared__ uint32_t s_tot;
     const uint32_t p = blockIdx.x, l = threadIdx.x;
     const uint32_t m = (l << V3_LOG_NP) | p;
-    const uint32_t c = m < nmetrics ? g_cnt[m] : 0u;
+    uint32_t c = m < nmetrics ? sv_count(S, m) : 0u;
+    // what reaches the second level: a name with a hot window in level 1 leaves it about a quarter of its samples
+    if (c && (g_hk[v3_hash(m)].x & 0xfffffu) == m) c = (c + 3u) / 4u;
     s_c[l] = c;
     if (l < V3_MAX_NS) s_w[l] = 0;
     if (l == 0) s_tot = 0;
@@ -294,10 +303,46 @@ __global__ __launch_bounds__(256) void k_survey_remap(const uint32_t *__restrict
     }
     __syncthreads();
     if (l < ns) {
-        uint32_t base = 0;
-        for (uint32_t i = 0; i < l; i++) base += s_cap[i];
-        g_pt2[p * V3_MAX_NS + l] = (pu2_t){base, s_cap[l]};
+        // The shares come from a few hundred sampled values per partition: a fine partition of cold names is
+        // regularly off by 30 % (measured with exact capacities: 3 % of all samples found their region full).  The
+        // region area is sized for a tile that forwards everything; what the estimates leave of it is shared out.
+        uint32_t base = 0, sum = 0;
+        for (uint32_t i = 0; i < ns; i++) {
+            if (i < l) base += s_cap[i];
+            sum += s_cap[i];
+        }
+        const uint32_t spare = (sum < SPLIT_REG_WORDS ? (SPLIT_REG_WORDS - sum) / ns : 0u) & ~3u;
+        g_pt2[p * V3_MAX_NS + l] = (pu2_t){base + l * spare, s_cap[l] + spare};
     }
+}
+
+// The exact path of a record that found no room in LDS, for use INSIDE the tile loops: the same three atomics as
+// v2_global_add, issued from inline asm and without the range pre-check.  Atomics that return nothing have no result
+// register, so hiding them from the compiler's s_waitcnt bookkeeping is as safe as hiding stores (k_scatter2); a
+// visible global operation in a rarely taken branch makes the compiler wait for vmcnt(0) at the join, and the
+// pre-check's load stalls the wave -- and, through the tile barrier, the workgroup -- for a memory round trip.
+__device__ __forceinline__ void v3_global_add(uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges, uint32_t m,
+                                              uint32_t bin, uint32_t c)
+{
+#ifdef V3_VISIBLE_ATOMICS
+    v2_global_add(counts, ranges, m, bin, c);
+    return;
+#endif
+    const unsigned long long c64 = c;
+    asm volatile("global_atomic_add_x2 %0, %1, off" : : "v"(&counts[(size_t)m * LH_NKEYS + bin]), "v"(c64) : "memory");
+    uint32_t *r = ranges + 2 * (size_t)m;
+    asm volatile("global_atomic_umin %0, %1, off\n\tglobal_atomic_umax %0, %1, off offset:4" : : "v"(r), "v"(bin) : "memory");
+}
+
+// compress of a sample inside the guard band of a threshold (or not finite), without touching memory: Go's log
+// restated operation by operation (lh_codec.h route 1; tests/test_gpu_parity.py holds it equal to the table compare
+// of lh_bin_of at +-3 ulp of every threshold).  ~60 float64 instructions for 1 sample in ~4 000, against a table
+// load whose wait drains the tile loop's prefetch.
+__device__ __forceinline__ uint32_t v3_bin_exact(double v)
+{
+    const double x = 1.0 + fabs(v);
+    const uint32_t eb = ((uint32_t)__double2hiint(x)) >> 20;
+    return bin_from_kext(eb < 0x7ffu ? d_kext_golog(x) : 0, v); // NaN / +Inf -> int16(...) == 0
 }
 
 // ---------------------------------------------------------------------------
@@ -313,7 +358,7 @@ struct Scatter4Lds {
     uint32_t missq[2][V3_MISSQ];
     uint32_t missn[2];
     uint32_t dummy[64];
-    uint32_t pool_next, ovn;
+    uint32_t pool_next, ovn, nrec, pad[3];
     pu2_t hk[V3_HN];                     // hot-name hash table
 };
 static_assert(sizeof(Scatter4Lds) % 16 == 0, "the regions follow the struct in LDS");
@@ -329,8 +374,7 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const uint32_t *__restrict
                                                       uint32_t cells, uint32_t *__restrict__ records,
                                                       uint32_t *__restrict__ cdesc, uint32_t chunks_per_wg,
                                                       uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
-                                                      uint32_t *__restrict__ err,
-                                                      unsigned long long *__restrict__ rstat)
+                                                      uint32_t *__restrict__ err, uint32_t *__restrict__ g_stats)
 {
     constexpr int BLOCK = 1024, NPT = V3_NP;
     static_assert(BLOCK == 4 * NPT, "flush: four threads per partition");
@@ -361,9 +405,10 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const uint32_t *__restrict
         L.cbase[tid] = INVALID;
     }
     ov_init(L.ov_key, L.ov_cnt, tid, BLOCK);
-    if (tid == 0) { L.pool_next = 0; L.ovn = 0; L.missn[0] = 0; L.missn[1] = 0; }
+    if (tid == 0) { L.pool_next = 0; L.ovn = 0; L.nrec = 0; L.missn[0] = 0; L.missn[1] = 0; }
     __syncthreads();
     const pu2_t my_pt = L.pt[tid >> 2]; // the flush phase's partition (constant over the launch)
+    uint32_t nrec = 0;                  // records this thread's partition emitted (q == 0 counts)
 
     const pd2_t *vp = reinterpret_cast<const pd2_t *>(v);
     const pu2_t *ip = reinterpret_cast<const pu2_t *>(ids);
@@ -414,11 +459,15 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const uint32_t *__restrict
                 bin[k] = lh_bin_fast((j & 1) ? val[j >> 1].y : val[j >> 1].x, u);
                 if (u) unc |= 1u << k;
             }
-            if (unc) { // inside the guard band of a bucket threshold (1 sample in ~4 000): exact table compare
+            if (unc) { // inside the guard band of a bucket threshold (1 sample in ~4 000): Go's log, exactly
 #pragma unroll
                 for (int k = 0; k < BATCH; k++) {
                     const int j = h + k;
+#ifdef V3_TABLE_EXACT
                     if (unc & (1u << k)) bin[k] = lh_bin_of((j & 1) ? val[j >> 1].y : val[j >> 1].x, Tx);
+#else
+                    if (unc & (1u << k)) bin[k] = v3_bin_exact((j & 1) ? val[j >> 1].y : val[j >> 1].x);
+#endif
                 }
             }
 #pragma unroll
@@ -448,7 +497,7 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const uint32_t *__restrict
                         const uint32_t key = (id[k] << 16) | bin[k];
                         const uint32_t at = atomicAdd(&L.missn[par], 1u);
                         if (at < V3_MISSQ) L.missq[par][at] = key;
-                        else if (!ov_add(L.ov_key, L.ov_cnt, key, 1u)) v2_global_add(counts, ranges, id[k], bin[k], 1);
+                        else if (!ov_add(L.ov_key, L.ov_cnt, key, 1u)) v3_global_add(counts, ranges, id[k], bin[k], 1);
                     }
             }
         }
@@ -495,14 +544,14 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const uint32_t *__restrict
                     *reinterpret_cast<pu4_t *>(lds32 + e.x + q * 4) =
                         *reinterpret_cast<const pu4_t *>(src + full * LINE4 + q * 4);
             }
-            if (q == 0) L.cnt[p] = left;
+            if (q == 0) { L.cnt[p] = left; nrec += full * LINE4; }
         }
         // the tile's overflowed records, one per thread: aggregated in the small LDS table, else a global atomic
         {
             const uint32_t nq = min(L.missn[par], V3_MISSQ);
             for (uint32_t i = tid; i < nq; i += BLOCK) {
                 const uint32_t key = L.missq[par][i];
-                if (!ov_add(L.ov_key, L.ov_cnt, key, 1u)) v2_global_add(counts, ranges, key >> 16, key & 0xffffu, 1);
+                if (!ov_add(L.ov_key, L.ov_cnt, key, 1u)) v3_global_add(counts, ranges, key >> 16, key & 0xffffu, 1);
             }
         }
         __syncthreads();                                   // barrier B: counters and regions are ready for the next tile
@@ -536,17 +585,21 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const uint32_t *__restrict
             }
             d = cb * CHUNK + cf;
             L.cfill[p] = cf + left;
+            nrec += left;
         }
         d = __builtin_amdgcn_mov_dpp(d, 0x00, 0xf, 0xf, false);
         if (left && q * 4 < left)
             *reinterpret_cast<pu4_t *>(records + d + q * 4) = *reinterpret_cast<const pu4_t *>(lds32 + L.pt[p].x + q * 4);
     }
+    if (nrec) atomicAdd(&L.nrec, nrec);
     __syncthreads();
     if (tid < NPT && L.cbase[tid] != INVALID) cdesc[L.cbase[tid]] = (tid << CD_SHIFT) | L.cfill[tid];
-    // the engine watches this count (pinned host memory): a stream whose tiles overflow the regions is clustered by
-    // name, and later calls take the first-generation (exact-layout) scatter instead
-    if (tid == 0 && L.ovn && rstat)
-        __hip_atomic_fetch_add(rstat, (unsigned long long)L.ovn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // self-metrics of the launch (k_v3_report adds them to the engine's pinned words): records that found their region
+    // full, records this level emitted
+    if (tid == 0) {
+        if (L.ovn) atomicAdd(&g_stats[0], L.ovn);
+        atomicAdd(&g_stats[1], L.nrec);
+    }
 
     // ---- flush the hot windows (one uint64 atomic per occupied bin) and the overflow table
     const uint32_t nhot = g_hdr[0];
@@ -606,7 +659,7 @@ struct SplitLds {
     uint32_t missq[2][V3_MISSQ];
     uint32_t missn[2];
     uint32_t dummy[64];
-    uint32_t pool_next, pad0;
+    uint32_t pool_next, ovn, nfwd, pad0[3];
     uint32_t tbl[256];
     uint32_t name[32], mn[32], mx[32], svc[32], svm[32], org[32]; // the names counted here
 };
@@ -625,14 +678,10 @@ __global__ __launch_bounds__(1024, 4) void k_split_records(const uint32_t *__res
                                                            uint32_t kp, uint32_t log_mpp2, uint32_t log_w, uint32_t ns,
                                                            const uint8_t *__restrict__ g_remap,
                                                            const uint8_t *__restrict__ g_inv,
-                                                           const pu2_t *__restrict__ g_pt2,
-                                                           const uint32_t *__restrict__ g_cnt,
-                                                           const uint32_t *__restrict__ g_mninv,
-                                                           const uint32_t *__restrict__ g_mx,
-                                                           const unsigned long long *__restrict__ g_sum,
+                                                           const pu2_t *__restrict__ g_pt2, const SurveyStat S,
                                                            uint32_t *__restrict__ records, uint32_t *__restrict__ cdesc,
                                                            uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
-                                                           uint32_t dbg_arg)
+                                                           uint32_t *__restrict__ g_stats, uint32_t dbg_arg)
 {
     const uint32_t dbg = LH_DBG(dbg_arg);
     constexpr int BLOCK = 1024;
@@ -661,11 +710,11 @@ __global__ __launch_bounds__(1024, 4) void k_split_records(const uint32_t *__res
             const uint32_t m = ((uint32_t)g_inv[p1 * 256u + tid] << V3_LOG_NP) | p1;
             if (m < nmetrics) {
                 name = m;
-                svc = g_cnt[m];
+                svc = sv_count(S, m);
                 if (svc) {
-                    mn = 65535u - g_mninv[m];
-                    mx = g_mx[m];
-                    svm = (uint32_t)(g_sum[m] / svc);
+                    mn = 65535u - S.mninv[m];
+                    mx = S.mx[m];
+                    svm = sv_mean(S, m);
                 }
             }
         }
@@ -685,7 +734,7 @@ __global__ __launch_bounds__(1024, 4) void k_split_records(const uint32_t *__res
         L.cbase[tid] = INVALID;
     }
     ov_init(L.ov_key, L.ov_cnt, tid, BLOCK);
-    if (tid == 0) { L.pool_next = 0; L.missn[0] = 0; L.missn[1] = 0; }
+    if (tid == 0) { L.pool_next = 0; L.ovn = 0; L.nfwd = 0; L.missn[0] = 0; L.missn[1] = 0; }
     __syncthreads();
     if (tid < n0) {
         const uint32_t r = L.tbl[(srec >> 16) & 0xffu], b = srec & 0xffffu;
@@ -759,6 +808,7 @@ __global__ __launch_bounds__(1024, 4) void k_split_records(const uint32_t *__res
                 lds32[fits ? pe[k].x + rank[k] : DUMMY_W + lane] = rec[k];
             }
             if (full) { // the fine partition's region is full: the record is counted exactly by the flush phase
+                atomicAdd(&L.ovn, (uint32_t)__popc(full));
 #pragma unroll
                 for (int k = 0; k < 4; k++)
                     if (full & (1u << k)) {
@@ -767,7 +817,7 @@ __global__ __launch_bounds__(1024, 4) void k_split_records(const uint32_t *__res
                         const uint32_t at = atomicAdd(&L.missn[par], 1u);
                         if (at < V3_MISSQ) L.missq[par][at] = key;
                         else if (!ov_add(L.ov_key, L.ov_cnt, key, 1u))
-                            v2_global_add(counts, ranges, key >> 16, bin, 1);
+                            v3_global_add(counts, ranges, key >> 16, bin, 1);
                     }
             }
         }
@@ -814,13 +864,13 @@ __global__ __launch_bounds__(1024, 4) void k_split_records(const uint32_t *__res
                     *reinterpret_cast<pu4_t *>(lds32 + e.x + lane * 4) =
                         *reinterpret_cast<const pu4_t *>(src + full * LINE4 + lane * 4);
             }
-            if (lane == 0) L.cnt[s] = left;
+            if (lane == 0) { L.cnt[s] = left; if (full) atomicAdd(&L.nfwd, full * LINE4); }
         }
         {
             const uint32_t nq = min(L.missn[par], V3_MISSQ);
             for (uint32_t i = tid; i < nq; i += BLOCK) {
                 const uint32_t key = L.missq[par][i];
-                if (!ov_add(L.ov_key, L.ov_cnt, key, 1u)) v2_global_add(counts, ranges, key >> 16, key & 0xffffu, 1);
+                if (!ov_add(L.ov_key, L.ov_cnt, key, 1u)) v3_global_add(counts, ranges, key >> 16, key & 0xffffu, 1);
             }
         }
         __syncthreads();
@@ -858,9 +908,14 @@ __global__ __launch_bounds__(1024, 4) void k_split_records(const uint32_t *__res
             const uint32_t *src = lds32 + L.pt[s].x;
             for (uint32_t i = 0; i < left; i++) records[(size_t)cb * CHUNK + cf + i] = src[i];
             L.cfill[s] = cf + left;
+            atomicAdd(&L.nfwd, left);
         }
     }
     __syncthreads();
+    if (tid == 0) { // self-metrics: records forwarded to the reduce pass, records that found a region full
+        atomicAdd(&g_stats[2], L.nfwd);
+        if (L.ovn) atomicAdd(&g_stats[3], L.ovn);
+    }
     if (tid < ns && L.cbase[tid] != INVALID) cdesc[L.cbase[tid]] = (((tid << V3_LOG_NP) | p1) << CD_SHIFT) | L.cfill[tid];
 
     // ---- flush the windows of the names counted here and the overflow table
@@ -907,12 +962,9 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
                                                          const uint32_t *__restrict__ slots,
                                                          const uint32_t *__restrict__ nslots, uint32_t nmetrics,
                                                          uint32_t log_mpp2, uint32_t log_w,
-                                                         const uint8_t *__restrict__ g_inv,
-                                                         const uint32_t *__restrict__ g_cnt,
-                                                         const uint32_t *__restrict__ g_mninv,
-                                                         const uint32_t *__restrict__ g_mx,
-                                                         const unsigned long long *__restrict__ g_sum,
-                                                         uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges)
+                                                         const uint8_t *__restrict__ g_inv, const SurveyStat S,
+                                                         uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
+                                                         uint32_t *__restrict__ g_stats)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *h = reinterpret_cast<uint32_t *>(smem);
@@ -936,8 +988,8 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
         const uint32_t m = ((uint32_t)g_inv[p1 * 256u + (fine << log_mpp2) + tid] << V3_LOG_NP) | p1;
         uint32_t svc = 0, svm = 0;
         if (m < nmetrics) {
-            svc = g_cnt[m];
-            if (svc) svm = (uint32_t)(g_sum[m] / svc);
+            svc = sv_count(S, m);
+            svm = sv_mean(S, m);
         }
         s_name[tid] = m < nmetrics ? m : INVALID;
         s_svc[tid] = svc;
@@ -958,8 +1010,8 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
         uint32_t mn = s_mn[tid], mx = s_mx[tid];
         const uint32_t m = s_name[tid];
         if (mn == INVALID && m != INVALID && s_svc[tid]) {
-            mn = 65535u - g_mninv[m];
-            mx = g_mx[m];
+            mn = 65535u - S.mninv[m];
+            mx = S.mx[m];
         }
         s_org[tid] = v3_place(mn, mx, s_svc[tid], s_svm[tid], W);
         s_mn[tid] = INVALID; // reused as the flush ranges
@@ -972,11 +1024,15 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
 #pragma unroll
         for (uint32_t k = 0; k < CHUNK / 256; k++) dst[k] = __builtin_nontemporal_load(src + k * 64);
     };
+    uint32_t nmiss = 0; // records outside their window (self-metric)
     auto add_one = [&](uint32_t rec, uint32_t c) {
         const uint32_t l = (rec >> 16) & 0xffu, b = rec & 0xffffu;
         const uint32_t rel = b - s_org[l];
         if (rel < W) atomicAdd(&h[(l << log_w) + rel], c);
-        else if (!ov_add(ov_key, ov_cnt, (l << 16) | b, c)) p2_global_add(counts, ranges, s_name[l], b, c);
+        else {
+            nmiss += c;
+            if (!ov_add(ov_key, ov_cnt, (l << 16) | b, c)) p2_global_add(counts, ranges, s_name[l], b, c);
+        }
     };
     auto reduce_chunk = [&](const u4_t (&r4)[CHUNK / 256], uint32_t cn) {
         const bool full = cn == CHUNK; // wave-uniform
@@ -1029,6 +1085,11 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
             }
         }
     }
+    if (__builtin_amdgcn_ballot_w64(nmiss != 0) != 0ull) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) nmiss += __shfl_xor(nmiss, d, 64);
+        if (lane == 0) atomicAdd(&g_stats[4], nmiss);
+    }
     __syncthreads();
 
     for (uint32_t i = tid; i < words; i += P2_BLOCK) {
@@ -1048,6 +1109,21 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
         uint32_t *r = ranges + 2 * (size_t)s_name[tid];
         if (s_mn[tid] < r[0]) atomicMin(&r[0], s_mn[tid]);
         if (s_mx[tid] > r[1]) atomicMax(&r[1], s_mx[tid]);
+    }
+}
+
+// Last kernel of a launch: the launch's self-metrics (g_stats, device memory, zero again afterwards) are added to the
+// engine's pinned words.  One thread: a system-scope atomic from every workgroup of the passes above cost 0.18 ms
+// per launch (256 of them on one host address).
+//   rstat[0] level-1 region overflows (the engine's clustered-stream switch)  [2] level-1 records  [3] records
+//   forwarded by level 2  [4] level-2 region overflows  [5] reduce-pass window misses
+__global__ void k_v3_report(uint32_t *__restrict__ g_stats, unsigned long long *__restrict__ rstat)
+{
+    if (threadIdx.x < 5) {
+        const uint32_t v = g_stats[threadIdx.x];
+        g_stats[threadIdx.x] = 0;
+        const uint32_t at = threadIdx.x == 0 ? 0u : threadIdx.x + 1u;
+        if (v && rstat) __hip_atomic_fetch_add(rstat + at, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1094,7 +1170,7 @@ static bool make_plan3(size_t n, uint32_t nmetrics, int num_cus, const PartTunin
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~size_t(255); return at; };
     // the survey's tables first: their offsets depend on the name count only, so every sub-launch of a call finds them
-    P.off_stat = take((size_t)nmetrics * 20 + 8);
+    P.off_stat = take((size_t)nmetrics * 16);
     P.off_aux = take((size_t)AUX_WORDS * 4);
     P.off_hk = take((size_t)V3_HN * sizeof(pu2_t));
     P.off_hs = take((size_t)V2_MAX_SLOTS * sizeof(pu4_t));
@@ -1162,13 +1238,14 @@ hipError_t launch_ingest_pairs_part3(const uint32_t *d_ids, const double *d_v, s
     unsigned char *base = static_cast<unsigned char *>(scratch);
     const LevelPtrs L1 = level_ptrs(base, P.off_rec1, P.off_cd1, P.off_sorted1, P.off_small1, V3_NP, V3_EXTRA1);
     const LevelPtrs L2 = level_ptrs(base, P.off_rec2, P.off_cd2, P.off_sorted2, P.off_small2, P.nq, V3_EXTRA2);
-    uint32_t *g_cnt = reinterpret_cast<uint32_t *>(base + P.off_stat);
-    uint32_t *g_mninv = g_cnt + nmetrics, *g_mx = g_mninv + nmetrics;
-    unsigned long long *g_sum = reinterpret_cast<unsigned long long *>(g_mx + nmetrics + (nmetrics & 1u));
+    unsigned long long *g_cs = reinterpret_cast<unsigned long long *>(base + P.off_stat);
+    uint32_t *g_mninv = reinterpret_cast<uint32_t *>(g_cs + nmetrics), *g_mx = g_mninv + nmetrics;
+    const SurveyStat S{g_cs, g_mninv, g_mx};
     uint32_t *g_aux = reinterpret_cast<uint32_t *>(base + P.off_aux);
     pu2_t *g_hk = reinterpret_cast<pu2_t *>(base + P.off_hk);
     pu4_t *g_hs = reinterpret_cast<pu4_t *>(base + P.off_hs);
     uint32_t *g_hdr = reinterpret_cast<uint32_t *>(base + P.off_hdr);
+    uint32_t *g_stats = g_hdr + 8; // self-metrics of the launch (zeroed below, read and zeroed by k_v3_report)
     pu2_t *g_pt = reinterpret_cast<pu2_t *>(base + P.off_pt);
     uint8_t *g_remap = base + P.off_remap, *g_inv = base + P.off_inv;
     pu2_t *g_pt2 = reinterpret_cast<pu2_t *>(base + P.off_pt2);
@@ -1181,6 +1258,8 @@ hipError_t launch_ingest_pairs_part3(const uint32_t *d_ids, const double *d_v, s
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(L2.pc, 0, small_words(P.nq, V3_EXTRA2) * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
+    e = hipMemsetAsync(g_stats, 0, 8 * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
     if (survey_n) {
         // stat and aux are adjacent (both multiples of 256 bytes apart): one memset
         e = hipMemsetAsync(base + P.off_stat, 0, P.off_hk - P.off_stat, s);
@@ -1188,18 +1267,17 @@ hipError_t launch_ingest_pairs_part3(const uint32_t *d_ids, const double *d_v, s
         const size_t sv_tiles = (survey_n / 2 + 1023) / 1024;
         const unsigned sv_grid = (unsigned)std::min<size_t>(SVH_GRID, std::max<size_t>(1, sv_tiles));
         hipLaunchKernelGGL(k_survey_count_h, dim3(sv_grid), dim3(1024), 5 * SVH_SLOTS * 4, s, d_ids, d_v, survey_n,
-                           nmetrics, d_Tx, g_cnt, g_mninv, g_mx, g_sum);
-        hipLaunchKernelGGL(k_survey_pick, dim3((nmetrics + 1023) / 1024), dim3(1024), 0, s, g_cnt, g_mninv, g_mx,
-                           nmetrics, g_aux);
-        hipLaunchKernelGGL(k_survey_plan_h, dim3(1), dim3(V2_BLOCK), 0, s, g_cnt, g_mninv, g_mx, g_sum, g_aux, P.cells,
-                           V3_TILE, g_hk, g_hs, g_pt, g_hdr, span_stat);
-        hipLaunchKernelGGL(k_survey_remap, dim3(V3_NP), dim3(256), 0, s, g_cnt, nmetrics, P.kp, P.log_mpp2, P.ns,
+                           nmetrics, d_Tx, g_cs, g_mninv, g_mx);
+        hipLaunchKernelGGL(k_survey_pick, dim3((nmetrics + 1023) / 1024), dim3(1024), 0, s, S, nmetrics, g_aux);
+        hipLaunchKernelGGL(k_survey_plan_h, dim3(1), dim3(V2_BLOCK), 0, s, S, g_aux, P.cells, V3_TILE, g_hk, g_hs, g_pt,
+                           g_hdr, span_stat);
+        hipLaunchKernelGGL(k_survey_remap, dim3(V3_NP), dim3(256), 0, s, S, g_hk, nmetrics, P.kp, P.log_mpp2, P.ns,
                            g_remap, g_inv, g_pt2);
     }
     const size_t nt_full = n / V3_TILE, done = nt_full * V3_TILE;
     hipLaunchKernelGGL(k_scatter4<4>, dim3(P.g1), dim3(1024), P.lds_dyn, s, d_ids, d_v, nt_full, nmetrics, d_Tx, g_hk,
                        g_hs, g_hdr, g_pt, P.region_words, P.cells, L1.records, L1.cdesc, P.chunks_per_wg, counts, ranges,
-                       d_err, region_stat);
+                       d_err, g_stats);
     if (done < n) {
         e = launch_ingest_pairs(d_ids + done, d_v + done, n - done, counts, ranges, nmetrics, d_Tx, d_err, num_cus, s);
         if (e != hipSuccess) return e;
@@ -1208,12 +1286,13 @@ hipError_t launch_ingest_pairs_part3(const uint32_t *d_ids, const double *d_v, s
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_split_records, dim3(V3_NP + V3_EXTRA1), dim3(1024), SPLIT_LDS_BYTES, s, L1.records, L1.cdesc,
                        L1.sorted, L1.part_start, L1.slots, L1.nslots, L1.pool_start, nmetrics, P.kp, P.log_mpp2,
-                       P.log_w, P.ns, g_remap, g_inv, g_pt2, g_cnt, g_mninv, g_mx, g_sum, L2.records, L2.cdesc, counts,
-                       ranges, dbg);
+                       P.log_w, P.ns, g_remap, g_inv, g_pt2, S, L2.records, L2.cdesc, counts,
+                       ranges, g_stats, dbg);
     e = run_plan(L2, P.nchunks2, P.nq, 0u, V3_EXTRA2, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_part_hist3, dim3(P.nq + V3_EXTRA2), dim3(P2_BLOCK), P3_LDS_BYTES, s, L2.records, L2.cdesc,
-                       L2.sorted, L2.part_start, L2.slots, L2.nslots, nmetrics, P.log_mpp2, P.log_w, g_inv, g_cnt,
-                       g_mninv, g_mx, g_sum, counts, ranges);
+                       L2.sorted, L2.part_start, L2.slots, L2.nslots, nmetrics, P.log_mpp2, P.log_w, g_inv, S,
+                       counts, ranges, g_stats);
+    hipLaunchKernelGGL(k_v3_report, dim3(1), dim3(64), 0, s, g_stats, region_stat);
     return hipGetLastError();
 }

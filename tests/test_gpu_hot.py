@@ -94,8 +94,10 @@ def test_hot_windows_with_bad_ids_and_two_launches_per_epoch(native_lib, torch_c
     keep[[3, 1_000_000, n - 1]] = False
     with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
         e.set_option(N.OPT_HOT_MIN_TILES, 1)
-        e.submit_pairs_device(_dev(torch_cuda, ids), _dev(torch_cuda, v))      # two launches into one epoch:
-        e.submit_pairs_device(_dev(torch_cuda, bad), _dev(torch_cuda, v))      # windows flush twice into the same rows
+        # (the device arrays must outlive the launches: the engine's stream is not one torch's allocator knows about)
+        d_ids, d_bad, d_v = _dev(torch_cuda, ids), _dev(torch_cuda, bad), _dev(torch_cuda, v)
+        e.submit_pairs_device(d_ids, d_v)      # two launches into one epoch:
+        e.submit_pairs_device(d_bad, d_v)      # windows flush twice into the same rows
         with pytest.raises(loghisto_amd.LhError) as ei:
             e.sync()
         assert ei.value.code == 6

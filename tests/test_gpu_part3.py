@@ -163,8 +163,10 @@ def test_bad_ids_sublaunches_and_two_launches_per_epoch(native_lib, torch_cuda):
     with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
         e.set_option(N.OPT_PART_V3_MIN_PAIRS, 1 << 17)
         e.set_option(N.OPT_SUBLAUNCH_PAIRS, 1 << 22)       # 3 sub-launches per call, one survey per call
-        e.submit_pairs_device(_dev(torch_cuda, ids), _dev(torch_cuda, v))
-        e.submit_pairs_device(_dev(torch_cuda, bad), _dev(torch_cuda, v))
+        # (the device arrays must outlive the launches: the engine's stream is not one torch's allocator knows about)
+        d_ids, d_bad, d_v = _dev(torch_cuda, ids), _dev(torch_cuda, bad), _dev(torch_cuda, v)
+        e.submit_pairs_device(d_ids, d_v)
+        e.submit_pairs_device(d_bad, d_v)
         with pytest.raises(loghisto_amd.LhError) as ei:
             e.sync()
         assert ei.value.code == 6

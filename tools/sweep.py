@@ -72,7 +72,10 @@ def main():
                           "occupied_buckets": int(st["nbuckets"].sum()), "opts": a.opt,
                           "v2_samples": eng.counters()["samples_partitioned_v2"],
                           "region_overflows": eng.counters()["region_overflows"],
-                          "regions_disabled": eng.counters()["regions_disabled"]}), flush=True)
+                          "regions_disabled": eng.counters()["regions_disabled"],
+                          "v3": {k: eng.counters()[k] for k in ("samples_partitioned_v3", "window_log2", "records_level1",
+                                                                "records_level2", "level2_overflows",
+                                                                "reduce_window_misses")}}), flush=True)
         del data
     eng.close()
 

@@ -9,4 +9,7 @@ from loghisto_amd import _native  # noqa: E402
 _native.LIB_PATH = os.path.abspath(sys.argv[1])
 import pytest  # noqa: E402
 
-sys.exit(pytest.main(["tests/test_gpu_part2.py", "-x", "-q", "-k", "direct or clustered or threshold"] + sys.argv[2:]))
+args = sys.argv[2:]
+if not any(a.startswith("tests/") for a in args):
+    args = ["tests/test_gpu_part2.py", "-k", "direct or clustered or threshold"] + args
+sys.exit(pytest.main(["-x", "-q"] + args))
