@@ -548,13 +548,33 @@ def run_c5(seconds=3.0):
                        "exact": bool(j["lossless"])}}
 
 
+def self_launch(n_gpus: int) -> int:
+    """`python bench.py --gpus N` started directly (no launcher in the environment): run this same command line under
+    torch.distributed.run, one rank per GPU of this node, rendezvous on 127.0.0.1.  Rank 0 of the child job prints
+    the JSON line; this process only relays the children's output and exit status.  LH_BENCH_LAUNCHER replaces the
+    launcher module's command prefix (tests/test_bench_launch.py uses it to look at the command without GPUs)."""
+    import shlex
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    launcher = os.environ.get("LH_BENCH_LAUNCHER")
+    prefix = shlex.split(launcher) if launcher else [sys.executable, "-m", "torch.distributed.run"]
+    cmd = prefix + ["--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1", "--master-port",
+                    str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path")
     torch.cuda.set_device(local_rank)
@@ -608,8 +628,13 @@ def main():
             args.no_parity = saved
             dist.barrier()
         res = run_c4(args, la, stream, rank, world, dist, args.steps, args.warmup)
+        res["value_per_gpu"] = res["value"] / world
         if ref is not None:
             res["one_rank_reference"] = ref
+            if ref.get("value"):
+                # the same workload's one-rank point, for a curve: the driver's N = 1 line is the C2 headline (one metric,
+                # 8 B per sample), a different workload from this one (65 536 names, 12 B per pair, merge at the flip)
+                res["efficiency_vs_one_rank"] = res["value"] / (world * ref["value"])
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

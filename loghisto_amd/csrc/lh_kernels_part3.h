@@ -950,6 +950,325 @@ __global__ __launch_bounds__(1024, 4) void k_split_records(const uint32_t *__res
 }
 
 // ---------------------------------------------------------------------------
+// Level 2 without workgroup barriers (at most 16 fine partitions per partition, i.e. windows of 1 024 or 2 048 bins).
+// k_split_records runs in lock step: classify a tile, barrier, copy lines out, barrier -- measured 4.2 us per
+// 8 192-record tile with the waves waiting at barriers for two thirds of it.  Here every WAVE owns its regions (one per
+// fine partition, 800 words of LDS per wave in all) and its open chunks, walks its own chunks of the slot (wave,
+// wave + 16, ...) and flushes after every 512 records; the 16 waves of the workgroup only share the windows of the
+// names counted here (LDS atomics), the chunk pool (one LDS counter) and the small overflow table.  No barrier
+// between setup and drain, so each wave's LDS round trips and loads hide behind the other fifteen.
+// ---------------------------------------------------------------------------
+constexpr uint32_t SW_WAVES = 16, SW_MAX_NS = 16, SW_AREA = SPLIT_REG_WORDS / SW_WAVES; // 800 words per wave
+struct SplitWLds {
+    uint32_t cnt[SW_WAVES * SW_MAX_NS], cfill[SW_WAVES * SW_MAX_NS], cbase[SW_WAVES * SW_MAX_NS];
+    pu2_t pt[SW_MAX_NS]; // fine partition -> {first word of its region inside a wave's area, capacity in records}
+    uint32_t ov_key[OV_SLOTS], ov_cnt[OV_SLOTS];
+    uint32_t dummy[64];
+    uint32_t pool_next, ovn, nfwd, pad0[1];
+    uint32_t tbl[256];
+    uint32_t name[32], mn[32], mx[32], svc[32], svm[32], org[32];
+};
+static_assert(sizeof(SplitWLds) % 16 == 0, "the regions follow the struct in LDS");
+constexpr size_t SPLITW_LDS_BYTES = sizeof(SplitWLds) + (size_t)(SPLIT_REG_WORDS + PEEL_WORDS) * 4;
+static_assert(SPLITW_LDS_BYTES <= 160 * 1024, "level 2 must fit one CU's LDS");
+
+__global__ __launch_bounds__(1024, 4) void k_split_waves(const uint32_t *__restrict__ in_records,
+                                                         const uint32_t *__restrict__ in_cdesc,
+                                                         const uint32_t *__restrict__ in_sorted,
+                                                         const uint32_t *__restrict__ in_part_start,
+                                                         const uint32_t *__restrict__ in_slots,
+                                                         const uint32_t *__restrict__ in_nslots,
+                                                         const uint32_t *__restrict__ pool_start, uint32_t nmetrics,
+                                                         uint32_t kp, uint32_t log_mpp2, uint32_t log_w, uint32_t log_ns,
+                                                         const uint8_t *__restrict__ g_remap,
+                                                         const uint8_t *__restrict__ g_inv,
+                                                         const pu2_t *__restrict__ g_pt2, const SurveyStat S,
+                                                         uint32_t *__restrict__ records, uint32_t *__restrict__ cdesc,
+                                                         uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
+                                                         uint32_t *__restrict__ g_stats)
+{
+    constexpr int BLOCK = 1024;
+    extern __shared__ __attribute__((aligned(16))) unsigned char v3_smem[];
+    SplitWLds &L = *reinterpret_cast<SplitWLds *>(v3_smem);
+    uint32_t *lds32 = reinterpret_cast<uint32_t *>(v3_smem);
+    constexpr uint32_t REG_W = sizeof(SplitWLds) / 4, WIN_W = REG_W + SPLIT_REG_WORDS;
+    constexpr uint32_t CNT_W = offsetof(SplitWLds, cnt) / 4, DUMMY_W = offsetof(SplitWLds, dummy) / 4;
+    uint32_t *win = lds32 + WIN_W;
+    const uint32_t slot = blockIdx.x;
+    if (slot >= *in_nslots) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t p1 = in_slots[3 * slot], first = in_slots[3 * slot + 1], cnt = in_slots[3 * slot + 2];
+    const uint32_t *list = in_sorted + in_part_start[p1] + first;
+    const uint32_t pool_base = pool_start[slot];
+    const uint32_t W = 1u << log_w, mmask = (1u << log_mpp2) - 1u, ns = 1u << log_ns;
+
+    // ---- setup (as k_split_records): rank table, the names counted here, window origins
+    const uint32_t c0 = list[0];
+    const uint32_t n0 = in_cdesc[c0] & CD_MASK;
+    const uint32_t srec = tid < n0 ? in_records[(size_t)c0 * CHUNK + tid] : 0u;
+    if (tid < 256) L.tbl[tid] = g_remap[p1 * 256u + tid];
+    if (tid < 32) {
+        uint32_t name = INVALID, mn = INVALID, mx = 0, svc = 0, svm = 0;
+        if (tid < kp) {
+            const uint32_t m = ((uint32_t)g_inv[p1 * 256u + tid] << V3_LOG_NP) | p1;
+            if (m < nmetrics) {
+                name = m;
+                svc = sv_count(S, m);
+                if (svc) {
+                    mn = 65535u - S.mninv[m];
+                    mx = S.mx[m];
+                    svm = sv_mean(S, m);
+                }
+            }
+        }
+        L.name[tid] = name;
+        L.mn[tid] = mn;
+        L.mx[tid] = mx;
+        L.svc[tid] = svc;
+        L.svm[tid] = svm;
+    }
+    for (uint32_t i = tid; i < kp << log_w; i += BLOCK) win[i] = 0;
+    if (tid < SW_WAVES * SW_MAX_NS) { L.cnt[tid] = 0; L.cfill[tid] = CHUNK; L.cbase[tid] = INVALID; }
+    if (tid < SW_MAX_NS) {
+        // a wave's share of the partition's region layout (k_survey_remap): 1/16 of every capacity
+        uint32_t off = 0, cap = 0;
+        if (tid < ns) {
+            for (uint32_t i = 0; i <= tid; i++) {
+                const uint32_t c = (g_pt2[p1 * V3_MAX_NS + i].y / SW_WAVES) & ~3u;
+                if (i < tid) off += c; else cap = c;
+            }
+        }
+        L.pt[tid] = (pu2_t){off, cap};
+    }
+    ov_init(L.ov_key, L.ov_cnt, tid, BLOCK);
+    if (tid == 0) { L.pool_next = 0; L.ovn = 0; L.nfwd = 0; }
+    __syncthreads();
+    if (tid < n0) {
+        const uint32_t r = L.tbl[(srec >> 16) & 0xffu], b = srec & 0xffffu;
+        if (r < kp) {
+            if (b < L.mn[r]) atomicMin(&L.mn[r], b);
+            if (b > L.mx[r]) atomicMax(&L.mx[r], b);
+        }
+    }
+    __syncthreads();
+    if (tid < 32) L.org[tid] = v3_place(L.mn[tid], L.mx[tid], L.svc[tid], L.svm[tid], W);
+    __syncthreads();
+    if (tid < 256) {
+        const uint32_t r = L.tbl[tid];
+        L.tbl[tid] = r | ((r < kp ? L.org[r] : 0u) << 8);
+    }
+    __syncthreads();
+
+    // ---- this wave's chunks
+    const uint32_t wreg = REG_W + wave * SW_AREA;      // first word of this wave's regions
+    const uint32_t wcnt = CNT_W + wave * SW_MAX_NS;    // word offset of this wave's region counters
+    uint32_t novf = 0, nfwd = 0;                       // self-metrics (per lane, summed at the end)
+    // flush: lane group g = lane >> gsh owns fine partition g (8 lanes each at ns = 8, 4 at ns = 16); lane q of the
+    // group copies 16-byte piece q & 3 of lines q >> 2, q >> 2 + G / 4, ..
+    const uint32_t gsh = 6u - log_ns, G = 1u << gsh, fs = lane >> gsh, fq = lane & (G - 1u);
+    const pu2_t fpe = L.pt[fs];
+    const uint32_t ftag = ((fs << V3_LOG_NP) | p1) << CD_SHIFT;
+    auto classify8 = [&](const u4_t &a, const u4_t &b, uint32_t base_idx, uint32_t cn) {
+        // records a.x .. a.w sit at base_idx + lane * 4 + 0 .. 3, b's 256 records later
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const u4_t &r4 = j ? b : a;
+            const uint32_t rr[4] = {r4.x, r4.y, r4.z, r4.w};
+            uint32_t t[4], where[4], rank[4], rec[4];
+            pu2_t pe[4];
+            uint32_t fwd = 0, full = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) t[k] = L.tbl[(rr[k] >> 16) & 0xffu];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool valid = base_idx + (uint32_t)j * 256u + lane * 4u + (uint32_t)k < cn;
+                const uint32_t nw = t[k] & 0xffu, bin = rr[k] & 0xffffu, rel = bin - (t[k] >> 8);
+                const bool here = valid && nw < kp && rel < W;
+                const uint32_t fine = (nw >> log_mpp2) & (SW_MAX_NS - 1u);
+                where[k] = here ? WIN_W + (nw << log_w) + rel : valid ? wcnt + fine : DUMMY_W + lane;
+                rec[k] = (fine << 24) | ((nw & mmask) << 16) | bin;
+                pe[k] = L.pt[fine];
+                if (valid && !here) fwd |= 1u << k;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) rank[k] = atomicAdd(lds32 + where[k], 1u);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool fits = (fwd & (1u << k)) && rank[k] < pe[k].y;
+                if ((fwd & (1u << k)) && !fits) full |= 1u << k;
+                lds32[fits ? wreg + pe[k].x + rank[k] : DUMMY_W + lane] = rec[k];
+            }
+            if (full) { // this wave's region of the fine partition is full: the record is counted exactly right away
+                novf += (uint32_t)__popc(full);
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (full & (1u << k)) {
+                        const uint32_t old = (rr[k] >> 16) & 0xffu, bin = rr[k] & 0xffffu;
+                        const uint32_t id = (old << V3_LOG_NP) | p1;
+                        if (!ov_add(L.ov_key, L.ov_cnt, (id << 16) | bin, 1u)) v3_global_add(counts, ranges, id, bin, 1);
+                    }
+            }
+        }
+    };
+    auto flush = [&]() {
+        // the stores above and the reads below belong to the same wave: LDS executes a wave's operations in order
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (fs < ns) {
+            const uint32_t c = min(lds32[wcnt + fs], fpe.y), full = c / LINE4, left = c % LINE4;
+            if (full) {
+                const uint32_t ci = wave * SW_MAX_NS + fs;
+                const uint32_t cf = L.cfill[ci], cb = L.cbase[ci];
+                const uint32_t room = (CHUNK - cf) / LINE4;
+                uint32_t firstc = 0;
+                if (fq == 0) {
+                    if (full > room) {
+                        const uint32_t over = full - room;
+                        const uint32_t k = (over + CHUNK / LINE4 - 1) / (CHUNK / LINE4);
+                        firstc = pool_base + atomicAdd(&L.pool_next, k);
+                        if (cb != INVALID) hidden_store_u32(cdesc + cb, ftag | CHUNK);
+#pragma nounroll
+                        for (uint32_t i = 0; i + 1 < k; i++) hidden_store_u32(cdesc + firstc + i, ftag | CHUNK);
+                        L.cbase[ci] = firstc + k - 1;
+                        L.cfill[ci] = (over - (k - 1) * (CHUNK / LINE4)) * LINE4;
+                    } else {
+                        L.cfill[ci] = cf + full * LINE4;
+                    }
+                    nfwd += full * LINE4;
+                }
+                firstc = __shfl(firstc, lane & ~(G - 1u), 64); // the group leader's value
+                const uint32_t dA = cb * CHUNK + cf, dB = firstc * CHUNK - room * LINE4;
+                const uint32_t *src = lds32 + wreg + fpe.x;
+#pragma nounroll
+                for (uint32_t l = fq >> 2; l < full; l += G / 4) {
+                    const uint32_t dst = (l < room ? dA : dB) + l * LINE4;
+                    const pu4_t r4 = *reinterpret_cast<const pu4_t *>(src + l * LINE4 + (fq & 3u) * 4);
+                    hidden_store_u4(records + dst + (fq & 3u) * 4, r4);
+                }
+                // the last partial line moves to the front (after every read of line 0: same wave, in order)
+                if (fq < 4 && fq * 4 < left)
+                    *reinterpret_cast<pu4_t *>(lds32 + wreg + fpe.x + fq * 4) =
+                        *reinterpret_cast<const pu4_t *>(src + full * LINE4 + fq * 4);
+                if (fq == 0) lds32[wcnt + fs] = left;
+            } else if (fq == 0 && c != lds32[wcnt + fs]) {
+                lds32[wcnt + fs] = c; // (overflowed without filling a line: cannot happen with capacities >= 16)
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto load_chunk = [&](uint32_t cidx, u4_t (&dst)[CHUNK / 256]) {
+        const u4_t *src = reinterpret_cast<const u4_t *>(in_records + (size_t)cidx * CHUNK) + lane;
+#pragma unroll
+        for (uint32_t k = 0; k < CHUNK / 256; k++) dst[k] = __builtin_nontemporal_load(src + k * 64);
+    };
+    constexpr uint32_t WSTEP = BLOCK / 64, DEPTH = 2;
+    u4_t buf[DEPTH][CHUNK / 256];
+    uint32_t cn[DEPTH];
+    const uint32_t mine = cnt > wave ? (cnt - wave + WSTEP - 1) / WSTEP : 0u; // chunks of this wave
+    for (uint32_t b0 = 0; b0 < mine; b0 += 64) {
+        const uint32_t nb = min(mine - b0, 64u);
+        uint32_t my_cid = 0, my_cn = 0;
+        if (lane < nb) {
+            my_cid = list[wave + (b0 + lane) * WSTEP];
+            my_cn = in_cdesc[my_cid] & CD_MASK;
+        }
+        auto fetch = [&](uint32_t k, uint32_t at) { // k: position in the batch (wave-uniform)
+            const uint32_t kk = min(k, nb - 1u);
+            const uint32_t cid = __builtin_amdgcn_readlane(my_cid, kk);
+            cn[at] = __builtin_amdgcn_readlane(my_cn, kk);
+            load_chunk(cid, buf[at]);
+        };
+#pragma unroll
+        for (uint32_t d = 0; d < DEPTH; d++) fetch(d, d);
+        for (uint32_t k = 0; k < nb; k += DEPTH) {
+#pragma unroll
+            for (uint32_t d = 0; d < DEPTH; d++) {
+                if (k + d < nb) { // wave-uniform
+                    classify8(buf[d][0], buf[d][1], 0u, cn[d]);
+                    flush();
+                    if (cn[d] > 512u) {
+                        classify8(buf[d][2], buf[d][3], 512u, cn[d]);
+                        flush();
+                    }
+                }
+                fetch(k + d + DEPTH, d);
+            }
+        }
+    }
+
+    // ---- drain: leftovers (< one line per wave and fine partition) and the open chunks' descriptors
+    {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            novf += __shfl_xor(novf, d, 64);
+            nfwd += __shfl_xor(nfwd, d, 64);
+        }
+    }
+    __syncthreads();
+    if (tid < SW_WAVES * SW_MAX_NS) {
+        const uint32_t w = tid / SW_MAX_NS, fsub = tid % SW_MAX_NS, left = L.cnt[tid];
+        if (fsub < ns && left) {
+            uint32_t cf = L.cfill[tid], cb = L.cbase[tid];
+            const uint32_t tag = ((fsub << V3_LOG_NP) | p1) << CD_SHIFT;
+            if (cf == CHUNK) {
+                if (cb != INVALID) cdesc[cb] = tag | CHUNK;
+                cb = pool_base + atomicAdd(&L.pool_next, 1u);
+                cf = 0;
+                L.cbase[tid] = cb;
+            }
+            const uint32_t *src = lds32 + REG_W + w * SW_AREA + L.pt[fsub].x;
+            for (uint32_t i = 0; i < left; i++) records[(size_t)cb * CHUNK + cf + i] = src[i];
+            L.cfill[tid] = cf + left;
+            atomicAdd(&L.nfwd, left);
+        }
+    }
+    if (lane == 0) {
+        if (nfwd) atomicAdd(&L.nfwd, nfwd);
+        if (novf) atomicAdd(&L.ovn, novf);
+    }
+    __syncthreads();
+    if (tid < SW_WAVES * SW_MAX_NS && (tid % SW_MAX_NS) < ns && L.cbase[tid] != INVALID)
+        cdesc[L.cbase[tid]] = ((((tid % SW_MAX_NS) << V3_LOG_NP) | p1) << CD_SHIFT) | L.cfill[tid];
+    if (tid == 0) { // self-metrics: records forwarded to the reduce pass, records that found a region full
+        atomicAdd(&g_stats[2], L.nfwd);
+        if (L.ovn) atomicAdd(&g_stats[3], L.ovn);
+    }
+
+    // ---- flush the windows of the names counted here and the overflow table
+    for (uint32_t r = wave; r < kp; r += BLOCK / 64) {
+        const uint32_t name = L.name[r];
+        if (name == INVALID) continue;
+        const uint32_t org = L.org[r];
+        uint32_t mn = INVALID, mx = 0;
+        for (uint32_t i = lane; i < W; i += 64) {
+            const uint32_t c = win[(r << log_w) + i];
+            if (c) {
+                const uint32_t b = org + i;
+                atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)name * LH_NKEYS + b]),
+                          (unsigned long long)c);
+                mn = min(mn, b);
+                mx = max(mx, b);
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            mn = min(mn, (uint32_t)__shfl_xor(mn, d, 64));
+            mx = max(mx, (uint32_t)__shfl_xor(mx, d, 64));
+        }
+        if (lane == 0 && mn != INVALID) {
+            uint32_t *rg = ranges + 2 * (size_t)name;
+            if (mn < rg[0]) atomicMin(&rg[0], mn);
+            if (mx > rg[1]) atomicMax(&rg[1], mx);
+        }
+    }
+    for (uint32_t i = tid; i < OV_SLOTS; i += BLOCK)
+        if (L.ov_key[i] != OV_EMPTY) v2_global_add(counts, ranges, L.ov_key[i] >> 16, L.ov_key[i] & 0xffffu, L.ov_cnt[i]);
+}
+
+// ---------------------------------------------------------------------------
 // Reduce: one workgroup per fine-partition work slot.  Fine partition q = fine << 8 | p1 holds the names of ranks
 // fine * mpp2 .. + mpp2 - 1 of level-1 partition p1; record = fine << 24 | rank % mpp2 << 16 | bin.
 // ---------------------------------------------------------------------------
@@ -1131,7 +1450,8 @@ __global__ void k_v3_report(uint32_t *__restrict__ g_stats, unsigned long long *
 // plan + launcher
 // ---------------------------------------------------------------------------
 struct Part3Plan {
-    uint32_t log_w, log_mpp2, mpp2, kp, mpp, ns, nq;
+    uint32_t log_w, log_mpp2, mpp2, kp, mpp, ns, log_ns, nq, extra1, extra2, pool_extra;
+    bool waves; // level 2 by k_split_waves (<= 16 fine partitions per partition)
     uint32_t region_words, cells, g1, chunks_per_wg, nchunks1, nchunks2;
     size_t lds_dyn;
     size_t off_stat, off_aux, off_hk, off_hs, off_hdr, off_pt, off_remap, off_inv, off_pt2;
@@ -1149,8 +1469,17 @@ static bool make_plan3(size_t n, uint32_t nmetrics, int num_cus, const PartTunin
     P.kp = PEEL_WORDS >> P.log_w;                // names counted in place by level 2: 24, 12, 6, 3
     P.mpp = (nmetrics + V3_NP - 1) >> V3_LOG_NP; // names per level-1 partition: 33 .. 256
     P.ns = 1;
-    while (P.ns * P.mpp2 < P.mpp) P.ns *= 2;     // fine partitions per level-1 partition: <= 64
+    P.log_ns = 0;
+    while (P.ns * P.mpp2 < P.mpp) { P.ns *= 2; P.log_ns++; } // fine partitions per level-1 partition: <= 64
     P.nq = V3_NP * P.ns;
+    P.waves = P.ns <= SW_MAX_NS;
+    // Work slots beyond one per partition.  Every level-2 slot zeroes and flushes 96 KiB of windows and every reduce
+    // slot 128 KiB, whatever it holds: a slot should see some 10^5 records (config 4's 1.25e8-pair slice: 494 and
+    // 2 167 slots instead of 1 024 and 3 072 saved 0.1 ms of 1.3).
+    P.extra1 = (uint32_t)std::min<size_t>(V3_EXTRA1, std::max<size_t>(64, n >> 19));
+    P.extra2 = (uint32_t)std::min<size_t>(V3_EXTRA2, std::max<size_t>(64, n >> 20));
+    // chunks a level-2 slot may strand partially filled: one per fine partition, and per wave in k_split_waves
+    P.pool_extra = (P.waves ? SW_WAVES : 1u) * P.ns + 1u;
     P.region_words = v3_region_words(V3_TILE);
     const size_t fixed = sizeof(Scatter4Lds) + (size_t)P.region_words * 4;
     P.cells = (uint32_t)((V2_LDS_TOTAL - fixed) / 4) & ~63u;
@@ -1166,7 +1495,7 @@ static bool make_plan3(size_t n, uint32_t nmetrics, int num_cus, const PartTunin
     P.chunks_per_wg = (uint32_t)(tiles_per_wg * (V3_TILE / CHUNK) + V3_NP + 1);
     P.nchunks1 = P.g1 * P.chunks_per_wg;
     // level 2: every level-1 slot re-scatters its chunks into <= cnt + ns + 1 chunks of its own pool
-    P.nchunks2 = P.nchunks1 + (V3_NP + V3_EXTRA1) * (P.ns + 1);
+    P.nchunks2 = P.nchunks1 + (V3_NP + P.extra1) * P.pool_extra;
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~size_t(255); return at; };
     // the survey's tables first: their offsets depend on the name count only, so every sub-launch of a call finds them
@@ -1182,11 +1511,11 @@ static bool make_plan3(size_t n, uint32_t nmetrics, int num_cus, const PartTunin
     P.off_rec1 = take((size_t)P.nchunks1 * CHUNK * sizeof(uint32_t));
     P.off_cd1 = take((size_t)P.nchunks1 * sizeof(uint32_t));
     P.off_sorted1 = take((size_t)P.nchunks1 * sizeof(uint32_t));
-    P.off_small1 = take(small_words(V3_NP, V3_EXTRA1) * sizeof(uint32_t));
+    P.off_small1 = take(small_words(V3_NP, P.extra1) * sizeof(uint32_t));
     P.off_rec2 = take((size_t)P.nchunks2 * CHUNK * sizeof(uint32_t));
     P.off_cd2 = take((size_t)P.nchunks2 * sizeof(uint32_t));
     P.off_sorted2 = take((size_t)P.nchunks2 * sizeof(uint32_t));
-    P.off_small2 = take(small_words(P.nq, V3_EXTRA2) * sizeof(uint32_t));
+    P.off_small2 = take(small_words(P.nq, P.extra2) * sizeof(uint32_t));
     P.total = o;
     return true;
 }
@@ -1216,6 +1545,9 @@ hipError_t launch_ingest_pairs_part3(const uint32_t *d_ids, const double *d_v, s
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_split_records),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPLIT_LDS_BYTES);
         if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_split_waves),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPLITW_LDS_BYTES);
+        if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_part_hist3),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)P3_LDS_BYTES);
         if (e == hipSuccess)
@@ -1236,8 +1568,8 @@ hipError_t launch_ingest_pairs_part3(const uint32_t *d_ids, const double *d_v, s
     const uint32_t dbg = 0;
 #endif
     unsigned char *base = static_cast<unsigned char *>(scratch);
-    const LevelPtrs L1 = level_ptrs(base, P.off_rec1, P.off_cd1, P.off_sorted1, P.off_small1, V3_NP, V3_EXTRA1);
-    const LevelPtrs L2 = level_ptrs(base, P.off_rec2, P.off_cd2, P.off_sorted2, P.off_small2, P.nq, V3_EXTRA2);
+    const LevelPtrs L1 = level_ptrs(base, P.off_rec1, P.off_cd1, P.off_sorted1, P.off_small1, V3_NP, P.extra1);
+    const LevelPtrs L2 = level_ptrs(base, P.off_rec2, P.off_cd2, P.off_sorted2, P.off_small2, P.nq, P.extra2);
     unsigned long long *g_cs = reinterpret_cast<unsigned long long *>(base + P.off_stat);
     uint32_t *g_mninv = reinterpret_cast<uint32_t *>(g_cs + nmetrics), *g_mx = g_mninv + nmetrics;
     const SurveyStat S{g_cs, g_mninv, g_mx};
@@ -1252,11 +1584,11 @@ hipError_t launch_ingest_pairs_part3(const uint32_t *d_ids, const double *d_v, s
 
     hipError_t e = hipMemsetAsync(L1.cdesc, 0xff, (size_t)P.nchunks1 * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(L1.pc, 0, small_words(V3_NP, V3_EXTRA1) * sizeof(uint32_t), s);
+    e = hipMemsetAsync(L1.pc, 0, small_words(V3_NP, P.extra1) * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(L2.cdesc, 0xff, (size_t)P.nchunks2 * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(L2.pc, 0, small_words(P.nq, V3_EXTRA2) * sizeof(uint32_t), s);
+    e = hipMemsetAsync(L2.pc, 0, small_words(P.nq, P.extra2) * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(g_stats, 0, 8 * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
@@ -1282,15 +1614,20 @@ hipError_t launch_ingest_pairs_part3(const uint32_t *d_ids, const double *d_v, s
         e = launch_ingest_pairs(d_ids + done, d_v + done, n - done, counts, ranges, nmetrics, d_Tx, d_err, num_cus, s);
         if (e != hipSuccess) return e;
     }
-    e = run_plan(L1, P.nchunks1, V3_NP, P.ns + 1, V3_EXTRA1, s);
+    e = run_plan(L1, P.nchunks1, V3_NP, P.pool_extra, P.extra1, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_split_records, dim3(V3_NP + V3_EXTRA1), dim3(1024), SPLIT_LDS_BYTES, s, L1.records, L1.cdesc,
-                       L1.sorted, L1.part_start, L1.slots, L1.nslots, L1.pool_start, nmetrics, P.kp, P.log_mpp2,
-                       P.log_w, P.ns, g_remap, g_inv, g_pt2, S, L2.records, L2.cdesc, counts,
-                       ranges, g_stats, dbg);
-    e = run_plan(L2, P.nchunks2, P.nq, 0u, V3_EXTRA2, s);
+    if (P.waves)
+        hipLaunchKernelGGL(k_split_waves, dim3(V3_NP + P.extra1), dim3(1024), SPLITW_LDS_BYTES, s, L1.records, L1.cdesc,
+                           L1.sorted, L1.part_start, L1.slots, L1.nslots, L1.pool_start, nmetrics, P.kp, P.log_mpp2,
+                           P.log_w, P.log_ns, g_remap, g_inv, g_pt2, S, L2.records, L2.cdesc, counts, ranges, g_stats);
+    else
+        hipLaunchKernelGGL(k_split_records, dim3(V3_NP + P.extra1), dim3(1024), SPLIT_LDS_BYTES, s, L1.records,
+                           L1.cdesc, L1.sorted, L1.part_start, L1.slots, L1.nslots, L1.pool_start, nmetrics, P.kp,
+                           P.log_mpp2, P.log_w, P.ns, g_remap, g_inv, g_pt2, S, L2.records, L2.cdesc, counts, ranges,
+                           g_stats, dbg);
+    e = run_plan(L2, P.nchunks2, P.nq, 0u, P.extra2, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_part_hist3, dim3(P.nq + V3_EXTRA2), dim3(P2_BLOCK), P3_LDS_BYTES, s, L2.records, L2.cdesc,
+    hipLaunchKernelGGL(k_part_hist3, dim3(P.nq + P.extra2), dim3(P2_BLOCK), P3_LDS_BYTES, s, L2.records, L2.cdesc,
                        L2.sorted, L2.part_start, L2.slots, L2.nslots, nmetrics, P.log_mpp2, P.log_w, g_inv, S,
                        counts, ranges, g_stats);
     hipLaunchKernelGGL(k_v3_report, dim3(1), dim3(64), 0, s, g_stats, region_stat);
