@@ -529,7 +529,7 @@ def run_hostfed(la, M=1024, total=int(8e8)):
             "parity": {"samples_conserved": cnt == per * T, "exact": cnt == per * T}}
 
 
-def run_c5(seconds=3.0):
+def run_c5(seconds=10.0):
     exe = os.path.join(ROOT, "loghisto_amd", "build", "c5_driver")
     if not os.path.exists(exe):
         return {"skipped": "loghisto_amd/build/c5_driver is not built"}

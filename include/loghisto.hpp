@@ -235,7 +235,9 @@ private:
     // counters: host side as in the reference (metrics.go:112-117), or -- Options::device_counters -- a mirror of
     // the lifetime store that lives in HBM (lh_counters_collect)
     std::mutex counter_store_mu_;
-    std::unordered_map<std::string, uint64_t> counter_store_;
+    std::unordered_map<std::string, uint64_t> counter_store_;        // lifetime totals as exported: device + host-staged
+    std::unordered_map<std::string, uint64_t> host_counter_store_;   // lifetime amounts that never reached the device
+    std::unordered_map<std::string, uint64_t> device_counter_total_; // last totals the device reported
     std::vector<std::string> counter_names_; // device counter id -> name (counter_store_mu_)
 
     // lifetime histogram aggregates (metrics.go:122-125)
@@ -283,7 +285,7 @@ public:
 private:
     bool connectIfNeeded();
     void disconnect();
-    bool submitBatch(const std::shared_ptr<const std::string> *requests, size_t n);
+    bool submitBatch(const std::shared_ptr<const std::string> *requests, size_t n, size_t *done);
     bool retryBacklog();
     void appendToBacklog(std::string request);
     MetricSystem *ms_;

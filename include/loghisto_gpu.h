@@ -166,8 +166,11 @@ int lh_extract_rows(lh_snapshot *s, uint32_t first, size_t nmetrics, const doubl
                     lh_stats *stats, double *pvals, int16_t *pkeys, uint8_t *pvalid);
 /* The same without the last copy: the results are handed out IN PLACE, in the engine's pinned result buffer (a
  * cgo caller wraps them as slices without copying; at 65 536 names the copy into caller arrays would cost more
- * than the scan).  The pointers stay valid until the next lh_extract* / lh_buckets* / lh_serialize* / merge call
- * on this engine or lh_release of the snapshot, whichever comes first. */
+ * than the scan).  The pointers point into the engine's one pinned result block, which every call that returns
+ * results through it rewrites (and may re-allocate): they stay valid until the next lh_extract*, lh_buckets*,
+ * lh_serialize*, lh_counters_collect, lh_lifetime, lh_format_f or lh_snapshot_merge call on this engine, or
+ * lh_release of the snapshot, whichever comes first.  A host layer that needs lifetime totals or counters for the
+ * same interval reads the view first (or copies what it keeps) and then makes those calls. */
 typedef struct lh_extract_view {
     const lh_stats *stats;   /* [nmetrics]      */
     const double *pvals;     /* [nmetrics * np] */

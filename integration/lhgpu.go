@@ -250,7 +250,10 @@ func (raw *RawMetricSet) fillCounters(g *gpuEngine) {
 	}
 }
 
-// Results in place for large name spaces: the library's own pinned arrays, valid until the next extract.
+// Results in place for large name spaces: the library's own pinned arrays.  Every call that returns results through
+// the engine's pinned block invalidates them (lh_extract*, lh_buckets*, lh_serialize*, lh_counters_collect,
+// lh_lifetime, lh_format_f, lh_snapshot_merge) and so does lh_release: the caller consumes the slices (or copies
+// what it keeps) BEFORE it asks for counters or lifetime totals of the same interval.
 func (ms *MetricSystem) extractView(raw *RawMetricSet, ps []C.double) (stats []C.lh_stats, pvals []C.double) {
 	n := len(ms.gpu.names)
 	var v C.lh_extract_view

@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <charconv>
+#include <cerrno>
 #include <cinttypes>
 #include <cmath>
 #include <cstdio>
@@ -380,16 +381,31 @@ std::shared_ptr<RawMetricSet> MetricSystem::collectRawMetrics()
         if (nc && note(lh_counters_collect(raw->snapshot, 0, nc, rate.data(), present.data(), total.data(), known.data()),
                        "lh_counters_collect") == LH_OK) {
             std::lock_guard<std::mutex> g(counter_store_mu_);
-            char buf[1024];
+            std::vector<char> buf(256);
             while (counter_names_.size() < nc) {
                 size_t len = 0;
                 const uint32_t id = (uint32_t)counter_names_.size();
-                if (lh_counter_name(engine_, id, buf, sizeof(buf), &len) != LH_OK) break;
-                counter_names_.emplace_back(buf, len < sizeof(buf) ? len : sizeof(buf));
+                if (lh_counter_name(engine_, id, buf.data(), buf.size(), &len) != LH_OK) break;
+                if (len > buf.size()) { // the whole name, whatever its length: a truncated name is a different key
+                    buf.resize(len);
+                    if (lh_counter_name(engine_, id, buf.data(), buf.size(), &len) != LH_OK) break;
+                }
+                counter_names_.emplace_back(buf.data(), len);
             }
+            // amounts staged on the host (Counter() calls made before the engine existed) are part of this interval's
+            // rates AND of the lifetime totals (metrics.go:435-458); the device only knows what was shipped to it
+            for (auto &kv : fresh) host_counter_store_[kv.first] += kv.second;
             for (uint32_t i = 0; i < nc && i < counter_names_.size(); i++) {
                 if (present[i]) fresh[counter_names_[i]] += rate[i];
-                if (known[i]) counter_store_[counter_names_[i]] = total[i];
+                if (known[i]) device_counter_total_[counter_names_[i]] = total[i];
+            }
+            counter_store_ = device_counter_total_;
+            for (auto &kv : host_counter_store_) counter_store_[kv.first] += kv.second;
+        } else {
+            std::lock_guard<std::mutex> g(counter_store_mu_);
+            for (auto &kv : fresh) {
+                host_counter_store_[kv.first] += kv.second;
+                counter_store_[kv.first] += kv.second;
             }
         }
         raw->Rates = fresh;
@@ -398,7 +414,10 @@ std::shared_ptr<RawMetricSet> MetricSystem::collectRawMetrics()
     } else {
         raw->Rates = fresh; // metrics.go:430-433
         std::lock_guard<std::mutex> g(counter_store_mu_); // metrics.go:435-458
-        for (auto &kv : fresh) counter_store_[kv.first] += kv.second;
+        for (auto &kv : fresh) {
+            host_counter_store_[kv.first] += kv.second;
+            counter_store_[kv.first] += kv.second;
+        }
         raw->Counters = counter_store_;
     }
     {
@@ -740,21 +759,40 @@ void Submitter::disconnect()
     fd_ = -1;
 }
 
-bool Submitter::submitBatch(const std::shared_ptr<const std::string> *requests, size_t n)
+// Sends requests[0 .. n) in order; *done receives how many were written completely (they must not be sent again).
+bool Submitter::submitBatch(const std::shared_ptr<const std::string> *requests, size_t n, size_t *done)
 {
+    *done = 0;
+    if (fd_ >= 0 && DestinationNetwork != "udp") {
+        // A kept connection whose peer has closed or restarted still accepts one write (the reference dials per
+        // request, submitter.go:106-116, and never meets this): look for the EOF before trusting it with a batch.
+        char c;
+        const ssize_t r = ::recv(fd_, &c, 1, MSG_PEEK | MSG_DONTWAIT);
+        if (r == 0 || (r < 0 && errno != EAGAIN && errno != EWOULDBLOCK && errno != EINTR)) disconnect();
+    }
     if (!connectIfNeeded()) return false;
     if (DestinationNetwork == "udp") {
-        for (size_t i = 0; i < n; i++)
+        for (size_t i = 0; i < n; i++) {
             if (::send(fd_, requests[i]->data(), requests[i]->size(), MSG_NOSIGNAL) != (ssize_t)requests[i]->size()) {
                 disconnect();
                 return false;
             }
+            *done = i + 1;
+        }
         return true;
     }
     iovec iov[60];
-    size_t cnt = 0;
-    for (size_t i = 0; i < n && cnt < 60; i++)
-        if (!requests[i]->empty()) iov[cnt++] = iovec{const_cast<char *>(requests[i]->data()), requests[i]->size()};
+    size_t req_of[60];
+    size_t cnt = 0, lead = 0; // lead: empty requests before the first non-empty one count as written
+    for (size_t i = 0; i < n && cnt < 60; i++) {
+        if (!requests[i]->empty()) {
+            req_of[cnt] = i;
+            iov[cnt++] = iovec{const_cast<char *>(requests[i]->data()), requests[i]->size()};
+        } else if (cnt == 0) {
+            lead = i + 1;
+        }
+    }
+    *done = cnt ? lead : n;
     size_t first = 0;
     while (first < cnt) {
         msghdr mh{};
@@ -763,12 +801,14 @@ bool Submitter::submitBatch(const std::shared_ptr<const std::string> *requests, 
         ssize_t w = ::sendmsg(fd_, &mh, MSG_NOSIGNAL); // writev with MSG_NOSIGNAL
         if (w <= 0) {
             disconnect(); // the peer went away or the deadline passed: re-dial at the next interval
-            return false;
+            return false; // (a request that was written in part is sent again whole: *done stops before it)
         }
         while (w > 0 && first < cnt) { // partial write: drop what has left
             if ((size_t)w >= iov[first].iov_len) {
                 w -= (ssize_t)iov[first].iov_len;
                 first++;
+                // everything up to the next non-empty request is done
+                *done = first < cnt ? req_of[first] : n;
             } else {
                 iov[first].iov_base = static_cast<char *>(iov[first].iov_base) + w;
                 iov[first].iov_len -= (size_t)w;
@@ -790,15 +830,17 @@ bool Submitter::retryBacklog() // submitter.go:70-93
         for (int i = head_; i != tail_; i = (i + 1) % 60) batch[n++] = backlog_[i];
     }
     if (n == 0) return true;
-    if (!submitBatch(batch, n)) return false;
-    sent_.fetch_add(n);
+    size_t done = 0;
+    const bool ok = submitBatch(batch, n, &done);
+    sent_.fetch_add(done);
     std::lock_guard<std::mutex> g(backlog_mu_);
-    // entries evicted while the batch was on the wire already moved the head past some of what was sent
-    for (uint64_t end = seq0 + n; head_seq_ < end; head_seq_++) {
+    // only what was written completely leaves the backlog (a failure after a partial write must not duplicate the
+    // requests already delivered); entries evicted while the batch was on the wire already moved the head
+    for (uint64_t end = seq0 + done; head_seq_ < end; head_seq_++) {
         backlog_[head_].reset();
         head_ = (head_ + 1) % 60;
     }
-    return true;
+    return ok;
 }
 
 void Submitter::appendToBacklog(std::string request) // submitter.go:95-104

@@ -1832,6 +1832,10 @@ int lh_release(lh_snapshot *s)
     EpochBuffer &b = e->bufs[(size_t)s->buf];
     {
         std::lock_guard<std::mutex> g(e->xmu);
+        // the reference folds the interval's amounts into the lifetime totals at the epoch boundary whoever reads
+        // them (metrics.go:435-458): a snapshot released before any counter call still folds
+        rc = fold_counters(s);
+        if (rc) return rc;
         HIPCHK(lh::launch_clear(b.counts, b.ranges, e->cfg.max_metrics, e->xstream));
         if (e->cfg.max_counters) {
             HIPCHK(hipMemsetAsync(b.ccur, 0, (size_t)e->cfg.max_counters * sizeof(uint64_t), e->xstream));

@@ -126,36 +126,10 @@ __global__ __launch_bounds__(K1_BLOCK) void k_ingest_single(const double *__rest
     const size_t tile = (size_t)K1_BLOCK * K1_UNROLL; // pairs per workgroup iteration
     const size_t nfull = npair / tile;
 
-#ifdef LH_K1_PREFETCH
-    // register double buffering: tile t+grid is in flight while tile t is bucketed
-    d2_t nx[K1_UNROLL];
-    if ((size_t)blockIdx.x < nfull) {
-        const d2_t *p0 = vp + (size_t)blockIdx.x * tile + tid;
-#pragma unroll
-        for (int u = 0; u < K1_UNROLL; u++) nx[u] = __builtin_nontemporal_load(p0 + u * K1_BLOCK);
-    }
+    // (register double buffering -- tile t + grid in flight while tile t is bucketed -- measured slower,
+    // profiles/r02_k1_variants.txt: two workgroups per CU already overlap each other's loads)
     for (size_t t = blockIdx.x; t < nfull; t += gridDim.x) {
-        d2_t r[K1_UNROLL];
-#pragma unroll
-        for (int u = 0; u < K1_UNROLL; u++) r[u] = nx[u];
-        if (t + gridDim.x < nfull) {
-            const d2_t *p = vp + (t + gridDim.x) * tile + tid;
-#pragma unroll
-            for (int u = 0; u < K1_UNROLL; u++) nx[u] = __builtin_nontemporal_load(p + u * K1_BLOCK);
-        }
-#pragma unroll
-        for (int u = 0; u < K1_UNROLL; u++) {
-            k1_add_fullwave(h, row, range, lh_bin_of(r[u].x, Tx));
-            k1_add_fullwave(h, row, range, lh_bin_of(r[u].y, Tx));
-        }
-    }
-#else
-    for (size_t t = blockIdx.x; t < nfull; t += gridDim.x) {
-#ifdef LH_K1_L2TEST // tuning builds only: every workgroup re-reads its first tile (L2 hits): compute time without HBM
-        const d2_t *p = vp + (size_t)blockIdx.x * tile + tid;
-#else
         const d2_t *p = vp + t * tile + tid;
-#endif
         d2_t r[K1_UNROLL];
 #pragma unroll
         for (int u = 0; u < K1_UNROLL; u++) r[u] = __builtin_nontemporal_load(p + u * K1_BLOCK);
@@ -165,7 +139,6 @@ __global__ __launch_bounds__(K1_BLOCK) void k_ingest_single(const double *__rest
             k1_add_fullwave(h, row, range, lh_bin_of(r[u].y, Tx));
         }
     }
-#endif
     // remainder pairs (guarded), owned by the workgroup next in the rotation
     if (blockIdx.x == nfull % gridDim.x) {
         for (size_t i = nfull * tile + tid; i < npair; i += K1_BLOCK) {

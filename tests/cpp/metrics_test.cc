@@ -323,6 +323,59 @@ TEST(TestSubmitterBacklogDrainsAfterTheSinkComesUp)
     CHECK(first_rate != std::string::npos && first_rate < 200);
 }
 
+// The reference dials per request (submitter.go:106-116); the kept connection must notice a peer that closed or
+// restarted BEFORE it writes a batch into the dead socket (the first write into a half-closed socket succeeds and the
+// batch would be counted as sent and lost), and must not re-send what was delivered.
+TEST(TestSubmitterRedialsAfterThePeerRestarts)
+{
+    int lfd = socket(AF_INET, SOCK_STREAM, 0);
+    sockaddr_in a{};
+    a.sin_family = AF_INET;
+    a.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
+    CHECK(bind(lfd, (sockaddr *)&a, sizeof a) == 0 && listen(lfd, 16) == 0);
+    socklen_t l = sizeof a;
+    getsockname(lfd, (sockaddr *)&a, &l);
+    std::string received;
+    std::atomic<int> accepted{0};
+    std::thread sink([&] {
+        char buf[65536];
+        // first connection: take whatever the first batch holds, then "restart"
+        int c = accept(lfd, nullptr, nullptr);
+        accepted.fetch_add(1);
+        ssize_t n = read(c, buf, sizeof buf);
+        if (n > 0) received.append(buf, (size_t)n);
+        std::this_thread::sleep_for(2ms); // the rest of a batch that is on the wire
+        while ((n = recv(c, buf, sizeof buf, MSG_DONTWAIT)) > 0) received.append(buf, (size_t)n);
+        close(c);
+        // second connection: until the submitter shuts down
+        c = accept(lfd, nullptr, nullptr);
+        accepted.fetch_add(1);
+        while ((n = read(c, buf, sizeof buf)) > 0) received.append(buf, (size_t)n);
+        close(c);
+    });
+    uint64_t sent = 0;
+    {
+        MetricSystem ms(20ms, false);
+        Submitter s(&ms, GraphiteProtocol, "tcp", "127.0.0.1:" + std::to_string(ntohs(a.sin_port)), 20ms);
+        s.Start();
+        ms.Counter("restart_total", 1);
+        ms.Start();
+        std::this_thread::sleep_for(400ms);
+        s.Shutdown();
+        ms.Stop();
+        sent = s.sent_requests();
+        CHECK(s.connections() == 2);
+    }
+    sink.join();
+    close(lfd);
+    // every request carries the lifetime counter once: as many of its lines arrived as requests were counted as sent
+    size_t lines = 0;
+    for (size_t at = 0; (at = received.find(".restart.total 1.000000 ", at)) != std::string::npos; at++) lines++;
+    CHECK(accepted.load() == 2 && sent >= 5);
+    if (lines != sent) std::printf("    lines %zu sent %llu\n", lines, (unsigned long long)sent);
+    CHECK(lines == sent);
+}
+
 // ---- histogram paths: need the GPU ---------------------------------------------------------------
 TEST(TestTimer) // metrics_test.go:183-200
 {
@@ -591,6 +644,7 @@ int main(int argc, char **argv)
     RUN(TestSerializers);
     RUN(TestSubmitterGraphite);
     RUN(TestSubmitterBacklogDrainsAfterTheSinkComesUp);
+    RUN(TestSubmitterRedialsAfterThePeerRestarts);
     RUN(TestFormatGoV);
     if (!cpu_only) {
         RUN(TestTimer);

@@ -155,3 +155,20 @@ def test_counter_wire_lines(native_lib, torch_cuda):
         assert "put errors 1411104988 0.000000 host=h\n" in tsdb and "put errors_rate" not in tsdb
         assert "never" not in text
         assert f"put huge 1411104988 {oracle.format_f(float((1 << 63) + 12346))} host=h\n" in tsdb
+
+
+def test_release_without_reading_counters_still_folds(native_lib, torch_cuda):
+    """metrics.go:435-458 folds the interval's amounts into the lifetime totals at the epoch boundary whoever reads them:
+    a snapshot released before lh_counters_collect / lh_serialize_counters (a consumer that skips an interval, an error
+    path) must not lose that interval's amounts from the totals."""
+    import loghisto_amd
+    with loghisto_amd.Engine(max_metrics=4, max_counters=16, num_lanes=1, lane_samples=1 << 12) as e:
+        c = e.intern_counter("skipped")
+        e.submit_counts([c, c], [5, 7])
+        e.flip().release()                       # nobody looks at this interval
+        e.submit_counts([c], [100])
+        rates, totals = _collect(e)
+        assert rates == {"skipped": 100} and totals == {"skipped": 112}
+        e.flip().release()
+        rates, totals = _collect(e)
+        assert rates == {} and totals == {"skipped": 112}
