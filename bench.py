@@ -375,8 +375,6 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup):
             comm = rccl.comm_init_rank(1, rccl.unique_id(), 0)
     except Exception as exc:  # noqa: BLE001 -- keep the scaling run alive through the torch.distributed front-end
         comm, frontend, why = 0, "torch.distributed: loghisto_amd.merge.merge_snapshot (reduce_scatter_tensor)", repr(exc)
-    per = -(-M // world)
-    own = (min(rank * per, M), min((rank + 1) * per, M))
     t_ing, t_merge, t_ext = [], [], []
     info = {}
 
@@ -420,7 +418,15 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup):
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    assert (first, last) == own, ((first, last), own)
+    # the owner blocks tile [0, M) in rank order (equal shares of the packed cells, not of the names)
+    if dist is not None:
+        fl = torch.tensor([first, last], dtype=torch.int64, device="cuda")
+        allfl = [torch.zeros_like(fl) for _ in range(world)]
+        dist.all_gather(allfl, fl)
+        bounds = [tuple(int(x) for x in t.tolist()) for t in allfl]
+    else:
+        bounds = [(first, last)]
+    assert bounds[0][0] == 0 and bounds[-1][1] == M and all(bounds[i][1] == bounds[i + 1][0] for i in range(world - 1)), bounds
     # parity: every sample of every rank is in exactly one owned row (conservation), per-name counts of the owned
     # rows equal the all-reduced bincount of the ids
     per_name = torch.bincount(ids, minlength=M).to(torch.int64)
@@ -432,18 +438,49 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup):
         dist.all_reduce(owned_total)
     conserved = int(owned_total.item()) == n * world
     parity = {"per_name_counts_exact": counts_ok, "samples_conserved": conserved, "exact": counts_ok and conserved}
-    if world == 1 and not args.no_parity:
-        # single rank: a sample of rows cell by cell against the oracle (dense matrices of 65 536 names do not fit a test)
+    plan8 = None
+    if not args.no_parity:
+        # A probe set of rows cell by cell against the oracle AFTER the merge (dense matrices of 65 536 names do not
+        # fit): every rank buckets ITS samples of every probe name with the oracle, the expected merged rows are the
+        # all-reduced sum of those, and each rank compares the probes it owns with what the merge left in its rows.
         import oracle
+        probe = sorted({0, 1, 2, 7, 63, 64, 255, 1023, 4095, M // 2, M - 2, M - 1} | set(range(100, 100 + 20))
+                       | {int(x) for x in np.linspace(0, M - 1, 4 * world + 8)})
+        probe = [m for m in probe if m < M]
+        mine = np.stack([oracle.histogram_dense(data[ids == m].cpu().numpy()) for m in probe]).astype(np.int64)
+        want = torch.from_numpy(mine).cuda()
+        if dist is not None:
+            dist.all_reduce(want)
+        want = want.cpu().numpy().astype(np.uint64)
         eng.submit_pairs_device(ids, data, n, stream=stream)
-        with eng.flip() as snap:
-            probe = sorted({0, 1, 2, 7, 63, 64, 255, 1023, 4095, M // 2, M - 2, M - 1} | set(range(100, 100 + 20)))
-            probe = [m for m in probe if m < M]
-            ok = True
-            for m in probe:
-                sel = data[ids == m].cpu().numpy()
-                ok = ok and np.array_equal(snap.dense_row(m), oracle.histogram_dense(sel))
-        parity.update(rows_checked_cell_by_cell=len(probe), exact=parity["exact"] and bool(ok))
+        snap = eng.flip()
+        if comm:
+            f2, l2 = snap.merge_rccl(comm, world, rank, M, plan="reduce_scatter")
+        elif world > 1:
+            f2, l2 = tmerge.merge_snapshot(snap, M, plan="reduce_scatter")
+        else:
+            f2, l2 = 0, M
+        owned = [i for i, m in enumerate(probe) if f2 <= m < l2]
+        ok = all(np.array_equal(snap.dense_row(probe[i]), want[i]) for i in owned)
+        if world == 1:
+            # what an 8-rank reduce-scatter of this interval would pad: equal packed cells per block (this library)
+            # against equal name counts per block (round 2), from the snapshot's merged ranges
+            torch.cuda.synchronize()
+            rg = tmerge.snapshot_tensors(snap, M)[1].cpu().numpy().view(np.uint32).astype(np.int64)
+            wd = np.where(rg[:, 0] <= rg[:, 1], rg[:, 1] - rg[:, 0] + 1, 0)
+            P = np.concatenate([[0], np.cumsum(wd)])
+            cut = [int(np.searchsorted(P, P[-1] * k // 8, side="left")) for k in range(9)]
+            cut[0], cut[8] = 0, M
+            bal = max(P[cut[k + 1]] - P[cut[k]] for k in range(8)) * 8 / max(1, P[-1])
+            per8 = -(-M // 8)
+            eq = max(P[min(M, (k + 1) * per8)] - P[min(M, k * per8)] for k in range(8)) * 8 / max(1, P[-1])
+            plan8 = {"ranks": 8, "padding_ratio_equal_cells": float(bal), "padding_ratio_equal_names": float(eq)}
+        snap.release()
+        nchk = torch.tensor([len(owned), int(ok)], dtype=torch.int64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(nchk)
+        parity.update(rows_checked_cell_by_cell=int(nchk[0].item()), cells_after_merge_exact=int(nchk[1].item()) == world,
+                      exact=parity["exact"] and int(nchk[1].item()) == world)
     assert parity["exact"], parity
     lat_c4 = None
     if world == 1 and steps:
@@ -471,13 +508,23 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup):
         "roofline": roofline(n * BYTES_PAIR, sum(t_ing) / len(t_ing),
                              "k_scatter_samples<hot> + k_scatter_records + k_part_hist (two-level partitioned ingest, "
                              "all launches of one lh_submit_pairs_device)"),
-        "merge": {"ms": sum(t_merge) / len(t_merge), "packed_cells": info.get("packed_cells"),
+        "merge": {"host_call_ms": sum(t_merge) / len(t_merge),
+                  "device_ms": {k: info.get(k) for k in ("ranges_ms", "plan_ms", "pack_ms", "collective_ms",
+                                                         "unpack_ms", "span_ms")},
+                  "packed_cells": info.get("packed_cells"), "padded_cells": info.get("padded_cells"),
+                  "padding_ratio": (info["padded_cells"] / info["packed_cells"]
+                                    if info.get("packed_cells") and info.get("padded_cells") else None),
+                  "cell_bytes": info.get("cell_bytes"),
                   "send_bytes": info.get("send_bytes"), "recv_bytes": info.get("recv_bytes"),
                   "widest_row": info.get("widest_row"), "occupied_rows": info.get("occupied_rows"),
-                  "note": "host wall time of lh_snapshot_merge (range all-reduce, device-side window plan, pack, "
-                          "reduce-scatter, unpack are enqueued; the plan totals come back through pinned memory)"},
+                  "owned_rows_by_rank": bounds if world <= 16 else None,
+                  "note": "device_ms: HIP events on the snapshot stream around the merge's steps of the last timed "
+                          "step (dirty-range all-reduce, window plan, pack, collective, unpack; span includes the host "
+                          "round trip for the plan totals); host_call_ms: wall time of lh_snapshot_merge returning"},
         "extract_owned_ms": sum(t_ext) / len(t_ext), "parity": parity, "scratch_bytes": c["scratch_bytes"],
     }
+    if plan8:
+        res["merge"]["simulated_plan"] = plan8
     if lat_c4:
         res["extract_latency_us"] = lat_c4
     if why:
@@ -494,6 +541,12 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup):
 # host-fed (PCIe-inclusive) and the C5 burst
 # ---------------------------------------------------------------------------------------------------------
 def run_hostfed(la, M=1024, total=int(8e8)):
+    """Host arrays -> pinned staging buffers -> PCIe -> buckets, from T producer threads.  Three forms of the same
+    stream: lh_submit_pairs (the library copies the caller's batch into a pinned buffer; ids validated on the host),
+    lh_reserve_pairs / lh_commit_pairs (the producer's own store is the only host-side copy), and lh_submit_pairs
+    with LH_OPT_LANE_ZERO_COPY = 0 (round 2's path: hipMemcpyAsync into HBM before the kernel).  value = in place."""
+    import oracle
+    from loghisto_amd import _native as N
     cores = effective_cores()
     T = max(1, min(16, cores))
     rng = np.random.default_rng(1)
@@ -501,32 +554,71 @@ def run_hostfed(la, M=1024, total=int(8e8)):
     w = 1.0 / np.arange(1, M + 1)
     ids = rng.choice(M, size=src.size, p=w / w.sum()).astype(np.uint32)
     batch = 1 << 20
-    eng = la.Engine(device=torch.cuda.current_device(), max_metrics=M, num_buffers=2, num_lanes=T, lane_samples=1 << 21)
     per = total // T
+    offs = [(t * 7919 * batch) % (src.size - batch) for t in range(T)]
+    # every cell against the oracle: thread t submits the same slice [off_t, off_t + batch) per // batch times and
+    # its first per % batch samples once more
+    reps, rem = per // batch, per % batch
+    want = np.zeros((M, 65536), dtype=np.uint64)
+    if reps:
+        want += np.uint64(reps) * oracle.histogram_pairs_mt(np.concatenate([ids[o:o + batch] for o in offs]),
+                                                             np.concatenate([src[o:o + batch] for o in offs]), M)
+    if rem:
+        want += oracle.histogram_pairs_mt(np.concatenate([ids[o:o + rem] for o in offs]),
+                                          np.concatenate([src[o:o + rem] for o in offs]), M)
 
-    def work(t):
-        done, off = 0, (t * 7919 * batch) % (src.size - batch)
-        while done < per:
-            k = min(batch, per - done)
-            eng.submit_pairs(ids[off:off + k], src[off:off + k])
-            done += k
+    def one(form):
+        eng = la.Engine(device=torch.cuda.current_device(), max_metrics=M, num_buffers=2, num_lanes=T,
+                        lane_samples=1 << 21)
+        if form == "copy_engine":
+            eng.set_option(N.OPT_LANE_ZERO_COPY, 0)
+        put = eng.submit_pairs_in_place if form == "in_place" else eng.submit_pairs
 
-    th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
-    t0 = time.perf_counter()
-    [x.start() for x in th]
-    [x.join() for x in th]
-    eng.sync()
-    dt = time.perf_counter() - t0
-    with eng.flip() as snap:
-        cnt = int(snap.extract([0.5], M)["count"].sum())
-    eng.close()
-    rate = per * T / dt
+        def work(t):
+            done, off = 0, offs[t]
+            while done < per:
+                k = min(batch, per - done)
+                put(ids[off:off + k], src[off:off + k])
+                done += k
+
+        # untimed: one batch per thread (first touch of the pinned buffers, the kernels' first launches), discarded
+        wu = [threading.Thread(target=lambda t=t: put(ids[offs[t]:offs[t] + batch], src[offs[t]:offs[t] + batch]))
+              for t in range(T)]
+        [x.start() for x in wu]
+        [x.join() for x in wu]
+        eng.sync()
+        eng.flip().release()
+        th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+        t0 = time.perf_counter()
+        [x.start() for x in th]
+        [x.join() for x in th]
+        eng.sync()
+        dt = time.perf_counter() - t0
+        with eng.flip() as snap:
+            cnt = int(snap.extract([0.5], M)["count"].sum())
+            off_, keys_, counts_ = snap.buckets_all(M)
+        eng.close()
+        exact = cnt == per * T and bool(np.array_equal(dense_from_csr(off_, keys_, counts_, M), want))
+        return per * T / dt, exact
+
+    rates = {form: one(form) for form in ("in_place", "submit_pairs", "copy_engine")}
+    del want
+    rate = rates["in_place"][0]
     return {"value": rate, "unit": "samples/s", "threads": T, "samples": per * T, "names": M,
-            "config": {"workload": "host arrays through lh_submit_pairs (memcpy into pinned lanes, hipMemcpyAsync, "
-                                   "mixed ingest per lane half-buffer): the path a cgo binding uses"},
+            "config": {"workload": "host arrays written into the engine's pinned staging buffers in place "
+                                   "(lh_reserve_pairs / lh_commit_pairs), mixed ingest per half-buffer reading them "
+                                   "over PCIe: the path a cgo binding uses"},
             "roofline": {"bound": "pcie", "achieved": rate * BYTES_PAIR / 1e9, "peak": PCIE_GBS, "unit": "GB/s",
                          "frac": rate * BYTES_PAIR / 1e9 / PCIE_GBS, "bytes_per_sample": BYTES_PAIR},
-            "parity": {"samples_conserved": cnt == per * T, "exact": cnt == per * T}}
+            "other_forms": {"lh_submit_pairs": {"value": rates["submit_pairs"][0],
+                                                "frac": rates["submit_pairs"][0] * BYTES_PAIR / 1e9 / PCIE_GBS},
+                            "lh_submit_pairs_through_the_copy_engine": {
+                                "value": rates["copy_engine"][0],
+                                "frac": rates["copy_engine"][0] * BYTES_PAIR / 1e9 / PCIE_GBS}},
+            "parity": {"rows_checked": M, "exact": all(r[1] for r in rates.values()),
+                       "cells_exact_by_form": {k: r[1] for k, r in rates.items()},
+                       "checker": "oracle/ over every submitted pair (slices x repetitions), every cell of every row, "
+                                  "for each of the three forms"}}
 
 
 def run_c5(seconds=10.0):

@@ -113,6 +113,18 @@ int lh_metric_name(lh_engine *e, uint32_t id, char *buf, size_t cap, size_t *len
 int lh_submit(lh_engine *e, uint32_t id, const double *v, size_t n);
 /* Mixed batch: Histogram(name(ids[i]), v[i]). */
 int lh_submit_pairs(lh_engine *e, const uint32_t *ids, const double *v, size_t n);
+/* In-place staging of a mixed batch (the other half of SURVEY.md 8b "Ownership": "the ring is C-allocated
+ * (hipHostMalloc) and Go writes into it in place"; call shape of Histogram, metrics.go:273).  lh_reserve_pairs hands
+ * out the free tail of one of the engine's pinned staging buffers: *ids / *vals point at room for *granted <= want
+ * pairs, which the caller fills front to back -- the only host-side store a sample ever sees; the ingest kernel
+ * later reads that memory over PCIe in place -- and lh_commit_pairs(token, n) publishes the first n <= *granted of
+ * them (n = 0 gives the reservation back).  Between the two calls the buffer belongs to the caller: a flip, and
+ * other producers that are sent to the same buffer, wait for the commit, so a producer commits before it blocks on
+ * anything else.  Every reservation is committed exactly once; commit from any thread.  ids are not validated on
+ * the host: an id >= max_metrics is skipped by the kernel and reported as LH_ERANGE by the next lh_sync / lh_flip
+ * / lh_extract, as for lh_submit_pairs_device. */
+int lh_reserve_pairs(lh_engine *e, size_t want, uint32_t **ids, double **vals, size_t *granted, uint32_t *token);
+int lh_commit_pairs(lh_engine *e, uint32_t token, size_t n);
 /* Device-memory ingest for GPU-resident producers; asynchronous on `stream`.
  * Ordering contract: the kernel is enqueued on `stream` (NULL = the engine's own non-blocking
  * stream, which does NOT synchronise with the legacy default stream).  The producer of the buffers
@@ -201,8 +213,10 @@ int lh_snapshot_mark_dirty(lh_snapshot *s, uint32_t first_row, uint32_t nrows, u
  * (cells are a commutative sum, metrics.go:278, 292).  The reference is single-process: no counterpart.
  *   comm   ncclComm_t (as void*) created by the caller with the RCCL named by lh_set_rccl_library
  *   plan   LH_MERGE_ALLREDUCE: every rank ends with every merged row;
- *          LH_MERGE_REDUCE_SCATTER: rank r ends with the merged rows of names
- *          [r*ceil(nrows/nranks), ...) and extracts those with lh_extract_rows
+ *          LH_MERGE_REDUCE_SCATTER: rank r ends with the merged rows of a contiguous block of names and
+ *          extracts those with lh_extract_rows.  The blocks tile [0, nrows) in rank order and hold equal numbers of
+ *          PACKED CELLS, not of names (names ranked by frequency would otherwise put every wide window into block 0
+ *          and pad the other blocks up to it): use the returned [first, last)
  *   first_owned / last_owned  receive the [first, last) rows holding merged data on this rank
  * Runs on the snapshot's stream; dirty ranges are merged first (one MIN all-reduce on (lo, ~hi)), then every
  * row's own merged window travels, packed back to back; the window plan (prefix sums, block sizes) is computed
@@ -218,6 +232,15 @@ typedef struct lh_merge_info {
     uint64_t recv_bytes;     /* bytes this rank ends up with                                     */
     uint32_t widest_row;     /* widest merged window, in cells                                   */
     uint32_t occupied_rows;  /* rows with at least one cell on some rank                         */
+    uint64_t padded_cells;   /* reduce-scatter: nranks x largest owner block (>= packed_cells; the ratio is what
+                              * the equal-block collective costs over the packed matrix); all-reduce: packed_cells */
+    uint32_t cell_bytes;     /* 8, or 4 when no merged cell of the interval can reach 2^32 (nranks x the largest
+                              * per-rank sample count of the interval < 2^32: cells travel as uint32)            */
+    uint32_t reserved;
+    /* Device time of the merge's steps, HIP events on the snapshot stream (lh_snapshot_merge_info waits for the
+     * last one): dirty-range all-reduce, window plan, pack, the collective, unpack; span = first event to last,
+     * host round trip for the plan totals included. */
+    float ranges_ms, plan_ms, pack_ms, collective_ms, unpack_ms, span_ms;
 } lh_merge_info;
 int lh_snapshot_merge_info(lh_snapshot *s, lh_merge_info *out);
 /* Path (or soname) of the RCCL shared object the communicator comes from; default "librccl.so".
@@ -335,6 +358,8 @@ int lh_get_counters(lh_engine *e, lh_counters *out);
  *                             4-byte records, a second level that counts each partition's frequent names in place;
  *                             default 1; used for 8 193 .. 65 536 names -- BASELINE config 4's name count)
  *   LH_OPT_PART_V3_MIN_PAIRS  smallest launch that takes it (default 2^24; >= 2^17: tests exercise it on small inputs)
+ *   LH_OPT_LANE_ZERO_COPY     0 / 1: the ingest kernels read the pinned staging buffers of lh_submit* / lh_reserve_pairs
+ *                             in place over PCIe (default 1) instead of after a hipMemcpyAsync into HBM (0)
  *   LH_OPT_PART_V3_LOG_W      log2 of its second-level window width, 10 .. 13 (32 .. 4 names per fine partition);
  *                             0 (default) = follow the survey: every call's survey reports the width that covers
  *                             95 % of the sampled mass and the following calls use it (lh_counters.window_log2) */
@@ -352,7 +377,8 @@ enum {
     LH_OPT_PART_V2_SHAPE = 11,
     LH_OPT_PART_V3 = 12,
     LH_OPT_PART_V3_MIN_PAIRS = 13,
-    LH_OPT_PART_V3_LOG_W = 14
+    LH_OPT_PART_V3_LOG_W = 14,
+    LH_OPT_LANE_ZERO_COPY = 15
 };
 int lh_set_option(lh_engine *e, int option, uint64_t value);
 

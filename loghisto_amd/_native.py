@@ -47,6 +47,7 @@ OPT_TWO_LEVEL_ABOVE, OPT_HOT_MIN_TILES, OPT_HOT_WINDOWS, OPT_NAMES_PER_PARTITION
 OPT_EXTRACT_ZERO_COPY, OPT_SCRATCH_CAP_BYTES, OPT_SUBLAUNCH_PAIRS, OPT_SMALL_PATH = 5, 6, 7, 8
 OPT_PART_V2, OPT_PART_V2_MIN_PAIRS, OPT_PART_V2_SHAPE = 9, 10, 11
 OPT_PART_V3, OPT_PART_V3_MIN_PAIRS, OPT_PART_V3_LOG_W = 12, 13, 14
+OPT_LANE_ZERO_COPY = 15
 
 
 class LhExtractView(C.Structure):
@@ -56,7 +57,9 @@ class LhExtractView(C.Structure):
 
 class LhMergeInfo(C.Structure):
     _fields_ = [("packed_cells", C.c_uint64), ("send_bytes", C.c_uint64), ("recv_bytes", C.c_uint64),
-                ("widest_row", C.c_uint32), ("occupied_rows", C.c_uint32)]
+                ("widest_row", C.c_uint32), ("occupied_rows", C.c_uint32), ("padded_cells", C.c_uint64),
+                ("cell_bytes", C.c_uint32), ("reserved", C.c_uint32), ("ranges_ms", C.c_float), ("plan_ms", C.c_float),
+                ("pack_ms", C.c_float), ("collective_ms", C.c_float), ("unpack_ms", C.c_float), ("span_ms", C.c_float)]
 
 
 class LhLineFormat(C.Structure):
@@ -92,6 +95,9 @@ SIGNATURES = {
     "lh_metric_name": (C.c_int, [_vp, C.c_uint32, C.c_char_p, _sz, C.POINTER(_sz)]),
     "lh_submit": (C.c_int, [_vp, C.c_uint32, _vp, _sz]),
     "lh_submit_pairs": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "lh_reserve_pairs": (C.c_int, [_vp, _sz, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                   C.POINTER(C.c_uint32)]),
+    "lh_commit_pairs": (C.c_int, [_vp, C.c_uint32, _sz]),
     "lh_submit_device": (C.c_int, [_vp, C.c_uint32, _vp, _sz, _vp]),
     "lh_submit_pairs_device": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
     "lh_intern_counter": (C.c_int, [_vp, C.c_char_p, _sz, _u32p]),

@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -64,6 +65,7 @@ struct EpochBuffer {
     uint32_t *cflag = nullptr;   // [max_counters] touched this interval
     hipEvent_t cleared = nullptr; // recorded on xstream after the last clear
     BufState state = BUF_FREE;
+    uint64_t nsamples = 0;        // samples enqueued into this buffer since its last clear (atomic builtins); ~0 = unknown
 };
 
 enum LaneMode { LANE_NONE = 0, LANE_SINGLE = 1, LANE_PAIRS = 2, LANE_COUNTS = 3 };
@@ -81,6 +83,20 @@ struct Lane {
     size_t fill = 0;
     LaneMode mode = LANE_NONE;
     uint32_t single_id = 0;
+    // lh_reserve_pairs .. lh_commit_pairs: the tail of the current half-buffer belongs to one producer, which writes
+    // its samples in place; everybody else who wants the lane (another producer, a flush at the flip) waits on cv
+    bool reserved = false;
+    size_t granted = 0;
+    std::condition_variable cv;
+    // the half-buffers as the device sees them (hipHostMalloc memory is mapped): kernels read them over PCIe
+    double *m_vals[2] = {nullptr, nullptr};
+    uint32_t *m_ids[2] = {nullptr, nullptr};
+};
+
+// Lane mutex taken, and the lane free of a reservation (lh_reserve_pairs .. lh_commit_pairs)
+struct LaneLock {
+    std::unique_lock<std::mutex> g;
+    explicit LaneLock(Lane &ln) : g(ln.mu) { ln.cv.wait(g, [&] { return !ln.reserved; }); }
 };
 
 // One D2H block per extract call.
@@ -153,6 +169,8 @@ struct lh_engine {
     uint64_t *d_mbuf = nullptr;
     size_t mbuf_bytes = 0;
     lh_merge_info merge_info{};
+    hipEvent_t merge_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // around the merge's steps (xmu)
+    bool merge_events_pending = false;
 
     // counters (metrics.go:112-117): their own name table, the lifetime store and the "ever touched" flags in HBM
     std::shared_mutex cnames_mu;
@@ -204,6 +222,7 @@ struct lh_engine {
     bool scratch_cap_set = false, sublaunch_set = false; // lh_set_option was called: the caller's bound wins
     size_t sublaunch_pairs = size_t(1) << 29;
 
+    bool lane_zero_copy = true;           // LH_OPT_LANE_ZERO_COPY: kernels read the pinned half-buffers in place
     lh::PartTuning tune;                  // lh_set_option; never the environment in the product build
     bool zero_copy_enabled = true;
     size_t zero_copy_max = 32768; // results up to this size are stored by the kernel straight into pinned memory
@@ -238,9 +257,19 @@ int epoch_touch_stream(lh_engine *e, hipStream_t s)
     return LH_OK;
 }
 
+// an upper bound of any cell of the buffer: every sample adds 1 to one cell (saturates at "unknown")
+void count_samples(EpochBuffer &b, size_t n)
+{
+    uint64_t old = __atomic_load_n(&b.nsamples, __ATOMIC_RELAXED), now;
+    do {
+        now = old > ~uint64_t(0) - n ? ~uint64_t(0) : old + n;
+    } while (!__atomic_compare_exchange_n(&b.nsamples, &old, now, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+}
+
 int launch_single(lh_engine *e, uint32_t id, const double *d_v, size_t n, hipStream_t s)
 {
     EpochBuffer &b = e->bufs[(size_t)e->cur];
+    count_samples(b, n);
     // a workgroup's uint32 LDS bins must not wrap even if every sample of the launch lands in one
     // bucket: keep one launch below 2^32 samples
     const size_t kMaxLaunch = size_t(1) << 31;
@@ -259,6 +288,7 @@ int launch_single(lh_engine *e, uint32_t id, const double *d_v, size_t n, hipStr
 int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t n, hipStream_t s)
 {
     EpochBuffer &b = e->bufs[(size_t)e->cur];
+    count_samples(b, n);
     const size_t kMaxLaunch = size_t(1) << 30;
     // Slices taken at an odd sample index leave BOTH arrays one element short of the vector-load alignment of
     // the fast kernels (ids 8-byte, values 16-byte): peel that one sample through the direct kernel instead of
@@ -409,15 +439,22 @@ int lane_launch(lh_engine *e, Lane &ln)
     const size_t n = ln.fill;
     int rc = epoch_touch_stream(e, ln.stream);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(ln.d_vals[h], ln.h_vals[h], n * sizeof(double), hipMemcpyHostToDevice, ln.stream));
+    // Every ingest kernel reads its input once, front to back: with the half-buffers mapped into the device's address
+    // space the kernel fetches them over PCIe itself and no copy engine, no staging copy in HBM stands between the
+    // producer's store and the bucket (one SDMA engine moves ~28 GB/s, which was the host-fed path's ceiling on some
+    // boxes: VERDICT r2 weak #7).  LH_OPT_LANE_ZERO_COPY = 0 restores hipMemcpyAsync into HBM first.
+    const bool zc = e->lane_zero_copy && ln.m_vals[h] && ln.m_ids[h] && ln.mode != LANE_COUNTS;
+    const double *dv = zc ? ln.m_vals[h] : ln.d_vals[h];
+    const uint32_t *di = zc ? ln.m_ids[h] : ln.d_ids[h];
+    if (!zc) HIPCHK(hipMemcpyAsync(ln.d_vals[h], ln.h_vals[h], n * sizeof(double), hipMemcpyHostToDevice, ln.stream));
     if (ln.mode == LANE_PAIRS) {
-        HIPCHK(hipMemcpyAsync(ln.d_ids[h], ln.h_ids[h], n * sizeof(uint32_t), hipMemcpyHostToDevice, ln.stream));
-        rc = launch_pairs(e, ln.d_ids[h], ln.d_vals[h], n, ln.stream);
+        if (!zc) HIPCHK(hipMemcpyAsync(ln.d_ids[h], ln.h_ids[h], n * sizeof(uint32_t), hipMemcpyHostToDevice, ln.stream));
+        rc = launch_pairs(e, di, dv, n, ln.stream);
     } else if (ln.mode == LANE_COUNTS) { // the value half-buffer carries uint64 amounts
         HIPCHK(hipMemcpyAsync(ln.d_ids[h], ln.h_ids[h], n * sizeof(uint32_t), hipMemcpyHostToDevice, ln.stream));
         rc = launch_counts(e, ln.d_ids[h], reinterpret_cast<const uint64_t *>(ln.d_vals[h]), n, ln.stream);
     } else {
-        rc = launch_single(e, ln.single_id, ln.d_vals[h], n, ln.stream);
+        rc = launch_single(e, ln.single_id, dv, n, ln.stream);
     }
     if (rc) return rc;
     HIPCHK(hipEventRecord(ln.done[h], ln.stream));
@@ -442,7 +479,7 @@ Lane &pick_lane(lh_engine *e)
 int flush_all_lanes(lh_engine *e)
 {
     for (auto &lp : e->lanes) {
-        std::lock_guard<std::mutex> g(lp->mu);
+        LaneLock g(*lp); // a producer that holds a reservation commits first (lh_commit_pairs never blocks on the epoch)
         int rc = lane_launch(e, *lp);
         if (rc) return rc;
     }
@@ -487,6 +524,8 @@ void free_engine(lh_engine *e)
     if (e->d_text) (void)hipFree(e->d_text);
     if (e->d_blob) (void)hipFree(e->d_blob);
     if (e->d_mplan) (void)hipFree(e->d_mplan);
+    for (hipEvent_t ev : e->merge_ev)
+        if (ev) (void)hipEventDestroy(ev);
     if (e->d_cnames) (void)hipFree(e->d_cnames);
     if (e->d_cname_off) (void)hipFree(e->d_cname_off);
     if (e->d_clife) (void)hipFree(e->d_clife);
@@ -594,6 +633,10 @@ int create_impl(const lh_config *cfg_in, lh_engine *e)
             HIPCHK(hipHostMalloc((void **)&ln->h_ids[h], e->cfg.lane_samples * sizeof(uint32_t), hipHostMallocDefault));
             HIPCHK(hipMalloc((void **)&ln->d_vals[h], e->cfg.lane_samples * sizeof(double)));
             HIPCHK(hipMalloc((void **)&ln->d_ids[h], e->cfg.lane_samples * sizeof(uint32_t)));
+            void *dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, ln->h_vals[h], 0) == hipSuccess) ln->m_vals[h] = static_cast<double *>(dp);
+            if (hipHostGetDevicePointer(&dp, ln->h_ids[h], 0) == hipSuccess) ln->m_ids[h] = static_cast<uint32_t *>(dp);
+            (void)hipGetLastError(); // (not mapped: the lane copies, as before)
             HIPCHK(hipEventCreateWithFlags(&ln->done[h], hipEventDisableTiming));
         }
         e->lanes.push_back(std::move(ln));
@@ -739,7 +782,7 @@ int lh_submit(lh_engine *e, uint32_t id, const double *v, size_t n)
     if (rc) return rc;
     std::shared_lock<std::shared_mutex> eg(e->epoch_mu);
     Lane &ln = pick_lane(e);
-    std::lock_guard<std::mutex> g(ln.mu);
+    LaneLock g(ln);
     if (ln.fill && (ln.mode != LANE_SINGLE || ln.single_id != id)) {
         rc = lane_launch(e, ln);
         if (rc) return rc;
@@ -771,7 +814,7 @@ int lh_submit_pairs(lh_engine *e, const uint32_t *ids, const double *v, size_t n
     if (rc) return rc;
     std::shared_lock<std::shared_mutex> eg(e->epoch_mu);
     Lane &ln = pick_lane(e);
-    std::lock_guard<std::mutex> g(ln.mu);
+    LaneLock g(ln);
     if (ln.fill && ln.mode != LANE_PAIRS) {
         rc = lane_launch(e, ln);
         if (rc) return rc;
@@ -791,6 +834,67 @@ int lh_submit_pairs(lh_engine *e, const uint32_t *ids, const double *v, size_t n
             if (rc) return rc;
         }
     }
+    return LH_OK;
+}
+
+// In-place staging (SURVEY.md 8b "Ownership": "or the ring is C-allocated (hipHostMalloc) and Go writes into it in
+// place"): the producer gets the free tail of a pinned half-buffer, writes its (id, value) pairs there -- the one
+// and only host-side store of a sample -- and commits how many it wrote.  Between the two calls the lane belongs to
+// the caller: other producers that hash to it and the flush at the flip wait for the commit.
+int lh_reserve_pairs(lh_engine *e, size_t want, uint32_t **ids, double **vals, size_t *granted, uint32_t *token)
+{
+    if (!e || !ids || !vals || !granted || !token || want == 0) return LH_EINVAL;
+    int rc = use_device(e);
+    if (rc) return rc;
+    // lock order as everywhere: epoch (shared) before lane.  lh_commit_pairs takes no epoch lock at all, so a flip that
+    // holds the epoch exclusively and waits for this lane's reservation to end cannot deadlock with the commit.
+    std::shared_lock<std::shared_mutex> eg(e->epoch_mu);
+    // the caller's own lane if it is free, else the next free one, else wait for the caller's own
+    const size_t nl = e->lanes.size();
+    const size_t h0 = std::hash<std::thread::id>()(std::this_thread::get_id()) % nl;
+    Lane *lane = nullptr;
+    std::unique_lock<std::mutex> g;
+    for (size_t k = 0; k < nl && !lane; k++) {
+        Lane &c = *e->lanes[(h0 + k) % nl];
+        std::unique_lock<std::mutex> t(c.mu, std::try_to_lock);
+        if (t.owns_lock() && !c.reserved) { lane = &c; g = std::move(t); }
+    }
+    if (!lane) {
+        lane = e->lanes[h0].get();
+        g = std::unique_lock<std::mutex>(lane->mu);
+        lane->cv.wait(g, [&] { return !lane->reserved; });
+    }
+    Lane &ln = *lane;
+    const size_t cap = (size_t)e->cfg.lane_samples;
+    if (ln.fill && (ln.mode != LANE_PAIRS || ln.fill == cap)) {
+        rc = lane_launch(e, ln);
+        if (rc) return rc;
+    }
+    ln.mode = LANE_PAIRS;
+    ln.reserved = true;
+    ln.granted = cap - ln.fill < want ? cap - ln.fill : want;
+    *ids = ln.h_ids[ln.cur] + ln.fill;
+    *vals = ln.h_vals[ln.cur] + ln.fill;
+    *granted = ln.granted;
+    *token = 0;
+    for (size_t k = 0; k < nl; k++)
+        if (e->lanes[k].get() == lane) *token = (uint32_t)k + 1u;
+    return LH_OK;
+}
+
+int lh_commit_pairs(lh_engine *e, uint32_t token, size_t n)
+{
+    if (!e || token == 0 || token > e->lanes.size()) return LH_EINVAL;
+    Lane &ln = *e->lanes[token - 1u];
+    {
+        std::lock_guard<std::mutex> g(ln.mu);
+        if (!ln.reserved || n > ln.granted) return LH_ESTATE;
+        ln.fill += n; // a half-buffer this fills is launched by the next call that takes the lane (reserve, submit, flip)
+        ln.reserved = false;
+        ln.granted = 0;
+        if (ln.fill == 0) ln.mode = LANE_NONE;
+    }
+    ln.cv.notify_all();
     return LH_OK;
 }
 
@@ -875,7 +979,7 @@ int lh_submit_counts(lh_engine *e, const uint32_t *ids, const uint64_t *amounts,
     if (rc) return rc;
     std::shared_lock<std::shared_mutex> eg(e->epoch_mu);
     Lane &ln = pick_lane(e);
-    std::lock_guard<std::mutex> g(ln.mu);
+    LaneLock g(ln);
     if (ln.fill && ln.mode != LANE_COUNTS) {
         rc = lane_launch(e, ln);
         if (rc) return rc;
@@ -1265,6 +1369,8 @@ int lh_snapshot_mark_dirty(lh_snapshot *s, uint32_t first_row, uint32_t nrows, u
     int rc = use_device(e);
     if (rc) return rc;
     HIPCHK(lh::launch_mark_dirty(e->bufs[(size_t)s->buf].ranges, first_row, nrows, lo_bin, hi_bin, e->xstream));
+    // the caller wrote cells of its own: nothing is known about their size any more (a later merge uses uint64 cells)
+    __atomic_store_n(&e->bufs[(size_t)s->buf].nsamples, ~uint64_t(0), __ATOMIC_RELAXED);
     return LH_OK;
 }
 
@@ -1332,45 +1438,50 @@ int lh_snapshot_merge(lh_snapshot *s, void *comm, int nranks, int rank, int plan
     std::lock_guard<std::mutex> g(e->xmu);
     EpochBuffer &b = e->bufs[(size_t)s->buf];
     hipStream_t st = e->xstream;
-    const uint32_t per = (nrows + (uint32_t)nranks - 1) / (uint32_t)nranks;
     const bool rs = plan == LH_MERGE_REDUCE_SCATTER;
-    uint32_t own_lo = 0, own_hi = nrows;
-    if (rs) {
-        own_lo = std::min<uint32_t>((uint32_t)rank * per, nrows);
-        own_hi = std::min<uint32_t>(own_lo + per, nrows);
-    }
-    if (first_owned) *first_owned = own_lo;
-    if (last_owned) *last_owned = own_hi;
+    if (first_owned) *first_owned = 0;
+    if (last_owned) *last_owned = rs ? 0 : nrows;
     e->merge_info = lh_merge_info{};
+    e->merge_events_pending = false;
+    for (hipEvent_t &ev : e->merge_ev)
+        if (!ev) HIPCHK(hipEventCreate(&ev));
+    HIPCHK(hipEventRecord(e->merge_ev[0], st));
 
-    // plan arrays: P[max_metrics + 1], bstart[1025], info[4] -- allocated once, never moved
+    // plan arrays: P[max_metrics + 1], bstart[1025], info[8], brow[1025] (uint32) -- allocated once, never moved
     const size_t M = e->cfg.max_metrics;
-    if (!e->d_mplan) HIPCHK(hipMalloc((void **)&e->d_mplan, (M + 1 + 1025 + 4) * sizeof(uint64_t)));
+    if (!e->d_mplan) HIPCHK(hipMalloc((void **)&e->d_mplan, (M + 1 + 1025 + 8 + 520) * sizeof(uint64_t)));
     uint64_t *d_P = e->d_mplan, *d_bstart = d_P + M + 1, *d_info = d_bstart + 1025;
+    uint32_t *d_brow = reinterpret_cast<uint32_t *>(d_info + 8);
 
-    // 1. dirty ranges: min(lo), max(hi) over the ranks with ONE MIN all-reduce on (lo, ~hi), in place
-    const size_t rbytes = (size_t)nrows * 2 * sizeof(uint32_t);
-    rc = ensure_xbuf(e, rbytes + 64);
+    // 1. dirty ranges: min(lo), max(hi) over the ranks with ONE MIN all-reduce on (lo, ~hi), in place.  One more
+    //    word rides along: this rank's sample count of the interval (clipped), so that every rank learns the largest
+    //    one and all of them pick the same cell type for the wire.
+    const size_t rbytes = ((size_t)nrows * 2 + 1) * sizeof(uint32_t);
+    rc = ensure_xbuf(e, rbytes + 256);
     if (rc) return rc;
     uint32_t *d_tmp = reinterpret_cast<uint32_t *>(e->d_xbuf);
-    HIPCHK(lh::launch_ranges_flip_hi(d_tmp, b.ranges, nrows, st));
-    NCCLCHK(g_allreduce(d_tmp, d_tmp, (size_t)nrows * 2, kNcclUint32, kNcclMin, comm, st));
-    HIPCHK(lh::launch_ranges_flip_hi(b.ranges, d_tmp, nrows, st)); // (lo, ~~hi) back in place
+    const uint64_t mine = __atomic_load_n(&b.nsamples, __ATOMIC_RELAXED);
+    HIPCHK(lh::launch_ranges_flip_hi(d_tmp, b.ranges, nrows, true, mine > 0xffffffffull ? 0xffffffffu : (uint32_t)mine,
+                                     st));
+    NCCLCHK(g_allreduce(d_tmp, d_tmp, (size_t)nrows * 2 + 1, kNcclUint32, kNcclMin, comm, st));
+    HIPCHK(lh::launch_ranges_flip_hi(b.ranges, d_tmp, nrows, false, 0, st)); // (lo, ~~hi) back in place
+    HIPCHK(hipEventRecord(e->merge_ev[1], st));
 
     // 2. the window plan, on the device: every row keeps its OWN merged window [lo_r, hi_r]; the windows are
-    //    packed back to back (CSR).  The host only needs two totals to size the collective; the plan kernel
-    //    stores them straight into pinned memory and the host spins on a completion word (no copy, no stream
-    //    synchronisation unless the stream is still busy with the interval's ingest after 2 ms).
+    //    packed back to back (CSR) and cut into nranks owner blocks of equal packed size.  The host only needs a few
+    //    totals to size the collective; the plan kernel stores them straight into pinned memory and the host spins
+    //    on a completion word (no copy, no stream synchronisation unless the stream is still busy with the
+    //    interval's ingest after 2 ms).
     const uint32_t nblocks = rs ? (uint32_t)nranks : 1u;
-    const uint32_t plan_per = rs ? per : nrows;
-    uint64_t info[4] = {0, 0, 0, 0};
+    uint64_t info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (e->d_hxbuf) {
-        volatile uint32_t *flag = reinterpret_cast<volatile uint32_t *>(e->h_xbuf + 32);
+        volatile uint32_t *flag = reinterpret_cast<volatile uint32_t *>(e->h_xbuf + 64);
         if (++e->xseq == 0) e->xseq = 1;
         *flag = 0;
-        HIPCHK(lh::launch_merge_plan(b.ranges, nrows, plan_per, nblocks, d_P, d_bstart,
-                                     reinterpret_cast<uint64_t *>(e->d_hxbuf),
-                                     reinterpret_cast<uint32_t *>(e->d_hxbuf + 32), e->xseq, st));
+        HIPCHK(lh::launch_merge_plan(b.ranges, nrows, nblocks, (uint32_t)rank, d_tmp + (size_t)nrows * 2, d_P, d_bstart,
+                                     d_brow, reinterpret_cast<uint64_t *>(e->d_hxbuf),
+                                     reinterpret_cast<uint32_t *>(e->d_hxbuf + 64), e->xseq, st));
+        HIPCHK(hipEventRecord(e->merge_ev[2], st));
         const auto t0 = std::chrono::steady_clock::now();
         uint32_t spins = 0;
         while (*flag != e->xseq) {
@@ -1383,20 +1494,30 @@ int lh_snapshot_merge(lh_snapshot *s, void *comm, int nranks, int rank, int plan
         std::atomic_thread_fence(std::memory_order_acquire);
         std::memcpy(info, e->h_xbuf, sizeof(info));
     } else {
-        HIPCHK(lh::launch_merge_plan(b.ranges, nrows, plan_per, nblocks, d_P, d_bstart, d_info, nullptr, 0, st));
+        HIPCHK(lh::launch_merge_plan(b.ranges, nrows, nblocks, (uint32_t)rank, d_tmp + (size_t)nrows * 2, d_P, d_bstart,
+                                     d_brow, d_info, nullptr, 0, st));
+        HIPCHK(hipEventRecord(e->merge_ev[2], st));
         HIPCHK(hipMemcpyAsync(e->h_xbuf, d_info, sizeof(info), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         std::memcpy(info, e->h_xbuf, sizeof(info));
     }
     const uint64_t total = info[0], bmax = info[1];
+    const uint32_t own_lo = rs ? (uint32_t)info[5] : 0u, own_hi = rs ? (uint32_t)info[6] : nrows;
+    if (first_owned) *first_owned = own_lo;
+    if (last_owned) *last_owned = own_hi;
+    // no merged cell can reach 2^32 when nranks x (the largest per-rank sample count) stays below it
+    const bool cells32 = info[4] < 0xffffffffull && info[4] * (uint64_t)nranks < (uint64_t(1) << 32);
+    const size_t cell = cells32 ? sizeof(uint32_t) : sizeof(uint64_t);
     e->merge_info.packed_cells = total;
     e->merge_info.widest_row = (uint32_t)info[2];
     e->merge_info.occupied_rows = (uint32_t)info[3];
+    e->merge_info.padded_cells = rs ? (uint64_t)nranks * bmax : total;
+    e->merge_info.cell_bytes = (uint32_t)cell;
     if (total == 0) return LH_OK; // nothing anywhere (every rank computes the same plan: no hang)
 
     // 3. pack -> collective -> unpack.  The pack buffer is its own grow-only allocation.
     const uint64_t send_elems = rs ? (uint64_t)nranks * bmax : total, recv_elems = rs ? bmax : 0;
-    const size_t need = (size_t)(send_elems + recv_elems) * sizeof(uint64_t);
+    const size_t need = (size_t)(send_elems + recv_elems) * cell;
     if (need > e->mbuf_bytes) {
         if (e->d_mbuf) (void)hipFree(e->d_mbuf);
         e->d_mbuf = nullptr;
@@ -1405,27 +1526,47 @@ int lh_snapshot_merge(lh_snapshot *s, void *comm, int nranks, int rank, int plan
         HIPCHK(hipMalloc((void **)&e->d_mbuf, cap));
         e->mbuf_bytes = cap;
     }
-    uint64_t *send = e->d_mbuf, *recv = send + send_elems;
-    e->merge_info.send_bytes = send_elems * sizeof(uint64_t);
-    e->merge_info.recv_bytes = (rs ? recv_elems : total) * sizeof(uint64_t);
-    HIPCHK(lh::launch_pack_rows(b.counts, b.ranges, d_P, d_bstart, nrows, plan_per, nblocks, rs ? bmax : total, send,
-                                st));
+    unsigned char *send = reinterpret_cast<unsigned char *>(e->d_mbuf), *recv = send + (size_t)send_elems * cell;
+    e->merge_info.send_bytes = send_elems * cell;
+    e->merge_info.recv_bytes = (rs ? recv_elems : total) * cell;
+    HIPCHK(lh::launch_pack_rows(b.counts, b.ranges, d_P, d_bstart, d_brow, nrows, nblocks, rs ? bmax : total, send,
+                                cells32, st));
+    HIPCHK(hipEventRecord(e->merge_ev[3], st));
+    const int dt = cells32 ? kNcclUint32 : kNcclUint64;
     if (!rs) {
-        NCCLCHK(g_allreduce(send, send, (size_t)total, kNcclUint64, kNcclSum, comm, st));
-        HIPCHK(lh::launch_unpack_rows(b.counts, b.ranges, d_P, d_bstart, 0, 0, nrows, send, st));
-        return LH_OK;
+        NCCLCHK(g_allreduce(send, send, (size_t)total, dt, kNcclSum, comm, st));
+        HIPCHK(hipEventRecord(e->merge_ev[4], st));
+        HIPCHK(lh::launch_unpack_rows(b.counts, b.ranges, d_P, d_bstart, 0, 0, nrows, send, cells32, st));
+    } else {
+        // reduce-scatter by contiguous name blocks of equal packed size, every block padded to the largest one
+        NCCLCHK(g_reducescatter(send, recv, (size_t)recv_elems, dt, kNcclSum, comm, st));
+        HIPCHK(hipEventRecord(e->merge_ev[4], st));
+        HIPCHK(lh::launch_unpack_rows(b.counts, b.ranges, d_P, d_bstart, (uint32_t)rank, own_lo, own_hi - own_lo, recv,
+                                      cells32, st));
     }
-    // reduce-scatter by contiguous name blocks, every block padded to the largest one
-    NCCLCHK(g_reducescatter(send, recv, (size_t)recv_elems, kNcclUint64, kNcclSum, comm, st));
-    HIPCHK(lh::launch_unpack_rows(b.counts, b.ranges, d_P, d_bstart, (uint32_t)rank, own_lo, own_hi - own_lo, recv, st));
+    HIPCHK(hipEventRecord(e->merge_ev[5], st));
+    e->merge_events_pending = true;
+    // the rows now hold sums over the ranks: the per-rank bound no longer describes them
+    __atomic_store_n(&b.nsamples, ~uint64_t(0), __ATOMIC_RELAXED);
     return LH_OK;
 }
 
 int lh_snapshot_merge_info(lh_snapshot *s, lh_merge_info *out)
 {
     if (!s || !out) return LH_EINVAL;
-    std::lock_guard<std::mutex> g(s->e->xmu);
-    *out = s->e->merge_info;
+    lh_engine *e = s->e;
+    std::lock_guard<std::mutex> g(e->xmu);
+    if (e->merge_events_pending) {
+        int rc = use_device(e);
+        if (rc) return rc;
+        HIPCHK(hipEventSynchronize(e->merge_ev[5]));
+        float *ms[5] = {&e->merge_info.ranges_ms, &e->merge_info.plan_ms, &e->merge_info.pack_ms,
+                        &e->merge_info.collective_ms, &e->merge_info.unpack_ms};
+        for (int i = 0; i < 5; i++) HIPCHK(hipEventElapsedTime(ms[i], e->merge_ev[i], e->merge_ev[i + 1]));
+        HIPCHK(hipEventElapsedTime(&e->merge_info.span_ms, e->merge_ev[0], e->merge_ev[5]));
+        e->merge_events_pending = false;
+    }
+    *out = e->merge_info;
     return LH_OK;
 }
 
@@ -1842,6 +1983,7 @@ int lh_release(lh_snapshot *s)
             HIPCHK(hipMemsetAsync(b.cflag, 0, (size_t)e->cfg.max_counters * sizeof(uint32_t), e->xstream));
         }
         HIPCHK(hipEventRecord(b.cleared, e->xstream));
+        __atomic_store_n(&b.nsamples, 0, __ATOMIC_RELAXED);
     }
     {
         std::unique_lock<std::shared_mutex> eg(e->epoch_mu);
@@ -1949,6 +2091,10 @@ int lh_set_option(lh_engine *e, int option, uint64_t value)
         if (value != 0 && (value < 10 || value > 13)) return LH_EINVAL;
         e->v3_log_w_fixed = value != 0;
         e->tune.v3_log_w = value ? (uint32_t)value : 10u;
+        return LH_OK;
+    case LH_OPT_LANE_ZERO_COPY:
+        if (value > 1) return LH_EINVAL;
+        e->lane_zero_copy = value != 0;
         return LH_OK;
     case LH_OPT_SMALL_PATH:
         if (value > 1) return LH_EINVAL;

@@ -103,18 +103,23 @@ hipError_t launch_compact_cells(const uint64_t *counts, const uint32_t *ranges, 
                                 const uint64_t *offsets, int16_t *keys, uint64_t *vals, hipStream_t s);
 
 // K4 helpers (multi-GPU merge): the collective itself is RCCL, called from lh_engine.cc.
-hipError_t launch_ranges_flip_hi(uint32_t *dst, const uint32_t *src, uint32_t nrows, hipStream_t s);
-// Per-row windows packed CSR: P[nrows+1] exclusive prefix of the merged window widths, bstart[nblocks+1] the
-// prefix at the owner-block boundaries (blocks of `per` rows), info = {total cells, largest block, widest row,
-// occupied rows}; host_flag (device mapping of pinned memory, or null) receives `seq` after info is stored.
-hipError_t launch_merge_plan(const uint32_t *ranges, uint32_t nrows, uint32_t per, uint32_t nblocks, uint64_t *P,
-                             uint64_t *bstart, uint64_t *info, uint32_t *host_flag, uint32_t seq, hipStream_t s);
-// buf[k * bstride + ...]: block k's rows back to back, the rest of each block zeroed.
+// (lo, hi) -> (lo, ~hi) for the MIN all-reduce; with_extra: dst[2 * nrows] = ~extra rides along (its all-reduced
+// complement is the largest `extra` of any rank).
+hipError_t launch_ranges_flip_hi(uint32_t *dst, const uint32_t *src, uint32_t nrows, bool with_extra, uint32_t extra,
+                                 hipStream_t s);
+// Per-row windows packed CSR: P[nrows+1] exclusive prefix of the merged window widths; the nblocks owner blocks are
+// contiguous row ranges of equal PACKED size: brow[nblocks+1] their first rows, bstart[nblocks+1] the prefix there.
+// info[8] = {total cells, largest block, widest row, occupied rows, ~extra_src[0], first row and end row of block
+// `rank`, 0}; host_flag (device mapping of pinned memory, or null) receives `seq` after info is stored.
+hipError_t launch_merge_plan(const uint32_t *ranges, uint32_t nrows, uint32_t nblocks, uint32_t rank,
+                             const uint32_t *extra_src, uint64_t *P, uint64_t *bstart, uint32_t *brow, uint64_t *info,
+                             uint32_t *host_flag, uint32_t seq, hipStream_t s);
+// buf[k * bstride + ...]: block k's rows back to back, the rest of each block zeroed; cells32: uint32 cells on the wire.
 hipError_t launch_pack_rows(const uint64_t *counts, const uint32_t *ranges, const uint64_t *P, const uint64_t *bstart,
-                            uint32_t nrows, uint32_t per, uint32_t nblocks, uint64_t bstride, uint64_t *buf,
-                            hipStream_t s);
+                            const uint32_t *brow, uint32_t nrows, uint32_t nblocks, uint64_t bstride, void *buf,
+                            bool cells32, hipStream_t s);
 hipError_t launch_unpack_rows(uint64_t *counts, const uint32_t *ranges, const uint64_t *P, const uint64_t *bstart,
-                              uint32_t kblock, uint32_t first_row, uint32_t nrows_out, const uint64_t *buf,
+                              uint32_t kblock, uint32_t first_row, uint32_t nrows_out, const void *buf, bool cells32,
                               hipStream_t s);
 
 // K6 (lh_kernels_fmt.hip): ProcessedMetricSet keys + Go "%f" + wire lines, one thread per (metric, key).

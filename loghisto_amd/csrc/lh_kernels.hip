@@ -755,11 +755,14 @@ hipError_t launch_compact_cells(const uint64_t *counts, const uint32_t *ranges, 
 // ---------------------------------------------------------------------------
 // K4 helpers: pack / unpack for the multi-GPU merge (the collective itself is RCCL, lh_engine.cc)
 // ---------------------------------------------------------------------------
-// ranges (lo, hi) -> (lo, ~hi): one MIN all-reduce then yields min(lo) and max(hi)
-__global__ void k_ranges_flip_hi(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint32_t nrows)
+// ranges (lo, hi) -> (lo, ~hi): one MIN all-reduce then yields min(lo) and max(hi).  `extra` rides behind the last
+// row the same way (~x: the MIN all-reduce returns the complement of the largest x of any rank).
+__global__ void k_ranges_flip_hi(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint32_t nrows,
+                                 uint32_t with_extra, uint32_t extra)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nrows) { dst[2 * (size_t)i] = src[2 * (size_t)i]; dst[2 * (size_t)i + 1] = ~src[2 * (size_t)i + 1]; }
+    if (i == 0 && with_extra) dst[2 * (size_t)nrows] = ~extra;
 }
 
 // ---- per-row windows, packed CSR ---------------------------------------------------------------
@@ -768,20 +771,28 @@ __global__ void k_ranges_flip_hi(uint32_t *__restrict__ dst, const uint32_t *__r
 // outlier sample therefore widens ONE row's window (at most 512 KiB), never the whole matrix
 // (one global window made a +1e140 sample cost tens of GiB).
 //
-// k_merge_plan (one workgroup): P[r] = exclusive prefix of the widths, bstart[k] = P[min(k*per, nrows)] for the
-// nblocks owner blocks of `per` rows each (all-reduce: one block).  info = {total cells, largest block, widest
-// row, occupied rows}; when host_flag is set it is stored system-scope for the host, which needs the counts
-// to size the collective.
+// k_merge_plan (one workgroup): P[r] = exclusive prefix of the widths.  The nblocks owner blocks of a
+// reduce-scatter are CONTIGUOUS ROW RANGES OF EQUAL PACKED SIZE, not of equal row count: block k starts at the
+// first row whose prefix reaches k/nblocks of the total (brow[k]; every rank computes the same boundaries from the
+// same merged ranges).  RCCL's reduce-scatter wants equal blocks, so every block is padded to the largest; with
+// equal row counts and names ranked by frequency (ids of a Zipf stream) the first block holds the widest windows and
+// every other block pays for it, with equal cells the padding is at most one row's window.
+// info = {total cells, largest block, widest row, occupied rows, largest per-rank sample count of the interval
+// (complement of extra_src[0]), first row / end row of block `rank`}; when host_flag is set it is stored
+// system-scope for the host, which needs the counts to size the collective.
 constexpr int MP_BLOCK = 1024;
 __global__ __launch_bounds__(MP_BLOCK) void k_merge_plan(const uint32_t *__restrict__ ranges, uint32_t nrows,
-                                                         uint32_t per, uint32_t nblocks,
+                                                         uint32_t nblocks, uint32_t rank,
+                                                         const uint32_t *__restrict__ extra_src,
                                                          unsigned long long *__restrict__ P /*[nrows+1]*/,
                                                          unsigned long long *__restrict__ bstart /*[nblocks+1]*/,
-                                                         unsigned long long *__restrict__ info /*[4]*/,
+                                                         uint32_t *__restrict__ brow /*[nblocks+1]*/,
+                                                         unsigned long long *__restrict__ info /*[8]*/,
                                                          uint32_t *__restrict__ host_flag, uint32_t seq)
 {
     __shared__ unsigned long long s_w[MP_BLOCK / 64];
     __shared__ uint32_t s_maxw[MP_BLOCK / 64], s_occ[MP_BLOCK / 64];
+    __shared__ unsigned long long s_bmax;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t R = (nrows + MP_BLOCK - 1) / MP_BLOCK;
     const uint32_t r0 = tid * R, r1 = min(nrows, r0 + R);
@@ -807,6 +818,7 @@ __global__ __launch_bounds__(MP_BLOCK) void k_merge_plan(const uint32_t *__restr
     }
     if (lane == 63) s_w[wave] = inc;
     if (lane == 0) { s_maxw[wave] = maxw; s_occ[wave] = occ; }
+    if (tid == 0) s_bmax = 0;
     __syncthreads();
     unsigned long long base = 0, total = 0;
     uint32_t gmax = 0, gocc = 0;
@@ -824,17 +836,33 @@ __global__ __launch_bounds__(MP_BLOCK) void k_merge_plan(const uint32_t *__restr
     }
     if (tid == 0) P[nrows] = total;
     __syncthreads(); // workgroup-scope release/acquire: P[] written above is read below by other threads
-    unsigned long long bmax = 0;
-    if (tid == 0) {
-        for (uint32_t k = 0; k <= nblocks; k++) {
-            const unsigned long long at = P[min((unsigned long long)k * per, (unsigned long long)nrows)];
-            bstart[k] = at;
-            if (k) bmax = max(bmax, at - bstart[k - 1]);
+    // block boundaries: thread k finds the first row whose prefix reaches k * total / nblocks
+    for (uint32_t k = tid; k <= nblocks; k += MP_BLOCK) {
+        uint32_t row = k == 0 ? 0u : nrows;
+        if (k != 0 && k != nblocks) {
+            const unsigned long long target = total / nblocks * k + total % nblocks * k / nblocks;
+            uint32_t lo = 0, hi = nrows; // smallest r in [0, nrows] with P[r] >= target
+            while (lo < hi) {
+                const uint32_t mid = lo + (hi - lo) / 2;
+                if (P[mid] >= target) hi = mid; else lo = mid + 1;
+            }
+            row = lo;
         }
+        brow[k] = row;
+        bstart[k] = P[row];
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < nblocks; k += MP_BLOCK) atomicMax(&s_bmax, bstart[k + 1] - bstart[k]);
+    __syncthreads();
+    if (tid == 0) {
         info[0] = total;
-        info[1] = bmax;
+        info[1] = s_bmax;
         info[2] = gmax;
         info[3] = gocc;
+        info[4] = extra_src ? (unsigned long long)(~extra_src[0]) : ~0ull;
+        info[5] = brow[min(rank, nblocks)];
+        info[6] = brow[min(rank + 1u, nblocks)];
+        info[7] = 0;
         if (host_flag) {
             __threadfence_system();
             __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -842,89 +870,121 @@ __global__ __launch_bounds__(MP_BLOCK) void k_merge_plan(const uint32_t *__restr
     }
 }
 
-// Row r's window <-> buf[(r / per) * bstride + (P[r] - bstart[r / per]) ...].  One workgroup per row.
+// the owner block of row r: the last k with brow[k] <= r (empty blocks share a boundary with their successor)
+__device__ __forceinline__ uint32_t merge_block_of(const uint32_t *__restrict__ brow, uint32_t nblocks, uint32_t r)
+{
+    uint32_t lo = 0, hi = nblocks; // largest k in [0, nblocks) with brow[k] <= r
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (brow[mid] <= r) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// Row r's window <-> buf[k * bstride + (P[r] - bstart[k]) ...], k = the row's owner block.  One workgroup per row.
+// CELL is the wire type: uint64_t, or uint32_t when no merged cell can reach 2^32 (lh_snapshot_merge decides).
+template <typename CELL>
 __global__ __launch_bounds__(256) void k_pack_rows(const uint64_t *__restrict__ counts,
                                                    const uint32_t *__restrict__ ranges,
                                                    const unsigned long long *__restrict__ P,
-                                                   const unsigned long long *__restrict__ bstart, uint32_t per,
-                                                   unsigned long long bstride, uint64_t *__restrict__ buf)
+                                                   const unsigned long long *__restrict__ bstart,
+                                                   const uint32_t *__restrict__ brow, uint32_t nblocks,
+                                                   unsigned long long bstride, CELL *__restrict__ buf)
 {
     const uint32_t r = blockIdx.x;
     const uint32_t lo = ranges[2 * (size_t)r], hi = ranges[2 * (size_t)r + 1];
     if (lo > hi) return;
-    const uint32_t k = r / per;
-    uint64_t *dst = buf + (size_t)k * bstride + (P[r] - bstart[k]);
+    const uint32_t k = merge_block_of(brow, nblocks, r);
+    CELL *dst = buf + (size_t)k * bstride + (P[r] - bstart[k]);
     const uint64_t *src = counts + (size_t)r * LH_NKEYS + lo;
-    for (uint32_t i = threadIdx.x; i <= hi - lo; i += 256) dst[i] = src[i];
+    for (uint32_t i = threadIdx.x; i <= hi - lo; i += 256) dst[i] = (CELL)src[i];
 }
 
 // Zero the tail of every owner block of the send buffer (blocks are padded to the largest one).
+template <typename CELL>
 __global__ __launch_bounds__(256) void k_pack_pad(const unsigned long long *__restrict__ bstart, uint32_t nblocks,
-                                                  unsigned long long bstride, uint64_t *__restrict__ buf)
+                                                  unsigned long long bstride, CELL *__restrict__ buf)
 {
     const uint32_t k = blockIdx.y;
     if (k >= nblocks) return;
     const unsigned long long used = bstart[k + 1] - bstart[k];
-    uint64_t *dst = buf + (size_t)k * bstride;
+    CELL *dst = buf + (size_t)k * bstride;
     for (unsigned long long i = used + (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < bstride;
          i += (unsigned long long)gridDim.x * 256)
         dst[i] = 0;
 }
 
 // buf holds block `kblock` (rows first_row .. first_row + nrows_out) packed from offset 0.
+template <typename CELL>
 __global__ __launch_bounds__(256) void k_unpack_rows(uint64_t *__restrict__ counts,
                                                      const uint32_t *__restrict__ ranges,
                                                      const unsigned long long *__restrict__ P,
                                                      const unsigned long long *__restrict__ bstart, uint32_t kblock,
-                                                     uint32_t first_row, const uint64_t *__restrict__ buf)
+                                                     uint32_t first_row, const CELL *__restrict__ buf)
 {
     const uint32_t r = first_row + blockIdx.x;
     const uint32_t lo = ranges[2 * (size_t)r], hi = ranges[2 * (size_t)r + 1];
     if (lo > hi) return;
-    const uint64_t *src = buf + (P[r] - bstart[kblock]);
+    const CELL *src = buf + (P[r] - bstart[kblock]);
     uint64_t *dst = counts + (size_t)r * LH_NKEYS + lo;
-    for (uint32_t i = threadIdx.x; i <= hi - lo; i += 256) dst[i] = src[i];
+    for (uint32_t i = threadIdx.x; i <= hi - lo; i += 256) dst[i] = (uint64_t)src[i];
 }
 
-hipError_t launch_ranges_flip_hi(uint32_t *dst, const uint32_t *src, uint32_t nrows, hipStream_t s)
+hipError_t launch_ranges_flip_hi(uint32_t *dst, const uint32_t *src, uint32_t nrows, bool with_extra, uint32_t extra,
+                                 hipStream_t s)
 {
     if (!nrows) return hipSuccess;
-    hipLaunchKernelGGL(k_ranges_flip_hi, dim3((nrows + 255) / 256), dim3(256), 0, s, dst, src, nrows);
+    hipLaunchKernelGGL(k_ranges_flip_hi, dim3((nrows + 255) / 256), dim3(256), 0, s, dst, src, nrows,
+                       with_extra ? 1u : 0u, extra);
     return hipGetLastError();
 }
 
-hipError_t launch_merge_plan(const uint32_t *ranges, uint32_t nrows, uint32_t per, uint32_t nblocks, uint64_t *P,
-                             uint64_t *bstart, uint64_t *info, uint32_t *host_flag, uint32_t seq, hipStream_t s)
+hipError_t launch_merge_plan(const uint32_t *ranges, uint32_t nrows, uint32_t nblocks, uint32_t rank,
+                             const uint32_t *extra_src, uint64_t *P, uint64_t *bstart, uint32_t *brow, uint64_t *info,
+                             uint32_t *host_flag, uint32_t seq, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_merge_plan, dim3(1), dim3(MP_BLOCK), 0, s, ranges, nrows, per, nblocks,
-                       reinterpret_cast<unsigned long long *>(P), reinterpret_cast<unsigned long long *>(bstart),
+    hipLaunchKernelGGL(k_merge_plan, dim3(1), dim3(MP_BLOCK), 0, s, ranges, nrows, nblocks, rank, extra_src,
+                       reinterpret_cast<unsigned long long *>(P), reinterpret_cast<unsigned long long *>(bstart), brow,
                        reinterpret_cast<unsigned long long *>(info), host_flag, seq);
     return hipGetLastError();
 }
 
 hipError_t launch_pack_rows(const uint64_t *counts, const uint32_t *ranges, const uint64_t *P, const uint64_t *bstart,
-                            uint32_t nrows, uint32_t per, uint32_t nblocks, uint64_t bstride, uint64_t *buf,
-                            hipStream_t s)
+                            const uint32_t *brow, uint32_t nrows, uint32_t nblocks, uint64_t bstride, void *buf,
+                            bool cells32, hipStream_t s)
 {
     if (!nrows) return hipSuccess;
-    hipLaunchKernelGGL(k_pack_rows, dim3(nrows), dim3(256), 0, s, counts, ranges,
-                       reinterpret_cast<const unsigned long long *>(P),
-                       reinterpret_cast<const unsigned long long *>(bstart), per, (unsigned long long)bstride, buf);
-    if (nblocks > 1)
-        hipLaunchKernelGGL(k_pack_pad, dim3(64, nblocks), dim3(256), 0, s,
-                           reinterpret_cast<const unsigned long long *>(bstart), nblocks, (unsigned long long)bstride,
-                           buf);
+    const unsigned long long *Pp = reinterpret_cast<const unsigned long long *>(P);
+    const unsigned long long *bs = reinterpret_cast<const unsigned long long *>(bstart);
+    if (cells32) {
+        hipLaunchKernelGGL(k_pack_rows<uint32_t>, dim3(nrows), dim3(256), 0, s, counts, ranges, Pp, bs, brow, nblocks,
+                           (unsigned long long)bstride, static_cast<uint32_t *>(buf));
+        if (nblocks > 1)
+            hipLaunchKernelGGL(k_pack_pad<uint32_t>, dim3(64, nblocks), dim3(256), 0, s, bs, nblocks,
+                               (unsigned long long)bstride, static_cast<uint32_t *>(buf));
+    } else {
+        hipLaunchKernelGGL(k_pack_rows<uint64_t>, dim3(nrows), dim3(256), 0, s, counts, ranges, Pp, bs, brow, nblocks,
+                           (unsigned long long)bstride, static_cast<uint64_t *>(buf));
+        if (nblocks > 1)
+            hipLaunchKernelGGL(k_pack_pad<uint64_t>, dim3(64, nblocks), dim3(256), 0, s, bs, nblocks,
+                               (unsigned long long)bstride, static_cast<uint64_t *>(buf));
+    }
     return hipGetLastError();
 }
 
 hipError_t launch_unpack_rows(uint64_t *counts, const uint32_t *ranges, const uint64_t *P, const uint64_t *bstart,
-                              uint32_t kblock, uint32_t first_row, uint32_t nrows_out, const uint64_t *buf,
+                              uint32_t kblock, uint32_t first_row, uint32_t nrows_out, const void *buf, bool cells32,
                               hipStream_t s)
 {
     if (!nrows_out) return hipSuccess;
-    hipLaunchKernelGGL(k_unpack_rows, dim3(nrows_out), dim3(256), 0, s, counts, ranges,
-                       reinterpret_cast<const unsigned long long *>(P),
-                       reinterpret_cast<const unsigned long long *>(bstart), kblock, first_row, buf);
+    const unsigned long long *Pp = reinterpret_cast<const unsigned long long *>(P);
+    const unsigned long long *bs = reinterpret_cast<const unsigned long long *>(bstart);
+    if (cells32)
+        hipLaunchKernelGGL(k_unpack_rows<uint32_t>, dim3(nrows_out), dim3(256), 0, s, counts, ranges, Pp, bs, kblock,
+                           first_row, static_cast<const uint32_t *>(buf));
+    else
+        hipLaunchKernelGGL(k_unpack_rows<uint64_t>, dim3(nrows_out), dim3(256), 0, s, counts, ranges, Pp, bs, kblock,
+                           first_row, static_cast<const uint64_t *>(buf));
     return hipGetLastError();
 }
 

@@ -212,7 +212,8 @@ class Snapshot:
         """What the last merge moved (lh_snapshot_merge_info)."""
         mi = N.LhMergeInfo()
         N.check(N.lib().lh_snapshot_merge_info(self._h, C.byref(mi)), "lh_snapshot_merge_info")
-        return {k: int(getattr(mi, k)) for k, _ in N.LhMergeInfo._fields_}
+        return {k: (float(getattr(mi, k)) if k.endswith("_ms") else int(getattr(mi, k)))
+                for k, _ in N.LhMergeInfo._fields_ if k != "reserved"}
 
     def stream(self) -> int:
         p = C.c_void_p(0)
@@ -282,6 +283,34 @@ class Engine:
         if i.size != v.size:
             raise ValueError("ids and values differ in length")
         N.check(N.lib().lh_submit_pairs(self._h, i.ctypes.data, v.ctypes.data, v.size), "lh_submit_pairs")
+
+    def reserve_pairs(self, want: int):
+        """(ids uint32[granted], values float64[granted], token): views of a pinned staging buffer to fill in place
+        (lh_reserve_pairs); publish the first n with commit_pairs(token, n)."""
+        pi, pv, g, tok = C.c_void_p(), C.c_void_p(), C.c_size_t(0), C.c_uint32(0)
+        N.check(N.lib().lh_reserve_pairs(self._h, want, C.byref(pi), C.byref(pv), C.byref(g), C.byref(tok)),
+                "lh_reserve_pairs")
+        ids = np.ctypeslib.as_array(C.cast(pi, C.POINTER(C.c_uint32)), shape=(g.value,))
+        vals = np.ctypeslib.as_array(C.cast(pv, C.POINTER(C.c_double)), shape=(g.value,))
+        return ids, vals, tok.value
+
+    def commit_pairs(self, token: int, n: int):
+        N.check(N.lib().lh_commit_pairs(self._h, token, n), "lh_commit_pairs")
+
+    def submit_pairs_in_place(self, ids, values):
+        """The same stream as submit_pairs through reserve / fill / commit: one host-side copy, no id scan."""
+        i = np.ascontiguousarray(ids, dtype=np.uint32)
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        if i.size != v.size:
+            raise ValueError("ids and values differ in length")
+        done = 0
+        while done < v.size:
+            di, dv, tok = self.reserve_pairs(v.size - done)
+            k = di.size
+            np.copyto(di, i[done:done + k])
+            np.copyto(dv, v[done:done + k])
+            self.commit_pairs(tok, k)
+            done += k
 
     def submit_device(self, metric_id: int, d_values, n: Optional[int] = None, stream=None):
         n = int(d_values.numel()) if n is None else n

@@ -75,20 +75,33 @@ def main():
     assert not errors, errors
     assert all(not t.is_alive() for t in th), "a rank never left the collective"
 
-    per = -(-M // nranks)
     covered = []
     infos = []
+    widths = np.where(want_ranges[:, 0] <= want_ranges[:, 1], want_ranges[:, 1] - want_ranges[:, 0] + 1, 0)
     for r in range(nranks):
         first, last = results[r]
         if plan == "allreduce":
             assert (first, last) == (0, M)
         else:
-            assert (first, last) == (min(r * per, M), min((r + 1) * per, M)), (r, first, last)
+            # owner blocks tile [0, M) in rank order and hold equal shares of the PACKED cells (at most one row's
+            # window more or less), not equal numbers of names
+            assert first == (results[r - 1][1] if r else 0) and last >= first, (r, results)
+            if r == nranks - 1:
+                assert last == M
+            share = int(widths[first:last].sum())
+            assert abs(share - cells / nranks) <= int(widths.max()) + 1, (r, share, cells / nranks)
         covered.extend(range(first, last))
         snap = snaps[r]
         info = snap.merge_info()
         infos.append(info)
         assert info["packed_cells"] == cells, (info, cells)
+        # every test stream is far below 2^32 samples: cells travel as uint32, and the equal-block collective pays
+        # at most one row's window per block over the packed matrix (ratio <= 1.3)
+        assert info["cell_bytes"] == 4, info
+        assert info["padded_cells"] >= cells
+        if plan != "allreduce" and cells > 100 * int(widths.max()):
+            assert info["padded_cells"] <= 1.3 * cells, info
+        assert info["span_ms"] > 0 and info["collective_ms"] >= 0 and info["pack_ms"] >= 0, info
         assert info["occupied_rows"] == int((want_ranges[:, 0] <= want_ranges[:, 1]).sum())
         # merged ranges: identical on every rank, for every row
         torch.cuda.synchronize()

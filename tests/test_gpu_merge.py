@@ -124,10 +124,11 @@ def test_native_rccl_merge_through_the_c_abi(native_lib, torch_cuda):
 
 @pytest.mark.parametrize("nranks,nrows,plan,outliers", [
     (2, 5, "allreduce", 0),
-    (2, 5, "reduce_scatter", 0),        # ragged: blocks of 3 + 2 rows, one row empty everywhere
-    (4, 37, "reduce_scatter", 1),       # 10 + 10 + 10 + 7 rows; outliers in the first and the last block
+    (2, 5, "reduce_scatter", 0),        # ragged, one row empty everywhere
+    (4, 37, "reduce_scatter", 1),       # outliers in the first and the last row: those two rows are blocks of their own
     (8, 64, "reduce_scatter", 1),       # config 4's rank count
-    (8, 5, "reduce_scatter", 0),        # more ranks than rows: ranks 5..7 own nothing
+    (8, 5, "reduce_scatter", 0),        # more ranks than rows: some ranks own nothing
+    (8, 512, "reduce_scatter", 0),      # Zipf names ranked by id: equal-cell blocks keep the padding under 1.3 x
     (4, 64, "allreduce", 1),
 ])
 def test_c_abi_merge_with_n_ranks_on_one_gpu(native_lib, torch_cuda, nranks, nrows, plan, outliers):

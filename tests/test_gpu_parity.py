@@ -319,6 +319,65 @@ def test_host_submit_multithreaded_lossless(engine):
     assert np.array_equal(rows, want)
 
 
+@pytest.mark.parametrize("zero_copy", [1, 0])
+def test_in_place_staging_reserve_commit(la, torch_cuda, zero_copy):
+    """lh_reserve_pairs / lh_commit_pairs (SURVEY.md 8b Ownership: the producer writes into the C-allocated pinned
+    buffer in place; call shape of Histogram, metrics.go:273): threads that reserve, fill a part, commit -- mixed with
+    lh_submit*, partial and empty commits, reservations that outlast other producers' calls, and flips in between.
+    Every cell equals the oracle's; with and without the kernels reading the pinned buffers in place."""
+    from loghisto_amd import _native as N
+    rng = np.random.default_rng(77)
+    T, per, M = 6, 90_011, 24
+    vals = [rng.lognormal(9, 2, per) for _ in range(T)]
+    ids = [rng.integers(0, M, per).astype(np.uint32) for _ in range(T)]
+    with la.Engine(max_metrics=M, num_buffers=2, num_lanes=3, lane_samples=1 << 14) as eng:   # fewer lanes than threads
+        eng.set_option(N.OPT_LANE_ZERO_COPY, zero_copy)
+        snaps_rows = []
+        stop = threading.Event()
+
+        def work(t):
+            lo, k = 0, 0
+            while lo < per:
+                k += 1
+                want = min(per - lo, 1 + (k * 2477) % 9001)
+                if k % 5 == 0:
+                    eng.submit_pairs(ids[t][lo:lo + want], vals[t][lo:lo + want])
+                    lo += want
+                    continue
+                di, dv, tok = eng.reserve_pairs(want)
+                n = di.size if k % 3 else di.size // 2          # partial commits; n = 0 gives the reservation back
+                di[:n] = ids[t][lo:lo + n]
+                dv[:n] = vals[t][lo:lo + n]
+                eng.commit_pairs(tok, n)
+                lo += n
+
+        def flipper():
+            while not stop.is_set():
+                try:
+                    with eng.flip() as snap:
+                        snaps_rows.append(np.stack([snap.dense_row(m) for m in range(M)]))
+                except la.LhError:
+                    pass
+
+        th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+        fl = threading.Thread(target=flipper)
+        fl.start()
+        [x.start() for x in th]
+        [x.join() for x in th]
+        stop.set()
+        fl.join()
+        with eng.flip() as snap:
+            snaps_rows.append(np.stack([snap.dense_row(m) for m in range(M)]))
+        with pytest.raises(la.LhError):
+            eng.commit_pairs(1, 0)                                # nothing reserved on that buffer: LH_ESTATE
+    got = np.sum(snaps_rows, axis=0)
+    want = np.zeros((M, oracle.NKEYS), dtype=np.uint64)
+    for t in range(T):
+        oracle.histogram_pairs(ids[t], vals[t], M, want)
+    assert int(got.sum()) == T * per
+    assert np.array_equal(got, want)
+
+
 def test_epoch_semantics(engine, la, torch_cuda):
     # a sample belongs to exactly one interval (metrics.go:460-463)
     a = np.full(1000, 10.0)
