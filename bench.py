@@ -44,6 +44,7 @@ BYTES_SINGLE, BYTES_PAIR = 8, 12                         # float
 METRIC = "float64 samples/sec bucketed (1 GPU) + % HBM roofline; p99 extract latency"
 K1_PMC = os.path.join("profiles", "r02_k1_pmc.json")
 C3_PMC = os.path.join("profiles", "r02_c3_pmc.json")
+C4_PMC = os.path.join("profiles", "r03_c4_pmc.json")
 
 
 def parse():
@@ -262,16 +263,17 @@ def run_c2(args, la, stream, rank):
 # ---------------------------------------------------------------------------------------------------------
 # C3: 1 024 Zipf names, (id, value) stream
 # ---------------------------------------------------------------------------------------------------------
-def c3_traffic(n, names):
-    """HBM bytes of one 1e9-pair call from the committed rocprofv3 --pmc summary of the same stream (PMC passes
-    cannot run inside this process); None when the run is not that configuration."""
-    path = os.path.join(ROOT, C3_PMC)
+def c3_traffic(n, names, which=None):
+    """HBM bytes of one call from the committed rocprofv3 --pmc summary of the same stream (PMC passes cannot run
+    inside this process); None when the run is not that configuration."""
+    which = which or C3_PMC
+    path = os.path.join(ROOT, which)
     try:
         j = json.load(open(path))
         if j["pairs_per_call"] == n and j["names"] == names:
             return {"traffic": j["hbm_bytes_per_call"],
-                    "traffic_source": f"{C3_PMC} (committed rocprofv3 --pmc summary of the same stream through "
-                                      "tools/sweep.py, not measured in this run)"}
+                    "traffic_source": f"{which} (committed rocprofv3 --pmc summary of the same command, every kernel "
+                                      "of one call summed; not measured in this run)"}
     except (OSError, ValueError, KeyError):
         pass
     return {"traffic": None, "traffic_source": None}
@@ -506,8 +508,8 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup):
                    "names": M, "pairs_per_gpu_per_step": n, "ranks": world, "owned_rows": [first, last],
                    "merge": frontend, "percentiles": PCTS},
         "roofline": roofline(n * BYTES_PAIR, sum(t_ing) / len(t_ing),
-                             "k_scatter_samples<hot> + k_scatter_records + k_part_hist (two-level partitioned ingest, "
-                             "all launches of one lh_submit_pairs_device)"),
+                             "k_survey_count_h .. k_scatter4 + k_split_waves + k_part_hist3 (third generation of the "
+                             "partitioned ingest: every launch of one lh_submit_pairs_device)", **c3_traffic(n, M, C4_PMC)),
         "merge": {"host_call_ms": sum(t_merge) / len(t_merge),
                   "device_ms": {k: info.get(k) for k in ("ranges_ms", "plan_ms", "pack_ms", "collective_ms",
                                                          "unpack_ms", "span_ms")},

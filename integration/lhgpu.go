@@ -31,10 +31,14 @@ import (
 const stageCap = 4096 // samples per crossing: a cgo call costs more than the old fast path
 
 // stage is a per-P (per logical processor) staging buffer; sync.Pool keeps them P-local.
+// A stage IS a piece of the engine's pinned staging memory (lh_reserve_pairs): Histogram stores the pair where the
+// ingest kernel will read it (SURVEY.md 8b Ownership: "the ring is C-allocated and Go writes into it in place").
+// ids / vals are Go slices over C memory: no Go pointer ever reaches C.
 type stage struct {
-	ids  [stageCap]C.uint32_t
-	vals [stageCap]C.double
+	ids  []C.uint32_t
+	vals []C.double
 	n    int
+	tok  C.uint32_t // reservation held by this stage (0: none)
 }
 
 type gpuEngine struct {
@@ -51,7 +55,7 @@ func newGPUEngine(maxMetrics int) *gpuEngine {
 	var cfg C.lh_config
 	C.lh_default_config(&cfg)
 	cfg.max_metrics = C.uint32_t(maxMetrics)
-	cfg.num_lanes = C.uint32_t(runtime.NumCPU())
+	cfg.num_lanes = C.uint32_t(2 * runtime.GOMAXPROCS(0)) // >= the stages that can hold a reservation
 	g := &gpuEngine{ids: make(map[string]uint32)}
 	if rc := C.lh_create(&cfg, &g.e); rc != C.LH_OK {
 		glog.Errorf("lh_create: %s (%s)", C.GoString(C.lh_strerror(rc)), C.GoString(C.lh_last_error()))
@@ -88,13 +92,28 @@ func (g *gpuEngine) id(name string) uint32 {
 	return uint32(cid)
 }
 
+// commit what the stage holds (the kernel reads it in place, over PCIe) and give the reservation back
 func (g *gpuEngine) ship(s *stage) {
-	if s.n == 0 { return }
-	// lh_submit_pairs copies into its pinned ring before returning: no Go pointer is retained.
-	if rc := C.lh_submit_pairs(g.e, &s.ids[0], &s.vals[0], C.size_t(s.n)); rc != C.LH_OK {
-		glog.Errorf("lh_submit_pairs: %s", C.GoString(C.lh_strerror(rc)))
+	if s.tok == 0 { return }
+	if rc := C.lh_commit_pairs(g.e, s.tok, C.size_t(s.n)); rc != C.LH_OK {
+		glog.Errorf("lh_commit_pairs: %s", C.GoString(C.lh_strerror(rc)))
 	}
-	s.n = 0
+	s.tok, s.n, s.ids, s.vals = 0, 0, nil, nil
+}
+
+// a fresh piece of pinned staging memory for the stage: up to stageCap pairs (one cgo crossing per stageCap samples,
+// as before).  lh_create gets num_lanes >= 2 x GOMAXPROCS so that a stage that sits idle with a reservation never
+// keeps another P waiting; every reservation is committed at the flip (collectRawMetrics below).
+func (g *gpuEngine) refill(s *stage) bool {
+	var pi *C.uint32_t
+	var pv *C.double
+	var granted C.size_t
+	if rc := C.lh_reserve_pairs(g.e, stageCap, &pi, &pv, &granted, &s.tok); rc != C.LH_OK {
+		glog.Errorf("lh_reserve_pairs: %s", C.GoString(C.lh_strerror(rc)))
+		return false
+	}
+	s.ids, s.vals, s.n = unsafe.Slice(pi, int(granted)), unsafe.Slice(pv, int(granted)), 0
+	return true
 }
 
 func (ms *MetricSystem) Histogram(name string, value float64) {
@@ -103,10 +122,12 @@ func (ms *MetricSystem) Histogram(name string, value float64) {
 	if id == ^uint32(0) { return }
 	ms.histogramMu.RLock()          // same lock, same role: readers = submitters, writer = the flip
 	s := g.pool.Get().(*stage)
-	s.ids[s.n] = C.uint32_t(id)
-	s.vals[s.n] = C.double(value)   // compress() now happens on the GPU
-	s.n++
-	if s.n == stageCap { g.ship(s) }
+	if s.tok != 0 || g.refill(s) {
+		s.ids[s.n] = C.uint32_t(id)     // the sample's only host-side store: pinned memory the kernel reads in place
+		s.vals[s.n] = C.double(value)   // compress() now happens on the GPU
+		s.n++
+		if s.n == len(s.ids) { g.ship(s) }
+	}
 	g.pool.Put(s)
 	ms.histogramMu.RUnlock()
 }

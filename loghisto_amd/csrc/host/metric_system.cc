@@ -238,7 +238,23 @@ uint32_t MetricSystem::intern(const std::string &name)
 void MetricSystem::ship(Stage &s)
 {
     if (s.n == 0) return;
-    note(lh_submit_pairs(engine_, s.ids.data(), s.vals.data(), s.n), "lh_submit_pairs");
+    // in-place staging: the stage's pairs go straight into the tail of a pinned staging buffer (their ids come from
+    // lh_intern, so the host-side validation scan of lh_submit_pairs has nothing to find); the reservation is held
+    // for the two memcpys only, never across a call that can block
+    size_t done = 0;
+    while (done < s.n) {
+        uint32_t *ids = nullptr, token = 0;
+        double *vals = nullptr;
+        size_t granted = 0;
+        if (note(lh_reserve_pairs(engine_, s.n - done, &ids, &vals, &granted, &token), "lh_reserve_pairs") != LH_OK) {
+            note(lh_submit_pairs(engine_, s.ids.data() + done, s.vals.data() + done, s.n - done), "lh_submit_pairs");
+            break;
+        }
+        std::memcpy(ids, s.ids.data() + done, granted * sizeof(uint32_t));
+        std::memcpy(vals, s.vals.data() + done, granted * sizeof(double));
+        note(lh_commit_pairs(engine_, token, granted), "lh_commit_pairs");
+        done += granted;
+    }
     s.n = 0;
 }
 

@@ -985,8 +985,9 @@ __global__ __launch_bounds__(1024, 4) void k_split_waves(const uint32_t *__restr
                                                          const pu2_t *__restrict__ g_pt2, const SurveyStat S,
                                                          uint32_t *__restrict__ records, uint32_t *__restrict__ cdesc,
                                                          uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
-                                                         uint32_t *__restrict__ g_stats)
+                                                         uint32_t *__restrict__ g_stats, uint32_t dbg_arg)
 {
+    const uint32_t dbg = LH_DBG(dbg_arg);
     constexpr int BLOCK = 1024;
     extern __shared__ __attribute__((aligned(16))) unsigned char v3_smem[];
     SplitWLds &L = *reinterpret_cast<SplitWLds *>(v3_smem);
@@ -1167,7 +1168,8 @@ __global__ __launch_bounds__(1024, 4) void k_split_waves(const uint32_t *__restr
     constexpr uint32_t WSTEP = BLOCK / 64, DEPTH = 2;
     u4_t buf[DEPTH][CHUNK / 256];
     uint32_t cn[DEPTH];
-    const uint32_t mine = cnt > wave ? (cnt - wave + WSTEP - 1) / WSTEP : 0u; // chunks of this wave
+    if (dbg & (1u << 27)) return;
+    const uint32_t mine = (dbg & (1u << 26)) ? 0u : cnt > wave ? (cnt - wave + WSTEP - 1) / WSTEP : 0u; // chunks of this wave
     for (uint32_t b0 = 0; b0 < mine; b0 += 64) {
         const uint32_t nb = min(mine - b0, 64u);
         uint32_t my_cid = 0, my_cn = 0;
@@ -1283,8 +1285,9 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
                                                          uint32_t log_mpp2, uint32_t log_w,
                                                          const uint8_t *__restrict__ g_inv, const SurveyStat S,
                                                          uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
-                                                         uint32_t *__restrict__ g_stats)
+                                                         uint32_t *__restrict__ g_stats, uint32_t dbg_arg)
 {
+    const uint32_t dbg = LH_DBG(dbg_arg);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *h = reinterpret_cast<uint32_t *>(smem);
     uint32_t *s_org = h + P3_WINWORDS, *s_mn = s_org + 32, *s_mx = s_mn + 32, *s_name = s_mx + 32, *s_svc = s_name + 32,
@@ -1380,7 +1383,8 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
     constexpr uint32_t WSTEP = P2_BLOCK / 64, DEPTH = 2;
     u4_t buf[DEPTH][CHUNK / 256];
     uint32_t cn[DEPTH];
-    const uint32_t mine = cnt > wave ? (cnt - wave + WSTEP - 1) / WSTEP : 0u; // chunks of this wave
+    if (dbg & (1u << 23)) return;
+    const uint32_t mine = (dbg & (1u << 22)) ? 0u : cnt > wave ? (cnt - wave + WSTEP - 1) / WSTEP : 0u; // chunks of this wave
     for (uint32_t b0 = 0; b0 < mine; b0 += 64) {
         const uint32_t nb = min(mine - b0, 64u);
         uint32_t my_cid = 0, my_cn = 0;
@@ -1411,14 +1415,21 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
     }
     __syncthreads();
 
+    // (one LDS atomic pair per occupied cell cost 42 us of the reduce pass's 277 on config 4's slice: one pair per wave)
     for (uint32_t i = tid; i < words; i += P2_BLOCK) {
         const uint32_t c = h[i];
+        const uint32_t l = i >> log_w, b = s_org[l] + (i & (W - 1));
         if (c) {
-            const uint32_t l = i >> log_w, b = s_org[l] + (i & (W - 1));
+            if (!(dbg & (1u << 21)))
             atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)s_name[l] * LH_NKEYS + b]),
                       (unsigned long long)c);
-            atomicMin(&s_mn[l], b);
-            atomicMax(&s_mx[l], b);
+        }
+        // the wave's 64 cells are consecutive bins of the name: its lowest and highest occupied bins are those of the
+        // first and the last lane that found a count
+        const unsigned long long occ = __builtin_amdgcn_ballot_w64(c != 0);
+        if (occ != 0ull && lane == 0) {
+            atomicMin(&s_mn[l], b + (uint32_t)__builtin_ctzll(occ));
+            atomicMax(&s_mx[l], b + 63u - (uint32_t)__builtin_clzll(occ));
         }
     }
     for (uint32_t i = tid; i < OV_SLOTS; i += P2_BLOCK)
@@ -1619,7 +1630,8 @@ hipError_t launch_ingest_pairs_part3(const uint32_t *d_ids, const double *d_v, s
     if (P.waves)
         hipLaunchKernelGGL(k_split_waves, dim3(V3_NP + P.extra1), dim3(1024), SPLITW_LDS_BYTES, s, L1.records, L1.cdesc,
                            L1.sorted, L1.part_start, L1.slots, L1.nslots, L1.pool_start, nmetrics, P.kp, P.log_mpp2,
-                           P.log_w, P.log_ns, g_remap, g_inv, g_pt2, S, L2.records, L2.cdesc, counts, ranges, g_stats);
+                           P.log_w, P.log_ns, g_remap, g_inv, g_pt2, S, L2.records, L2.cdesc, counts, ranges, g_stats,
+                           dbg);
     else
         hipLaunchKernelGGL(k_split_records, dim3(V3_NP + P.extra1), dim3(1024), SPLIT_LDS_BYTES, s, L1.records,
                            L1.cdesc, L1.sorted, L1.part_start, L1.slots, L1.nslots, L1.pool_start, nmetrics, P.kp,
@@ -1629,7 +1641,7 @@ hipError_t launch_ingest_pairs_part3(const uint32_t *d_ids, const double *d_v, s
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_part_hist3, dim3(P.nq + P.extra2), dim3(P2_BLOCK), P3_LDS_BYTES, s, L2.records, L2.cdesc,
                        L2.sorted, L2.part_start, L2.slots, L2.nslots, nmetrics, P.log_mpp2, P.log_w, g_inv, S,
-                       counts, ranges, g_stats);
+                       counts, ranges, g_stats, dbg);
     hipLaunchKernelGGL(k_v3_report, dim3(1), dim3(64), 0, s, g_stats, region_stat);
     return hipGetLastError();
 }

@@ -1,10 +1,11 @@
-# Per-round evidence under gpurun_out/round/ (copy into profiles/ as r02_* afterwards).  One gpurun call.
+# Per-round evidence under gpurun_out/round/ (copy into profiles/ as r03_* afterwards).  One gpurun call.
 #   bench.json              python bench.py (default flags: headline C2 + secondary C3 / C4 / host-fed / C5)
 #   kernel_trace.txt        rocprofv3 --kernel-trace of the C2 bench command (no cpu baseline), summarised
 #   k1_pmc.json             FETCH_SIZE / WRITE_SIZE passes for k_ingest_single, corrected per MI355X_MICROARCH.md
 #   c3_kernel_trace.txt     rocprofv3 --kernel-trace of bench.py --workload c3
 #   c3_pmc.json             FETCH_SIZE / WRITE_SIZE passes of the same command, every kernel of the call summed
 #   c4_bench.json           bench.py --workload c4 (one rank)
+#   c4_kernel_trace.txt / c4_pmc.json   the same for bench.py --workload c4 (65 536 names, one rank's 1.25e8-pair slice)
 # PMC passes are separate runs with no tracing domain mixed in.
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/round; mkdir -p $OUT; cd $R
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
@@ -24,6 +25,12 @@ rocprofv3 --kernel-trace -d /tmp/pr_c3t -o t -- $CMD3 > $OUT/c3_under_trace.json
 { echo "# rocprofv3 --kernel-trace -- $CMD3"; python $R/profiles/summarize_rocpd.py stats /tmp/pr_c3t/t_results.db | grep -E "^#|^kernel|lh::" | cut -c1-170; } > $OUT/c3_kernel_trace.txt
 rocprofv3 --pmc FETCH_SIZE -d /tmp/pr_c3f -o t -- $CMD3 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE -d /tmp/pr_c3w -o t -- $CMD3 > /dev/null 2>&1
+CMD4="python $R/bench.py --workload c4 --steps 3 --warmup 1 --no-parity"
+rm -rf /tmp/pr_c4t /tmp/pr_c4f /tmp/pr_c4w
+rocprofv3 --kernel-trace -d /tmp/pr_c4t -o t -- $CMD4 > $OUT/c4_under_trace.json 2>/dev/null
+{ echo "# rocprofv3 --kernel-trace -- $CMD4"; python $R/profiles/summarize_rocpd.py stats /tmp/pr_c4t/t_results.db | grep -E "^#|^kernel|lh::" | cut -c1-170; } > $OUT/c4_kernel_trace.txt
+rocprofv3 --pmc FETCH_SIZE -d /tmp/pr_c4f -o t -- $CMD4 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE -d /tmp/pr_c4w -o t -- $CMD4 > /dev/null 2>&1
 python - <<PY
 import json, subprocess
 R="$R"
@@ -57,6 +64,27 @@ json.dump({"workload":"C3: 1e9 (uint32 id, float64 value) pairs over 1 024 Zipf(
  "commands":["rocprofv3 --pmc FETCH_SIZE -- $CMD3","rocprofv3 --pmc WRITE_SIZE -- $CMD3"], "corrections": CORR,
  "kernels": per, "hbm_read_bytes_per_call": rd, "hbm_write_bytes_per_call": wr, "hbm_bytes_per_call": rd+wr,
  "algorithmic_bytes_per_call": 12e9, "traffic_over_algorithmic": (rd+wr)/12e9}, open("$OUT/c3_pmc.json","w"), indent=1)
+# C4: every kernel of one lh_submit_pairs_device call of the slice.  The run makes 1 warm-up + 3 timed calls and, for
+# the extract-latency leg, 100 calls of 2^22 pairs that take other kernels (first generation): only launches of the
+# third-generation kernels and of the slice's k_ingest_pairs tail are summed, per call of the slice.
+calls = 4
+k4 = ["k_survey_count_h", "k_survey_pick", "k_survey_plan_h", "k_survey_remap", "k_scatter4", "k_split_waves",
+      "k_split_records", "k_part_hist3", "k_v3_report"]
+per = {}; rd = wr = 0.0
+for k in k4:
+    cf = pmc("/tmp/pr_c4f/t_results.db", k).get("FETCH_SIZE"); cw = pmc("/tmp/pr_c4w/t_results.db", k).get("WRITE_SIZE")
+    if not cf: continue
+    r = cf["avg"]*cf["launches"]*2048/calls; ww = (cw["avg"]*cw["launches"]*1024/calls) if cw else 0.0
+    per[k] = {"launches_per_call": cf["launches"]/calls, "read_bytes_per_call": r, "write_bytes_per_call": ww,
+              "avg_duration_us_under_pmc": cf["avg_duration_us_profiled"]}
+    rd += r; wr += ww
+json.dump({"workload":"C4 one rank: 1.25e8 (uint32 id, float64 value) pairs over 65 536 Zipf(1.0) names, lognormal values",
+ "pairs_per_call": 125000000, "names": 65536,
+ "commands":["rocprofv3 --pmc FETCH_SIZE -- $CMD4","rocprofv3 --pmc WRITE_SIZE -- $CMD4"], "corrections": CORR,
+ "note": "the plan kernels (k_plan_count / k_plan_scan / k_plan_scatter: chunk descriptors only) and memsets are not in the sum",
+ "kernels": per, "hbm_read_bytes_per_call": rd, "hbm_write_bytes_per_call": wr, "hbm_bytes_per_call": rd+wr,
+ "algorithmic_bytes_per_call": 1.5e9, "traffic_over_algorithmic": (rd+wr)/1.5e9}, open("$OUT/c4_pmc.json","w"), indent=1)
 PY
+cat $OUT/c4_kernel_trace.txt | cut -c1-150
 ls -la $OUT; tail -c 1500 $OUT/bench.json; grep -E "k_ingest_single" $OUT/kernel_trace.txt | cut -c1-140; cat $OUT/c3_kernel_trace.txt | cut -c1-150; python -c "
 import json; j=json.load(open('$OUT/c3_pmc.json')); print({k:j[k] for k in ('hbm_read_bytes_per_call','hbm_write_bytes_per_call','traffic_over_algorithmic')})"
