@@ -42,8 +42,8 @@ HBM_PEAK_GBS = 8000.0                                    # MI355X_MICROARCH.md: 
 PCIE_GBS = 63.0                                          # PCIe Gen5 x16 (spec)
 BYTES_SINGLE, BYTES_PAIR = 8, 12                         # float64 / float64 + uint32 id
 METRIC = "float64 samples/sec bucketed (1 GPU) + % HBM roofline; p99 extract latency"
-K1_PMC = os.path.join("profiles", "r02_k1_pmc.json")
-C3_PMC = os.path.join("profiles", "r02_c3_pmc.json")
+K1_PMC = os.path.join("profiles", "r03_k1_pmc.json")
+C3_PMC = os.path.join("profiles", "r03_c3_pmc.json")
 C4_PMC = os.path.join("profiles", "r03_c4_pmc.json")
 
 

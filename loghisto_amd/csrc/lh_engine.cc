@@ -1449,9 +1449,10 @@ int lh_snapshot_merge(lh_snapshot *s, void *comm, int nranks, int rank, int plan
 
     // plan arrays: P[max_metrics + 1], bstart[1025], info[8], brow[1025] (uint32) -- allocated once, never moved
     const size_t M = e->cfg.max_metrics;
-    if (!e->d_mplan) HIPCHK(hipMalloc((void **)&e->d_mplan, (M + 1 + 1025 + 8 + 520) * sizeof(uint64_t)));
+    if (!e->d_mplan) HIPCHK(hipMalloc((void **)&e->d_mplan, (M + 1 + 1025 + 8 + 520 + 3072) * sizeof(uint64_t)));
     uint64_t *d_P = e->d_mplan, *d_bstart = d_P + M + 1, *d_info = d_bstart + 1025;
     uint32_t *d_brow = reinterpret_cast<uint32_t *>(d_info + 8);
+    uint64_t *d_work = d_info + 8 + 520; // the plan kernels' per-row-block partial sums
 
     // 1. dirty ranges: min(lo), max(hi) over the ranks with ONE MIN all-reduce on (lo, ~hi), in place.  One more
     //    word rides along: this rank's sample count of the interval (clipped), so that every rank learns the largest
@@ -1479,7 +1480,7 @@ int lh_snapshot_merge(lh_snapshot *s, void *comm, int nranks, int rank, int plan
         if (++e->xseq == 0) e->xseq = 1;
         *flag = 0;
         HIPCHK(lh::launch_merge_plan(b.ranges, nrows, nblocks, (uint32_t)rank, d_tmp + (size_t)nrows * 2, d_P, d_bstart,
-                                     d_brow, reinterpret_cast<uint64_t *>(e->d_hxbuf),
+                                     d_brow, d_work, reinterpret_cast<uint64_t *>(e->d_hxbuf),
                                      reinterpret_cast<uint32_t *>(e->d_hxbuf + 64), e->xseq, st));
         HIPCHK(hipEventRecord(e->merge_ev[2], st));
         const auto t0 = std::chrono::steady_clock::now();
@@ -1495,7 +1496,7 @@ int lh_snapshot_merge(lh_snapshot *s, void *comm, int nranks, int rank, int plan
         std::memcpy(info, e->h_xbuf, sizeof(info));
     } else {
         HIPCHK(lh::launch_merge_plan(b.ranges, nrows, nblocks, (uint32_t)rank, d_tmp + (size_t)nrows * 2, d_P, d_bstart,
-                                     d_brow, d_info, nullptr, 0, st));
+                                     d_brow, d_work, d_info, nullptr, 0, st));
         HIPCHK(hipEventRecord(e->merge_ev[2], st));
         HIPCHK(hipMemcpyAsync(e->h_xbuf, d_info, sizeof(info), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));

@@ -111,9 +111,10 @@ hipError_t launch_ranges_flip_hi(uint32_t *dst, const uint32_t *src, uint32_t nr
 // contiguous row ranges of equal PACKED size: brow[nblocks+1] their first rows, bstart[nblocks+1] the prefix there.
 // info[8] = {total cells, largest block, widest row, occupied rows, ~extra_src[0], first row and end row of block
 // `rank`, 0}; host_flag (device mapping of pinned memory, or null) receives `seq` after info is stored.
+// work: scratch of 3 072 uint64 for the per-row-block partial sums (three kernels: widths, plan, finish).
 hipError_t launch_merge_plan(const uint32_t *ranges, uint32_t nrows, uint32_t nblocks, uint32_t rank,
-                             const uint32_t *extra_src, uint64_t *P, uint64_t *bstart, uint32_t *brow, uint64_t *info,
-                             uint32_t *host_flag, uint32_t seq, hipStream_t s);
+                             const uint32_t *extra_src, uint64_t *P, uint64_t *bstart, uint32_t *brow, uint64_t *work,
+                             uint64_t *info, uint32_t *host_flag, uint32_t seq, hipStream_t s);
 // buf[k * bstride + ...]: block k's rows back to back, the rest of each block zeroed; cells32: uint32 cells on the wire.
 hipError_t launch_pack_rows(const uint64_t *counts, const uint32_t *ranges, const uint64_t *P, const uint64_t *bstart,
                             const uint32_t *brow, uint32_t nrows, uint32_t nblocks, uint64_t bstride, void *buf,

@@ -781,30 +781,76 @@ __global__ void k_ranges_flip_hi(uint32_t *__restrict__ dst, const uint32_t *__r
 // (complement of extra_src[0]), first row / end row of block `rank`}; when host_flag is set it is stored
 // system-scope for the host, which needs the counts to size the collective.
 constexpr int MP_BLOCK = 1024;
-__global__ __launch_bounds__(MP_BLOCK) void k_merge_plan(const uint32_t *__restrict__ ranges, uint32_t nrows,
-                                                         uint32_t nblocks, uint32_t rank,
+// Step 1 (one workgroup per 1 024 rows, coalesced): P[r] = exclusive prefix of the widths INSIDE the row block,
+// btot / bmaxw / bocc [block] = the block's total, widest window and occupied rows.  (One workgroup walking all
+// 65 536 rows with 64 rows per thread took 124 us: strided loads, twice.)
+__global__ __launch_bounds__(MP_BLOCK) void k_merge_widths(const uint32_t *__restrict__ ranges, uint32_t nrows,
+                                                           unsigned long long *__restrict__ P,
+                                                           unsigned long long *__restrict__ btot,
+                                                           uint32_t *__restrict__ bmaxw, uint32_t *__restrict__ bocc)
+{
+    __shared__ uint32_t s_w[MP_BLOCK / 64], s_maxw[MP_BLOCK / 64], s_occ[MP_BLOCK / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t r = blockIdx.x * MP_BLOCK + tid;
+    uint32_t w = 0;
+    if (r < nrows) {
+        const uint32_t lo = ranges[2 * (size_t)r], hi = ranges[2 * (size_t)r + 1];
+        w = lo <= hi ? hi - lo + 1 : 0u;
+    }
+    uint32_t inc = w, maxw = w, occ = w != 0; // a block's total is at most 1 024 x 65 536 = 2^26
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(inc, d, 64);
+        if ((int)lane >= d) inc += y;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        maxw = max(maxw, (uint32_t)__shfl_xor(maxw, d, 64));
+        occ += __shfl_xor(occ, d, 64);
+    }
+    if (lane == 63) s_w[wave] = inc;
+    if (lane == 0) { s_maxw[wave] = maxw; s_occ[wave] = occ; }
+    __syncthreads();
+    uint32_t base = 0, total = 0, gmax = 0, gocc = 0;
+    for (uint32_t k = 0; k < MP_BLOCK / 64; k++) {
+        if (k < wave) base += s_w[k];
+        total += s_w[k];
+        gmax = max(gmax, s_maxw[k]);
+        gocc += s_occ[k];
+    }
+    if (r < nrows) P[r] = base + inc - w;
+    if (tid == 0) { btot[blockIdx.x] = total; bmaxw[blockIdx.x] = gmax; bocc[blockIdx.x] = gocc; }
+}
+
+// Step 2 (one workgroup; at most MP_BLOCK row blocks = 2^20 rows): the row blocks' bases, the totals, and the nblocks
+// owner blocks of a reduce-scatter, which are CONTIGUOUS ROW RANGES OF EQUAL PACKED SIZE, not of equal row count:
+// block k starts at the first row whose prefix reaches k/nblocks of the total (brow[k]; every rank computes the same
+// boundaries from the same merged ranges).  RCCL's reduce-scatter wants equal blocks, so every block is padded to the
+// largest; with equal row counts and names ranked by frequency (ids of a Zipf stream) the first block holds the
+// widest windows and every other block pays for it (1.20 x on config 4's slice), with equal
+// cells the padding is at most one row's window (1.0001 x).
+// info = {total cells, largest block, widest row, occupied rows, largest per-rank sample count of the interval
+// (complement of extra_src[0]), first row / end row of block `rank`, 0}; when host_flag is set it is stored
+// system-scope for the host, which needs the counts to size the collective.  P still holds block-local prefixes:
+// k_merge_finish adds bbase.
+__global__ __launch_bounds__(MP_BLOCK) void k_merge_plan(uint32_t nrows, uint32_t nblocks, uint32_t rank,
                                                          const uint32_t *__restrict__ extra_src,
-                                                         unsigned long long *__restrict__ P /*[nrows+1]*/,
+                                                         const unsigned long long *__restrict__ P,
+                                                         const unsigned long long *__restrict__ btot,
+                                                         const uint32_t *__restrict__ bmaxw,
+                                                         const uint32_t *__restrict__ bocc,
+                                                         unsigned long long *__restrict__ bbase,
                                                          unsigned long long *__restrict__ bstart /*[nblocks+1]*/,
                                                          uint32_t *__restrict__ brow /*[nblocks+1]*/,
                                                          unsigned long long *__restrict__ info /*[8]*/,
                                                          uint32_t *__restrict__ host_flag, uint32_t seq)
 {
-    __shared__ unsigned long long s_w[MP_BLOCK / 64];
+    __shared__ unsigned long long s_base[MP_BLOCK], s_wsum[MP_BLOCK / 64], s_bmax;
     __shared__ uint32_t s_maxw[MP_BLOCK / 64], s_occ[MP_BLOCK / 64];
-    __shared__ unsigned long long s_bmax;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t R = (nrows + MP_BLOCK - 1) / MP_BLOCK;
-    const uint32_t r0 = tid * R, r1 = min(nrows, r0 + R);
-    unsigned long long mine = 0;
-    uint32_t maxw = 0, occ = 0;
-    for (uint32_t r = r0; r < r1; r++) {
-        const uint32_t lo = ranges[2 * (size_t)r], hi = ranges[2 * (size_t)r + 1];
-        const uint32_t w = lo <= hi ? hi - lo + 1 : 0u;
-        mine += w;
-        maxw = max(maxw, w);
-        occ += w != 0;
-    }
+    const uint32_t nrb = (nrows + MP_BLOCK - 1) / MP_BLOCK; // row blocks (<= MP_BLOCK: the launcher checks)
+    const unsigned long long mine = tid < nrb ? btot[tid] : 0ull;
+    uint32_t maxw = tid < nrb ? bmaxw[tid] : 0u, occ = tid < nrb ? bocc[tid] : 0u;
     unsigned long long inc = mine;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -816,40 +862,36 @@ __global__ __launch_bounds__(MP_BLOCK) void k_merge_plan(const uint32_t *__restr
         maxw = max(maxw, (uint32_t)__shfl_xor(maxw, d, 64));
         occ += __shfl_xor(occ, d, 64);
     }
-    if (lane == 63) s_w[wave] = inc;
+    if (lane == 63) s_wsum[wave] = inc;
     if (lane == 0) { s_maxw[wave] = maxw; s_occ[wave] = occ; }
     if (tid == 0) s_bmax = 0;
     __syncthreads();
     unsigned long long base = 0, total = 0;
     uint32_t gmax = 0, gocc = 0;
     for (uint32_t w = 0; w < MP_BLOCK / 64; w++) {
-        if (w < wave) base += s_w[w];
-        total += s_w[w];
+        if (w < wave) base += s_wsum[w];
+        total += s_wsum[w];
         gmax = max(gmax, s_maxw[w]);
         gocc += s_occ[w];
     }
-    unsigned long long run = base + inc - mine;
-    for (uint32_t r = r0; r < r1; r++) {
-        const uint32_t lo = ranges[2 * (size_t)r], hi = ranges[2 * (size_t)r + 1];
-        P[r] = run;
-        run += lo <= hi ? hi - lo + 1 : 0u;
-    }
-    if (tid == 0) P[nrows] = total;
-    __syncthreads(); // workgroup-scope release/acquire: P[] written above is read below by other threads
-    // block boundaries: thread k finds the first row whose prefix reaches k * total / nblocks
+    s_base[tid] = base + inc - mine;
+    if (tid < nrb) bbase[tid] = base + inc - mine;
+    __syncthreads();
+    auto prefix = [&](uint32_t r) { return r >= nrows ? total : P[r] + s_base[r / MP_BLOCK]; };
+    // owner-block boundaries: thread k finds the first row whose prefix reaches k * total / nblocks
     for (uint32_t k = tid; k <= nblocks; k += MP_BLOCK) {
         uint32_t row = k == 0 ? 0u : nrows;
         if (k != 0 && k != nblocks) {
             const unsigned long long target = total / nblocks * k + total % nblocks * k / nblocks;
-            uint32_t lo = 0, hi = nrows; // smallest r in [0, nrows] with P[r] >= target
+            uint32_t lo = 0, hi = nrows; // smallest r in [0, nrows] with prefix(r) >= target
             while (lo < hi) {
                 const uint32_t mid = lo + (hi - lo) / 2;
-                if (P[mid] >= target) hi = mid; else lo = mid + 1;
+                if (prefix(mid) >= target) hi = mid; else lo = mid + 1;
             }
             row = lo;
         }
         brow[k] = row;
-        bstart[k] = P[row];
+        bstart[k] = prefix(row);
     }
     __syncthreads();
     for (uint32_t k = tid; k < nblocks; k += MP_BLOCK) atomicMax(&s_bmax, bstart[k + 1] - bstart[k]);
@@ -868,6 +910,16 @@ __global__ __launch_bounds__(MP_BLOCK) void k_merge_plan(const uint32_t *__restr
             __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+}
+
+// Step 3: P[r] becomes the exclusive prefix over ALL rows (what pack / unpack index with); P[nrows] = the total.
+__global__ __launch_bounds__(MP_BLOCK) void k_merge_finish(unsigned long long *__restrict__ P,
+                                                           const unsigned long long *__restrict__ bbase,
+                                                           const unsigned long long *__restrict__ btot, uint32_t nrows)
+{
+    const uint32_t r = blockIdx.x * MP_BLOCK + threadIdx.x;
+    if (r < nrows) P[r] += bbase[blockIdx.x];
+    if (r == nrows - 1) P[nrows] = bbase[blockIdx.x] + btot[blockIdx.x];
 }
 
 // the owner block of row r: the last k with brow[k] <= r (empty blocks share a boundary with their successor)
@@ -940,12 +992,20 @@ hipError_t launch_ranges_flip_hi(uint32_t *dst, const uint32_t *src, uint32_t nr
 }
 
 hipError_t launch_merge_plan(const uint32_t *ranges, uint32_t nrows, uint32_t nblocks, uint32_t rank,
-                             const uint32_t *extra_src, uint64_t *P, uint64_t *bstart, uint32_t *brow, uint64_t *info,
-                             uint32_t *host_flag, uint32_t seq, hipStream_t s)
+                             const uint32_t *extra_src, uint64_t *P, uint64_t *bstart, uint32_t *brow, uint64_t *work,
+                             uint64_t *info, uint32_t *host_flag, uint32_t seq, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_merge_plan, dim3(1), dim3(MP_BLOCK), 0, s, ranges, nrows, nblocks, rank, extra_src,
-                       reinterpret_cast<unsigned long long *>(P), reinterpret_cast<unsigned long long *>(bstart), brow,
+    const uint32_t nrb = (nrows + MP_BLOCK - 1) / MP_BLOCK;
+    if (nrows == 0 || nrb > (uint32_t)MP_BLOCK) return hipErrorInvalidValue; // more than 2^20 rows
+    // work: btot[1024] | bbase[1024] (uint64), bmaxw[1024] | bocc[1024] (uint32)
+    unsigned long long *btot = reinterpret_cast<unsigned long long *>(work), *bbase = btot + MP_BLOCK;
+    uint32_t *bmaxw = reinterpret_cast<uint32_t *>(bbase + MP_BLOCK), *bocc = bmaxw + MP_BLOCK;
+    unsigned long long *Pp = reinterpret_cast<unsigned long long *>(P);
+    hipLaunchKernelGGL(k_merge_widths, dim3(nrb), dim3(MP_BLOCK), 0, s, ranges, nrows, Pp, btot, bmaxw, bocc);
+    hipLaunchKernelGGL(k_merge_plan, dim3(1), dim3(MP_BLOCK), 0, s, nrows, nblocks, rank, extra_src, Pp, btot, bmaxw,
+                       bocc, bbase, reinterpret_cast<unsigned long long *>(bstart), brow,
                        reinterpret_cast<unsigned long long *>(info), host_flag, seq);
+    hipLaunchKernelGGL(k_merge_finish, dim3(nrb), dim3(MP_BLOCK), 0, s, Pp, bbase, btot, nrows);
     return hipGetLastError();
 }
 

@@ -4,6 +4,8 @@ files committed under profiles/.
 
   python profiles/summarize_rocpd.py stats <trace.db> [--min-ns N]      per-kernel stats table
   python profiles/summarize_rocpd.py pmc   <pmc.db> <kernel-substr>     per-launch counter values
+  python profiles/summarize_rocpd.py list  <trace.db> <kernel-substr> [--min-ns N] [--skip K]
+                                                                         every launch in start order, stats without the first K
 
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  On gfx950 FETCH_SIZE counts 128-B
 requests as 64 B for wide coalesced streaming reads (MI355X_MICROARCH.md "HBM"), so the read
@@ -58,6 +60,19 @@ def pmc(db_path: str, kernel_substr: str, min_ns: int = 0):
     return res
 
 
+def launches(db_path: str, kernel_substr: str, min_ns: int = 0, skip: int = 0):
+    cur = sqlite3.connect(db_path).cursor()
+    rows = cur.execute("select name, start, duration from kernels order by start").fetchall()
+    d = [dur for name, _, dur in rows if kernel_substr in name and dur >= min_ns]
+    out = [f"# launches of {kernel_substr} in {db_path}, in start order (us; min duration filter {min_ns} ns): {len(d)}",
+           " ".join(f"{x / 1e3:.1f}" for x in d)]
+    for label, sel in (("all", d), (f"without the first {skip}", d[skip:])):
+        if sel:
+            out.append(f"{label}: n {len(sel)} avg {sum(sel) / len(sel) / 1e3:.2f} min {min(sel) / 1e3:.2f} "
+                       f"max {max(sel) / 1e3:.2f} median {sorted(sel)[len(sel) // 2] / 1e3:.2f}")
+    return "\n".join(out)
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
     min_ns = 0
@@ -65,7 +80,14 @@ if __name__ == "__main__":
         i = sys.argv.index("--min-ns")
         min_ns = int(sys.argv[i + 1])
         del sys.argv[i:i + 2]
+    skip = 0
+    if "--skip" in sys.argv:
+        i = sys.argv.index("--skip")
+        skip = int(sys.argv[i + 1])
+        del sys.argv[i:i + 2]
     if mode == "stats":
         print(stats(sys.argv[2], min_ns))
+    elif mode == "list":
+        print(launches(sys.argv[2], sys.argv[3], min_ns, skip))
     else:
         print(json.dumps(pmc(sys.argv[2], sys.argv[3], min_ns), indent=1))
