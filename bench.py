@@ -353,7 +353,9 @@ def run_c3(args, la, stream, rank, steps, warmup, latency_flips=0):
 # ---------------------------------------------------------------------------------------------------------
 # C4: 65 536 names, data-parallel ingest, reduce-scatter merge through the C ABI
 # ---------------------------------------------------------------------------------------------------------
-def run_c4(args, la, stream, rank, world, dist, steps, warmup):
+def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=None):
+    """comm_override: an ncclComm_t the caller made (tests/_bench_ranks_driver.py: ranks as threads on one GPU over the
+    stub RCCL, with a thread-rendezvous stand-in for torch.distributed as `dist`)."""
     from loghisto_amd import merge as tmerge
     from loghisto_amd import rccl
     M = args.names or 65536
@@ -367,7 +369,9 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup):
     # communicator for the C-ABI front-end (what a cgo caller would hold); torch.distributed only carries the id
     comm, frontend, why = 0, "c-abi: lh_snapshot_merge -> RCCL ncclReduceScatter", ""
     try:
-        if world > 1:
+        if comm_override is not None:
+            comm = comm_override
+        elif world > 1:
             uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
             if rank == 0:
                 uid.copy_(torch.frombuffer(bytearray(rccl.unique_id()), dtype=torch.uint8))
@@ -531,7 +535,7 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup):
         res["extract_latency_us"] = lat_c4
     if why:
         res["merge_frontend_fallback_reason"] = why
-    if comm:
+    if comm and comm_override is None:
         rccl.comm_destroy(comm)
     eng.close()
     del ids, data

@@ -1,0 +1,29 @@
+"""The N-rank path of bench.py's config-4 workload, N ranks as threads on one GPU (tests/_bench_ranks_driver.py):
+what the driver's `python bench.py --gpus N` runs on a multi-GPU node, minus RCCL itself (the stub of
+tests/cpp/rccl_stub.cc stands in) and torch.distributed's transport (a thread rendezvous stands in).
+Reference semantics: cells are a commutative sum (metrics.go:278, 292); SURVEY.md 8(e)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("nranks,names", [(2, 8192 + 1), (4, 65536)])
+def test_c4_step_with_ranks_as_threads(native_lib, torch_cuda, nranks, names):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_bench_ranks_driver.py"), str(nranks), str(names),
+                        "3e6"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-3000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["ok"] and res["parity"]["exact"] and res["parity"]["cells_after_merge_exact"]
+    assert res["parity"]["rows_checked_cell_by_cell"] >= 40          # every probe row is owned by exactly one rank
+    rows = res["owned_rows"]
+    assert rows[0][0] == 0 and rows[-1][1] == names and all(rows[i][1] == rows[i + 1][0] for i in range(nranks - 1))
+    m = res["merge"]
+    assert m["cell_bytes"] == 4 and m["padded_cells"] >= m["packed_cells"] and m["padding_ratio"] <= 1.3
+    assert m["device_ms"]["span_ms"] > 0
