@@ -968,12 +968,21 @@ __global__ __launch_bounds__(P2_BLOCK, 8) void k_part_hist(const uint32_t *__res
     __syncthreads();
 
     // flush: one uint64 atomic per occupied cell
+    // (a wave's 64 cells are consecutive bins of ONE name when W >= 64: the name's range is updated once per wave, from
+    // the first and the last lane that found a count, not once per occupied cell)
     for (uint32_t i = tid; i < words; i += P2_BLOCK) {
         const uint32_t c = h[i];
-        if (c) {
-            const uint32_t l = i >> log_w, b = s_org[l] + (i & (W - 1));
+        const uint32_t l = i >> log_w, b = s_org[l] + (i & (W - 1));
+        if (c)
             atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)((l << log_nq) | p) * LH_NKEYS + b]),
                       (unsigned long long)c);
+        if (W >= 64u) {
+            const unsigned long long occ = __builtin_amdgcn_ballot_w64(c != 0);
+            if (occ != 0ull && (tid & 63u) == 0u) {
+                atomicMin(&s_mn[l], b + (uint32_t)__builtin_ctzll(occ));
+                atomicMax(&s_mx[l], b + 63u - (uint32_t)__builtin_clzll(occ));
+            }
+        } else if (c) {
             atomicMin(&s_mn[l], b);
             atomicMax(&s_mx[l], b);
         }

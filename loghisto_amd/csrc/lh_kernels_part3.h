@@ -1281,7 +1281,8 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
                                                          const uint32_t *__restrict__ sorted,
                                                          const uint32_t *__restrict__ part_start,
                                                          const uint32_t *__restrict__ slots,
-                                                         const uint32_t *__restrict__ nslots, uint32_t nmetrics,
+                                                         const uint32_t *__restrict__ nslots,
+                                                         const uint32_t *__restrict__ part_chunks, uint32_t nmetrics,
                                                          uint32_t log_mpp2, uint32_t log_w,
                                                          const uint8_t *__restrict__ g_inv, const SurveyStat S,
                                                          uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
@@ -1415,21 +1416,41 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
     }
     __syncthreads();
 
-    // (one LDS atomic pair per occupied cell cost 42 us of the reduce pass's 277 on config 4's slice: one pair per wave)
-    for (uint32_t i = tid; i < words; i += P2_BLOCK) {
-        const uint32_t c = h[i];
-        const uint32_t l = i >> log_w, b = s_org[l] + (i & (W - 1));
-        if (c) {
-            if (!(dbg & (1u << 21)))
-            atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)s_name[l] * LH_NKEYS + b]),
-                      (unsigned long long)c);
+    // Flush.  A slot that holds ALL the chunks of its fine partition is the only writer of its names' window cells in
+    // this launch (other slots count other names; out-of-window records of these names go to other cells), so it adds
+    // with plain loads and stores, sixteen cells per thread in flight, instead of one uint64 atomic per occupied cell
+    // (memory-side on this part: 15 M of them were 77 us of the pass's 257 on config 4's slice).  Slots that share a
+    // partition keep the atomics.  (One LDS range update per wave, not per cell: that was another 42 us.)
+    const bool sole = first == 0 && cnt == part_chunks[q]; // workgroup-uniform
+    constexpr uint32_t FL = 16;
+    static_assert(P3_WINWORDS % (P2_BLOCK * FL) == 0, "flush batches");
+    for (uint32_t i0 = tid; i0 < words; i0 += P2_BLOCK * FL) {
+        uint32_t c[FL];
+        unsigned long long *at[FL], old[FL];
+#pragma unroll
+        for (uint32_t k = 0; k < FL; k++) {
+            const uint32_t i = i0 + k * P2_BLOCK;
+            c[k] = h[i];
+            const uint32_t l = i >> log_w, b = s_org[l] + (i & (W - 1));
+            at[k] = reinterpret_cast<unsigned long long *>(&counts[(size_t)s_name[l] * LH_NKEYS + b]);
+            // the wave's 64 cells are consecutive bins of the name: its lowest and highest occupied bins are those of
+            // the first and the last lane that found a count
+            const unsigned long long occ = __builtin_amdgcn_ballot_w64(c[k] != 0);
+            if (occ != 0ull && lane == 0) {
+                atomicMin(&s_mn[l], b + (uint32_t)__builtin_ctzll(occ));
+                atomicMax(&s_mx[l], b + 63u - (uint32_t)__builtin_clzll(occ));
+            }
         }
-        // the wave's 64 cells are consecutive bins of the name: its lowest and highest occupied bins are those of the
-        // first and the last lane that found a count
-        const unsigned long long occ = __builtin_amdgcn_ballot_w64(c != 0);
-        if (occ != 0ull && lane == 0) {
-            atomicMin(&s_mn[l], b + (uint32_t)__builtin_ctzll(occ));
-            atomicMax(&s_mx[l], b + 63u - (uint32_t)__builtin_clzll(occ));
+        if (sole && !(dbg & (1u << 20))) {
+#pragma unroll
+            for (uint32_t k = 0; k < FL; k++) old[k] = c[k] ? *at[k] : 0ull;
+#pragma unroll
+            for (uint32_t k = 0; k < FL; k++)
+                if (c[k]) *at[k] = old[k] + c[k];
+        } else if (!(dbg & (1u << 21))) {
+#pragma unroll
+            for (uint32_t k = 0; k < FL; k++)
+                if (c[k]) atomicAdd(at[k], (unsigned long long)c[k]);
         }
     }
     for (uint32_t i = tid; i < OV_SLOTS; i += P2_BLOCK)
@@ -1640,7 +1661,7 @@ hipError_t launch_ingest_pairs_part3(const uint32_t *d_ids, const double *d_v, s
     e = run_plan(L2, P.nchunks2, P.nq, 0u, P.extra2, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_part_hist3, dim3(P.nq + P.extra2), dim3(P2_BLOCK), P3_LDS_BYTES, s, L2.records, L2.cdesc,
-                       L2.sorted, L2.part_start, L2.slots, L2.nslots, nmetrics, P.log_mpp2, P.log_w, g_inv, S,
+                       L2.sorted, L2.part_start, L2.slots, L2.nslots, L2.pc, nmetrics, P.log_mpp2, P.log_w, g_inv, S,
                        counts, ranges, g_stats, dbg);
     hipLaunchKernelGGL(k_v3_report, dim3(1), dim3(64), 0, s, g_stats, region_stat);
     return hipGetLastError();
