@@ -40,7 +40,8 @@ class LhCounters(C.Structure):
                                                                 ("records_level1", C.c_uint64),
                                                                 ("records_level2", C.c_uint64),
                                                                 ("level2_overflows", C.c_uint64),
-                                                                ("reduce_window_misses", C.c_uint64)]
+                                                                ("reduce_window_misses", C.c_uint64),
+                                                               ("surveys_reused", C.c_uint64)]
 
 # lh_set_option keys (include/loghisto_gpu.h)
 OPT_TWO_LEVEL_ABOVE, OPT_HOT_MIN_TILES, OPT_HOT_WINDOWS, OPT_NAMES_PER_PARTITION = 1, 2, 3, 4
@@ -48,6 +49,7 @@ OPT_EXTRACT_ZERO_COPY, OPT_SCRATCH_CAP_BYTES, OPT_SUBLAUNCH_PAIRS, OPT_SMALL_PAT
 OPT_PART_V2, OPT_PART_V2_MIN_PAIRS, OPT_PART_V2_SHAPE = 9, 10, 11
 OPT_PART_V3, OPT_PART_V3_MIN_PAIRS, OPT_PART_V3_LOG_W = 12, 13, 14
 OPT_LANE_ZERO_COPY = 15
+OPT_SURVEY_EVERY = 16
 
 
 class LhExtractView(C.Structure):

@@ -134,6 +134,46 @@ def test_third_generation_is_exact(native_lib, torch_cuda, M, n, kind, skew, per
                 check(snap, ids, v, M, got)
 
 
+def test_survey_is_reused_while_the_stream_looks_the_same(native_lib, torch_cuda):
+    """LH_OPT_SURVEY_EVERY (default 8): calls run on the previous call's survey while its tables are still in the
+    scratch block, the window width is unchanged and the self-metrics stay healthy; a stream that changes under a stale
+    survey is still bucketed exactly (every cell against the oracle) and makes the next call survey again."""
+    import loghisto_amd
+    rng = np.random.default_rng(11)
+    M, n = 65536, 1_500_000
+    ids = _ids(rng, M, n, 1.0)
+    v1 = _values(rng, "lognormal", ids, n)
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        e.set_option(N.OPT_PART_V3_MIN_PAIRS, 1 << 17)
+        e.set_option(N.OPT_PART_V3_LOG_W, 10)
+        d_ids, d_v1 = _dev(torch_cuda, ids), _dev(torch_cuda, v1)
+        for rep in range(5):
+            e.submit_pairs_device(d_ids, d_v1)
+            e.sync()
+            with e.flip() as snap:
+                check(snap, ids, v1, M, snap.extract(PCTS, M))
+        c = e.counters()
+        assert c["surveys_reused"] == 4, c                       # one survey, four calls on it
+        # the stream changes completely (other names are frequent, values 9 decades wide): the stale survey sends most
+        # records down the overflow paths -- exact all the same -- and the call after that surveys again
+        ids2 = (M - 1 - ids).astype(np.uint32)
+        v2 = _values(rng, "loguniform", ids2, n)
+        d_ids2, d_v2 = _dev(torch_cuda, ids2), _dev(torch_cuda, v2)
+        for rep in range(3):
+            e.submit_pairs_device(d_ids2, d_v2)
+            e.sync()
+            with e.flip() as snap:
+                check(snap, ids2, v2, M, snap.extract(PCTS, M))
+        c2 = e.counters()
+        assert c2["surveys_reused"] - c["surveys_reused"] <= 2, (c, c2)   # at least one of the three surveyed
+        e.set_option(N.OPT_SURVEY_EVERY, 1)
+        before = e.counters()["surveys_reused"]
+        e.submit_pairs_device(d_ids, d_v1)
+        e.sync()
+        assert e.counters()["surveys_reused"] == before
+        e.flip().release()
+
+
 def test_window_width_follows_the_stream(native_lib, torch_cuda):
     """The survey's report: lognormal sigma = 1 spans ~900 bins (1 024-bin windows), 21 decades span 4 147 (8 192)."""
     import loghisto_amd
@@ -142,6 +182,7 @@ def test_window_width_follows_the_stream(native_lib, torch_cuda):
     ids = _ids(rng, M, n, 1.0)
     with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
         e.set_option(N.OPT_PART_V3_MIN_PAIRS, 1 << 17)
+        e.set_option(N.OPT_SURVEY_EVERY, 1)      # every call surveys: the report follows the stream call by call
         for kind, want in (("lognormal", 10), ("loguniform", 13), ("sigma25", 12), ("lognormal", 10)):
             e.submit_pairs_device(_dev(torch_cuda, ids), _dev(torch_cuda, _values(rng, kind, ids, n)))
             e.sync()
