@@ -223,6 +223,12 @@ struct lh_engine {
     bool v3_tables_valid = false;
     uint32_t v3_tables_log_w = 0, v3_tables_age = 0, survey_every = 8;
     uint64_t v3_seen_bad = 0, v3_seen_pairs = 0; // self-metrics / pairs at the last check
+    // A stream without skew among its names gives the third generation nothing to count in place: with more than 3/4
+    // of the pairs forwarded to the reduce pass (65 536 uniform names: 88 %, 9.7 ms per 1e9 pairs) the first
+    // generation's fixed two-level split is faster (7.9 ms).  Judged over completed calls; re-armed every 64 flips.
+    uint64_t v3_seen_fwd = 0;
+    std::atomic<bool> v3_disabled{false};
+    uint32_t flips_since_v3_off = 0;
     std::atomic<uint64_t> c_scratch{0}, c_sublaunches{0}, c_part2{0}, c_part3{0};
     // Third generation (8 193 .. 65 536 names): the survey reports the window width that covers the stream's spans
     // (h_rstat[1], pinned); later calls use it.  A width that is too small only costs speed.
@@ -355,6 +361,7 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
             size_t sub = (bounded && take > e->sublaunch_pairs) ? e->sublaunch_pairs : take;
             lh::PartTuning tune = e->tune;
             if (e->regions_disabled.load(std::memory_order_relaxed)) tune.v2_shape &= ~2u; // clustered stream: exact layout
+            if (e->v3_disabled.load(std::memory_order_relaxed)) tune.v3 = false;            // skew-free names: first generation
             tune.v3_log_w = call_log_w;
             // generation 2 (survey + 2-byte records) for <= 8 192 names, generation 3 above, when the launch is large
             // enough; otherwise the first generation
@@ -408,8 +415,12 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
                     const uint64_t bad = __atomic_load_n(&e->h_rstat[0], __ATOMIC_RELAXED) +
                                          __atomic_load_n(&e->h_rstat[4], __ATOMIC_RELAXED) +
                                          __atomic_load_n(&e->h_rstat[5], __ATOMIC_RELAXED);
-                    const uint64_t pairs = e->c_part3.load(std::memory_order_relaxed);
+                    const uint64_t pairs = __atomic_load_n(&e->h_rstat[6], __ATOMIC_RELAXED); // of the launches that reported
                     const bool healthy = (bad - e->v3_seen_bad) * 50 <= pairs - e->v3_seen_pairs;
+                    const uint64_t fwd = __atomic_load_n(&e->h_rstat[3], __ATOMIC_RELAXED);
+                    if (pairs - e->v3_seen_pairs >= (uint64_t(1) << 22) && (fwd - e->v3_seen_fwd) * 4 > (pairs - e->v3_seen_pairs) * 3)
+                        e->v3_disabled.store(true); // (takes effect at the next launch)
+                    e->v3_seen_fwd = fwd;
                     e->v3_seen_bad = bad;
                     e->v3_seen_pairs = pairs;
                     if (e->v3_tables_valid && e->scratch_gen == 3 && e->v3_tables_log_w == call_log_w && healthy &&
@@ -618,7 +629,7 @@ int create_impl(const lh_config *cfg_in, lh_engine *e)
     HIPCHK(hipMalloc((void **)&e->d_Tx, sizeof(double) * LH_NTHRESH));
     HIPCHK(hipMalloc((void **)&e->d_D, sizeof(double) * LH_NKEYS));
     HIPCHK(hipHostMalloc((void **)&e->h_rstat, 64, hipHostMallocDefault));
-    for (int i = 0; i < 8; i++) e->h_rstat[i] = 0; // [0] level-1 region overflows [1] window class [2..5] part3 self-metrics
+    for (int i = 0; i < 8; i++) e->h_rstat[i] = 0; // [0] level-1 region overflows [1] window class [2..5] part3 self-metrics [6] pairs they cover
     {
         void *dp = nullptr;
         HIPCHK(hipHostGetDevicePointer(&dp, e->h_rstat, 0));
@@ -1141,6 +1152,10 @@ int lh_flip(lh_engine *e, lh_snapshot **out)
             }
             e->win_ovf = 0;
             e->win_samples = 0;
+        }
+        if (e->v3_disabled.load(std::memory_order_relaxed) && ++e->flips_since_v3_off > 64) {
+            e->flips_since_v3_off = 0;
+            e->v3_disabled.store(false);
         }
         if (e->regions_disabled.load(std::memory_order_relaxed) && ++e->flips_since_regions_off > 64) {
             e->flips_since_regions_off = 0;

@@ -1468,8 +1468,12 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
 // per launch (256 of them on one host address).
 //   rstat[0] level-1 region overflows (the engine's clustered-stream switch)  [2] level-1 records  [3] records
 //   forwarded by level 2  [4] level-2 region overflows  [5] reduce-pass window misses
-__global__ void k_v3_report(uint32_t *__restrict__ g_stats, unsigned long long *__restrict__ rstat)
+__global__ void k_v3_report(uint32_t *__restrict__ g_stats, unsigned long long *__restrict__ rstat,
+                            unsigned long long pairs)
 {
+    // rstat[6]: pairs of the launches that have reported (the engine judges the other words against THIS count, not
+    // against what it has enqueued: the reports arrive when a launch completes)
+    if (threadIdx.x == 5 && rstat) __hip_atomic_fetch_add(rstat + 6, pairs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (threadIdx.x < 5) {
         const uint32_t v = g_stats[threadIdx.x];
         g_stats[threadIdx.x] = 0;
@@ -1663,6 +1667,6 @@ hipError_t launch_ingest_pairs_part3(const uint32_t *d_ids, const double *d_v, s
     hipLaunchKernelGGL(k_part_hist3, dim3(P.nq + P.extra2), dim3(P2_BLOCK), P3_LDS_BYTES, s, L2.records, L2.cdesc,
                        L2.sorted, L2.part_start, L2.slots, L2.nslots, L2.pc, nmetrics, P.log_mpp2, P.log_w, g_inv, S,
                        counts, ranges, g_stats, dbg);
-    hipLaunchKernelGGL(k_v3_report, dim3(1), dim3(64), 0, s, g_stats, region_stat);
+    hipLaunchKernelGGL(k_v3_report, dim3(1), dim3(64), 0, s, g_stats, region_stat, (unsigned long long)n);
     return hipGetLastError();
 }

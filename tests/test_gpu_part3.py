@@ -174,6 +174,29 @@ def test_survey_is_reused_while_the_stream_looks_the_same(native_lib, torch_cuda
         e.flip().release()
 
 
+def test_names_without_skew_go_back_to_the_first_generation(native_lib, torch_cuda):
+    """Nothing is frequent among uniform names: the second level counts next to nothing in place and forwards > 3/4 of
+    the pairs.  The engine reads that from the self-metrics of the completed calls and routes the following calls
+    through the first generation (7.9 against 9.7 ms per 1e9 pairs at 65 536 names); exact either way."""
+    import loghisto_amd
+    rng = np.random.default_rng(23)
+    M, n = 65536, 4_500_000
+    ids = _ids(rng, M, n, 0.0)
+    v = _values(rng, "lognormal", ids, n)
+    d_ids, d_v = _dev(torch_cuda, ids), _dev(torch_cuda, v)
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        e.set_option(N.OPT_PART_V3_MIN_PAIRS, 1 << 17)
+        seen = []
+        for rep in range(4):
+            e.submit_pairs_device(d_ids, d_v)
+            e.sync()
+            seen.append(e.counters()["samples_partitioned_v3"])
+            with e.flip() as snap:
+                check(snap, ids, v, M, snap.extract(PCTS, M))
+        assert seen[0] == n and seen[-1] == seen[-2] < 4 * n, seen   # the later calls did not take the third generation
+        assert e.counters()["samples_partitioned"] == 4 * n
+
+
 def test_window_width_follows_the_stream(native_lib, torch_cuda):
     """The survey's report: lognormal sigma = 1 spans ~900 bins (1 024-bin windows), 21 decades span 4 147 (8 192)."""
     import loghisto_amd
