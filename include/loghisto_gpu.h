@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define LH_ABI_VERSION 2
+#define LH_ABI_VERSION 3
 #define LH_NKEYS 65536            /* int16 key space (metrics.go:316)        */
 #define LH_NTHRESH 70980          /* extended-key thresholds incl. sentinel  */
 #define LH_MAX_PERCENTILES 32

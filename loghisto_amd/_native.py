@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblhgpu.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 NKEYS = 65536
 NTHRESH = 70980
 MAX_PERCENTILES = 32
