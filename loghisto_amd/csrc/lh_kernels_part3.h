@@ -681,9 +681,8 @@ __global__ __launch_bounds__(1024, 4) void k_split_records(const uint32_t *__res
                                                            const pu2_t *__restrict__ g_pt2, const SurveyStat S,
                                                            uint32_t *__restrict__ records, uint32_t *__restrict__ cdesc,
                                                            uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
-                                                           uint32_t *__restrict__ g_stats, uint32_t dbg_arg)
+                                                           uint32_t *__restrict__ g_stats)
 {
-    const uint32_t dbg = LH_DBG(dbg_arg);
     constexpr int BLOCK = 1024;
     extern __shared__ __attribute__((aligned(16))) unsigned char v3_smem[];
     SplitLds &L = *reinterpret_cast<SplitLds *>(v3_smem);
@@ -879,19 +878,18 @@ __global__ __launch_bounds__(1024, 4) void k_split_records(const uint32_t *__res
     asm volatile("" : "+v"(ra[0]), "+v"(ra[1]));
     load_tile(1, rb, cnb);
     uint32_t par = 0;
-    for (uint32_t tile = 0; tile < ((dbg & 1u) ? 0u : ntiles); tile += 2) {
-        if (!(dbg & 8u)) classify(ra, cna, par);
+    for (uint32_t tile = 0; tile < ntiles; tile += 2) {
+        classify(ra, cna, par);
         load_tile(tile + 2, ra, cna);
-        if (!(dbg & 4u)) flush(par);
+        flush(par);
         par ^= 1u;
         if (tile + 1 < ntiles) {
-            if (!(dbg & 8u)) classify(rb, cnb, par);
+            classify(rb, cnb, par);
             load_tile(tile + 3, rb, cnb);
-            if (!(dbg & 4u)) flush(par);
+            flush(par);
             par ^= 1u;
         }
     }
-    if (dbg & 2u) return;
 
     // ---- drain: leftovers (< one line per fine partition) and the open chunks' descriptors
     if (tid < ns) {
@@ -985,9 +983,8 @@ __global__ __launch_bounds__(1024, 4) void k_split_waves(const uint32_t *__restr
                                                          const pu2_t *__restrict__ g_pt2, const SurveyStat S,
                                                          uint32_t *__restrict__ records, uint32_t *__restrict__ cdesc,
                                                          uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
-                                                         uint32_t *__restrict__ g_stats, uint32_t dbg_arg)
+                                                         uint32_t *__restrict__ g_stats)
 {
-    const uint32_t dbg = LH_DBG(dbg_arg);
     constexpr int BLOCK = 1024;
     extern __shared__ __attribute__((aligned(16))) unsigned char v3_smem[];
     SplitWLds &L = *reinterpret_cast<SplitWLds *>(v3_smem);
@@ -1168,8 +1165,7 @@ __global__ __launch_bounds__(1024, 4) void k_split_waves(const uint32_t *__restr
     constexpr uint32_t WSTEP = BLOCK / 64, DEPTH = 2;
     u4_t buf[DEPTH][CHUNK / 256];
     uint32_t cn[DEPTH];
-    if (dbg & (1u << 27)) return;
-    const uint32_t mine = (dbg & (1u << 26)) ? 0u : cnt > wave ? (cnt - wave + WSTEP - 1) / WSTEP : 0u; // chunks of this wave
+    const uint32_t mine = cnt > wave ? (cnt - wave + WSTEP - 1) / WSTEP : 0u; // chunks of this wave
     for (uint32_t b0 = 0; b0 < mine; b0 += 64) {
         const uint32_t nb = min(mine - b0, 64u);
         uint32_t my_cid = 0, my_cn = 0;
@@ -1286,9 +1282,8 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
                                                          uint32_t log_mpp2, uint32_t log_w,
                                                          const uint8_t *__restrict__ g_inv, const SurveyStat S,
                                                          uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
-                                                         uint32_t *__restrict__ g_stats, uint32_t dbg_arg)
+                                                         uint32_t *__restrict__ g_stats)
 {
-    const uint32_t dbg = LH_DBG(dbg_arg);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *h = reinterpret_cast<uint32_t *>(smem);
     uint32_t *s_org = h + P3_WINWORDS, *s_mn = s_org + 32, *s_mx = s_mn + 32, *s_name = s_mx + 32, *s_svc = s_name + 32,
@@ -1384,8 +1379,7 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
     constexpr uint32_t WSTEP = P2_BLOCK / 64, DEPTH = 2;
     u4_t buf[DEPTH][CHUNK / 256];
     uint32_t cn[DEPTH];
-    if (dbg & (1u << 23)) return;
-    const uint32_t mine = (dbg & (1u << 22)) ? 0u : cnt > wave ? (cnt - wave + WSTEP - 1) / WSTEP : 0u; // chunks of this wave
+    const uint32_t mine = cnt > wave ? (cnt - wave + WSTEP - 1) / WSTEP : 0u; // chunks of this wave
     for (uint32_t b0 = 0; b0 < mine; b0 += 64) {
         const uint32_t nb = min(mine - b0, 64u);
         uint32_t my_cid = 0, my_cn = 0;
@@ -1441,13 +1435,13 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
                 atomicMax(&s_mx[l], b + 63u - (uint32_t)__builtin_clzll(occ));
             }
         }
-        if (sole && !(dbg & (1u << 20))) {
+        if (sole) {
 #pragma unroll
             for (uint32_t k = 0; k < FL; k++) old[k] = c[k] ? *at[k] : 0ull;
 #pragma unroll
             for (uint32_t k = 0; k < FL; k++)
                 if (c[k]) *at[k] = old[k] + c[k];
-        } else if (!(dbg & (1u << 21))) {
+        } else {
 #pragma unroll
             for (uint32_t k = 0; k < FL; k++)
                 if (c[k]) atomicAdd(at[k], (unsigned long long)c[k]);
@@ -1613,11 +1607,6 @@ hipError_t launch_ingest_pairs_part3(const uint32_t *d_ids, const double *d_v, s
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-#ifdef LH_TUNING
-    const uint32_t dbg = tune.dbg;
-#else
-    const uint32_t dbg = 0;
-#endif
     unsigned char *base = static_cast<unsigned char *>(scratch);
     const LevelPtrs L1 = level_ptrs(base, P.off_rec1, P.off_cd1, P.off_sorted1, P.off_small1, V3_NP, P.extra1);
     const LevelPtrs L2 = level_ptrs(base, P.off_rec2, P.off_cd2, P.off_sorted2, P.off_small2, P.nq, P.extra2);
@@ -1664,18 +1653,17 @@ hipError_t launch_ingest_pairs_part3(const uint32_t *d_ids, const double *d_v, s
     if (P.waves)
         hipLaunchKernelGGL(k_split_waves, dim3(V3_NP + P.extra1), dim3(1024), SPLITW_LDS_BYTES, s, L1.records, L1.cdesc,
                            L1.sorted, L1.part_start, L1.slots, L1.nslots, L1.pool_start, nmetrics, P.kp, P.log_mpp2,
-                           P.log_w, P.log_ns, g_remap, g_inv, g_pt2, S, L2.records, L2.cdesc, counts, ranges, g_stats,
-                           dbg);
+                           P.log_w, P.log_ns, g_remap, g_inv, g_pt2, S, L2.records, L2.cdesc, counts, ranges, g_stats);
     else
         hipLaunchKernelGGL(k_split_records, dim3(V3_NP + P.extra1), dim3(1024), SPLIT_LDS_BYTES, s, L1.records,
                            L1.cdesc, L1.sorted, L1.part_start, L1.slots, L1.nslots, L1.pool_start, nmetrics, P.kp,
                            P.log_mpp2, P.log_w, P.ns, g_remap, g_inv, g_pt2, S, L2.records, L2.cdesc, counts, ranges,
-                           g_stats, dbg);
+                           g_stats);
     e = run_plan(L2, P.nchunks2, P.nq, 0u, P.extra2, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_part_hist3, dim3(P.nq + P.extra2), dim3(P2_BLOCK), P3_LDS_BYTES, s, L2.records, L2.cdesc,
                        L2.sorted, L2.part_start, L2.slots, L2.nslots, L2.pc, nmetrics, P.log_mpp2, P.log_w, g_inv, S,
-                       counts, ranges, g_stats, dbg);
+                       counts, ranges, g_stats);
     hipLaunchKernelGGL(k_v3_report, dim3(1), dim3(64), 0, s, g_stats, region_stat, (unsigned long long)n);
     return hipGetLastError();
 }

@@ -1,3 +1,5 @@
+# NOTE: the ablation bits of k_split_waves / k_part_hist3 were removed after the measurements (commit a835df4 has
+# them: profiles/r03_level1_experiments.txt records the results); lh_kernels_part3.h carries no ablation hooks.
 # Ablations of k_split_waves / k_part_hist3 (tuning build), 65 536 names.  usage: bash tools/r3_abl23.sh <tag> <samples> [bits...]
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/${1:-r3abl23}; mkdir -p $OUT; cd $R; SZ=${2:-1.25e8}; shift; shift
 LIBT=$R/loghisto_amd/build/liblhgpu_tuning.so

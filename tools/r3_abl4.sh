@@ -1,3 +1,5 @@
+# NOTE: the ablation bits of k_scatter4 / k_scatter5 this script drives lived in the working tree of round 3 only (see
+# profiles/r03_level1_experiments.txt for what they measured); lh_kernels_part3.h carries no ablation hooks.
 # Ablations of k_scatter4 (tuning build), 65 536 names, 1e9 pairs.  usage: bash tools/r3_abl4.sh <tag> [bits...]
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/${1:-r3abl4}; mkdir -p $OUT; cd $R; shift
 LIBT=$R/loghisto_amd/build/liblhgpu_tuning.so
