@@ -962,7 +962,7 @@ struct SplitWLds {
     pu2_t pt[SW_MAX_NS]; // fine partition -> {first word of its region inside a wave's area, capacity in records}
     uint32_t ov_key[OV_SLOTS], ov_cnt[OV_SLOTS];
     uint32_t dummy[64];
-    uint32_t pool_next, ovn, nfwd, pad0[1];
+    uint32_t pool_next, ovn, nfwd, next_tail; // next_tail: the next chunk of the slot's last quarter, taken by whoever is free
     uint32_t tbl[256];
     uint32_t name[32], mn[32], mx[32], svc[32], svm[32], org[32];
 };
@@ -1039,7 +1039,7 @@ __global__ __launch_bounds__(1024, 4) void k_split_waves(const uint32_t *__restr
         L.pt[tid] = (pu2_t){off, cap};
     }
     ov_init(L.ov_key, L.ov_cnt, tid, BLOCK);
-    if (tid == 0) { L.pool_next = 0; L.ovn = 0; L.nfwd = 0; }
+    if (tid == 0) { L.pool_next = 0; L.ovn = 0; L.nfwd = 0; L.next_tail = 0; }
     __syncthreads();
     if (tid < n0) {
         const uint32_t r = L.tbl[(srec >> 16) & 0xffu], b = srec & 0xffffu;
@@ -1165,7 +1165,11 @@ __global__ __launch_bounds__(1024, 4) void k_split_waves(const uint32_t *__restr
     constexpr uint32_t WSTEP = BLOCK / 64, DEPTH = 2;
     u4_t buf[DEPTH][CHUNK / 256];
     uint32_t cn[DEPTH];
-    const uint32_t mine = cnt > wave ? (cnt - wave + WSTEP - 1) / WSTEP : 0u; // chunks of this wave
+    // Three quarters of the slot's chunks are dealt out (wave, wave + 16, ...); the last quarter is taken chunk by chunk
+    // by whichever wave is free.  (Time stamps of single slots: wave 0 was done after 90 - 105 us of a 140 - 160 us
+    // slot and waited for the slowest wave: partially filled chunks and the names' skew make the waves' loads uneven.)
+    const uint32_t cnt_dealt = (cnt - cnt / 4u) & ~(WSTEP - 1u);
+    const uint32_t mine = cnt_dealt / WSTEP; // dealt chunks of this wave
     for (uint32_t b0 = 0; b0 < mine; b0 += 64) {
         const uint32_t nb = min(mine - b0, 64u);
         uint32_t my_cid = 0, my_cn = 0;
@@ -1194,6 +1198,21 @@ __global__ __launch_bounds__(1024, 4) void k_split_waves(const uint32_t *__restr
                 }
                 fetch(k + d + DEPTH, d);
             }
+        }
+    }
+    for (;;) { // the last quarter
+        uint32_t pos = 0;
+        if (lane == 0) pos = atomicAdd(&L.next_tail, 1u);
+        pos = cnt_dealt + __builtin_amdgcn_readfirstlane(pos);
+        if (pos >= cnt) break;
+        const uint32_t cid = __builtin_amdgcn_readfirstlane(list[pos]);
+        const uint32_t cn1 = __builtin_amdgcn_readfirstlane(in_cdesc[cid] & CD_MASK);
+        load_chunk(cid, buf[0]);
+        classify8(buf[0][0], buf[0][1], 0u, cn1);
+        flush();
+        if (cn1 > 512u) {
+            classify8(buf[0][2], buf[0][3], 512u, cn1);
+            flush();
         }
     }
 
