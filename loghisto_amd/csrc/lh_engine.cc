@@ -222,6 +222,10 @@ struct lh_engine {
     // The survey only decides WHERE a sample is counted: a stale one costs speed, never exactness.  (scratch_mu)
     bool v3_tables_valid = false;
     uint32_t v3_tables_log_w = 0, v3_tables_age = 0, survey_every = 8;
+    // Every lh_set_option that feeds a launch plan (LDS budgets, window cells, generation switches) is written under
+    // scratch_mu and bumps tune_gen; a call takes ONE snapshot of `tune` (all its sub-launches share the survey's
+    // tables, which are laid out for one plan) and tables are reused only by calls that saw the same tune_gen.
+    uint64_t tune_gen = 0, v3_tables_tune_gen = 0;
     uint64_t v3_seen_bad = 0, v3_seen_pairs = 0; // self-metrics / pairs at the last check
     // A stream without skew among its names gives the third generation nothing to count in place: with more than 3/4
     // of the pairs forwarded to the reduce pass (65 536 uniform names: 88 %, 9.7 ms per 1e9 pairs) the first
@@ -326,8 +330,17 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
     // Third generation: the window width the last completed survey reported (0 until one has run).  Read ONCE per
     // call: the sub-launches of a call share the survey's per-partition tables, which are laid out for one width,
     // and the call's own survey stores its report while later sub-launches are still being enqueued.
-    uint32_t call_log_w = e->tune.v3_log_w;
-    if (!e->v3_log_w_fixed) {
+    lh::PartTuning call_tune;
+    uint64_t call_tune_gen;
+    bool log_w_fixed;
+    {
+        std::lock_guard<std::mutex> g(e->scratch_mu);
+        call_tune = e->tune;
+        call_tune_gen = e->tune_gen;
+        log_w_fixed = e->v3_log_w_fixed;
+    }
+    uint32_t call_log_w = call_tune.v3_log_w;
+    if (!log_w_fixed) {
         const uint32_t lw = (uint32_t)__atomic_load_n(&e->h_rstat[1], __ATOMIC_RELAXED);
         if (lw >= 10 && lw <= 13) call_log_w = lw;
     }
@@ -347,7 +360,7 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
             n -= take;
             continue;
         }
-        if (lh::part_aligned(d_ids, d_v) && lh::part_scratch_bytes(take, e->cfg.max_metrics, e->num_cus, e->tune)) {
+        if (lh::part_aligned(d_ids, d_v) && lh::part_scratch_bytes(take, e->cfg.max_metrics, e->num_cus, call_tune)) {
             // large launch over many names: partition by name, then reduce in LDS.  Sub-launches keep the scratch
             // block bounded: at most `sublaunch_pairs` pairs each, halved until the block fits `scratch_cap`
             // (power-of-two cuts keep both arrays on their vector alignment).
@@ -359,7 +372,7 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
             const bool bounded = !two_level || e->scratch_cap_set || e->sublaunch_set;
             if (!scratch_lock.owns_lock()) scratch_lock.lock();
             size_t sub = (bounded && take > e->sublaunch_pairs) ? e->sublaunch_pairs : take;
-            lh::PartTuning tune = e->tune;
+            lh::PartTuning tune = call_tune;
             if (e->regions_disabled.load(std::memory_order_relaxed)) tune.v2_shape &= ~2u; // clustered stream: exact layout
             if (e->v3_disabled.load(std::memory_order_relaxed)) tune.v3 = false;            // skew-free names: first generation
             tune.v3_log_w = call_log_w;
@@ -424,13 +437,14 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
                     e->v3_seen_bad = bad;
                     e->v3_seen_pairs = pairs;
                     if (e->v3_tables_valid && e->scratch_gen == 3 && e->v3_tables_log_w == call_log_w && healthy &&
-                        e->v3_tables_age < e->survey_every && !surveyed) {
+                        e->v3_tables_tune_gen == call_tune_gen && e->v3_tables_age < e->survey_every && !surveyed) {
                         surveyed = true; // this call runs on the previous survey
                         e->v3_tables_age++;
                         e->c_survey_reuse.fetch_add(1, std::memory_order_relaxed);
                     } else if (!surveyed) {
                         e->v3_tables_valid = true; // (the launch below surveys)
                         e->v3_tables_log_w = call_log_w;
+                        e->v3_tables_tune_gen = call_tune_gen;
                         e->v3_tables_age = 1;
                     }
                 }
@@ -931,16 +945,21 @@ int lh_commit_pairs(lh_engine *e, uint32_t token, size_t n)
 {
     if (!e || token == 0 || token > e->lanes.size()) return LH_EINVAL;
     Lane &ln = *e->lanes[token - 1u];
+    int rc = LH_OK;
     {
         std::lock_guard<std::mutex> g(ln.mu);
-        if (!ln.reserved || n > ln.granted) return LH_ESTATE;
-        ln.fill += n; // a half-buffer this fills is launched by the next call that takes the lane (reserve, submit, flip)
+        if (!ln.reserved) return LH_ESTATE;
+        // more than was granted: nothing is published, but the reservation ENDS (a lane left reserved would block
+        // every later flip, sync and submit on it for good) -- the caller's pairs are not ingested
+        const bool bad = n > ln.granted;
+        if (!bad) ln.fill += n; // a half-buffer this fills is launched by the next call that takes the lane (reserve, submit, flip)
         ln.reserved = false;
         ln.granted = 0;
         if (ln.fill == 0) ln.mode = LANE_NONE;
+        rc = bad ? LH_ESTATE : LH_OK;
     }
     ln.cv.notify_all();
-    return LH_OK;
+    return rc;
 }
 
 int lh_submit_device(lh_engine *e, uint32_t id, const double *d_v, size_t n, void *stream)
@@ -2021,18 +2040,28 @@ int lh_release(lh_snapshot *s)
     int rc = use_device(e);
     if (rc) return rc;
     EpochBuffer &b = e->bufs[(size_t)s->buf];
+    // The first error is reported, but the buffer is recycled and the handle freed whatever happens on the way: a
+    // failed step that returned early would leave the epoch buffer BUF_SNAPSHOT for good (every later lh_flip
+    // LH_EBUSY) and leak the handle.
+    int first_err = LH_OK;
+    auto keep = [&](int r) { if (r != LH_OK && first_err == LH_OK) first_err = r; };
+    auto hip = [&](hipError_t he) {
+        if (he != hipSuccess) {
+            set_last_error("lh_release", he);
+            keep(LH_EDEVICE);
+        }
+    };
     {
         std::lock_guard<std::mutex> g(e->xmu);
         // the reference folds the interval's amounts into the lifetime totals at the epoch boundary whoever reads
         // them (metrics.go:435-458): a snapshot released before any counter call still folds
-        rc = fold_counters(s);
-        if (rc) return rc;
-        HIPCHK(lh::launch_clear(b.counts, b.ranges, e->cfg.max_metrics, e->xstream));
+        keep(fold_counters(s));
+        hip(lh::launch_clear(b.counts, b.ranges, e->cfg.max_metrics, e->xstream));
         if (e->cfg.max_counters) {
-            HIPCHK(hipMemsetAsync(b.ccur, 0, (size_t)e->cfg.max_counters * sizeof(uint64_t), e->xstream));
-            HIPCHK(hipMemsetAsync(b.cflag, 0, (size_t)e->cfg.max_counters * sizeof(uint32_t), e->xstream));
+            hip(hipMemsetAsync(b.ccur, 0, (size_t)e->cfg.max_counters * sizeof(uint64_t), e->xstream));
+            hip(hipMemsetAsync(b.cflag, 0, (size_t)e->cfg.max_counters * sizeof(uint32_t), e->xstream));
         }
-        HIPCHK(hipEventRecord(b.cleared, e->xstream));
+        hip(hipEventRecord(b.cleared, e->xstream));
         __atomic_store_n(&b.nsamples, 0, __ATOMIC_RELAXED);
     }
     {
@@ -2041,7 +2070,7 @@ int lh_release(lh_snapshot *s)
     }
     e->live_snapshots.fetch_sub(1);
     delete s;
-    return LH_OK;
+    return first_err;
 }
 
 int lh_get_counters(lh_engine *e, lh_counters *out)
@@ -2072,8 +2101,20 @@ int lh_get_counters(lh_engine *e, lh_counters *out)
     out->surveys_reused = e->c_survey_reuse.load();
     {
         const uint64_t lw = __atomic_load_n(&e->h_rstat[1], __ATOMIC_RELAXED);
+        std::lock_guard<std::mutex> g(e->scratch_mu);
         out->window_log2 = e->v3_log_w_fixed ? e->tune.v3_log_w : (lw >= 10 && lw <= 13 ? lw : e->tune.v3_log_w);
     }
+    return LH_OK;
+}
+
+// An option that feeds the launch plans: written under the scratch lock (launch_pairs snapshots `tune` under it), and
+// the third generation's kept survey tables -- laid out for the old plan's LDS budget -- are not reused.
+static int set_tune(lh_engine *e, const std::function<void(lh::PartTuning &)> &f)
+{
+    std::lock_guard<std::mutex> g(e->scratch_mu);
+    f(e->tune);
+    e->tune_gen++;
+    e->v3_tables_valid = false;
     return LH_OK;
 }
 
@@ -2083,20 +2124,16 @@ int lh_set_option(lh_engine *e, int option, uint64_t value)
     switch (option) {
     case LH_OPT_TWO_LEVEL_ABOVE:
         if (value > 256) return LH_EINVAL;
-        e->tune.two_level_above = (uint32_t)value;
-        return LH_OK;
+        return set_tune(e, [&](lh::PartTuning &t) { t.two_level_above = (uint32_t)value; });
     case LH_OPT_HOT_MIN_TILES:
         if (value < 1 || value > (1u << 20)) return LH_EINVAL;
-        e->tune.hot_min_tiles = (uint32_t)value;
-        return LH_OK;
+        return set_tune(e, [&](lh::PartTuning &t) { t.hot_min_tiles = (uint32_t)value; });
     case LH_OPT_HOT_WINDOWS:
         if (value > 1) return LH_EINVAL;
-        e->tune.hot = value != 0;
-        return LH_OK;
+        return set_tune(e, [&](lh::PartTuning &t) { t.hot = value != 0; });
     case LH_OPT_NAMES_PER_PARTITION:
         if (value < 1 || value > 64) return LH_EINVAL;
-        e->tune.names_per_part = (uint32_t)value;
-        return LH_OK;
+        return set_tune(e, [&](lh::PartTuning &t) { t.names_per_part = (uint32_t)value; });
     case LH_OPT_EXTRACT_ZERO_COPY:
         if (value > 1 && (value < 4096 || value > (uint64_t(64) << 20))) return LH_EINVAL;
         e->zero_copy_enabled = value != 0;
@@ -2120,29 +2157,25 @@ int lh_set_option(lh_engine *e, int option, uint64_t value)
     }
     case LH_OPT_PART_V2:
         if (value > 1) return LH_EINVAL;
-        e->tune.v2 = value != 0;
-        return LH_OK;
+        return set_tune(e, [&](lh::PartTuning &t) { t.v2 = value != 0; });
     case LH_OPT_PART_V2_SHAPE:
         if (value > 3) return LH_EINVAL;
-        e->tune.v2_shape = (uint32_t)value;
-        return LH_OK;
+        return set_tune(e, [&](lh::PartTuning &t) { t.v2_shape = (uint32_t)value; });
     case LH_OPT_PART_V2_MIN_PAIRS:
         if (value < (1u << 17) || value > (uint64_t(1) << 31)) return LH_EINVAL;
-        e->tune.v2_min_samples = (size_t)value;
-        return LH_OK;
+        return set_tune(e, [&](lh::PartTuning &t) { t.v2_min_samples = (size_t)value; });
     case LH_OPT_PART_V3:
         if (value > 1) return LH_EINVAL;
-        e->tune.v3 = value != 0;
-        return LH_OK;
+        return set_tune(e, [&](lh::PartTuning &t) { t.v3 = value != 0; });
     case LH_OPT_PART_V3_MIN_PAIRS:
         if (value < (1u << 17) || value > (uint64_t(1) << 31)) return LH_EINVAL;
-        e->tune.v3_min_samples = (size_t)value;
-        return LH_OK;
+        return set_tune(e, [&](lh::PartTuning &t) { t.v3_min_samples = (size_t)value; });
     case LH_OPT_PART_V3_LOG_W:
         if (value != 0 && (value < 10 || value > 13)) return LH_EINVAL;
-        e->v3_log_w_fixed = value != 0;
-        e->tune.v3_log_w = value ? (uint32_t)value : 10u;
-        return LH_OK;
+        return set_tune(e, [&](lh::PartTuning &t) {
+            e->v3_log_w_fixed = value != 0;
+            t.v3_log_w = value ? (uint32_t)value : 10u;
+        });
     case LH_OPT_SURVEY_EVERY: {
         if (value < 1 || value > 1024) return LH_EINVAL;
         std::lock_guard<std::mutex> g(e->scratch_mu);
@@ -2161,8 +2194,7 @@ int lh_set_option(lh_engine *e, int option, uint64_t value)
         return LH_OK;
 #ifdef LH_TUNING
     case 100: // timing ablations of the scatter kernels (results are wrong): tools/ builds only
-        e->tune.dbg = (uint32_t)value;
-        return LH_OK;
+        return set_tune(e, [&](lh::PartTuning &t) { t.dbg = (uint32_t)value; });
 #endif
     default:
         return LH_EINVAL;

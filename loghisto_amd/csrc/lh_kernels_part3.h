@@ -1429,63 +1429,29 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
     }
     __syncthreads();
 
-    // Flush.  A slot that holds ALL the chunks of its fine partition is the only writer of its names' window cells in
-    // this launch (other slots count other names; out-of-window records of these names go to other cells), so it adds
-    // with plain loads and stores, sixteen cells per thread in flight, instead of one uint64 atomic per occupied cell
-    // (memory-side on this part: 15 M of them were 77 us of the pass's 257 on config 4's slice).  Slots that share a
-    // partition keep the atomics.  (One LDS range update per wave, not per cell: that was another 42 us.)
-    const bool sole = first == 0 && cnt == part_chunks[q]; // workgroup-uniform
-    // (device time stamps of single slots on config 4's slice: setup 3 us, a wave's chunk 3.3 us, the flush 15 us --
-    // two batches of sixteen cells, each a full round trip to HBM.  All of a thread's 32 cells in ONE batch.)
+    // Flush: one uint64 atomic per occupied cell.  Always atomics: a slot that holds all the chunks of its fine
+    // partition is the only writer of its names' cells in THIS launch, but not in the epoch buffer -- another stream
+    // (a lane's lh_submit, lh_submit_device on a caller's stream, the small and direct kernels) may add to the same
+    // cell while this launch runs, and a plain load + store would lose that increment (round 3 flushed such slots
+    // with read-modify-writes: 9 % of this pass on config 4's slice, and wrong under concurrent ingest;
+    // tests/test_gpu_part3.py::test_concurrent_streams_into_the_same_names).  The atomics return nothing, so a
+    // thread issues all 32 of its cells back to back and never waits for memory.  (One LDS range update per wave,
+    // not per cell: the wave's 64 cells are consecutive bins of one name, its lowest and highest occupied bins are
+    // those of the first and the last lane that found a count.)
     constexpr uint32_t FL = P3_WINWORDS / P2_BLOCK;
     static_assert(FL == 32 && P3_WINWORDS % P2_BLOCK == 0, "a thread flushes 32 cells");
-    {
-        auto cell = [&](uint32_t k, uint32_t &l, uint32_t &b) {
-            const uint32_t i = tid + k * P2_BLOCK;
-            l = i >> log_w;
-            b = s_org[l] + (i & (W - 1));
-        };
-#pragma unroll 4
-        for (uint32_t k = 0; k < FL; k++) {
-            uint32_t l, b;
-            cell(k, l, b);
-            // the wave's 64 cells are consecutive bins of the name: its lowest and highest occupied bins are those of
-            // the first and the last lane that found a count
-            const unsigned long long occ = __builtin_amdgcn_ballot_w64(h[tid + k * P2_BLOCK] != 0);
-            if (occ != 0ull && lane == 0) {
-                atomicMin(&s_mn[l], b + (uint32_t)__builtin_ctzll(occ));
-                atomicMax(&s_mx[l], b + 63u - (uint32_t)__builtin_clzll(occ));
-            }
+#pragma unroll 8
+    for (uint32_t k = 0; k < FL; k++) {
+        const uint32_t i = tid + k * P2_BLOCK, l = i >> log_w, b = s_org[l] + (i & (W - 1));
+        const uint32_t c = h[i];
+        const unsigned long long occ = __builtin_amdgcn_ballot_w64(c != 0);
+        if (occ != 0ull && lane == 0) {
+            atomicMin(&s_mn[l], b + (uint32_t)__builtin_ctzll(occ));
+            atomicMax(&s_mx[l], b + 63u - (uint32_t)__builtin_clzll(occ));
         }
-        if (sole) {
-            unsigned long long old[FL]; // (the counts are read from LDS again below: 64 registers of old values are enough)
-#pragma unroll
-            for (uint32_t k = 0; k < FL; k++) {
-                uint32_t l, b;
-                cell(k, l, b);
-                old[k] = h[tid + k * P2_BLOCK] ? counts[(size_t)s_name[l] * LH_NKEYS + b] : 0ull;
-            }
-            // (the addresses are worked out again from an index the compiler cannot match with the loads' -- kept in
-            // registers next to the 32 old values they would spill)
-            uint32_t tid2 = tid;
-            asm volatile("" : "+v"(tid2));
-#pragma unroll
-            for (uint32_t k = 0; k < FL; k++) {
-                const uint32_t i = tid2 + k * P2_BLOCK, l = i >> log_w, b = s_org[l] + (i & (W - 1));
-                const uint32_t c = h[i];
-                if (c) counts[(size_t)s_name[l] * LH_NKEYS + b] = old[k] + c;
-            }
-        } else {
-#pragma unroll 4
-            for (uint32_t k = 0; k < FL; k++) {
-                uint32_t l, b;
-                cell(k, l, b);
-                const uint32_t c = h[tid + k * P2_BLOCK];
-                if (c)
-                    atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)s_name[l] * LH_NKEYS + b]),
-                              (unsigned long long)c);
-            }
-        }
+        if (c)
+            atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)s_name[l] * LH_NKEYS + b]),
+                      (unsigned long long)c);
     }
     for (uint32_t i = tid; i < OV_SLOTS; i += P2_BLOCK)
         if (ov_key[i] != OV_EMPTY) p2_global_add(counts, ranges, s_name[ov_key[i] >> 16], ov_key[i] & 0xffffu, ov_cnt[i]);

@@ -128,3 +128,56 @@ def test_extract_view_equals_extract(native_lib, torch_cuda, M):
         assert np.array_equal(bits(a[k][5:M - 6]), bits(c[k])), k
         # the wave-per-metric kernel (>= 2 048 names) is bit-identical to the block-per-metric one, _sum included
         assert np.array_equal(bits(a[k][5:hi]), bits(d[k])), k
+
+
+def test_plan_options_end_the_reuse_of_survey_tables(native_lib, torch_cuda):
+    """the third generation keeps its survey tables between calls (LH_OPT_SURVEY_EVERY); they are laid out
+    for one plan (hot-window cells, window width).  LH_OPT_HOT_WINDOWS 1 -> 0 gives the next launch no hot-window
+    LDS at all, so a reused table would point hot names at cells that are not there.  Every option that feeds the
+    plan ends the reuse; every cell is exact before and after."""
+    import loghisto_amd
+    from test_gpu_part3 import _ids, _values, check
+    rng = np.random.default_rng(77)
+    M, n = 65536, 1_500_000
+    ids = _ids(rng, M, n, 1.0)
+    v = _values(rng, "lognormal", ids, n)
+    d_ids, d_v = _dev(torch_cuda, ids), _dev(torch_cuda, v)
+    P = [0.0, .5, .9, .99, .999, 1.0]
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        e.set_option(N.OPT_PART_V3_MIN_PAIRS, 1 << 17)
+        e.set_option(N.OPT_PART_V3_LOG_W, 10)
+
+        def call():
+            e.submit_pairs_device(d_ids, d_v)
+            e.sync()
+            with e.flip() as snap:
+                check(snap, ids, v, M, snap.extract(P, M))
+            return e.counters()["surveys_reused"]
+
+        call()
+        assert call() == 1                                  # the second call ran on the first one's survey
+        for opt, val in ((N.OPT_HOT_WINDOWS, 0), (N.OPT_HOT_WINDOWS, 1), (N.OPT_PART_V3_LOG_W, 11),
+                         (N.OPT_HOT_MIN_TILES, 2), (N.OPT_PART_V2_SHAPE, 1)):
+            before = e.counters()["surveys_reused"]
+            e.set_option(opt, val)
+            assert call() == before, (opt, val)             # surveyed again
+            assert call() == before + 1                     # and the call after that reuses the new tables
+
+
+def test_commit_of_more_than_was_granted_ends_the_reservation(native_lib, torch_cuda):
+    """lh_commit_pairs(n > granted) is an error, publishes nothing and must not leave the lane reserved
+    (every later flip, sync and submit on it would block for good)."""
+    import loghisto_amd
+    with loghisto_amd.Engine(max_metrics=8, num_buffers=2, num_lanes=1, lane_samples=1 << 12) as e:
+        di, dv, tok = e.reserve_pairs(100)
+        di[:100] = 3
+        dv[:100] = 5.0
+        with pytest.raises(loghisto_amd.LhError):
+            e.commit_pairs(tok, di.size + 1)
+        with pytest.raises(loghisto_amd.LhError):           # the reservation is over: a second commit has nothing to end
+            e.commit_pairs(tok, 1)
+        e.submit_pairs(np.full(10, 2, dtype=np.uint32), np.full(10, 7.0))   # the lane is usable again
+        e.sync()
+        with e.flip() as snap:
+            got = snap.extract(PCTS, 8)
+        assert got["count"].tolist() == [0, 0, 10, 0, 0, 0, 0, 0]

@@ -288,3 +288,41 @@ def test_clustered_stream_falls_back_to_the_first_generation(native_lib, torch_c
         c = e.counters()
         assert c["region_overflows"] > n // 50 and c["regions_disabled"] == 1, c
         assert c["samples_partitioned_v3"] < 3 * n and c["samples_partitioned"] == 3 * n, (c, seen_v3)
+
+
+def test_concurrent_streams_into_the_same_names(native_lib, torch_cuda):
+    """a third-generation launch on one stream while other streams add to the SAME cells of the same
+    epoch buffer (a device-resident producer on stream A, small launches of the direct-atomic kernel and the host
+    lanes on others).  Every cell update of every pass must be atomic: round 3's reduce pass flushed the slots that own
+    their whole partition with a plain load + store and could lose the other stream's increment.  metrics.go:273-295:
+    Histogram is called from any number of goroutines and never loses a sample."""
+    import loghisto_amd
+    torch = torch_cuda
+    rng = np.random.default_rng(404)
+    M, n = 65536, 6_000_000
+    ids = _ids(rng, M, n, 1.0, permute=False)
+    v = _values(rng, "constant", ids, n)              # few cells per name: both streams hit the same ones
+    small = 100_000                                   # < 131 072 pairs: the direct-atomic kernel
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    d_ids, d_v = _dev(torch, ids), _dev(torch, v)
+    rounds, per_round = 3, 12
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=2, lane_samples=1 << 16) as e:
+        e.set_option(N.OPT_PART_V3_MIN_PAIRS, 1 << 17)
+        torch.cuda.synchronize()
+        for r in range(rounds):
+            e.submit_pairs_device(d_ids, d_v, stream=sa)               # survey + three passes on stream A
+            for k in range(per_round):                                  # ... while stream B and a host lane add too
+                lo = (r * per_round + k) * small
+                e.submit_pairs_device(d_ids[lo:lo + small], d_v[lo:lo + small], stream=sb)
+                e.submit_pairs(ids[lo:lo + 4096], v[lo:lo + 4096])
+        e.sync()
+        torch.cuda.synchronize()
+        assert e.counters()["samples_partitioned_v3"] == rounds * n
+        parts_i = [ids] * rounds + [ids[: rounds * per_round * small]]
+        parts_v = [v] * rounds + [v[: rounds * per_round * small]]
+        for k in range(rounds * per_round):
+            parts_i.append(ids[k * small:k * small + 4096])
+            parts_v.append(v[k * small:k * small + 4096])
+        all_i, all_v = np.concatenate(parts_i), np.concatenate(parts_v)
+        with e.flip() as snap:
+            check(snap, all_i, all_v, M, snap.extract(PCTS, M))

@@ -4,7 +4,7 @@
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/${1:-r2x}; shift; mkdir -p $OUT; cd $R
 for V in "$@"; do
   LIB=loghisto_amd/build/liblhgpu_tuning_$V.so; [ "$V" = base ] && LIB=loghisto_amd/build/liblhgpu_tuning.so
-  echo "== parity $V: $(timeout 600 python tools/test_with_lib.py $LIB 2>&1 | tail -1)" | tee -a $OUT/variants.txt
+  echo "== parity $V: $(timeout 600 python tools/run_tests_with_lib.py $LIB 2>&1 | tail -1)" | tee -a $OUT/variants.txt
 done
 for rep in 1 2; do
 for V in "$@"; do

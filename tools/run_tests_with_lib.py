@@ -1,5 +1,5 @@
 """Runs the survey-path parity tests against another build of the library (a tuning variant under evaluation):
-    python tools/test_with_lib.py loghisto_amd/build/liblhgpu_tuning_x.so [pytest args...]"""
+    python tools/run_tests_with_lib.py loghisto_amd/build/liblhgpu_tuning_x.so [pytest args...]"""
 import os
 import sys
 
