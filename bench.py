@@ -11,12 +11,14 @@ C3 (1e9 pairs over 1 024 Zipf names), one rank's slice of C4 (65 536 names, redu
 C ABI), the host-fed lh_submit_pairs rate and a short C5 burst -- each with its own roofline and parity flag
 (VERDICT r1 next #4), and "parity": the GPU row against the oracle over ALL 1e9 samples of the step.
 
-N > 1: one process per GPU (torch.distributed launches and rendezvous), weak scaling of BASELINE configs[3]
-"65536 histogram names sharded across the GPUs, RCCL merge of bucket arrays": every rank buckets ITS slice of a
-Zipf stream over ALL 65 536 names, and at the flip lh_snapshot_merge reduce-scatters the per-row merged windows
-over RCCL/xGMI so that rank r ends with the rows of the names it owns, which it extracts.  The only collective
-is that merge.  value = N * n * K / max-over-ranks wall time.  (The N = 1 line's secondary.c4_one_rank is the
-single-rank point of this series.)
+N > 1: one process per GPU (torch.distributed launches and rendezvous), WEAK SCALING OF THE SAME HEADLINE: every
+rank buckets its own 1e9-sample slice of the ONE metric (K1), and at the flip lh_snapshot_merge all-reduces the
+one row's merged window over RCCL/xGMI (LH_MERGE_ALLREDUCE, through the C ABI), then every rank extracts.  The
+only collective is that merge.  value = N * n * K / max-over-ranks wall time; N = 1 of this code path IS the
+N = 1 line (no merge).  BASELINE configs[3] ("65536 histogram names sharded across the GPUs, RCCL merge of bucket
+arrays": every rank buckets ITS slice of a Zipf stream over ALL 65 536 names, lh_snapshot_merge reduce-scatters
+the per-row merged windows so that rank r ends with the rows of the names it owns, which it extracts) runs on the
+same ranks afterwards and is reported under secondary.c4 with its own one-rank reference.
 
 Prints ONE JSON line on rank 0.
 """
@@ -42,9 +44,39 @@ HBM_PEAK_GBS = 8000.0                                    # MI355X_MICROARCH.md: 
 PCIE_GBS = 63.0                                          # PCIe Gen5 x16 (spec)
 BYTES_SINGLE, BYTES_PAIR = 8, 12                         # float64 / float64 + uint32 id
 METRIC = "float64 samples/sec bucketed (1 GPU) + % HBM roofline; p99 extract latency"
-K1_PMC = os.path.join("profiles", "r03_k1_pmc.json")
-C3_PMC = os.path.join("profiles", "r03_c3_pmc.json")
-C4_PMC = os.path.join("profiles", "r03_c4_pmc.json")
+K1_PMC = os.path.join("profiles", "r04_k1_pmc.json")
+C3_PMC = os.path.join("profiles", "r04_c3_pmc.json")
+C4_PMC = os.path.join("profiles", "r04_c4_pmc.json")
+C4_1E9_PMC = os.path.join("profiles", "r04_c4_names_1e9_pmc.json")
+
+
+# Kernel sources each committed PMC summary was measured on.  The summary records their hashes ("sources"); a summary
+# whose hashes differ from the tree's is STALE -- the kernels changed after it was taken -- and its bytes are not
+# reported as `traffic` (the constant must not go stale silently).
+PMC_SOURCES = {
+    "k1": ["lh_kernels.hip", "lh_codec.h", "lh_kernels.h"],
+    "c3": ["lh_kernels_part.hip", "lh_kernels_part2.h", "lh_codec.h", "lh_windows.h", "lh_kernels.h"],
+    "c4": ["lh_kernels_part.hip", "lh_kernels_part2.h", "lh_kernels_part3.h", "lh_codec.h", "lh_windows.h", "lh_kernels.h"],
+}
+
+
+def source_hashes(kind):
+    import hashlib
+    out = {}
+    for f in PMC_SOURCES[kind]:
+        with open(os.path.join(ROOT, "loghisto_amd", "csrc", f), "rb") as fh:
+            out[f] = hashlib.sha256(fh.read()).hexdigest()[:16]
+    return out
+
+
+def pmc_stale(j, kind):
+    """None when the summary j was measured on the kernel sources of this tree, else what differs."""
+    rec = j.get("sources")
+    if not rec:
+        return "the summary records no source hashes"
+    cur = source_hashes(kind)
+    diff = sorted(f for f in cur if rec.get(f) != cur[f])
+    return ("kernel sources changed since the summary was taken: " + ", ".join(diff)) if diff else None
 
 
 def parse():
@@ -54,15 +86,17 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--samples", type=float, default=1e9, help="float64 samples per GPU per step (c2 / c3)")
     ap.add_argument("--dist", default="lognormal", choices=["lognormal", "constant", "uniform", "exponential",
-                                                            "normal", "loguniform", "lognormal25"])
+                                                            "normal", "loguniform", "lognormal25", "kvalues2",
+                                                            "kvalues4", "kvalues8", "kvalues16", "bimodal"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="N = 1: only the C2 headline")
     ap.add_argument("--no-parity", action="store_true", help="skip the full-stream oracle checks (profiling runs)")
     ap.add_argument("--latency-flips", type=int, default=1000)
     ap.add_argument("--workload", default="auto", choices=["auto", "c2", "c3", "c4"],
-                    help="auto: c2 (+ secondary) on one GPU, c4 on several; c3: 1024 Zipf names; c4: 65536 names "
-                         "+ reduce-scatter merge")
+                    help="auto = c2: the single-metric headline (+ secondary legs; on several GPUs weak scaling of it with "
+                         "an all-reduce of the row, config 4 under secondary.c4); c3: 1024 Zipf names; c4: 65536 names + "
+                         "reduce-scatter merge as the top-level line")
     ap.add_argument("--names", type=int, default=0, help="histogram names (default 1024 for c3, 65536 for c4)")
     ap.add_argument("--c4-slice", type=float, default=1.25e8, help="pairs per rank per step of the C4 stream")
     return ap.parse_args()
@@ -74,6 +108,24 @@ def make_samples(n: int, kind: str, seed: int) -> torch.Tensor:
     g.manual_seed(seed)
     if kind == "constant":
         return torch.full((n,), 123.0, dtype=torch.float64, device="cuda")
+    if kind == "kvalues3_skewed":
+        # one dominant value: 90 % / 9 % / 1 % (a wave holds ~58 lanes of one bucket)
+        u = torch.rand(n, device="cuda", generator=g)
+        j = (u > 0.9).to(torch.int32) + (u > 0.99).to(torch.int32)
+        return torch.pow(torch.tensor(1.5, dtype=torch.float64, device="cuda"), j).mul_(1e3)
+    if kind.startswith("kvalues"):
+        # few-valued stream (quantised timers, status codes, queue depths: what TimerToken.Stop produces): k distinct
+        # values 1000 * 1.5^j, uniformly drawn
+        j = torch.randint(0, int(kind[7:]), (n,), device="cuda", generator=g, dtype=torch.int32)
+        return torch.pow(torch.tensor(1.5, dtype=torch.float64, device="cuda"), j).mul_(1e3)
+    if kind == "bimodal":
+        # two lognormal lobes 10x apart, 90 / 10
+        v = torch.randn(n, dtype=torch.float64, device="cuda", generator=g).add_(math.log(1e5)).exp_()
+        step = 1 << 27
+        for lo in range(0, n, step):
+            u = torch.rand(min(step, n - lo), device="cuda", generator=g)
+            v[lo:lo + step].mul_(torch.where(u < 0.1, 10.0, 1.0).to(torch.float64))
+        return v
     if kind in ("uniform", "loguniform", "exponential"):
         v = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
         if kind == "uniform":
@@ -167,9 +219,41 @@ def dense_from_csr(off, keys, counts, M):
 
 
 # ---------------------------------------------------------------------------------------------------------
-# C2: single metric (the headline)
+# the communicator of the C-ABI merge
 # ---------------------------------------------------------------------------------------------------------
-def run_c2(args, la, stream, rank):
+def make_comm(world, rank, dist, comm_override=None):
+    """(ncclComm_t, front-end label, reason): the communicator lh_snapshot_merge runs on (what a cgo caller would hold;
+    torch.distributed only carries the unique id).  If RCCL cannot be set up from here the run continues through the
+    torch.distributed front-end (loghisto_amd.merge) -- NOT silently: the label goes into the line's top-level
+    `config.merge` as "fallback: ..." together with the reason (VERDICT r3 weak #5)."""
+    from loghisto_amd import rccl
+    if comm_override is not None:
+        return comm_override, "c-abi: lh_snapshot_merge -> RCCL", ""
+    try:
+        if world > 1:
+            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(rccl.unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, 0)
+            comm = rccl.comm_init_rank(world, bytes(uid.cpu().numpy().tobytes()), rank)
+        else:
+            comm = rccl.comm_init_rank(1, rccl.unique_id(), 0)
+        return comm, "c-abi: lh_snapshot_merge -> RCCL", ""
+    except Exception as exc:  # noqa: BLE001
+        if world == 1:
+            return 0, "none (one rank, no communicator)", repr(exc)
+        return 0, "fallback: torch.distributed front-end (loghisto_amd.merge), the RCCL communicator for the C ABI " \
+                  "could not be made", repr(exc)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# C2: single metric (the headline); with several ranks: weak scaling of the same stream, one all-reduce per step
+# ---------------------------------------------------------------------------------------------------------
+def run_c2(args, la, stream, rank, world=1, dist=None, comm=0, frontend="none", why=""):
+    """Every rank buckets its own slice (n samples of the one metric); with world > 1 the row's merged window is
+    all-reduced at the flip (lh_snapshot_merge, LH_MERGE_ALLREDUCE) before every rank extracts.  world == 1 is the
+    N = 1 headline: the same code with no merge."""
+    from loghisto_amd import merge as tmerge
     n = int(args.samples)
     eng = la.Engine(device=torch.cuda.current_device(), max_metrics=1, num_buffers=2, num_lanes=1, lane_samples=1 << 16)
     data = make_samples(n, args.dist, seed=2 + rank)
@@ -185,21 +269,37 @@ def run_c2(args, la, stream, rank):
             b.record(stream)
             events.append((a, b))
         snap = eng.flip()
+        if world > 1:                                              # the only collective: the one row's window
+            if comm:
+                snap.merge_rccl(comm, world, rank, 1, plan="allreduce")
+            else:
+                tmerge.merge_snapshot(snap, 1, plan="allreduce")
         out = snap.extract(PCTS, 1)                                # K2 + results on the host
+        if timed and world > 1 and comm:
+            minfo.update(snap.merge_info())
         snap.release()                                             # K3 (async)
         return out
 
+    minfo = {}
+
     def fence():
         torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
 
     dt, out = timed_steps(step, args.steps, args.warmup, fence)
-    assert int(out["count"].sum()) == n
+    if dist is not None:                                           # the slowest rank's clock
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert int(out["count"].sum()) == n * world, (int(out["count"].sum()), n, world)
     k1_ms = sum(a.elapsed_time(b) for a, b in events) / len(events)
 
-    # p99 extract latency: flip -> stats on host (BASELINE.json metric, part 2)
+    # p99 extract latency: flip -> stats on host (BASELINE.json metric, part 2); one rank's own interval
     lat = []
     small = data[: 1 << 20]
-    for _ in range(args.latency_flips):
+    for _ in range(args.latency_flips if world == 1 else 0):
         eng.submit_device(0, small, small.numel(), stream=stream)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -218,22 +318,59 @@ def run_c2(args, la, stream, rank):
             # prescribes; see the JSON's "corrections").  It only applies to the workload it was measured on.
             j = json.load(open(pmc))
             if n * BYTES_SINGLE == int(j["algorithmic_bytes_per_launch"]) and args.dist == "lognormal":
-                traffic = j["hbm_read_bytes_per_launch"] + j["hbm_write_bytes_per_launch"]
-                traffic_source = f"{K1_PMC} (committed rocprofv3 --pmc summary of this command, not measured in this run)"
+                stale = pmc_stale(j, "k1")
+                if stale:
+                    traffic_source = f"stale: {K1_PMC} not used ({stale})"
+                else:
+                    traffic = j["hbm_read_bytes_per_launch"] + j["hbm_write_bytes_per_launch"]
+                    traffic_source = f"{K1_PMC} (committed rocprofv3 --pmc summary of this command on these kernel " \
+                                     "sources, not measured in this run)"
         except Exception:
             traffic = None
     res = {
-        "value": n * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
-        "config": {"workload": "C2 single-metric float64 stream, one ingest kernel + one percentile scan per step",
+        "value": world * n * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+        "config": {"workload": "C2 single-metric float64 stream, one ingest kernel + one percentile scan per step"
+                               + ("" if world == 1 else "; every rank buckets its own slice, the row's merged window is "
+                                  "all-reduced at the flip (lh_snapshot_merge, LH_MERGE_ALLREDUCE), every rank extracts"),
                    "samples_per_gpu_per_step": n, "distribution": args.dist, "metrics": 1, "percentiles": PCTS,
-                   "merge": "none"},
+                   "ranks": world, "merge": "none" if world == 1 else frontend},
         "roofline": roofline(n * BYTES_SINGLE, k1_ms, "k_ingest_single", traffic=traffic,
                              traffic_source=traffic_source, frac_of_measured_copy_ceiling_6290=n * BYTES_SINGLE / (k1_ms * 1e-3) / 1e9 / 6290.0),
         "extract_latency_us": {"p50": float(np.percentile(lat_us, 50)), "p99": float(np.percentile(lat_us, 99)),
                                "flips": len(lat), "names": 1},
     }
+    if world > 1:
+        res["value_per_gpu"] = res["value"] / world
+        res["merge"] = {"device_ms": {k: minfo.get(k) for k in ("ranges_ms", "plan_ms", "pack_ms", "collective_ms",
+                                                                "unpack_ms", "span_ms")},
+                        "packed_cells": minfo.get("packed_cells"), "cell_bytes": minfo.get("cell_bytes"),
+                        "note": "one row: its merged window (~1 000 cells) is all that crosses xGMI per step"}
+        if why:
+            res["config"]["merge_fallback_reason"] = why
     host = None
-    if not args.no_parity:
+    if not args.no_parity and world > 1:
+        # the merged row on every rank == the oracle over the CONCATENATED slices: every rank buckets its own slice
+        # with the oracle, the expected merged row is the all-reduced sum of those
+        import oracle
+        eng.submit_device(0, data, n, stream=stream)
+        snap = eng.flip()
+        if comm:
+            snap.merge_rccl(comm, world, rank, 1, plan="allreduce")
+        else:
+            tmerge.merge_snapshot(snap, 1, plan="allreduce")
+        gpu_row = snap.dense_row(0)
+        snap.release()
+        mine = oracle.histogram_dense_mt(data.cpu().numpy())
+        want = torch.from_numpy(mine.astype(np.int64)).cuda()
+        dist.all_reduce(want)
+        want = want.cpu().numpy().astype(np.uint64)
+        ok = torch.tensor([int(np.array_equal(gpu_row, want))], dtype=torch.int64, device="cuda")
+        dist.all_reduce(ok)
+        res["parity"] = {"samples_checked": int(want.sum()), "exact": int(ok.item()) == world,
+                         "ranks_with_the_exact_merged_row": int(ok.item()),
+                         "checker": "oracle/ over every rank's slice, all-reduced, against the merged GPU row on every rank"}
+        assert res["parity"]["exact"], "merged GPU row differs from the oracle over the concatenated slices"
+    if not args.no_parity and world == 1:
         # the whole step's stream through the oracle on every granted host core: bit-exact bucket counts
         import oracle
         eng.submit_device(0, data, n, stream=stream)
@@ -249,7 +386,7 @@ def run_c2(args, la, stream, rank):
                          "checker": f"oracle/ (C restatement of metrics.go:316-322 + Go math.Log), {effective_cores()} "
                                     f"threads, {t_cpu:.2f} s (+ {t_copy:.2f} s for the 8 GB device-to-host copy)"}
         assert res["parity"]["exact"], "GPU row differs from the oracle over the full stream"
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1 and rank == 0:
         if host is None:
             host = data[: 1 << 27].cpu().numpy()
         res["cpu_baseline"] = cpu_baseline(host, args.cpu_seconds)
@@ -271,9 +408,12 @@ def c3_traffic(n, names, which=None):
     try:
         j = json.load(open(path))
         if j["pairs_per_call"] == n and j["names"] == names:
+            stale = pmc_stale(j, "c3" if names <= 8192 else "c4")
+            if stale:
+                return {"traffic": None, "traffic_source": f"stale: {which} not used ({stale})"}
             return {"traffic": j["hbm_bytes_per_call"],
-                    "traffic_source": f"{which} (committed rocprofv3 --pmc summary of the same command, every kernel "
-                                      "of one call summed; not measured in this run)"}
+                    "traffic_source": f"{which} (committed rocprofv3 --pmc summary of the same command on these kernel "
+                                      "sources, every kernel of one call summed; not measured in this run)"}
     except (OSError, ValueError, KeyError):
         pass
     return {"traffic": None, "traffic_source": None}
@@ -353,9 +493,11 @@ def run_c3(args, la, stream, rank, steps, warmup, latency_flips=0):
 # ---------------------------------------------------------------------------------------------------------
 # C4: 65 536 names, data-parallel ingest, reduce-scatter merge through the C ABI
 # ---------------------------------------------------------------------------------------------------------
-def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=None):
-    """comm_override: an ncclComm_t the caller made (tests/_bench_ranks_driver.py: ranks as threads on one GPU over the
-    stub RCCL, with a thread-rendezvous stand-in for torch.distributed as `dist`)."""
+def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=None, frontend=None, why=""):
+    """comm_override: the ncclComm_t to merge on -- the one main() made for this job (make_comm; 0 = the recorded
+    torch.distributed fallback), or one the caller made (tests/_bench_ranks_driver.py: ranks as threads on one GPU over
+    the stub RCCL, with a thread-rendezvous stand-in for torch.distributed as `dist`).  None: a one-rank communicator
+    of its own (world == 1)."""
     from loghisto_amd import merge as tmerge
     from loghisto_amd import rccl
     M = args.names or 65536
@@ -366,21 +508,13 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=Non
     data = make_samples(n, "lognormal", seed=40 + rank)
     data.mul_(torch.exp(3e-5 * ids.to(torch.float64)))
     torch.cuda.synchronize()
-    # communicator for the C-ABI front-end (what a cgo caller would hold); torch.distributed only carries the id
-    comm, frontend, why = 0, "c-abi: lh_snapshot_merge -> RCCL ncclReduceScatter", ""
-    try:
-        if comm_override is not None:
-            comm = comm_override
-        elif world > 1:
-            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-            if rank == 0:
-                uid.copy_(torch.frombuffer(bytearray(rccl.unique_id()), dtype=torch.uint8))
-            dist.broadcast(uid, 0)
-            comm = rccl.comm_init_rank(world, bytes(uid.cpu().numpy().tobytes()), rank)
-        else:
-            comm = rccl.comm_init_rank(1, rccl.unique_id(), 0)
-    except Exception as exc:  # noqa: BLE001 -- keep the scaling run alive through the torch.distributed front-end
-        comm, frontend, why = 0, "torch.distributed: loghisto_amd.merge.merge_snapshot (reduce_scatter_tensor)", repr(exc)
+    own_comm = False
+    if comm_override is None:
+        comm, frontend, why = make_comm(world, rank, dist)
+        own_comm = bool(comm)
+    else:
+        comm = comm_override
+        frontend = frontend or "c-abi: lh_snapshot_merge -> RCCL"
     t_ing, t_merge, t_ext = [], [], []
     info = {}
 
@@ -534,9 +668,63 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=Non
     if lat_c4:
         res["extract_latency_us"] = lat_c4
     if why:
-        res["merge_frontend_fallback_reason"] = why
-    if comm and comm_override is None:
+        res["config"]["merge_fallback_reason"] = why
+    if own_comm:
         rccl.comm_destroy(comm)
+    eng.close()
+    del ids, data
+    torch.cuda.empty_cache()
+    return res
+
+
+def run_c4_1e9(args, la, stream, steps=3, warmup=2):
+    """config 4's name count at a full-size interval: 65 536 Zipf names, 1e9 pairs per step on one rank (the slice of
+    c4_one_rank is 1.25e8 pairs = 2 ms of stream, where fixed work dominates; SURVEY.md 8d says "merge every 1 s of
+    simulated stream").  ingest + flip + extract of all names (results in place) + release per step."""
+    M, n = 65536, int(1e9)
+    eng = la.Engine(device=torch.cuda.current_device(), max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16)
+    ids = zipf_ids(n, M, 4100)
+    data = make_samples(n, "lognormal", seed=41)
+    chunk = 1 << 27
+    for lo in range(0, n, chunk):
+        data[lo:lo + chunk].mul_(torch.exp(3e-5 * ids[lo:lo + chunk].to(torch.float64)))
+    torch.cuda.synchronize()
+    events = []
+
+    def step(timed):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        eng.submit_pairs_device(ids, data, n, stream=stream)
+        b.record(stream)
+        if timed:
+            events.append((a, b))
+        snap = eng.flip()
+        out = snap.extract_view(PCTS, M)
+        cnt = out["count"].copy()
+        snap.release()
+        return cnt
+
+    dt, cnt = timed_steps(step, steps, warmup, torch.cuda.synchronize)
+    ing_ms = sum(a.elapsed_time(b) for a, b in events) / len(events)
+    per_name = torch.bincount(ids, minlength=M).cpu().numpy()
+    counts_ok = bool(np.array_equal(cnt.astype(np.int64), per_name))
+    parity = {"per_name_counts_exact": counts_ok, "exact": counts_ok}
+    if not args.no_parity:
+        import oracle
+        probe = sorted({0, 1, 2, 7, 63, 255, 1023, 4095, M // 2, M - 2, M - 1} | {int(x) for x in np.linspace(0, M - 1, 12)})
+        eng.submit_pairs_device(ids, data, n, stream=stream)
+        with eng.flip() as snap:
+            ok = all(np.array_equal(snap.dense_row(m), oracle.histogram_dense(data[ids == m].cpu().numpy())) for m in probe)
+        parity.update(rows_checked_cell_by_cell=len(probe), exact=counts_ok and ok)
+    assert parity["exact"], parity
+    c = eng.counters()
+    res = {"value": n * steps / dt, "unit": "samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+           "config": {"workload": "65536 histogram names (config 4's name count), Zipf(1.0), 1e9 pairs per step on one "
+                                  "rank, extract of every name per step", "names": M, "pairs_per_step": n},
+           "roofline": roofline(n * BYTES_PAIR, ing_ms,
+                                "k_scatter4 + k_split_waves + k_part_hist3 (+ survey, plans): every launch of one "
+                                "lh_submit_pairs_device", **c3_traffic(n, M, C4_1E9_PMC)),
+           "parity": parity, "scratch_bytes": c["scratch_bytes"]}
     eng.close()
     del ids, data
     torch.cuda.empty_cache()
@@ -689,50 +877,67 @@ def main():
     torch.cuda.set_stream(stream)
     workload = args.workload
     if workload == "auto":
-        workload = "c2" if world == 1 else "c4"
-    if world > 1 and workload != "c4":
-        raise SystemExit("several GPUs run the C4 workload (data-parallel ingest + merge); use --workload c4 or auto")
+        workload = "c2"          # at any rank count: the N-rank line continues the N = 1 headline (weak scaling)
+    if world > 1 and workload == "c3":
+        raise SystemExit("several GPUs run the C2 headline (auto / c2) or config 4 (c4)")
 
     base = {"metric": METRIC, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
+    comm, frontend, why = (0, "none", "")
+    if world > 1:
+        comm, frontend, why = make_comm(world, rank, dist)   # ONE communicator for the job: headline and secondary.c4
+
+    def c4_with_reference():
+        """config 4 on these ranks, with the same slice on rank 0's GPU alone as its own one-rank reference (the curve's
+        N = 1 line is the C2 headline -- a different workload from this one)."""
+        ref = None
+        saved = args.no_parity
+        args.no_parity = True
+        try:
+            one = run_c4(args, la, stream, 0, 1, None, steps=5, warmup=2)
+            ref = {"value": one["value"], "ms_per_step": one["ms_per_step"], "ranks": 1,
+                   "note": "same C4 slice on this rank's GPU alone, measured in this process before the N-rank steps"}
+        except Exception as exc:  # noqa: BLE001
+            ref = {"failed": repr(exc)[:300]}
+        args.no_parity = saved
+        dist.barrier()
+        r4 = run_c4(args, la, stream, rank, world, dist, 5, 2, comm_override=comm, frontend=frontend, why=why)
+        r4["value_per_gpu"] = r4["value"] / world
+        r4["one_rank_reference"] = ref
+        if ref.get("value"):
+            r4["efficiency_vs_one_rank"] = r4["value"] / (world * ref["value"])
+        return r4
+
     if workload == "c2":
-        res = run_c2(args, la, stream, rank)
+        res = run_c2(args, la, stream, rank, world, dist, comm, frontend, why)
         if not args.no_secondary:
             sec = {}
-            for name, fn in (("c3", lambda: run_c3(args, la, stream, rank, steps=5, warmup=2, latency_flips=200)),
-                             ("c4_one_rank", lambda: run_c4(args, la, stream, 0, 1, None, steps=5, warmup=2)),
-                             ("hostfed_pairs", lambda: run_hostfed(la)),
-                             ("c5", run_c5)):
+            if world == 1:
+                legs = (("c3", lambda: run_c3(args, la, stream, rank, steps=5, warmup=2, latency_flips=200)),
+                        ("c4_one_rank", lambda: run_c4(args, la, stream, 0, 1, None, steps=5, warmup=2)),
+                        ("c4_one_rank_1e9", lambda: run_c4_1e9(args, la, stream)),
+                        ("hostfed_pairs", lambda: run_hostfed(la)),
+                        ("c5", run_c5))
+            else:
+                legs = (("c4", c4_with_reference),)
+            for name, fn in legs:
                 try:
                     sec[name] = fn()
                 except Exception as exc:  # noqa: BLE001 -- a secondary leg must not take the headline down
+                    if world > 1:
+                        raise           # ... but on several ranks a rank that drops out of a collective hangs the others
                     sec[name] = {"failed": repr(exc)[:300]}
             res["secondary"] = sec
     elif workload == "c3":
         res = run_c3(args, la, stream, rank, args.steps, args.warmup, latency_flips=min(args.latency_flips, 200))
+    elif world > 1:
+        res = c4_with_reference()
     else:
-        ref = None
-        if world > 1:
-            # the same workload on this GPU alone (1-rank communicator, no exchange): the N = 1 line of the driver is the
-            # C2 headline, so the N-rank line carries its own one-rank reference for this workload
-            saved = args.no_parity
-            args.no_parity = True
-            try:
-                one = run_c4(args, la, stream, 0, 1, None, steps=5, warmup=2)
-                ref = {"value": one["value"], "ms_per_step": one["ms_per_step"], "ranks": 1,
-                       "note": "same C4 slice on rank 0's GPU alone, measured in this process before the N-rank steps"}
-            except Exception as exc:  # noqa: BLE001
-                ref = {"failed": repr(exc)[:300]}
-            args.no_parity = saved
-            dist.barrier()
         res = run_c4(args, la, stream, rank, world, dist, args.steps, args.warmup)
-        res["value_per_gpu"] = res["value"] / world
-        if ref is not None:
-            res["one_rank_reference"] = ref
-            if ref.get("value"):
-                # the same workload's one-rank point, for a curve: the driver's N = 1 line is the C2 headline (one metric,
-                # 8 B per sample), a different workload from this one (65 536 names, 12 B per pair, merge at the flip)
-                res["efficiency_vs_one_rank"] = res["value"] / (world * ref["value"])
+        res["value_per_gpu"] = res["value"]
+    if comm:
+        from loghisto_amd import rccl
+        rccl.comm_destroy(comm)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -37,6 +37,13 @@ _PROGRAMS = [
 ]
 
 
+# standalone HIP measurement tools (no library): (source relative to the repo root, output name)
+_HIP_PROGRAMS = [
+    ("tools/read_ceiling.hip", "read_ceiling"),      # what a kernel that only reads gets from HBM (K1's ceiling)
+    ("tools/valu_rates.hip", "valu_rates"),          # issue cost of the bucket index's VALU instructions
+]
+
+
 def _hipcc() -> str:
     for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):
@@ -81,6 +88,16 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
         if force or _stale(out, [s, LIB] + headers):
             cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-Wall", "-I", INCLUDE, s, "-o", out,
                    "-L", _HERE, "-llhgpu", "-Wl,-rpath," + _HERE, "-Wl,-rpath,$ORIGIN/.."]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+    for src, name in _HIP_PROGRAMS:
+        s = os.path.join(root, src)
+        if not os.path.exists(s):
+            continue
+        out = os.path.join(bdir, name)
+        if force or _stale(out, [s]):
+            cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", s, "-o", out]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)

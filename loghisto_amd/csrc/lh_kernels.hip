@@ -64,14 +64,32 @@ hipError_t launch_gen_tables(double *d_Tx, double *d_D, hipStream_t s)
 // ---------------------------------------------------------------------------
 // K1 single-metric ingest
 // ---------------------------------------------------------------------------
-constexpr int K1_BLOCK = 512;                      // 8 waves; 2 workgroups per CU
+#ifndef LH_K1_BLOCK
+#define LH_K1_BLOCK 512
+#endif
+constexpr int K1_BLOCK = LH_K1_BLOCK;              // 8 waves; 2 workgroups per CU
 #ifndef LH_K1_UNROLL
 #define LH_K1_UNROLL 8   // measured on MI355X: 8 is 3-5 % faster than 4; register prefetch adds nothing (tools/k1_variants.sh)
 #endif
 constexpr int K1_UNROLL = LH_K1_UNROLL;             // 16-B loads in flight per lane
-constexpr uint32_t K1_WIN = 16384;                 // LDS window, u32 bins (64 KiB)
-constexpr uint32_t K1_WIN_LO = 32768 - K1_WIN / 2; // keys [-8192, 8191]
-constexpr size_t K1_LDS_BYTES = K1_WIN * sizeof(uint32_t) + 16;
+// LDS: K1_COPIES private histograms of K1_WIN uint32 bins each (64 KiB together).  A lane adds to copy lane % K1_COPIES:
+// same-address LDS atomics serialise, and what a wave-instruction costs is the largest number of lanes on ONE word per
+// 32-lane group.  Measured on few-valued streams (quantised timers, status codes, queue depths -- the ordinary input
+// of TimerToken.Stop, metrics.go:242-246; profiles/r04_fewvalued.jsonl): with one copy, 8 lanes per word and group
+// (k = 4 distinct values) are free next to the HBM stream, 11 (k = 3) cost 0.3 ms per 1e9 samples, 16 (k = 2) 0.7 ms.
+// Two copies halve every multiplicity (k = 2 becomes k = 4's pattern) for half the window: keys -4096 .. 4095, i.e.
+// |v| < 6.1e17 -- nanosecond timers up to 19 years; samples outside go straight to the global row (exact, rare).
+#ifndef LH_K1_COPIES
+#define LH_K1_COPIES 2
+#endif
+constexpr uint32_t K1_COPIES = LH_K1_COPIES;
+constexpr uint32_t K1_WIN = 16384 / K1_COPIES;     // bins per copy
+constexpr uint32_t K1_WIN_LO = 32768 - K1_WIN / 2; // first bin of the window
+// copy k starts K1_PAD words past a multiple of the 32 banks: the same bin of two copies must not share a bank, or
+// the copies would serialise on the bank what they no longer serialise on the word
+constexpr uint32_t K1_PAD = 16;
+constexpr uint32_t K1_STRIDE = K1_WIN + (K1_COPIES > 1 ? K1_PAD : 0);
+constexpr size_t K1_LDS_BYTES = (size_t)K1_STRIDE * K1_COPIES * sizeof(uint32_t) + 16;
 
 // Out-of-window cell: straight to the global row.
 __device__ __forceinline__ void global_cell_add(uint64_t *row, uint32_t *range, uint32_t bin, uint64_t c)
@@ -81,27 +99,34 @@ __device__ __forceinline__ void global_cell_add(uint64_t *row, uint32_t *range, 
     atomicMax(&range[1], bin);
 }
 
-__device__ __forceinline__ void k1_add(uint32_t *h, uint64_t *row, uint32_t *range, uint32_t bin)
+// hc: this lane's copy of the window
+__device__ __forceinline__ void k1_add(uint32_t *hc, uint64_t *row, uint32_t *range, uint32_t bin, uint32_t c = 1u)
 {
     const uint32_t rel = bin - K1_WIN_LO;
-    if (rel < K1_WIN) atomicAdd(&h[rel], 1u);
-    else global_cell_add(row, range, bin, 1);
+    if (rel < K1_WIN) atomicAdd(&hc[rel], c);
+    else global_cell_add(row, range, bin, c);
 }
 
-// All 64 lanes active.  A wave whose 64 samples share one bucket (constant or
-// tightly clustered streams) would serialise 64 same-address LDS atomics; one
-// lane adds 64 instead.
-__device__ __forceinline__ void k1_add_fullwave(uint32_t *h, uint64_t *row, uint32_t *range, uint32_t bin)
+// All 64 lanes active.  A wave whose samples mostly share ONE bucket (a constant stream; a stream dominated by one
+// value) aggregates that group before the atomic: if lane 0's bucket is shared by >= K1_AGG_MIN lanes, lane 0 adds
+// the group's size, the other lanes of the group add nothing, everybody else adds 1 -- one ds_add with a per-lane
+// count, no scalar round trip beyond the ballot.  (Measured and dropped: peeling up to four groups leader by leader --
+// its readlane / ballot round trips cost more than the conflicts they removed, k = 4: 3.9 ms per 1e9 samples -- and
+// a second group led by the first lane outside the first: constant streams 1.29 -> 1.55 ms.)  Streams with many
+// buckets never enter: a lognormal stream's hottest bucket holds 0.4 % of the samples.
+#ifndef LH_K1_AGG_MIN
+#define LH_K1_AGG_MIN 24
+#endif
+__device__ __forceinline__ void k1_add_fullwave(uint32_t *hc, uint64_t *row, uint32_t *range, uint32_t bin)
 {
     const uint32_t first = __builtin_amdgcn_readfirstlane(bin);
-    if (__builtin_amdgcn_ballot_w64(bin != first) == 0ull) {
-        if (__lane_id() == 0) {
-            const uint32_t rel = first - K1_WIN_LO;
-            if (rel < K1_WIN) atomicAdd(&h[rel], 64u);
-            else global_cell_add(row, range, first, 64);
-        }
+    const unsigned long long same = __builtin_amdgcn_ballot_w64(bin == first);
+    const uint32_t nsame = (uint32_t)__builtin_popcountll(same);
+    if (nsame >= LH_K1_AGG_MIN) { // wave-uniform
+        const bool leader = __lane_id() == 0;
+        if (leader || bin != first) k1_add(hc, row, range, bin, leader ? nsame : 1u);
     } else {
-        k1_add(h, row, range, bin);
+        k1_add(hc, row, range, bin);
     }
 }
 
@@ -111,11 +136,12 @@ __global__ __launch_bounds__(K1_BLOCK) void k_ingest_single(const double *__rest
                                                             const double *__restrict__ Tx)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *h = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *s_minmax = h + K1_WIN; // [0]=min rel bin, [1]=max rel bin
+    uint32_t *h0 = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *s_minmax = h0 + K1_STRIDE * K1_COPIES; // [0]=min rel bin, [1]=max rel bin
     const uint32_t tid = threadIdx.x;
+    uint32_t *h = h0 + (tid % K1_COPIES) * K1_STRIDE;   // this lane's copy
 
-    for (uint32_t i = tid; i < K1_WIN; i += K1_BLOCK) h[i] = 0;
+    for (uint32_t i = tid; i < K1_STRIDE * K1_COPIES; i += K1_BLOCK) h0[i] = 0;
     if (tid == 0) { s_minmax[0] = 0xffffffffu; s_minmax[1] = 0; }
     __syncthreads();
 
@@ -128,6 +154,31 @@ __global__ __launch_bounds__(K1_BLOCK) void k_ingest_single(const double *__rest
 
     // (register double buffering -- tile t + grid in flight while tile t is bucketed -- measured slower,
     // profiles/r02_k1_variants.txt: two workgroups per CU already overlap each other's loads)
+#ifdef LH_K1_ROLL
+    // Rolling refill (variant under measurement): a lane's K1_UNROLL loads stay in flight ALL the time -- as soon as
+    // slot u of tile t has been taken out of its registers, the same registers receive slot u of the workgroup's next
+    // tile; the wait before slot u + 1 is then always vmcnt(K1_UNROLL - 1).  The tile past the end that the last round
+    // requests is the workgroup's own last tile again (loaded, not used).
+    if ((size_t)blockIdx.x < nfull) {
+        d2_t r[K1_UNROLL];
+        {
+            const d2_t *p = vp + (size_t)blockIdx.x * tile + tid;
+#pragma unroll
+            for (int u = 0; u < K1_UNROLL; u++) r[u] = __builtin_nontemporal_load(p + u * K1_BLOCK);
+        }
+        for (size_t t = blockIdx.x; t < nfull; t += gridDim.x) {
+            const size_t tn = t + gridDim.x < nfull ? t + gridDim.x : t;
+            const d2_t *pn = vp + tn * tile + tid;
+#pragma unroll
+            for (int u = 0; u < K1_UNROLL; u++) {
+                const d2_t x = r[u];
+                r[u] = __builtin_nontemporal_load(pn + u * K1_BLOCK);
+                k1_add_fullwave(h, row, range, lh_bin_of(x.x, Tx));
+                k1_add_fullwave(h, row, range, lh_bin_of(x.y, Tx));
+            }
+        }
+    }
+#else
     for (size_t t = blockIdx.x; t < nfull; t += gridDim.x) {
         const d2_t *p = vp + t * tile + tid;
         d2_t r[K1_UNROLL];
@@ -139,6 +190,7 @@ __global__ __launch_bounds__(K1_BLOCK) void k_ingest_single(const double *__rest
             k1_add_fullwave(h, row, range, lh_bin_of(r[u].y, Tx));
         }
     }
+#endif
     // remainder pairs (guarded), owned by the workgroup next in the rotation
     if (blockIdx.x == nfull % gridDim.x) {
         for (size_t i = nfull * tile + tid; i < npair; i += K1_BLOCK) {
@@ -151,10 +203,12 @@ __global__ __launch_bounds__(K1_BLOCK) void k_ingest_single(const double *__rest
     }
     __syncthreads();
 
-    // flush: one u64 atomic per occupied LDS bin
+    // flush: one u64 atomic per occupied bin (the copies summed)
     uint32_t lmin = 0xffffffffu, lmax = 0;
     for (uint32_t i = tid; i < K1_WIN; i += K1_BLOCK) {
-        const uint32_t c = h[i];
+        uint32_t c = h0[i];
+#pragma unroll
+        for (uint32_t k = 1; k < K1_COPIES; k++) c += h0[k * K1_STRIDE + i];
         if (c) {
             atomicAdd(reinterpret_cast<unsigned long long *>(&row[K1_WIN_LO + i]), (unsigned long long)c);
             lmin = min(lmin, i);

@@ -94,20 +94,32 @@ __global__ __launch_bounds__(KS_BLOCK) void k_ingest_pairs_small(const uint32_t 
         if (id >= nmetrics) { atomicOr(err, 1u); return; } // reported by lh_sync / lh_extract
         const uint32_t bin = lh_bin_of(x, Tx);
         const uint32_t rel = bin - s_org[id];
+        auto put = [&](uint32_t c) {
+            if (rel < W) atomicAdd(&h[(id << log_w) + rel], c);
+            else if (!ov_add(ov_key, ov_cnt, (id << 16) | bin, c)) { ks_global_add(counts, ranges, id, bin, c); nfall += c; }
+        };
         if (fullwave) {
-            // constant streams: all 64 lanes carry the same (name, bucket) -> one lane adds 64
+            // few-valued streams: lanes that carry the same (name, bucket) serialise on one LDS word.  As in K1
+            // (k1_add_fullwave): when lane 0's cell is shared by >= 16 lanes, lane 0 adds that group's size, the first
+            // lane outside it leads a second group the same way, everybody else adds 1 -- one atomic instruction with a
+            // per-lane count.  A constant stream is the one-group case.
             const uint32_t key = (id << 16) | bin;
             const uint32_t f0 = __builtin_amdgcn_readfirstlane(key);
-            if (__builtin_amdgcn_ballot_w64(key != f0) == 0ull) {
-                if (lane == 0) {
-                    if (rel < W) atomicAdd(&h[(id << log_w) + rel], 64u);
-                    else if (!ov_add(ov_key, ov_cnt, key, 64u)) { ks_global_add(counts, ranges, id, bin, 64); nfall += 64; }
-                }
+            const unsigned long long same = __builtin_amdgcn_ballot_w64(key == f0);
+            const uint32_t nsame = (uint32_t)__builtin_popcountll(same);
+            if (nsame >= 16u) { // wave-uniform
+                const unsigned long long rest = ~same;
+                const uint32_t src2 = rest ? (uint32_t)__builtin_ctzll(rest) : 0u;
+                const uint32_t leader2 = __builtin_amdgcn_readlane(key, src2);
+                const unsigned long long same2 = rest ? __builtin_amdgcn_ballot_w64(key == leader2) : 0ull;
+                const bool lead2 = rest && lane == src2;
+                const bool grouped = key == f0 || (rest && key == leader2);
+                if (!grouped || lane == 0 || lead2)
+                    put(lane == 0 ? nsame : lead2 ? (uint32_t)__builtin_popcountll(same2) : 1u);
                 return;
             }
         }
-        if (rel < W) atomicAdd(&h[(id << log_w) + rel], 1u);
-        else if (!ov_add(ov_key, ov_cnt, (id << 16) | bin, 1u)) { ks_global_add(counts, ranges, id, bin, 1); nfall++; }
+        put(1u);
     };
 
     const size_t nfull = npair / tile;

@@ -10,10 +10,13 @@ collective: torch.distributed over RCCL/xGMI on the GPU, gloo on CPU for tests.
 Two plans:
   * "allreduce":      every rank ends with every merged row (what BASELINE.json's
                       north star names).
-  * "reduce_scatter": rank r ends with the merged rows of the names it owns
-                      (contiguous blocks of ceil(M/world) ids), then extracts only
-                      those.  On a fully connected xGMI hive this moves 1/world of
-                      the all-reduce bytes per link.
+  * "reduce_scatter": rank r ends with the merged rows of the names it owns, then
+                      extracts only those.  The owner blocks are contiguous name ranges
+                      of EQUAL PACKED SIZE (cells), not of equal name count: the same
+                      rule as k_merge_plan of the C-ABI front-end (lh_snapshot_merge),
+                      so both front-ends give a rank the same [first, last).  On a fully
+                      connected xGMI hive this moves 1/world of the all-reduce bytes per
+                      link.
 
 uint64 counts are reduced through an int64 view: two's-complement addition is the
 same bits.  Dirty ranges are merged with MIN/MAX first; then every row travels with its
@@ -31,11 +34,20 @@ import torch.distributed as dist
 NKEYS = 65536
 
 
-def owned_rows(nrows: int, rank: int, world: int) -> Tuple[int, int]:
-    """[first, last) rows owned by `rank` under the reduce-scatter plan."""
+def name_blocks(nrows: int, rank: int, world: int) -> Tuple[int, int]:
+    """[first, last) of `rank` when names are cut into blocks of ceil(nrows / world) ids -- for callers that shard the
+    name space without a merge plan (logical shards on one device, tools/c4_sim.py).  NOT the reduce-scatter's
+    ownership: that follows the merged windows (plan_windows / owned_rows)."""
     per = (nrows + world - 1) // world
     lo = min(rank * per, nrows)
     return lo, min(lo + per, nrows)
+
+
+def owned_rows(W: dict, rank: int) -> Tuple[int, int]:
+    """[first, last) rows owned by `rank` under the plan W = plan_windows(merged ranges, world, plan)."""
+    if W["nblocks"] == 1:
+        return 0, int(W["width"].shape[0])
+    return int(W["brow"][rank]), int(W["brow"][rank + 1])
 
 
 def merge_ranges(ranges: torch.Tensor, group=None) -> torch.Tensor:
@@ -54,11 +66,17 @@ def plan_windows(ranges: torch.Tensor, world: int, plan: str):
 
     Every row keeps its own window [lo_r, hi_r]; the windows travel packed back to back, so one outlier
     sample widens one row (at most 65 536 cells), never the whole matrix.  Returns a dict:
-      width[nrows]   cells of row r (0 when the row is empty everywhere)
-      P[nrows + 1]   exclusive prefix of the widths (P[nrows] = total cells)
-      per            rows per owner block (reduce-scatter: ceil(nrows / world); all-reduce: nrows)
-      bstart[nb + 1] P at the owner-block boundaries;  bmax = largest block, in cells
-    The same plan is computed on the device by k_merge_plan for the C-ABI front-end (lh_snapshot_merge).
+      width[nrows]    cells of row r (0 when the row is empty everywhere)
+      P[nrows + 1]    exclusive prefix of the widths (P[nrows] = total cells)
+      nblocks         owner blocks (reduce-scatter: world; all-reduce: 1)
+      brow[nb + 1]    first row of every owner block: brow[0] = 0, brow[nb] = nrows, and block k (0 < k < nb) starts
+                      at the first row whose prefix reaches k / nb of the total, i.e. the smallest r with
+                      P[r] >= total // nb * k + total % nb * k // nb -- contiguous name ranges of equal PACKED size
+                      (RCCL's reduce-scatter pads every block to the largest; with equal name counts and names ranked
+                      by frequency block 0 holds the widest windows: 1.2 x padding on config 4's slice, 1.0001 x so)
+      bstart[nb + 1]  P at the block boundaries;  bmax = largest block, in cells
+    The SAME rule as k_merge_plan computes on the device for the C-ABI front-end (lh_snapshot_merge returns
+    brow[rank], brow[rank + 1]); tests/_stub_merge_driver.py compares the two at 2 .. 8 ranks.
     """
     nrows = ranges.shape[0]
     lo = ranges[:, 0].to(torch.int64)
@@ -66,14 +84,21 @@ def plan_windows(ranges: torch.Tensor, world: int, plan: str):
     width = (hi - lo + 1).clamp_(min=0)
     P = torch.zeros(nrows + 1, dtype=torch.int64, device=ranges.device)
     torch.cumsum(width, 0, out=P[1:])
-    if plan == "reduce_scatter":
-        per, nb = (nrows + world - 1) // world, world
-    else:
-        per, nb = nrows, 1
-    edges = torch.clamp(torch.arange(nb + 1, device=ranges.device, dtype=torch.int64) * per, max=nrows)
-    bstart = P[edges]
+    total = int(P[-1].item())
+    nb = world if plan == "reduce_scatter" else 1
+    k = torch.arange(nb + 1, device=ranges.device, dtype=torch.int64)
+    target = total // nb * k + total % nb * k // nb
+    brow = torch.searchsorted(P, target, right=False)      # smallest r in [0, nrows] with P[r] >= target
+    brow[0], brow[nb] = 0, nrows
+    bstart = P[brow]
     bmax = int((bstart[1:] - bstart[:-1]).max().item()) if nb else 0
-    return dict(lo=lo, width=width, P=P, per=per, nblocks=nb, bstart=bstart, bmax=bmax, total=int(P[-1].item()))
+    return dict(lo=lo, width=width, P=P, nblocks=nb, brow=brow, bstart=bstart, bmax=bmax, total=total)
+
+
+def block_of_rows(W: dict, rows: torch.Tensor) -> torch.Tensor:
+    """Owner block of every row index: the last k with brow[k] <= r (empty blocks share a boundary with their
+    successor) -- merge_block_of in lh_kernels.hip."""
+    return torch.searchsorted(W["brow"][: W["nblocks"]].contiguous(), rows, right=True) - 1
 
 
 _buffers = {}
@@ -108,12 +133,12 @@ def merge_rows(rows: torch.Tensor, ranges: Optional[torch.Tensor] = None, plan: 
         merge_ranges(ranges, group)
     else:
         ranges = torch.tensor([[0, NKEYS - 1]], dtype=torch.int32, device=rows.device).repeat(nrows, 1)
-    own = (0, nrows) if plan == "allreduce" else owned_rows(nrows, rank, world)
     last_info.clear()
     if world == 1:
         return 0, nrows
     W = plan_windows(ranges, world, plan)
-    total, bmax, per = W["total"], W["bmax"], W["per"]
+    own = owned_rows(W, rank)
+    total, bmax = W["total"], W["bmax"]
     last_info.update(packed_cells=total, widest_row=int(W["width"].max().item()) if nrows else 0)
     if total == 0:
         return own
@@ -129,16 +154,17 @@ def merge_rows(rows: torch.Tensor, ranges: Optional[torch.Tensor] = None, plan: 
         cells[flat] = buf
         last_info.update(send_bytes=total * 8, recv_bytes=total * 8)
         return own
-    # reduce-scatter by contiguous name blocks, every block padded to the largest one
+    # reduce-scatter by contiguous name blocks of equal packed size, every block padded to the largest one
     both = _buffer(rows.device, (world + 1) * bmax)
     send, recv = both[: world * bmax], both[world * bmax:]
     send.zero_()
-    blk = row_of // per
+    blk = block_of_rows(W, row_of)
     send[blk * bmax + (q - W["bstart"][blk])] = cells[flat]
     dist.reduce_scatter_tensor(recv, send, op=dist.ReduceOp.SUM, group=group)
     mine = blk == rank
     cells[flat[mine]] = recv[(q - W["bstart"][blk])[mine]]
-    last_info.update(send_bytes=world * bmax * 8, recv_bytes=bmax * 8)
+    last_info.update(send_bytes=world * bmax * 8, recv_bytes=bmax * 8, padded_cells=world * bmax,
+                     owned_rows_by_rank=[(int(W["brow"][k]), int(W["brow"][k + 1])) for k in range(world)])
     return own
 
 

@@ -1,9 +1,14 @@
-"""bench.run_c4 with N ranks as THREADS on the one reachable GPU (test infrastructure for test_gpu_bench_ranks.py).
+"""bench.py's N-rank paths with N ranks as THREADS on the one reachable GPU (test infrastructure for
+test_gpu_bench_ranks.py).
 
-The driver runs `bench.py --gpus N` on an 8-GPU node at round end; here one GPU is reachable.  The N-rank code of
-run_c4 (owned-block bookkeeping, the all-gathered bounds, per-name counts, the probe rows compared cell by cell after
-the merge, the merge report) is exercised with tests/cpp/rccl_stub.cc as the RCCL of lh_snapshot_merge and a
-thread-rendezvous stand-in for the few torch.distributed calls run_c4 makes.  usage: python _bench_ranks_driver.py N names slice"""
+The driver runs `bench.py --gpus N` on an 8-GPU node at round end; here one GPU is reachable.  The N-rank code of the
+headline (run_c2: every rank's slice of the ONE metric, all-reduce of the row at the flip, merged row against the oracle
+over the concatenated slices) and of config 4 (run_c4: owned-block bookkeeping, the all-gathered bounds, per-name
+counts, the probe rows compared cell by cell after the merge, the merge report) is exercised with
+tests/cpp/rccl_stub.cc as the RCCL of lh_snapshot_merge and a thread-rendezvous stand-in for the few
+torch.distributed calls they make.
+usage: python _bench_ranks_driver.py N names slice        (config 4)
+       python _bench_ranks_driver.py N c2 samples         (the headline)"""
 import ctypes as C
 import json
 import os
@@ -53,7 +58,8 @@ class ThreadDist:
 
 
 def main():
-    nranks, names, slice_pairs = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3])
+    c2 = sys.argv[2] == "c2"
+    nranks, names, slice_pairs = int(sys.argv[1]), (1 if c2 else int(sys.argv[2])), float(sys.argv[3])
     import torch
     import bench
     import loghisto_amd as la
@@ -63,7 +69,8 @@ def main():
     stub = C.CDLL(stub_path)
     comms = (C.c_void_p * nranks)()
     assert stub.stub_comm_create(nranks, comms) == 0
-    args = types.SimpleNamespace(names=names, c4_slice=slice_pairs, no_parity=False)
+    args = types.SimpleNamespace(names=names, c4_slice=slice_pairs, no_parity=False, samples=slice_pairs, dist="lognormal",
+                                 steps=2, warmup=1, latency_flips=3, no_cpu_baseline=True)
     dist = ThreadDist(nranks)
     results, errors = [None] * nranks, []
 
@@ -73,7 +80,11 @@ def main():
             dist.bind(r)
             stream = torch.cuda.Stream()
             torch.cuda.set_stream(stream)
-            results[r] = bench.run_c4(args, la, stream, r, nranks, dist, steps=2, warmup=1, comm_override=comms[r])
+            if c2:
+                results[r] = bench.run_c2(args, la, stream, r, nranks, dist if nranks > 1 else None,
+                                          comms[r] if nranks > 1 else 0, "c-abi: lh_snapshot_merge -> RCCL (stub)")
+            else:
+                results[r] = bench.run_c4(args, la, stream, r, nranks, dist, steps=2, warmup=1, comm_override=comms[r])
         except BaseException as exc:  # noqa: BLE001
             errors.append((r, repr(exc)))
             dist.bar.abort()
@@ -83,6 +94,11 @@ def main():
     [t.join(timeout=600) for t in th]
     assert not errors, errors
     res = results[0]
+    if c2:
+        print(json.dumps({"ok": True, "ranks": nranks, "parity": res["parity"], "merge": res.get("merge"),
+                          "config": res["config"], "values": [r["value"] for r in results],
+                          "samples_per_step": slice_pairs * nranks}))
+        return
     print(json.dumps({"ok": True, "ranks": nranks, "parity": res["parity"], "merge": res["merge"],
                       "owned_rows": [r["config"]["owned_rows"] for r in results]}))
 

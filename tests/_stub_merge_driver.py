@@ -78,6 +78,12 @@ def main():
     covered = []
     infos = []
     widths = np.where(want_ranges[:, 0] <= want_ranges[:, 1], want_ranges[:, 1] - want_ranges[:, 0] + 1, 0)
+    # ONE merge plan: the torch front-end's plan (loghisto_amd.merge.plan_windows) from the same merged ranges must give
+    # every rank the [first, last) that k_merge_plan gave it on the device, and the same padded block size
+    W = merge.plan_windows(torch.from_numpy(want_ranges.astype(np.int32)), nranks,
+                           "allreduce" if plan == "allreduce" else "reduce_scatter")
+    for r in range(nranks):
+        assert tuple(results[r]) == merge.owned_rows(W, r), (r, results[r], merge.owned_rows(W, r))
     for r in range(nranks):
         first, last = results[r]
         if plan == "allreduce":
@@ -99,6 +105,7 @@ def main():
         # at most one row's window per block over the packed matrix (ratio <= 1.3)
         assert info["cell_bytes"] == 4, info
         assert info["padded_cells"] >= cells
+        assert info["padded_cells"] == W["bmax"] * W["nblocks"], (info, W["bmax"], W["nblocks"])
         if plan != "allreduce" and cells > 100 * int(widths.max()):
             assert info["padded_cells"] <= 1.3 * cells, info
         assert info["span_ms"] > 0 and info["collective_ms"] >= 0 and info["pack_ms"] >= 0, info

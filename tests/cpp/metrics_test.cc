@@ -565,7 +565,11 @@ TEST(TestPrintBenchmark) // print_benchmark.go:49-106
     CHECK(p50 != std::string::npos);
     if (p50 != std::string::npos) {
         const double v = std::atof(text.c_str() + text.find(' ', p50));
-        CHECK(v >= 197000.0 && v < 5e8);
+        // lower bound: a guarantee (steady_clock around a sleep of 200 us); upper bound: a sanity check only -- on a box
+        // that is still paging the image in, sleeps of the first interval have been seen stretched a lot
+        CHECK(v >= 197000.0);
+        CHECK(v < 6e10);
+        if (!(v >= 197000.0 && v < 6e10)) std::printf("    p50 = %.17g in\n%s\n", v, text.substr(0, 1500).c_str());
     }
 }
 

@@ -27,3 +27,24 @@ def test_c4_step_with_ranks_as_threads(native_lib, torch_cuda, nranks, names):
     m = res["merge"]
     assert m["cell_bytes"] == 4 and m["padded_cells"] >= m["packed_cells"] and m["padding_ratio"] <= 1.3
     assert m["device_ms"]["span_ms"] > 0
+
+
+@pytest.mark.parametrize("nranks", [1, 2, 4])
+def test_headline_step_with_ranks_as_threads(native_lib, torch_cuda, nranks):
+    """`bench.py --gpus N`'s top-level line: weak scaling of the C2 headline.  Every rank buckets its own slice of the
+    one metric, lh_snapshot_merge all-reduces the row, every rank extracts; the merged row on every rank equals the
+    oracle over the concatenated slices.  N = 1 runs the same function with no merge: it IS the N = 1 line."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_bench_ranks_driver.py"), str(nranks), "c2", "3000001"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-3000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["ok"] and res["parity"]["exact"]
+    assert res["parity"]["samples_checked"] == 3000001 * nranks
+    assert res["config"]["ranks"] == nranks and res["config"]["metrics"] == 1
+    if nranks == 1:
+        assert res["config"]["merge"] == "none" and res["merge"] is None
+    else:
+        assert res["config"]["merge"].startswith("c-abi") and res["parity"]["ranks_with_the_exact_merged_row"] == nranks
+        assert res["merge"]["cell_bytes"] == 4 and 0 < res["merge"]["packed_cells"] < 4000
+        assert len(set(res["values"])) == 1            # every rank reports the job's value (max-over-ranks clock)

@@ -136,7 +136,7 @@ def test_plan_options_end_the_reuse_of_survey_tables(native_lib, torch_cuda):
     LDS at all, so a reused table would point hot names at cells that are not there.  Every option that feeds the
     plan ends the reuse; every cell is exact before and after."""
     import loghisto_amd
-    from test_gpu_part3 import _ids, _values, check
+    from tests.test_gpu_part3 import _ids, _values, check
     rng = np.random.default_rng(77)
     M, n = 65536, 1_500_000
     ids = _ids(rng, M, n, 1.0)
@@ -157,7 +157,7 @@ def test_plan_options_end_the_reuse_of_survey_tables(native_lib, torch_cuda):
         call()
         assert call() == 1                                  # the second call ran on the first one's survey
         for opt, val in ((N.OPT_HOT_WINDOWS, 0), (N.OPT_HOT_WINDOWS, 1), (N.OPT_PART_V3_LOG_W, 11),
-                         (N.OPT_HOT_MIN_TILES, 2), (N.OPT_PART_V2_SHAPE, 1)):
+                         (N.OPT_HOT_MIN_TILES, 2), (N.OPT_NAMES_PER_PARTITION, 8)):
             before = e.counters()["surveys_reused"]
             e.set_option(opt, val)
             assert call() == before, (opt, val)             # surveyed again

@@ -54,6 +54,15 @@ def dists(n, seed):
         "loguniform": 10.0 ** rng.uniform(-3, 18, n),
         "lognormal_s2.5": rng.lognormal(math.log(1e5), 2.5, n),
         "tiny": rng.uniform(-0.6, 0.6, n),
+        # few-valued streams (quantised timers, status codes, queue depths -- what TimerToken.Stop produces,
+        # metrics.go:242-246): k distinct buckets, every wave holds 64 / k same-address LDS atomics per value
+        "kvalues2": 1e3 * 1.5 ** rng.integers(0, 2, n),
+        "kvalues4": 1e3 * 1.5 ** rng.integers(0, 4, n),
+        "kvalues8": 1e3 * 1.5 ** rng.integers(0, 8, n),
+        "kvalues16": 1e3 * 1.5 ** rng.integers(0, 16, n),
+        "kvalues3_skewed": 1e3 * 1.5 ** rng.choice(3, n, p=[0.9, 0.09, 0.01]),
+        # two lognormal lobes 10x apart, 90 / 10
+        "bimodal": rng.lognormal(math.log(1e5), 1.0, n) * np.where(rng.random(n) < 0.1, 10.0, 1.0),
     }
 
 

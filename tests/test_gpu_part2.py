@@ -36,6 +36,10 @@ def _values(rng, kind, ids, n):
         return rng.lognormal(math.log(1e5) + 2e-3 * ids, 1.0)
     if kind == "constant":
         return 1000.0 + (ids % 5)
+    if kind.startswith("kvalues"):               # few-valued: k distinct buckets shared by all names
+        return 1e3 * 1.5 ** rng.integers(0, int(kind[7:]), n)
+    if kind == "bimodal":                        # two lognormal lobes 10x apart, 90 / 10
+        return rng.lognormal(math.log(1e5), 1.0, n) * np.where(rng.random(n) < 0.1, 10.0, 1.0)
     if kind == "allsame":
         return np.full(n, 123.0)
     if kind == "signed":                         # two lobes of bins per name, the mean bin between them
@@ -89,6 +93,9 @@ CASES = [
     (8192, 3_100_001, "edge", 1.0),          # the largest name count of this path
     (33, 1_000_000, "drift", 0.5),
     (1024, 2_000_000, "edge", 1.0),
+    (1024, 2_000_000, "kvalues2", 1.0),      # few-valued: every hot name's samples land on two cells
+    (1024, 2_000_000, "kvalues16", 1.0),
+    (1024, 2_000_000, "bimodal", 1.0),
 ]
 
 

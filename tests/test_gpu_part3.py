@@ -38,6 +38,10 @@ def _values(rng, kind, ids, n):
         return rng.lognormal(math.log(1e5) + 2e-3 * (ids % 4096), 1.0)
     if kind == "constant":
         return 1000.0 + (ids % 5)
+    if kind.startswith("kvalues"):               # few-valued: k distinct buckets shared by all names
+        return 1e3 * 1.5 ** rng.integers(0, int(kind[7:]), n)
+    if kind == "bimodal":                        # two lognormal lobes 10x apart, 90 / 10
+        return rng.lognormal(math.log(1e5), 1.0, n) * np.where(rng.random(n) < 0.1, 10.0, 1.0)
     if kind == "allsame":
         return np.full(n, 123.0)
     if kind == "signed":                         # two lobes of bins per name, the mean bin between them
@@ -110,6 +114,9 @@ CASES = [
     (16384, 2_600_000, "sigma25", 1.0, True, 0),      # 64 names per partition
     (8193, 2_000_000, "signed", 1.5, True, 0),        # the smallest name count of this path: 33 names per partition
     (20000, 1_800_000, "drift", 0.5, False, 0),
+    (65536, 2_000_000, "kvalues2", 1.0, False, 0),    # few-valued streams (quantised timers): two cells per name
+    (65536, 2_000_000, "kvalues8", 1.0, True, 0),
+    (65536, 2_000_000, "bimodal", 1.0, False, 0),
 ]
 
 

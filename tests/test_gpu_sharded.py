@@ -38,7 +38,7 @@ def test_sharded_ingest_merge_extract(native_lib, torch_cuda):
         torch.cuda.synchronize()
         # "reduce-scatter": rank r ends up with the sum of everybody's rows for the names it owns
         for r in range(S):
-            first, last = merge.owned_rows(M, r, S)
+            first, last = merge.name_blocks(M, r, S)
             rows_r, ranges_r = views[r]
             for q in range(S):
                 if q != r:
@@ -50,7 +50,7 @@ def test_sharded_ingest_merge_extract(native_lib, torch_cuda):
         torch.cuda.synchronize()
         total = 0
         for r in range(S):
-            first, last = merge.owned_rows(M, r, S)
+            first, last = merge.name_blocks(M, r, S)
             got = snaps[r].extract(PCTS, last - first, first=first)
             total += int(got["count"].sum())
             # oracle on the whole stream for a sample of the owned names (hot, middle and cold ones)

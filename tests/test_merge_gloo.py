@@ -45,47 +45,72 @@ def test_outliers_widen_one_row_not_the_matrix(tmp_path, plan):
     assert b["packed_cells"] < 64 * b["widest_row"] / 8
 
 
+def expected_blocks(width, world):
+    """The reduce-scatter's owner blocks, stated independently of both front-ends: block
+    k of `world` starts at the first row whose exclusive prefix of packed cells reaches k / world of the total;
+    block 0 starts at row 0 and the last block ends at the last row.  Returns brow[world + 1]."""
+    import numpy as np
+    nrows = len(width)
+    P = np.concatenate([[0], np.cumsum(width)]).astype(np.int64)
+    total = int(P[-1])
+    brow = [0]
+    for k in range(1, world):
+        target = total // world * k + total % world * k // world
+        brow.append(int(np.nonzero(P >= target)[0][0]))
+    return brow + [nrows]
+
+
 def test_window_plan_for_2_4_8_ranks():
-    """Pure plan arithmetic (loghisto_amd.merge.plan_windows == k_merge_plan on the device): per-row widths,
-    prefix, owner blocks of ceil(M/world) rows, padded block size; ragged name counts and empty rows."""
+    """Pure plan arithmetic: loghisto_amd.merge.plan_windows must give per-row widths, their prefix and the owner
+    blocks of EQUAL PACKED CELLS that k_merge_plan computes on the device for lh_snapshot_merge (the device side of
+    the same comparison: tests/_stub_merge_driver.py); ragged name counts, empty rows, all-empty matrices."""
     import numpy as np
     import torch
     from loghisto_amd import merge
     rng = np.random.default_rng(3)
     for nrows in (1, 5, 8, 61, 1000):
-        lo = rng.integers(0, 60000, nrows)
-        hi = lo + rng.integers(0, 3000, nrows)
-        empty = rng.random(nrows) < 0.2
-        lo[empty], hi[empty] = 65536, 0
-        ranges = torch.from_numpy(np.stack([lo, hi], 1).astype(np.int32))
-        width = np.where(empty, 0, hi - lo + 1)
-        for world in (2, 4, 8):
-            for plan in ("allreduce", "reduce_scatter"):
-                W = merge.plan_windows(ranges, world, plan)
-                assert np.array_equal(W["width"].numpy(), width)
-                assert np.array_equal(W["P"].numpy(), np.concatenate([[0], np.cumsum(width)]))
-                assert W["total"] == int(width.sum())
-                if plan == "allreduce":
-                    assert W["per"] == nrows and W["bmax"] == W["total"]
-                    continue
-                per = -(-nrows // world)
-                assert W["per"] == per and W["nblocks"] == world
-                blocks = [int(width[k * per:(k + 1) * per].sum()) for k in range(world)]
-                assert np.array_equal(np.diff(W["bstart"].numpy()), blocks) and W["bmax"] == max(blocks)
-                covered = []
-                for r in range(world):
-                    a, b = merge.owned_rows(nrows, r, world)
-                    assert (a, b) == (min(r * per, nrows), min((r + 1) * per, nrows))
-                    covered.extend(range(a, b))
-                assert covered == list(range(nrows))
+        for variant in ("random", "zipf-like", "all-empty"):
+            lo = rng.integers(0, 60000, nrows)
+            hi = lo + rng.integers(0, 3000, nrows)
+            if variant == "zipf-like":                       # names ranked by frequency: widest windows first
+                hi = lo + (3000 / (1 + np.arange(nrows)) ** 0.3).astype(np.int64)
+            empty = rng.random(nrows) < (1.0 if variant == "all-empty" else 0.2)
+            lo[empty], hi[empty] = 65536, 0
+            ranges = torch.from_numpy(np.stack([lo, hi], 1).astype(np.int32))
+            width = np.where(empty, 0, hi - lo + 1)
+            for world in (2, 4, 8):
+                for plan in ("allreduce", "reduce_scatter"):
+                    W = merge.plan_windows(ranges, world, plan)
+                    assert np.array_equal(W["width"].numpy(), width)
+                    assert np.array_equal(W["P"].numpy(), np.concatenate([[0], np.cumsum(width)]))
+                    assert W["total"] == int(width.sum())
+                    if plan == "allreduce":
+                        assert W["nblocks"] == 1 and W["bmax"] == W["total"]
+                        assert merge.owned_rows(W, 0) == (0, nrows) == merge.owned_rows(W, world - 1)
+                        continue
+                    brow = expected_blocks(width, world)
+                    assert W["nblocks"] == world and W["brow"].tolist() == brow
+                    blocks = [int(width[brow[k]:brow[k + 1]].sum()) for k in range(world)]
+                    assert np.array_equal(np.diff(W["bstart"].numpy()), blocks) and W["bmax"] == max(blocks)
+                    # equal shares: no block exceeds total / world by more than one row's window
+                    assert W["bmax"] <= -(-W["total"] // world) + int(width.max(initial=0))
+                    covered = []
+                    for r in range(world):
+                        a, b = merge.owned_rows(W, r)
+                        assert (a, b) == (brow[r], brow[r + 1])
+                        covered.extend(range(a, b))
+                    assert covered == list(range(nrows))
+                    rows = torch.arange(nrows)
+                    blk = merge.block_of_rows(W, rows).numpy()
+                    assert all(brow[blk[r]] <= r < brow[blk[r] + 1] for r in range(nrows))
 
 
-def test_owned_rows_partition():
+def test_name_blocks_partition():
     from loghisto_amd import merge
     for nrows in (1, 7, 8, 65536):
         for world in (1, 2, 4, 8):
             seen = []
             for r in range(world):
-                lo, hi = merge.owned_rows(nrows, r, world)
+                lo, hi = merge.name_blocks(nrows, r, world)
                 seen.extend(range(lo, hi))
             assert seen == list(range(nrows))

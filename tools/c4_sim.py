@@ -81,7 +81,7 @@ def main():
         hi = int(ranges[:, 1].max().item())
         width = hi - lo + 1
         per = (M + W - 1) // W
-        first, last = merge.owned_rows(M, 0, W)
+        first, last = merge.name_blocks(M, 0, W)
         matrix = M * width * 8
         out.update(window_bins=width, merge_matrix_bytes=matrix,
                    merge_bytes_sent_per_rank=matrix * (W - 1) // W, merge_bytes_per_peer_block=per * width * 8)
