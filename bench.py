@@ -42,7 +42,7 @@ sys.path.insert(0, ROOT)
 PCTS = [0.0, .5, .75, .9, .95, .99, .999, .9999, 1.0]   # metrics.go:145-155
 HBM_PEAK_GBS = 8000.0                                    # MI355X_MICROARCH.md: 8.0 TB/s spec
 PCIE_GBS = 63.0                                          # PCIe Gen5 x16 (spec)
-BYTES_SINGLE, BYTES_PAIR = 8, 12                         # float64 / float64 + uint32 id
+BYTES_SINGLE, BYTES_PAIR, BYTES_PAIR16 = 8, 12, 10        # float64 / float64 + uint32 id / + uint16 id
 METRIC = "float64 samples/sec bucketed (1 GPU) + % HBM roofline; p99 extract latency"
 K1_PMC = os.path.join("profiles", "r04_k1_pmc.json")
 C3_PMC = os.path.join("profiles", "r04_c3_pmc.json")
@@ -515,7 +515,7 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=Non
     else:
         comm = comm_override
         frontend = frontend or "c-abi: lh_snapshot_merge -> RCCL"
-    t_ing, t_merge, t_ext = [], [], []
+    t_ing, t_merge, t_ext, t_k2 = [], [], [], []
     info = {}
 
     def step(timed):
@@ -534,7 +534,11 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=Non
         else:
             first, last = 0, M
         t1 = time.perf_counter()
+        xs = torch.cuda.ExternalStream(snap.stream())            # the snapshot's own stream: K2 runs there
+        k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        k0.record(xs)
         out = snap.extract_view(PCTS, last - first, first=first) # the names this rank owns, results in place (pinned)
+        k1.record(xs)
         out = {k: v.copy() for k, v in out.items() if k in ("count",)}
         t2 = time.perf_counter()
         if timed:
@@ -545,6 +549,7 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=Non
             t_ing.append(a.elapsed_time(b))
             t_merge.append((t1 - t0) * 1e3)
             t_ext.append((t2 - t1) * 1e3)
+            t_k2.append(k0.elapsed_time(k1))
         return out, (first, last)
 
     def fence():
@@ -663,6 +668,14 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=Non
                           "round trip for the plan totals); host_call_ms: wall time of lh_snapshot_merge returning"},
         "extract_owned_ms": sum(t_ext) / len(t_ext), "parity": parity, "scratch_bytes": c["scratch_bytes"],
     }
+    if info.get("packed_cells") and t_k2:
+        # K2's roofline: every cell of every owned row's window read once (8 B x row_len per metric);
+        # after a reduce-scatter the owned rows' windows are packed_cells / ranks on average
+        owned_cells = info["packed_cells"] / world
+        res["extract_roofline"] = roofline(8.0 * owned_cells, sum(t_k2) / len(t_k2),
+                                           "k_extract_wave over the owned rows (HIP events on the snapshot's stream around "
+                                           "lh_extract_rows_view: the kernel + its result stores into pinned memory)",
+                                           window_cells=owned_cells)
     if plan8:
         res["merge"]["simulated_plan"] = plan8
     if lat_c4:
@@ -735,10 +748,12 @@ def run_c4_1e9(args, la, stream, steps=3, warmup=2):
 # host-fed (PCIe-inclusive) and the C5 burst
 # ---------------------------------------------------------------------------------------------------------
 def run_hostfed(la, M=1024, total=int(8e8)):
-    """Host arrays -> pinned staging buffers -> PCIe -> buckets, from T producer threads.  Three forms of the same
-    stream: lh_submit_pairs (the library copies the caller's batch into a pinned buffer; ids validated on the host),
-    lh_reserve_pairs / lh_commit_pairs (the producer's own store is the only host-side copy), and lh_submit_pairs
-    with LH_OPT_LANE_ZERO_COPY = 0 (round 2's path: hipMemcpyAsync into HBM before the kernel).  value = in place."""
+    """Host arrays -> pinned staging buffers -> PCIe -> buckets, from T producer threads.  Four forms of the same
+    stream: lh_reserve_pairs16 / lh_commit_pairs16 (uint16 ids, 10 B per pair over the link, the producer's own store
+    is the only host-side copy: what the binding uses for <= 65 536 names), lh_reserve_pairs / lh_commit_pairs (the
+    same with uint32 ids, 12 B), lh_submit_pairs (the library copies the caller's batch into a pinned buffer; ids
+    validated on the host), and lh_submit_pairs with LH_OPT_LANE_ZERO_COPY = 0 (round 2's path: hipMemcpyAsync into
+    HBM before the kernel).  value = in place with uint16 ids."""
     import oracle
     from loghisto_amd import _native as N
     cores = effective_cores()
@@ -747,6 +762,7 @@ def run_hostfed(la, M=1024, total=int(8e8)):
     src = rng.lognormal(np.log(1e5), 1.0, 1 << 24)
     w = 1.0 / np.arange(1, M + 1)
     ids = rng.choice(M, size=src.size, p=w / w.sum()).astype(np.uint32)
+    ids16 = ids.astype(np.uint16)
     batch = 1 << 20
     per = total // T
     offs = [(t * 7919 * batch) % (src.size - batch) for t in range(T)]
@@ -761,12 +777,15 @@ def run_hostfed(la, M=1024, total=int(8e8)):
         want += oracle.histogram_pairs_mt(np.concatenate([ids[o:o + rem] for o in offs]),
                                           np.concatenate([src[o:o + rem] for o in offs]), M)
 
+    ids32 = ids
+
     def one(form):
         eng = la.Engine(device=torch.cuda.current_device(), max_metrics=M, num_buffers=2, num_lanes=T,
                         lane_samples=1 << 21)
         if form == "copy_engine":
             eng.set_option(N.OPT_LANE_ZERO_COPY, 0)
-        put = eng.submit_pairs_in_place if form == "in_place" else eng.submit_pairs
+        put = eng.submit_pairs_in_place if form.startswith("in_place") else eng.submit_pairs
+        ids = ids16 if form == "in_place16" else ids32
 
         def work(t):
             done, off = 0, offs[t]
@@ -795,16 +814,19 @@ def run_hostfed(la, M=1024, total=int(8e8)):
         exact = cnt == per * T and bool(np.array_equal(dense_from_csr(off_, keys_, counts_, M), want))
         return per * T / dt, exact
 
-    rates = {form: one(form) for form in ("in_place", "submit_pairs", "copy_engine")}
+    rates = {form: one(form) for form in ("in_place16", "in_place", "submit_pairs", "copy_engine")}
     del want
-    rate = rates["in_place"][0]
+    rate = rates["in_place16"][0]
     return {"value": rate, "unit": "samples/s", "threads": T, "samples": per * T, "names": M,
-            "config": {"workload": "host arrays written into the engine's pinned staging buffers in place "
-                                   "(lh_reserve_pairs / lh_commit_pairs), mixed ingest per half-buffer reading them "
-                                   "over PCIe: the path a cgo binding uses"},
-            "roofline": {"bound": "pcie", "achieved": rate * BYTES_PAIR / 1e9, "peak": PCIE_GBS, "unit": "GB/s",
-                         "frac": rate * BYTES_PAIR / 1e9 / PCIE_GBS, "bytes_per_sample": BYTES_PAIR},
-            "other_forms": {"lh_submit_pairs": {"value": rates["submit_pairs"][0],
+            "config": {"workload": "host arrays written into the engine's pinned staging buffers in place with uint16 ids "
+                                   "(lh_reserve_pairs16 / lh_commit_pairs16: 10 B per pair), mixed ingest per half-buffer "
+                                   "reading them over PCIe: the path a cgo binding uses for <= 65 536 names",
+                       "id_bytes": 2},
+            "roofline": {"bound": "pcie", "achieved": rate * BYTES_PAIR16 / 1e9, "peak": PCIE_GBS, "unit": "GB/s",
+                         "frac": rate * BYTES_PAIR16 / 1e9 / PCIE_GBS, "bytes_per_sample": BYTES_PAIR16},
+            "other_forms": {"lh_reserve_pairs / lh_commit_pairs (uint32 ids, 12 B per pair)": {
+                                "value": rates["in_place"][0], "frac": rates["in_place"][0] * BYTES_PAIR / 1e9 / PCIE_GBS},
+                            "lh_submit_pairs": {"value": rates["submit_pairs"][0],
                                                 "frac": rates["submit_pairs"][0] * BYTES_PAIR / 1e9 / PCIE_GBS},
                             "lh_submit_pairs_through_the_copy_engine": {
                                 "value": rates["copy_engine"][0],
@@ -812,7 +834,7 @@ def run_hostfed(la, M=1024, total=int(8e8)):
             "parity": {"rows_checked": M, "exact": all(r[1] for r in rates.values()),
                        "cells_exact_by_form": {k: r[1] for k, r in rates.items()},
                        "checker": "oracle/ over every submitted pair (slices x repetitions), every cell of every row, "
-                                  "for each of the three forms"}}
+                                  "for each of the four forms"}}
 
 
 def run_c5(seconds=10.0):

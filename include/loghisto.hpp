@@ -215,6 +215,7 @@ private:
     std::mutex percentiles_mu_;
 
     lh_engine *engine_ = nullptr;
+    bool narrow_ids_ = false;      // max_metrics <= 65 536: stages ship uint16 ids (lh_reserve_pairs16)
     std::mutex engine_mu_;
 
     std::atomic<int> wire_format_{0};

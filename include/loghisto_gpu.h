@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define LH_ABI_VERSION 3
+#define LH_ABI_VERSION 4           /* 4: uint16-id pairs (lh_*pairs16*)         */
 #define LH_NKEYS 65536            /* int16 key space (metrics.go:316)        */
 #define LH_NTHRESH 70980          /* extended-key thresholds incl. sentinel  */
 #define LH_MAX_PERCENTILES 32
@@ -133,6 +133,17 @@ int lh_commit_pairs(lh_engine *e, uint32_t token, size_t n);
  * caller-owned stream must outlive the next lh_flip, which records an event on it. */
 int lh_submit_device(lh_engine *e, uint32_t id, const double *d_v, size_t n, void *stream);
 int lh_submit_pairs_device(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t n, void *stream);
+/* The same three ways in with uint16 ids: 10 bytes per pair instead of 12 (SURVEY.md 8d "mixed stream: 12 B/sample ...
+ * 10 B if ids are uint16, legal for <= 65 536 names").  Every mixed-ingest kernel is a template on the id width and
+ * reads the narrow ids directly (two per 4-byte load), so nothing is widened on the way: the host-fed path moves 17 %
+ * fewer bytes over PCIe, the device-resident path reads 17 % fewer from HBM.  Replaces the same Go lines as the
+ * uint32 forms (body of Histogram, /root/reference/metrics.go:273-295); a binding uses them whenever the engine was
+ * created with max_metrics <= 65 536.  A staging buffer holds one id width at a time: a producer that switches width
+ * makes the library launch what the buffer holds first.  lh_commit_pairs16 == lh_commit_pairs (the token knows). */
+int lh_submit_pairs16(lh_engine *e, const uint16_t *ids, const double *v, size_t n);
+int lh_reserve_pairs16(lh_engine *e, size_t want, uint16_t **ids, double **vals, size_t *granted, uint32_t *token);
+int lh_commit_pairs16(lh_engine *e, uint32_t token, size_t n);
+int lh_submit_pairs16_device(lh_engine *e, const uint16_t *d_ids, const double *d_v, size_t n, void *stream);
 /* Counters on the device.  Counter names have their own dense id space.
  *   (*MetricSystem).Counter           /root/reference/metrics.go:251-269  -> lh_intern_counter + lh_submit_counts
  *   collectRawMetrics, counter part   /root/reference/metrics.go:425-458  -> lh_flip (steals the interval's amounts
@@ -361,7 +372,7 @@ int lh_get_counters(lh_engine *e, lh_counters *out);
  *   LH_OPT_PART_V3_MIN_PAIRS  smallest launch that takes it (default 2^24; >= 2^17: tests exercise it on small inputs)
  *   LH_OPT_SURVEY_EVERY       8 193 .. 65 536 names: a call may run on the survey of an earlier call (hot names, region
  *                             sizes, per-partition ranking stay in the scratch block) until this many calls have used
- *                             it (default 8; 1 = every call surveys).  Only while the stream looks the same: a survey
+ *                             it (default 32; 1 = every call surveys).  Only while the stream looks the same: a survey
  *                             is also repeated when the window width changed, when anything else used the block, or
  *                             when more than 2 % of the pairs of the calls completed since took an overflow / window-miss
  *                             path.  A stale survey costs speed, never exactness

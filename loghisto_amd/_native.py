@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblhgpu.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 NKEYS = 65536
 NTHRESH = 70980
 MAX_PERCENTILES = 32
@@ -100,6 +100,11 @@ SIGNATURES = {
     "lh_reserve_pairs": (C.c_int, [_vp, _sz, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                    C.POINTER(C.c_uint32)]),
     "lh_commit_pairs": (C.c_int, [_vp, C.c_uint32, _sz]),
+    "lh_submit_pairs16": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "lh_reserve_pairs16": (C.c_int, [_vp, _sz, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                     C.POINTER(C.c_uint32)]),
+    "lh_commit_pairs16": (C.c_int, [_vp, C.c_uint32, _sz]),
+    "lh_submit_pairs16_device": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
     "lh_submit_device": (C.c_int, [_vp, C.c_uint32, _vp, _sz, _vp]),
     "lh_submit_pairs_device": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
     "lh_intern_counter": (C.c_int, [_vp, C.c_char_p, _sz, _u32p]),

@@ -155,25 +155,9 @@ __device__ __forceinline__ uint32_t lh_bin_fast(double v, bool &uncertain)
     const uint32_t hi = (uint32_t)__double2hiint(x), lo = (uint32_t)__double2loint(x);
     const float m = __uint_as_float(0x3f800000u | ((hi & 0xfffffu) << 3) | (lo >> 29));
     const float l2 = __builtin_amdgcn_logf(m);
-#ifdef LH_BIN_FAST_F32
-    // Variant under measurement: only x = 1 + |v| in float64.  u = e * C + l2 * C + bias in Q14
-    // with e * floor(C) as an exact 24-bit integer multiply-add and the fractions in two float32 fmas (the float32
-    // sum stays below 2^21, its ulp is 1/8 of a Q14 unit: two roundings + the constants' own <= 0.2 of a unit, next to
-    // the 0.26 of v_log_f32 -- inside the guard band of 2).  The constant 2 the guard test adds is folded into the bias.
-    constexpr double C = 69.314718055994530942 * 16384.0;             // 1 135 652.34...
-    constexpr uint32_t C_INT = 1135652u;
-    constexpr float C_FRAC = (float)(C - 1135652.0);
-    constexpr double BIAS = 8192.0 - 1023.0 * C + LH_GUARD_Q14;        // negative: its integer part wraps in uint32
-    constexpr long long BIAS_FLOOR = (long long)BIAS - 1;              // floor of a negative non-integer
-    constexpr uint32_t BIAS_INT = (uint32_t)(BIAS_FLOOR & 0xffffffffll);
-    constexpr float BIAS_FRAC = (float)(BIAS - (double)BIAS_FLOOR);    // in (0, 1)
-    const uint32_t e = hi >> 20;
-    const float t = __builtin_fmaf(l2, (float)C, __builtin_fmaf((float)e, C_FRAC, BIAS_FRAC));
-    const uint32_t w = e * C_INT + BIAS_INT + (uint32_t)t;             // u + LH_GUARD_Q14
-    uncertain = hi >= 0x7ff00000u || ((w & 16383u) < 2u * LH_GUARD_Q14);
-    // (w >> 14 == u >> 14 unless u's fraction is within LH_GUARD_Q14 of the next integer -- then it is uncertain)
-    return bin_from_kext((int)(w >> 14), v);
-#else
+    // (An integer / float32 form of the next three lines -- e * floor(C) as v_mad_u32_u24, the fractions in two float32
+    // fmas -- was measured in round 4: float64 add / fma / converts issue at the same rate as their replacements on
+    // gfx950 and the variant was 3 % slower end to end; profiles/r04_index_arithmetic.txt.)
     // (biased exponent + log2 m) * C + (8192 - 1023 C): the bias folded into the constant.  The sum is exact
     // (an integer below 2 048 plus a float), the constant's rounding (2.4e-7 of a Q14 unit) is far inside the guard.
     constexpr double C = 69.314718055994530942 * 16384.0;
@@ -182,7 +166,6 @@ __device__ __forceinline__ uint32_t lh_bin_fast(double v, bool &uncertain)
     // NaN / Inf (x's exponent field all ones) take the exact path too: lh_bin_of gives them bucket 0
     uncertain = hi >= 0x7ff00000u || ((((uint32_t)u + LH_GUARD_Q14) & 16383u) < 2u * LH_GUARD_Q14);
     return bin_from_kext(u >> 14, v);
-#endif
 }
 
 } // namespace lh

@@ -68,7 +68,8 @@ struct EpochBuffer {
     uint64_t nsamples = 0;        // samples enqueued into this buffer since its last clear (atomic builtins); ~0 = unknown
 };
 
-enum LaneMode { LANE_NONE = 0, LANE_SINGLE = 1, LANE_PAIRS = 2, LANE_COUNTS = 3 };
+// LANE_PAIRS16: (uint16 id, value) pairs -- the id half-buffer holds 2-byte ids (10 B per pair over PCIe instead of 12)
+enum LaneMode { LANE_NONE = 0, LANE_SINGLE = 1, LANE_PAIRS = 2, LANE_COUNTS = 3, LANE_PAIRS16 = 4 };
 
 struct Lane {
     std::mutex mu;
@@ -221,7 +222,7 @@ struct lh_engine {
     // survey stay healthy (region overflows + level-2 overflows + reduce-pass window misses < 2 % of the pairs).
     // The survey only decides WHERE a sample is counted: a stale one costs speed, never exactness.  (scratch_mu)
     bool v3_tables_valid = false;
-    uint32_t v3_tables_log_w = 0, v3_tables_age = 0, survey_every = 8;
+    uint32_t v3_tables_log_w = 0, v3_tables_age = 0, survey_every = 32;
     // Every lh_set_option that feeds a launch plan (LDS budgets, window cells, generation switches) is written under
     // scratch_mu and bumps tune_gen; a call takes ONE snapshot of `tune` (all its sub-launches share the survey's
     // tables, which are laid out for one plan) and tables are reused only by calls that saw the same tune_gen.
@@ -304,7 +305,7 @@ int launch_single(lh_engine *e, uint32_t id, const double *d_v, size_t n, hipStr
     return LH_OK;
 }
 
-int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t n, hipStream_t s)
+int launch_pairs(lh_engine *e, lh::Ids d_ids, const double *d_v, size_t n, hipStream_t s)
 {
     EpochBuffer &b = e->bufs[(size_t)e->cur];
     count_samples(b, n);
@@ -312,12 +313,12 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
     // Slices taken at an odd sample index leave BOTH arrays one element short of the vector-load alignment of
     // the fast kernels (ids 8-byte, values 16-byte): peel that one sample through the direct kernel instead of
     // sending the whole launch down the one-atomic-per-sample path (25x slower).
-    if (n > 1 && ((uintptr_t)d_ids & 7) == 4 && ((uintptr_t)d_v & 15) == 8) {
+    if (n > 1 && ((uintptr_t)d_ids.p & (2u * d_ids.width - 1u)) == d_ids.width && ((uintptr_t)d_v & 15) == 8) {
         HIPCHK(lh::launch_ingest_pairs(d_ids, d_v, 1, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx, e->d_err,
                                        e->num_cus, s));
         e->c_direct.fetch_add(1, std::memory_order_relaxed);
         e->c_launches.fetch_add(1, std::memory_order_relaxed);
-        d_ids++;
+        d_ids = d_ids.plus(1);
         d_v++;
         n--;
     }
@@ -355,7 +356,7 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
             e->small_samples.fetch_add(take, std::memory_order_relaxed);
             e->c_small.fetch_add(take, std::memory_order_relaxed);
             e->c_launches.fetch_add(1, std::memory_order_relaxed);
-            d_ids += take;
+            d_ids = d_ids.plus(take);
             d_v += take;
             n -= take;
             continue;
@@ -474,7 +475,7 @@ int launch_pairs(lh_engine *e, const uint32_t *d_ids, const double *d_v, size_t 
             e->c_direct.fetch_add(take, std::memory_order_relaxed);
         }
         e->c_launches.fetch_add(1, std::memory_order_relaxed);
-        d_ids += take;
+        d_ids = d_ids.plus(take);
         d_v += take;
         n -= take;
     }
@@ -509,6 +510,9 @@ int lane_launch(lh_engine *e, Lane &ln)
     if (ln.mode == LANE_PAIRS) {
         if (!zc) HIPCHK(hipMemcpyAsync(ln.d_ids[h], ln.h_ids[h], n * sizeof(uint32_t), hipMemcpyHostToDevice, ln.stream));
         rc = launch_pairs(e, di, dv, n, ln.stream);
+    } else if (ln.mode == LANE_PAIRS16) {
+        if (!zc) HIPCHK(hipMemcpyAsync(ln.d_ids[h], ln.h_ids[h], n * sizeof(uint16_t), hipMemcpyHostToDevice, ln.stream));
+        rc = launch_pairs(e, reinterpret_cast<const uint16_t *>(di), dv, n, ln.stream);
     } else if (ln.mode == LANE_COUNTS) { // the value half-buffer carries uint64 amounts
         HIPCHK(hipMemcpyAsync(ln.d_ids[h], ln.h_ids[h], n * sizeof(uint32_t), hipMemcpyHostToDevice, ln.stream));
         rc = launch_counts(e, ln.d_ids[h], reinterpret_cast<const uint64_t *>(ln.d_vals[h]), n, ln.stream);
@@ -863,27 +867,32 @@ int lh_submit(lh_engine *e, uint32_t id, const double *v, size_t n)
     return LH_OK;
 }
 
-int lh_submit_pairs(lh_engine *e, const uint32_t *ids, const double *v, size_t n)
+// lh_submit_pairs / lh_submit_pairs16: the caller's batch is copied into the lane's pinned half-buffers
+extern "C++" {
+template <typename IDT>
+static int submit_pairs_t(lh_engine *e, const IDT *ids, const double *v, size_t n)
 {
     if (!e || ((!v || !ids) && n)) return LH_EINVAL;
     if (n == 0) return LH_OK;
-    for (size_t i = 0; i < n; i++)
-        if (ids[i] >= e->cfg.max_metrics) return LH_ERANGE;
+    constexpr LaneMode MODE = sizeof(IDT) == 2 ? LANE_PAIRS16 : LANE_PAIRS;
+    if (sizeof(IDT) == 4 || e->cfg.max_metrics < 65536u)
+        for (size_t i = 0; i < n; i++)
+            if (ids[i] >= e->cfg.max_metrics) return LH_ERANGE;
     int rc = use_device(e);
     if (rc) return rc;
     std::shared_lock<std::shared_mutex> eg(e->epoch_mu);
     Lane &ln = pick_lane(e);
     LaneLock g(ln);
-    if (ln.fill && ln.mode != LANE_PAIRS) {
+    if (ln.fill && ln.mode != MODE) {
         rc = lane_launch(e, ln);
         if (rc) return rc;
     }
     const size_t cap = (size_t)e->cfg.lane_samples;
     while (n) {
-        ln.mode = LANE_PAIRS;
+        ln.mode = MODE;
         const size_t take = (cap - ln.fill) < n ? (cap - ln.fill) : n;
         std::memcpy(ln.h_vals[ln.cur] + ln.fill, v, take * sizeof(double));
-        std::memcpy(ln.h_ids[ln.cur] + ln.fill, ids, take * sizeof(uint32_t));
+        std::memcpy(reinterpret_cast<IDT *>(ln.h_ids[ln.cur]) + ln.fill, ids, take * sizeof(IDT));
         ln.fill += take;
         v += take;
         ids += take;
@@ -896,13 +905,26 @@ int lh_submit_pairs(lh_engine *e, const uint32_t *ids, const double *v, size_t n
     return LH_OK;
 }
 
+} // extern "C++"
+
+int lh_submit_pairs(lh_engine *e, const uint32_t *ids, const double *v, size_t n) { return submit_pairs_t(e, ids, v, n); }
+
+int lh_submit_pairs16(lh_engine *e, const uint16_t *ids, const double *v, size_t n)
+{
+    if (e && e->cfg.max_metrics > 65536u) return LH_ERANGE; // (cannot happen: lh_create bounds max_metrics; kept explicit)
+    return submit_pairs_t(e, ids, v, n);
+}
+
 // In-place staging (SURVEY.md 8b "Ownership": "or the ring is C-allocated (hipHostMalloc) and Go writes into it in
 // place"): the producer gets the free tail of a pinned half-buffer, writes its (id, value) pairs there -- the one
 // and only host-side store of a sample -- and commits how many it wrote.  Between the two calls the lane belongs to
 // the caller: other producers that hash to it and the flush at the flip wait for the commit.
-int lh_reserve_pairs(lh_engine *e, size_t want, uint32_t **ids, double **vals, size_t *granted, uint32_t *token)
+extern "C++" {
+template <typename IDT>
+static int reserve_pairs_t(lh_engine *e, size_t want, IDT **ids, double **vals, size_t *granted, uint32_t *token)
 {
     if (!e || !ids || !vals || !granted || !token || want == 0) return LH_EINVAL;
+    constexpr LaneMode MODE = sizeof(IDT) == 2 ? LANE_PAIRS16 : LANE_PAIRS;
     int rc = use_device(e);
     if (rc) return rc;
     // lock order as everywhere: epoch (shared) before lane.  lh_commit_pairs takes no epoch lock at all, so a flip that
@@ -925,20 +947,32 @@ int lh_reserve_pairs(lh_engine *e, size_t want, uint32_t **ids, double **vals, s
     }
     Lane &ln = *lane;
     const size_t cap = (size_t)e->cfg.lane_samples;
-    if (ln.fill && (ln.mode != LANE_PAIRS || ln.fill == cap)) {
+    if (ln.fill && (ln.mode != MODE || ln.fill == cap)) {
         rc = lane_launch(e, ln);
         if (rc) return rc;
     }
-    ln.mode = LANE_PAIRS;
+    ln.mode = MODE;
     ln.reserved = true;
     ln.granted = cap - ln.fill < want ? cap - ln.fill : want;
-    *ids = ln.h_ids[ln.cur] + ln.fill;
+    *ids = reinterpret_cast<IDT *>(ln.h_ids[ln.cur]) + ln.fill;
     *vals = ln.h_vals[ln.cur] + ln.fill;
     *granted = ln.granted;
     *token = 0;
     for (size_t k = 0; k < nl; k++)
         if (e->lanes[k].get() == lane) *token = (uint32_t)k + 1u;
     return LH_OK;
+}
+
+} // extern "C++"
+
+int lh_reserve_pairs(lh_engine *e, size_t want, uint32_t **ids, double **vals, size_t *granted, uint32_t *token)
+{
+    return reserve_pairs_t(e, want, ids, vals, granted, token);
+}
+
+int lh_reserve_pairs16(lh_engine *e, size_t want, uint16_t **ids, double **vals, size_t *granted, uint32_t *token)
+{
+    return reserve_pairs_t(e, want, ids, vals, granted, token);
 }
 
 int lh_commit_pairs(lh_engine *e, uint32_t token, size_t n)
@@ -962,6 +996,8 @@ int lh_commit_pairs(lh_engine *e, uint32_t token, size_t n)
     return rc;
 }
 
+int lh_commit_pairs16(lh_engine *e, uint32_t token, size_t n) { return lh_commit_pairs(e, token, n); }
+
 int lh_submit_device(lh_engine *e, uint32_t id, const double *d_v, size_t n, void *stream)
 {
     if (!e || (!d_v && n)) return LH_EINVAL;
@@ -981,6 +1017,20 @@ int lh_submit_pairs_device(lh_engine *e, const uint32_t *d_ids, const double *d_
 {
     if (!e || ((!d_v || !d_ids) && n)) return LH_EINVAL;
     if (((uintptr_t)d_v & 7) != 0 || ((uintptr_t)d_ids & 3) != 0) return LH_EINVAL;
+    if (n == 0) return LH_OK;
+    int rc = use_device(e);
+    if (rc) return rc;
+    hipStream_t s = stream ? (hipStream_t)stream : e->main_stream;
+    std::shared_lock<std::shared_mutex> eg(e->epoch_mu);
+    rc = epoch_touch_stream(e, s);
+    if (rc) return rc;
+    return launch_pairs(e, d_ids, d_v, n, s);
+}
+
+int lh_submit_pairs16_device(lh_engine *e, const uint16_t *d_ids, const double *d_v, size_t n, void *stream)
+{
+    if (!e || ((!d_v || !d_ids) && n)) return LH_EINVAL;
+    if (((uintptr_t)d_v & 7) != 0 || ((uintptr_t)d_ids & 1) != 0) return LH_EINVAL;
     if (n == 0) return LH_OK;
     int rc = use_device(e);
     if (rc) return rc;

@@ -18,13 +18,26 @@ struct ExtractOut {          // device mirror of lh_stats, one per metric
     uint32_t present;
 };
 
+// The ids of an (id, value) stream on the device: uint32 (width 4) or uint16 (width 2; at most 65 536 names).
+struct Ids {
+    const void *p = nullptr;
+    uint32_t width = 4;
+    Ids() = default;
+    Ids(const uint32_t *q) : p(q), width(4) {}
+    Ids(const uint16_t *q) : p(q), width(2) {}
+    Ids plus(size_t n) const { Ids r = *this; r.p = static_cast<const char *>(p) + n * width; return r; }
+    bool pair_aligned() const { return ((uintptr_t)p & (2u * width - 1u)) == 0; } // two ids per load
+    const uint32_t *u32() const { return static_cast<const uint32_t *>(p); }
+    const uint16_t *u16() const { return static_cast<const uint16_t *>(p); }
+};
+
 // Table generation (once per engine).
 hipError_t launch_gen_tables(double *d_Tx, double *d_D, hipStream_t s);
 
 // K1: ingest.  counts: [nmetrics][65536] u64; ranges: [nmetrics][2] u32 (lo,hi bin).
 hipError_t launch_ingest_single(const double *d_v, size_t n, uint64_t *row, uint32_t *range,
                                 const double *d_Tx, int num_cus, hipStream_t s);
-hipError_t launch_ingest_pairs(const uint32_t *d_ids, const double *d_v, size_t n, uint64_t *counts,
+hipError_t launch_ingest_pairs(Ids d_ids, const double *d_v, size_t n, uint64_t *counts,
                                uint32_t *ranges, uint32_t nmetrics, const double *d_Tx, uint32_t *d_err,
                                int num_cus, hipStream_t s);
 
@@ -48,14 +61,14 @@ struct PartTuning {
 // Partitioned mixed ingest (lh_kernels_part.hip).  part_scratch_bytes returns 0 when the launch
 // should use the direct kernel instead (small n, one name, or too many names per partition).
 size_t part_scratch_bytes(size_t n, uint32_t nmetrics, int num_cus, const PartTuning &tune);
-bool part_aligned(const uint32_t *d_ids, const double *d_v); // 8-B ids / 16-B values: vector loads
+bool part_aligned(Ids d_ids, const double *d_v); // two ids per load (8 B / 4 B), 16-B values: vector loads
 
 // Few names (<= 32): single streaming pass with every name's window in LDS (lh_kernels_small.hip).
-bool small_supported(size_t n, uint32_t nmetrics, const uint32_t *d_ids, const double *d_v);
-hipError_t launch_ingest_pairs_small(const uint32_t *d_ids, const double *d_v, size_t n, uint64_t *counts,
+bool small_supported(size_t n, uint32_t nmetrics, Ids d_ids, const double *d_v);
+hipError_t launch_ingest_pairs_small(Ids d_ids, const double *d_v, size_t n, uint64_t *counts,
                                      uint32_t *ranges, uint32_t nmetrics, const double *d_Tx, uint32_t *d_err,
                                      int num_cus, hipStream_t s);
-hipError_t launch_ingest_pairs_part(const uint32_t *d_ids, const double *d_v, size_t n, uint64_t *counts,
+hipError_t launch_ingest_pairs_part(Ids d_ids, const double *d_v, size_t n, uint64_t *counts,
                                     uint32_t *ranges, uint32_t nmetrics, const double *d_Tx, uint32_t *d_err,
                                     void *scratch, size_t scratch_bytes, int num_cus, const PartTuning &tune,
                                     hipStream_t s);
@@ -72,7 +85,7 @@ hipError_t launch_count_fold(const uint64_t *cur, const uint32_t *flag, uint64_t
 size_t part2_scratch_bytes(size_t n, uint32_t nmetrics, int num_cus, const PartTuning &tune);
 // survey_n: pairs of [d_ids, d_v) to survey before the scatter (the whole call), 0 = reuse the scratch block's tables
 // region_stat: device-visible counter (pinned host memory) the region kernel adds its overflowed records to, or null
-hipError_t launch_ingest_pairs_part2(const uint32_t *d_ids, const double *d_v, size_t n, size_t survey_n,
+hipError_t launch_ingest_pairs_part2(Ids d_ids, const double *d_v, size_t n, size_t survey_n,
                                      uint64_t *counts, uint32_t *ranges, uint32_t nmetrics, const double *d_Tx,
                                      uint32_t *d_err, void *scratch, size_t scratch_bytes, int num_cus,
                                      const PartTuning &tune, unsigned long long *region_stat, hipStream_t s);
@@ -80,7 +93,7 @@ hipError_t launch_ingest_pairs_part2(const uint32_t *d_ids, const double *d_v, s
 // Third generation (lh_kernels_part3.h): 8 193 .. 65 536 names.  part3_scratch_bytes returns 0 when the launch should
 // take another path.  span_stat: device-visible word (pinned host memory) that receives the survey's window class.
 size_t part3_scratch_bytes(size_t n, uint32_t nmetrics, int num_cus, const PartTuning &tune);
-hipError_t launch_ingest_pairs_part3(const uint32_t *d_ids, const double *d_v, size_t n, size_t survey_n,
+hipError_t launch_ingest_pairs_part3(Ids d_ids, const double *d_v, size_t n, size_t survey_n,
                                      uint64_t *counts, uint32_t *ranges, uint32_t nmetrics, const double *d_Tx,
                                      uint32_t *d_err, void *scratch, size_t scratch_bytes, int num_cus,
                                      const PartTuning &tune, unsigned long long *region_stat, uint32_t *span_stat,

@@ -17,6 +17,7 @@
 // occupied (workgroup, bin) at flush.
 #include "lh_kernels.h"
 #include "lh_codec.h"
+#include "lh_ids.h"
 
 #include <algorithm>
 #include <atomic>
@@ -153,32 +154,9 @@ __global__ __launch_bounds__(K1_BLOCK) void k_ingest_single(const double *__rest
     const size_t nfull = npair / tile;
 
     // (register double buffering -- tile t + grid in flight while tile t is bucketed -- measured slower,
-    // profiles/r02_k1_variants.txt: two workgroups per CU already overlap each other's loads)
-#ifdef LH_K1_ROLL
-    // Rolling refill (variant under measurement): a lane's K1_UNROLL loads stay in flight ALL the time -- as soon as
-    // slot u of tile t has been taken out of its registers, the same registers receive slot u of the workgroup's next
-    // tile; the wait before slot u + 1 is then always vmcnt(K1_UNROLL - 1).  The tile past the end that the last round
-    // requests is the workgroup's own last tile again (loaded, not used).
-    if ((size_t)blockIdx.x < nfull) {
-        d2_t r[K1_UNROLL];
-        {
-            const d2_t *p = vp + (size_t)blockIdx.x * tile + tid;
-#pragma unroll
-            for (int u = 0; u < K1_UNROLL; u++) r[u] = __builtin_nontemporal_load(p + u * K1_BLOCK);
-        }
-        for (size_t t = blockIdx.x; t < nfull; t += gridDim.x) {
-            const size_t tn = t + gridDim.x < nfull ? t + gridDim.x : t;
-            const d2_t *pn = vp + tn * tile + tid;
-#pragma unroll
-            for (int u = 0; u < K1_UNROLL; u++) {
-                const d2_t x = r[u];
-                r[u] = __builtin_nontemporal_load(pn + u * K1_BLOCK);
-                k1_add_fullwave(h, row, range, lh_bin_of(x.x, Tx));
-                k1_add_fullwave(h, row, range, lh_bin_of(x.y, Tx));
-            }
-        }
-    }
-#else
+    // profiles/r02_k1_variants.txt: two workgroups per CU already overlap each other's loads; a rolling refill of the
+    // same eight registers -- slot u reloaded as soon as it has been consumed -- and 1 024-thread workgroups likewise,
+    // profiles/r04_fewvalued.jsonl)
     for (size_t t = blockIdx.x; t < nfull; t += gridDim.x) {
         const d2_t *p = vp + t * tile + tid;
         d2_t r[K1_UNROLL];
@@ -190,7 +168,6 @@ __global__ __launch_bounds__(K1_BLOCK) void k_ingest_single(const double *__rest
             k1_add_fullwave(h, row, range, lh_bin_of(r[u].y, Tx));
         }
     }
-#endif
     // remainder pairs (guarded), owned by the workgroup next in the rotation
     if (blockIdx.x == nfull % gridDim.x) {
         for (size_t i = nfull * tile + tid; i < npair; i += K1_BLOCK) {
@@ -261,7 +238,8 @@ __device__ __forceinline__ void kp_add(uint64_t *__restrict__ counts, uint32_t *
     if (bin > r[1]) atomicMax(&r[1], bin);
 }
 
-__global__ __launch_bounds__(KP_BLOCK) void k_ingest_pairs(const uint32_t *__restrict__ ids,
+template <typename IDT>
+__global__ __launch_bounds__(KP_BLOCK) void k_ingest_pairs(const IDT *__restrict__ ids,
                                                            const double *__restrict__ v, size_t n,
                                                            uint64_t *__restrict__ counts,
                                                            uint32_t *__restrict__ ranges, uint32_t nmetrics,
@@ -273,12 +251,12 @@ __global__ __launch_bounds__(KP_BLOCK) void k_ingest_pairs(const uint32_t *__res
     if (vec) {
         const size_t npair = n / 2;
         const d2_t *vp = reinterpret_cast<const d2_t *>(v);
-        const u2_t *ip = reinterpret_cast<const u2_t *>(ids);
+        const IdStream<IDT> ip(ids);
         for (size_t i = gtid; i < npair; i += gsz) {
             const d2_t r = __builtin_nontemporal_load(vp + i);
-            const u2_t m = __builtin_nontemporal_load(ip + i);
-            kp_add(counts, ranges, nmetrics, err, m.x, r.x, Tx);
-            kp_add(counts, ranges, nmetrics, err, m.y, r.y, Tx);
+            const typename IdStream<IDT>::raw_t m = ip.ld_nt(i);
+            kp_add(counts, ranges, nmetrics, err, IdStream<IDT>::first(m), r.x, Tx);
+            kp_add(counts, ranges, nmetrics, err, IdStream<IDT>::second(m), r.y, Tx);
         }
         if (gtid == 0 && (n & 1)) kp_add(counts, ranges, nmetrics, err, ids[n - 1], v[n - 1], Tx);
     } else {
@@ -286,18 +264,22 @@ __global__ __launch_bounds__(KP_BLOCK) void k_ingest_pairs(const uint32_t *__res
     }
 }
 
-hipError_t launch_ingest_pairs(const uint32_t *d_ids, const double *d_v, size_t n, uint64_t *counts,
+hipError_t launch_ingest_pairs(Ids d_ids, const double *d_v, size_t n, uint64_t *counts,
                                uint32_t *ranges, uint32_t nmetrics, const double *d_Tx, uint32_t *d_err,
                                int num_cus, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
-    const int vec = (((uintptr_t)d_v & 15) == 0 && ((uintptr_t)d_ids & 7) == 0) ? 1 : 0;
+    const int vec = (((uintptr_t)d_v & 15) == 0 && d_ids.pair_aligned()) ? 1 : 0;
     size_t want = (n / 2 + KP_BLOCK - 1) / KP_BLOCK;
     size_t cap = (size_t)num_cus * 8;
     unsigned grid = (unsigned)(want < cap ? want : cap);
     if (grid == 0) grid = 1;
-    hipLaunchKernelGGL(k_ingest_pairs, dim3(grid), dim3(KP_BLOCK), 0, s, d_ids, d_v, n, counts, ranges,
-                       nmetrics, d_Tx, d_err, vec);
+    if (d_ids.width == 2)
+        hipLaunchKernelGGL(k_ingest_pairs<uint16_t>, dim3(grid), dim3(KP_BLOCK), 0, s, d_ids.u16(), d_v, n, counts, ranges,
+                           nmetrics, d_Tx, d_err, vec);
+    else
+        hipLaunchKernelGGL(k_ingest_pairs<uint32_t>, dim3(grid), dim3(KP_BLOCK), 0, s, d_ids.u32(), d_v, n, counts, ranges,
+                           nmetrics, d_Tx, d_err, vec);
     return hipGetLastError();
 }
 
@@ -587,10 +569,18 @@ __global__ __launch_bounds__(K2_BLOCK) void k_extract(const uint64_t *__restrict
 
 // The same, one WAVE per metric (four metrics per workgroup, no workgroup barriers): for thousands of names with
 // narrow spans the block-per-metric form is bound by workgroup dispatch and its six barriers, not by the scan
-// (65 536 names: ~290 us).  Results are BIT-IDENTICAL to k_extract, _sum included: every lane keeps the four
-// partial sums of the four k_extract threads it stands for (tid = lane, lane + 64, lane + 128, lane + 192, each
-// accumulating bins lo + tid, + 256, ... in the same order), reduces each with the same shuffle tree and adds the
-// four wave totals in the same order; counts and the percentile scan are integer arithmetic.
+// (65 536 names: ~290 us).  Results are BIT-IDENTICAL to k_extract, _sum included: the wave forms the partial sums of
+// the 256 k_extract threads it stands for (thread t accumulates bins lo + t, lo + t + 256, ... in that order), reduces
+// them with the same shuffle tree per 64 threads and adds the four wave totals in the same order; counts and the
+// percentile scan are integer arithmetic.
+//
+// Spans of at most EW_REG bins (1 024: every window of the third generation's default width) are read ONCE: the row's
+// cells stay in registers between the count / sum pass and the prefix scan, and the decompress table entries are
+// requested with the cells instead of after them (round 3 read every window twice and took three dependent round
+// trips per name: 139 us for 65 536 names, 0.28 of the HBM roofline).  Layout: lane L holds bins
+// lo + 256 s + 4 L + k (s < 4, k < 4), i.e. the k_extract threads t = 4 L + k.  Wider spans take the two-pass loop.
+constexpr uint32_t EW_STEPS = 4, EW_REG = EW_STEPS * K2_BLOCK;
+
 __global__ __launch_bounds__(K2_BLOCK) void k_extract_wave(const uint64_t *__restrict__ counts,
                                                            const uint32_t *__restrict__ ranges, uint32_t nmetrics,
                                                            const PctArgs pa, uint32_t np,
@@ -610,39 +600,91 @@ __global__ __launch_bounds__(K2_BLOCK) void k_extract_wave(const uint64_t *__res
     if (m >= nmetrics) return; // wave-uniform
     const uint64_t *row = counts + (size_t)m * LH_NKEYS;
     const uint32_t lo = ranges[2 * (size_t)m], hi = ranges[2 * (size_t)m + 1];
+    const bool inreg = lo <= hi && hi - lo < EW_REG; // wave-uniform
 
-    // ---- pass 1 (metrics.go:342-347)
-    uint64_t cnt = 0;
-    double sum4[K2_WAVES] = {0, 0, 0, 0};
-    uint32_t nb = 0;
-    if (lo <= hi) {
-        for (uint32_t base = lo; base <= hi; base += K2_BLOCK) {
+    uint64_t total = 0;
+    double tsum = 0;
+    uint32_t tnb = 0;
+    uint64_t creg[EW_STEPS][K2_PER_THREAD];
+    if (inreg) {
+        // ---- one read of the span: cells and their decompressed values
+        double dreg[EW_STEPS][K2_PER_THREAD];
 #pragma unroll
-            for (int v = 0; v < K2_WAVES; v++) { // virtual thread v * 64 + lane of k_extract
-                const uint32_t b = base + (uint32_t)v * 64 + lane;
-                if (b <= hi) {
-                    const uint64_t c = row[b];
-                    if (c) {
-                        cnt += c;
-                        sum4[v] += D[b] * (double)c;
-                        nb++;
+        for (uint32_t s = 0; s < EW_STEPS; s++) {
+            const uint32_t b0 = lo + s * K2_BLOCK + lane * K2_PER_THREAD;
+#pragma unroll
+            for (int k = 0; k < K2_PER_THREAD; k++) {
+                const bool in = b0 + k <= hi;
+                creg[s][k] = in ? row[b0 + k] : 0;
+                dreg[s][k] = in ? D[b0 + k] : 0.0;
+            }
+        }
+        // pass 1 (metrics.go:342-347) from the registers: psum[k] is k_extract's thread 4 * lane + k
+        uint64_t cnt = 0;
+        uint32_t nb = 0;
+        double psum[K2_PER_THREAD] = {0, 0, 0, 0};
+#pragma unroll
+        for (uint32_t s = 0; s < EW_STEPS; s++)
+#pragma unroll
+            for (int k = 0; k < K2_PER_THREAD; k++) {
+                const uint64_t c = creg[s][k];
+                if (c) {
+                    cnt += c;
+                    psum[k] += dreg[s][k] * (double)c; // value * float64(*count), metrics.go:344
+                    nb++;
+                }
+            }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            cnt += shfl_down_u64(cnt, d);
+            nb += __shfl_down(nb, d, 64);
+        }
+        // k_extract's tree over the 64 threads of each of its four waves (threads 64 w .. 64 w + 63 live in lanes
+        // 16 w .. 16 w + 15): distances 32, 16, 8, 4 threads are 8, 4, 2, 1 lanes; 2 and 1 stay inside the lane
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1)
+#pragma unroll
+            for (int k = 0; k < K2_PER_THREAD; k++) psum[k] += shfl_down_f64(psum[k], d);
+        psum[0] += psum[2];
+        psum[1] += psum[3];
+        psum[0] += psum[1];
+        total = shfl_u64(cnt, 0);
+        tnb = __shfl(nb, 0, 64);
+#pragma unroll
+        for (int w = 0; w < K2_WAVES; w++) tsum += shfl_f64(psum[0], 16 * w); // ((w0 + w1) + w2) + w3, as k_extract
+    } else {
+        // ---- pass 1, wide span: every bin read here and again by the scan below
+        uint64_t cnt = 0;
+        double sum4[K2_WAVES] = {0, 0, 0, 0};
+        uint32_t nb = 0;
+        if (lo <= hi) {
+            for (uint32_t base = lo; base <= hi; base += K2_BLOCK) {
+#pragma unroll
+                for (int v = 0; v < K2_WAVES; v++) { // virtual thread v * 64 + lane of k_extract
+                    const uint32_t b = base + (uint32_t)v * 64 + lane;
+                    if (b <= hi) {
+                        const uint64_t c = row[b];
+                        if (c) {
+                            cnt += c;
+                            sum4[v] += D[b] * (double)c;
+                            nb++;
+                        }
                     }
                 }
             }
         }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            cnt += shfl_down_u64(cnt, d);
+            nb += __shfl_down(nb, d, 64);
+#pragma unroll
+            for (int v = 0; v < K2_WAVES; v++) sum4[v] += shfl_down_f64(sum4[v], d);
+        }
+        total = shfl_u64(cnt, 0);
+#pragma unroll
+        for (int v = 0; v < K2_WAVES; v++) tsum += shfl_f64(sum4[v], 0); // ((w0 + w1) + w2) + w3, as k_extract
+        tnb = __shfl(nb, 0, 64);
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        cnt += shfl_down_u64(cnt, d);
-        nb += __shfl_down(nb, d, 64);
-#pragma unroll
-        for (int v = 0; v < K2_WAVES; v++) sum4[v] += shfl_down_f64(sum4[v], d);
-    }
-    const uint64_t total = shfl_u64(cnt, 0);
-    double tsum = 0;
-#pragma unroll
-    for (int v = 0; v < K2_WAVES; v++) tsum += shfl_f64(sum4[v], 0); // ((w0 + w1) + w2) + w3, as k_extract
-    const uint32_t tnb = __shfl(nb, 0, 64);
     if (lane == 0) {
         ExtractOut o;
         o.count = total;
@@ -660,11 +702,7 @@ __global__ __launch_bounds__(K2_BLOCK) void k_extract_wave(const uint64_t *__res
         const double ftotal = (double)total;
         uint64_t carry = 0;
         uint32_t open = np; // percentiles without a bin yet (wave-uniform)
-        for (uint32_t base = lo; base <= hi && open; base += K2_TILE / K2_WAVES) { // 256 bins per step
-            const uint32_t b0 = base + lane * K2_PER_THREAD;
-            uint64_t c[K2_PER_THREAD];
-#pragma unroll
-            for (int k = 0; k < K2_PER_THREAD; k++) c[k] = (b0 + k <= hi) ? row[b0 + k] : 0;
+        auto scan_step = [&](uint32_t b0, const uint64_t (&c)[K2_PER_THREAD]) {
             uint64_t tsumc = 0;
 #pragma unroll
             for (int k = 0; k < K2_PER_THREAD; k++) tsumc += c[k];
@@ -675,7 +713,7 @@ __global__ __launch_bounds__(K2_BLOCK) void k_extract_wave(const uint64_t *__res
                 if ((int)lane >= d) inc += y;
             }
             uint64_t sofar = carry + (inc - tsumc);
-            double q[K2_PER_THREAD];
+            double q[K2_PER_THREAD]; // float64(sofar)/float64(totalCount), metrics.go:413; -1 for empty buckets
 #pragma unroll
             for (int k = 0; k < K2_PER_THREAD; k++) {
                 sofar += c[k];
@@ -697,6 +735,19 @@ __global__ __launch_bounds__(K2_BLOCK) void k_extract_wave(const uint64_t *__res
                 }
             }
             carry += shfl_u64(inc, 63);
+        };
+        if (inreg) {
+#pragma unroll
+            for (uint32_t s = 0; s < EW_STEPS; s++)
+                if (open && lo + s * K2_BLOCK <= hi) scan_step(lo + s * K2_BLOCK + lane * K2_PER_THREAD, creg[s]); // wave-uniform
+        } else {
+            for (uint32_t base = lo; base <= hi && open; base += K2_TILE / K2_WAVES) { // 256 bins per step
+                const uint32_t b0 = base + lane * K2_PER_THREAD;
+                uint64_t c[K2_PER_THREAD];
+#pragma unroll
+                for (int k = 0; k < K2_PER_THREAD; k++) c[k] = (b0 + k <= hi) ? row[b0 + k] : 0;
+                scan_step(b0, c);
+            }
         }
     }
     if (lane < np) {
@@ -1119,6 +1170,21 @@ __global__ __launch_bounds__(256) void k_clear_spans(uint64_t *__restrict__ coun
     for (uint32_t i = a + threadIdx.x; i <= b && i >= a; i += 256) row[i] = 0;
 }
 
+// Many names with narrow spans: one WAVE per row clears the span and resets the row's range (the block form above
+// launches 8 workgroups per row -- 524 288 of them at 65 536 names, 135 us of dispatch for 0.3 GB of stores -- and
+// needs k_init_ranges behind it).
+__global__ __launch_bounds__(256) void k_clear_rows_wave(uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
+                                                         uint32_t nmetrics)
+{
+    const uint32_t lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= nmetrics) return; // wave-uniform
+    const uint32_t lo = ranges[2 * (size_t)m], hi = ranges[2 * (size_t)m + 1];
+    if (lo > hi) return;       // nothing was counted and the range is already empty
+    uint64_t *row = counts + (size_t)m * LH_NKEYS;
+    for (uint32_t i = lo + lane; i <= hi; i += 64) row[i] = 0;
+    if (lane == 0) { ranges[2 * (size_t)m] = LH_NKEYS; ranges[2 * (size_t)m + 1] = 0; }
+}
+
 __global__ void k_init_ranges(uint32_t *__restrict__ ranges, uint32_t nmetrics)
 {
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1138,6 +1204,10 @@ __global__ void k_mark_dirty(uint32_t *__restrict__ ranges, uint32_t first, uint
 hipError_t launch_clear(uint64_t *counts, uint32_t *ranges, uint32_t nmetrics, hipStream_t s)
 {
     if (nmetrics == 0) return hipSuccess;
+    if (nmetrics >= 2048) {
+        hipLaunchKernelGGL(k_clear_rows_wave, dim3((nmetrics + 3) / 4), dim3(256), 0, s, counts, ranges, nmetrics);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_clear_spans, dim3(nmetrics, K3_SPLIT), dim3(256), 0, s, counts, ranges);
     hipLaunchKernelGGL(k_init_ranges, dim3((nmetrics + 255) / 256), dim3(256), 0, s, ranges, nmetrics);
     return hipGetLastError();

@@ -30,6 +30,7 @@
 // out-of-window records and small launches fall back to direct global atomics.
 #include "lh_kernels.h"
 #include "lh_codec.h"
+#include "lh_ids.h"
 #include "lh_windows.h"
 
 #include <algorithm>
@@ -150,9 +151,9 @@ static bool make_plan(size_t n, uint32_t nmetrics, int num_cus, const PartTuning
     return true;
 }
 
-bool part_aligned(const uint32_t *d_ids, const double *d_v)
+bool part_aligned(Ids d_ids, const double *d_v)
 {
-    return (((uintptr_t)d_v & 15) == 0) && (((uintptr_t)d_ids & 7) == 0);
+    return (((uintptr_t)d_v & 15) == 0) && d_ids.pair_aligned();
 }
 
 size_t part_scratch_bytes(size_t n, uint32_t nmetrics, int num_cus, const PartTuning &tune)
@@ -384,8 +385,8 @@ struct HotLds {
 };
 constexpr size_t HOT_LDS_BYTES = sizeof(HotLds);
 
-template <bool HOT>
-__global__ __launch_bounds__(P1_BLOCK, HOT ? 4 : 6) void k_scatter_samples(const uint32_t *__restrict__ ids,
+template <bool HOT, typename IDT>
+__global__ __launch_bounds__(P1_BLOCK, HOT ? 4 : 6) void k_scatter_samples(const IDT *__restrict__ ids,
                                                                            const double *__restrict__ v, size_t n,
                                                                            uint32_t nmetrics, uint32_t log_np,
                                                                            const double *__restrict__ Tx,
@@ -409,9 +410,10 @@ __global__ __launch_bounds__(P1_BLOCK, HOT ? 4 : 6) void k_scatter_samples(const
     const size_t ntiles = (n + P1_TILE - 1) / P1_TILE;
     const size_t npairs = (n + 1) / 2;
     const pd2_t *vp = reinterpret_cast<const pd2_t *>(v);
-    const pu2_t *ip = reinterpret_cast<const pu2_t *>(ids);
+    typedef IdStream<IDT> IS;
+    const IS ip(ids);
     constexpr int NPAIR = P1_SPT / 2;
-    pu2_t idv[NPAIR];
+    typename IS::raw_t idv[NPAIR];
     pd2_t val[NPAIR];
     // software pipeline: the loads of tile t+1 are issued right after tile t's samples have been
     // consumed, so their latency hides behind tile t's scan / LDS sort / copy-out phases.
@@ -424,10 +426,10 @@ __global__ __launch_bounds__(P1_BLOCK, HOT ? 4 : 6) void k_scatter_samples(const
             if (tile < ntiles && i < npairs) {
                 // the last pair of an odd-length stream reads one element past n inside the same
                 // 16-byte granule; it is masked below
-                idv[j] = __builtin_nontemporal_load(ip + i);
+                idv[j] = ip.ld_nt(i);
                 val[j] = __builtin_nontemporal_load(vp + i);
             } else {
-                idv[j] = (pu2_t){INVALID, INVALID};
+                idv[j] = typename IS::raw_t{}; // (pairs beyond the stream: every use checks the sample's index)
                 val[j] = (pd2_t){0.0, 0.0};
             }
         }
@@ -449,7 +451,7 @@ __global__ __launch_bounds__(P1_BLOCK, HOT ? 4 : 6) void k_scatter_samples(const
 #pragma unroll
         for (int j = 0; j < P1_SPT; j++) {
             const size_t i = 2 * (pbase0 + (size_t)(j >> 1) * P1_BLOCK + tid) + (j & 1);
-            const uint32_t id = (j & 1) ? idv[j >> 1].y : idv[j >> 1].x;
+            const uint32_t id = (j & 1) ? IS::second(idv[j >> 1]) : IS::first(idv[j >> 1]);
             if (i < n && id < nmetrics) {
                 const uint32_t h = exact ? id : (id * 2654435761u) >> 21;
                 const uint32_t old = atomicCAS(&tag[h], 0u, id + 1u);
@@ -501,7 +503,7 @@ __global__ __launch_bounds__(P1_BLOCK, HOT ? 4 : 6) void k_scatter_samples(const
 #pragma unroll
         for (int j = 0; j < P1_SPT; j++) {
             const size_t i = 2 * (pbase0 + (size_t)(j >> 1) * P1_BLOCK + tid) + (j & 1);
-            const uint32_t id = (j & 1) ? idv[j >> 1].y : idv[j >> 1].x;
+            const uint32_t id = (j & 1) ? IS::second(idv[j >> 1]) : IS::first(idv[j >> 1]);
             const double x = (j & 1) ? val[j >> 1].y : val[j >> 1].x;
             if (i < n && id < nmetrics) {
                 const uint32_t e = H.hmap[id & (HOT_MAPW - 1)], hs = e & 0xffu;
@@ -537,11 +539,11 @@ __global__ __launch_bounds__(P1_BLOCK, HOT ? 4 : 6) void k_scatter_samples(const
             constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
             for (int j = 0; j < P1_SPT; j++) {
-                const uint32_t id = (j & 1) ? idv[j >> 1].y : idv[j >> 1].x;
+                const uint32_t id = (j & 1) ? IS::second(idv[j >> 1]) : IS::first(idv[j >> 1]);
                 const double x = (j & 1) ? val[j >> 1].y : val[j >> 1].x;
                 pr[j] = INVALID;
                 rec[j] = 0;
-                bool live = true; // load_tile pads pairs beyond the stream with id 0xffffffff: not an error
+                bool live = true; // (load_tile pads pairs beyond the stream: not an error)
                 if (!FULL) live = 2 * (pbase + (size_t)(j >> 1) * P1_BLOCK + tid) + (j & 1) < n;
                 if (!live) continue;
                 if (id >= nmetrics) {
@@ -1034,7 +1036,7 @@ static hipError_t run_plan(const LevelPtrs &L, uint32_t nchunks, uint32_t nq, ui
     return hipGetLastError();
 }
 
-hipError_t launch_ingest_pairs_part(const uint32_t *d_ids, const double *d_v, size_t n, uint64_t *counts,
+hipError_t launch_ingest_pairs_part(Ids d_ids, const double *d_v, size_t n, uint64_t *counts,
                                     uint32_t *ranges, uint32_t nmetrics, const double *d_Tx, uint32_t *d_err,
                                     void *scratch, size_t scratch_bytes, int num_cus, const PartTuning &tune,
                                     hipStream_t s)
@@ -1053,7 +1055,10 @@ hipError_t launch_ingest_pairs_part(const uint32_t *d_ids, const double *d_v, si
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_plan_scatter),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NQMAX * sizeof(uint32_t)));
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_samples<true>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_samples<true, uint32_t>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)HOT_LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_samples<true, uint16_t>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)HOT_LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -1074,12 +1079,16 @@ hipError_t launch_ingest_pairs_part(const uint32_t *d_ids, const double *d_v, si
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(L1.pc, 0, small_words(P.np, P.extra1) * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
-    if (P.hot)
-        hipLaunchKernelGGL(k_scatter_samples<true>, dim3(P.g1), dim3(P1_BLOCK), HOT_LDS_BYTES, s, d_ids, d_v, n, nmetrics,
-                           P.log_np, d_Tx, L1.records, L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, dbg);
-    else
-        hipLaunchKernelGGL(k_scatter_samples<false>, dim3(P.g1), dim3(P1_BLOCK), 0, s, d_ids, d_v, n, nmetrics,
-                           P.log_np, d_Tx, L1.records, L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, dbg);
+    auto scatter = [&](auto idp) { // idp: the ids as const uint32_t * or const uint16_t *
+        typedef std::remove_cv_t<std::remove_pointer_t<decltype(idp)>> IDT;
+        if (P.hot)
+            hipLaunchKernelGGL((k_scatter_samples<true, IDT>), dim3(P.g1), dim3(P1_BLOCK), HOT_LDS_BYTES, s, idp, d_v, n,
+                               nmetrics, P.log_np, d_Tx, L1.records, L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, dbg);
+        else
+            hipLaunchKernelGGL((k_scatter_samples<false, IDT>), dim3(P.g1), dim3(P1_BLOCK), 0, s, idp, d_v, n, nmetrics,
+                               P.log_np, d_Tx, L1.records, L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, dbg);
+    };
+    if (d_ids.width == 2) scatter(d_ids.u16()); else scatter(d_ids.u32());
     e = run_plan(L1, P.nchunks1, P.np, P.log_ns ? P.ns + 1 : 0u, P.extra1, s);
     if (e != hipSuccess) return e;
 

@@ -78,7 +78,8 @@ struct NameEntry { uint32_t org; uint32_t hot; };
 // Survey
 // ---------------------------------------------------------------------------
 // g_stat layout (zero-initialised): cnt[M] u32 | mninv[M] u32 (max of 65535 - bin) | mx[M] u32 | sum[M] u64
-__global__ __launch_bounds__(V2_BLOCK) void k_survey_count(const uint32_t *__restrict__ ids,
+template <typename IDT>
+__global__ __launch_bounds__(V2_BLOCK) void k_survey_count(const IDT *__restrict__ ids,
                                                            const double *__restrict__ v, size_t n,
                                                            uint32_t nmetrics, const double *__restrict__ Tx,
                                                            uint32_t *__restrict__ g_cnt,
@@ -96,16 +97,17 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_count(const uint32_t *__res
     const size_t npairs = n / 2; // an odd last sample is not surveyed
     const size_t stride = npairs / gridDim.x;
     const pd2_t *vp = reinterpret_cast<const pd2_t *>(v);
-    const pu2_t *ip = reinterpret_cast<const pu2_t *>(ids);
+    typedef IdStream<IDT> IS;
+    const IS ip(ids);
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const size_t i = (size_t)blockIdx.x * stride + (size_t)j * V2_BLOCK + tid;
         if (i < npairs && (size_t)j * V2_BLOCK + tid < (stride ? stride : npairs)) {
-            const pu2_t id2 = ip[i];
+            const typename IS::raw_t id2 = ip.ld(i);
             const pd2_t x2 = vp[i];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                const uint32_t id = h ? id2.y : id2.x;
+                const uint32_t id = h ? IS::second(id2) : IS::first(id2);
                 if (id < nmetrics) {
                     const uint32_t bin = lh_bin_of(h ? x2.y : x2.x, Tx);
                     atomicAdd(&s_cnt[id], 1u);
@@ -295,8 +297,8 @@ __device__ __forceinline__ void hidden_store_u32(void *p, uint32_t v)
     asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v) : "memory");
 }
 
-template <int BLOCK, int NPT>
-__global__ __launch_bounds__(BLOCK, 4) void k_scatter2(const uint32_t *__restrict__ ids,
+template <int BLOCK, int NPT, typename IDT>
+__global__ __launch_bounds__(BLOCK, 4) void k_scatter2(const IDT *__restrict__ ids,
                                                        const double *__restrict__ v, size_t n, uint32_t nmetrics,
                                                        uint32_t log_np, uint32_t log_w,
                                                        const double *__restrict__ Tx,
@@ -344,7 +346,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter2(const uint32_t *__restric
     const size_t ntiles = (n + V2_TILE - 1) / V2_TILE;
     const size_t npairs = (n + 1) / 2;
     const pd2_t *vp = reinterpret_cast<const pd2_t *>(v);
-    const pu2_t *ip = reinterpret_cast<const pu2_t *>(ids);
+    typedef IdStream<IDT> IS;
+    const IS ip(ids);
     constexpr int NPAIR = V2_SPT / 2;
     // Two register sets, used by alternate tiles.  A set's loads are issued right after barrier A of the tile that
     // last used it, a whole tile period before they are needed, so HBM always has ~96 KiB per CU in flight while
@@ -358,9 +361,9 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter2(const uint32_t *__restric
     // counter bookkeeping is safe: vmcnt retires in order and operations the compiler does not know about only
     // make its waits stricter.  (Hiding the LOADS instead is not safe: the register allocator may copy a
     // destination register before the data has landed.)
-    pu2_t ida[NPAIR], idb[NPAIR];
+    typename IS::raw_t ida[NPAIR], idb[NPAIR];
     pd2_t vaa[NPAIR], vab[NPAIR];
-    auto load_tile = [&](size_t tile, pu2_t (&di)[NPAIR], pd2_t (&dv)[NPAIR]) {
+    auto load_tile = [&](size_t tile, typename IS::raw_t (&di)[NPAIR], pd2_t (&dv)[NPAIR]) {
         const size_t pbase = tile * (V2_TILE / 2);
 #pragma unroll
         for (int j = 0; j < NPAIR; j++) {
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter2(const uint32_t *__restric
             // the same 16-byte granule; it is masked too.
             size_t i = pbase + (size_t)j * V2_BLOCK + tid;
             i = i < npairs ? i : npairs - 1;
-            di[j] = __builtin_nontemporal_load(ip + i);
+            di[j] = ip.ld_nt(i);
             dv[j] = __builtin_nontemporal_load(vp + i);
         }
     };
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter2(const uint32_t *__restric
     // registers receive the loads of the tile two steps ahead.  The loop below alternates between the two register
     // sets, so no value ever has to be copied from one set to the other -- a copy would have to wait for loads that
     // were issued moments ago.
-    auto process_tile = [&](size_t tile, pu2_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
+    auto process_tile = [&](size_t tile, typename IS::raw_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
         // samples of this tile that exist (every tile but the last is full)
         const uint32_t lim = (tile + 1) * (size_t)V2_TILE <= n ? (uint32_t)V2_TILE : (uint32_t)(n - tile * (size_t)V2_TILE);
         uint32_t pr[V2_SPT];  // partition | rank << 8, INVALID when the sample left no record
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter2(const uint32_t *__restric
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int j = h + k;
-                const uint32_t raw = (j & 1) ? idv[j >> 1].y : idv[j >> 1].x;
+                const uint32_t raw = (j & 1) ? IS::second(idv[j >> 1]) : IS::first(idv[j >> 1]);
                 // padding beyond the stream is not an error; an id >= nmetrics is (reported, sample skipped)
                 const bool live = 2u * ((uint32_t)(j >> 1) * V2_BLOCK + tid) + (uint32_t)(j & 1) < lim;
                 const bool ok = live && raw < nmetrics;
@@ -735,8 +738,8 @@ __global__ __launch_bounds__(256) void k_survey_parts(const uint32_t *__restrict
     }
 }
 
-template <int BLOCK, int NPT, int BATCH>
-__global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const uint32_t *__restrict__ ids,
+template <int BLOCK, int NPT, int BATCH, typename IDT>
+__global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ ids,
                                                        const double *__restrict__ v, size_t ntiles, uint32_t nmetrics,
                                                        uint32_t log_np, uint32_t log_w,
                                                        const double *__restrict__ Tx,
@@ -789,20 +792,21 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const uint32_t *__restric
     const pu2_t my_pt = L.pt[tid >> 2]; // the flush phase's partition (constant over the launch)
 
     const pd2_t *vp = reinterpret_cast<const pd2_t *>(v);
-    const pu2_t *ip = reinterpret_cast<const pu2_t *>(ids);
+    typedef IdStream<IDT> IS;
+    const IS ip(ids);
     constexpr int NPAIR = V2_SPT / 2;
     // two register sets used by alternate tiles, loads issued a whole tile period ahead, stores hidden from the
     // compiler's s_waitcnt bookkeeping: see k_scatter2
-    pu2_t ida[NPAIR], idb[NPAIR];
+    typename IS::raw_t ida[NPAIR], idb[NPAIR];
     pd2_t vaa[NPAIR], vab[NPAIR];
-    auto load_tile = [&](size_t tile, pu2_t (&di)[NPAIR], pd2_t (&dv)[NPAIR]) {
+    auto load_tile = [&](size_t tile, typename IS::raw_t (&di)[NPAIR], pd2_t (&dv)[NPAIR]) {
         if (tile >= ntiles) tile = ntiles - 1; // the two tiles past the end that the pipeline touches (uniform)
         if (dbg & 512u) tile = blockIdx.x;     // ablation: every load hits L2 (the workgroup re-reads its first tile)
-        const pu2_t *it = ip + tile * (V3_TILE / 2) + tid;
+        const size_t it = tile * (V3_TILE / 2) + tid;
         const pd2_t *vt = vp + tile * (V3_TILE / 2) + tid;
 #pragma unroll
         for (int j = 0; j < NPAIR; j++) {
-            di[j] = __builtin_nontemporal_load(it + j * BLOCK);
+            di[j] = ip.ld_nt(it + (size_t)j * BLOCK);
             dv[j] = __builtin_nontemporal_load(vt + j * BLOCK);
         }
     };
@@ -812,7 +816,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const uint32_t *__restric
     static_assert(NPAIR == 4, "the asm above names four register pairs");
     load_tile((size_t)blockIdx.x + gridDim.x, idb, vab);
 
-    auto classify = [&](pu2_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
+    auto classify = [&](typename IS::raw_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
         uint32_t rare = 0;
         // ---- phase 1: classify and place.  Straight-line code, four samples at a time: their table reads, then
         // their LDS atomics, then their record stores are in flight together.
@@ -825,7 +829,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const uint32_t *__restric
 #pragma unroll
             for (int k = 0; k < BATCH; k++) {
                 const int j = h + k;
-                const uint32_t raw = (j & 1) ? idv[j >> 1].y : idv[j >> 1].x;
+                const uint32_t raw = (j & 1) ? IS::second(idv[j >> 1]) : IS::first(idv[j >> 1]);
                 const bool ok = raw < nmetrics; // an id >= nmetrics is reported, the sample skipped
                 rare |= ok ? 0u : 1u;
                 id[k] = ok ? raw : INVALID;
@@ -1240,10 +1244,11 @@ size_t part2_scratch_bytes(size_t n, uint32_t nmetrics, int num_cus, const PartT
 
 // survey_n > 0: first sub-launch of a call -- survey pairs [0, survey_n) of the same arrays (the whole call) before
 // the scatter; survey_n == 0: a later sub-launch, the tables of the first one are still in the scratch block.
-hipError_t launch_ingest_pairs_part2(const uint32_t *d_ids, const double *d_v, size_t n, size_t survey_n,
-                                     uint64_t *counts, uint32_t *ranges, uint32_t nmetrics, const double *d_Tx,
-                                     uint32_t *d_err, void *scratch, size_t scratch_bytes, int num_cus,
-                                     const PartTuning &tune, unsigned long long *region_stat, hipStream_t s)
+template <typename IDT>
+static hipError_t launch_part2_t(const IDT *d_ids, const double *d_v, size_t n, size_t survey_n,
+                                 uint64_t *counts, uint32_t *ranges, uint32_t nmetrics, const double *d_Tx,
+                                 uint32_t *d_err, void *scratch, size_t scratch_bytes, int num_cus,
+                                 const PartTuning &tune, unsigned long long *region_stat, hipStream_t s)
 {
     Part2Plan P;
     if (!make_plan2(n, nmetrics, num_cus, tune, P) || scratch_bytes < P.total || !scratch) return hipErrorInvalidValue;
@@ -1255,19 +1260,19 @@ hipError_t launch_ingest_pairs_part2(const uint32_t *d_ids, const double *d_v, s
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_part_hist2),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)P2V2_LDS_BYTES);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter2<1024, 256>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter2<1024, 256, IDT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)V2_LDS_TOTAL);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter2<512, 128>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter2<512, 128, IDT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(V2_LDS_TOTAL / 2));
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter3<1024, 256, SC3_BATCH>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter3<1024, 256, SC3_BATCH, IDT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)V2_LDS_TOTAL);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter3<512, 128, SC3_BATCH>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter3<512, 128, SC3_BATCH, IDT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(V2_LDS_TOTAL / 2));
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_survey_count),
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_survey_count<IDT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(V2_MAX_NAMES * 16));
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_plan_count),
@@ -1303,7 +1308,7 @@ hipError_t launch_ingest_pairs_part2(const uint32_t *d_ids, const double *d_v, s
         if (e != hipSuccess) return e;
         const size_t sv_tiles = (survey_n / 2 + 2047) / 2048;
         const unsigned sv_grid = (unsigned)std::min<size_t>(SV_GRID, std::max<size_t>(1, sv_tiles));
-        hipLaunchKernelGGL(k_survey_count, dim3(sv_grid), dim3(V2_BLOCK), sv_dyn, s, d_ids, d_v, survey_n, nmetrics,
+        hipLaunchKernelGGL(k_survey_count<IDT>, dim3(sv_grid), dim3(V2_BLOCK), sv_dyn, s, d_ids, d_v, survey_n, nmetrics,
                            d_Tx, g_cnt, g_mninv, g_mx, g_sum);
         hipLaunchKernelGGL(k_survey_plan, dim3(1), dim3(V2_BLOCK), 0, s, g_cnt, g_mninv, g_mx, g_sum, nmetrics,
                            P.log_w, P.cells, g_nt, g_hs, g_hdr);
@@ -1314,11 +1319,11 @@ hipError_t launch_ingest_pairs_part2(const uint32_t *d_ids, const double *d_v, s
     if (P.shape & 2u) { // whole tiles through the region kernel, the last n % tile pairs through the plain kernel
         const size_t nt_full = n / P.tile, done = nt_full * P.tile;
         if (P.shape == 3)
-            hipLaunchKernelGGL((k_scatter3<512, 128, SC3_BATCH>), dim3(P.g1), dim3(512), p1_dyn, s, d_ids, d_v, nt_full, nmetrics,
+            hipLaunchKernelGGL((k_scatter3<512, 128, SC3_BATCH, IDT>), dim3(P.g1), dim3(512), p1_dyn, s, d_ids, d_v, nt_full, nmetrics,
                                P.log_np, P.log_w, d_Tx, g_nt, g_hs, g_hdr, g_pt, P.region_recs, P.cells, records,
                                L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, region_stat, dbg);
         else
-            hipLaunchKernelGGL((k_scatter3<1024, 256, SC3_BATCH>), dim3(P.g1), dim3(1024), p1_dyn, s, d_ids, d_v, nt_full,
+            hipLaunchKernelGGL((k_scatter3<1024, 256, SC3_BATCH, IDT>), dim3(P.g1), dim3(1024), p1_dyn, s, d_ids, d_v, nt_full,
                                nmetrics, P.log_np, P.log_w, d_Tx, g_nt, g_hs, g_hdr, g_pt, P.region_recs, P.cells,
                                records, L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, region_stat, dbg);
         if (done < n) {
@@ -1327,11 +1332,11 @@ hipError_t launch_ingest_pairs_part2(const uint32_t *d_ids, const double *d_v, s
         }
     }
     else if (P.shape == 1)
-        hipLaunchKernelGGL((k_scatter2<512, 128>), dim3(P.g1), dim3(512), p1_dyn, s, d_ids, d_v, n, nmetrics, P.log_np,
+        hipLaunchKernelGGL((k_scatter2<512, 128, IDT>), dim3(P.g1), dim3(512), p1_dyn, s, d_ids, d_v, n, nmetrics, P.log_np,
                            P.log_w, d_Tx, g_nt, g_hs, g_hdr, P.cells, records, L1.cdesc, P.chunks_per_wg, counts,
                            ranges, d_err, dbg);
     else
-        hipLaunchKernelGGL((k_scatter2<1024, 256>), dim3(P.g1), dim3(1024), p1_dyn, s, d_ids, d_v, n, nmetrics,
+        hipLaunchKernelGGL((k_scatter2<1024, 256, IDT>), dim3(P.g1), dim3(1024), p1_dyn, s, d_ids, d_v, n, nmetrics,
                            P.log_np, P.log_w, d_Tx, g_nt, g_hs, g_hdr, P.cells, records, L1.cdesc, P.chunks_per_wg,
                            counts, ranges, d_err, dbg);
     e = run_plan(L1, P.nchunks, P.np, 0u, P2V2_SLOT_EXTRA, s);
@@ -1341,4 +1346,15 @@ hipError_t launch_ingest_pairs_part2(const uint32_t *d_ids, const double *d_v, s
                            L1.sorted, L1.part_start, L1.slots, L1.nslots, P.log_np, P.mpp, P.log_w, nmetrics, g_nt,
                            counts, ranges);
     return hipGetLastError();
+}
+
+hipError_t launch_ingest_pairs_part2(Ids d_ids, const double *d_v, size_t n, size_t survey_n,
+                                     uint64_t *counts, uint32_t *ranges, uint32_t nmetrics, const double *d_Tx,
+                                     uint32_t *d_err, void *scratch, size_t scratch_bytes, int num_cus,
+                                     const PartTuning &tune, unsigned long long *region_stat, hipStream_t s)
+{
+    return d_ids.width == 2 ? launch_part2_t(d_ids.u16(), d_v, n, survey_n, counts, ranges, nmetrics, d_Tx, d_err, scratch,
+                                             scratch_bytes, num_cus, tune, region_stat, s)
+                            : launch_part2_t(d_ids.u32(), d_v, n, survey_n, counts, ranges, nmetrics, d_Tx, d_err, scratch,
+                                             scratch_bytes, num_cus, tune, region_stat, s);
 }

@@ -42,6 +42,14 @@ constexpr uint32_t V3_LOG_NP = 8, V3_NP = 256;          // level-1 partitions: i
 constexpr uint32_t V3_HN = 1024;                        // hot-name hash entries (8 B each)
 constexpr uint32_t V3_TILE = 8192;                      // samples per level-1 tile
 constexpr uint32_t LINE4 = 16;                          // 4-byte records per 64-byte line
+#ifndef LH_V3_PIECE
+#define LH_V3_PIECE 2
+#endif
+// Level 1 copies whole PIECES of V3_PIECE consecutive lines out of a partition's region (128 bytes at 2): what the
+// scattered record writes cost the memory system next to the 12 GB streaming read falls with their size
+// (profiles/r03_level1_experiments.txt: 64 -> 128 bytes, -8 % of the kernel); up to V3_PIECE * 16 - 1 records stay
+// behind in the region, so every capacity grows by 16 records per extra line.
+constexpr uint32_t V3_PIECE = LH_V3_PIECE, PIECE4 = V3_PIECE * LINE4;
 constexpr uint32_t V3_MISSQ = 512;                      // records a tile can queue for the exact path (per parity)
 constexpr size_t V3_MIN_SAMPLES = size_t(1) << 24;
 constexpr uint32_t SVH_GRID = 256, SVH_SLOTS = 4096;    // hashed survey: 256 workgroups x 2 048 samples
@@ -73,7 +81,8 @@ __device__ __forceinline__ uint32_t sv_mean(const SurveyStat &S, uint32_t m)
 // ---------------------------------------------------------------------------
 // LDS hash table: key[SVH_SLOTS] (id + 1, 0 = free) | cnt | sum | mninv | mx.  A workgroup inserts <= 2 048 samples
 // into 4 096 slots, so linear probing always terminates.
-__global__ __launch_bounds__(1024) void k_survey_count_h(const uint32_t *__restrict__ ids, const double *__restrict__ v,
+template <typename IDT>
+__global__ __launch_bounds__(1024) void k_survey_count_h(const IDT *__restrict__ ids, const double *__restrict__ v,
                                                          size_t n, uint32_t nmetrics, const double *__restrict__ Tx,
                                                          unsigned long long *__restrict__ g_cs,
                                                          uint32_t *__restrict__ g_mninv, uint32_t *__restrict__ g_mx)
@@ -89,11 +98,12 @@ __global__ __launch_bounds__(1024) void k_survey_count_h(const uint32_t *__restr
     const size_t stride = npairs / gridDim.x;
     const size_t i = (size_t)blockIdx.x * stride + tid;
     if (i < npairs && tid < (stride ? stride : npairs)) {
-        const pu2_t id2 = reinterpret_cast<const pu2_t *>(ids)[i];
+        typedef IdStream<IDT> IS;
+        const typename IS::raw_t id2 = IS(ids).ld(i);
         const pd2_t x2 = reinterpret_cast<const pd2_t *>(v)[i];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const uint32_t id = h ? id2.y : id2.x;
+            const uint32_t id = h ? IS::second(id2) : IS::first(id2);
             if (id < nmetrics) {
                 const uint32_t bin = lh_bin_of(h ? x2.y : x2.x, Tx);
                 uint32_t s = (id * 2654435761u) >> 20;
@@ -225,13 +235,13 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan_h(const SurveyStat S,
         g_hs[slot] = (pu4_t){name, o | (want << 16), cellpos, 0u};
     }
     g_hk[tid] = e;
-    // level-1 regions: 1.5 x the partition's expected records per tile + 24 (leftover < 16 and some air), the
+    // level-1 regions: 1.5 x the partition's expected records per tile + 8 + one piece (the leftover), the
     // names' TOTAL counts (hot samples included: a mispredicted hot window must not overflow a region)
     uint32_t cap = 0;
     if (tid < V3_NP) {
         const uint32_t est = total_cnt ? (uint32_t)(((unsigned long long)pc * tile) / total_cnt) : tile / V3_NP;
-        cap = (est * 6u / 4u + 24u + 3u) & ~3u;
-        if (cap > tile + 16u) cap = tile + 16u;
+        cap = (est * 6u / 4u + 8u + PIECE4 + 3u) & ~3u; // (the leftover is < PIECE4)
+        if (cap > tile + PIECE4) cap = tile + PIECE4;
         s_cap[tid] = cap;
     }
     __syncthreads();
@@ -363,10 +373,10 @@ struct Scatter4Lds {
 };
 static_assert(sizeof(Scatter4Lds) % 16 == 0, "the regions follow the struct in LDS");
 // upper bound of the sum of the level-1 region capacities (k_survey_plan_h)
-constexpr uint32_t v3_region_words(uint32_t tile) { return 6u * tile / 4u + 28u * V3_NP; }
+constexpr uint32_t v3_region_words(uint32_t tile) { return 6u * tile / 4u + (12u + PIECE4) * V3_NP; }
 
-template <int BATCH>
-__global__ __launch_bounds__(1024, 4) void k_scatter4(const uint32_t *__restrict__ ids, const double *__restrict__ v,
+template <int BATCH, typename IDT>
+__global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ ids, const double *__restrict__ v,
                                                       size_t ntiles, uint32_t nmetrics, const double *__restrict__ Tx,
                                                       const pu2_t *__restrict__ g_hk, const pu4_t *__restrict__ g_hs,
                                                       const uint32_t *__restrict__ g_hdr,
@@ -411,19 +421,20 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const uint32_t *__restrict
     uint32_t nrec = 0;                  // records this thread's partition emitted (q == 0 counts)
 
     const pd2_t *vp = reinterpret_cast<const pd2_t *>(v);
-    const pu2_t *ip = reinterpret_cast<const pu2_t *>(ids);
+    typedef IdStream<IDT> IS;
+    const IS ip(ids);
     constexpr int NPAIR = V2_SPT / 2;
     // two register sets used by alternate tiles, loads issued a whole tile period ahead, the loop's global stores
     // hidden from the compiler's s_waitcnt bookkeeping: see k_scatter2 in lh_kernels_part2.h
-    pu2_t ida[NPAIR], idb[NPAIR];
+    typename IS::raw_t ida[NPAIR], idb[NPAIR];
     pd2_t vaa[NPAIR], vab[NPAIR];
-    auto load_tile = [&](size_t tile, pu2_t (&di)[NPAIR], pd2_t (&dv)[NPAIR]) {
+    auto load_tile = [&](size_t tile, typename IS::raw_t (&di)[NPAIR], pd2_t (&dv)[NPAIR]) {
         if (tile >= ntiles) tile = ntiles - 1; // the two tiles past the end that the pipeline touches (uniform)
-        const pu2_t *it = ip + tile * (V3_TILE / 2) + tid;
+        const size_t it = tile * (V3_TILE / 2) + tid;
         const pd2_t *vt = vp + tile * (V3_TILE / 2) + tid;
 #pragma unroll
         for (int j = 0; j < NPAIR; j++) {
-            di[j] = __builtin_nontemporal_load(it + j * BLOCK);
+            di[j] = ip.ld_nt(it + (size_t)j * BLOCK);
             dv[j] = __builtin_nontemporal_load(vt + j * BLOCK);
         }
     };
@@ -433,7 +444,7 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const uint32_t *__restrict
     static_assert(NPAIR == 4, "the asm above names four register pairs");
     load_tile((size_t)blockIdx.x + gridDim.x, idb, vab);
 
-    auto classify = [&](pu2_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
+    auto classify = [&](typename IS::raw_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
         uint32_t rare = 0;
         // ---- phase 1: classify and place.  Straight-line code, BATCH samples at a time: their table reads, then
         // their LDS atomics, then their record stores are in flight together.
@@ -445,7 +456,7 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const uint32_t *__restrict
 #pragma unroll
             for (int k = 0; k < BATCH; k++) {
                 const int j = h + k;
-                const uint32_t raw = (j & 1) ? idv[j >> 1].y : idv[j >> 1].x;
+                const uint32_t raw = (j & 1) ? IS::second(idv[j >> 1]) : IS::first(idv[j >> 1]);
                 const bool ok = raw < nmetrics; // an id >= nmetrics is reported, the sample skipped
                 rare |= ok ? 0u : 1u;
                 id[k] = ok ? raw : INVALID;
@@ -512,10 +523,11 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const uint32_t *__restrict
             asm volatile("" : "+v"(t2)); // keeps this phase's address arithmetic inside the loop (see k_scatter2)
             const uint32_t p = t2 >> 2, q = t2 & 3u;
             const pu2_t e = my_pt;
-            const uint32_t c = min(L.cnt[p], e.y), full = c / LINE4, left = c % LINE4;
+            // whole pieces only: `full` lines leave (a multiple of V3_PIECE), up to PIECE4 - 1 records stay behind
+            const uint32_t c = min(L.cnt[p], e.y), full = c / PIECE4 * V3_PIECE, left = c - full * LINE4;
             if (full) {
                 const uint32_t cf = L.cfill[p], cb = L.cbase[p];
-                const uint32_t room = (CHUNK - cf) / LINE4; // lines left in the open chunk (0: none open)
+                const uint32_t room = (CHUNK - cf) / LINE4; // lines left in the open chunk (0: none open; whole pieces)
                 uint32_t first = 0;
                 if (full > room && q == 0) {
                     const uint32_t tag = p << CD_SHIFT;
@@ -539,10 +551,13 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const uint32_t *__restrict
                     const pu4_t r4 = *reinterpret_cast<const pu4_t *>(src + l * LINE4 + q * 4);
                     hidden_store_u4(records + dst + q * 4, r4);
                 }
-                // the last partial line moves to the front of the region (its slots are this thread's own)
-                if (q * 4 < left)
-                    *reinterpret_cast<pu4_t *>(lds32 + e.x + q * 4) =
-                        *reinterpret_cast<const pu4_t *>(src + full * LINE4 + q * 4);
+                // the leftover (less than a piece) moves to the front of the region: thread q moves 16-byte pieces q,
+                // q + 4, .. -- source and destination are at least one piece apart, every slot is read by its writer
+#pragma unroll
+                for (uint32_t j = 0; j < V3_PIECE; j++)
+                    if (j * LINE4 + q * 4 < left)
+                        *reinterpret_cast<pu4_t *>(lds32 + e.x + j * LINE4 + q * 4) =
+                            *reinterpret_cast<const pu4_t *>(src + (full + j) * LINE4 + q * 4);
             }
             if (q == 0) { L.cnt[p] = left; nrec += full * LINE4; }
         }
@@ -573,10 +588,10 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const uint32_t *__restrict
     // ---- drain: the regions' leftovers (< one line each) and the open chunks' descriptors
     {
         const uint32_t p = tid >> 2, q = tid & 3u;
-        const uint32_t left = L.cnt[p]; // < LINE4 after a flush
+        const uint32_t left = L.cnt[p]; // < PIECE4 after a flush
         uint32_t d = INVALID;
         if (left && q == 0) {
-            uint32_t cf = L.cfill[p], cb = L.cbase[p];
+            uint32_t cf = L.cfill[p], cb = L.cbase[p]; // (cf is a multiple of PIECE4: the leftover fits the open chunk)
             if (cf == CHUNK) { // no open chunk, or it is exactly full
                 if (cb != INVALID) cdesc[cb] = (p << CD_SHIFT) | CHUNK;
                 cb = pool_base + atomicAdd(&L.pool_next, 1u);
@@ -588,8 +603,11 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const uint32_t *__restrict
             nrec += left;
         }
         d = __builtin_amdgcn_mov_dpp(d, 0x00, 0xf, 0xf, false);
-        if (left && q * 4 < left)
-            *reinterpret_cast<pu4_t *>(records + d + q * 4) = *reinterpret_cast<const pu4_t *>(lds32 + L.pt[p].x + q * 4);
+#pragma unroll
+        for (uint32_t j = 0; j < V3_PIECE; j++)
+            if (j * LINE4 + q * 4 < left)
+                *reinterpret_cast<pu4_t *>(records + d + j * LINE4 + q * 4) =
+                    *reinterpret_cast<const pu4_t *>(lds32 + L.pt[p].x + j * LINE4 + q * 4);
     }
     if (nrec) atomicAdd(&L.nrec, nrec);
     __syncthreads();
@@ -1579,7 +1597,8 @@ size_t part3_scratch_bytes(size_t n, uint32_t nmetrics, int num_cus, const PartT
 
 // survey_n / region_stat: as launch_ingest_pairs_part2.  span_stat: device-visible word (pinned host memory) that
 // receives the survey's window-width class, or null.
-hipError_t launch_ingest_pairs_part3(const uint32_t *d_ids, const double *d_v, size_t n, size_t survey_n,
+template <typename IDT>
+static hipError_t launch_part3_t(const IDT *d_ids, const double *d_v, size_t n, size_t survey_n,
                                      uint64_t *counts, uint32_t *ranges, uint32_t nmetrics, const double *d_Tx,
                                      uint32_t *d_err, void *scratch, size_t scratch_bytes, int num_cus,
                                      const PartTuning &tune, unsigned long long *region_stat, uint32_t *span_stat,
@@ -1590,7 +1609,7 @@ hipError_t launch_ingest_pairs_part3(const uint32_t *d_ids, const double *d_v, s
     if (!part_aligned(d_ids, d_v)) return hipErrorInvalidValue;
     static std::atomic<bool> attr_set{false}; // benign if two threads race: both set the same attributes
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter4<4>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter4<4, IDT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)V2_LDS_TOTAL);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_split_records),
@@ -1602,7 +1621,7 @@ hipError_t launch_ingest_pairs_part3(const uint32_t *d_ids, const double *d_v, s
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_part_hist3),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)P3_LDS_BYTES);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_survey_count_h),
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_survey_count_h<IDT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(5 * SVH_SLOTS * 4));
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_plan_count),
@@ -1638,7 +1657,7 @@ hipError_t launch_ingest_pairs_part3(const uint32_t *d_ids, const double *d_v, s
         if (e != hipSuccess) return e;
         const size_t sv_tiles = (survey_n / 2 + 1023) / 1024;
         const unsigned sv_grid = (unsigned)std::min<size_t>(SVH_GRID, std::max<size_t>(1, sv_tiles));
-        hipLaunchKernelGGL(k_survey_count_h, dim3(sv_grid), dim3(1024), 5 * SVH_SLOTS * 4, s, d_ids, d_v, survey_n,
+        hipLaunchKernelGGL(k_survey_count_h<IDT>, dim3(sv_grid), dim3(1024), 5 * SVH_SLOTS * 4, s, d_ids, d_v, survey_n,
                            nmetrics, d_Tx, g_cs, g_mninv, g_mx);
         hipLaunchKernelGGL(k_survey_pick, dim3((nmetrics + 1023) / 1024), dim3(1024), 0, s, S, nmetrics, g_aux);
         hipLaunchKernelGGL(k_survey_plan_h, dim3(1), dim3(V2_BLOCK), 0, s, S, g_aux, P.cells, V3_TILE, g_hk, g_hs, g_pt,
@@ -1647,7 +1666,7 @@ hipError_t launch_ingest_pairs_part3(const uint32_t *d_ids, const double *d_v, s
                            g_remap, g_inv, g_pt2);
     }
     const size_t nt_full = n / V3_TILE, done = nt_full * V3_TILE;
-    hipLaunchKernelGGL(k_scatter4<4>, dim3(P.g1), dim3(1024), P.lds_dyn, s, d_ids, d_v, nt_full, nmetrics, d_Tx, g_hk,
+    hipLaunchKernelGGL((k_scatter4<4, IDT>), dim3(P.g1), dim3(1024), P.lds_dyn, s, d_ids, d_v, nt_full, nmetrics, d_Tx, g_hk,
                        g_hs, g_hdr, g_pt, P.region_words, P.cells, L1.records, L1.cdesc, P.chunks_per_wg, counts, ranges,
                        d_err, g_stats);
     if (done < n) {
@@ -1672,4 +1691,16 @@ hipError_t launch_ingest_pairs_part3(const uint32_t *d_ids, const double *d_v, s
                        counts, ranges, g_stats);
     hipLaunchKernelGGL(k_v3_report, dim3(1), dim3(64), 0, s, g_stats, region_stat, (unsigned long long)n);
     return hipGetLastError();
+}
+
+hipError_t launch_ingest_pairs_part3(Ids d_ids, const double *d_v, size_t n, size_t survey_n,
+                                     uint64_t *counts, uint32_t *ranges, uint32_t nmetrics, const double *d_Tx,
+                                     uint32_t *d_err, void *scratch, size_t scratch_bytes, int num_cus,
+                                     const PartTuning &tune, unsigned long long *region_stat, uint32_t *span_stat,
+                                     hipStream_t s)
+{
+    return d_ids.width == 2 ? launch_part3_t(d_ids.u16(), d_v, n, survey_n, counts, ranges, nmetrics, d_Tx, d_err, scratch,
+                                             scratch_bytes, num_cus, tune, region_stat, span_stat, s)
+                            : launch_part3_t(d_ids.u32(), d_v, n, survey_n, counts, ranges, nmetrics, d_Tx, d_err, scratch,
+                                             scratch_bytes, num_cus, tune, region_stat, span_stat, s);
 }

@@ -13,6 +13,7 @@
 // tile (lh_windows.h); records outside a window go to global atomics (exact).  Grid-stride over tiles.
 #include "lh_kernels.h"
 #include "lh_codec.h"
+#include "lh_ids.h"
 
 #include <atomic>
 #include "lh_windows.h"
@@ -28,10 +29,10 @@ constexpr uint32_t KS_MAXM_SMALL = 16;        // up to here: 64 KiB windows, 512
 constexpr size_t ks_lds_bytes(uint32_t words) { return (words + 3 * KS_MAXM + 2 * OV_SLOTS) * sizeof(uint32_t) + 16; }
 constexpr size_t KS_MIN_SAMPLES = 65536;
 
-bool small_supported(size_t n, uint32_t nmetrics, const uint32_t *d_ids, const double *d_v)
+bool small_supported(size_t n, uint32_t nmetrics, Ids d_ids, const double *d_v)
 {
     return nmetrics >= 1 && nmetrics <= KS_MAXM && n >= KS_MIN_SAMPLES && (((uintptr_t)d_v & 15) == 0) &&
-           (((uintptr_t)d_ids & 7) == 0);
+           d_ids.pair_aligned();
 }
 
 __device__ __forceinline__ void ks_global_add(uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
@@ -43,8 +44,8 @@ __device__ __forceinline__ void ks_global_add(uint64_t *__restrict__ counts, uin
     if (bin > r[1]) atomicMax(&r[1], bin);
 }
 
-template <uint32_t KS_WORDS, int KS_BLOCK>
-__global__ __launch_bounds__(KS_BLOCK) void k_ingest_pairs_small(const uint32_t *__restrict__ ids,
+template <uint32_t KS_WORDS, int KS_BLOCK, typename IDT>
+__global__ __launch_bounds__(KS_BLOCK) void k_ingest_pairs_small(const IDT *__restrict__ ids,
                                                                  const double *__restrict__ v, size_t n,
                                                                  uint64_t *__restrict__ counts,
                                                                  uint32_t *__restrict__ ranges, uint32_t nmetrics,
@@ -63,7 +64,8 @@ __global__ __launch_bounds__(KS_BLOCK) void k_ingest_pairs_small(const uint32_t 
 
     const size_t npair = n / 2; // the odd tail sample is handled by workgroup 0
     const sd2_t *vp = reinterpret_cast<const sd2_t *>(v);
-    const su2_t *ip = reinterpret_cast<const su2_t *>(ids);
+    const IdStream<IDT> ip(ids);
+    typedef IdStream<IDT> IS;
     const size_t tile = (size_t)KS_BLOCK * KS_UNROLL; // pairs per workgroup iteration
     const size_t ntiles = (npair + tile - 1) / tile;
 
@@ -75,10 +77,11 @@ __global__ __launch_bounds__(KS_BLOCK) void k_ingest_pairs_small(const uint32_t 
         for (int u = 0; u < KS_UNROLL; u++) {
             const size_t i = base + (size_t)u * KS_BLOCK + tid;
             if (i < npair) {
-                const su2_t id = ip[i];
+                const typename IS::raw_t id = ip.ld(i);
                 const sd2_t x = vp[i];
-                if (id.x < nmetrics) atomicAdd(&h[(id.x << log_w) + (lh_bin_of(x.x, Tx) >> log_cw)], 1u);
-                if (id.y < nmetrics) atomicAdd(&h[(id.y << log_w) + (lh_bin_of(x.y, Tx) >> log_cw)], 1u);
+                const uint32_t ia = IS::first(id), ib = IS::second(id);
+                if (ia < nmetrics) atomicAdd(&h[(ia << log_w) + (lh_bin_of(x.x, Tx) >> log_cw)], 1u);
+                if (ib < nmetrics) atomicAdd(&h[(ib << log_w) + (lh_bin_of(x.y, Tx) >> log_cw)], 1u);
             }
         }
     }
@@ -125,27 +128,28 @@ __global__ __launch_bounds__(KS_BLOCK) void k_ingest_pairs_small(const uint32_t 
     const size_t nfull = npair / tile;
     for (size_t t = blockIdx.x; t < nfull; t += gridDim.x) {
         const size_t base = t * tile + tid;
-        su2_t idr[KS_UNROLL];
+        typename IS::raw_t idr[KS_UNROLL];
         sd2_t vr[KS_UNROLL];
 #pragma unroll
         for (int u = 0; u < KS_UNROLL; u++) {
-            idr[u] = __builtin_nontemporal_load(ip + base + (size_t)u * KS_BLOCK);
+            idr[u] = ip.ld_nt(base + (size_t)u * KS_BLOCK);
             vr[u] = __builtin_nontemporal_load(vp + base + (size_t)u * KS_BLOCK);
         }
 #pragma unroll
         for (int u = 0; u < KS_UNROLL; u++) {
             // a bad id breaks wave uniformity of the branch inside add(); checked there
-            const bool ok = __builtin_amdgcn_ballot_w64(idr[u].x >= nmetrics || idr[u].y >= nmetrics) == 0ull;
-            add(idr[u].x, vr[u].x, ok);
-            add(idr[u].y, vr[u].y, ok);
+            const uint32_t ia = IS::first(idr[u]), ib = IS::second(idr[u]);
+            const bool ok = __builtin_amdgcn_ballot_w64(ia >= nmetrics || ib >= nmetrics) == 0ull;
+            add(ia, vr[u].x, ok);
+            add(ib, vr[u].y, ok);
         }
     }
     if (blockIdx.x == nfull % gridDim.x) { // remainder pairs + odd tail (guarded)
         for (size_t i = nfull * tile + tid; i < npair; i += KS_BLOCK) {
-            const su2_t id = ip[i];
+            const typename IS::raw_t id = ip.ld(i);
             const sd2_t x = vp[i];
-            add(id.x, x.x, false);
-            add(id.y, x.y, false);
+            add(IS::first(id), x.x, false);
+            add(IS::second(id), x.y, false);
         }
         if (tid == 0 && (n & 1)) add(ids[n - 1], v[n - 1], false);
     }
@@ -174,17 +178,16 @@ __global__ __launch_bounds__(KS_BLOCK) void k_ingest_pairs_small(const uint32_t 
     }
 }
 
-hipError_t launch_ingest_pairs_small(const uint32_t *d_ids, const double *d_v, size_t n, uint64_t *counts,
-                                     uint32_t *ranges, uint32_t nmetrics, const double *d_Tx, uint32_t *d_err,
-                                     int num_cus, hipStream_t s)
+template <typename IDT>
+static hipError_t launch_small_t(const IDT *d_ids, const double *d_v, size_t n, uint64_t *counts, uint32_t *ranges,
+                                 uint32_t nmetrics, const double *d_Tx, uint32_t *d_err, int num_cus, hipStream_t s)
 {
-    if (!small_supported(n, nmetrics, d_ids, d_v)) return hipErrorInvalidValue;
     static std::atomic<bool> attr_set{false}; // benign if two threads race: both set the same attribute
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ingest_pairs_small<16384, 512>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ingest_pairs_small<16384, 512, IDT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ks_lds_bytes(16384));
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ingest_pairs_small<32768, 1024>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ingest_pairs_small<32768, 1024, IDT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ks_lds_bytes(32768));
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -199,12 +202,21 @@ hipError_t launch_ingest_pairs_small(const uint32_t *d_ids, const double *d_v, s
     const size_t cap = (size_t)num_cus * (big ? 1 : 2);
     const unsigned grid = (unsigned)(want < cap ? want : cap);
     if (big)
-        hipLaunchKernelGGL((k_ingest_pairs_small<32768, 1024>), dim3(grid ? grid : 1), dim3(1024), ks_lds_bytes(32768), s,
+        hipLaunchKernelGGL((k_ingest_pairs_small<32768, 1024, IDT>), dim3(grid ? grid : 1), dim3(1024), ks_lds_bytes(32768), s,
                            d_ids, d_v, n, counts, ranges, nmetrics, log_w, d_Tx, d_err);
     else
-        hipLaunchKernelGGL((k_ingest_pairs_small<16384, 512>), dim3(grid ? grid : 1), dim3(512), ks_lds_bytes(16384), s,
+        hipLaunchKernelGGL((k_ingest_pairs_small<16384, 512, IDT>), dim3(grid ? grid : 1), dim3(512), ks_lds_bytes(16384), s,
                            d_ids, d_v, n, counts, ranges, nmetrics, log_w, d_Tx, d_err);
     return hipGetLastError();
+}
+
+hipError_t launch_ingest_pairs_small(Ids d_ids, const double *d_v, size_t n, uint64_t *counts,
+                                     uint32_t *ranges, uint32_t nmetrics, const double *d_Tx, uint32_t *d_err,
+                                     int num_cus, hipStream_t s)
+{
+    if (!small_supported(n, nmetrics, d_ids, d_v)) return hipErrorInvalidValue;
+    return d_ids.width == 2 ? launch_small_t(d_ids.u16(), d_v, n, counts, ranges, nmetrics, d_Tx, d_err, num_cus, s)
+                            : launch_small_t(d_ids.u32(), d_v, n, counts, ranges, nmetrics, d_Tx, d_err, num_cus, s);
 }
 
 } // namespace lh

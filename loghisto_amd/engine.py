@@ -278,19 +278,25 @@ class Engine:
         N.check(N.lib().lh_submit(self._h, metric_id, v.ctypes.data, v.size), "lh_submit")
 
     def submit_pairs(self, ids, values):
-        i = np.ascontiguousarray(ids, dtype=np.uint32)
+        """(id, value) pairs from host arrays (copied before the call returns).  uint16 ids take the 10-byte form
+        (lh_submit_pairs16: legal for <= 65 536 names), anything else is sent as uint32 (lh_submit_pairs)."""
+        narrow = isinstance(ids, np.ndarray) and ids.dtype == np.uint16
+        i = np.ascontiguousarray(ids, dtype=np.uint16 if narrow else np.uint32)
         v = np.ascontiguousarray(values, dtype=np.float64)
         if i.size != v.size:
             raise ValueError("ids and values differ in length")
-        N.check(N.lib().lh_submit_pairs(self._h, i.ctypes.data, v.ctypes.data, v.size), "lh_submit_pairs")
+        if narrow:
+            N.check(N.lib().lh_submit_pairs16(self._h, i.ctypes.data, v.ctypes.data, v.size), "lh_submit_pairs16")
+        else:
+            N.check(N.lib().lh_submit_pairs(self._h, i.ctypes.data, v.ctypes.data, v.size), "lh_submit_pairs")
 
-    def reserve_pairs(self, want: int):
-        """(ids uint32[granted], values float64[granted], token): views of a pinned staging buffer to fill in place
-        (lh_reserve_pairs); publish the first n with commit_pairs(token, n)."""
+    def reserve_pairs(self, want: int, id_bits: int = 32):
+        """(ids uint32[granted] or uint16[granted], values float64[granted], token): views of a pinned staging buffer
+        to fill in place (lh_reserve_pairs / lh_reserve_pairs16); publish the first n with commit_pairs(token, n)."""
         pi, pv, g, tok = C.c_void_p(), C.c_void_p(), C.c_size_t(0), C.c_uint32(0)
-        N.check(N.lib().lh_reserve_pairs(self._h, want, C.byref(pi), C.byref(pv), C.byref(g), C.byref(tok)),
-                "lh_reserve_pairs")
-        ids = np.ctypeslib.as_array(C.cast(pi, C.POINTER(C.c_uint32)), shape=(g.value,))
+        fn, ct = (N.lib().lh_reserve_pairs16, C.c_uint16) if id_bits == 16 else (N.lib().lh_reserve_pairs, C.c_uint32)
+        N.check(fn(self._h, want, C.byref(pi), C.byref(pv), C.byref(g), C.byref(tok)), "lh_reserve_pairs")
+        ids = np.ctypeslib.as_array(C.cast(pi, C.POINTER(ct)), shape=(g.value,))
         vals = np.ctypeslib.as_array(C.cast(pv, C.POINTER(C.c_double)), shape=(g.value,))
         return ids, vals, tok.value
 
@@ -298,14 +304,16 @@ class Engine:
         N.check(N.lib().lh_commit_pairs(self._h, token, n), "lh_commit_pairs")
 
     def submit_pairs_in_place(self, ids, values):
-        """The same stream as submit_pairs through reserve / fill / commit: one host-side copy, no id scan."""
-        i = np.ascontiguousarray(ids, dtype=np.uint32)
+        """The same stream as submit_pairs through reserve / fill / commit: one host-side copy, no id scan.  uint16 ids
+        are staged as uint16 (10 bytes per pair over PCIe)."""
+        narrow = isinstance(ids, np.ndarray) and ids.dtype == np.uint16
+        i = np.ascontiguousarray(ids, dtype=np.uint16 if narrow else np.uint32)
         v = np.ascontiguousarray(values, dtype=np.float64)
         if i.size != v.size:
             raise ValueError("ids and values differ in length")
         done = 0
         while done < v.size:
-            di, dv, tok = self.reserve_pairs(v.size - done)
+            di, dv, tok = self.reserve_pairs(v.size - done, 16 if narrow else 32)
             k = di.size
             np.copyto(di, i[done:done + k])
             np.copyto(dv, v[done:done + k])
@@ -318,7 +326,13 @@ class Engine:
                 "lh_submit_device")
 
     def submit_pairs_device(self, d_ids, d_values, n: Optional[int] = None, stream=None):
+        """Device-resident (id, value) pairs.  A 2-byte id tensor (torch.int16 / torch.uint16: the bits of uint16 ids)
+        takes lh_submit_pairs16_device, a 4-byte one lh_submit_pairs_device."""
         n = int(d_values.numel()) if n is None else n
+        if getattr(d_ids, "element_size", lambda: 4)() == 2:
+            N.check(N.lib().lh_submit_pairs16_device(self._h, _ptr(d_ids), _ptr(d_values), n, _stream_handle(stream)),
+                    "lh_submit_pairs16_device")
+            return
         N.check(N.lib().lh_submit_pairs_device(self._h, _ptr(d_ids), _ptr(d_values), n, _stream_handle(stream)),
                 "lh_submit_pairs_device")
 

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(native_lib):
 
 
 def test_abi_version_and_strerror(native_lib):
-    assert native_lib.lh_abi_version() == 3
+    assert native_lib.lh_abi_version() == 4
     msgs = {native_lib.lh_strerror(c).decode() for c in range(8)}
     assert len(msgs) == 8 and "ok" in msgs
 
