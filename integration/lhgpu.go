@@ -30,15 +30,17 @@ import (
 
 const stageCap = 4096 // samples per crossing: a cgo call costs more than the old fast path
 
-// stage is a per-P (per logical processor) staging buffer; sync.Pool keeps them P-local.
-// A stage IS a piece of the engine's pinned staging memory (lh_reserve_pairs): Histogram stores the pair where the
-// ingest kernel will read it (SURVEY.md 8b Ownership: "the ring is C-allocated and Go writes into it in place").
-// ids / vals are Go slices over C memory: no Go pointer ever reaches C.
+// stage is a per-P (per logical processor) staging buffer; sync.Pool keeps them P-local.  It lives in GO memory: a
+// stage may sit idle in the pool for any length of time, be dropped by the GC or multiply when a P's slot is empty,
+// and none of that may hold engine resources.  (Round 3 made a stage a reservation of pinned staging memory held
+// across Put: stages that the pool dropped kept their lanes reserved, and once every lane was taken the next refill
+// blocked inside lh_reserve_pairs under histogramMu.RLock -- the flip could never take the write lock again.  ADVICE
+// r3.)  The pinned memory is touched in ship() only: reserve, copy, commit, all inside one call, exactly what the
+// tested C++ twin does (MetricSystem::ship, loghisto_amd/csrc/host/metric_system.cc).
 type stage struct {
-	ids  []C.uint32_t
-	vals []C.double
+	ids  [stageCap]uint32
+	vals [stageCap]float64
 	n    int
-	tok  C.uint32_t // reservation held by this stage (0: none)
 }
 
 type gpuEngine struct {
@@ -49,14 +51,15 @@ type gpuEngine struct {
 	pool   sync.Pool  // *stage
 	all    []*stage   // every stage ever handed out, for the flush at the flip
 	allMu  sync.Mutex
+	narrow bool       // <= 65 536 names: ids cross PCIe as uint16 (lh_reserve_pairs16: 10 B per sample, not 12)
 }
 
 func newGPUEngine(maxMetrics int) *gpuEngine {
 	var cfg C.lh_config
 	C.lh_default_config(&cfg)
 	cfg.max_metrics = C.uint32_t(maxMetrics)
-	cfg.num_lanes = C.uint32_t(2 * runtime.GOMAXPROCS(0)) // >= the stages that can hold a reservation
-	g := &gpuEngine{ids: make(map[string]uint32)}
+	cfg.num_lanes = C.uint32_t(runtime.GOMAXPROCS(0)) // concurrent ship() calls: at most one per P
+	g := &gpuEngine{ids: make(map[string]uint32), narrow: maxMetrics <= 65536}
 	if rc := C.lh_create(&cfg, &g.e); rc != C.LH_OK {
 		glog.Errorf("lh_create: %s (%s)", C.GoString(C.lh_strerror(rc)), C.GoString(C.lh_last_error()))
 		return nil // caller falls back to refusing Histogram; there is no CPU path in the library
@@ -92,28 +95,45 @@ func (g *gpuEngine) id(name string) uint32 {
 	return uint32(cid)
 }
 
-// commit what the stage holds (the kernel reads it in place, over PCIe) and give the reservation back
+// ship moves what the stage holds into the engine's pinned staging memory: reserve -> copy -> commit, never holding
+// the reservation across anything that can block or across a return.  The copy is the sample's only store into pinned
+// memory; the ingest kernel reads it in place over PCIe.  With at most 65 536 names the ids are narrowed to uint16 on
+// the way (SURVEY.md 8d: 10 B per sample).  No Go pointer reaches C: C hands out its own memory and Go writes into it.
 func (g *gpuEngine) ship(s *stage) {
-	if s.tok == 0 { return }
-	if rc := C.lh_commit_pairs(g.e, s.tok, C.size_t(s.n)); rc != C.LH_OK {
-		glog.Errorf("lh_commit_pairs: %s", C.GoString(C.lh_strerror(rc)))
+	for done := 0; done < s.n; {
+		var pv *C.double
+		var granted C.size_t
+		var tok C.uint32_t
+		want := C.size_t(s.n - done)
+		if g.narrow {
+			var pi *C.uint16_t
+			if rc := C.lh_reserve_pairs16(g.e, want, &pi, &pv, &granted, &tok); rc != C.LH_OK {
+				glog.Errorf("lh_reserve_pairs16: %s", C.GoString(C.lh_strerror(rc)))
+				break // the engine is unusable (device lost): the interval's remaining samples are dropped WITH a log line
+			}
+			ids, vals := unsafe.Slice(pi, int(granted)), unsafe.Slice(pv, int(granted))
+			for i := range ids {
+				ids[i] = C.uint16_t(s.ids[done+i])
+				vals[i] = C.double(s.vals[done+i])
+			}
+		} else {
+			var pi *C.uint32_t
+			if rc := C.lh_reserve_pairs(g.e, want, &pi, &pv, &granted, &tok); rc != C.LH_OK {
+				glog.Errorf("lh_reserve_pairs: %s", C.GoString(C.lh_strerror(rc)))
+				break
+			}
+			ids, vals := unsafe.Slice(pi, int(granted)), unsafe.Slice(pv, int(granted))
+			for i := range ids {
+				ids[i] = C.uint32_t(s.ids[done+i])
+				vals[i] = C.double(s.vals[done+i])
+			}
+		}
+		if rc := C.lh_commit_pairs(g.e, tok, granted); rc != C.LH_OK { // (== lh_commit_pairs16: the token knows the width)
+			glog.Errorf("lh_commit_pairs: %s", C.GoString(C.lh_strerror(rc)))
+		}
+		done += int(granted)
 	}
-	s.tok, s.n, s.ids, s.vals = 0, 0, nil, nil
-}
-
-// a fresh piece of pinned staging memory for the stage: up to stageCap pairs (one cgo crossing per stageCap samples,
-// as before).  lh_create gets num_lanes >= 2 x GOMAXPROCS so that a stage that sits idle with a reservation never
-// keeps another P waiting; every reservation is committed at the flip (collectRawMetrics below).
-func (g *gpuEngine) refill(s *stage) bool {
-	var pi *C.uint32_t
-	var pv *C.double
-	var granted C.size_t
-	if rc := C.lh_reserve_pairs(g.e, stageCap, &pi, &pv, &granted, &s.tok); rc != C.LH_OK {
-		glog.Errorf("lh_reserve_pairs: %s", C.GoString(C.lh_strerror(rc)))
-		return false
-	}
-	s.ids, s.vals, s.n = unsafe.Slice(pi, int(granted)), unsafe.Slice(pv, int(granted)), 0
-	return true
+	s.n = 0
 }
 
 func (ms *MetricSystem) Histogram(name string, value float64) {
@@ -122,12 +142,10 @@ func (ms *MetricSystem) Histogram(name string, value float64) {
 	if id == ^uint32(0) { return }
 	ms.histogramMu.RLock()          // same lock, same role: readers = submitters, writer = the flip
 	s := g.pool.Get().(*stage)
-	if s.tok != 0 || g.refill(s) {
-		s.ids[s.n] = C.uint32_t(id)     // the sample's only host-side store: pinned memory the kernel reads in place
-		s.vals[s.n] = C.double(value)   // compress() now happens on the GPU
-		s.n++
-		if s.n == len(s.ids) { g.ship(s) }
-	}
+	s.ids[s.n] = id                 // Go memory; compress() now happens on the GPU
+	s.vals[s.n] = value
+	s.n++
+	if s.n == stageCap { g.ship(s) } // one cgo crossing per stageCap samples
 	g.pool.Put(s)
 	ms.histogramMu.RUnlock()
 }

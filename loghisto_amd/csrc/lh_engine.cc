@@ -232,6 +232,7 @@ struct lh_engine {
     // of the pairs forwarded to the reduce pass (65 536 uniform names: 88 %, 9.7 ms per 1e9 pairs) the first
     // generation's fixed two-level split is faster (7.9 ms).  Judged over completed calls; re-armed every 64 flips.
     uint64_t v3_seen_fwd = 0;
+    uint32_t v3_last_call_log_w = 0;         // window width of the previous third-generation call (scratch_mu)
     std::atomic<bool> v3_disabled{false};
     uint32_t flips_since_v3_off = 0;
     std::atomic<uint64_t> c_scratch{0}, c_sublaunches{0}, c_part2{0}, c_part3{0};
@@ -432,8 +433,14 @@ int launch_pairs(lh_engine *e, lh::Ids d_ids, const double *d_v, size_t n, hipSt
                     const uint64_t pairs = __atomic_load_n(&e->h_rstat[6], __ATOMIC_RELAXED); // of the launches that reported
                     const bool healthy = (bad - e->v3_seen_bad) * 50 <= pairs - e->v3_seen_pairs;
                     const uint64_t fwd = __atomic_load_n(&e->h_rstat[3], __ATOMIC_RELAXED);
-                    if (pairs - e->v3_seen_pairs >= (uint64_t(1) << 22) && (fwd - e->v3_seen_fwd) * 4 > (pairs - e->v3_seen_pairs) * 3)
+                    // (not when the survey has just reported another window width: the calls being judged ran with
+                    // windows that were too narrow -- or too wide -- for this stream, which forwards most records
+                    // whatever the names' skew; measured: a 21-decade stream after a lognormal one was sent to the first
+                    // generation for 64 flips, 12.4 instead of 8.8 ms per 1e9 pairs)
+                    if (pairs - e->v3_seen_pairs >= (uint64_t(1) << 22) && (fwd - e->v3_seen_fwd) * 4 > (pairs - e->v3_seen_pairs) * 3 &&
+                        call_log_w == e->v3_last_call_log_w)
                         e->v3_disabled.store(true); // (takes effect at the next launch)
+                    e->v3_last_call_log_w = call_log_w;
                     e->v3_seen_fwd = fwd;
                     e->v3_seen_bad = bad;
                     e->v3_seen_pairs = pairs;

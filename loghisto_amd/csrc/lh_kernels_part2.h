@@ -189,6 +189,11 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__rest
                 // a bell-shaped bin distribution is ~ +-3.5 sigma; 3/4 of it keeps ~99 %), in steps of 64 bins
                 if (c >= 16) {
                     uint32_t w = (((mx - mn + 1) * 3u / 4u) + 63u) & ~63u;
+#ifdef LH_HOT_FULL_SPAN
+                    // variant under measurement: the whole sampled span when it fits the largest window (few-valued and
+                    // flat distributions have their mass at the ends of the span, where 3/4 of it cuts them off)
+                    if (mx - mn + 1 <= 512u) w = ((mx - mn + 1) + 63u) & ~63u;
+#endif
                     want[e] = w < 64u ? 64u : w;
                 }
             }
@@ -699,9 +704,15 @@ constexpr uint32_t SC3_TILES_PER_FLUSH = LH_SC3_TILES_PER_FLUSH; // tiles classi
 #ifndef LH_SC3_CAP_NUM
 #define LH_SC3_CAP_NUM 6
 #endif
-constexpr uint32_t SC3_CAP_NUM = LH_SC3_CAP_NUM; // region capacity = expected records * CAP_NUM / 4 + 40 (6: 1.5 x)
+constexpr uint32_t SC3_CAP_NUM = LH_SC3_CAP_NUM; // region capacity = expected records * CAP_NUM / 4 + 8 + one piece (6: 1.5 x)
+#ifndef LH_SC3_PIECE
+#define LH_SC3_PIECE 1
+#endif
+// The region scatter copies whole PIECES of SC3_PIECE consecutive 64-byte lines out of a partition's region (see
+// V3_PIECE in lh_kernels_part3.h); up to SC3_PIECE * 32 - 1 records stay behind.
+constexpr uint32_t SC3_PIECE = LH_SC3_PIECE, PIECE2 = SC3_PIECE * LINE2;
 // upper bound of the sum of the partitions' capacities; `tile` = samples between two flushes
-constexpr uint32_t region_records(uint32_t tile, uint32_t np) { return SC3_CAP_NUM * tile / 4u + 72u * np; }
+constexpr uint32_t region_records(uint32_t tile, uint32_t np) { return SC3_CAP_NUM * tile / 4u + (40u + PIECE2) * np; }
 
 // Region sizes from the survey: g_pt[p] = {first record of the region (relative to the region area), capacity}.
 // One workgroup of 256 threads, after k_survey_plan.
@@ -726,8 +737,8 @@ __global__ __launch_bounds__(256) void k_survey_parts(const uint32_t *__restrict
     uint32_t cap = 0;
     if (tid < np) {
         const uint32_t est = total ? (uint32_t)(((unsigned long long)s_pc[tid] * tile) / total) : tile / np;
-        cap = (est * SC3_CAP_NUM / 4u + 40u + 31u) & ~31u;
-        if (cap > tile + 32u) cap = tile + 32u; // leftover (< 32) + a whole tile
+        cap = (est * SC3_CAP_NUM / 4u + 8u + PIECE2 + 31u) & ~31u;
+        if (cap > tile + PIECE2) cap = tile + PIECE2; // leftover (< one piece) + a whole tile
     }
     s_cap[tid] = cap;
     __syncthreads();
@@ -905,10 +916,11 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
             asm volatile("" : "+v"(t2)); // keeps this phase's address arithmetic inside the loop (see k_scatter2)
             const uint32_t p = t2 / TPP, q = t2 % TPP;
             const pu2_t e = TPP == 4 ? my_pt : L.pt[p];
-            const uint32_t c = min(L.cnt[p], e.y), full = c / LINE2, left = c % LINE2;
+            // whole pieces only: `full` lines leave (a multiple of SC3_PIECE), fewer than PIECE2 records stay behind
+            const uint32_t c = min(L.cnt[p], e.y), full = c / PIECE2 * SC3_PIECE, left = c - full * LINE2;
             if (full) {
                 const uint32_t cf = L.cfill[p], cb = L.cbase[p];
-                const uint32_t room = (CHUNK - cf) / LINE2; // lines left in the open chunk (0: none open)
+                const uint32_t room = (CHUNK - cf) / LINE2; // lines left in the open chunk (0: none open; whole pieces)
                 uint32_t first = 0;
                 if (full > room && q == 0) {
                     const uint32_t tag = p << CD_SHIFT;
@@ -939,10 +951,11 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
                         for (uint32_t i = 0; i < 4 / TPP; i++) hidden_store_u4(records + dst + (q + i * TPP) * 8, r4[i]);
                     }
                 }
-                // the last partial line moves to the front of the region (its slots are this thread's own)
+                // the leftover (less than a piece) moves to the front of the region (its slots are this thread's own:
+                // source and destination are at least one piece apart)
 #pragma unroll
-                for (uint32_t i = 0; i < 4 / TPP; i++) {
-                    const uint32_t piece = q + i * TPP;
+                for (uint32_t i = 0; i < SC3_PIECE * 4 / TPP; i++) {
+                    const uint32_t piece = q + i * TPP; // 16-byte pieces 0 .. 4 * SC3_PIECE - 1 of the leftover
                     if (piece * 8 < left)
                         *reinterpret_cast<pu4_t *>(lds16 + e.x + piece * 8) =
                             *reinterpret_cast<const pu4_t *>(src + full * LINE2 + piece * 8);
@@ -982,10 +995,10 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
     // ---- drain: the regions' leftovers (< one line each) and the open chunks' descriptors
     {
         const uint32_t p = tid >> 2, q = tid & 3u;
-        const uint32_t left = L.cnt[p]; // < LINE2 after a flush
+        const uint32_t left = L.cnt[p]; // < PIECE2 after a flush
         uint32_t d = INVALID;
         if (left && q == 0) {
-            uint32_t cf = L.cfill[p], cb = L.cbase[p];
+            uint32_t cf = L.cfill[p], cb = L.cbase[p]; // (cf is a multiple of PIECE2: the leftover fits the open chunk)
             if (cf == CHUNK) { // no open chunk, or it is exactly full
                 if (cb != INVALID) cdesc[cb] = (p << CD_SHIFT) | CHUNK;
                 cb = pool_base + atomicAdd(&L.pool_next, 1u);
@@ -996,8 +1009,11 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
             L.cfill[p] = cf + left;
         }
         d = __builtin_amdgcn_mov_dpp(d, 0x00, 0xf, 0xf, false);
-        if (left && q * 8 < left)
-            *reinterpret_cast<pu4_t *>(records + d + q * 8) = *reinterpret_cast<const pu4_t *>(lds16 + L.pt[p].x + q * 8);
+#pragma unroll
+        for (uint32_t j = 0; j < SC3_PIECE; j++)
+            if (left && j * LINE2 + q * 8 < left)
+                *reinterpret_cast<pu4_t *>(records + d + j * LINE2 + q * 8) =
+                    *reinterpret_cast<const pu4_t *>(lds16 + L.pt[p].x + j * LINE2 + q * 8);
     }
     __syncthreads();
     if (tid < np && L.cbase[tid] != INVALID) cdesc[L.cbase[tid]] = (tid << CD_SHIFT) | L.cfill[tid];

@@ -184,7 +184,10 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan_h(const SurveyStat S,
         cnt = sv_count(S, name);
         const uint32_t mn = 65535u - S.mninv[name], mx = S.mx[name];
         mean = sv_mean(S, name);
-        const uint32_t w = (((mx - mn + 1u) * 3u / 4u) + 63u) & ~63u; // as k_survey_plan: 3/4 of the sampled span
+        uint32_t w = (((mx - mn + 1u) * 3u / 4u) + 63u) & ~63u; // as k_survey_plan: 3/4 of the sampled span
+#ifdef LH_HOT_FULL_SPAN
+        if (mx - mn + 1u <= 512u) w = ((mx - mn + 1u) + 63u) & ~63u;
+#endif
         want = w < 64u ? 64u : w;
     }
     const uint32_t pc = tid < V3_NP ? g_aux[AUX_PC + tid] : 0u;
