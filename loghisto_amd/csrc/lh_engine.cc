@@ -433,12 +433,13 @@ int launch_pairs(lh_engine *e, lh::Ids d_ids, const double *d_v, size_t n, hipSt
                     const uint64_t pairs = __atomic_load_n(&e->h_rstat[6], __ATOMIC_RELAXED); // of the launches that reported
                     const bool healthy = (bad - e->v3_seen_bad) * 50 <= pairs - e->v3_seen_pairs;
                     const uint64_t fwd = __atomic_load_n(&e->h_rstat[3], __ATOMIC_RELAXED);
-                    // (not when the survey has just reported another window width: the calls being judged ran with
-                    // windows that were too narrow -- or too wide -- for this stream, which forwards most records
-                    // whatever the names' skew; measured: a 21-decade stream after a lognormal one was sent to the first
-                    // generation for 64 flips, 12.4 instead of 8.8 ms per 1e9 pairs)
+                    // (only calls that ran HEALTHY, and not when the survey has just reported another window width: a call
+                    // on a stale survey -- other value spans than the windows were placed for -- forwards most records
+                    // whatever the names' skew, and says so through its overflow / window-miss counts; measured: a
+                    // 21-decade stream after a lognormal one was sent to the first generation for 64 flips, 12.4 instead
+                    // of 8.8 ms per 1e9 pairs.  Names without skew forward > 3/4 with clean counters.)
                     if (pairs - e->v3_seen_pairs >= (uint64_t(1) << 22) && (fwd - e->v3_seen_fwd) * 4 > (pairs - e->v3_seen_pairs) * 3 &&
-                        call_log_w == e->v3_last_call_log_w)
+                        healthy && call_log_w == e->v3_last_call_log_w)
                         e->v3_disabled.store(true); // (takes effect at the next launch)
                     e->v3_last_call_log_w = call_log_w;
                     e->v3_seen_fwd = fwd;
@@ -764,15 +765,6 @@ int lh_create(const lh_config *cfg, lh_engine **out)
     lh_engine *e = new (std::nothrow) lh_engine();
     if (!e) return LH_ENOMEM;
     e->cfg = *cfg;
-#ifdef LH_TUNING
-    // tools/ builds only (-DLH_TUNING): the sweep scripts steer the dispatch through the environment
-    if (const char *v = getenv("LH_PART_NAMES")) e->tune.names_per_part = (uint32_t)std::max(1, atoi(v));
-    if (const char *v = getenv("LH_PART_TWO_LEVEL_ABOVE")) e->tune.two_level_above = (uint32_t)std::max(0, atoi(v));
-    if (const char *v = getenv("LH_PART_HOT")) e->tune.hot = atoi(v) != 0;
-    if (const char *v = getenv("LH_PART_HOT_MIN_TILES")) e->tune.hot_min_tiles = (uint32_t)std::max(1, atoi(v));
-    if (const char *v = getenv("LH_DEBUG_FLAGS")) e->tune.dbg = (uint32_t)atoi(v);
-    if (getenv("LH_NO_ZERO_COPY")) e->zero_copy_enabled = false;
-#endif
     int rc = create_impl(cfg, e);
     if (rc != LH_OK) {
         free_engine(e);

@@ -188,12 +188,9 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__rest
                 // hot window the name would like: 3/4 of the sampled span (the span of a few thousand samples of
                 // a bell-shaped bin distribution is ~ +-3.5 sigma; 3/4 of it keeps ~99 %), in steps of 64 bins
                 if (c >= 16) {
+                    // (the WHOLE span when it fits 512 bins was measured in round 4: few-valued streams gain -- k = 8: 3.74 ->
+                    // 3.43 ms per 1e9 pairs -- lognormal ones lose 3 % to the names that no longer fit; not kept)
                     uint32_t w = (((mx - mn + 1) * 3u / 4u) + 63u) & ~63u;
-#ifdef LH_HOT_FULL_SPAN
-                    // variant under measurement: the whole sampled span when it fits the largest window (few-valued and
-                    // flat distributions have their mass at the ends of the span, where 3/4 of it cuts them off)
-                    if (mx - mn + 1 <= 512u) w = ((mx - mn + 1) + 63u) & ~63u;
-#endif
                     want[e] = w < 64u ? 64u : w;
                 }
             }
@@ -709,7 +706,10 @@ constexpr uint32_t SC3_CAP_NUM = LH_SC3_CAP_NUM; // region capacity = expected r
 #define LH_SC3_PIECE 1
 #endif
 // The region scatter copies whole PIECES of SC3_PIECE consecutive 64-byte lines out of a partition's region (see
-// V3_PIECE in lh_kernels_part3.h); up to SC3_PIECE * 32 - 1 records stay behind.
+// V3_PIECE in lh_kernels_part3.h); up to SC3_PIECE * 32 - 1 records stay behind.  Measured at 1 024 names
+// (profiles/r04_level1_experiments.txt): 128-byte pieces are SLOWER here (2.89 -> 3.04 ms per 1e9 pairs) -- with 2-byte
+// records and 45 % of the pairs cold a partition gathers a piece only every fifth tile, and the 16 KiB of LDS come out
+// of the hot windows -- so this path stays at one line; the third generation (4-byte records, 67 % cold) gains 8 %.
 constexpr uint32_t SC3_PIECE = LH_SC3_PIECE, PIECE2 = SC3_PIECE * LINE2;
 // upper bound of the sum of the partitions' capacities; `tile` = samples between two flushes
 constexpr uint32_t region_records(uint32_t tile, uint32_t np) { return SC3_CAP_NUM * tile / 4u + (40u + PIECE2) * np; }

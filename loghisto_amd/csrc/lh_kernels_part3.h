@@ -47,8 +47,9 @@ constexpr uint32_t LINE4 = 16;                          // 4-byte records per 64
 #endif
 // Level 1 copies whole PIECES of V3_PIECE consecutive lines out of a partition's region (128 bytes at 2): what the
 // scattered record writes cost the memory system next to the 12 GB streaming read falls with their size
-// (profiles/r03_level1_experiments.txt: 64 -> 128 bytes, -8 % of the kernel); up to V3_PIECE * 16 - 1 records stay
-// behind in the region, so every capacity grows by 16 records per extra line.
+// (profiles/r03_level1_experiments.txt; round 4, profiles/r04_level1_experiments.txt: 64 -> 128 bytes takes the 1e9-pair
+// call from 5.18 to 4.74 ms, 256 bytes give it back -- 4.91 -- because the 32 KiB of extra region come out of the hot
+// windows); up to V3_PIECE * 16 - 1 records stay behind in the region, so every capacity grows by 16 records per line.
 constexpr uint32_t V3_PIECE = LH_V3_PIECE, PIECE4 = V3_PIECE * LINE4;
 constexpr uint32_t V3_MISSQ = 512;                      // records a tile can queue for the exact path (per parity)
 constexpr size_t V3_MIN_SAMPLES = size_t(1) << 24;
@@ -184,10 +185,7 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan_h(const SurveyStat S,
         cnt = sv_count(S, name);
         const uint32_t mn = 65535u - S.mninv[name], mx = S.mx[name];
         mean = sv_mean(S, name);
-        uint32_t w = (((mx - mn + 1u) * 3u / 4u) + 63u) & ~63u; // as k_survey_plan: 3/4 of the sampled span
-#ifdef LH_HOT_FULL_SPAN
-        if (mx - mn + 1u <= 512u) w = ((mx - mn + 1u) + 63u) & ~63u;
-#endif
+        const uint32_t w = (((mx - mn + 1u) * 3u / 4u) + 63u) & ~63u; // as k_survey_plan: 3/4 of the sampled span
         want = w < 64u ? 64u : w;
     }
     const uint32_t pc = tid < V3_NP ? g_aux[AUX_PC + tid] : 0u;
@@ -337,10 +335,6 @@ __global__ __launch_bounds__(256) void k_survey_remap(const SurveyStat S, const 
 __device__ __forceinline__ void v3_global_add(uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges, uint32_t m,
                                               uint32_t bin, uint32_t c)
 {
-#ifdef V3_VISIBLE_ATOMICS
-    v2_global_add(counts, ranges, m, bin, c);
-    return;
-#endif
     const unsigned long long c64 = c;
     asm volatile("global_atomic_add_x2 %0, %1, off" : : "v"(&counts[(size_t)m * LH_NKEYS + bin]), "v"(c64) : "memory");
     uint32_t *r = ranges + 2 * (size_t)m;
@@ -477,11 +471,7 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
 #pragma unroll
                 for (int k = 0; k < BATCH; k++) {
                     const int j = h + k;
-#ifdef V3_TABLE_EXACT
-                    if (unc & (1u << k)) bin[k] = lh_bin_of((j & 1) ? val[j >> 1].y : val[j >> 1].x, Tx);
-#else
                     if (unc & (1u << k)) bin[k] = v3_bin_exact((j & 1) ? val[j >> 1].y : val[j >> 1].x);
-#endif
                 }
             }
 #pragma unroll

@@ -1,4 +1,6 @@
-# Per-round evidence under gpurun_out/round/ (copy into profiles/ as r03_* afterwards).  One gpurun call.
+# Per-round evidence under gpurun_out/round/ (copy into profiles/ as r04_* afterwards).  One gpurun call.
+# Every PMC summary records the hashes of the kernel sources it was measured on (bench.source_hashes): bench.py refuses a
+# summary whose hashes differ from the tree's (traffic_source: "stale ...").
 #   bench.json              python bench.py (default flags: headline C2 + secondary C3 / C4 / host-fed / C5)
 #   kernel_trace.txt        rocprofv3 --kernel-trace of the C2 bench command (no cpu baseline), summarised
 #   k1_pmc.json             FETCH_SIZE / WRITE_SIZE passes for k_ingest_single, corrected per MI355X_MICROARCH.md
@@ -8,13 +10,18 @@
 #   c4_kernel_trace.txt / c4_pmc.json   the same for bench.py --workload c4 (65 536 names, one rank's 1.25e8-pair slice)
 # PMC passes are separate runs with no tracing domain mixed in.
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/round; mkdir -p $OUT; cd $R
-python bench.py > $OUT/bench.json 2> $OUT/bench.err
-python bench.py --workload c4 > $OUT/c4_bench.json 2> $OUT/c4_bench.err
+python bench.py 2> $OUT/bench.err | grep "^{" | tail -1 > $OUT/bench.json
+python bench.py --workload c4 2> $OUT/c4_bench.err | grep "^{" | tail -1 > $OUT/c4_bench.json
+loghisto_amd/build/read_ceiling --reps 20 > $OUT/read_ceiling.jsonl 2>&1
 cd /tmp; export TMPDIR=/tmp
-CMD="python $R/bench.py --workload c2 --no-secondary --steps 10 --warmup 2 --no-cpu-baseline --no-parity --latency-flips 50"
-rm -rf /tmp/pr_trace; rocprofv3 --kernel-trace -d /tmp/pr_trace -o t -- $CMD > $OUT/bench_under_trace.json 2>/dev/null
-{ echo "# rocprofv3 --kernel-trace -- $CMD"; python $R/profiles/summarize_rocpd.py stats /tmp/pr_trace/t_results.db | cut -c1-170
-  echo; echo "## full-size launches only (duration >= 0.5 ms)"; python $R/profiles/summarize_rocpd.py stats /tmp/pr_trace/t_results.db --min-ns 500000 | cut -c1-170; } > $OUT/kernel_trace.txt
+CMD="python $R/bench.py --workload c2 --no-secondary --steps 30 --warmup 5 --no-cpu-baseline --no-parity --latency-flips 0"
+rm -rf /tmp/pr_trace; rocprofv3 --kernel-trace -d /tmp/pr_trace -o t -- $CMD 2>/dev/null | grep "^{" | tail -1 > $OUT/bench_under_trace.json
+$CMD 2>/dev/null | grep "^{" | tail -1 > $OUT/bench_unprofiled_after.json
+{ echo "# rocprofv3 --kernel-trace -- $CMD"
+  python $R/profiles/summarize_rocpd.py stats /tmp/pr_trace/t_results.db --min-ns 500000 | grep -E "^#|^kernel|k_ingest_single" | cut -c1-170
+  python $R/profiles/summarize_rocpd.py list /tmp/pr_trace/t_results.db k_ingest_single --min-ns 500000 --skip 5
+  for f in bench_under_trace bench_unprofiled_after; do python -c "
+import json; j=json.loads(open('$OUT/$f.json').read()); r=j['roofline']; print('HIP events, $f run: avg_launch_ms %.4f frac %.4f ms_per_step %.4f' % (r['avg_launch_ms'], r['frac'], j['ms_per_step']))"; done; } > $OUT/kernel_trace.txt
 CMD2="python $R/bench.py --workload c2 --no-secondary --steps 3 --warmup 1 --no-cpu-baseline --no-parity --latency-flips 0"
 rm -rf /tmp/pr_fetch /tmp/pr_write
 rocprofv3 --pmc FETCH_SIZE -d /tmp/pr_fetch -o t -- $CMD2 > /dev/null 2>&1
@@ -34,6 +41,9 @@ rocprofv3 --pmc WRITE_SIZE -d /tmp/pr_c4w -o t -- $CMD4 > /dev/null 2>&1
 python - <<PY
 import json, subprocess
 R="$R"
+import sys
+sys.path.insert(0, R)
+import bench
 def pmc(db, k, min_ns=0):
     return json.loads(subprocess.check_output(["python", R+"/profiles/summarize_rocpd.py", "pmc", db, k, "--min-ns", str(min_ns)]))["counters"]
 CORR = ("FETCH_SIZE is in KiB and on gfx950 counts the 128-B requests of a 16-B/lane coalesced stream as 64 B: read "
@@ -42,7 +52,7 @@ f=pmc("/tmp/pr_fetch/t_results.db","k_ingest_single",500000)["FETCH_SIZE"]; w=pm
 out={"kernel":"lh::k_ingest_single","workload":"1e9 float64 samples, lognormal(ln 1e5, 1), one metric",
  "commands":["rocprofv3 --pmc FETCH_SIZE -- $CMD2","rocprofv3 --pmc WRITE_SIZE -- $CMD2"],
  "FETCH_SIZE_KiB_per_launch":f["avg"],"WRITE_SIZE_KiB_per_launch":w["avg"],"launches":f["launches"],
- "corrections":CORR,
+ "corrections":CORR, "sources": bench.source_hashes("k1"),
  "hbm_read_bytes_per_launch":f["avg"]*2048,"hbm_write_bytes_per_launch":w["avg"]*1024,"algorithmic_bytes_per_launch":8e9,
  "read_over_algorithmic":f["avg"]*2048/8e9,
  "avg_duration_us_under_pmc":{"FETCH_SIZE pass":f["avg_duration_us_profiled"],"WRITE_SIZE pass":w["avg_duration_us_profiled"]}}
@@ -60,7 +70,7 @@ for k in kernels:
               "avg_duration_us_under_pmc": cf["avg_duration_us_profiled"]}
     rd += r; wr += ww
 json.dump({"workload":"C3: 1e9 (uint32 id, float64 value) pairs over 1 024 Zipf(1.0) names, lognormal values",
- "pairs_per_call": 1000000000, "names": 1024,
+ "pairs_per_call": 1000000000, "names": 1024, "sources": bench.source_hashes("c3"),
  "commands":["rocprofv3 --pmc FETCH_SIZE -- $CMD3","rocprofv3 --pmc WRITE_SIZE -- $CMD3"], "corrections": CORR,
  "kernels": per, "hbm_read_bytes_per_call": rd, "hbm_write_bytes_per_call": wr, "hbm_bytes_per_call": rd+wr,
  "algorithmic_bytes_per_call": 12e9, "traffic_over_algorithmic": (rd+wr)/12e9}, open("$OUT/c3_pmc.json","w"), indent=1)
@@ -79,11 +89,44 @@ for k in k4:
               "avg_duration_us_under_pmc": cf["avg_duration_us_profiled"]}
     rd += r; wr += ww
 json.dump({"workload":"C4 one rank: 1.25e8 (uint32 id, float64 value) pairs over 65 536 Zipf(1.0) names, lognormal values",
- "pairs_per_call": 125000000, "names": 65536,
+ "pairs_per_call": 125000000, "names": 65536, "sources": bench.source_hashes("c4"),
  "commands":["rocprofv3 --pmc FETCH_SIZE -- $CMD4","rocprofv3 --pmc WRITE_SIZE -- $CMD4"], "corrections": CORR,
  "note": "the plan kernels (k_plan_count / k_plan_scan / k_plan_scatter: chunk descriptors only) and memsets are not in the sum",
  "kernels": per, "hbm_read_bytes_per_call": rd, "hbm_write_bytes_per_call": wr, "hbm_bytes_per_call": rd+wr,
  "algorithmic_bytes_per_call": 1.5e9, "traffic_over_algorithmic": (rd+wr)/1.5e9}, open("$OUT/c4_pmc.json","w"), indent=1)
+PY
+# 65 536 names, 1e9 pairs per call: bytes of every kernel of one call (tools/sweep.py), and its kernel split
+CMD5="python $R/tools/sweep.py --samples 1e9 --pairs 65536 --reps 3 --dists lognormal"
+rm -rf /tmp/pr_5t /tmp/pr_5f /tmp/pr_5w
+rocprofv3 --kernel-trace -d /tmp/pr_5t -o t -- $CMD5 > /dev/null 2>&1
+{ echo "# rocprofv3 --kernel-trace -- $CMD5"; python $R/profiles/summarize_rocpd.py stats /tmp/pr_5t/t_results.db | grep -E "^#|^kernel|lh::" | cut -c1-170; } > $OUT/c4_names_1e9_kernel_trace.txt
+rocprofv3 --pmc FETCH_SIZE -d /tmp/pr_5f -o t -- $CMD5 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE -d /tmp/pr_5w -o t -- $CMD5 > /dev/null 2>&1
+python - <<PY
+import json, subprocess, sys
+R="$R"
+sys.path.insert(0, R)
+import bench
+def pmc(db, k):
+    return json.loads(subprocess.check_output(["python", R+"/profiles/summarize_rocpd.py", "pmc", db, k]))["counters"]
+ks = ["k_survey_count_h", "k_survey_pick", "k_survey_plan_h", "k_survey_remap", "k_v3_prepare", "k_scatter4", "k_split_waves",
+      "k_split_records", "k_part_hist3", "k_plan_count", "k_plan_scan", "k_plan_scatter", "k_v3_report", "k_ingest_pairs"]
+per = {}; rd = wr = 0.0
+calls = pmc("/tmp/pr_5f/t_results.db", "k_scatter4")["FETCH_SIZE"]["launches"]
+for k in ks:
+    cf = pmc("/tmp/pr_5f/t_results.db", k).get("FETCH_SIZE"); cw = pmc("/tmp/pr_5w/t_results.db", k).get("WRITE_SIZE")
+    if not cf: continue
+    r = cf["avg"]*cf["launches"]*2048/calls; w = (cw["avg"]*cw["launches"]*1024/calls) if cw else 0.0
+    per[k] = {"launches_per_call": cf["launches"]/calls, "read_bytes_per_call": r, "write_bytes_per_call": w,
+              "avg_duration_us_under_pmc": cf["avg_duration_us_profiled"]}
+    rd += r; wr += w
+json.dump({"workload": "65 536 Zipf(1.0) names, 1e9 (uint32 id, float64 value) pairs, lognormal values: one lh_submit_pairs_device call",
+ "pairs_per_call": 1000000000, "names": 65536, "calls_in_the_run": calls, "sources": bench.source_hashes("c4"),
+ "commands": ["rocprofv3 --pmc FETCH_SIZE -- $CMD5", "rocprofv3 --pmc WRITE_SIZE -- $CMD5"],
+ "corrections": "FETCH_SIZE is in KiB and on gfx950 counts the 128-B requests of a 16-B/lane coalesced stream as 64 B: read bytes = FETCH_SIZE*1024*2 (MI355X_MICROARCH.md 'HBM'). WRITE_SIZE*1024, uncalibrated.",
+ "kernels": per, "hbm_read_bytes_per_call": rd, "hbm_write_bytes_per_call": wr, "hbm_bytes_per_call": rd+wr,
+ "algorithmic_bytes_per_call": 12e9, "traffic_over_algorithmic": (rd+wr)/12e9}, open("$OUT/c4_names_1e9_pmc.json", "w"), indent=1)
+print(json.dumps({"c4 1e9 read": rd, "write": wr, "ratio": (rd+wr)/12e9, "calls": calls}))
 PY
 cat $OUT/c4_kernel_trace.txt | cut -c1-150
 ls -la $OUT; tail -c 1500 $OUT/bench.json; grep -E "k_ingest_single" $OUT/kernel_trace.txt | cut -c1-140; cat $OUT/c3_kernel_trace.txt | cut -c1-150; python -c "
