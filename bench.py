@@ -2,7 +2,9 @@
 """bench.py -- loghisto hot path on MI355X: float64 samples/s bucketed.
 
 A "step" is one pass of the hot path over one resident batch: ingest, epoch flip, [N>1: merge], percentile /
-sum / count scan, results on the host, buffer recycled.
+sum / count scan, results on the host, buffer recycled.  Consecutive steps are software-pipelined as the reference
+itself is (its reaper reduces interval i while producers fill interval i + 1): ingest of step i + 1 is enqueued right
+after the flip of step i, before the host waits for step i's results (pipelined_steps).
 
 N = 1 (the headline): BASELINE.json configs[1] "Single-metric 1B float64 samples, 1xMI355X, one ingest kernel
 + one percentile scan" (SURVEY.md 8d "C2": lognormal(mu = ln 1e5, sigma = 1), seeded, generated on device).
@@ -48,6 +50,7 @@ K1_PMC = os.path.join("profiles", "r04_k1_pmc.json")
 C3_PMC = os.path.join("profiles", "r04_c3_pmc.json")
 C4_PMC = os.path.join("profiles", "r04_c4_pmc.json")
 C4_1E9_PMC = os.path.join("profiles", "r04_c4_names_1e9_pmc.json")
+PREWARM = 25                                             # untimed K1 launches before the warm-up steps (run_c2)
 
 
 # Kernel sources each committed PMC summary was measured on.  The summary records their hashes ("sources"); a summary
@@ -210,6 +213,32 @@ def timed_steps(step, steps, warmup, fence):
     return time.perf_counter() - t0, out
 
 
+def pipelined_steps(ingest, flip, finish, steps, warmup, fence):
+    """K steps driven the way the engine is meant to be driven -- and the reference is built: its reaper reduces
+    interval i on the worker pool while the producers already fill interval i + 1 (metrics.go:530-639).  Step i =
+    ingest_i, flip_i, reduce_i (merge, extract, results on the host, release); ingest_{i+1} is enqueued right after
+    flip_i, BEFORE the host waits for reduce_i's results, so that the small reduction runs beside the next ingest kernel
+    instead of leaving the GPU idle for a launch round trip per step.  Exactly `steps` ingests, flips and reductions
+    happen inside the timed region (the fences on both sides drain everything); nothing is skipped or carried over."""
+    def run(k, timed):
+        out = None
+        if k:
+            ingest(timed)
+        for i in range(k):
+            snap = flip()
+            if i + 1 < k:
+                ingest(timed)
+            out = finish(snap, timed)
+        return out
+
+    run(warmup, False)
+    fence()
+    t0 = time.perf_counter()
+    out = run(steps, True)
+    fence()
+    return time.perf_counter() - t0, out
+
+
 def dense_from_csr(off, keys, counts, M):
     import oracle
     dense = np.zeros((M, 65536), dtype=np.uint64)
@@ -260,7 +289,7 @@ def run_c2(args, la, stream, rank, world=1, dist=None, comm=0, frontend="none", 
     torch.cuda.synchronize()
     events = []
 
-    def step(timed):
+    def ingest(timed):
         if timed:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(stream)
@@ -268,7 +297,8 @@ def run_c2(args, la, stream, rank, world=1, dist=None, comm=0, frontend="none", 
         if timed:
             b.record(stream)
             events.append((a, b))
-        snap = eng.flip()
+
+    def finish(snap, timed):
         if world > 1:                                              # the only collective: the one row's window
             if comm:
                 snap.merge_rccl(comm, world, rank, 1, plan="allreduce")
@@ -288,7 +318,15 @@ def run_c2(args, la, stream, rank, world=1, dist=None, comm=0, frontend="none", 
             dist.barrier()
             torch.cuda.synchronize()
 
-    dt, out = timed_steps(step, args.steps, args.warmup, fence)
+    # The GPU's clocks take ~10 full-size launches to settle after an idle period (profiles/r04_kernel_trace.txt: the
+    # first launches of a process run 1.76, 1.68, 1.55, 1.45, 1.46, 1.34, 1.34, 1.30 ... ms against 1.25 in steady state),
+    # more than the W warm-up steps a caller may ask for: PREWARM untimed K1 launches into an interval that is thrown
+    # away, before the W warm-up steps.  Setup, like generating the data; disclosed in config.prewarm.
+    for _ in range(PREWARM):
+        eng.submit_device(0, data, n, stream=stream)
+    eng.flip().release()
+    torch.cuda.synchronize()
+    dt, out = pipelined_steps(ingest, eng.flip, finish, args.steps, args.warmup, fence)
     if dist is not None:                                           # the slowest rank's clock
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -333,7 +371,10 @@ def run_c2(args, la, stream, rank, world=1, dist=None, comm=0, frontend="none", 
                                + ("" if world == 1 else "; every rank buckets its own slice, the row's merged window is "
                                   "all-reduced at the flip (lh_snapshot_merge, LH_MERGE_ALLREDUCE), every rank extracts"),
                    "samples_per_gpu_per_step": n, "distribution": args.dist, "metrics": 1, "percentiles": PCTS,
-                   "ranks": world, "merge": "none" if world == 1 else frontend},
+                   "ranks": world, "merge": "none" if world == 1 else frontend,
+                   "prewarm": f"{PREWARM} untimed K1 launches before the W warm-up steps (clock ramp after idle)",
+                   "steps": "software-pipelined: ingest of step i + 1 is enqueued after the flip of step i, before the host "
+                            "waits for step i's results (as the reference's reaper overlaps reduction with ingest)"},
         "roofline": roofline(n * BYTES_SINGLE, k1_ms, "k_ingest_single", traffic=traffic,
                              traffic_source=traffic_source, frac_of_measured_copy_ceiling_6290=n * BYTES_SINGLE / (k1_ms * 1e-3) / 1e9 / 6290.0),
         "extract_latency_us": {"p50": float(np.percentile(lat_us, 50)), "p99": float(np.percentile(lat_us, 99)),
@@ -431,7 +472,7 @@ def run_c3(args, la, stream, rank, steps, warmup, latency_flips=0):
     torch.cuda.synchronize()
     events = []
 
-    def step(timed):
+    def ingest(timed):
         if timed:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(stream)
@@ -439,12 +480,13 @@ def run_c3(args, la, stream, rank, steps, warmup, latency_flips=0):
         if timed:
             b.record(stream)
             events.append((a, b))
-        snap = eng.flip()
+
+    def finish(snap, timed):
         out = snap.extract(PCTS, M)
         snap.release()
         return out
 
-    dt, out = timed_steps(step, steps, warmup, torch.cuda.synchronize)
+    dt, out = pipelined_steps(ingest, eng.flip, finish, steps, warmup, torch.cuda.synchronize)
     assert int(out["count"].sum()) == n
     ing_ms = sum(a.elapsed_time(b) for a, b in events) / len(events)
     c = eng.counters()
