@@ -581,7 +581,7 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=Non
         k0.record(xs)
         out = snap.extract_view(PCTS, last - first, first=first) # the names this rank owns, results in place (pinned)
         k1.record(xs)
-        out = {k: v.copy() for k, v in out.items() if k in ("count",)}
+        out = {k: v.copy() for k, v in out.items() if k in ("count", "nbuckets")}
         t2 = time.perf_counter()
         if timed:
             info.update(snap.merge_info() if comm else dict(tmerge.last_info))
@@ -704,6 +704,12 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=Non
                   "cell_bytes": info.get("cell_bytes"),
                   "send_bytes": info.get("send_bytes"), "recv_bytes": info.get("recv_bytes"),
                   "widest_row": info.get("widest_row"), "occupied_rows": info.get("occupied_rows"),
+                  # how dense the windows that travel are: occupied cells of the rows this rank owns
+                  # after the merge over the cells of their windows; a (key, count) list for rows under ~2/3 density would
+                  # move 6 B per occupied cell instead of 4 B per window cell
+                  "owned_occupied_cells": int(out["nbuckets"].sum()),
+                  "owned_window_density": (float(out["nbuckets"].sum()) * world / info["packed_cells"]
+                                           if info.get("packed_cells") else None),
                   "owned_rows_by_rank": bounds if world <= 16 else None,
                   "note": "device_ms: HIP events on the snapshot stream around the merge's steps of the last timed "
                           "step (dirty-range all-reduce, window plan, pack, collective, unpack; span includes the host "

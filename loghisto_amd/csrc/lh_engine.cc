@@ -2241,10 +2241,6 @@ int lh_set_option(lh_engine *e, int option, uint64_t value)
         e->small_disabled.store(value == 0);
         e->small_forced_off = value == 0;
         return LH_OK;
-#ifdef LH_TUNING
-    case 100: // timing ablations of the scatter kernels (results are wrong): tools/ builds only
-        return set_tune(e, [&](lh::PartTuning &t) { t.dbg = (uint32_t)value; });
-#endif
     default:
         return LH_EINVAL;
     }

@@ -55,7 +55,6 @@ struct PartTuning {
     bool v3 = true;                 // hashed survey + region scatter + in-place second level (lh_kernels_part3.h) for 8 193 .. 65 536 names
     size_t v3_min_samples = 0;      // 0 = default (2^24)
     uint32_t v3_log_w = 10;         // log2 of the second level's window width, 10 .. 13: the engine follows the survey's report
-    uint32_t dbg = 0;               // -DLH_TUNING builds only: timing ablations (results are wrong); ignored otherwise
 };
 
 // Partitioned mixed ingest (lh_kernels_part.hip).  part_scratch_bytes returns 0 when the launch

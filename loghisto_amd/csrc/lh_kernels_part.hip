@@ -53,12 +53,6 @@ constexpr int P1_TILE = P1_BLOCK * P1_SPT;
 #define LH_P1_WGS_PER_CU 3
 #endif
 constexpr uint32_t INVALID = 0xffffffffu;
-// timing ablations of the scatter kernels: a kernel argument in -DLH_TUNING builds, the constant 0 otherwise
-#ifdef LH_TUNING
-#define LH_DBG(arg) (arg)
-#else
-#define LH_DBG(arg) 0u
-#endif
 constexpr int P2_BLOCK = 1024;         // 16 waves: two workgroups (64 KiB windows each) fill a CU
 constexpr uint32_t P2_WINWORDS = 16384; // 64 KiB of uint32 windows per workgroup
 constexpr uint32_t SLOT_EXTRA = 1024;  // work slots beyond one per partition (measured: 512 is 25 % slower)
@@ -201,8 +195,8 @@ __device__ __forceinline__ void scatter_init(ScatterLds &L, uint32_t tid)
 template <class Prefetch>
 __device__ __forceinline__ void scatter_tile(ScatterLds &L, const uint32_t (&rec)[P1_SPT], const uint32_t (&pr)[P1_SPT],
                                              uint32_t *__restrict__ records, uint32_t *__restrict__ cdesc,
-                                             uint32_t pool_base, uint32_t tag_shift, uint32_t tag_base, uint32_t dbg,
-                                             uint32_t tid, Prefetch prefetch)
+                                             uint32_t pool_base, uint32_t tag_shift, uint32_t tag_base, uint32_t tid,
+                                             Prefetch prefetch)
 {
     const uint32_t lane = tid & 63, wave = tid >> 6;
     __syncthreads();
@@ -279,44 +273,32 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const uint32_t (&rec
     // 64-byte aligned, and the slots at or beyond n1 belong to the same emitted line, which the copy-out below
     // (after the barrier, so ordered after these stores) fills with this tile's records.
     static_assert(P1_BLOCK * 8 == NPMAX * LINE || LINE != 16, "one thread per 8 staged records");
-    if (!(dbg & 1u)) {
-        if (LINE == 16) {
-            const uint32_t p = tid >> 1, u0 = (tid & 1u) * 8u;
+    if (LINE == 16) {
+        const uint32_t p = tid >> 1, u0 = (tid & 1u) * 8u;
+        const uint32_t d = L.d1[p];
+        if (d != INVALID && u0 < L.n1[p]) {
+            const pu4_t a = *reinterpret_cast<const pu4_t *>(&L.stage[p * LINE + u0]);
+            const pu4_t b = *reinterpret_cast<const pu4_t *>(&L.stage[p * LINE + u0 + 4]);
+            *reinterpret_cast<pu4_t *>(&records[d + u0]) = a;
+            *reinterpret_cast<pu4_t *>(&records[d + u0 + 4]) = b;
+        }
+    } else {
+        for (uint32_t e = tid; e < NPMAX * LINE; e += P1_BLOCK) {
+            const uint32_t p = e / LINE, u = e % LINE;
             const uint32_t d = L.d1[p];
-            if (d != INVALID && u0 < L.n1[p]) {
-                const pu4_t a = *reinterpret_cast<const pu4_t *>(&L.stage[p * LINE + u0]);
-                const pu4_t b = *reinterpret_cast<const pu4_t *>(&L.stage[p * LINE + u0 + 4]);
-                *reinterpret_cast<pu4_t *>(&records[d + u0]) = a;
-                *reinterpret_cast<pu4_t *>(&records[d + u0 + 4]) = b;
-            }
-        } else {
-            for (uint32_t e = tid; e < NPMAX * LINE; e += P1_BLOCK) {
-                const uint32_t p = e / LINE, u = e % LINE;
-                const uint32_t d = L.d1[p];
-                if (d != INVALID && u < L.n1[p]) records[d + u] = L.stage[e];
-            }
+            if (d != INVALID && u < L.n1[p]) records[d + u] = L.stage[e];
         }
     }
     __syncthreads();
 
     // copy out: whole lines to HBM, the remainder of each partition into its staging line
     const uint32_t tile_total = L.total;
-    if (dbg & 8u) {
-        // TIMING-ONLY ablation (results are wrong): the same number of bytes leaves the CU as one 16-B store
-        // per lane instead of four 4-B stores, to tell store-issue cost from store-bandwidth cost
-        for (uint32_t i4 = tid * 4; i4 + 3 < tile_total; i4 += P1_BLOCK * 4) {
-            const pu4_t r4 = *reinterpret_cast<const pu4_t *>(&L.sorted[i4]);
-            const pu4_t t = L.tbl[r4.x >> 24];
-            const uint32_t dst = ((i4 < t.z ? t.x : t.y) + i4) & ~3u;
-            *reinterpret_cast<pu4_t *>(&records[dst]) = r4;
-        }
-    } else
     for (uint32_t i = tid; i < tile_total; i += P1_BLOCK) {
         const uint32_t r = L.sorted[i];
         const pu4_t t = L.tbl[r >> 24];
         const uint32_t E = t.w & 0xffffu;
         if (i < E) {
-            if (!(dbg & 1u)) records[(i < t.z ? t.x : t.y) + i] = r;
+            records[(i < t.z ? t.x : t.y) + i] = r;
         } else {
             L.stage[(r >> 24) * LINE + (i - E) + (t.w >> 16)] = r;
         }
@@ -395,9 +377,8 @@ __global__ __launch_bounds__(P1_BLOCK, HOT ? 4 : 6) void k_scatter_samples(const
                                                                            uint32_t chunks_per_wg,
                                                                            uint64_t *__restrict__ counts,
                                                                            uint32_t *__restrict__ ranges,
-                                                                           uint32_t *__restrict__ err, uint32_t dbg_arg)
+                                                                           uint32_t *__restrict__ err)
 {
-    const uint32_t dbg = LH_DBG(dbg_arg);
     __shared__ __attribute__((aligned(16))) ScatterLds L;
     extern __shared__ __attribute__((aligned(16))) unsigned char hot_smem[];
     HotLds &H = *reinterpret_cast<HotLds *>(hot_smem); // only touched when HOT
@@ -550,7 +531,7 @@ __global__ __launch_bounds__(P1_BLOCK, HOT ? 4 : 6) void k_scatter_samples(const
                     atomicOr(err, 1u); // reported by lh_sync / lh_extract
                     continue;
                 }
-                const uint32_t bin = (dbg & 2u) ? (uint32_t)(__double2loint(x) & 0xffff) : lh_bin_of(x, Tx);
+                const uint32_t bin = lh_bin_of(x, Tx);
                 if (HOT) {
                     const uint32_t e = H.hmap[id & (HOT_MAPW - 1)], hs = e & 0xffu;
                     if ((e >> 8) == id) {
@@ -568,7 +549,7 @@ __global__ __launch_bounds__(P1_BLOCK, HOT ? 4 : 6) void k_scatter_samples(const
         };
         if (full_tile) classify(std::true_type{});
         else classify(std::false_type{});
-        scatter_tile(L, rec, pr, records, cdesc, pool_base, 0u, 0u, dbg, tid,
+        scatter_tile(L, rec, pr, records, cdesc, pool_base, 0u, 0u, tid,
                      [&] { load_tile(tile + gridDim.x); });
     }
     scatter_drain(L, records, cdesc, pool_base, np, 0u, 0u, tid);
@@ -612,9 +593,8 @@ __global__ __launch_bounds__(P1_BLOCK, 6) void k_scatter_records(const uint32_t 
                                                                  const uint32_t *__restrict__ pool_start,
                                                                  uint32_t log_np, uint32_t log_ns,
                                                                  uint32_t *__restrict__ records,
-                                                                 uint32_t *__restrict__ cdesc, uint32_t dbg_arg)
+                                                                 uint32_t *__restrict__ cdesc)
 {
-    const uint32_t dbg = LH_DBG(dbg_arg);
     __shared__ __attribute__((aligned(16))) ScatterLds L;
     const uint32_t slot = blockIdx.x;
     if (slot >= *in_nslots) return;
@@ -662,7 +642,7 @@ __global__ __launch_bounds__(P1_BLOCK, 6) void k_scatter_records(const uint32_t 
                 pr[j] = sub | (atomicAdd(&L.cnt[sub], 1u) << 8);
             }
         }
-        scatter_tile(L, rec, pr, records, cdesc, pool_base, log_np, p1, dbg, tid, [&] { load_tile(tile + 1); });
+        scatter_tile(L, rec, pr, records, cdesc, pool_base, log_np, p1, tid, [&] { load_tile(tile + 1); });
     }
     scatter_drain(L, records, cdesc, pool_base, ns, log_np, p1, tid);
 }
@@ -1066,14 +1046,6 @@ hipError_t launch_ingest_pairs_part(Ids d_ids, const double *d_v, size_t n, uint
     unsigned char *base = static_cast<unsigned char *>(scratch);
     const LevelPtrs L1 = level_ptrs(base, P.off_rec1, P.off_cd1, P.off_sorted1, P.off_small1, P.np, P.extra1);
 
-    // Ablation bits exist in -DLH_TUNING builds only (tools/): 1 = P1 skips its record stores, 2 = P1 skips
-    // compress, 4 = skip P2, 8 = 16-B store ablation.  Results are wrong with any bit set; the product build
-    // compiles them out (LH_DBG() is the constant 0) and never reads the environment.
-#ifdef LH_TUNING
-    const uint32_t dbg = tune.dbg;
-#else
-    const uint32_t dbg = 0;
-#endif
 
     hipError_t e = hipMemsetAsync(L1.cdesc, 0xff, (size_t)P.nchunks1 * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
@@ -1083,10 +1055,10 @@ hipError_t launch_ingest_pairs_part(Ids d_ids, const double *d_v, size_t n, uint
         typedef std::remove_cv_t<std::remove_pointer_t<decltype(idp)>> IDT;
         if (P.hot)
             hipLaunchKernelGGL((k_scatter_samples<true, IDT>), dim3(P.g1), dim3(P1_BLOCK), HOT_LDS_BYTES, s, idp, d_v, n,
-                               nmetrics, P.log_np, d_Tx, L1.records, L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, dbg);
+                               nmetrics, P.log_np, d_Tx, L1.records, L1.cdesc, P.chunks_per_wg, counts, ranges, d_err);
         else
             hipLaunchKernelGGL((k_scatter_samples<false, IDT>), dim3(P.g1), dim3(P1_BLOCK), 0, s, idp, d_v, n, nmetrics,
-                               P.log_np, d_Tx, L1.records, L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, dbg);
+                               P.log_np, d_Tx, L1.records, L1.cdesc, P.chunks_per_wg, counts, ranges, d_err);
     };
     if (d_ids.width == 2) scatter(d_ids.u16()); else scatter(d_ids.u32());
     e = run_plan(L1, P.nchunks1, P.np, P.log_ns ? P.ns + 1 : 0u, P.extra1, s);
@@ -1102,15 +1074,14 @@ hipError_t launch_ingest_pairs_part(Ids d_ids, const double *d_v, size_t n, uint
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_scatter_records, dim3(P.np + P.extra1), dim3(P1_BLOCK), 0, s, L1.records, L1.cdesc,
                            L1.sorted, L1.part_start, L1.slots, L1.nslots, L1.pool_start, P.log_np, P.log_ns,
-                           L2.records, L2.cdesc, dbg);
+                           L2.records, L2.cdesc);
         e = run_plan(L2, P.nchunks2, P.nq, 0u, SLOT_EXTRA, s);
         if (e != hipSuccess) return e;
         last = &L2;
     }
-    if (!(dbg & 4u))
-        hipLaunchKernelGGL(k_part_hist, dim3((P.log_ns ? P.nq : P.np) + SLOT_EXTRA), dim3(P2_BLOCK), P2_LDS_BYTES, s, last->records,
-                           last->cdesc, last->sorted, last->part_start, last->slots, last->nslots, P.log_nq, P.mpp2,
-                           P.log_w, counts, ranges);
+    hipLaunchKernelGGL(k_part_hist, dim3((P.log_ns ? P.nq : P.np) + SLOT_EXTRA), dim3(P2_BLOCK), P2_LDS_BYTES, s, last->records,
+                       last->cdesc, last->sorted, last->part_start, last->slots, last->nslots, P.log_nq, P.mpp2, P.log_w,
+                       counts, ranges);
     return hipGetLastError();
 }
 

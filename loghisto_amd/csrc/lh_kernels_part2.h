@@ -309,10 +309,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter2(const IDT *__restrict__ i
                                                        const uint32_t *__restrict__ g_hdr, uint32_t cells,
                                                        rec16_t *__restrict__ records, uint32_t *__restrict__ cdesc,
                                                        uint32_t chunks_per_wg, uint64_t *__restrict__ counts,
-                                                       uint32_t *__restrict__ ranges, uint32_t *__restrict__ err,
-                                                       uint32_t dbg_arg)
+                                                       uint32_t *__restrict__ ranges, uint32_t *__restrict__ err)
 {
-    const uint32_t dbg = LH_DBG(dbg_arg);
     // ONE LDS allocation: [Scatter2Lds][name table][hot windows].  Phases 1 and 3 address it through word / halfword
     // offsets from its base, so that a sample's single LDS operation has one form whatever the sample turns into.
     typedef Scatter2LdsT<BLOCK, NPT> LdsT;
@@ -413,19 +411,14 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter2(const IDT *__restrict__ i
                 const bool ok = live && raw < nmetrics;
                 rare |= (live && !ok) ? 1u : 0u;
                 id[k] = ok ? raw : INVALID;
-                ne[k] = nt[(ok && !(dbg & 64u)) ? raw : 0u]; // 64: every sample reads entry 0
+                ne[k] = nt[ok ? raw : 0u];
             }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int j = h + k;
                 const double x = (j & 1) ? val[j >> 1].y : val[j >> 1].x;
                 bool u;
-                if (dbg & 2u) { // ablation: no compress -- a pseudo-bin near the name's window origins
-                    bin[k] = (ne[k].org >> 16) + ((uint32_t)__double2loint(x) & 1023u);
-                    u = false;
-                } else {
-                    bin[k] = lh_bin_fast(x, u);
-                }
+                bin[k] = lh_bin_fast(x, u);
                 if (u) unc |= 1u << k;
             }
             if (unc) { // inside the guard band of a bucket threshold (1 sample in ~4 000): exact table compare
@@ -449,7 +442,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter2(const IDT *__restrict__ i
                 if (valid && !hot && !cold) miss |= 1u << k;
             }
 #pragma unroll
-            for (int k = 0; k < 4; k++) rank[k] = (dbg & 32u) ? 0u : atomicAdd(lds32 + where[k], 1u); // 32: no LDS atomics
+            for (int k = 0; k < 4; k++) rank[k] = atomicAdd(lds32 + where[k], 1u);
 #pragma unroll
             for (int k = 0; k < 4; k++)
                 if (pr[h + k] != INVALID) pr[h + k] |= rank[k] << 8;
@@ -466,10 +459,6 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter2(const IDT *__restrict__ i
         }
         if (rare) atomicOr(err, 1u); // an id >= nmetrics: reported by lh_sync / lh_extract
         __syncthreads();                                   // barrier A: counts complete
-        if (dbg & 16u) { // ablation: phase 1 and the loads only
-            load_tile(tile + 2 * (size_t)gridDim.x, idv, val);
-            return;
-        }
         // this register set is free again: it receives the tile two steps ahead (a whole tile period in flight)
         load_tile(tile + 2 * (size_t)gridDim.x, idv, val);
 
@@ -547,10 +536,6 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter2(const IDT *__restrict__ i
             }
         }
         __syncthreads();                                   // barrier B: plan of the tile is visible
-        if (dbg & 128u) { // ablation: no placement, no copy-out
-            if (tid < NPMAX) { L.sf[tid] = L.newsf[tid]; L.cnt[tid] = 0; }
-            return;
-        }
 
         // ---- phase 3: place the records (again one form for every sample: eight table reads, eight stores)
         if (tid < NPMAX) { L.sf[tid] = L.newsf[tid]; L.cnt[tid] = 0; }
@@ -568,19 +553,16 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter2(const IDT *__restrict__ i
             }
         }
         __syncthreads();                                   // barrier C: lines complete
-        if (dbg & 256u) return; // ablation: no copy-out
 
         // ---- phase 4: copy whole lines out, 16 bytes per lane
         const uint32_t npieces = L.nlines * 4;
-        if (!(dbg & 1u)) {
-            for (uint32_t i = tid; i < npieces; i += V2_BLOCK) {
-                const uint32_t line = i >> 2, q = i & 3u;
-                const uint32_t p = L.owner[line];
-                const uint32_t u = (line - L.lbase[p]) * LINE2 + q * 8;
-                const pu4_t r4 = *reinterpret_cast<const pu4_t *>(&L.sorted[line * LINE2 + q * 8]);
-                const uint32_t dst = (u < L.room[p] ? L.dA[p] : L.dB[p]) + u;
-                hidden_store_u4(records + dst, r4);
-            }
+        for (uint32_t i = tid; i < npieces; i += V2_BLOCK) {
+            const uint32_t line = i >> 2, q = i & 3u;
+            const uint32_t p = L.owner[line];
+            const uint32_t u = (line - L.lbase[p]) * LINE2 + q * 8;
+            const pu4_t r4 = *reinterpret_cast<const pu4_t *>(&L.sorted[line * LINE2 + q * 8]);
+            const uint32_t dst = (u < L.room[p] ? L.dA[p] : L.dB[p]) + u;
+            hidden_store_u4(records + dst, r4);
         }
         // the tile's out-of-window samples, one per thread: aggregated in the small LDS table, else a global atomic
         {
@@ -762,9 +744,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
                                                        uint32_t *__restrict__ cdesc, uint32_t chunks_per_wg,
                                                        uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
                                                        uint32_t *__restrict__ err,
-                                                       unsigned long long *__restrict__ rstat, uint32_t dbg_arg)
+                                                       unsigned long long *__restrict__ rstat)
 {
-    const uint32_t dbg = LH_DBG(dbg_arg);
     // ONE LDS allocation: [Scatter3Lds][name table][regions][hot windows]
     typedef Scatter3LdsT<NPT> LdsT;
     static_assert(sizeof(LdsT) % 16 == 0, "the name table follows the struct in LDS");
@@ -812,7 +793,6 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
     pd2_t vaa[NPAIR], vab[NPAIR];
     auto load_tile = [&](size_t tile, typename IS::raw_t (&di)[NPAIR], pd2_t (&dv)[NPAIR]) {
         if (tile >= ntiles) tile = ntiles - 1; // the two tiles past the end that the pipeline touches (uniform)
-        if (dbg & 512u) tile = blockIdx.x;     // ablation: every load hits L2 (the workgroup re-reads its first tile)
         const size_t it = tile * (V3_TILE / 2) + tid;
         const pd2_t *vt = vp + tile * (V3_TILE / 2) + tid;
 #pragma unroll
@@ -844,7 +824,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
                 const bool ok = raw < nmetrics; // an id >= nmetrics is reported, the sample skipped
                 rare |= ok ? 0u : 1u;
                 id[k] = ok ? raw : INVALID;
-                ne[k] = nt[(ok && !(dbg & 64u)) ? raw : 0u];
+                ne[k] = nt[ok ? raw : 0u];
                 pe[k] = L.pt[raw & pmask];
             }
 #pragma unroll
@@ -852,15 +832,10 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
                 const int j = h + k;
                 const double x = (j & 1) ? val[j >> 1].y : val[j >> 1].x;
                 bool u;
-                if (dbg & 2u) { // ablation: no compress -- a pseudo-bin near the name's window origins
-                    bin[k] = (ne[k].org >> 16) + ((uint32_t)__double2loint(x) & 1023u);
-                    u = false;
-                } else {
-                    bin[k] = lh_bin_fast(x, u);
-                }
+                bin[k] = lh_bin_fast(x, u);
                 if (u) unc |= 1u << k;
             }
-            if (unc && !(dbg & 1024u)) { // inside the guard band of a bucket threshold (1 sample in ~4 000): exact table compare
+            if (unc) { // inside the guard band of a bucket threshold (1 sample in ~4 000): exact table compare
 #pragma unroll
                 for (int k = 0; k < BATCH; k++) {
                     const int j = h + k;
@@ -880,7 +855,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
             }
 #pragma unroll
             for (int k = 0; k < BATCH; k++) {
-                rank[k] = (dbg & 32u) ? 0u : atomicAdd(lds32 + where[k], 1u); // 32: no LDS atomics
+                rank[k] = atomicAdd(lds32 + where[k], 1u);
             }
 #pragma unroll
             for (int k = 0; k < BATCH; k++) {
@@ -910,8 +885,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
         if (tid == BLOCK - 1) L.missn[par ^ 1u] = 0; // the other parity's queue was drained in the previous tile
         constexpr uint32_t TPP = SC3_FLUSH_TPP;
         static_assert(TPP == 1 || TPP == 2 || TPP == 4, "pieces of a 64-byte line per thread: 4 / TPP");
-        if (!(dbg & 16u)) {
-          if (tid < NPT * TPP) {
+        if (tid < NPT * TPP) {
             uint32_t t2 = tid;
             asm volatile("" : "+v"(t2)); // keeps this phase's address arithmetic inside the loop (see k_scatter2)
             const uint32_t p = t2 / TPP, q = t2 % TPP;
@@ -946,10 +920,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
 #pragma unroll
                     for (uint32_t i = 0; i < 4 / TPP; i++)
                         r4[i] = *reinterpret_cast<const pu4_t *>(src + l * LINE2 + (q + i * TPP) * 8);
-                    if (!(dbg & 1u)) {
 #pragma unroll
-                        for (uint32_t i = 0; i < 4 / TPP; i++) hidden_store_u4(records + dst + (q + i * TPP) * 8, r4[i]);
-                    }
+                    for (uint32_t i = 0; i < 4 / TPP; i++) hidden_store_u4(records + dst + (q + i * TPP) * 8, r4[i]);
                 }
                 // the leftover (less than a piece) moves to the front of the region (its slots are this thread's own:
                 // source and destination are at least one piece apart)
@@ -962,9 +934,6 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
                 }
             }
             if (q == 0) L.cnt[p] = left;
-          }
-        } else if (tid < NPT) {
-            L.cnt[tid] = 0; // ablation: phase 1 and the loads only
         }
         // the tile's out-of-window samples, one per thread: aggregated in the small LDS table, else a global atomic
         {
@@ -1299,11 +1268,6 @@ static hipError_t launch_part2_t(const IDT *d_ids, const double *d_v, size_t n, 
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-#ifdef LH_TUNING
-    const uint32_t dbg = tune.dbg;
-#else
-    const uint32_t dbg = 0;
-#endif
     unsigned char *base = static_cast<unsigned char *>(scratch);
     LevelPtrs L1 = level_ptrs(base, P.off_rec, P.off_cd, P.off_sorted, P.off_small, P.np, P2V2_SLOT_EXTRA);
     rec16_t *records = reinterpret_cast<rec16_t *>(base + P.off_rec);
@@ -1337,11 +1301,11 @@ static hipError_t launch_part2_t(const IDT *d_ids, const double *d_v, size_t n, 
         if (P.shape == 3)
             hipLaunchKernelGGL((k_scatter3<512, 128, SC3_BATCH, IDT>), dim3(P.g1), dim3(512), p1_dyn, s, d_ids, d_v, nt_full, nmetrics,
                                P.log_np, P.log_w, d_Tx, g_nt, g_hs, g_hdr, g_pt, P.region_recs, P.cells, records,
-                               L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, region_stat, dbg);
+                               L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, region_stat);
         else
             hipLaunchKernelGGL((k_scatter3<1024, 256, SC3_BATCH, IDT>), dim3(P.g1), dim3(1024), p1_dyn, s, d_ids, d_v, nt_full,
                                nmetrics, P.log_np, P.log_w, d_Tx, g_nt, g_hs, g_hdr, g_pt, P.region_recs, P.cells,
-                               records, L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, region_stat, dbg);
+                               records, L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, region_stat);
         if (done < n) {
             e = launch_ingest_pairs(d_ids + done, d_v + done, n - done, counts, ranges, nmetrics, d_Tx, d_err, num_cus, s);
             if (e != hipSuccess) return e;
@@ -1350,17 +1314,16 @@ static hipError_t launch_part2_t(const IDT *d_ids, const double *d_v, size_t n, 
     else if (P.shape == 1)
         hipLaunchKernelGGL((k_scatter2<512, 128, IDT>), dim3(P.g1), dim3(512), p1_dyn, s, d_ids, d_v, n, nmetrics, P.log_np,
                            P.log_w, d_Tx, g_nt, g_hs, g_hdr, P.cells, records, L1.cdesc, P.chunks_per_wg, counts,
-                           ranges, d_err, dbg);
+                           ranges, d_err);
     else
         hipLaunchKernelGGL((k_scatter2<1024, 256, IDT>), dim3(P.g1), dim3(1024), p1_dyn, s, d_ids, d_v, n, nmetrics,
                            P.log_np, P.log_w, d_Tx, g_nt, g_hs, g_hdr, P.cells, records, L1.cdesc, P.chunks_per_wg,
-                           counts, ranges, d_err, dbg);
+                           counts, ranges, d_err);
     e = run_plan(L1, P.nchunks, P.np, 0u, P2V2_SLOT_EXTRA, s);
     if (e != hipSuccess) return e;
-    if (!(dbg & 4u))
-        hipLaunchKernelGGL(k_part_hist2, dim3(P.np + P2V2_SLOT_EXTRA), dim3(P2_BLOCK), P2V2_LDS_BYTES, s, records, L1.cdesc,
-                           L1.sorted, L1.part_start, L1.slots, L1.nslots, P.log_np, P.mpp, P.log_w, nmetrics, g_nt,
-                           counts, ranges);
+    hipLaunchKernelGGL(k_part_hist2, dim3(P.np + P2V2_SLOT_EXTRA), dim3(P2_BLOCK), P2V2_LDS_BYTES, s, records, L1.cdesc,
+                       L1.sorted, L1.part_start, L1.slots, L1.nslots, P.log_np, P.mpp, P.log_w, nmetrics, g_nt, counts,
+                       ranges);
     return hipGetLastError();
 }
 
