@@ -19,7 +19,7 @@ rm -rf /tmp/pr_trace; rocprofv3 --kernel-trace -d /tmp/pr_trace -o t -- $CMD 2>/
 $CMD 2>/dev/null | grep "^{" | tail -1 > $OUT/bench_unprofiled_after.json
 { echo "# rocprofv3 --kernel-trace -- $CMD"
   python $R/profiles/summarize_rocpd.py stats /tmp/pr_trace/t_results.db --min-ns 500000 | grep -E "^#|^kernel|k_ingest_single" | cut -c1-170
-  python $R/profiles/summarize_rocpd.py list /tmp/pr_trace/t_results.db k_ingest_single --min-ns 500000 --skip 5
+  python $R/profiles/summarize_rocpd.py list /tmp/pr_trace/t_results.db k_ingest_single --min-ns 500000 --skip 30
   for f in bench_under_trace bench_unprofiled_after; do python -c "
 import json; j=json.loads(open('$OUT/$f.json').read()); r=j['roofline']; print('HIP events, $f run: avg_launch_ms %.4f frac %.4f ms_per_step %.4f' % (r['avg_launch_ms'], r['frac'], j['ms_per_step']))"; done; } > $OUT/kernel_trace.txt
 CMD2="python $R/bench.py --workload c2 --no-secondary --steps 3 --warmup 1 --no-cpu-baseline --no-parity --latency-flips 0"
