@@ -34,6 +34,7 @@ _PROGRAMS = [
     ("tools/c5_driver.cc", "c5_driver"),             # BASELINE config 5 driver
     ("tools/wire_bench.cc", "wire_bench"),           # per-key vs bulk (K6) ProcessedMetricSet serialization
     ("tools/latency.cc", "latency"),                 # flip -> extract latency at the C ABI
+    ("tools/hostfed_native.cc", "hostfed_native"),   # host-fed pairs from native threads through the in-place staging API
 ]
 
 
