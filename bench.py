@@ -959,14 +959,76 @@ def main():
     if world > 1:
         comm, frontend, why = make_comm(world, rank, dist)   # ONE communicator for the job: headline and secondary.c4
 
+    def emit(res):
+        res = dict(res)
+        res.pop("unit", None)
+        res.pop("steps", None)
+        # RCCL prints its version banner through C stdio: push it out first so that the JSON line is the last one
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        sys.stdout.flush()
+        print(json.dumps({**base, **res}), flush=True)
+
+    res, clean = run_job(args, la, stream, rank, world, dist, comm, frontend, why, workload,
+                         on_headline=(lambda r: _Watchdog(r, emit)) if (world > 1 and rank == 0) else None)
+    if not clean:
+        # a secondary leg failed on this rank while the others may still sit in one of its collectives: no barrier, no
+        # communicator teardown (either could hang) -- the headline is complete, print it and leave
+        if rank == 0:
+            emit(res)
+        sys.stdout.flush()
+        os._exit(0)
+    if comm:
+        from loghisto_amd import rccl
+        rccl.comm_destroy(comm)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        emit(res)
+
+
+class _Watchdog:
+    """Several ranks, rank 0 only: the headline line is complete when the secondary config-4 leg starts; that leg is
+    the first code of this repository to run real multi-rank RCCL collectives over 157 MB buffers.  If it has not come
+    back after LIMIT seconds (a rank died inside a collective, a hang), print the headline with the leg marked
+    "timed out" and leave, instead of losing the scaling point with it."""
+    LIMIT = 300.0
+
+    def __init__(self, headline, emit):
+        self.t = threading.Timer(self.LIMIT, self.fire)
+        self.headline, self.emit = headline, emit
+        self.t.daemon = True
+        self.t.start()
+
+    def fire(self):
+        r = dict(self.headline)
+        r["secondary"] = {"c4": {"failed": f"no result after {self.LIMIT:.0f} s: abandoned so that the headline is not lost"}}
+        self.emit(r)
+        os._exit(0)
+
+    def cancel(self):
+        self.t.cancel()
+
+
+def run_job(args, la, stream, rank, world, dist, comm, frontend, why, workload="c2", on_headline=None, ref_comm=None):
+    """What main() runs between set-up and printing (also driven by tests/_bench_ranks_driver.py with ranks as threads):
+    the headline, then the secondary legs.  Returns (result, clean); clean is False when a secondary leg raised on this
+    rank of a multi-rank job.  on_headline(result) is called when the headline is complete and returns an object whose
+    cancel() is called when the secondary legs are back.  ref_comm: a one-rank communicator for config 4's one-rank
+    reference (tests: from the stub RCCL); None makes a real one."""
+    clean = True
+
     def c4_with_reference():
-        """config 4 on these ranks, with the same slice on rank 0's GPU alone as its own one-rank reference (the curve's
-        N = 1 line is the C2 headline -- a different workload from this one)."""
-        ref = None
+        """config 4 on these ranks, with the same slice on this rank's GPU alone as its own one-rank reference (the
+        curve's N = 1 line is the C2 headline -- a different workload from this one)."""
         saved = args.no_parity
         args.no_parity = True
         try:
-            one = run_c4(args, la, stream, 0, 1, None, steps=5, warmup=2)
+            one = run_c4(args, la, stream, 0, 1, None, steps=5, warmup=2, comm_override=ref_comm)
             ref = {"value": one["value"], "ms_per_step": one["ms_per_step"], "ranks": 1,
                    "note": "same C4 slice on this rank's GPU alone, measured in this process before the N-rank steps"}
         except Exception as exc:  # noqa: BLE001
@@ -992,13 +1054,17 @@ def main():
                         ("c5", run_c5))
             else:
                 legs = (("c4", c4_with_reference),)
+            guard = on_headline(res) if on_headline else None
             for name, fn in legs:
                 try:
                     sec[name] = fn()
                 except Exception as exc:  # noqa: BLE001 -- a secondary leg must not take the headline down
-                    if world > 1:
-                        raise           # ... but on several ranks a rank that drops out of a collective hangs the others
                     sec[name] = {"failed": repr(exc)[:300]}
+                    if world > 1:
+                        clean = False   # the other ranks may sit in a collective this rank left: see main()
+                        break
+            if guard:
+                guard.cancel()
             res["secondary"] = sec
     elif workload == "c3":
         res = run_c3(args, la, stream, rank, args.steps, args.warmup, latency_flips=min(args.latency_flips, 200))
@@ -1007,23 +1073,7 @@ def main():
     else:
         res = run_c4(args, la, stream, rank, world, dist, args.steps, args.warmup)
         res["value_per_gpu"] = res["value"]
-    if comm:
-        from loghisto_amd import rccl
-        rccl.comm_destroy(comm)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        res.pop("unit", None)
-        res.pop("steps", None)
-        # RCCL prints its version banner through C stdio: push it out first so that the JSON line is the last one
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:  # noqa: BLE001
-            pass
-        sys.stdout.flush()
-        print(json.dumps({**base, **res}), flush=True)
+    return res, clean
 
 
 if __name__ == "__main__":

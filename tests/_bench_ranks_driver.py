@@ -8,7 +8,9 @@ counts, the probe rows compared cell by cell after the merge, the merge report) 
 tests/cpp/rccl_stub.cc as the RCCL of lh_snapshot_merge and a thread-rendezvous stand-in for the few
 torch.distributed calls they make.
 usage: python _bench_ranks_driver.py N names slice        (config 4)
-       python _bench_ranks_driver.py N c2 samples         (the headline)"""
+       python _bench_ranks_driver.py N c2 samples         (the headline)
+       python _bench_ranks_driver.py N job samples        (bench.run_job: what main() runs -- the headline, then config 4 with
+                                                           its one-rank reference under secondary.c4)"""
 import ctypes as C
 import json
 import os
@@ -58,8 +60,8 @@ class ThreadDist:
 
 
 def main():
-    c2 = sys.argv[2] == "c2"
-    nranks, names, slice_pairs = int(sys.argv[1]), (1 if c2 else int(sys.argv[2])), float(sys.argv[3])
+    c2, job = sys.argv[2] == "c2", sys.argv[2] == "job"
+    nranks, names, slice_pairs = int(sys.argv[1]), (1 if c2 else 9000 if job else int(sys.argv[2])), float(sys.argv[3])
     import torch
     import bench
     import loghisto_amd as la
@@ -70,7 +72,13 @@ def main():
     comms = (C.c_void_p * nranks)()
     assert stub.stub_comm_create(nranks, comms) == 0
     args = types.SimpleNamespace(names=names, c4_slice=slice_pairs, no_parity=False, samples=slice_pairs, dist="lognormal",
-                                 steps=2, warmup=1, latency_flips=3, no_cpu_baseline=True)
+                                 steps=2, warmup=1, latency_flips=3, no_cpu_baseline=True, no_secondary=False)
+    ref_comms = []
+    if job:                           # one-rank communicators (stub) for config 4's one-rank reference on every rank
+        for _ in range(nranks):
+            c1 = (C.c_void_p * 1)()
+            assert stub.stub_comm_create(1, c1) == 0
+            ref_comms.append(c1)
     dist = ThreadDist(nranks)
     results, errors = [None] * nranks, []
 
@@ -80,7 +88,10 @@ def main():
             dist.bind(r)
             stream = torch.cuda.Stream()
             torch.cuda.set_stream(stream)
-            if c2:
+            if job:
+                results[r] = bench.run_job(args, la, stream, r, nranks, dist, comms[r], "c-abi: lh_snapshot_merge -> RCCL (stub)",
+                                           "", "c2", ref_comm=ref_comms[r][0])
+            elif c2:
                 results[r] = bench.run_c2(args, la, stream, r, nranks, dist if nranks > 1 else None,
                                           comms[r] if nranks > 1 else 0, "c-abi: lh_snapshot_merge -> RCCL (stub)")
             else:
@@ -94,6 +105,15 @@ def main():
     [t.join(timeout=600) for t in th]
     assert not errors, errors
     res = results[0]
+    if job:
+        res, clean = res
+        assert all(c for _, c in results), [c for _, c in results]
+        c4 = res["secondary"]["c4"]
+        print(json.dumps({"ok": True, "ranks": nranks, "parity": res["parity"], "config": res["config"],
+                          "c4_parity": c4["parity"], "c4_ranks": c4["config"]["ranks"], "c4_merge": c4["config"]["merge"],
+                          "c4_one_rank_reference": c4["one_rank_reference"], "c4_efficiency": c4.get("efficiency_vs_one_rank"),
+                          "values": [r[0]["value"] for r in results]}))
+        return
     if c2:
         print(json.dumps({"ok": True, "ranks": nranks, "parity": res["parity"], "merge": res.get("merge"),
                           "config": res["config"], "values": [r["value"] for r in results],

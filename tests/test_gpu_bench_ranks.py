@@ -48,3 +48,16 @@ def test_headline_step_with_ranks_as_threads(native_lib, torch_cuda, nranks):
         assert res["config"]["merge"].startswith("c-abi") and res["parity"]["ranks_with_the_exact_merged_row"] == nranks
         assert res["merge"]["cell_bytes"] == 4 and 0 < res["merge"]["packed_cells"] < 4000
         assert len(set(res["values"])) == 1            # every rank reports the job's value (max-over-ranks clock)
+
+
+def test_whole_job_with_ranks_as_threads(native_lib, torch_cuda):
+    """bench.run_job, i.e. everything `python bench.py --gpus 2` does between set-up and printing: the headline on two
+    ranks, then config 4 on the same ranks with its one-rank reference under secondary.c4 -- one communicator for both."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_bench_ranks_driver.py"), "2", "job", "3000001"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-3000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["ok"] and res["parity"]["exact"] and res["config"]["ranks"] == 2
+    assert res["c4_parity"]["exact"] and res["c4_ranks"] == 2 and res["c4_merge"].startswith("c-abi")
+    assert res["c4_one_rank_reference"].get("value", 0) > 0 and 0 < res["c4_efficiency"] < 10
