@@ -369,13 +369,15 @@ int lh_get_counters(lh_engine *e, lh_counters *out);
  *   LH_OPT_PART_V3            0 / 1: the third generation of the partitioned path (hashed survey, region scatter of
  *                             4-byte records, a second level that counts each partition's frequent names in place;
  *                             default 1; used for 8 193 .. 65 536 names -- BASELINE config 4's name count)
- *   LH_OPT_PART_V3_MIN_PAIRS  smallest launch that takes it (default 2^24; >= 2^17: tests exercise it on small inputs)
+ *   LH_OPT_PART_V3_MIN_PAIRS  smallest launch that takes it (default 2^18; >= 2^17: tests exercise it on small inputs)
  *   LH_OPT_SURVEY_EVERY       8 193 .. 65 536 names: a call may run on the survey of an earlier call (hot names, region
  *                             sizes, per-partition ranking stay in the scratch block) until this many calls have used
  *                             it (default 32; 1 = every call surveys).  Only while the stream looks the same: a survey
  *                             is also repeated when the window width changed, when anything else used the block, or
  *                             when more than 2 % of the pairs of the calls completed since took an overflow / window-miss
  *                             path.  A stale survey costs speed, never exactness
+ *   LH_OPT_PART_MIN_PAIRS     smallest mixed launch that takes a partitioned path at all (below it: one global atomic per
+ *                             sample); 0 = the default, which follows the name count; >= 65 536 otherwise
  *   LH_OPT_LANE_ZERO_COPY     0 / 1: the ingest kernels read the pinned staging buffers of lh_submit* / lh_reserve_pairs
  *                             in place over PCIe (default 1) instead of after a hipMemcpyAsync into HBM (0)
  *   LH_OPT_PART_V3_LOG_W      log2 of its second-level window width, 10 .. 13 (32 .. 4 names per fine partition);
@@ -397,7 +399,8 @@ enum {
     LH_OPT_PART_V3_MIN_PAIRS = 13,
     LH_OPT_PART_V3_LOG_W = 14,
     LH_OPT_LANE_ZERO_COPY = 15,
-    LH_OPT_SURVEY_EVERY = 16
+    LH_OPT_SURVEY_EVERY = 16,
+    LH_OPT_PART_MIN_PAIRS = 17
 };
 int lh_set_option(lh_engine *e, int option, uint64_t value);
 

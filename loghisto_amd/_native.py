@@ -50,6 +50,7 @@ OPT_PART_V2, OPT_PART_V2_MIN_PAIRS, OPT_PART_V2_SHAPE = 9, 10, 11
 OPT_PART_V3, OPT_PART_V3_MIN_PAIRS, OPT_PART_V3_LOG_W = 12, 13, 14
 OPT_LANE_ZERO_COPY = 15
 OPT_SURVEY_EVERY = 16
+OPT_PART_MIN_PAIRS = 17
 
 
 class LhExtractView(C.Structure):

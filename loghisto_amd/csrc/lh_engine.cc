@@ -2225,6 +2225,9 @@ int lh_set_option(lh_engine *e, int option, uint64_t value)
             e->v3_log_w_fixed = value != 0;
             t.v3_log_w = value ? (uint32_t)value : 10u;
         });
+    case LH_OPT_PART_MIN_PAIRS:
+        if (value != 0 && (value < 65536 || value > (uint64_t(1) << 31))) return LH_EINVAL;
+        return set_tune(e, [&](lh::PartTuning &t) { t.part_min_samples = (size_t)value; });
     case LH_OPT_SURVEY_EVERY: {
         if (value < 1 || value > 1024) return LH_EINVAL;
         std::lock_guard<std::mutex> g(e->scratch_mu);

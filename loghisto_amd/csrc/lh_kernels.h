@@ -47,6 +47,7 @@ struct PartTuning {
     uint32_t names_per_part = 4;    // names per LDS-reduce partition: 4 gives every name a 4 096-bin window in P2
     uint32_t two_level_above = 32;  // second scatter level when a level-1 partition holds more names than this
     uint32_t hot_min_tiles = 32;    // hot-name windows in P1 when every workgroup gets at least this many tiles
+    size_t part_min_samples = 0;    // smallest launch that is partitioned at all (0 = default by name count); below: direct atomics
     bool hot = true;                // hot-name windows allowed at all
     bool v2 = true;                 // survey + 2-byte-record path (lh_kernels_part2.h) for <= 8 192 names
     size_t v2_min_samples = 0;      // 0 = default (2^24): smaller launches do not amortise the survey

@@ -82,9 +82,16 @@ static uint32_t ilog2_ceil(uint32_t x)
 // nslots [1], pool_start [nq + extra + 1]   (extra = slots beyond one per partition)
 static size_t small_words(uint32_t nq, uint32_t extra) { return (size_t)3 * nq + 3 * (nq + extra) + 1 + (nq + extra + 1) + 16; }
 
+// Smallest launch worth partitioning (below it: one global atomic per sample, k_ingest_pairs).
+static size_t part_min_samples(uint32_t nmetrics, const PartTuning &tune)
+{
+    if (tune.part_min_samples) return tune.part_min_samples;
+    return PART_MIN_SAMPLES;
+}
+
 static bool make_plan(size_t n, uint32_t nmetrics, int num_cus, const PartTuning &tune, PartPlan &P)
 {
-    if (n < PART_MIN_SAMPLES || n > (size_t(1) << 31) || nmetrics < 2) return false;
+    if (n < part_min_samples(nmetrics, tune) || n > (size_t(1) << 31) || nmetrics < 2) return false;
     // names per partition: 4 gives every name a 4 096-bin LDS window in P2.  Fewer partitions mean longer
     // contiguous runs in P1 but narrower windows in P2 (measured at 1 024 names, profiles/r01c: 4 is the best
     // overall).

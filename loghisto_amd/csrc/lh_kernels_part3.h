@@ -52,7 +52,11 @@ constexpr uint32_t LINE4 = 16;                          // 4-byte records per 64
 // windows); up to V3_PIECE * 16 - 1 records stay behind in the region, so every capacity grows by 16 records per line.
 constexpr uint32_t V3_PIECE = LH_V3_PIECE, PIECE4 = V3_PIECE * LINE4;
 constexpr uint32_t V3_MISSQ = 512;                      // records a tile can queue for the exact path (per parity)
-constexpr size_t V3_MIN_SAMPLES = size_t(1) << 24;
+// Smallest launch that takes this path.  2^24 while every call surveyed (0.18 ms); with one survey per 32 calls the third
+// generation beats the first at every size measured (round 4, profiles/r04_level1_experiments.txt: 65 536 names, 0.26 M /
+// 1 M / 2 M / 4 M / 8 M pairs 0.17 / 0.30 / 0.36 / 0.41 / 0.49 ms against 0.49 / 0.53 / 0.58 / 0.63 / 0.69) -- lane-sized
+// host-fed launches included.
+constexpr size_t V3_MIN_SAMPLES = size_t(1) << 18;
 constexpr uint32_t SVH_GRID = 256, SVH_SLOTS = 4096;    // hashed survey: 256 workgroups x 2 048 samples
 constexpr uint32_t V3_EXTRA1 = 768;                     // level-1 work slots beyond one per partition
 constexpr uint32_t V3_EXTRA2 = 1024;                    // fine work slots beyond one per fine partition
