@@ -670,11 +670,12 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=Non
                       exact=parity["exact"] and int(nchk[1].item()) == world)
     assert parity["exact"], parity
     lat_c4 = None
-    if world == 1 and steps:
+    nlat = min(100, int(getattr(args, "latency_flips", 100)))
+    if world == 1 and steps and nlat > 10:
         # flip -> results of ALL 65 536 names on the host (in place, lh_extract_rows_view), small intervals
         lat = []
         sl_i, sl_v = ids[: 1 << 22], data[: 1 << 22]
-        for _ in range(100):
+        for _ in range(nlat):
             eng.submit_pairs_device(sl_i, sl_v, sl_v.numel(), stream=stream)
             torch.cuda.synchronize()
             t1 = time.perf_counter()

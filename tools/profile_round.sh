@@ -32,7 +32,7 @@ rocprofv3 --kernel-trace -d /tmp/pr_c3t -o t -- $CMD3 > $OUT/c3_under_trace.json
 { echo "# rocprofv3 --kernel-trace -- $CMD3"; python $R/profiles/summarize_rocpd.py stats /tmp/pr_c3t/t_results.db | grep -E "^#|^kernel|lh::" | cut -c1-170; } > $OUT/c3_kernel_trace.txt
 rocprofv3 --pmc FETCH_SIZE -d /tmp/pr_c3f -o t -- $CMD3 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE -d /tmp/pr_c3w -o t -- $CMD3 > /dev/null 2>&1
-CMD4="python $R/bench.py --workload c4 --steps 3 --warmup 1 --no-parity"
+CMD4="python $R/bench.py --workload c4 --steps 3 --warmup 1 --no-parity --latency-flips 0"
 rm -rf /tmp/pr_c4t /tmp/pr_c4f /tmp/pr_c4w
 rocprofv3 --kernel-trace -d /tmp/pr_c4t -o t -- $CMD4 > $OUT/c4_under_trace.json 2>/dev/null
 { echo "# rocprofv3 --kernel-trace -- $CMD4"; python $R/profiles/summarize_rocpd.py stats /tmp/pr_c4t/t_results.db | grep -E "^#|^kernel|lh::" | cut -c1-170; } > $OUT/c4_kernel_trace.txt
@@ -74,9 +74,8 @@ json.dump({"workload":"C3: 1e9 (uint32 id, float64 value) pairs over 1 024 Zipf(
  "commands":["rocprofv3 --pmc FETCH_SIZE -- $CMD3","rocprofv3 --pmc WRITE_SIZE -- $CMD3"], "corrections": CORR,
  "kernels": per, "hbm_read_bytes_per_call": rd, "hbm_write_bytes_per_call": wr, "hbm_bytes_per_call": rd+wr,
  "algorithmic_bytes_per_call": 12e9, "traffic_over_algorithmic": (rd+wr)/12e9}, open("$OUT/c3_pmc.json","w"), indent=1)
-# C4: every kernel of one lh_submit_pairs_device call of the slice.  The run makes 1 warm-up + 3 timed calls and, for
-# the extract-latency leg, 100 calls of 2^22 pairs that take other kernels (first generation): only launches of the
-# third-generation kernels and of the slice's k_ingest_pairs tail are summed, per call of the slice.
+# C4: every kernel of one lh_submit_pairs_device call of the slice.  The run makes 1 warm-up + 3 timed calls (the
+# extract-latency leg, whose small intervals take the same kernels since round 4, is switched off: --latency-flips 0).
 calls = 4
 k4 = ["k_survey_count_h", "k_survey_pick", "k_survey_plan_h", "k_survey_remap", "k_scatter4", "k_split_waves",
       "k_split_records", "k_part_hist3", "k_v3_report"]
