@@ -129,6 +129,29 @@ def make_samples(n: int, kind: str, seed: int) -> torch.Tensor:
             u = torch.rand(min(step, n - lo), device="cuda", generator=g)
             v[lo:lo + step].mul_(torch.where(u < 0.1, 10.0, 1.0).to(torch.float64))
         return v
+    if kind in ("far_1e30", "negative_far", "signed_wide", "thin_far_tail"):
+        # streams that leave K1's main LDS window (|v| < 6.1e17): all of it far above / far below, a little beyond on
+        # both sides, a 0.1 % tail up to 1e60 (tools/sweep.py; tests/test_gpu_parity.py holds the numpy twins)
+        if kind == "far_1e30":
+            return torch.randn(n, dtype=torch.float64, device="cuda", generator=g).add_(math.log(1e30)).exp_()
+        if kind == "negative_far":
+            return torch.randn(n, dtype=torch.float64, device="cuda", generator=g).mul_(0.5).add_(math.log(1e25)).exp_().neg_()
+        v = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
+        if kind == "signed_wide":
+            v = v.mul_(23.0).sub_(3.0).mul_(math.log(10.0)).exp_()
+            step = 1 << 27
+            for lo in range(0, n, step):
+                u = torch.rand(min(step, n - lo), device="cuda", generator=g)
+                v[lo:lo + step].mul_(torch.where(u < 0.5, -1.0, 1.0).to(torch.float64))
+            return v
+        far = v.mul_(41.0).add_(19.0).mul_(math.log(10.0)).exp_()
+        step = 1 << 27
+        for lo in range(0, n, step):
+            m = min(step, n - lo)
+            u = torch.rand(m, device="cuda", generator=g)
+            body = torch.randn(m, dtype=torch.float64, device="cuda", generator=g).add_(math.log(1e5)).exp_()
+            far[lo:lo + step] = torch.where(u < 1e-3, far[lo:lo + step], body)
+        return far
     if kind in ("uniform", "loguniform", "exponential"):
         v = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
         if kind == "uniform":

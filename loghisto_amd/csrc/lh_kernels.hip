@@ -78,34 +78,91 @@ constexpr int K1_UNROLL = LH_K1_UNROLL;             // 16-B loads in flight per 
 // 32-lane group.  Measured on few-valued streams (quantised timers, status codes, queue depths -- the ordinary input
 // of TimerToken.Stop, metrics.go:242-246; profiles/r04_fewvalued.jsonl): with one copy, 8 lanes per word and group
 // (k = 4 distinct values) are free next to the HBM stream, 11 (k = 3) cost 0.3 ms per 1e9 samples, 16 (k = 2) 0.7 ms.
-// Two copies halve every multiplicity (k = 2 becomes k = 4's pattern) for half the window: keys -4096 .. 4095, i.e.
-// |v| < 6.1e17 -- nanosecond timers up to 19 years; samples outside go straight to the global row (exact, rare).
+// Two copies halve every multiplicity (k = 2 becomes k = 4's pattern) for half the window: 8 192 bins, by default the
+// keys -4096 .. 4095, i.e. |v| < 6.1e17 -- nanosecond timers up to 19 years, either sign.
+//
+// Streams that do not live there are still bucketed in LDS:
+//  * every workgroup looks at the first three samples of its share; if all three lie beyond the same end of the
+//    default window the workgroup centres its main window on their median key instead (|v| ~ 1e30: the whole stream
+//    at full speed);
+//  * samples outside the main window go to one of two FLOATING windows of K1_OVF bins (one copy each; one for the keys
+//    above the main window, one for those below) that the workgroup anchors where its first such sample falls:
+//    adjacent to the main window when the sample is within K1_OVF bins of it (a stream a little wider than the
+//    window: loguniform[1e-3, 1e18] reaches key 4146), centred on the sample otherwise (a far tail, a second mode);
+//  * only what misses these too goes straight to the global row, and that path reads the row's range before it widens
+//    it.
+// Measured before any of this existed (profiles/r04_k1_lds_counters.jsonl, the first run of tools/r4_counters.sh):
+// the 1.2 % of loguniform[1e-3, 1e18] above key 4095 -- 12 M samples on 50 cells plus two unconditional atomics each
+// on the row's ONE range pair -- took a 1e9-sample launch from 1.25 ms to 170 ms; now 1.38 ms
+// (profiles/r04_k1_wide_streams.txt).
 #ifndef LH_K1_COPIES
 #define LH_K1_COPIES 2
 #endif
 constexpr uint32_t K1_COPIES = LH_K1_COPIES;
 constexpr uint32_t K1_WIN = 16384 / K1_COPIES;     // bins per copy
-constexpr uint32_t K1_WIN_LO = 32768 - K1_WIN / 2; // first bin of the window
+constexpr uint32_t K1_WIN_LO = 32768 - K1_WIN / 2; // first bin of the default window
 // copy k starts K1_PAD words past a multiple of the 32 banks: the same bin of two copies must not share a bank, or
 // the copies would serialise on the bank what they no longer serialise on the word
 constexpr uint32_t K1_PAD = 16;
 constexpr uint32_t K1_STRIDE = K1_WIN + (K1_COPIES > 1 ? K1_PAD : 0);
-constexpr size_t K1_LDS_BYTES = (size_t)K1_STRIDE * K1_COPIES * sizeof(uint32_t) + 16;
+#ifndef LH_K1_OVF
+#define LH_K1_OVF 1024
+#endif
+constexpr uint32_t K1_OVF = LH_K1_OVF;             // bins of each floating window
+constexpr uint32_t K1_OVF_NONE = 0xffffffffu;      // not anchored yet
+constexpr uint32_t K1_MAIN_WORDS = K1_STRIDE * K1_COPIES;
+// layout: main copies | floating window below | floating window above | [0] min bin [1] max bin of the flush
+//         [2] anchor of the window below [3] anchor of the window above [4] first bin of the main window
+constexpr uint32_t K1_CTL_WORDS = 8;
+constexpr size_t K1_LDS_BYTES = (size_t)(K1_MAIN_WORDS + 2 * K1_OVF + K1_CTL_WORDS) * sizeof(uint32_t);
+static_assert(2 * K1_LDS_BYTES + 2048 <= 160 * 1024, "two workgroups per CU");
+static_assert(K1_OVF >= 64 && K1_OVF <= K1_WIN, "anchor arithmetic");
 
-// Out-of-window cell: straight to the global row.
+// A cell outside every LDS window: straight to the global row.  The range only widens, so a stale read of it can cost
+// a redundant atomic, never miss one.
 __device__ __forceinline__ void global_cell_add(uint64_t *row, uint32_t *range, uint32_t bin, uint64_t c)
 {
     atomicAdd(reinterpret_cast<unsigned long long *>(&row[bin]), (unsigned long long)c);
-    atomicMin(&range[0], bin);
-    atomicMax(&range[1], bin);
+    if (bin < range[0]) atomicMin(&range[0], bin);
+    if (bin > range[1]) atomicMax(&range[1], bin);
 }
 
-// hc: this lane's copy of the window
-__device__ __forceinline__ void k1_add(uint32_t *hc, uint64_t *row, uint32_t *range, uint32_t bin, uint32_t c = 1u)
+// where a workgroup puts a floating window when `bin` is its first sample on that side of the main window [win_lo, +K1_WIN)
+__device__ __forceinline__ uint32_t k1_anchor(uint32_t bin, uint32_t win_lo)
 {
-    const uint32_t rel = bin - K1_WIN_LO;
-    if (rel < K1_WIN) atomicAdd(&hc[rel], c);
+    const uint32_t centred = bin >= K1_OVF / 2 ? bin - K1_OVF / 2 : 0u;
+    if (bin >= win_lo + K1_WIN) return min(max(win_lo + K1_WIN, centred), (uint32_t)LH_NKEYS - K1_OVF);
+    return min(win_lo >= K1_OVF ? win_lo - K1_OVF : 0u, centred);
+}
+
+// the sample missed the main window.  h0: the workgroup's LDS block.
+__device__ __forceinline__ void k1_miss(uint32_t *h0, uint32_t win_lo, uint64_t *row, uint32_t *range, uint32_t bin, uint32_t c)
+{
+    const uint32_t side = bin >= win_lo + K1_WIN ? 1u : 0u;
+    uint32_t *anchor = h0 + K1_MAIN_WORDS + 2 * K1_OVF + 2 + side;
+    uint32_t lo = __atomic_load_n(anchor, __ATOMIC_RELAXED);
+    if (lo == K1_OVF_NONE) {
+        const uint32_t want = k1_anchor(bin, win_lo);
+        const uint32_t seen = atomicCAS(anchor, K1_OVF_NONE, want);
+        lo = seen == K1_OVF_NONE ? want : seen;
+    }
+    const uint32_t rel = bin - lo;
+    if (rel < K1_OVF) atomicAdd(&h0[K1_MAIN_WORDS + side * K1_OVF + rel], c);
     else global_cell_add(row, range, bin, c);
+}
+
+// the workgroup's window state, wave-uniform: h0 = its LDS block, win_lo = first bin of its main window
+struct K1Win {
+    uint32_t *h0;
+    uint32_t win_lo;
+};
+
+// hc: this lane's copy of the main window
+__device__ __forceinline__ void k1_add(const K1Win w, uint32_t *hc, uint64_t *row, uint32_t *range, uint32_t bin, uint32_t c = 1u)
+{
+    const uint32_t rel = bin - w.win_lo;
+    if (rel < K1_WIN) atomicAdd(&hc[rel], c);
+    else k1_miss(w.h0, w.win_lo, row, range, bin, c);
 }
 
 // All 64 lanes active.  A wave whose samples mostly share ONE bucket (a constant stream; a stream dominated by one
@@ -118,16 +175,16 @@ __device__ __forceinline__ void k1_add(uint32_t *hc, uint64_t *row, uint32_t *ra
 #ifndef LH_K1_AGG_MIN
 #define LH_K1_AGG_MIN 24
 #endif
-__device__ __forceinline__ void k1_add_fullwave(uint32_t *hc, uint64_t *row, uint32_t *range, uint32_t bin)
+__device__ __forceinline__ void k1_add_fullwave(const K1Win w, uint32_t *hc, uint64_t *row, uint32_t *range, uint32_t bin)
 {
     const uint32_t first = __builtin_amdgcn_readfirstlane(bin);
     const unsigned long long same = __builtin_amdgcn_ballot_w64(bin == first);
     const uint32_t nsame = (uint32_t)__builtin_popcountll(same);
     if (nsame >= LH_K1_AGG_MIN) { // wave-uniform
         const bool leader = __lane_id() == 0;
-        if (leader || bin != first) k1_add(hc, row, range, bin, leader ? nsame : 1u);
+        if (leader || bin != first) k1_add(w, hc, row, range, bin, leader ? nsame : 1u);
     } else {
-        k1_add(hc, row, range, bin);
+        k1_add(w, hc, row, range, bin);
     }
 }
 
@@ -138,13 +195,9 @@ __global__ __launch_bounds__(K1_BLOCK) void k_ingest_single(const double *__rest
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *h0 = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *s_minmax = h0 + K1_STRIDE * K1_COPIES; // [0]=min rel bin, [1]=max rel bin
+    uint32_t *s_ctl = h0 + K1_MAIN_WORDS + 2 * K1_OVF; // [0] min bin, [1] max bin of the flush, [2] [3] floating anchors, [4] win_lo
     const uint32_t tid = threadIdx.x;
     uint32_t *h = h0 + (tid % K1_COPIES) * K1_STRIDE;   // this lane's copy
-
-    for (uint32_t i = tid; i < K1_STRIDE * K1_COPIES; i += K1_BLOCK) h0[i] = 0;
-    if (tid == 0) { s_minmax[0] = 0xffffffffu; s_minmax[1] = 0; }
-    __syncthreads();
 
     // 16-B alignment: at most one scalar head sample, then pairs, then an odd tail.
     const size_t head = (((uintptr_t)v & 8) && n) ? 1 : 0;
@@ -153,10 +206,33 @@ __global__ __launch_bounds__(K1_BLOCK) void k_ingest_single(const double *__rest
     const size_t tile = (size_t)K1_BLOCK * K1_UNROLL; // pairs per workgroup iteration
     const size_t nfull = npair / tile;
 
+    for (uint32_t i = tid; i < K1_MAIN_WORDS + 2 * K1_OVF; i += K1_BLOCK) h0[i] = 0;
+    if (tid == 0) {
+        s_ctl[0] = 0xffffffffu;
+        s_ctl[1] = 0;
+        s_ctl[2] = s_ctl[3] = K1_OVF_NONE;
+        // the main window: the default one unless the first three samples of this workgroup's share all lie beyond the
+        // same end of it -- then the stream lives elsewhere and the window is centred on their median key.  (One or two
+        // of three is not enough: measured with the median alone deciding, a two-signed stream reaching 1e20 lost its
+        // other half to the global row in every tenth workgroup, 1.7 -> 6.3 ms per 1e9 samples.)
+        const size_t i0 = min(head + (size_t)blockIdx.x * tile * 2, n - 1);
+        const uint32_t b0 = lh_bin_of(v[i0], Tx), b1 = lh_bin_of(v[min(i0 + 1, n - 1)], Tx), b2 = lh_bin_of(v[min(i0 + 2, n - 1)], Tx);
+        const uint32_t lowest = min(b0, min(b1, b2)), highest = max(b0, max(b1, b2));
+        const uint32_t med = max(min(b0, b1), min(max(b0, b1), b2));
+        uint32_t lo = K1_WIN_LO;
+        if (lowest >= K1_WIN_LO + K1_WIN || highest < K1_WIN_LO)
+            lo = min(med >= K1_WIN / 2 ? med - K1_WIN / 2 : 0u, (uint32_t)LH_NKEYS - K1_WIN);
+        s_ctl[4] = lo;
+    }
+    __syncthreads();
+    const K1Win w = {h0, (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ctl[4])};
+
     // (register double buffering -- tile t + grid in flight while tile t is bucketed -- measured slower,
     // profiles/r02_k1_variants.txt: two workgroups per CU already overlap each other's loads; a rolling refill of the
     // same eight registers -- slot u reloaded as soon as it has been consumed -- and 1 024-thread workgroups likewise,
-    // profiles/r04_fewvalued.jsonl)
+    // profiles/r04_fewvalued.jsonl.  Keeping the out-of-window handling out of the sixteen unrolled slots -- a first
+    // pass that only notes misses, a second over the same registers when any lane had one -- was no faster on streams
+    // without misses and up to 1.6 x slower on streams with them: profiles/r04_k1_wide_streams.txt.)
     for (size_t t = blockIdx.x; t < nfull; t += gridDim.x) {
         const d2_t *p = vp + t * tile + tid;
         d2_t r[K1_UNROLL];
@@ -164,39 +240,51 @@ __global__ __launch_bounds__(K1_BLOCK) void k_ingest_single(const double *__rest
         for (int u = 0; u < K1_UNROLL; u++) r[u] = __builtin_nontemporal_load(p + u * K1_BLOCK);
 #pragma unroll
         for (int u = 0; u < K1_UNROLL; u++) {
-            k1_add_fullwave(h, row, range, lh_bin_of(r[u].x, Tx));
-            k1_add_fullwave(h, row, range, lh_bin_of(r[u].y, Tx));
+            k1_add_fullwave(w, h, row, range, lh_bin_of(r[u].x, Tx));
+            k1_add_fullwave(w, h, row, range, lh_bin_of(r[u].y, Tx));
         }
     }
     // remainder pairs (guarded), owned by the workgroup next in the rotation
     if (blockIdx.x == nfull % gridDim.x) {
         for (size_t i = nfull * tile + tid; i < npair; i += K1_BLOCK) {
             const d2_t r = vp[i];
-            k1_add(h, row, range, lh_bin_of(r.x, Tx));
-            k1_add(h, row, range, lh_bin_of(r.y, Tx));
+            k1_add(w, h, row, range, lh_bin_of(r.x, Tx));
+            k1_add(w, h, row, range, lh_bin_of(r.y, Tx));
         }
-        if (tid == 0 && head) k1_add(h, row, range, lh_bin_of(v[0], Tx));
-        if (tid == 1 && ((n - head) & 1)) k1_add(h, row, range, lh_bin_of(v[n - 1], Tx));
+        if (tid == 0 && head) k1_add(w, h, row, range, lh_bin_of(v[0], Tx));
+        if (tid == 1 && ((n - head) & 1)) k1_add(w, h, row, range, lh_bin_of(v[n - 1], Tx));
     }
     __syncthreads();
 
-    // flush: one u64 atomic per occupied bin (the copies summed)
+    // flush: one u64 atomic per occupied bin (the copies summed), then the floating windows that were anchored
     uint32_t lmin = 0xffffffffu, lmax = 0;
     for (uint32_t i = tid; i < K1_WIN; i += K1_BLOCK) {
         uint32_t c = h0[i];
 #pragma unroll
         for (uint32_t k = 1; k < K1_COPIES; k++) c += h0[k * K1_STRIDE + i];
         if (c) {
-            atomicAdd(reinterpret_cast<unsigned long long *>(&row[K1_WIN_LO + i]), (unsigned long long)c);
-            lmin = min(lmin, i);
-            lmax = max(lmax, i);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&row[w.win_lo + i]), (unsigned long long)c);
+            lmin = min(lmin, w.win_lo + i);
+            lmax = max(lmax, w.win_lo + i);
         }
     }
-    if (lmin != 0xffffffffu) { atomicMin(&s_minmax[0], lmin); atomicMax(&s_minmax[1], lmax); }
+    for (uint32_t side = 0; side < 2; side++) {
+        const uint32_t ovf_lo = s_ctl[2 + side];
+        if (ovf_lo == K1_OVF_NONE) continue;
+        for (uint32_t i = tid; i < K1_OVF; i += K1_BLOCK) {
+            const uint32_t c = h0[K1_MAIN_WORDS + side * K1_OVF + i];
+            if (c) {
+                atomicAdd(reinterpret_cast<unsigned long long *>(&row[ovf_lo + i]), (unsigned long long)c);
+                lmin = min(lmin, ovf_lo + i);
+                lmax = max(lmax, ovf_lo + i);
+            }
+        }
+    }
+    if (lmin != 0xffffffffu) { atomicMin(&s_ctl[0], lmin); atomicMax(&s_ctl[1], lmax); }
     __syncthreads();
-    if (tid == 0 && s_minmax[0] != 0xffffffffu) {
-        atomicMin(&range[0], K1_WIN_LO + s_minmax[0]);
-        atomicMax(&range[1], K1_WIN_LO + s_minmax[1]);
+    if (tid == 0 && s_ctl[0] != 0xffffffffu) {
+        atomicMin(&range[0], s_ctl[0]);
+        atomicMax(&range[1], s_ctl[1]);
     }
 }
 

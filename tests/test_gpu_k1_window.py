@@ -1,0 +1,140 @@
+"""K1 (k_ingest_single) on streams that leave its main LDS window (keys -4096 .. 4095, |v| < 6.1e17): exact against the
+oracle on every path (floating windows above / below, the global row), and not a performance cliff -- before the
+floating windows existed the 1.2 % of loguniform[1e-3, 1e18] above key 4095 took a 1e9-sample launch from 1.25 ms to
+170 ms (profiles/r04_k1_lds_counters.jsonl).  Semantics: metrics.go:273-295 (one increment per sample, any key)."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oracle  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+PCTS = [0.0, 0.5, 0.99, 1.0]
+
+
+@pytest.fixture(scope="module")
+def la(native_lib, torch_cuda):
+    import loghisto_amd
+    return loghisto_amd
+
+
+@pytest.fixture()
+def engine(la):
+    e = la.Engine(max_metrics=1, num_buffers=2, num_lanes=1, lane_samples=1 << 16)
+    yield e
+    e.close()
+
+
+def ingest_and_check(engine, torch_cuda, v):
+    d = torch_cuda.from_numpy(np.ascontiguousarray(v, dtype=np.float64)).cuda()
+    engine.submit_device(0, d)
+    with engine.flip() as snap:
+        row = snap.dense_row(0)
+        got = snap.extract(PCTS, 1)
+    want = oracle.histogram_dense(v)
+    assert np.array_equal(row, want)
+    w = oracle.process_dense(want, PCTS)
+    assert int(got["count"][0]) == w["count"] == len(v)
+    assert np.array_equal(got["pkeys"][0], w["pkeys"])
+    assert np.array_equal(np.asarray(got["pvals"][0]).view(np.uint64), w["pvals"].view(np.uint64))
+
+
+def key_values(keys):
+    """one value in the middle of each key's bucket (oracle.decompress is the bucket's representative value)"""
+    return oracle.decompress_table()[oracle.key_to_bin(np.asarray(keys))]
+
+
+@pytest.mark.parametrize("case", ["just_above", "just_below", "both_sides_near", "both_sides_far", "beyond_a_floating_window",
+                                  "anchor_at_the_top_key", "anchor_at_the_bottom_key", "dominant_value_outside",
+                                  "misleading_first_samples", "all_far_above", "all_far_below_narrow"])
+def test_streams_around_the_window_edges(engine, torch_cuda, case):
+    rng = np.random.default_rng(17)
+    n = 1_500_001                                                   # ~180 workgroups, ragged tail
+    body = rng.lognormal(math.log(1e5), 1.0, n)
+    if case == "just_above":                                        # keys 4090 .. 4200: straddles the window's top
+        v = key_values(rng.integers(4090, 4201, n))
+    elif case == "just_below":
+        v = key_values(-rng.integers(4090, 4201, n))
+    elif case == "both_sides_near":
+        v = key_values(rng.integers(4000, 5000, n) * rng.choice([-1, 1], n))
+    elif case == "both_sides_far":                                  # two clusters far outside, plus the body inside
+        far = key_values(rng.integers(20000, 20600, n) * rng.choice([-1, 1], n))
+        v = np.where(rng.random(n) < 0.3, far, body)
+    elif case == "beyond_a_floating_window":                        # wider than main + floating windows: the global row too
+        v = key_values(rng.integers(3000, 9000, n))
+    elif case == "anchor_at_the_top_key":
+        v = key_values(rng.integers(32000, 32768, n))
+    elif case == "anchor_at_the_bottom_key":
+        v = key_values(-rng.integers(32000, 32769, n))
+    elif case == "misleading_first_samples":                        # every workgroup's first three samples are outliers:
+        v = body.copy()                                             # its main window moves away from the body
+        for j in range(3):
+            v[j::8192] = 1e40
+    elif case == "all_far_above":                                   # the main window moves with the stream
+        v = rng.lognormal(math.log(1e30), 1.5, n)
+    elif case == "all_far_below_narrow":
+        v = -rng.lognormal(math.log(1e100), 0.1, n)
+    else:                                                           # >= 24 lanes of a wave share one bucket OUTSIDE the window
+        v = np.where(rng.random(n) < 0.9, key_values([5000])[0], body)
+    assert np.all(np.isfinite(v))
+    ingest_and_check(engine, torch_cuda, v)
+
+
+def test_first_miss_decides_the_anchor_not_the_result(engine, torch_cuda):
+    """The floating windows are anchored per workgroup by whichever sample misses first: the same multiset in different
+    orders (and a second launch into the same interval) must give the same row."""
+    rng = np.random.default_rng(3)
+    v = np.concatenate([key_values(rng.integers(4096, 12000, 400_000)), rng.lognormal(math.log(1e5), 1.0, 400_000),
+                        key_values(-rng.integers(4096, 30000, 200_000))])
+    want = oracle.histogram_dense(v)
+    for order in (np.arange(len(v)), np.arange(len(v))[::-1], rng.permutation(len(v))):
+        d = torch_cuda.from_numpy(np.ascontiguousarray(v[order])).cuda()
+        engine.submit_device(0, d)
+        with engine.flip() as snap:
+            assert np.array_equal(snap.dense_row(0), want)
+    d = torch_cuda.from_numpy(np.ascontiguousarray(v)).cuda()
+    engine.submit_device(0, d)
+    engine.submit_device(0, d)
+    with engine.flip() as snap:
+        assert np.array_equal(snap.dense_row(0), 2 * want)
+
+
+def test_wide_streams_are_not_a_cliff(engine, torch_cuda):
+    """Kernel time per distribution against the lognormal stream's, HIP events, 2e8 samples.  The bound is loose (boxes
+    differ, the wide streams do pay for their global-row cells); the failure it guards against was 136 x."""
+    import bench
+    torch = torch_cuda
+    n = 200_000_000
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+
+    def timed(kind):
+        data = bench.make_samples(n, kind, 7)
+        ms = []
+        for r in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            engine.submit_device(0, data, n, stream=stream)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            if r >= 2:
+                ms.append(e0.elapsed_time(e1))
+            with engine.flip() as snap:
+                assert int(snap.extract([0.5], 1)["count"][0]) == n
+        del data
+        return min(ms)
+
+    base = timed("lognormal")
+    report = {"lognormal": base}
+    for kind in ("loguniform", "far_1e30", "negative_far", "signed_wide", "thin_far_tail"):
+        report[kind] = timed(kind)
+    print("K1 ms per 2e8 samples:", {k: round(x, 3) for k, x in report.items()})
+    torch.cuda.set_stream(torch.cuda.default_stream())
+    assert base > 0.1, report                                       # the events did bracket the kernel
+    for kind, ms in report.items():
+        assert ms < 3.0 * base + 0.2, report

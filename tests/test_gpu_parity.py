@@ -63,6 +63,12 @@ def dists(n, seed):
         "kvalues3_skewed": 1e3 * 1.5 ** rng.choice(3, n, p=[0.9, 0.09, 0.01]),
         # two lognormal lobes 10x apart, 90 / 10
         "bimodal": rng.lognormal(math.log(1e5), 1.0, n) * np.where(rng.random(n) < 0.1, 10.0, 1.0),
+        # streams that leave K1's main LDS window (keys -4096 .. 4095, |v| < 6.1e17) for its floating windows or the
+        # global row: everything far above it, far below it, a little beyond it on both sides, and a thin far tail
+        "far_1e30": rng.lognormal(math.log(1e30), 1.0, n),
+        "negative_far": -rng.lognormal(math.log(1e25), 0.5, n),
+        "signed_wide": 10.0 ** rng.uniform(-3, 20, n) * np.where(rng.random(n) < 0.5, -1.0, 1.0),
+        "thin_far_tail": np.where(rng.random(n) < 1e-3, 10.0 ** rng.uniform(19, 60, n), rng.lognormal(math.log(1e5), 1.0, n)),
     }
 
 
