@@ -129,6 +129,11 @@ def make_samples(n: int, kind: str, seed: int) -> torch.Tensor:
             u = torch.rand(min(step, n - lo), device="cuda", generator=g)
             v[lo:lo + step].mul_(torch.where(u < 0.1, 10.0, 1.0).to(torch.float64))
         return v
+    if kind == "on_thresholds":
+        # every sample within rounding of a bucket boundary (100 * log(1 + v) = k - 0.5, 500 boundaries around 1e5): the
+        # bucket index takes its exact route (threshold table) for all of them -- the worst case of lh_bin_of
+        k = torch.randint(900, 1400, (n,), device="cuda", generator=g, dtype=torch.int32).to(torch.float64)
+        return k.sub_(0.5).div_(100.0).expm1_()
     if kind in ("far_1e30", "negative_far", "signed_wide", "thin_far_tail"):
         # streams that leave K1's main LDS window (|v| < 6.1e17): all of it far above / far below, a little beyond on
         # both sides, a 0.1 % tail up to 1e60 (tools/sweep.py; tests/test_gpu_parity.py holds the numpy twins)

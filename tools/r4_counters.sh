@@ -3,9 +3,10 @@
 #   1 024 names (k_scatter3, k_part_hist2) and 65 536 names (k_scatter4, k_split_waves, k_part_hist3), 1e9 pairs:
 #   instruction mix and LDS conflicts, lognormal + kvalues2                                        -> mixed_counters.jsonl
 # One rocprofv3 --pmc pass per (distribution, counter set); no tracing domains in the same run.
-# usage: bash tools/r4_counters.sh OUTDIR
+# usage: [PARTS="k1 mixed"] bash tools/r4_counters.sh OUTDIR
 cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; OUTD=$R/gpurun_out/${1:-r4cnt}; mkdir -p $OUTD
-K1=$OUTD/k1_lds_counters.jsonl; MX=$OUTD/mixed_counters.jsonl; : > $K1; : > $MX
+PARTS=${PARTS:-k1 mixed}
+K1=$OUTD/k1_lds_counters.jsonl; MX=$OUTD/mixed_counters.jsonl
 
 row() {  # row DB KERNEL SAMPLES_PER_LAUNCH LABEL... : one JSON line with every counter of that kernel in the db
   python - "$@" <<PY
@@ -33,7 +34,9 @@ PY
 SET_A="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
 SET_B="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS"
 
-for D in lognormal constant kvalues2 kvalues4 kvalues16 bimodal loguniform; do
+case " $PARTS " in *" k1 "*) : > $K1;; esac
+for D in lognormal constant kvalues2 kvalues4 kvalues16 bimodal loguniform signed_wide far_1e30; do
+  case " $PARTS " in *" k1 "*) ;; *) break;; esac
   for S in A B; do
     eval "SET=\$SET_$S"
     rm -rf /tmp/kc; timeout 300 rocprofv3 --pmc $SET -d /tmp/kc -o t -- python $R/tools/sweep.py --samples 1e9 --reps 3 --dists $D > /tmp/kc.out 2>&1
@@ -41,7 +44,9 @@ for D in lognormal constant kvalues2 kvalues4 kvalues16 bimodal loguniform; do
   done
 done
 
+case " $PARTS " in *" mixed "*) : > $MX;; esac
 for D in lognormal kvalues2; do
+  case " $PARTS " in *" mixed "*) ;; *) break;; esac
   for S in A B; do
     eval "SET=\$SET_$S"
     rm -rf /tmp/kc; timeout 300 rocprofv3 --pmc $SET -d /tmp/kc -o t -- python $R/tools/sweep.py --samples 1e9 --pairs 1024 --reps 2 --dists $D > /tmp/kc.out 2>&1
@@ -52,4 +57,4 @@ for D in lognormal kvalues2; do
     for k in k_scatter4 k_split_waves k_part_hist3; do row /tmp/kc/t_results.db $k 1e9 dist=$D names=65536 set=$S >> $MX; done
   done
 done
-cat $K1 $MX
+cat $K1 $MX 2>/dev/null
