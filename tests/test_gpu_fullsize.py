@@ -145,3 +145,48 @@ def test_mixed_stream_full_size(native_lib, torch_cuda, M, n, scale):
         assert np.array_equal(again["count"], per_name)
         assert np.array_equal(again["pvals"].view(np.uint64), got["pvals"].view(np.uint64))
         assert np.array_equal(off2, off) and np.array_equal(keys2, keys) and np.array_equal(counts2, counts)
+
+
+def test_calls_larger_than_one_launch(native_lib, torch_cuda):
+    """One call above the engine's per-launch caps (2^31 samples single-metric, 2^30 pairs mixed): the call is cut into
+    launches at 64-bit offsets.  Size-independent property (no 40 GB oracle pass): a stream made of k copies of a base
+    stream gives k times the base stream's rows; the base rows are checked against the oracle by the tests above."""
+    torch = torch_cuda
+    import loghisto_amd
+    base_n, k = 900_000_001, 5                                      # 4.5e9 samples = 36 GB: launches of 2^31, 2^31, rest
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    base = torch.randn(base_n, dtype=torch.float64, device="cuda", generator=g).add_(math.log(1e5)).exp_()
+    big = base.repeat(k)
+    torch.cuda.synchronize()
+    with loghisto_amd.Engine(max_metrics=1, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as eng:
+        eng.submit_device(0, base)
+        with eng.flip() as snap:
+            row1 = snap.dense_row(0)
+        assert int(row1.sum()) == base_n
+        eng.submit_device(0, big)
+        with eng.flip() as snap:
+            rowk = snap.dense_row(0)
+            got = snap.extract(PCTS, 1)
+        assert np.array_equal(rowk, k * row1)
+        assert int(got["count"][0]) == k * base_n                  # > 2^32 samples in one interval
+        want = oracle.process_dense(rowk, PCTS)
+        assert np.array_equal(got["pvals"][0].view(np.uint64), want["pvals"].view(np.uint64))
+    del big, base
+
+    M, pn, pk = 1024, 500_000_003, 5                               # 2.5e9 pairs = 40 GB: launches of 2^30, 2^30, rest
+    ids, v = _zipf_stream(torch, pn, M, 12, 0.002)
+    bids, bv = ids.repeat(pk), v.repeat(pk)
+    torch.cuda.synchronize()
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as eng:
+        eng.submit_pairs_device(ids, v)
+        with eng.flip() as snap:
+            c1 = snap.extract([0.5], M)["count"].astype(np.int64).copy()
+            probe = [0, 1, 7, 100, 511, 1023]
+            r1 = [snap.dense_row(m).copy() for m in probe]
+        eng.submit_pairs_device(bids, bv)
+        with eng.flip() as snap:
+            ck = snap.extract([0.5], M)["count"].astype(np.int64)
+            assert np.array_equal(ck, pk * c1) and int(ck.sum()) == pk * pn
+            for m, r in zip(probe, r1):
+                assert np.array_equal(snap.dense_row(m), pk * r)
