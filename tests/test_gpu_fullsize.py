@@ -173,6 +173,7 @@ def test_calls_larger_than_one_launch(native_lib, torch_cuda):
         want = oracle.process_dense(rowk, PCTS)
         assert np.array_equal(got["pvals"][0].view(np.uint64), want["pvals"].view(np.uint64))
     del big, base
+    torch.cuda.empty_cache()
 
     M, pn, pk = 1024, 500_000_003, 5                               # 2.5e9 pairs = 40 GB: launches of 2^30, 2^30, rest
     ids, v = _zipf_stream(torch, pn, M, 12, 0.002)
@@ -190,3 +191,5 @@ def test_calls_larger_than_one_launch(native_lib, torch_cuda):
             assert np.array_equal(ck, pk * c1) and int(ck.sum()) == pk * pn
             for m, r in zip(probe, r1):
                 assert np.array_equal(snap.dense_row(m), pk * r)
+    del bids, bv, ids, v
+    torch.cuda.empty_cache()                                       # 40 GB back to the device for the tests that follow
