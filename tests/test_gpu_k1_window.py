@@ -141,3 +141,30 @@ def test_no_stream_is_a_cliff(engine, torch_cuda):
     assert base > 0.1, report                                       # the events did bracket the kernel
     for kind, ms in report.items():
         assert ms < 3.0 * base + 0.2, report
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_cluster_mixtures(engine, torch_cuda, seed):
+    """Seeded mixtures of 1 .. 4 clusters of keys anywhere in -32768 .. 32767 (widths 1 .. 3 000 keys, random weights,
+    sometimes sorted so that a workgroup's first samples come from one cluster), ragged sizes, 8-byte-aligned starts:
+    every placement of the main and the floating windows, both sides, the clamps at the ends of the key range and the
+    global row behind them -- cell by cell against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(1, 3_000_000)) if seed % 5 else int(rng.integers(1, 20_000))
+    k = int(rng.integers(1, 5))
+    centres = rng.integers(-32768, 32768, k)
+    if seed % 3 == 0:
+        centres[0] = int(rng.choice([-32768, 32767, -4097, 4096, 4095, -4096, 0]))
+    widths = rng.integers(1, 3000, k)
+    which = rng.choice(k, n, p=rng.dirichlet(np.ones(k)))
+    keys = np.clip(centres[which] + (rng.random(n) * widths[which]).astype(np.int64) - widths[which] // 2, -32768, 32767)
+    v = key_values(keys)
+    if seed % 4 == 1:
+        v = v[np.argsort(which, kind="stable")]
+    off = seed & 1
+    buf = np.concatenate([[0.0] * off, v])
+    d = torch_cuda.from_numpy(np.ascontiguousarray(buf)).cuda()
+    engine.submit_device(0, d[off:], n)
+    with engine.flip() as snap:
+        row = snap.dense_row(0)
+    assert np.array_equal(row, oracle.histogram_dense(v))
