@@ -378,6 +378,10 @@ int lh_get_counters(lh_engine *e, lh_counters *out);
  *                             path.  A stale survey costs speed, never exactness
  *   LH_OPT_PART_MIN_PAIRS     smallest mixed launch that takes a partitioned path at all (below it: one global atomic per
  *                             sample); 0 = the default, which follows the name count; >= 65 536 otherwise
+ *   LH_OPT_LANE_SCRATCH_BLOCKS  0 .. 8 (default 8): host-fed mixed launches (lh_submit_pairs*, lh_commit_pairs*: one staging
+ *                             half-buffer each, at most 2^22 pairs) take the first partitioned generation in one of this
+ *                             many scratch blocks of their own, so that one lane's later passes run beside another
+ *                             lane's link-bound read; 0 = every partitioned launch shares the engine's one block
  *   LH_OPT_LANE_ZERO_COPY     0 / 1: the ingest kernels read the pinned staging buffers of lh_submit* / lh_reserve_pairs
  *                             in place over PCIe (default 1) instead of after a hipMemcpyAsync into HBM (0)
  *   LH_OPT_PART_V3_LOG_W      log2 of its second-level window width, 10 .. 13 (32 .. 4 names per fine partition);
@@ -400,7 +404,8 @@ enum {
     LH_OPT_PART_V3_LOG_W = 14,
     LH_OPT_LANE_ZERO_COPY = 15,
     LH_OPT_SURVEY_EVERY = 16,
-    LH_OPT_PART_MIN_PAIRS = 17
+    LH_OPT_PART_MIN_PAIRS = 17,
+    LH_OPT_LANE_SCRATCH_BLOCKS = 18
 };
 int lh_set_option(lh_engine *e, int option, uint64_t value);
 

@@ -51,6 +51,7 @@ OPT_PART_V3, OPT_PART_V3_MIN_PAIRS, OPT_PART_V3_LOG_W = 12, 13, 14
 OPT_LANE_ZERO_COPY = 15
 OPT_SURVEY_EVERY = 16
 OPT_PART_MIN_PAIRS = 17
+OPT_LANE_SCRATCH_BLOCKS = 18
 
 
 class LhExtractView(C.Structure):

@@ -239,6 +239,24 @@ struct lh_engine {
     // Third generation (8 193 .. 65 536 names): the survey reports the window width that covers the stream's spans
     // (h_rstat[1], pinned); later calls use it.  A width that is too small only costs speed.
     bool v3_log_w_fixed = false;             // lh_set_option(LH_OPT_PART_V3_LOG_W) pinned it
+    // Host-fed lane launches (one half-buffer of pairs each, read over PCIe in place) are link-bound in their first
+    // pass and leave the link idle in the passes behind it.  On the ONE block above they run one after another -- the
+    // link idles a third of the time (measured: 44 of the 52 GB/s lh_submit's single pass gets, and 2.3 G pairs/s at
+    // 65 536 names where one launch's later passes take as long as its read).  Such launches therefore take the first
+    // generation (no tables that outlive the launch) in one of `lane_blocks` small blocks of their own, so that lane
+    // A's later passes run beside lane B's read.  (scratch_mu; lh_set_option(LH_OPT_LANE_SCRATCH_BLOCKS), 0 = the one
+    // shared block as before)
+    struct AuxScratch {
+        void *p = nullptr;
+        size_t bytes = 0;
+        hipEvent_t done = nullptr;
+        hipStream_t stream = nullptr;
+        bool used = false;
+    };
+    static constexpr uint32_t kAuxBlocks = 8;
+    static constexpr size_t kAuxMaxPairs = size_t(1) << 22; // larger launches amortise their passes: the shared block
+    AuxScratch aux[kAuxBlocks];
+    uint32_t lane_blocks = kAuxBlocks, aux_next = 0;
     size_t scratch_cap = size_t(1536) << 20;     // 1.5 GiB
     bool scratch_cap_set = false, sublaunch_set = false; // lh_set_option was called: the caller's bound wins
     size_t sublaunch_pairs = size_t(1) << 29;
@@ -306,7 +324,7 @@ int launch_single(lh_engine *e, uint32_t id, const double *d_v, size_t n, hipStr
     return LH_OK;
 }
 
-int launch_pairs(lh_engine *e, lh::Ids d_ids, const double *d_v, size_t n, hipStream_t s)
+int launch_pairs(lh_engine *e, lh::Ids d_ids, const double *d_v, size_t n, hipStream_t s, bool host_fed = false)
 {
     EpochBuffer &b = e->bufs[(size_t)e->cur];
     count_samples(b, n);
@@ -361,6 +379,51 @@ int launch_pairs(lh_engine *e, lh::Ids d_ids, const double *d_v, size_t n, hipSt
             d_v += take;
             n -= take;
             continue;
+        }
+        if (host_fed && take <= lh_engine::kAuxMaxPairs && lh::part_aligned(d_ids, d_v)) {
+            // a lane's half-buffer: first generation in a block of the lanes' own (see lh_engine::aux)
+            const size_t need1 = lh::part_scratch_bytes(take, e->cfg.max_metrics, e->num_cus, call_tune);
+            if (!scratch_lock.owns_lock()) scratch_lock.lock();
+            if (need1 && e->lane_blocks) {
+                const uint32_t nb = e->lane_blocks;
+                lh_engine::AuxScratch *a = nullptr;
+                for (uint32_t i = 0; i < nb && !a; i++)
+                    if (e->aux[i].used && e->aux[i].stream == s) a = &e->aux[i]; // stream order is all it needs
+                for (uint32_t i = 0; i < nb && !a; i++)
+                    if (!e->aux[i].used) a = &e->aux[i];
+                for (uint32_t i = 0; i < nb && !a; i++)
+                    if (hipEventQuery(e->aux[i].done) == hipSuccess) a = &e->aux[i];
+                if (!a) a = &e->aux[e->aux_next++ % nb];                          // all busy: behind one of them
+                (void)hipGetLastError(); // hipEventQuery's "not ready" is not an error of this call
+                if (a->bytes < need1) {
+                    if (a->p) {
+                        if (a->used) HIPCHK(hipEventSynchronize(a->done));
+                        HIPCHK(hipFree(a->p));
+                        a->p = nullptr;
+                        a->bytes = 0;
+                        a->used = false;
+                    }
+                    // sized once for the lanes' largest launch: a lane's launches are all of about one size
+                    const size_t want = std::max(need1, lh::part_scratch_bytes(std::min(lh_engine::kAuxMaxPairs,
+                                                                                          std::max(take, (size_t)e->cfg.lane_samples)),
+                                                                               e->cfg.max_metrics, e->num_cus, call_tune));
+                    HIPCHK(hipMalloc(&a->p, want));
+                    a->bytes = want;
+                }
+                if (a->used && a->stream != s) HIPCHK(hipStreamWaitEvent(s, a->done, 0));
+                HIPCHK(lh::launch_ingest_pairs_part(d_ids, d_v, take, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx,
+                                                    e->d_err, a->p, a->bytes, e->num_cus, call_tune, s));
+                HIPCHK(hipEventRecord(a->done, s));
+                a->stream = s;
+                a->used = true;
+                e->c_part.fetch_add(take, std::memory_order_relaxed);
+                e->c_sublaunches.fetch_add(1, std::memory_order_relaxed);
+                e->c_launches.fetch_add(1, std::memory_order_relaxed);
+                d_ids = d_ids.plus(take);
+                d_v += take;
+                n -= take;
+                continue;
+            }
         }
         if (lh::part_aligned(d_ids, d_v) && lh::part_scratch_bytes(take, e->cfg.max_metrics, e->num_cus, call_tune)) {
             // large launch over many names: partition by name, then reduce in LDS.  Sub-launches keep the scratch
@@ -517,10 +580,10 @@ int lane_launch(lh_engine *e, Lane &ln)
     if (!zc) HIPCHK(hipMemcpyAsync(ln.d_vals[h], ln.h_vals[h], n * sizeof(double), hipMemcpyHostToDevice, ln.stream));
     if (ln.mode == LANE_PAIRS) {
         if (!zc) HIPCHK(hipMemcpyAsync(ln.d_ids[h], ln.h_ids[h], n * sizeof(uint32_t), hipMemcpyHostToDevice, ln.stream));
-        rc = launch_pairs(e, di, dv, n, ln.stream);
+        rc = launch_pairs(e, di, dv, n, ln.stream, true);
     } else if (ln.mode == LANE_PAIRS16) {
         if (!zc) HIPCHK(hipMemcpyAsync(ln.d_ids[h], ln.h_ids[h], n * sizeof(uint16_t), hipMemcpyHostToDevice, ln.stream));
-        rc = launch_pairs(e, reinterpret_cast<const uint16_t *>(di), dv, n, ln.stream);
+        rc = launch_pairs(e, reinterpret_cast<const uint16_t *>(di), dv, n, ln.stream, true);
     } else if (ln.mode == LANE_COUNTS) { // the value half-buffer carries uint64 amounts
         HIPCHK(hipMemcpyAsync(ln.d_ids[h], ln.h_ids[h], n * sizeof(uint32_t), hipMemcpyHostToDevice, ln.stream));
         rc = launch_counts(e, ln.d_ids[h], reinterpret_cast<const uint64_t *>(ln.d_vals[h]), n, ln.stream);
@@ -583,6 +646,10 @@ void free_engine(lh_engine *e)
     for (hipEvent_t ev : e->flip_events) (void)hipEventDestroy(ev);
     if (e->scratch_p) (void)hipFree(e->scratch_p);
     if (e->scratch_done) (void)hipEventDestroy(e->scratch_done);
+    for (auto &a : e->aux) {
+        if (a.p) (void)hipFree(a.p);
+        if (a.done) (void)hipEventDestroy(a.done);
+    }
     if (e->d_Tx) (void)hipFree(e->d_Tx);
     if (e->d_D) (void)hipFree(e->d_D);
     if (e->d_err) (void)hipFree(e->d_err);
@@ -651,6 +718,7 @@ int create_impl(const lh_config *cfg_in, lh_engine *e)
     HIPCHK(hipStreamCreateWithFlags(&e->main_stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&e->xstream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&e->scratch_done, hipEventDisableTiming));
+    for (auto &a : e->aux) HIPCHK(hipEventCreateWithFlags(&a.done, hipEventDisableTiming));
 
     HIPCHK(hipMalloc((void **)&e->d_Tx, sizeof(double) * LH_NTHRESH));
     HIPCHK(hipMalloc((void **)&e->d_D, sizeof(double) * LH_NKEYS));
@@ -2228,6 +2296,12 @@ int lh_set_option(lh_engine *e, int option, uint64_t value)
     case LH_OPT_PART_MIN_PAIRS:
         if (value != 0 && (value < 65536 || value > (uint64_t(1) << 31))) return LH_EINVAL;
         return set_tune(e, [&](lh::PartTuning &t) { t.part_min_samples = (size_t)value; });
+    case LH_OPT_LANE_SCRATCH_BLOCKS: {
+        if (value > lh_engine::kAuxBlocks) return LH_EINVAL;
+        std::lock_guard<std::mutex> g(e->scratch_mu);
+        e->lane_blocks = (uint32_t)value;
+        return LH_OK;
+    }
     case LH_OPT_SURVEY_EVERY: {
         if (value < 1 || value > 1024) return LH_EINVAL;
         std::lock_guard<std::mutex> g(e->scratch_mu);

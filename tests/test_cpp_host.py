@@ -57,7 +57,21 @@ def test_cpp_host_layer_under_thread_sanitizer(native_lib, tmp_path):
         pytest.skip("libtsan not available")
     assert build.returncode == 0, build.stdout
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66")
-    r = subprocess.run([out, "--cpu"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=env)
+
+    def go(cmd):
+        return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=env)
+
+    # gcc 11's TSan runtime dies at start-up ("FATAL: ThreadSanitizer: unexpected memory mapping") when the kernel's
+    # address-space randomisation puts a mapping where its shadow layout does not expect one -- a property of the box
+    # (vm.mmap_rnd_bits), seen on one gpurun box in twenty, and nothing the test is about: run it again without ASLR
+    # (setarch -R), and if the runtime still cannot start there is nothing to check on this box.
+    import platform
+    import shutil
+    r = go([out, "--cpu"])
+    if "unexpected memory mapping" in r.stdout and shutil.which("setarch"):
+        r = go(["setarch", platform.machine(), "-R", out, "--cpu"])
+    if "unexpected memory mapping" in r.stdout:
+        pytest.skip("ThreadSanitizer's runtime cannot map its shadow memory on this box")
     print(r.stdout[-3000:])
     assert "ThreadSanitizer" not in r.stdout, r.stdout[-3000:]
     assert r.returncode == 0

@@ -1,0 +1,110 @@
+"""Host-fed mixed launches in the lanes' own scratch blocks (LH_OPT_LANE_SCRATCH_BLOCKS): lanes of several threads launch
+concurrently, each launch partitioned (first generation) in its own block -- every cell of every row against the oracle,
+with the blocks on (default) and off (the engine's one shared block), for both name-count classes and both id widths.
+Semantics: metrics.go:273-295 (lossless, one increment per sample whatever thread submitted it)."""
+import os
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oracle  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def la(native_lib, torch_cuda):
+    import loghisto_amd
+    return loghisto_amd
+
+
+@pytest.mark.parametrize("M,width", [(1024, 4), (1024, 2), (20000, 4), (65536, 2)])
+@pytest.mark.parametrize("blocks", [8, 2, 0])
+def test_concurrent_lanes_in_their_own_blocks(la, M, width, blocks):
+    from loghisto_amd import _native as N
+    rng = np.random.default_rng(M + blocks)
+    T, batches, per = 8, 6, 200_003                     # every launch above the partitioned minimum (131 072 pairs)
+    eng = la.Engine(max_metrics=M, num_buffers=2, num_lanes=4, lane_samples=1 << 18)
+    try:
+        eng.set_option(N.OPT_LANE_SCRATCH_BLOCKS, blocks)
+        w = 1.0 / np.arange(1, M + 1)
+        ids = [rng.choice(M, per, p=w / w.sum()).astype(np.uint16 if width == 2 else np.uint32) for _ in range(T)]
+        vals = [rng.lognormal(np.log(1e5), 1.0, per) * (1.0 + 1e-4 * ids[t]) for t in range(T)]
+        errors = []
+
+        def work(t):
+            try:
+                for _ in range(batches):
+                    eng.submit_pairs(ids[t], vals[t])
+            except Exception as exc:  # noqa: BLE001
+                errors.append(exc)
+
+        th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+        [x.start() for x in th]
+        [x.join() for x in th]
+        assert not errors, errors
+        with eng.flip() as snap:
+            got = snap.extract([0.5], M)
+            probe = sorted({0, 1, 2, 3, 17, 255, 256, M // 2, M - 1} | set(int(x) for x in rng.integers(0, M, 12)))
+            rows = {m: snap.dense_row(m) for m in probe}
+        want_count = np.zeros(M, dtype=np.int64)
+        for t in range(T):
+            want_count += batches * np.bincount(ids[t].astype(np.int64), minlength=M)
+        assert np.array_equal(got["count"].astype(np.int64), want_count)
+        for m in probe:
+            want = np.zeros(oracle.NKEYS, dtype=np.uint64)
+            for t in range(T):
+                oracle.histogram_dense(vals[t][ids[t] == m], want)
+            assert np.array_equal(rows[m], batches * want), m
+        c = eng.counters()
+        assert c["samples_partitioned"] >= T * batches * per * 0.8     # the full half-buffers were partitioned launches
+        if blocks:
+            assert c["scratch_bytes"] == 0                             # ... and none of them used the shared block
+        else:
+            assert c["scratch_bytes"] > 0
+    finally:
+        eng.close()
+
+
+def test_device_resident_launches_keep_the_shared_block(la, torch_cuda):
+    """lh_submit_pairs_device is not host-fed: its launches (and the survey tables the later generations keep between
+    calls) stay in the engine's one block whatever the option says; lanes running beside it do not disturb them."""
+    torch = torch_cuda
+    rng = np.random.default_rng(5)
+    M, n = 20000, 600_000
+    eng = la.Engine(max_metrics=M, num_buffers=2, num_lanes=2, lane_samples=1 << 18)
+    try:
+        w = 1.0 / np.arange(1, M + 1)
+        ids = rng.choice(M, n, p=w / w.sum()).astype(np.uint32)
+        v = rng.lognormal(np.log(1e5), 1.0, n)
+        d_ids, d_v = torch.from_numpy(ids.view(np.int32)).cuda(), torch.from_numpy(v).cuda()
+        stop, errors = threading.Event(), []
+
+        def lanes():
+            try:
+                while not stop.is_set():
+                    eng.submit_pairs(ids[:200_000], v[:200_000])
+                    lanes.count += 1
+            except Exception as exc:  # noqa: BLE001
+                errors.append(exc)
+        lanes.count = 0
+        th = threading.Thread(target=lanes)
+        th.start()
+        calls = 12
+        for _ in range(calls):
+            eng.submit_pairs_device(d_ids, d_v)
+        stop.set()
+        th.join()
+        assert not errors, errors
+        with eng.flip() as snap:
+            got = snap.extract([0.5], M)["count"].astype(np.int64)
+        want = calls * np.bincount(ids, minlength=M) + lanes.count * np.bincount(ids[:200_000], minlength=M)
+        assert np.array_equal(got, want)
+        c = eng.counters()
+        assert c["scratch_bytes"] > 0 and c["samples_partitioned_v3"] == calls * n
+        assert c["surveys_reused"] >= calls - 4                        # the lanes did not end the survey's reuse
+    finally:
+        eng.close()
