@@ -1,9 +1,9 @@
 // hostfed_native.cc -- host-fed (PCIe-inclusive) mixed ingest from NATIVE producer threads, at the C ABI.
 //
 // bench.py's secondary.hostfed_pairs drives the staging API from 16 Python threads (numpy copies into the pinned
-// buffers): with uint16 ids the host side, not the link, is its ceiling (profiles/r04_bench.json: 4.4 G pairs/s = 70 %
-// of PCIe Gen5 x16).  This is the same stream from plain C++ threads, the way a compiled binding (the C++ host layer's
-// stage flush, the cgo binding's ship()) produces it: every thread reserves the tail of a pinned staging buffer
+// buffers).  This is the same stream from plain C++ threads, the way a compiled binding (the C++ host layer's stage
+// flush, the cgo binding's ship()) produces it -- it showed that the producers were not what held the path at 44 GB/s
+// (the lanes' launches sharing one scratch block were: profiles/r04_hostfed_native.jsonl, 4.4 -> 5.3 G pairs/s): every thread reserves the tail of a pinned staging buffer
 // (lh_reserve_pairs16 / lh_reserve_pairs), stores its pairs there -- the one host-side copy -- and commits.
 // Checked: per-name counts of the interval against the generator's own counts.  Prints one JSON line per form.
 //
