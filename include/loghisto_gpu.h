@@ -320,7 +320,8 @@ typedef struct lh_counters {
     uint64_t window_misses;        /* samples the single-pass kernel sent to global atomics */
     uint32_t small_path_disabled;  /* 1 while adaptive dispatch routes few-name streams through the partitioned path */
     uint32_t regions_disabled;     /* 1 while a name-clustered stream keeps the mixed ingest on the exact-layout scatter */
-    uint64_t scratch_bytes;        /* HBM scratch of the partitioned mixed ingest (one block per engine)  */
+    uint64_t scratch_bytes;        /* HBM scratch of the partitioned mixed ingest: the engine's shared block (the host-fed
+                                      lanes' own small blocks, LH_OPT_LANE_SCRATCH_BLOCKS, are not counted) */
     uint64_t sublaunches;          /* partitioned sub-launches (a large launch is cut so the scratch stays bounded) */
     uint64_t samples_partitioned_v2; /* of samples_partitioned: through the survey + 2-byte-record path          */
     uint64_t counter_events;         /* (id, amount) events through lh_submit_counts*                               */
