@@ -204,10 +204,11 @@ struct lh_engine {
     std::atomic<uint64_t> c_single{0}, c_small{0}, c_part{0}, c_direct{0}, c_launches{0}, c_flips{0}, c_busy{0},
         c_extracts{0}, c_waits{0}, c_misses{0};
 
-    // Scratch of the partitioned mixed-ingest kernels: ONE block per engine, shared by every launching stream
-    // (a stream that finds it last used by another stream waits on `scratch_done` first; partitioned launches fill
-    // the chip, so nothing is lost by running them one after another).  Large launches are cut into sub-launches
-    // so that the block stays below `scratch_cap` (lh_set_option(LH_OPT_SCRATCH_CAP_BYTES)).
+    // Scratch of the partitioned mixed-ingest kernels: ONE shared block per engine for device-resident and large
+    // launches (a stream that finds it last used by another stream waits on `scratch_done` first; such launches fill
+    // the chip, so nothing is lost by running them one after another) -- the host-fed lanes' small launches have
+    // blocks of their own, `aux` below.  Large launches are cut into sub-launches so that the block stays below
+    // `scratch_cap` (lh_set_option(LH_OPT_SCRATCH_CAP_BYTES)).
     std::mutex scratch_mu;
     void *scratch_p = nullptr;
     size_t scratch_bytes = 0;
