@@ -42,6 +42,7 @@ _PROGRAMS = [
 _HIP_PROGRAMS = [
     ("tools/read_ceiling.hip", "read_ceiling"),      # what a kernel that only reads gets from HBM (K1's ceiling)
     ("tools/valu_rates.hip", "valu_rates"),          # issue cost of the bucket index's VALU instructions
+    ("tools/row_stride.hip", "row_stride"),          # the 65 536 rows' windows read / cleared / flushed at several row strides
 ]
 
 

@@ -141,6 +141,30 @@ def test_third_generation_is_exact(native_lib, torch_cuda, M, n, kind, skew, per
                 check(snap, ids, v, M, got)
 
 
+def test_one_bucket_of_a_frequent_name_without_hot_windows(native_lib, torch_cuda):
+    """With the first level's hot windows off the most frequent name reaches the second level with every sample in one
+    of two adjacent buckets: ~60 000 records of a 62 000-record work slot land in ONE LDS cell there, its neighbour gets
+    3 % of that.  (Written for a 16-bit-cell form of that pass -- measured slower and dropped, profiles/
+    r05_level23_experiments.txt -- and kept: no other case puts 10^4 .. 10^5 counts into single cells of levels 2 and 3.)"""
+    import loghisto_amd
+    M, n = 65536, 4_000_000
+    rng = np.random.default_rng(99)
+    ids = _ids(rng, M, n, 1.0, permute=False)
+    v = np.where(rng.random(n) < 0.97, 123.0, 124.0)      # bins 482 and 483 of every name: the two halves of one word
+    d_ids, d_v = _dev(torch_cuda, ids), _dev(torch_cuda, v)
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        e.set_option(N.OPT_PART_V3_MIN_PAIRS, 1 << 17)
+        e.set_option(N.OPT_HOT_WINDOWS, 0)
+        for log_w in (10, 11):
+            e.set_option(N.OPT_PART_V3_LOG_W, log_w)
+            e.submit_pairs_device(d_ids, d_v)
+            e.sync()
+            with e.flip() as snap:
+                got = snap.extract(PCTS, M)
+                check(snap, ids, v, M, got)
+        assert e.counters()["samples_partitioned_v3"] == 2 * n
+
+
 def test_survey_is_reused_while_the_stream_looks_the_same(native_lib, torch_cuda):
     """LH_OPT_SURVEY_EVERY (default 8): calls run on the previous call's survey while its tables are still in the
     scratch block, the window width is unchanged and the self-metrics stay healthy; a stream that changes under a stale

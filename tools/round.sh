@@ -1,0 +1,67 @@
+#!/bin/bash
+# tools/round.sh -- the GPU calls of a round as sub-commands of ONE script (each is one `gpurun` call; outputs go to
+# gpurun_out/<tag>/ and the summaries worth keeping are copied into profiles/ by hand).
+#
+#   gpurun --timeout 900 -- 'bash tools/round.sh <sub-command> [tag] [args...]'
+#
+#   ab <tag> <suffix,...>   mixed-ingest A/B on one box: the third generation's parity tests against the product
+#                           library, then config 4's slice and the 1e9-pair call (65 536 names) and config 3 (1 024 names)
+#                           timed with the product library and with every build/liblhgpu_tuning_<suffix>.so
+#                           (tools/build_tuning.py -D... --name <suffix>), then the product's kernel split
+#   abl <tag> <suffix,...>  timing of ablation builds (wrong counts by construction) + tools/row_stride.hip
+#   tests <tag> [pytest args]   the GPU suite (or a part of it) + smoke()
+#   profile <tag>           the round's evidence: tools/profile_round.sh (bench lines, kernel traces, PMC passes)
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+SUB=$1; TAG=${2:-r5}; shift 2
+OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; cd $R
+
+sweep() { # sweep <pairs> <names> <reps> <extra sweep.py args...>: one line per distribution
+    local n=$1 m=$2 reps=$3; shift 3
+    timeout 400 python tools/sweep.py --samples $n --pairs $m --reps $reps "$@" 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    j = json.loads(l); v = j['v3']; n = max(1, v['samples_partitioned_v3'])
+    print('n=$n names=$m', '$*', j['dist'], 'avg_ms %.3f min_ms %.3f' % (j['avg_ms'], j['min_ms']), 'frac %.3f' % j['frac_hbm_peak'],
+          'ovf', j['region_overflows'], 'logw', v['window_log2'],
+          'l1 %.3f l2 %.3f l2ovf %.5f p2miss %.5f' % (v['records_level1'] / n, v['records_level2'] / n, v['level2_overflows'] / n, v['reduce_window_misses'] / n))"
+}
+ktrace() { # ktrace <pairs> <names> <file>: per-kernel averages of a sweep under rocprofv3 --kernel-trace
+    (cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/pk
+     timeout 400 rocprofv3 --kernel-trace -d /tmp/pk -o t -- python $R/tools/sweep.py --samples $1 --pairs $2 --reps 4 --dists lognormal > /dev/null 2>&1
+     python $R/profiles/summarize_rocpd.py stats /tmp/pk/t_results.db | grep -E "kernel|k_scatter|k_part|k_split|k_survey|k_plan|k_v3|k_ingest" | cut -c1-170) | tee $3
+}
+
+case $SUB in
+ab)
+    (timeout 1200 python -m pytest tests/test_gpu_part3.py tests/test_gpu_options.py tests/test_gpu_pairs16.py -x -q) > $OUT/pytest.log 2>&1
+    tail -5 $OUT/pytest.log | cut -c1-300
+    for sfx in "" $(echo ${1:-} | tr ',' ' '); do
+        lib=""; [ -n "$sfx" ] && lib="--lib loghisto_amd/build/liblhgpu_tuning_$sfx.so"
+        echo "== ${sfx:-product}" | tee -a $OUT/ab.txt
+        sweep 1.25e8 65536 24 --dists lognormal $lib | tee -a $OUT/ab.txt
+        sweep 1e9 65536 5 --dists lognormal $lib | tee -a $OUT/ab.txt
+    done
+    sweep 1e9 65536 3 --dists constant,kvalues8,bimodal,lognormal25,loguniform | tee -a $OUT/ab.txt
+    sweep 1e9 1024 5 --dists lognormal,kvalues8 | tee -a $OUT/ab.txt
+    ktrace 1.25e8 65536 $OUT/trace_slice.txt
+    ktrace 1e9 65536 $OUT/trace_1e9.txt
+    ;;
+abl)    # abl <tag> <suffix,...>: timing only (sweep.py --nocheck) of ablation builds, beside the row-store access tool
+    loghisto_amd/build/row_stride --reps 10 2>&1 | cut -c1-250 | tee $OUT/row_stride.jsonl
+    for sfx in $(echo ${1:-} | tr ',' ' '); do
+        echo "== $sfx" | tee -a $OUT/abl.txt
+        sweep 1.25e8 65536 16 --dists lognormal --nocheck --lib loghisto_amd/build/liblhgpu_tuning_$sfx.so | tee -a $OUT/abl.txt
+        sweep 1e9 65536 4 --dists lognormal --nocheck --lib loghisto_amd/build/liblhgpu_tuning_$sfx.so | tee -a $OUT/abl.txt
+    done
+    ;;
+tests)
+    (timeout 2400 python -m pytest tests -m gpu -x -q "$@") > $OUT/pytest.log 2>&1
+    tail -6 $OUT/pytest.log | cut -c1-300
+    (timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')") 2>&1 | tail -2 | tee $OUT/smoke.log
+    ;;
+profile)
+    bash tools/profile_round.sh $TAG "$@"
+    ;;
+*)
+    echo "unknown sub-command: $SUB"; exit 2;;
+esac
