@@ -89,7 +89,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--samples", type=float, default=1e9, help="float64 samples per GPU per step (c2 / c3)")
     ap.add_argument("--dist", default="lognormal", choices=["lognormal", "constant", "uniform", "exponential",
-                                                            "normal", "loguniform", "lognormal25", "kvalues2",
+                                                            "normal", "loguniform", "loguniform21", "lognormal25", "kvalues2",
                                                             "kvalues4", "kvalues8", "kvalues16", "bimodal"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -157,12 +157,16 @@ def make_samples(n: int, kind: str, seed: int) -> torch.Tensor:
             body = torch.randn(m, dtype=torch.float64, device="cuda", generator=g).add_(math.log(1e5)).exp_()
             far[lo:lo + step] = torch.where(u < 1e-3, far[lo:lo + step], body)
         return far
-    if kind in ("uniform", "loguniform", "exponential"):
+    if kind in ("uniform", "loguniform", "loguniform21", "exponential"):
         v = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
         if kind == "uniform":
             return v.mul_(1e9)
         if kind == "loguniform":
             return v.mul_(21.0).sub_(3.0).mul_(math.log(10.0)).exp_()
+        if kind == "loguniform21":
+            # a stream only slightly wider than K1's main window (|v| < 6.1e17): 10^U(-3, 21), 14 % of it up to 740 bins
+            # above the window -- the bins a floating window must sit ADJACENT to the main window for
+            return v.mul_(24.0).sub_(3.0).mul_(math.log(10.0)).exp_()
         return v.neg_().log1p_().neg_().mul_(1e6)
     v = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
     if kind == "normal":

@@ -52,7 +52,9 @@
 extern "C" {
 #endif
 
-#define LH_ABI_VERSION 4           /* 4: uint16-id pairs (lh_*pairs16*)         */
+#define LH_ABI_VERSION 5           /* 5: lh_row_stride() (rows of lh_snapshot_rows are no longer 65 536 cells apart), the
+                                      tuning / test options moved to loghisto_gpu_tuning.h, ingest falls back to the
+                                      scratch-free kernel when scratch cannot be had; 4: uint16-id pairs (lh_*pairs16*) */
 #define LH_NKEYS 65536            /* int16 key space (metrics.go:316)        */
 #define LH_NTHRESH 70980          /* extended-key thresholds incl. sentinel  */
 #define LH_MAX_PERCENTILES 32
@@ -213,9 +215,13 @@ int lh_buckets(lh_snapshot *s, uint32_t id, int16_t *keys, uint64_t *counts, siz
 int lh_buckets_all(lh_snapshot *s, uint32_t first, size_t nmetrics, uint64_t *offsets, int16_t *keys,
                    uint64_t *counts, size_t cap, size_t *total);
 /* Dense device view of the snapshot for the multi-GPU merge: row r of metric r
- * is d_counts + r*65536 (uint64).  After an in-place reduction the caller must
- * call lh_snapshot_mark_dirty so that extract/clear cover the merged cells. */
+ * is (uint64 *)d_counts + r * lh_row_stride(), LH_NKEYS cells long (bin = key ^ 0x8000).
+ * The rows are NOT back to back: lh_row_stride() > LH_NKEYS (ABI 5; rows exactly 512 KiB
+ * apart put every name's occupied window on the same low address bits -- DESIGN.md 4).
+ * After an in-place reduction the caller must call lh_snapshot_mark_dirty so that
+ * extract/clear cover the merged cells. */
 int lh_snapshot_rows(lh_snapshot *s, void **d_counts, uint32_t *nrows);
+size_t lh_row_stride(void); /* in uint64 cells */
 int lh_snapshot_ranges(lh_snapshot *s, void **d_ranges /* uint32[nrows][2] lo,hi bins */);
 int lh_snapshot_mark_dirty(lh_snapshot *s, uint32_t first_row, uint32_t nrows, uint32_t lo_bin, uint32_t hi_bin);
 /* K4 -- multi-GPU merge of a snapshot across the ranks of an RCCL communicator (one process per GPU).
@@ -332,19 +338,17 @@ typedef struct lh_counters {
     uint64_t records_level2;         /* ... records its second level forwarded to the reduce pass                     */
     uint64_t level2_overflows;       /* ... records that found a second-level region full (exact path)                */
     uint64_t reduce_window_misses;   /* ... records outside their window in the reduce pass (exact path)              */
-    uint64_t surveys_reused;         /* ... calls that ran on the previous call's survey (LH_OPT_SURVEY_EVERY)        */
+    uint64_t surveys_reused;         /* calls that ran on an earlier call's survey (LH_OPT_SURVEY_EVERY)              */
+    uint64_t scratch_alloc_failures; /* scratch blocks of the mixed ingest that could not be allocated (ABI 5)         */
+    uint64_t samples_fallback;       /* samples that therefore went through the scratch-free kernel: exact, slower     */
 } lh_counters;
 int lh_get_counters(lh_engine *e, lh_counters *out);
 
-/* Dispatch settings.  Every option only chooses among EXACT kernel paths or sizes a buffer: no option (and no
- * environment variable -- the library never calls getenv) can change a result.  Takes effect for later calls;
- * not synchronised with concurrent submits (set options before the producers start).
- *   LH_OPT_TWO_LEVEL_ABOVE    second scatter level when a level-1 partition holds more names than this (default 32,
- *                             i.e. above 8 192 names; 0 forces it whenever there are more than 4 names per partition)
- *   LH_OPT_HOT_MIN_TILES      hot-name windows in the scatter pass when every workgroup gets >= this many
- *                             4 096-sample tiles (default 32); 1 exercises the path on small inputs
- *   LH_OPT_HOT_WINDOWS        0 / 1: hot-name windows allowed (default 1)
- *   LH_OPT_NAMES_PER_PARTITION names per LDS-reduce partition, 1..64 (default 4 = 4 096-bin windows)
+/* Settings.  Every option only chooses among EXACT kernel paths or sizes a buffer: no option (and no environment
+ * variable -- the library never calls getenv) can change a result.  Takes effect for later calls; not synchronised
+ * with concurrent submits (set options before the producers start).  These are the operational ones; the keys that
+ * only exist to steer the mixed ingest's path choice in tests and tuning runs (generation switches, size thresholds,
+ * window widths, the allocation-failure hook) live in loghisto_gpu_tuning.h and are not part of the drop-in contract.
  *   LH_OPT_EXTRACT_ZERO_COPY  0 / 1: small extract results (<= 32 KiB) are stored by the kernel straight into pinned
  *                             host memory (default 1); a value >= 4096 also sets that size limit (measured: beyond
  *                             32 KiB the copy engine wins -- 1 024 names, 158 KB: 48 us by copy, 95 us by stores)
@@ -354,58 +358,26 @@ int lh_get_counters(lh_engine *e, lh_counters *out);
  *                             Engines with more than 8 192 names (two scatter levels: ~1.2 GB of chunk pools and
  *                             ~0.35 ms of fixed work per launch) are NOT cut by default -- a 1e9-pair launch over
  *                             65 536 names takes a 9 GB block -- unless one of these two options was set, and then
- *                             not below 2^28 pairs
- *   LH_OPT_PART_V2            0 / 1: the survey + 2-byte-record generation of the partitioned path (default 1;
- *                             used for 33 .. 8 192 names)
- *   LH_OPT_PART_V2_MIN_PAIRS  smallest launch that takes it (default 2^25, the measured crossover with the first generation; >= 2^17: tests
- *                             exercise it on small inputs)
- *   LH_OPT_PART_V2_SHAPE      bit 0: two 512-thread scatter workgroups per CU over <= 128 partitions instead of one
- *                             1 024-thread workgroup over <= 256; bit 1: fixed per-partition LDS regions (records
- *                             placed by the classifying phase) instead of the exact per-tile layout.  Default 2.
- *                             With bit 1 set the engine falls back to the exact layout while more than 2 % of an
- *                             interval's samples overflow their regions (a stream clustered by name), see
- *                             lh_counters.regions_disabled
- *   LH_OPT_SMALL_PATH         0 / 1: the single-pass kernel for <= 32 names (1 also re-arms it after adaptive
- *                             dispatch turned it off)
- *   LH_OPT_PART_V3            0 / 1: the third generation of the partitioned path (hashed survey, region scatter of
- *                             4-byte records, a second level that counts each partition's frequent names in place;
- *                             default 1; used for 8 193 .. 65 536 names -- BASELINE config 4's name count)
- *   LH_OPT_PART_V3_MIN_PAIRS  smallest launch that takes it (default 2^18; >= 2^17: tests exercise it on small inputs)
- *   LH_OPT_SURVEY_EVERY       8 193 .. 65 536 names: a call may run on the survey of an earlier call (hot names, region
+ *                             not below 2^28 pairs.  A block that cannot be had never fails a call: the sub-launch goes
+ *                             through the scratch-free kernel (lh_counters.scratch_alloc_failures / samples_fallback)
+ *   LH_OPT_SURVEY_EVERY       33 .. 65 536 names: a call may run on the survey of an earlier call (hot names, region
  *                             sizes, per-partition ranking stay in the scratch block) until this many calls have used
  *                             it (default 32; 1 = every call surveys).  Only while the stream looks the same: a survey
- *                             is also repeated when the window width changed, when anything else used the block, or
- *                             when more than 2 % of the pairs of the calls completed since took an overflow / window-miss
- *                             path.  A stale survey costs speed, never exactness
- *   LH_OPT_PART_MIN_PAIRS     smallest mixed launch that takes a partitioned path at all (below it: one global atomic per
- *                             sample); 0 = the default, which follows the name count; >= 65 536 otherwise
+ *                             is also repeated when the window width or scatter shape changed, when anything else used
+ *                             the block, or when more than 2 % of the pairs of the calls completed since took an
+ *                             overflow / window-miss path.  A stale survey costs speed, never exactness
  *   LH_OPT_LANE_SCRATCH_BLOCKS  0 .. 8 (default 8): host-fed mixed launches (lh_submit_pairs*, lh_commit_pairs*: one staging
  *                             half-buffer each, at most 2^22 pairs) take the first partitioned generation in one of this
  *                             many scratch blocks of their own, so that one lane's later passes run beside another
  *                             lane's link-bound read; 0 = every partitioned launch shares the engine's one block
  *   LH_OPT_LANE_ZERO_COPY     0 / 1: the ingest kernels read the pinned staging buffers of lh_submit* / lh_reserve_pairs
- *                             in place over PCIe (default 1) instead of after a hipMemcpyAsync into HBM (0)
- *   LH_OPT_PART_V3_LOG_W      log2 of its second-level window width, 10 .. 13 (32 .. 4 names per fine partition);
- *                             0 (default) = follow the survey: every call's survey reports the width that covers
- *                             95 % of the sampled mass and the following calls use it (lh_counters.window_log2) */
+ *                             in place over PCIe (default 1) instead of after a hipMemcpyAsync into HBM (0) */
 enum {
-    LH_OPT_TWO_LEVEL_ABOVE = 1,
-    LH_OPT_HOT_MIN_TILES = 2,
-    LH_OPT_HOT_WINDOWS = 3,
-    LH_OPT_NAMES_PER_PARTITION = 4,
     LH_OPT_EXTRACT_ZERO_COPY = 5,
     LH_OPT_SCRATCH_CAP_BYTES = 6,
     LH_OPT_SUBLAUNCH_PAIRS = 7,
-    LH_OPT_SMALL_PATH = 8,
-    LH_OPT_PART_V2 = 9,
-    LH_OPT_PART_V2_MIN_PAIRS = 10,
-    LH_OPT_PART_V2_SHAPE = 11,
-    LH_OPT_PART_V3 = 12,
-    LH_OPT_PART_V3_MIN_PAIRS = 13,
-    LH_OPT_PART_V3_LOG_W = 14,
     LH_OPT_LANE_ZERO_COPY = 15,
     LH_OPT_SURVEY_EVERY = 16,
-    LH_OPT_PART_MIN_PAIRS = 17,
     LH_OPT_LANE_SCRATCH_BLOCKS = 18
 };
 int lh_set_option(lh_engine *e, int option, uint64_t value);

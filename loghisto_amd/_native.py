@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblhgpu.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 NKEYS = 65536
 NTHRESH = 70980
 MAX_PERCENTILES = 32
@@ -41,9 +41,11 @@ class LhCounters(C.Structure):
                                                                 ("records_level2", C.c_uint64),
                                                                 ("level2_overflows", C.c_uint64),
                                                                 ("reduce_window_misses", C.c_uint64),
-                                                               ("surveys_reused", C.c_uint64)]
+                                                               ("surveys_reused", C.c_uint64),
+                                                               ("scratch_alloc_failures", C.c_uint64),
+                                                               ("samples_fallback", C.c_uint64)]
 
-# lh_set_option keys (include/loghisto_gpu.h)
+# lh_set_option keys (include/loghisto_gpu.h; the path-steering ones and the fault hook: include/loghisto_gpu_tuning.h)
 OPT_TWO_LEVEL_ABOVE, OPT_HOT_MIN_TILES, OPT_HOT_WINDOWS, OPT_NAMES_PER_PARTITION = 1, 2, 3, 4
 OPT_EXTRACT_ZERO_COPY, OPT_SCRATCH_CAP_BYTES, OPT_SUBLAUNCH_PAIRS, OPT_SMALL_PATH = 5, 6, 7, 8
 OPT_PART_V2, OPT_PART_V2_MIN_PAIRS, OPT_PART_V2_SHAPE = 9, 10, 11
@@ -52,6 +54,26 @@ OPT_LANE_ZERO_COPY = 15
 OPT_SURVEY_EVERY = 16
 OPT_PART_MIN_PAIRS = 17
 OPT_LANE_SCRATCH_BLOCKS = 18
+OPT_FAIL_SCRATCH_ALLOCS = 19
+
+
+class LhDispatchQuery(C.Structure):
+    """lh_dispatch_query (include/loghisto_gpu_tuning.h): the state the mixed ingest's path choice reads."""
+    _fields_ = [("struct_size", C.c_uint32), ("max_metrics", C.c_uint32), ("n", C.c_uint64), ("ids_addr", C.c_uint64),
+                ("vals_addr", C.c_uint64), ("id_width", C.c_uint32), ("host_fed", C.c_uint32), ("num_cus", C.c_uint32),
+                ("lane_blocks", C.c_uint32), ("lane_samples", C.c_uint64), ("small_disabled", C.c_uint32),
+                ("regions_disabled", C.c_uint32), ("v3_disabled", C.c_uint32), ("call_log_w", C.c_uint32),
+                ("scratch_cap", C.c_uint64), ("sublaunch_pairs", C.c_uint64), ("part_min_pairs", C.c_uint64),
+                ("v2_min_pairs", C.c_uint64), ("v3_min_pairs", C.c_uint64), ("v2_off", C.c_uint32), ("v3_off", C.c_uint32),
+                ("hot_off", C.c_uint32), ("v2_shape_set", C.c_uint32), ("v2_shape", C.c_uint32), ("fail_allocs", C.c_uint32)]
+
+
+class LhDispatchStep(C.Structure):
+    _fields_ = [("path", C.c_uint32), ("lane_block", C.c_uint32), ("take", C.c_uint64), ("scratch", C.c_uint64),
+                ("fell_back", C.c_uint32), ("peeled", C.c_uint32)]
+
+
+PATH_DIRECT, PATH_SMALL, PATH_GEN1, PATH_GEN2, PATH_GEN3 = range(5)
 
 
 class LhExtractView(C.Structure):
@@ -84,6 +106,11 @@ class LhStats(C.Structure):
 _vp, _sz = C.c_void_p, C.c_size_t
 _dp, _u32p, _u64p = C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
 _i16p, _u8p = C.POINTER(C.c_int16), C.POINTER(C.c_uint8)
+
+# name -> (restype, argtypes): the test / tuning hooks of include/loghisto_gpu_tuning.h
+TUNING_SIGNATURES = {
+    "lh_dispatch_probe": (C.c_int, [C.POINTER(LhDispatchQuery), C.POINTER(LhDispatchStep), _sz, C.POINTER(_sz)]),
+}
 
 # name -> (restype, argtypes): every symbol include/loghisto_gpu.h declares.
 SIGNATURES = {
@@ -125,6 +152,7 @@ SIGNATURES = {
     "lh_buckets": (C.c_int, [_vp, C.c_uint32, _i16p, _u64p, _sz, C.POINTER(_sz)]),
     "lh_buckets_all": (C.c_int, [_vp, C.c_uint32, _sz, _u64p, _i16p, _u64p, _sz, C.POINTER(_sz)]),
     "lh_snapshot_rows": (C.c_int, [_vp, C.POINTER(_vp), _u32p]),
+    "lh_row_stride": (C.c_size_t, []),
     "lh_snapshot_ranges": (C.c_int, [_vp, C.POINTER(_vp)]),
     "lh_snapshot_mark_dirty": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "lh_snapshot_merge": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_uint32, _u32p, _u32p]),
@@ -178,7 +206,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
     except OSError as exc:  # e.g. libamdhip64 not found
         raise NativeLibraryError(f"cannot load {LIB_PATH}: {exc}") from exc
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(TUNING_SIGNATURES.items()):
         try:
             fn = getattr(L, name)
         except AttributeError as exc:

@@ -25,6 +25,7 @@ _UNITS = [
     ("lh_kernels_small.hip", ["--offload-arch=gfx950"]),
     ("lh_kernels_fmt.hip", ["--offload-arch=gfx950"]),
     ("lh_engine.cc", []),
+    ("lh_dispatch.cc", []),         # the mixed ingest's path choice: pure functions (tests/test_dispatch.py)
     ("host/metric_system.cc", []),   # C++ host layer with the reference's MetricSystem API (include/loghisto.hpp)
 ]
 
@@ -90,6 +91,19 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
         if force or _stale(out, [s, LIB] + headers):
             cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-Wall", "-I", INCLUDE, s, "-o", out,
                    "-L", _HERE, "-llhgpu", "-Wl,-rpath," + _HERE, "-Wl,-rpath,$ORIGIN/.."]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+    # the path choice's pure functions, table-tested on the CPU box (tests/test_dispatch.py): needs the HIP headers for
+    # the launch interface's types only
+    dsrc = os.path.join(root, "tests", "cpp", "dispatch_test.cc")
+    if os.path.exists(dsrc):
+        out = os.path.join(bdir, "dispatch_test")
+        if force or _stale(out, [dsrc, LIB, os.path.join(CSRC, "lh_dispatch.cc")] + headers):
+            rocm = os.path.dirname(os.path.dirname(os.path.realpath(hipcc)))
+            cmd = ["g++", "-O1", "-std=c++17", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(rocm, "include"),
+                   dsrc, "-o", out, "-L", _HERE, "-llhgpu", "-Wl,-rpath," + _HERE, "-Wl,-rpath,$ORIGIN/..",
+                   "-L", os.path.join(rocm, "lib"), "-Wl,-rpath," + os.path.join(rocm, "lib")]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)

@@ -11,7 +11,8 @@
 //
 // All bucket arithmetic runs in the kernels of lh_kernels.hip.  There is no CPU
 // compute path: without a gfx950 device lh_create fails with LH_ENODEVICE.
-#include "../../include/loghisto_gpu.h"
+#include "../../include/loghisto_gpu_tuning.h"
+#include "lh_dispatch.h"
 #include "lh_kernels.h"
 
 #include <hip/hip_runtime_api.h>
@@ -222,13 +223,17 @@ struct lh_engine {
     // `survey_every` - 1 calls have reused them and the self-metrics of the calls that have completed since the
     // survey stay healthy (region overflows + level-2 overflows + reduce-pass window misses < 2 % of the pairs).
     // The survey only decides WHERE a sample is counted: a stale one costs speed, never exactness.  (scratch_mu)
-    bool v3_tables_valid = false;
-    uint32_t v3_tables_log_w = 0, v3_tables_age = 0, survey_every = 32;
+    lh::SurveyTables tables;              // (lh_dispatch.h; second generation, round 5: the same rules)
+    uint32_t survey_every = 32;
     // Every lh_set_option that feeds a launch plan (LDS budgets, window cells, generation switches) is written under
     // scratch_mu and bumps tune_gen; a call takes ONE snapshot of `tune` (all its sub-launches share the survey's
     // tables, which are laid out for one plan) and tables are reused only by calls that saw the same tune_gen.
-    uint64_t tune_gen = 0, v3_tables_tune_gen = 0;
+    uint64_t tune_gen = 0;
     uint64_t v3_seen_bad = 0, v3_seen_pairs = 0; // self-metrics / pairs at the last check
+    uint64_t v2_seen_bad = 0, v2_seen_pairs = 0;
+    // a scratch block that cannot be had sends the sub-launch through the scratch-free kernel (exact, slower)
+    std::atomic<uint64_t> c_alloc_fail{0}, c_fallback{0};
+    std::atomic<uint32_t> fail_allocs{0}; // LH_OPT_FAIL_SCRATCH_ALLOCS: the next N scratch allocations fail (tests)
     // A stream without skew among its names gives the third generation nothing to count in place: with more than 3/4
     // of the pairs forwarded to the reduce pass (65 536 uniform names: 88 %, 9.7 ms per 1e9 pairs) the first
     // generation's fixed two-level split is faster (7.9 ms).  Judged over completed calls; re-armed every 64 flips.
@@ -255,7 +260,6 @@ struct lh_engine {
         bool used = false;
     };
     static constexpr uint32_t kAuxBlocks = 8;
-    static constexpr size_t kAuxMaxPairs = size_t(1) << 22; // larger launches amortise their passes: the shared block
     AuxScratch aux[kAuxBlocks];
     uint32_t lane_blocks = kAuxBlocks, aux_next = 0;
     size_t scratch_cap = size_t(1536) << 20;     // 1.5 GiB
@@ -315,7 +319,7 @@ int launch_single(lh_engine *e, uint32_t id, const double *d_v, size_t n, hipStr
     const size_t kMaxLaunch = size_t(1) << 31;
     while (n) {
         const size_t take = n < kMaxLaunch ? n : kMaxLaunch;
-        HIPCHK(lh::launch_ingest_single(d_v, take, b.counts + (size_t)id * LH_NKEYS, b.ranges + 2 * (size_t)id,
+        HIPCHK(lh::launch_ingest_single(d_v, take, b.counts + (size_t)id * LH_ROW_STRIDE, b.ranges + 2 * (size_t)id,
                                         e->d_Tx, e->num_cus, s));
         e->c_single.fetch_add(take, std::memory_order_relaxed);
         e->c_launches.fetch_add(1, std::memory_order_relaxed);
@@ -325,231 +329,283 @@ int launch_single(lh_engine *e, uint32_t id, const double *d_v, size_t n, hipStr
     return LH_OK;
 }
 
-int launch_pairs(lh_engine *e, lh::Ids d_ids, const double *d_v, size_t n, hipStream_t s, bool host_fed = false)
+// ---- mixed (id, value) ingest: lh_dispatch.h chooses, these execute ------------------------------------------------
+
+// A scratch block that cannot be had is not an error of the call (ingest never fails, metrics.go:251, 273): the caller
+// of this function sends the sub-launch through the scratch-free direct kernel instead -- exact, slower -- and the
+// engine counts it (lh_counters.scratch_alloc_failures / samples_fallback).  LH_OPT_FAIL_SCRATCH_ALLOCS makes the next N
+// attempts fail (tests/test_gpu_faults.py).
+bool scratch_alloc(lh_engine *e, void **p, size_t bytes)
 {
-    EpochBuffer &b = e->bufs[(size_t)e->cur];
-    count_samples(b, n);
-    const size_t kMaxLaunch = size_t(1) << 30;
-    // Slices taken at an odd sample index leave BOTH arrays one element short of the vector-load alignment of
-    // the fast kernels (ids 8-byte, values 16-byte): peel that one sample through the direct kernel instead of
-    // sending the whole launch down the one-atomic-per-sample path (25x slower).
-    if (n > 1 && ((uintptr_t)d_ids.p & (2u * d_ids.width - 1u)) == d_ids.width && ((uintptr_t)d_v & 15) == 8) {
-        HIPCHK(lh::launch_ingest_pairs(d_ids, d_v, 1, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx, e->d_err,
-                                       e->num_cus, s));
-        e->c_direct.fetch_add(1, std::memory_order_relaxed);
-        e->c_launches.fetch_add(1, std::memory_order_relaxed);
-        d_ids = d_ids.plus(1);
-        d_v++;
-        n--;
+    uint32_t left = e->fail_allocs.load(std::memory_order_relaxed);
+    while (left && !e->fail_allocs.compare_exchange_weak(left, left - 1u, std::memory_order_relaxed)) {}
+    hipError_t he = left ? hipErrorOutOfMemory : hipMalloc(p, bytes);
+    if (he == hipSuccess) return true;
+    if (!left) set_last_error("hipMalloc(scratch)", he); // (also clears the runtime's sticky error)
+    *p = nullptr;
+    e->c_alloc_fail.fetch_add(1, std::memory_order_relaxed);
+    return false;
+}
+
+int run_direct(lh_engine *e, EpochBuffer &b, lh::Ids d_ids, const double *d_v, size_t take, hipStream_t s)
+{
+    HIPCHK(lh::launch_ingest_pairs(d_ids, d_v, take, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx, e->d_err,
+                                   e->num_cus, s));
+    e->c_direct.fetch_add(take, std::memory_order_relaxed);
+    return LH_OK;
+}
+
+int run_small(lh_engine *e, EpochBuffer &b, lh::Ids d_ids, const double *d_v, size_t take, hipStream_t s)
+{
+    HIPCHK(lh::launch_ingest_pairs_small(d_ids, d_v, take, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx, e->d_err,
+                                         e->num_cus, s));
+    e->small_samples.fetch_add(take, std::memory_order_relaxed);
+    e->c_small.fetch_add(take, std::memory_order_relaxed);
+    return LH_OK;
+}
+
+int run_fallback(lh_engine *e, EpochBuffer &b, lh::Ids d_ids, const double *d_v, size_t take, hipStream_t s)
+{
+    e->c_fallback.fetch_add(take, std::memory_order_relaxed);
+    return run_direct(e, b, d_ids, d_v, take, s);
+}
+
+// One call's view of the shared block: ONE survey per call, not one per sub-launch (second and third generation).  The
+// survey's tables live in the shared scratch block, which every stream of the engine shares: the block's lock is held
+// from the call's first partitioned sub-launch to its last, so that no other stream's launch can overwrite them in
+// between (enqueueing is all that happens under the lock; the kernels run later, in stream order behind `scratch_done`).
+struct PairsCall {
+    lh::DispatchState st;
+    uint64_t tune_gen = 0;
+    bool surveyed = false; // the block holds the survey this call runs on (its own, or a reused one)
+    bool judged = false;   // the reuse decision is made once per call, at its first surveyed-generation launch
+    std::unique_lock<std::mutex> lock;
+};
+
+// A lane's half-buffer through the first generation in one of the lanes' own blocks (lh_engine::aux).  The lock is held
+// only while the block is picked and the launch enqueued (the lanes' small launches used to keep it for the
+// rest of the call, direct and small kernels included).
+int run_lane_block(lh_engine *e, EpochBuffer &b, PairsCall &c, const lh::Step &st, lh::Ids d_ids, const double *d_v,
+                   hipStream_t s)
+{
+    // (a call whose earlier sub-launch went through the shared block already holds the lock, and keeps it)
+    struct Hold {
+        PairsCall &c;
+        const bool had;
+        Hold(PairsCall &c_, std::mutex &m) : c(c_), had(c_.lock.owns_lock()) { if (!had) c.lock = std::unique_lock<std::mutex>(m); }
+        ~Hold() { if (!had) c.lock.unlock(); }
+    } hold(c, e->scratch_mu);
+    const uint32_t nb = e->lane_blocks;
+    if (!nb) return run_fallback(e, b, d_ids, d_v, st.take, s); // (the option changed under the call: exact anyway)
+    lh_engine::AuxScratch *a = nullptr;
+    for (uint32_t i = 0; i < nb && !a; i++)
+        if (e->aux[i].used && e->aux[i].stream == s) a = &e->aux[i]; // stream order is all it needs
+    for (uint32_t i = 0; i < nb && !a; i++)
+        if (!e->aux[i].used) a = &e->aux[i];
+    for (uint32_t i = 0; i < nb && !a; i++)
+        if (hipEventQuery(e->aux[i].done) == hipSuccess) a = &e->aux[i];
+    if (!a) a = &e->aux[e->aux_next++ % nb];                          // all busy: behind one of them
+    (void)hipGetLastError(); // hipEventQuery's "not ready" is not an error of this call
+    if (a->bytes < st.scratch) {
+        if (a->p) {
+            if (a->used) HIPCHK(hipEventSynchronize(a->done));
+            HIPCHK(hipFree(a->p));
+            a->p = nullptr;
+            a->bytes = 0;
+            a->used = false;
+        }
+        if (!scratch_alloc(e, &a->p, st.scratch_alloc)) return run_fallback(e, b, d_ids, d_v, st.take, s);
+        a->bytes = st.scratch_alloc;
     }
-    // One survey per call, not one per sub-launch (second and third generation).  The survey's tables live in the
-    // scratch block, which every stream of the engine shares: the block's lock is held from the call's first
-    // partitioned sub-launch to its last, so that no other stream's launch can overwrite them in between (enqueueing
-    // is all that happens under the lock; the kernels run later, in stream order behind `scratch_done`).
-    bool surveyed = false;
-    std::unique_lock<std::mutex> scratch_lock(e->scratch_mu, std::defer_lock);
-    // Third generation: the window width the last completed survey reported (0 until one has run).  Read ONCE per
-    // call: the sub-launches of a call share the survey's per-partition tables, which are laid out for one width,
-    // and the call's own survey stores its report while later sub-launches are still being enqueued.
-    lh::PartTuning call_tune;
-    uint64_t call_tune_gen;
+    if (a->used && a->stream != s) HIPCHK(hipStreamWaitEvent(s, a->done, 0));
+    HIPCHK(lh::launch_ingest_pairs_part(d_ids, d_v, st.take, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx, e->d_err,
+                                        a->p, a->bytes, e->num_cus, st.tune, s));
+    HIPCHK(hipEventRecord(a->done, s));
+    a->stream = s;
+    a->used = true;
+    e->c_part.fetch_add(st.take, std::memory_order_relaxed);
+    e->c_sublaunches.fetch_add(1, std::memory_order_relaxed);
+    return LH_OK;
+}
+
+// scratch_mu held.  The shared block, at least `bytes` large; false: cannot be had.
+bool shared_block(lh_engine *e, PairsCall &c, size_t bytes, int *rc)
+{
+    *rc = LH_OK;
+    if (e->scratch_bytes >= bytes) return true;
+    void *np = nullptr;
+    bool ok = scratch_alloc(e, &np, bytes);
+    if (!ok && e->scratch_p) { // the old block and the new one did not fit side by side: give the old one up first
+        if (e->scratch_used && hipEventSynchronize(e->scratch_done) != hipSuccess) { *rc = LH_EDEVICE; return false; }
+        (void)hipFree(e->scratch_p);
+        e->scratch_p = nullptr;
+        e->scratch_bytes = 0;
+        e->scratch_used = false;
+        e->tables.valid = false;
+        c.surveyed = false;
+        e->c_scratch.store(0, std::memory_order_relaxed);
+        ok = scratch_alloc(e, &np, bytes);
+    }
+    if (!ok) return false;
+    if (e->scratch_p) {
+        if (e->scratch_used && hipEventSynchronize(e->scratch_done) != hipSuccess) { *rc = LH_EDEVICE; (void)hipFree(np); return false; }
+        (void)hipFree(e->scratch_p); // earlier launches have finished reading it
+    }
+    e->scratch_p = np;
+    e->scratch_bytes = bytes;
+    e->scratch_used = false;
+    e->c_scratch.store(bytes, std::memory_order_relaxed);
+    c.surveyed = false; // a new block: the tables of this call's earlier sub-launches went with the old one
+    e->tables.valid = false;
+    return true;
+}
+
+// The reuse decision, once per call: what the launches completed since the last look reported (pinned words).
+void judge_tables(lh_engine *e, PairsCall &c, int gen, uint32_t layout)
+{
+    c.judged = true;
+    bool healthy = true;
+    if (gen == 3) {
+        const uint64_t bad = __atomic_load_n(&e->h_rstat[0], __ATOMIC_RELAXED) + __atomic_load_n(&e->h_rstat[4], __ATOMIC_RELAXED) +
+                             __atomic_load_n(&e->h_rstat[5], __ATOMIC_RELAXED);
+        const uint64_t pairs = __atomic_load_n(&e->h_rstat[6], __ATOMIC_RELAXED); // of the launches that reported
+        const uint64_t fwd = __atomic_load_n(&e->h_rstat[3], __ATOMIC_RELAXED);
+        healthy = lh::healthy_share(bad - e->v3_seen_bad, pairs - e->v3_seen_pairs);
+        if (lh::names_without_skew(pairs - e->v3_seen_pairs, fwd - e->v3_seen_fwd, healthy, c.st.call_log_w == e->v3_last_call_log_w))
+            e->v3_disabled.store(true); // (takes effect at the next call)
+        e->v3_last_call_log_w = c.st.call_log_w;
+        e->v3_seen_fwd = fwd;
+        e->v3_seen_bad = bad;
+        e->v3_seen_pairs = pairs;
+    } else {
+        // second generation: region overflows (k_scatter3 adds them to the pinned word as it retires) against the pairs
+        // ENQUEUED through it since the last look -- an upper bound of what has completed, so the share is a lower
+        // bound; lh_flip's per-interval judgement (regions_disabled) is the backstop
+        const uint64_t bad = __atomic_load_n(&e->h_rstat[0], __ATOMIC_RELAXED), pairs = e->c_part2.load(std::memory_order_relaxed);
+        healthy = lh::healthy_share(bad - e->v2_seen_bad, pairs - e->v2_seen_pairs);
+        e->v2_seen_bad = bad;
+        e->v2_seen_pairs = pairs;
+    }
+    if (!c.surveyed && lh::survey_reusable(e->tables, gen, layout, c.tune_gen, e->survey_every, healthy)) {
+        c.surveyed = true; // this call runs on an earlier call's survey
+        e->tables.age++;
+        e->c_survey_reuse.fetch_add(1, std::memory_order_relaxed);
+    } else if (!c.surveyed) {
+        e->tables.valid = true; // (the launch that follows surveys)
+        e->tables.gen = gen;
+        e->tables.log_w = layout;
+        e->tables.tune_gen = c.tune_gen;
+        e->tables.age = 1;
+    }
+}
+
+// A partitioned sub-launch in the engine's shared block.  n_left: what is left of the call (the first sub-launch
+// surveys all of it).
+int run_shared(lh_engine *e, EpochBuffer &b, PairsCall &c, const lh::Step &st, lh::Ids d_ids, const double *d_v,
+               size_t n_left, hipStream_t s)
+{
+    if (!c.lock.owns_lock()) c.lock = std::unique_lock<std::mutex>(e->scratch_mu);
+    int rc = LH_OK;
+    if (!shared_block(e, c, st.scratch, &rc)) return rc != LH_OK ? rc : run_fallback(e, b, d_ids, d_v, st.take, s);
+    if (e->scratch_used && e->scratch_stream != s) HIPCHK(hipStreamWaitEvent(s, e->scratch_done, 0));
+    const int gen = st.kind == lh::PATH_GEN2 ? 2 : st.kind == lh::PATH_GEN3 ? 3 : 1;
+    if (gen != e->scratch_gen) c.surveyed = false; // the generations lay their tables out differently
+    if (gen == 1) {
+        HIPCHK(lh::launch_ingest_pairs_part(d_ids, d_v, st.take, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx,
+                                            e->d_err, e->scratch_p, e->scratch_bytes, e->num_cus, st.tune, s));
+        c.surveyed = false; // its records start at offset 0 of the block: the survey's tables are gone
+        e->tables.valid = false;
+    } else {
+        // what the tables were laid out for: the window width (third generation) / the scatter shape (second: the exact
+        // layout has no per-partition regions)
+        if (!c.judged) judge_tables(e, c, gen, gen == 3 ? st.tune.v3_log_w : (st.tune.v2_shape & 3u));
+        const size_t survey_n = c.surveyed ? 0 : n_left;
+        if (gen == 2) {
+            HIPCHK(lh::launch_ingest_pairs_part2(d_ids, d_v, st.take, survey_n, b.counts, b.ranges, e->cfg.max_metrics,
+                                                 e->d_Tx, e->d_err, e->scratch_p, e->scratch_bytes, e->num_cus, st.tune,
+                                                 e->d_rstat, s));
+            if (st.tune.v2_shape & 2u) e->region_samples.fetch_add(st.take, std::memory_order_relaxed);
+            e->c_part2.fetch_add(st.take, std::memory_order_relaxed);
+        } else {
+            HIPCHK(lh::launch_ingest_pairs_part3(d_ids, d_v, st.take, survey_n, b.counts, b.ranges, e->cfg.max_metrics,
+                                                 e->d_Tx, e->d_err, e->scratch_p, e->scratch_bytes, e->num_cus, st.tune,
+                                                 e->d_rstat, e->d_rstat ? reinterpret_cast<uint32_t *>(e->d_rstat + 1) : nullptr,
+                                                 s));
+            e->region_samples.fetch_add(st.take, std::memory_order_relaxed);
+            e->c_part3.fetch_add(st.take, std::memory_order_relaxed);
+        }
+        c.surveyed = true;
+    }
+    e->scratch_gen = gen;
+    HIPCHK(hipEventRecord(e->scratch_done, s));
+    e->scratch_stream = s;
+    e->scratch_used = true;
+    e->c_part.fetch_add(st.take, std::memory_order_relaxed);
+    e->c_sublaunches.fetch_add(1, std::memory_order_relaxed);
+    return LH_OK;
+}
+
+// What a call's path choice reads: one snapshot, taken under the lock every plan option is written under.
+void snapshot_dispatch(lh_engine *e, PairsCall &c)
+{
     bool log_w_fixed;
     {
         std::lock_guard<std::mutex> g(e->scratch_mu);
-        call_tune = e->tune;
-        call_tune_gen = e->tune_gen;
+        c.st.tune = e->tune;
+        c.tune_gen = e->tune_gen;
+        c.st.lane_blocks = e->lane_blocks;
+        c.st.scratch_cap = e->scratch_cap;
+        c.st.scratch_cap_set = e->scratch_cap_set;
+        c.st.sublaunch_pairs = e->sublaunch_pairs;
+        c.st.sublaunch_set = e->sublaunch_set;
         log_w_fixed = e->v3_log_w_fixed;
     }
-    uint32_t call_log_w = call_tune.v3_log_w;
+    c.st.max_metrics = e->cfg.max_metrics;
+    c.st.num_cus = e->num_cus;
+    c.st.lane_samples = (size_t)e->cfg.lane_samples;
+    c.st.small_disabled = e->small_disabled.load(std::memory_order_relaxed);
+    c.st.regions_disabled = e->regions_disabled.load(std::memory_order_relaxed);
+    c.st.v3_disabled = e->v3_disabled.load(std::memory_order_relaxed);
+    // Third generation: the window width the last completed survey reported (0 until one has run).  Read ONCE per call:
+    // the sub-launches of a call share the survey's per-partition tables, which are laid out for one width, and the
+    // call's own survey stores its report while later sub-launches are still being enqueued.
+    c.st.call_log_w = c.st.tune.v3_log_w;
     if (!log_w_fixed) {
         const uint32_t lw = (uint32_t)__atomic_load_n(&e->h_rstat[1], __ATOMIC_RELAXED);
-        if (lw >= 10 && lw <= 13) call_log_w = lw;
+        if (lw >= 10 && lw <= 13) c.st.call_log_w = lw;
     }
-    bool call_checked_tables = false; // the reuse decision is made once per call, at its first third-generation launch
+}
+
+int launch_pairs(lh_engine *e, lh::Ids d_ids, const double *d_v, size_t n, hipStream_t s, bool host_fed = false)
+{
+    EpochBuffer &b = e->bufs[(size_t)e->cur];
+    PairsCall c;
+    snapshot_dispatch(e, c);
+    bool peel = lh::peel_first((uintptr_t)d_ids.p, d_ids.width, (uintptr_t)d_v, n);
     while (n) {
-        size_t take = n < kMaxLaunch ? n : kMaxLaunch;
-        if (!e->small_disabled.load(std::memory_order_relaxed) &&
-            lh::small_supported(take, e->cfg.max_metrics, d_ids, d_v)) {
-            // a handful of names: every workgroup keeps all of them in LDS, one streaming pass
-            HIPCHK(lh::launch_ingest_pairs_small(d_ids, d_v, take, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx,
-                                                 e->d_err, e->num_cus, s));
-            e->small_samples.fetch_add(take, std::memory_order_relaxed);
-            e->c_small.fetch_add(take, std::memory_order_relaxed);
-            e->c_launches.fetch_add(1, std::memory_order_relaxed);
-            d_ids = d_ids.plus(take);
-            d_v += take;
-            n -= take;
-            continue;
-        }
-        if (host_fed && take <= lh_engine::kAuxMaxPairs && lh::part_aligned(d_ids, d_v)) {
-            // a lane's half-buffer: first generation in a block of the lanes' own (see lh_engine::aux)
-            const size_t need1 = lh::part_scratch_bytes(take, e->cfg.max_metrics, e->num_cus, call_tune);
-            if (!scratch_lock.owns_lock()) scratch_lock.lock();
-            if (need1 && e->lane_blocks) {
-                const uint32_t nb = e->lane_blocks;
-                lh_engine::AuxScratch *a = nullptr;
-                for (uint32_t i = 0; i < nb && !a; i++)
-                    if (e->aux[i].used && e->aux[i].stream == s) a = &e->aux[i]; // stream order is all it needs
-                for (uint32_t i = 0; i < nb && !a; i++)
-                    if (!e->aux[i].used) a = &e->aux[i];
-                for (uint32_t i = 0; i < nb && !a; i++)
-                    if (hipEventQuery(e->aux[i].done) == hipSuccess) a = &e->aux[i];
-                if (!a) a = &e->aux[e->aux_next++ % nb];                          // all busy: behind one of them
-                (void)hipGetLastError(); // hipEventQuery's "not ready" is not an error of this call
-                if (a->bytes < need1) {
-                    if (a->p) {
-                        if (a->used) HIPCHK(hipEventSynchronize(a->done));
-                        HIPCHK(hipFree(a->p));
-                        a->p = nullptr;
-                        a->bytes = 0;
-                        a->used = false;
-                    }
-                    // sized once for the lanes' largest launch: a lane's launches are all of about one size
-                    const size_t want = std::max(need1, lh::part_scratch_bytes(std::min(lh_engine::kAuxMaxPairs,
-                                                                                          std::max(take, (size_t)e->cfg.lane_samples)),
-                                                                               e->cfg.max_metrics, e->num_cus, call_tune));
-                    HIPCHK(hipMalloc(&a->p, want));
-                    a->bytes = want;
-                }
-                if (a->used && a->stream != s) HIPCHK(hipStreamWaitEvent(s, a->done, 0));
-                HIPCHK(lh::launch_ingest_pairs_part(d_ids, d_v, take, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx,
-                                                    e->d_err, a->p, a->bytes, e->num_cus, call_tune, s));
-                HIPCHK(hipEventRecord(a->done, s));
-                a->stream = s;
-                a->used = true;
-                e->c_part.fetch_add(take, std::memory_order_relaxed);
-                e->c_sublaunches.fetch_add(1, std::memory_order_relaxed);
-                e->c_launches.fetch_add(1, std::memory_order_relaxed);
-                d_ids = d_ids.plus(take);
-                d_v += take;
-                n -= take;
-                continue;
-            }
-        }
-        if (lh::part_aligned(d_ids, d_v) && lh::part_scratch_bytes(take, e->cfg.max_metrics, e->num_cus, call_tune)) {
-            // large launch over many names: partition by name, then reduce in LDS.  Sub-launches keep the scratch
-            // block bounded: at most `sublaunch_pairs` pairs each, halved until the block fits `scratch_cap`
-            // (power-of-two cuts keep both arrays on their vector alignment).
-            // Above 8 192 names the second scatter level carries its chunk pools and ~0.2 ms of fixed work per launch
-            // whatever the launch size, so cutting costs more than the bytes it saves.  Such launches are cut only
-            // when the caller asked for a bound (LH_OPT_SCRATCH_CAP_BYTES / LH_OPT_SUBLAUNCH_PAIRS), and then not
-            // below 2^28 pairs.
-            const bool two_level = e->cfg.max_metrics > 8192;
-            const bool bounded = !two_level || e->scratch_cap_set || e->sublaunch_set;
-            if (!scratch_lock.owns_lock()) scratch_lock.lock();
-            size_t sub = (bounded && take > e->sublaunch_pairs) ? e->sublaunch_pairs : take;
-            lh::PartTuning tune = call_tune;
-            if (e->regions_disabled.load(std::memory_order_relaxed)) tune.v2_shape &= ~2u; // clustered stream: exact layout
-            if (e->v3_disabled.load(std::memory_order_relaxed)) tune.v3 = false;            // skew-free names: first generation
-            tune.v3_log_w = call_log_w;
-            // generation 2 (survey + 2-byte records) for <= 8 192 names, generation 3 above, when the launch is large
-            // enough; otherwise the first generation
-            auto scratch_need = [&](size_t m, int *gen) {
-                size_t bytes = lh::part2_scratch_bytes(m, e->cfg.max_metrics, e->num_cus, tune);
-                *gen = 2;
-                if (!bytes) { bytes = lh::part3_scratch_bytes(m, e->cfg.max_metrics, e->num_cus, tune); *gen = 3; }
-                if (!bytes) { bytes = lh::part_scratch_bytes(m, e->cfg.max_metrics, e->num_cus, tune); *gen = 1; }
-                return bytes;
-            };
-            int gen = 1;
-            size_t need = scratch_need(sub, &gen);
-            const size_t floor = two_level ? (size_t(1) << 28) : (size_t(1) << 24);
-            while (bounded && need > e->scratch_cap && sub > floor) {
-                size_t half = floor;
-                while (half * 2 < sub) half *= 2;
-                sub = half;
-                need = scratch_need(sub, &gen);
-            }
-            if (need == 0) return LH_EDEVICE; // cannot happen: sub is above the partitioned path's minimum
-            take = sub;
-            if (e->scratch_bytes < need) {
-                if (e->scratch_p) {
-                    if (e->scratch_used) HIPCHK(hipEventSynchronize(e->scratch_done)); // earlier launches still read it
-                    HIPCHK(hipFree(e->scratch_p));
-                    e->scratch_p = nullptr;
-                    e->scratch_bytes = 0;
-                    e->scratch_used = false;
-                }
-                HIPCHK(hipMalloc(&e->scratch_p, need));
-                e->scratch_bytes = need;
-                e->c_scratch.store(need, std::memory_order_relaxed);
-                surveyed = false; // a new block: the tables of this call's earlier sub-launches went with the old one
-                e->v3_tables_valid = false;
-            }
-            if (e->scratch_used && e->scratch_stream != s) HIPCHK(hipStreamWaitEvent(s, e->scratch_done, 0));
-            if (gen != e->scratch_gen) surveyed = false; // the generations lay their tables out differently
-            if (gen == 2) {
-                // the first sub-launch samples everything that is left of the call (n pairs)
-                HIPCHK(lh::launch_ingest_pairs_part2(d_ids, d_v, take, surveyed ? 0 : n, b.counts, b.ranges,
-                                                     e->cfg.max_metrics, e->d_Tx, e->d_err, e->scratch_p,
-                                                     e->scratch_bytes, e->num_cus, tune, e->d_rstat, s));
-                surveyed = true;
-                e->v3_tables_valid = false; // the second generation lays its own tables over them
-                if (tune.v2_shape & 2u) e->region_samples.fetch_add(take, std::memory_order_relaxed);
-                e->c_part2.fetch_add(take, std::memory_order_relaxed);
-            } else if (gen == 3) {
-                if (!call_checked_tables) {
-                    call_checked_tables = true;
-                    // what the completed launches reported since the last look (pinned words, k_v3_report)
-                    const uint64_t bad = __atomic_load_n(&e->h_rstat[0], __ATOMIC_RELAXED) +
-                                         __atomic_load_n(&e->h_rstat[4], __ATOMIC_RELAXED) +
-                                         __atomic_load_n(&e->h_rstat[5], __ATOMIC_RELAXED);
-                    const uint64_t pairs = __atomic_load_n(&e->h_rstat[6], __ATOMIC_RELAXED); // of the launches that reported
-                    const bool healthy = (bad - e->v3_seen_bad) * 50 <= pairs - e->v3_seen_pairs;
-                    const uint64_t fwd = __atomic_load_n(&e->h_rstat[3], __ATOMIC_RELAXED);
-                    // (only calls that ran HEALTHY, and not when the survey has just reported another window width: a call
-                    // on a stale survey -- other value spans than the windows were placed for -- forwards most records
-                    // whatever the names' skew, and says so through its overflow / window-miss counts; measured: a
-                    // 21-decade stream after a lognormal one was sent to the first generation for 64 flips, 12.4 instead
-                    // of 8.8 ms per 1e9 pairs.  Names without skew forward > 3/4 with clean counters.)
-                    if (pairs - e->v3_seen_pairs >= (uint64_t(1) << 22) && (fwd - e->v3_seen_fwd) * 4 > (pairs - e->v3_seen_pairs) * 3 &&
-                        healthy && call_log_w == e->v3_last_call_log_w)
-                        e->v3_disabled.store(true); // (takes effect at the next launch)
-                    e->v3_last_call_log_w = call_log_w;
-                    e->v3_seen_fwd = fwd;
-                    e->v3_seen_bad = bad;
-                    e->v3_seen_pairs = pairs;
-                    if (e->v3_tables_valid && e->scratch_gen == 3 && e->v3_tables_log_w == call_log_w && healthy &&
-                        e->v3_tables_tune_gen == call_tune_gen && e->v3_tables_age < e->survey_every && !surveyed) {
-                        surveyed = true; // this call runs on the previous survey
-                        e->v3_tables_age++;
-                        e->c_survey_reuse.fetch_add(1, std::memory_order_relaxed);
-                    } else if (!surveyed) {
-                        e->v3_tables_valid = true; // (the launch below surveys)
-                        e->v3_tables_log_w = call_log_w;
-                        e->v3_tables_tune_gen = call_tune_gen;
-                        e->v3_tables_age = 1;
-                    }
-                }
-                HIPCHK(lh::launch_ingest_pairs_part3(d_ids, d_v, take, surveyed ? 0 : n, b.counts, b.ranges,
-                                                     e->cfg.max_metrics, e->d_Tx, e->d_err, e->scratch_p,
-                                                     e->scratch_bytes, e->num_cus, tune, e->d_rstat,
-                                                     e->d_rstat ? reinterpret_cast<uint32_t *>(e->d_rstat + 1) : nullptr,
-                                                     s));
-                surveyed = true;
-                e->region_samples.fetch_add(take, std::memory_order_relaxed);
-                e->c_part3.fetch_add(take, std::memory_order_relaxed);
-            } else {
-                HIPCHK(lh::launch_ingest_pairs_part(d_ids, d_v, take, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx,
-                                                    e->d_err, e->scratch_p, e->scratch_bytes, e->num_cus, tune, s));
-                surveyed = false; // its records start at offset 0 of the block: the survey's tables are gone
-                e->v3_tables_valid = false;
-            }
-            e->scratch_gen = gen;
-            HIPCHK(hipEventRecord(e->scratch_done, s));
-            e->scratch_stream = s;
-            e->scratch_used = true;
-            e->c_part.fetch_add(take, std::memory_order_relaxed);
-            e->c_sublaunches.fetch_add(1, std::memory_order_relaxed);
+        lh::Step st;
+        if (peel) { // the odd-aligned first sample: the direct kernel, so that the rest of the call is vector-aligned
+            st.take = 1;
+            peel = false;
         } else {
-            HIPCHK(lh::launch_ingest_pairs(d_ids, d_v, take, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx,
-                                           e->d_err, e->num_cus, s));
-            e->c_direct.fetch_add(take, std::memory_order_relaxed);
+            st = lh::choose_step(c.st, (uintptr_t)d_ids.p, d_ids.width, (uintptr_t)d_v, n, host_fed);
         }
+        int rc;
+        if (st.kind == lh::PATH_SMALL) {
+            rc = run_small(e, b, d_ids, d_v, st.take, s);
+        } else if (st.kind == lh::PATH_DIRECT) {
+            rc = run_direct(e, b, d_ids, d_v, st.take, s);
+        } else if (st.lane_block) {
+            rc = run_lane_block(e, b, c, st, d_ids, d_v, s);
+        } else {
+            rc = run_shared(e, b, c, st, d_ids, d_v, n, s);
+        }
+        if (rc) return rc; // a device error: what was enqueued before it is counted and stays in the interval
+        count_samples(b, st.take); // (behind the enqueue: the merge's cell bound counts what is in the buffer)
         e->c_launches.fetch_add(1, std::memory_order_relaxed);
-        d_ids = d_ids.plus(take);
-        d_v += take;
-        n -= take;
+        d_ids = d_ids.plus(st.take);
+        d_v += st.take;
+        n -= st.take;
     }
     return LH_OK;
 }
@@ -753,9 +809,9 @@ int create_impl(const lh_config *cfg_in, lh_engine *e)
             HIPCHK(hipMemsetAsync(b.ccur, 0, NC * sizeof(uint64_t), e->xstream));
             HIPCHK(hipMemsetAsync(b.cflag, 0, NC * sizeof(uint32_t), e->xstream));
         }
-        HIPCHK(hipMalloc((void **)&b.counts, M * LH_NKEYS * sizeof(uint64_t)));
+        HIPCHK(hipMalloc((void **)&b.counts, M * LH_ROW_STRIDE * sizeof(uint64_t)));
         HIPCHK(hipMalloc((void **)&b.ranges, M * 2 * sizeof(uint32_t)));
-        HIPCHK(hipMemsetAsync(b.counts, 0, M * LH_NKEYS * sizeof(uint64_t), e->xstream));
+        HIPCHK(hipMemsetAsync(b.counts, 0, M * LH_ROW_STRIDE * sizeof(uint64_t), e->xstream));
         HIPCHK(lh::launch_init_ranges(b.ranges, (uint32_t)M, e->xstream));
         HIPCHK(hipEventCreateWithFlags(&b.cleared, hipEventDisableTiming));
         HIPCHK(hipEventRecord(b.cleared, e->xstream));
@@ -977,11 +1033,9 @@ static int submit_pairs_t(lh_engine *e, const IDT *ids, const double *v, size_t 
 
 int lh_submit_pairs(lh_engine *e, const uint32_t *ids, const double *v, size_t n) { return submit_pairs_t(e, ids, v, n); }
 
-int lh_submit_pairs16(lh_engine *e, const uint16_t *ids, const double *v, size_t n)
-{
-    if (e && e->cfg.max_metrics > 65536u) return LH_ERANGE; // (cannot happen: lh_create bounds max_metrics; kept explicit)
-    return submit_pairs_t(e, ids, v, n);
-}
+// (uint16 ids are valid for ANY engine with at least 65 536 names, not only for one with exactly that many: the four
+// narrow entry points agree -- ADVICE r4; below 65 536 names submit_pairs_t checks every id)
+int lh_submit_pairs16(lh_engine *e, const uint16_t *ids, const double *v, size_t n) { return submit_pairs_t(e, ids, v, n); }
 
 // In-place staging (SURVEY.md 8b "Ownership": "or the ring is C-allocated (hipHostMalloc) and Go writes into it in
 // place"): the producer gets the free tail of a pinned half-buffer, writes its (id, value) pairs there -- the one
@@ -1397,7 +1451,7 @@ int extract_impl(lh_snapshot *s, uint32_t first, size_t nmetrics, const double *
         nt.host_flag = reinterpret_cast<uint32_t *>(e->d_hxbuf + L.total);
         nt.seq = e->xseq;
     }
-    HIPCHK(lh::launch_extract(b.counts + (size_t)first * LH_NKEYS, b.ranges + 2 * (size_t)first,
+    HIPCHK(lh::launch_extract(b.counts + (size_t)first * LH_ROW_STRIDE, b.ranges + 2 * (size_t)first,
                               (uint32_t)nmetrics, p, (uint32_t)np, e->d_D,
                               reinterpret_cast<lh::ExtractOut *>(xb + L.off_stats),
                               reinterpret_cast<double *>(xb + L.off_pvals),
@@ -1463,7 +1517,7 @@ int lh_buckets(lh_snapshot *s, uint32_t id, int16_t *keys, uint64_t *counts, siz
     const size_t span = (size_t)r[1] - r[0] + 1;
     rc = ensure_xbuf(e, span * sizeof(uint64_t));
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(e->h_xbuf, b.counts + (size_t)id * LH_NKEYS + r[0], span * sizeof(uint64_t),
+    HIPCHK(hipMemcpyAsync(e->h_xbuf, b.counts + (size_t)id * LH_ROW_STRIDE + r[0], span * sizeof(uint64_t),
                           hipMemcpyDeviceToHost, e->xstream));
     HIPCHK(hipStreamSynchronize(e->xstream));
     const uint64_t *row = reinterpret_cast<const uint64_t *>(e->h_xbuf);
@@ -1493,7 +1547,7 @@ int lh_buckets_all(lh_snapshot *s, uint32_t first, size_t nmetrics, uint64_t *of
     if (rc) return rc;
     std::lock_guard<std::mutex> g(e->xmu);
     EpochBuffer &b = e->bufs[(size_t)s->buf];
-    const uint64_t *rows = b.counts + (size_t)first * LH_NKEYS;
+    const uint64_t *rows = b.counts + (size_t)first * LH_ROW_STRIDE;
     const uint32_t *rng = b.ranges + 2 * (size_t)first;
     // pass 1: occupied cells per row
     const size_t off_bytes = (nmetrics + 1) * sizeof(uint64_t);
@@ -1539,6 +1593,8 @@ int lh_snapshot_rows(lh_snapshot *s, void **d_counts, uint32_t *nrows)
     if (nrows) *nrows = s->e->cfg.max_metrics;
     return LH_OK;
 }
+
+size_t lh_row_stride(void) { return LH_ROW_STRIDE; }
 
 int lh_snapshot_ranges(lh_snapshot *s, void **d_ranges)
 {
@@ -1891,7 +1947,7 @@ int lh_serialize(lh_snapshot *s, uint32_t first, size_t nmetrics, const double *
 
     EpochBuffer &b = e->bufs[(size_t)s->buf];
     HIPCHK(hipMemcpyAsync(e->d_blob, bb.bytes.data(), bb.bytes.size(), hipMemcpyHostToDevice, e->xstream));
-    HIPCHK(lh::launch_extract(b.counts + (size_t)first * LH_NKEYS, b.ranges + 2 * (size_t)first, (uint32_t)nmetrics,
+    HIPCHK(lh::launch_extract(b.counts + (size_t)first * LH_ROW_STRIDE, b.ranges + 2 * (size_t)first, (uint32_t)nmetrics,
                               p, (uint32_t)np, e->d_D, reinterpret_cast<lh::ExtractOut *>(e->d_xbuf + L.off_stats),
                               reinterpret_cast<double *>(e->d_xbuf + L.off_pvals),
                               reinterpret_cast<int16_t *>(e->d_xbuf + L.off_pkeys), e->d_xbuf + L.off_pvalid,
@@ -2217,6 +2273,8 @@ int lh_get_counters(lh_engine *e, lh_counters *out)
     out->level2_overflows = __atomic_load_n(&e->h_rstat[4], __ATOMIC_RELAXED);
     out->reduce_window_misses = __atomic_load_n(&e->h_rstat[5], __ATOMIC_RELAXED);
     out->surveys_reused = e->c_survey_reuse.load();
+    out->scratch_alloc_failures = e->c_alloc_fail.load();
+    out->samples_fallback = e->c_fallback.load();
     {
         const uint64_t lw = __atomic_load_n(&e->h_rstat[1], __ATOMIC_RELAXED);
         std::lock_guard<std::mutex> g(e->scratch_mu);
@@ -2232,7 +2290,7 @@ static int set_tune(lh_engine *e, const std::function<void(lh::PartTuning &)> &f
     std::lock_guard<std::mutex> g(e->scratch_mu);
     f(e->tune);
     e->tune_gen++;
-    e->v3_tables_valid = false;
+    e->tables.valid = false;
     return LH_OK;
 }
 
@@ -2307,9 +2365,13 @@ int lh_set_option(lh_engine *e, int option, uint64_t value)
         if (value < 1 || value > 1024) return LH_EINVAL;
         std::lock_guard<std::mutex> g(e->scratch_mu);
         e->survey_every = (uint32_t)value;
-        e->v3_tables_valid = false;
+        e->tables.valid = false;
         return LH_OK;
     }
+    case LH_OPT_FAIL_SCRATCH_ALLOCS:
+        if (value > 0xffffffffull) return LH_EINVAL;
+        e->fail_allocs.store((uint32_t)value);
+        return LH_OK;
     case LH_OPT_LANE_ZERO_COPY:
         if (value > 1) return LH_EINVAL;
         e->lane_zero_copy = value != 0;
@@ -2349,6 +2411,68 @@ int lh_codec_tables(lh_engine *e, double *Tx, double *D)
     if (rc) return rc;
     if (Tx) HIPCHK(hipMemcpy(Tx, e->d_Tx, sizeof(double) * LH_NTHRESH, hipMemcpyDeviceToHost));
     if (D) HIPCHK(hipMemcpy(D, e->d_D, sizeof(double) * LH_NKEYS, hipMemcpyDeviceToHost));
+    return LH_OK;
+}
+
+// The path choice of launch_pairs without an engine or a device (loghisto_gpu_tuning.h): the same choose_step /
+// peel_first calls, in the same order; a sub-launch whose scratch "cannot be had" (fail_allocs) takes the direct kernel
+// exactly as run_lane_block / run_shared do.  (A lane's block, once allocated, serves the call's later lane launches; the
+// shared block grows to the largest sub-launch.)
+int lh_dispatch_probe(const lh_dispatch_query *q, lh_dispatch_step *steps, size_t cap, size_t *nsteps)
+{
+    if (!q || !nsteps || (cap && !steps) || q->struct_size != sizeof(lh_dispatch_query)) return LH_EINVAL;
+    if (q->max_metrics == 0 || (q->id_width != 2 && q->id_width != 4) || q->n == 0) return LH_EINVAL;
+    lh::DispatchState st;
+    st.max_metrics = q->max_metrics;
+    st.num_cus = q->num_cus ? (int)q->num_cus : 256;
+    st.lane_samples = (size_t)q->lane_samples;
+    st.lane_blocks = q->lane_blocks;
+    st.small_disabled = q->small_disabled != 0;
+    st.regions_disabled = q->regions_disabled != 0;
+    st.v3_disabled = q->v3_disabled != 0;
+    st.call_log_w = q->call_log_w ? q->call_log_w : 10u;
+    if (q->scratch_cap) { st.scratch_cap = (size_t)q->scratch_cap; st.scratch_cap_set = true; }
+    if (q->sublaunch_pairs) { st.sublaunch_pairs = (size_t)q->sublaunch_pairs; st.sublaunch_set = true; }
+    st.tune.part_min_samples = (size_t)q->part_min_pairs;
+    st.tune.v2_min_samples = (size_t)q->v2_min_pairs;
+    st.tune.v3_min_samples = (size_t)q->v3_min_pairs;
+    st.tune.v2 = !q->v2_off;
+    st.tune.v3 = !q->v3_off;
+    st.tune.hot = !q->hot_off;
+    if (q->v2_shape_set) st.tune.v2_shape = q->v2_shape & 3u;
+    uintptr_t ids = (uintptr_t)q->ids_addr, vals = (uintptr_t)q->vals_addr;
+    size_t n = (size_t)q->n, k = 0, shared_bytes = 0, lane_bytes = 0;
+    uint32_t fail = q->fail_allocs;
+    bool peel = lh::peel_first(ids, q->id_width, vals, n);
+    while (n) {
+        lh::Step s;
+        lh_dispatch_step o{};
+        if (peel) {
+            s.take = 1;
+            o.peeled = 1;
+            peel = false;
+        } else {
+            s = lh::choose_step(st, ids, q->id_width, vals, n, q->host_fed != 0);
+        }
+        if (s.take == 0 || s.take > n) return LH_ESTATE; // (cannot happen: every step makes progress inside the call)
+        if (s.scratch) {
+            size_t &have = s.lane_block ? lane_bytes : shared_bytes;
+            if (have < s.scratch) {
+                if (fail) { fail--; s.kind = lh::PATH_DIRECT; s.lane_block = false; s.scratch = 0; o.fell_back = 1; }
+                else have = s.lane_block ? s.scratch_alloc : s.scratch;
+            }
+        }
+        o.path = (uint32_t)s.kind;
+        o.lane_block = s.lane_block ? 1u : 0u;
+        o.take = s.take;
+        o.scratch = s.scratch;
+        if (k < cap) steps[k] = o;
+        k++;
+        ids += s.take * q->id_width;
+        vals += s.take * sizeof(double);
+        n -= s.take;
+    }
+    *nsteps = k;
     return LH_OK;
 }
 

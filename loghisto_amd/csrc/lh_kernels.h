@@ -7,6 +7,14 @@
 #include <stddef.h>
 #include <stdint.h>
 
+// Cells from one row of an epoch buffer to the next.  A row is uint64[65536] (bin = key ^ 0x8000), but the rows are NOT
+// packed back to back: names with similar value distributions keep their occupied windows at the same offset inside the
+// row, and windows exactly 512 KiB apart share the low 19 address bits -- measured on 65 536 windows of 600 cells
+// (tools/row_stride.hip, profiles/r05_row_stride.jsonl): the reduce passes' atomic flush 275 -> 238 us, the clear
+// 94 -> 66 us, the wave-per-row read 79 -> 74 us with rows 256 bytes further apart; packing the windows tightly buys
+// nothing beyond that.  Exposed to callers that index the device rows themselves as lh_row_stride().
+#define LH_ROW_STRIDE ((size_t)65536 + 32)
+
 namespace lh {
 
 struct ExtractOut {          // device mirror of lh_stats, one per metric
@@ -47,10 +55,10 @@ struct PartTuning {
     uint32_t names_per_part = 4;    // names per LDS-reduce partition: 4 gives every name a 4 096-bin window in P2
     uint32_t two_level_above = 32;  // second scatter level when a level-1 partition holds more names than this
     uint32_t hot_min_tiles = 32;    // hot-name windows in P1 when every workgroup gets at least this many tiles
-    size_t part_min_samples = 0;    // smallest launch that is partitioned at all (0 = default by name count); below: direct atomics
+    size_t part_min_samples = 0;    // smallest launch that is partitioned at all (0 = the default, 131 072); below: direct atomics
     bool hot = true;                // hot-name windows allowed at all
     bool v2 = true;                 // survey + 2-byte-record path (lh_kernels_part2.h) for <= 8 192 names
-    size_t v2_min_samples = 0;      // 0 = default (2^24): smaller launches do not amortise the survey
+    size_t v2_min_samples = 0;      // 0 = default (2^25): smaller launches do not amortise the survey
     uint32_t v2_shape = 2;          // bit 0: two 512-thread workgroups per CU (128 partitions) instead of one 1 024-thread (256);
                                     // bit 1: fixed per-partition regions (k_scatter3) instead of the exact per-tile layout
     bool v3 = true;                 // hashed survey + region scatter + in-place second level (lh_kernels_part3.h) for 8 193 .. 65 536 names

@@ -127,12 +127,16 @@ __device__ __forceinline__ void global_cell_add(uint64_t *row, uint32_t *range, 
     if (bin > range[1]) atomicMax(&range[1], bin);
 }
 
-// where a workgroup puts a floating window when `bin` is its first sample on that side of the main window [win_lo, +K1_WIN)
+// Where a workgroup puts a floating window when `bin` is its first sample on that side of the main window
+// [win_lo, + K1_WIN): ADJACENT to the main window when the sample is within K1_OVF bins of it -- the bins right next to
+// the main window are the dense ones of a stream slightly wider than it, and a window centred on a first miss 512 ..
+// 1 023 bins out would leave a gap of them on the global row -- centred on the sample only beyond that.
 __device__ __forceinline__ uint32_t k1_anchor(uint32_t bin, uint32_t win_lo)
 {
-    const uint32_t centred = bin >= K1_OVF / 2 ? bin - K1_OVF / 2 : 0u;
-    if (bin >= win_lo + K1_WIN) return min(max(win_lo + K1_WIN, centred), (uint32_t)LH_NKEYS - K1_OVF);
-    return min(win_lo >= K1_OVF ? win_lo - K1_OVF : 0u, centred);
+    const uint32_t centred = bin >= K1_OVF / 2 ? bin - K1_OVF / 2 : 0u, win_hi = win_lo + K1_WIN;
+    if (bin >= win_hi) return min(bin < win_hi + K1_OVF ? win_hi : centred, (uint32_t)LH_NKEYS - K1_OVF);
+    const uint32_t below = win_lo >= K1_OVF ? win_lo - K1_OVF : 0u;
+    return bin >= below ? below : centred;
 }
 
 // the sample missed the main window.  h0: the workgroup's LDS block.
@@ -319,7 +323,7 @@ __device__ __forceinline__ void kp_add(uint64_t *__restrict__ counts, uint32_t *
 {
     if (id >= nmetrics) { atomicOr(err, 1u); return; }
     const uint32_t bin = lh_bin_of(v, Tx);
-    atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)id * LH_NKEYS + bin]), 1ull);
+    atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)id * LH_ROW_STRIDE + bin]), 1ull);
     // ranges only widen: a stale read can cost a redundant atomic, never miss one
     uint32_t *r = ranges + 2 * (size_t)id;
     if (bin < r[0]) atomicMin(&r[0], bin);
@@ -528,7 +532,7 @@ __global__ __launch_bounds__(K2_BLOCK) void k_extract(const uint64_t *__restrict
     __shared__ double s_p[K2_MAXP];
 
     const uint32_t m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint64_t *row = counts + (size_t)m * LH_NKEYS;
+    const uint64_t *row = counts + (size_t)m * LH_ROW_STRIDE;
     const uint32_t lo = ranges[2 * (size_t)m], hi = ranges[2 * (size_t)m + 1];
 
     if (tid < K2_MAXP) {
@@ -686,7 +690,7 @@ __global__ __launch_bounds__(K2_BLOCK) void k_extract_wave(const uint64_t *__res
         err_out[1] = err_in[1];
     }
     if (m >= nmetrics) return; // wave-uniform
-    const uint64_t *row = counts + (size_t)m * LH_NKEYS;
+    const uint64_t *row = counts + (size_t)m * LH_ROW_STRIDE;
     const uint32_t lo = ranges[2 * (size_t)m], hi = ranges[2 * (size_t)m + 1];
     const bool inreg = lo <= hi && hi - lo < EW_REG; // wave-uniform
 
@@ -886,7 +890,7 @@ __global__ __launch_bounds__(256) void k_count_cells(const uint64_t *__restrict_
     __syncthreads();
     uint32_t n = 0;
     if (lo <= hi) {
-        const uint64_t *row = counts + (size_t)m * LH_NKEYS;
+        const uint64_t *row = counts + (size_t)m * LH_ROW_STRIDE;
         for (uint32_t b = lo + threadIdx.x; b <= hi; b += 256) n += row[b] != 0;
     }
 #pragma unroll
@@ -905,7 +909,7 @@ __global__ __launch_bounds__(256) void k_compact_cells(const uint64_t *__restric
     const uint32_t m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t lo = ranges[2 * (size_t)m], hi = ranges[2 * (size_t)m + 1];
     if (lo > hi) return;
-    const uint64_t *row = counts + (size_t)m * LH_NKEYS;
+    const uint64_t *row = counts + (size_t)m * LH_ROW_STRIDE;
     uint64_t base = offsets[m];
     for (uint32_t t0 = lo; t0 <= hi; t0 += 256) { // ascending bin == ascending key
         const uint32_t b = t0 + tid;
@@ -1141,7 +1145,7 @@ __global__ __launch_bounds__(256) void k_pack_rows(const uint64_t *__restrict__ 
     if (lo > hi) return;
     const uint32_t k = merge_block_of(brow, nblocks, r);
     CELL *dst = buf + (size_t)k * bstride + (P[r] - bstart[k]);
-    const uint64_t *src = counts + (size_t)r * LH_NKEYS + lo;
+    const uint64_t *src = counts + (size_t)r * LH_ROW_STRIDE + lo;
     for (uint32_t i = threadIdx.x; i <= hi - lo; i += 256) dst[i] = (CELL)src[i];
 }
 
@@ -1171,7 +1175,7 @@ __global__ __launch_bounds__(256) void k_unpack_rows(uint64_t *__restrict__ coun
     const uint32_t lo = ranges[2 * (size_t)r], hi = ranges[2 * (size_t)r + 1];
     if (lo > hi) return;
     const CELL *src = buf + (P[r] - bstart[kblock]);
-    uint64_t *dst = counts + (size_t)r * LH_NKEYS + lo;
+    uint64_t *dst = counts + (size_t)r * LH_ROW_STRIDE + lo;
     for (uint32_t i = threadIdx.x; i <= hi - lo; i += 256) dst[i] = (uint64_t)src[i];
 }
 
@@ -1254,7 +1258,7 @@ __global__ __launch_bounds__(256) void k_clear_spans(uint64_t *__restrict__ coun
     if (lo > hi) return;
     const uint32_t seg = LH_NKEYS / K3_SPLIT;
     const uint32_t a = max(lo, blockIdx.y * seg), b = min(hi, (blockIdx.y + 1) * seg - 1);
-    uint64_t *row = counts + (size_t)m * LH_NKEYS;
+    uint64_t *row = counts + (size_t)m * LH_ROW_STRIDE;
     for (uint32_t i = a + threadIdx.x; i <= b && i >= a; i += 256) row[i] = 0;
 }
 
@@ -1268,7 +1272,7 @@ __global__ __launch_bounds__(256) void k_clear_rows_wave(uint64_t *__restrict__ 
     if (m >= nmetrics) return; // wave-uniform
     const uint32_t lo = ranges[2 * (size_t)m], hi = ranges[2 * (size_t)m + 1];
     if (lo > hi) return;       // nothing was counted and the range is already empty
-    uint64_t *row = counts + (size_t)m * LH_NKEYS;
+    uint64_t *row = counts + (size_t)m * LH_ROW_STRIDE;
     for (uint32_t i = lo + lane; i <= hi; i += 64) row[i] = 0;
     if (lane == 0) { ranges[2 * (size_t)m] = LH_NKEYS; ranges[2 * (size_t)m + 1] = 0; }
 }

@@ -83,15 +83,11 @@ static uint32_t ilog2_ceil(uint32_t x)
 static size_t small_words(uint32_t nq, uint32_t extra) { return (size_t)3 * nq + 3 * (nq + extra) + 1 + (nq + extra + 1) + 16; }
 
 // Smallest launch worth partitioning (below it: one global atomic per sample, k_ingest_pairs).
-static size_t part_min_samples(uint32_t nmetrics, const PartTuning &tune)
-{
-    if (tune.part_min_samples) return tune.part_min_samples;
-    return PART_MIN_SAMPLES;
-}
+static size_t part_min_samples(const PartTuning &tune) { return tune.part_min_samples ? tune.part_min_samples : PART_MIN_SAMPLES; }
 
 static bool make_plan(size_t n, uint32_t nmetrics, int num_cus, const PartTuning &tune, PartPlan &P)
 {
-    if (n < part_min_samples(nmetrics, tune) || n > (size_t(1) << 31) || nmetrics < 2) return false;
+    if (n < part_min_samples(tune) || n > (size_t(1) << 31) || nmetrics < 2) return false;
     // names per partition: 4 gives every name a 4 096-bin LDS window in P2.  Fewer partitions mean longer
     // contiguous runs in P1 but narrower windows in P2 (measured at 1 024 names, profiles/r01c: 4 is the best
     // overall).
@@ -568,7 +564,7 @@ __global__ __launch_bounds__(P1_BLOCK, HOT ? 4 : 6) void k_scatter_samples(const
             const uint32_t c = H.win[i];
             if (c) {
                 const uint32_t hs = i >> HOT_LOGW, b = H.org[hs] + (i & (HOT_W - 1));
-                atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)H.name[hs] * LH_NKEYS + b]),
+                atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)H.name[hs] * LH_ROW_STRIDE + b]),
                           (unsigned long long)c);
                 atomicMin(&H.mn[hs], b);
                 atomicMax(&H.mx[hs], b);
@@ -812,7 +808,7 @@ constexpr size_t P2_LDS_BYTES = (P2_WINWORDS + 3 * PART_MAX_MPP + 2 * OV_SLOTS) 
 __device__ __forceinline__ void p2_global_add(uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
                                               uint32_t m, uint32_t bin, uint64_t c)
 {
-    atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)m * LH_NKEYS + bin]), (unsigned long long)c);
+    atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)m * LH_ROW_STRIDE + bin]), (unsigned long long)c);
     uint32_t *r = ranges + 2 * (size_t)m;
     if (bin < r[0]) atomicMin(&r[0], bin);
     if (bin > r[1]) atomicMax(&r[1], bin);
@@ -963,7 +959,7 @@ __global__ __launch_bounds__(P2_BLOCK, 8) void k_part_hist(const uint32_t *__res
         const uint32_t c = h[i];
         const uint32_t l = i >> log_w, b = s_org[l] + (i & (W - 1));
         if (c)
-            atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)((l << log_nq) | p) * LH_NKEYS + b]),
+            atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)((l << log_nq) | p) * LH_ROW_STRIDE + b]),
                       (unsigned long long)c);
         if (W >= 64u) {
             const unsigned long long occ = __builtin_amdgcn_ballot_w64(c != 0);

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__rest
 __device__ __forceinline__ void v2_global_add(uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
                                               uint32_t m, uint32_t bin, uint64_t c)
 {
-    atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)m * LH_NKEYS + bin]), (unsigned long long)c);
+    atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)m * LH_ROW_STRIDE + bin]), (unsigned long long)c);
     uint32_t *r = ranges + 2 * (size_t)m;
     if (bin < r[0]) atomicMin(&r[0], bin);
     if (bin > r[1]) atomicMax(&r[1], bin);
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter2(const IDT *__restrict__ i
             const uint32_t c = win[base + i];
             if (c) {
                 const uint32_t b = org + i;
-                atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)name * LH_NKEYS + b]),
+                atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)name * LH_ROW_STRIDE + b]),
                           (unsigned long long)c);
                 mn = min(mn, b);
                 mx = max(mx, b);
@@ -1001,7 +1001,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
             const uint32_t c = win[base + i];
             if (c) {
                 const uint32_t b = org + i;
-                atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)name * LH_NKEYS + b]),
+                atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)name * LH_ROW_STRIDE + b]),
                           (unsigned long long)c);
                 mn = min(mn, b);
                 mx = max(mx, b);
@@ -1049,21 +1049,40 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist2(const rec16_t *__restri
     const uint32_t p = slots[3 * slot], first = slots[3 * slot + 1], cnt = slots[3 * slot + 2];
     const uint32_t *list = sorted + part_start[p] + first;
     const uint32_t W = 1u << log_w, words = mpp << log_w;
-    for (uint32_t i = tid; i < words; i += P2_BLOCK) h[i] = 0;
-    if (tid < mpp) {
-        const uint32_t m = (tid << log_np) | p;
-        s_org[tid] = m < nmetrics ? (g_nt[m].org & 0xffffu) : 0u;
-        s_mn[tid] = INVALID;
-        s_mx[tid] = 0;
-    }
-    __syncthreads();
-
     // one chunk (1 024 records = 2 KiB) per wave per iteration: two 16-byte loads per lane, double-buffered
     auto load_chunk = [&](uint32_t cidx, u4_t (&dst)[2]) {
         const u4_t *src = reinterpret_cast<const u4_t *>(records + (size_t)cidx * CHUNK) + lane;
         dst[0] = __builtin_nontemporal_load(src);
         dst[1] = __builtin_nontemporal_load(src + 64);
     };
+    // Each wave walks chunks wave, wave + 16, ...  Their indices and descriptors are fetched 64 at a time (lane l
+    // holds the wave's l-th chunk of the batch: two dependent loads per 64 chunks instead of two per chunk), and
+    // DEPTH chunks are in flight per wave (8 KiB per wave, 128 KiB per CU) while the oldest is reduced: with one
+    // workgroup per CU nothing else hides the load latency.  The first batch and its first DEPTH chunks are requested
+    // HERE, before the windows are set up (a slot is a chain of dependent round trips: slot -> chunk list -> records ->
+    // LDS -> flush), and a chunk's records are not held back for its descriptor: 2 KiB are read whatever it holds.
+    constexpr uint32_t WSTEP = P2_BLOCK / 64, DEPTH = 4;
+    u4_t buf[DEPTH][2];
+    const uint32_t mine = cnt > wave ? (cnt - wave + WSTEP - 1) / WSTEP : 0u; // chunks of this wave
+    uint32_t nb = min(mine, 64u), my_cid = 0, my_cn = 0;
+    if (lane < nb) my_cid = list[wave + lane * WSTEP];
+    uint32_t org0 = 0;
+    if (tid < mpp) {
+        const uint32_t m = (tid << log_np) | p;
+        org0 = m < nmetrics ? (g_nt[m].org & 0xffffu) : 0u;
+    }
+    if (lane < nb) my_cn = cdesc[my_cid] & CD_MASK;
+#pragma unroll
+    for (uint32_t d = 0; d < DEPTH; d++) // (unconditional: a wave without chunks reads chunk 0 and ignores it)
+        load_chunk(__builtin_amdgcn_readlane(my_cid, min(d, max(nb, 1u) - 1u)), buf[d]);
+    for (uint32_t i = tid; i < words; i += P2_BLOCK) h[i] = 0;
+    if (tid < mpp) {
+        s_org[tid] = org0;
+        s_mn[tid] = INVALID;
+        s_mx[tid] = 0;
+    }
+    __syncthreads();
+
     auto reduce_chunk = [&](const u4_t (&r4)[2], uint32_t cn) {
         if (cn == CHUNK) { // full chunk (wave-uniform): sixteen unconditional LDS adds per lane
 #pragma unroll
@@ -1088,37 +1107,27 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist2(const rec16_t *__restri
             }
         }
     };
-    // Each wave walks chunks wave, wave + 16, ...  Their indices and descriptors are fetched 64 at a time (lane l
-    // holds the wave's l-th chunk of the batch: two dependent loads per 64 chunks instead of two per chunk), and
-    // DEPTH chunks are in flight per wave (8 KiB per wave, 128 KiB per CU) while the oldest is reduced: with one
-    // workgroup per CU nothing else hides the load latency.
-    constexpr uint32_t WSTEP = P2_BLOCK / 64, DEPTH = 4;
-    u4_t buf[DEPTH][2];
-    uint32_t cn[DEPTH];
-    const uint32_t mine = cnt > wave ? (cnt - wave + WSTEP - 1) / WSTEP : 0u; // chunks of this wave
     for (uint32_t b0 = 0; b0 < mine; b0 += 64) {
-        const uint32_t nb = min(mine - b0, 64u);
-        uint32_t my_cid = 0, my_cn = 0;
-        if (lane < nb) {
-            my_cid = list[wave + (b0 + lane) * WSTEP];
-            my_cn = cdesc[my_cid] & CD_MASK;
-        }
         // Loads are issued unconditionally (positions past the batch re-read its last chunk; the data is ignored) and
         // only the LDS work is conditional: with a load inside a branch the compiler cannot count the loads in
         // flight at the join and falls back to s_waitcnt vmcnt(0) before every chunk, which serialises the four
         // chunks this loop keeps in flight.
         auto fetch = [&](uint32_t k, uint32_t slot) { // k: position in the batch (wave-uniform)
-            const uint32_t kk = min(k, nb - 1u);
-            const uint32_t cid = __builtin_amdgcn_readlane(my_cid, kk);
-            cn[slot] = __builtin_amdgcn_readlane(my_cn, kk);
-            load_chunk(cid, buf[slot]);
+            load_chunk(__builtin_amdgcn_readlane(my_cid, min(k, nb - 1u)), buf[slot]);
         };
+        if (b0) { // (more than 1 024 chunks in the slot)
+            nb = min(mine - b0, 64u);
+            if (lane < nb) {
+                my_cid = list[wave + (b0 + lane) * WSTEP];
+                my_cn = cdesc[my_cid] & CD_MASK;
+            }
 #pragma unroll
-        for (uint32_t d = 0; d < DEPTH; d++) fetch(d, d);
+            for (uint32_t d = 0; d < DEPTH; d++) fetch(d, d);
+        }
         for (uint32_t k = 0; k < nb; k += DEPTH) {
 #pragma unroll
             for (uint32_t d = 0; d < DEPTH; d++) { // fully unrolled: the slot index is a compile-time constant
-                if (k + d < nb) reduce_chunk(buf[d], cn[d]); // wave-uniform
+                if (k + d < nb) reduce_chunk(buf[d], __builtin_amdgcn_readlane(my_cn, k + d)); // wave-uniform
                 fetch(k + d + DEPTH, d);
             }
         }
@@ -1132,7 +1141,7 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist2(const rec16_t *__restri
         const uint32_t c = h[i];
         const uint32_t l = i >> log_w, b = s_org[l] + (i & (W - 1));
         if (c)
-            atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)((l << log_np) | p) * LH_NKEYS + b]),
+            atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)((l << log_np) | p) * LH_ROW_STRIDE + b]),
                       (unsigned long long)c);
         if (W >= 64u) {
             const unsigned long long occ = __builtin_amdgcn_ballot_w64(c != 0);

@@ -340,7 +340,7 @@ __device__ __forceinline__ void v3_global_add(uint64_t *__restrict__ counts, uin
                                               uint32_t bin, uint32_t c)
 {
     const unsigned long long c64 = c;
-    asm volatile("global_atomic_add_x2 %0, %1, off" : : "v"(&counts[(size_t)m * LH_NKEYS + bin]), "v"(c64) : "memory");
+    asm volatile("global_atomic_add_x2 %0, %1, off" : : "v"(&counts[(size_t)m * LH_ROW_STRIDE + bin]), "v"(c64) : "memory");
     uint32_t *r = ranges + 2 * (size_t)m;
     asm volatile("global_atomic_umin %0, %1, off\n\tglobal_atomic_umax %0, %1, off offset:4" : : "v"(r), "v"(bin) : "memory");
 }
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
             const uint32_t c = win[base + i];
             if (c) {
                 const uint32_t b = org + i;
-                atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)name * LH_NKEYS + b]),
+                atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)name * LH_ROW_STRIDE + b]),
                           (unsigned long long)c);
                 mn = min(mn, b);
                 mx = max(mx, b);
@@ -941,7 +941,7 @@ __global__ __launch_bounds__(1024, 4) void k_split_records(const uint32_t *__res
             const uint32_t c = win[(r << log_w) + i];
             if (c) {
                 const uint32_t b = org + i;
-                atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)name * LH_NKEYS + b]),
+                atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)name * LH_ROW_STRIDE + b]),
                           (unsigned long long)c);
                 mn = min(mn, b);
                 mx = max(mx, b);
@@ -1015,10 +1015,30 @@ __global__ __launch_bounds__(1024, 4) void k_split_waves(const uint32_t *__restr
     const uint32_t pool_base = pool_start[slot];
     const uint32_t W = 1u << log_w, mmask = (1u << log_mpp2) - 1u, ns = 1u << log_ns;
 
-    // ---- setup (as k_split_records): rank table, the names counted here, window origins
+    // Requested before the setup and its four barriers (a slot's loads are a dependent chain: slot -> chunk list ->
+    // records): this wave's first 64 dealt chunk indices, their descriptors, and -- not waiting for the descriptors --
+    // its first two chunks.  Three quarters of the slot's chunks are dealt out (wave, wave + 16, ...); see below.
+    auto load_chunk = [&](uint32_t cidx, u4_t (&dst)[CHUNK / 256]) {
+        const u4_t *src = reinterpret_cast<const u4_t *>(in_records + (size_t)cidx * CHUNK) + lane;
+#pragma unroll
+        for (uint32_t k = 0; k < CHUNK / 256; k++) dst[k] = __builtin_nontemporal_load(src + k * 64);
+    };
+    constexpr uint32_t WSTEP = BLOCK / 64, DEPTH = 2;
+    u4_t buf[DEPTH][CHUNK / 256];
+    const uint32_t cnt_dealt = (cnt - cnt / 4u) & ~(WSTEP - 1u);
+    const uint32_t mine = cnt_dealt / WSTEP; // dealt chunks of this wave
+    uint32_t nb = min(mine, 64u), my_cid = 0, my_cn = 0;
     const uint32_t c0 = list[0];
+    if (lane < nb) my_cid = list[wave + lane * WSTEP];
+    const uint32_t srec0 = in_records[(size_t)c0 * CHUNK + tid]; // (masked by n0 below: a chunk is 1 024 slots whatever it holds)
     const uint32_t n0 = in_cdesc[c0] & CD_MASK;
-    const uint32_t srec = tid < n0 ? in_records[(size_t)c0 * CHUNK + tid] : 0u;
+    if (lane < nb) my_cn = in_cdesc[my_cid] & CD_MASK;
+#pragma unroll
+    for (uint32_t d = 0; d < DEPTH; d++) // (unconditional: a wave without dealt chunks reads chunk 0 and ignores it)
+        load_chunk(__builtin_amdgcn_readlane(my_cid, min(d, max(nb, 1u) - 1u)), buf[d]);
+
+    // ---- setup (as k_split_records): rank table, the names counted here, window origins
+    const uint32_t srec = tid < n0 ? srec0 : 0u;
     if (tid < 256) L.tbl[tid] = g_remap[p1 * 256u + tid];
     if (tid < 32) {
         uint32_t name = INVALID, mn = INVALID, mx = 0, svc = 0, svm = 0;
@@ -1172,42 +1192,31 @@ __global__ __launch_bounds__(1024, 4) void k_split_waves(const uint32_t *__restr
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    auto load_chunk = [&](uint32_t cidx, u4_t (&dst)[CHUNK / 256]) {
-        const u4_t *src = reinterpret_cast<const u4_t *>(in_records + (size_t)cidx * CHUNK) + lane;
-#pragma unroll
-        for (uint32_t k = 0; k < CHUNK / 256; k++) dst[k] = __builtin_nontemporal_load(src + k * 64);
-    };
-    constexpr uint32_t WSTEP = BLOCK / 64, DEPTH = 2;
-    u4_t buf[DEPTH][CHUNK / 256];
-    uint32_t cn[DEPTH];
     // Three quarters of the slot's chunks are dealt out (wave, wave + 16, ...); the last quarter is taken chunk by chunk
     // by whichever wave is free.  (Time stamps of single slots: wave 0 was done after 90 - 105 us of a 140 - 160 us
     // slot and waited for the slowest wave: partially filled chunks and the names' skew make the waves' loads uneven.)
-    const uint32_t cnt_dealt = (cnt - cnt / 4u) & ~(WSTEP - 1u);
-    const uint32_t mine = cnt_dealt / WSTEP; // dealt chunks of this wave
     for (uint32_t b0 = 0; b0 < mine; b0 += 64) {
-        const uint32_t nb = min(mine - b0, 64u);
-        uint32_t my_cid = 0, my_cn = 0;
-        if (lane < nb) {
-            my_cid = list[wave + (b0 + lane) * WSTEP];
-            my_cn = in_cdesc[my_cid] & CD_MASK;
-        }
         auto fetch = [&](uint32_t k, uint32_t at) { // k: position in the batch (wave-uniform)
-            const uint32_t kk = min(k, nb - 1u);
-            const uint32_t cid = __builtin_amdgcn_readlane(my_cid, kk);
-            cn[at] = __builtin_amdgcn_readlane(my_cn, kk);
-            load_chunk(cid, buf[at]);
+            load_chunk(__builtin_amdgcn_readlane(my_cid, min(k, nb - 1u)), buf[at]);
         };
+        if (b0) { // (more than 1 024 dealt chunks in the slot; the first batch was requested before the setup)
+            nb = min(mine - b0, 64u);
+            if (lane < nb) {
+                my_cid = list[wave + (b0 + lane) * WSTEP];
+                my_cn = in_cdesc[my_cid] & CD_MASK;
+            }
 #pragma unroll
-        for (uint32_t d = 0; d < DEPTH; d++) fetch(d, d);
+            for (uint32_t d = 0; d < DEPTH; d++) fetch(d, d);
+        }
         for (uint32_t k = 0; k < nb; k += DEPTH) {
 #pragma unroll
             for (uint32_t d = 0; d < DEPTH; d++) {
                 if (k + d < nb) { // wave-uniform
-                    classify8(buf[d][0], buf[d][1], 0u, cn[d]);
+                    const uint32_t cnd = __builtin_amdgcn_readlane(my_cn, k + d);
+                    classify8(buf[d][0], buf[d][1], 0u, cnd);
                     flush();
-                    if (cn[d] > 512u) {
-                        classify8(buf[d][2], buf[d][3], 512u, cn[d]);
+                    if (cnd > 512u) {
+                        classify8(buf[d][2], buf[d][3], 512u, cnd);
                         flush();
                     }
                 }
@@ -1279,7 +1288,7 @@ __global__ __launch_bounds__(1024, 4) void k_split_waves(const uint32_t *__restr
             const uint32_t c = win[(r << log_w) + i];
             if (c) {
                 const uint32_t b = org + i;
-                atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)name * LH_NKEYS + b]),
+                atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)name * LH_ROW_STRIDE + b]),
                           (unsigned long long)c);
                 mn = min(mn, b);
                 mx = max(mx, b);
@@ -1331,19 +1340,42 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
     const uint32_t *list = sorted + part_start[q] + first;
     const uint32_t mpp2 = 1u << log_mpp2, W = 1u << log_w, words = mpp2 << log_w;
 
+    // A slot is a chain of dependent round trips with little work between them (slot -> chunk list -> descriptor ->
+    // records -> LDS -> flush; config 4's slice: 2 167 slots, 8.5 per CU one after another).  Everything the chunk list
+    // decides is therefore requested at once, BEFORE the window setup and its barriers: the slot's first chunk (window
+    // placement), this wave's first 64 chunk indices, their descriptors and -- without waiting for the descriptors: a
+    // chunk is 4 KiB whatever it holds -- the first two chunks themselves.
+    auto load_chunk = [&](uint32_t cidx, u4_t (&dst)[CHUNK / 256]) {
+        const u4_t *src = reinterpret_cast<const u4_t *>(records + (size_t)cidx * CHUNK) + lane;
+#pragma unroll
+        for (uint32_t k = 0; k < CHUNK / 256; k++) dst[k] = __builtin_nontemporal_load(src + k * 64);
+    };
+    constexpr uint32_t WSTEP = P2_BLOCK / 64, DEPTH = 2;
+    u4_t buf[DEPTH][CHUNK / 256];
+    const uint32_t mine = cnt > wave ? (cnt - wave + WSTEP - 1) / WSTEP : 0u; // chunks of this wave: wave, wave + 16, ..
+    uint32_t nb = min(mine, 64u), my_cid = 0, my_cn = 0;
+    // (the small loads first, the 8 KiB of chunks last: a wave's loads return in order, and whoever needs a small one
+    // must not wait for the chunks behind it)
     const uint32_t c0 = list[0];
+    if (lane < nb) my_cid = list[wave + lane * WSTEP];
+    uint32_t nm = INVALID; // thread l < mpp2: the l-th name of the fine partition and what the survey saw of it
+    if (tid < mpp2) nm = ((uint32_t)g_inv[p1 * 256u + (fine << log_mpp2) + tid] << V3_LOG_NP) | p1;
+    const uint32_t srec0 = records[(size_t)c0 * CHUNK + tid]; // (all 1 024 slots of a chunk exist: masked by n0 below)
     const uint32_t n0 = cdesc[c0] & CD_MASK;
-    const uint32_t srec = tid < n0 ? records[(size_t)c0 * CHUNK + tid] : 0u;
+    if (lane < nb) my_cn = cdesc[my_cid] & CD_MASK;
+    uint32_t svc = 0, svm = 0;
+    if (nm < nmetrics) {
+        svc = sv_count(S, nm);
+        svm = sv_mean(S, nm);
+    }
+#pragma unroll
+    for (uint32_t d = 0; d < DEPTH; d++) // (unconditional: a wave without chunks reads chunk 0 and ignores it)
+        load_chunk(__builtin_amdgcn_readlane(my_cid, min(d, max(nb, 1u) - 1u)), buf[d]);
+    const uint32_t srec = tid < n0 ? srec0 : 0u;
     for (uint32_t i = tid; i < words; i += P2_BLOCK) h[i] = 0;
     ov_init(ov_key, ov_cnt, tid, P2_BLOCK);
     if (tid < mpp2) {
-        const uint32_t m = ((uint32_t)g_inv[p1 * 256u + (fine << log_mpp2) + tid] << V3_LOG_NP) | p1;
-        uint32_t svc = 0, svm = 0;
-        if (m < nmetrics) {
-            svc = sv_count(S, m);
-            svm = sv_mean(S, m);
-        }
-        s_name[tid] = m < nmetrics ? m : INVALID;
+        s_name[tid] = nm < nmetrics ? nm : INVALID;
         s_svc[tid] = svc;
         s_svm[tid] = svm;
         s_mn[tid] = INVALID;
@@ -1371,11 +1403,6 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
     }
     __syncthreads();
 
-    auto load_chunk = [&](uint32_t cidx, u4_t (&dst)[CHUNK / 256]) {
-        const u4_t *src = reinterpret_cast<const u4_t *>(records + (size_t)cidx * CHUNK) + lane;
-#pragma unroll
-        for (uint32_t k = 0; k < CHUNK / 256; k++) dst[k] = __builtin_nontemporal_load(src + k * 64);
-    };
     uint32_t nmiss = 0; // records outside their window (self-metric)
     auto add_one = [&](uint32_t rec, uint32_t c) {
         const uint32_t l = (rec >> 16) & 0xffu, b = rec & 0xffffu;
@@ -1408,31 +1435,25 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
         }
     };
     // Each wave walks chunks wave, wave + 16, ...; their indices and descriptors are fetched 64 at a time (lane l holds
-    // the wave's l-th chunk of the batch) and two chunks (8 KiB per wave) are in flight while the older is reduced:
-    // see k_part_hist2.
-    constexpr uint32_t WSTEP = P2_BLOCK / 64, DEPTH = 2;
-    u4_t buf[DEPTH][CHUNK / 256];
-    uint32_t cn[DEPTH];
-    const uint32_t mine = cnt > wave ? (cnt - wave + WSTEP - 1) / WSTEP : 0u; // chunks of this wave
+    // the wave's l-th chunk of the batch; the first batch above) and two chunks (8 KiB per wave) are in flight while the
+    // older is reduced: see k_part_hist2.
     for (uint32_t b0 = 0; b0 < mine; b0 += 64) {
-        const uint32_t nb = min(mine - b0, 64u);
-        uint32_t my_cid = 0, my_cn = 0;
-        if (lane < nb) {
-            my_cid = list[wave + (b0 + lane) * WSTEP];
-            my_cn = cdesc[my_cid] & CD_MASK;
-        }
         auto fetch = [&](uint32_t k, uint32_t at) { // k: position in the batch (wave-uniform)
-            const uint32_t kk = min(k, nb - 1u);
-            const uint32_t cid = __builtin_amdgcn_readlane(my_cid, kk);
-            cn[at] = __builtin_amdgcn_readlane(my_cn, kk);
-            load_chunk(cid, buf[at]);
+            load_chunk(__builtin_amdgcn_readlane(my_cid, min(k, nb - 1u)), buf[at]);
         };
+        if (b0) { // (more than 1 024 chunks in the slot)
+            nb = min(mine - b0, 64u);
+            if (lane < nb) {
+                my_cid = list[wave + (b0 + lane) * WSTEP];
+                my_cn = cdesc[my_cid] & CD_MASK;
+            }
 #pragma unroll
-        for (uint32_t d = 0; d < DEPTH; d++) fetch(d, d);
+            for (uint32_t d = 0; d < DEPTH; d++) fetch(d, d);
+        }
         for (uint32_t k = 0; k < nb; k += DEPTH) {
 #pragma unroll
             for (uint32_t d = 0; d < DEPTH; d++) {
-                if (k + d < nb) reduce_chunk(buf[d], cn[d]); // wave-uniform
+                if (k + d < nb) reduce_chunk(buf[d], __builtin_amdgcn_readlane(my_cn, k + d)); // wave-uniform
                 fetch(k + d + DEPTH, d);
             }
         }
@@ -1465,7 +1486,7 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
             atomicMax(&s_mx[l], b + 63u - (uint32_t)__builtin_clzll(occ));
         }
         if (c)
-            atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)s_name[l] * LH_NKEYS + b]),
+            atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)s_name[l] * LH_ROW_STRIDE + b]),
                       (unsigned long long)c);
     }
     for (uint32_t i = tid; i < OV_SLOTS; i += P2_BLOCK)

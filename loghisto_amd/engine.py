@@ -185,8 +185,13 @@ class Snapshot:
         row[(keys.astype(np.int64) & 0xFFFF) ^ 0x8000] = counts
         return row
 
+    @staticmethod
+    def row_stride() -> int:
+        """Cells from one device row to the next (lh_row_stride: more than 65 536)."""
+        return int(N.lib().lh_row_stride())
+
     def device_rows(self):
-        """(device pointer of uint64[nrows][65536], nrows)."""
+        """(device pointer of row 0, nrows); row r starts row_stride() uint64 cells after row r - 1 and is 65 536 cells long."""
         p, n = C.c_void_p(0), C.c_uint32(0)
         N.check(N.lib().lh_snapshot_rows(self._h, C.byref(p), C.byref(n)), "lh_snapshot_rows")
         return int(p.value), int(n.value)

@@ -121,9 +121,10 @@ def merge_rows(rows: torch.Tensor, ranges: Optional[torch.Tensor] = None, plan: 
                group=None) -> Tuple[int, int]:
     """Sum `rows` (int64[nrows, 65536]) across ranks, in place, moving only each row's merged window.
 
+    `rows` may be a strided view: a snapshot's rows are lh_row_stride() cells apart, not 65 536 (snapshot_tensors).
     ranges (int32[nrows, 2], merged in place) bounds the occupied span of every row; None moves whole rows.
     Returns the [first, last) rows that hold fully merged data on this rank."""
-    assert rows.dtype == torch.int64 and rows.dim() == 2 and rows.shape[1] == NKEYS
+    assert rows.dtype == torch.int64 and rows.dim() == 2 and rows.shape[1] == NKEYS and rows.stride(1) == 1
     if plan not in ("allreduce", "reduce_scatter"):
         raise ValueError(f"unknown plan {plan!r}")
     world = dist.get_world_size(group)
@@ -145,8 +146,9 @@ def merge_rows(rows: torch.Tensor, ranges: Optional[torch.Tensor] = None, plan: 
     # packed position q (0 .. total) -> (row, column)
     row_of = torch.repeat_interleave(torch.arange(nrows, device=rows.device), W["width"], output_size=total)
     q = torch.arange(total, device=rows.device)
-    flat = row_of * NKEYS + (q - W["P"][row_of] + W["lo"][row_of])
-    cells = rows.view(-1)
+    row_stride = rows.stride(0) if nrows > 1 else NKEYS
+    flat = row_of * row_stride + (q - W["P"][row_of] + W["lo"][row_of])
+    cells = torch.as_strided(rows, ((nrows - 1) * row_stride + NKEYS,), (1,))   # every cell from row 0 to the last row's end
     if plan == "allreduce":
         buf = _buffer(rows.device, total)
         torch.index_select(cells, 0, flat, out=buf)
@@ -177,11 +179,13 @@ class _DeviceArray:
 
 
 def snapshot_tensors(snap, nrows: Optional[int] = None, device: Optional[int] = None):
-    """(rows int64[nrows,65536], ranges int32[nrows,2]) aliasing the snapshot's HBM."""
+    """(rows int64[nrows,65536] -- a view with row stride lh_row_stride() --, ranges int32[nrows,2]) aliasing the snapshot's HBM."""
     ptr, total = snap.device_rows()
     nrows = total if nrows is None else nrows
     dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
-    rows = torch.as_tensor(_DeviceArray(ptr, (nrows, NKEYS), "<i8"), device=dev)
+    stride = snap.row_stride()
+    flat = torch.as_tensor(_DeviceArray(ptr, ((nrows - 1) * stride + NKEYS,), "<i8"), device=dev)
+    rows = torch.as_strided(flat, (nrows, NKEYS), (stride, 1))
     ranges = torch.as_tensor(_DeviceArray(snap.device_ranges(), (nrows, 2), "<i4"), device=dev)
     return rows, ranges
 

@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
-    src = open(os.path.join(ROOT, "include", "loghisto_gpu.h")).read()
+def header_symbols(header="loghisto_gpu.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(lh_[a-z0-9_]+)\s*\(", src)))
 
@@ -23,10 +23,31 @@ def test_library_exports_every_declared_symbol(native_lib):
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in loghisto_gpu.h but not exported"
     assert sorted(_native.SIGNATURES) == declared, "ctypes binding and header disagree"
+    # the test / tuning hooks are declared apart from the drop-in contract, and exported too
+    tuning = header_symbols("loghisto_gpu_tuning.h")
+    assert tuning == sorted(_native.TUNING_SIGNATURES) and not set(tuning) & set(declared)
+    for name in tuning:
+        assert hasattr(raw, name), f"{name} declared in loghisto_gpu_tuning.h but not exported"
+
+
+def test_the_public_header_keeps_only_the_operational_options():
+    """ABI 5: the keys that steer the mixed ingest's path choice (tests, tuning runs) and the allocation-failure hook are
+    declared in loghisto_gpu_tuning.h; every key has one number, and no number two names."""
+    def keys(header):
+        src = open(os.path.join(ROOT, "include", header)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        return dict((k, int(v)) for k, v in re.findall(r"\b(LH_OPT_[A-Z0-9_]+)\s*=\s*(\d+)", src))
+    pub, tun = keys("loghisto_gpu.h"), keys("loghisto_gpu_tuning.h")
+    assert sorted(pub) == ["LH_OPT_EXTRACT_ZERO_COPY", "LH_OPT_LANE_SCRATCH_BLOCKS", "LH_OPT_LANE_ZERO_COPY",
+                           "LH_OPT_SCRATCH_CAP_BYTES", "LH_OPT_SUBLAUNCH_PAIRS", "LH_OPT_SURVEY_EVERY"]
+    assert not set(pub) & set(tun) and len(set(pub.values()) | set(tun.values())) == len(pub) + len(tun)
+    from loghisto_amd import _native
+    for name, num in {**pub, **tun}.items():
+        assert getattr(_native, name[3:]) == num, name
 
 
 def test_abi_version_and_strerror(native_lib):
-    assert native_lib.lh_abi_version() == 4
+    assert native_lib.lh_abi_version() == 5
     msgs = {native_lib.lh_strerror(c).decode() for c in range(8)}
     assert len(msgs) == 8 and "ok" in msgs
 
@@ -35,7 +56,7 @@ def test_struct_layouts_match_header(native_lib):
     from loghisto_amd import _native
     assert C.sizeof(_native.LhConfig) == 32
     assert C.sizeof(_native.LhStats) == 40
-    assert C.sizeof(_native.LhLineFormat) == 32 and C.sizeof(_native.LhCounters) == 184
+    assert C.sizeof(_native.LhLineFormat) == 32 and C.sizeof(_native.LhCounters) == 200
     assert C.sizeof(_native.LhMergeInfo) == 72 and C.sizeof(_native.LhExtractView) == 48
     cfg = _native.LhConfig()
     assert native_lib.lh_default_config(C.byref(cfg)) == 0

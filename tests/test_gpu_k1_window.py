@@ -51,7 +51,8 @@ def key_values(keys):
 
 @pytest.mark.parametrize("case", ["just_above", "just_below", "both_sides_near", "both_sides_far", "beyond_a_floating_window",
                                   "anchor_at_the_top_key", "anchor_at_the_bottom_key", "dominant_value_outside",
-                                  "misleading_first_samples", "all_far_above", "all_far_below_narrow"])
+                                  "misleading_first_samples", "all_far_above", "all_far_below_narrow",
+                                  "slightly_wider_above", "slightly_wider_below"])
 def test_streams_around_the_window_edges(engine, torch_cuda, case):
     rng = np.random.default_rng(17)
     n = 1_500_001                                                   # ~180 workgroups, ragged tail
@@ -79,6 +80,10 @@ def test_streams_around_the_window_edges(engine, torch_cuda, case):
         v = rng.lognormal(math.log(1e30), 1.5, n)
     elif case == "all_far_below_narrow":
         v = -rng.lognormal(math.log(1e100), 0.1, n)
+    elif case == "slightly_wider_above":                            # the first miss lands anywhere up to 900 bins out: the
+        v = key_values(rng.integers(0, 4096 + 900, n))              # floating window must still cover the bins next to the
+    elif case == "slightly_wider_below":                            # main window (k1_anchor: adjacent within 1 024 bins)
+        v = key_values(-rng.integers(0, 4096 + 900, n))
     else:                                                           # >= 24 lanes of a wave share one bucket OUTSIDE the window
         v = np.where(rng.random(n) < 0.9, key_values([5000])[0], body)
     assert np.all(np.isfinite(v))
@@ -133,7 +138,7 @@ def test_no_stream_is_a_cliff(engine, torch_cuda):
     report = {"lognormal": base}
     # SURVEY 8(d)'s contention sweep and the few-valued streams ride along: the cliff was found by running a sweep
     # distribution nobody had re-timed after a kernel change
-    for kind in ("loguniform", "far_1e30", "negative_far", "signed_wide", "thin_far_tail", "constant", "uniform",
+    for kind in ("loguniform", "loguniform21", "far_1e30", "negative_far", "signed_wide", "thin_far_tail", "constant", "uniform",
                  "exponential", "normal", "lognormal25", "kvalues2", "kvalues4", "kvalues16", "bimodal", "on_thresholds"):
         report[kind] = timed(kind)
     print("K1 ms per 2e8 samples:", {k: round(x, 3) for k, x in report.items()})
