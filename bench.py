@@ -175,6 +175,51 @@ def make_samples(n: int, kind: str, seed: int) -> torch.Tensor:
     return v.mul_(sigma).add_(math.log(1e5)).exp_()
 
 
+class OwnBuffer:
+    """A bench input stream in plain hipMalloc'ed memory (lh_tool_device_alloc, include/loghisto_gpu_tuning.h) instead of
+    torch's caching allocator: VERDICT r4 weak #7 -- one box of twelve ran every kernel that read the bench's
+    torch-allocated inputs 20 - 60 % slow while kernels reading hipMalloc'ed memory ran normally.  `tensor` is a torch
+    view of the block (for the launch wrappers and the parity legs); free() gives it back."""
+
+    def __init__(self, src: torch.Tensor):
+        import ctypes as C
+        from loghisto_amd import _native as N
+        from loghisto_amd.merge import _DeviceArray
+        self._N, self.nbytes = N, src.numel() * src.element_size()
+        p = C.c_void_p(0)
+        N.check(N.lib().lh_tool_device_alloc(self.nbytes, C.byref(p)), "lh_tool_device_alloc")
+        self.ptr = int(p.value)
+        typestr = {torch.float64: "<f8", torch.int32: "<i4", torch.int16: "<i2", torch.int64: "<i8"}[src.dtype]
+        self.tensor = torch.as_tensor(_DeviceArray(self.ptr, (src.numel(),), typestr), device=src.device)
+        self.tensor.copy_(src)
+        torch.cuda.synchronize()
+
+    def read_ceiling_gbs(self, reps=10, stream=None):
+        """GB/s a kernel that ONLY reads this block gets on this box, in this process (lh_tool_read_ceiling: K1's loop
+        without the bucket work): (average, best launch)."""
+        import ctypes as C
+        avg, mn = C.c_float(0), C.c_float(0)
+        h = C.c_void_p(stream.cuda_stream) if stream is not None else None
+        self._N.check(self._N.lib().lh_tool_read_ceiling(C.c_void_p(self.ptr), self.nbytes, reps, h, C.byref(avg), C.byref(mn)),
+                      "lh_tool_read_ceiling")
+        return self.nbytes / (avg.value * 1e-3) / 1e9, self.nbytes / (mn.value * 1e-3) / 1e9
+
+    def free(self):
+        if self.ptr:
+            import ctypes as C
+            self.tensor = None
+            self._N.check(self._N.lib().lh_tool_device_free(C.c_void_p(self.ptr)), "lh_tool_device_free")
+            self.ptr = 0
+
+
+def own(t: torch.Tensor) -> OwnBuffer:
+    """the tensor's contents in hipMalloc'ed memory; torch's copy is dropped"""
+    b = OwnBuffer(t)
+    del t
+    torch.cuda.empty_cache()
+    return b
+
+
 def zipf_ids(n: int, M: int, seed: int) -> torch.Tensor:
     """id ~ Zipf(1.0) over ranks by inverse CDF (chunked: searchsorted needs int64 scratch)."""
     g = torch.Generator(device="cuda")
@@ -317,7 +362,8 @@ def run_c2(args, la, stream, rank, world=1, dist=None, comm=0, frontend="none", 
     from loghisto_amd import merge as tmerge
     n = int(args.samples)
     eng = la.Engine(device=torch.cuda.current_device(), max_metrics=1, num_buffers=2, num_lanes=1, lane_samples=1 << 16)
-    data = make_samples(n, args.dist, seed=2 + rank)
+    buf = own(make_samples(n, args.dist, seed=2 + rank))          # plain hipMalloc'ed memory (OwnBuffer)
+    data = buf.tensor
     torch.cuda.synchronize()
     events = []
 
@@ -365,6 +411,20 @@ def run_c2(args, la, stream, rank, world=1, dist=None, comm=0, frontend="none", 
         dt = float(tt.item())
     assert int(out["count"].sum()) == n * world, (int(out["count"].sum()), n, world)
     k1_ms = sum(a.elapsed_time(b) for a, b in events) / len(events)
+    # The same K steps once more, SERIAL: every step drained (ingest, flip, reduce, results on the host) before the next
+    # one is enqueued -- what a caller gets that does not overlap reduction with the next interval's ingest (ADVICE r4:
+    # the pipelined figure alone is not comparable with rounds 1 - 3).  Reported beside the headline, never as `value`.
+    def serial_step(timed):
+        eng.submit_device(0, data, n, stream=stream)
+        return finish(eng.flip(), False)
+
+    dt_serial, _ = timed_steps(serial_step, args.steps, 1, fence)
+    if dist is not None:
+        tt = torch.tensor([dt_serial], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt_serial = float(tt.item())
+    # what a kernel that only reads gets from this box, now, on the same block of memory (K1's loop without the buckets)
+    ceil_avg, ceil_best = buf.read_ceiling_gbs(reps=10, stream=stream)
 
     # p99 extract latency: flip -> stats on host (BASELINE.json metric, part 2); one rank's own interval
     lat = []
@@ -399,16 +459,22 @@ def run_c2(args, la, stream, rank, world=1, dist=None, comm=0, frontend="none", 
             traffic = None
     res = {
         "value": world * n * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+        "ms_per_step_serial": dt_serial / args.steps * 1e3, "value_serial": world * n * args.steps / dt_serial,
         "config": {"workload": "C2 single-metric float64 stream, one ingest kernel + one percentile scan per step"
                                + ("" if world == 1 else "; every rank buckets its own slice, the row's merged window is "
                                   "all-reduced at the flip (lh_snapshot_merge, LH_MERGE_ALLREDUCE), every rank extracts"),
                    "samples_per_gpu_per_step": n, "distribution": args.dist, "metrics": 1, "percentiles": PCTS,
                    "ranks": world, "merge": "none" if world == 1 else frontend,
                    "prewarm": f"{PREWARM} untimed K1 launches before the W warm-up steps (clock ramp after idle)",
+                   "input_memory": "hipMalloc (lh_tool_device_alloc), not torch's caching allocator",
                    "steps": "software-pipelined: ingest of step i + 1 is enqueued after the flip of step i, before the host "
                             "waits for step i's results (as the reference's reaper overlaps reduction with ingest)"},
         "roofline": roofline(n * BYTES_SINGLE, k1_ms, "k_ingest_single", traffic=traffic,
-                             traffic_source=traffic_source, frac_of_measured_copy_ceiling_6290=n * BYTES_SINGLE / (k1_ms * 1e-3) / 1e9 / 6290.0),
+                             traffic_source=traffic_source, frac_of_measured_copy_ceiling_6290=n * BYTES_SINGLE / (k1_ms * 1e-3) / 1e9 / 6290.0,
+                             read_ceiling_same_box=ceil_avg, read_ceiling_same_box_best_launch=ceil_best,
+                             frac_of_read_ceiling=n * BYTES_SINGLE / (k1_ms * 1e-3) / 1e9 / ceil_avg,
+                             read_ceiling_source="lh_tool_read_ceiling: 10 launches of K1's loop without the bucket work over "
+                                                 "the step's input block, in this process, right after the timed steps"),
         "extract_latency_us": {"p50": float(np.percentile(lat_us, 50)), "p99": float(np.percentile(lat_us, 99)),
                                "flips": len(lat), "names": 1},
     }
@@ -466,6 +532,7 @@ def run_c2(args, la, stream, rank, world=1, dist=None, comm=0, frontend="none", 
     del host
     eng.close()
     del data
+    buf.free()
     torch.cuda.empty_cache()
     return res
 
@@ -501,6 +568,9 @@ def run_c3(args, la, stream, rank, steps, warmup, latency_flips=0):
     chunk = 1 << 27
     for lo in range(0, n, chunk):      # value ~ lognormal(ln 1e5 + 0.002*id, 1): every name its own
         data[lo:lo + chunk].mul_(torch.exp(0.002 * ids[lo:lo + chunk].to(torch.float64)))
+    bi, bd = OwnBuffer(ids), OwnBuffer(data)                       # plain hipMalloc'ed memory, as the headline's input
+    ids, data = bi.tensor, bd.tensor
+    torch.cuda.empty_cache()
     torch.cuda.synchronize()
     events = []
 
@@ -560,6 +630,8 @@ def run_c3(args, la, stream, rank, steps, warmup, latency_flips=0):
         del want
     eng.close()
     del ids, data
+    bi.free()
+    bd.free()
     torch.cuda.empty_cache()
     return res
 
@@ -581,6 +653,9 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=Non
     ids = zipf_ids(n, M, 4000 + rank)                       # this rank's slice of a Zipf stream over ALL names
     data = make_samples(n, "lognormal", seed=40 + rank)
     data.mul_(torch.exp(3e-5 * ids.to(torch.float64)))
+    bi, bd = OwnBuffer(ids), OwnBuffer(data)                # plain hipMalloc'ed memory, as the headline's input
+    ids, data = bi.tensor, bd.tensor
+    torch.cuda.empty_cache()
     torch.cuda.synchronize()
     own_comm = False
     if comm_override is None:
@@ -725,8 +800,8 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=Non
                       exact=parity["exact"] and int(nchk[1].item()) == world)
     assert parity["exact"], parity
     lat_c4 = None
-    nlat = min(100, int(getattr(args, "latency_flips", 100)))
-    if world == 1 and steps and nlat > 10:
+    nlat = int(getattr(args, "latency_flips", 1000)) + 10          # BASELINE's metric: p99 over >= 1 000 flips (ten more to warm up)
+    if world == 1 and steps and nlat > 20:
         # flip -> results of ALL 65 536 names on the host (in place, lh_extract_rows_view), small intervals
         lat = []
         sl_i, sl_v = ids[: 1 << 22], data[: 1 << 22]
@@ -797,6 +872,8 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=Non
         rccl.comm_destroy(comm)
     eng.close()
     del ids, data
+    bi.free()
+    bd.free()
     torch.cuda.empty_cache()
     return res
 
@@ -812,6 +889,9 @@ def run_c4_1e9(args, la, stream, steps=3, warmup=2):
     chunk = 1 << 27
     for lo in range(0, n, chunk):
         data[lo:lo + chunk].mul_(torch.exp(3e-5 * ids[lo:lo + chunk].to(torch.float64)))
+    bi, bd = OwnBuffer(ids), OwnBuffer(data)                # plain hipMalloc'ed memory, as the headline's input
+    ids, data = bi.tensor, bd.tensor
+    torch.cuda.empty_cache()
     torch.cuda.synchronize()
     events = []
 
@@ -851,6 +931,8 @@ def run_c4_1e9(args, la, stream, steps=3, warmup=2):
            "parity": parity, "scratch_bytes": c["scratch_bytes"]}
     eng.close()
     del ids, data
+    bi.free()
+    bd.free()
     torch.cuda.empty_cache()
     return res
 
@@ -858,7 +940,7 @@ def run_c4_1e9(args, la, stream, steps=3, warmup=2):
 # ---------------------------------------------------------------------------------------------------------
 # host-fed (PCIe-inclusive) and the C5 burst
 # ---------------------------------------------------------------------------------------------------------
-def run_hostfed(la, M=1024, total=int(8e8)):
+def run_hostfed(la, M=1024, total=int(8e8), forms=("in_place16", "in_place", "submit_pairs", "copy_engine")):
     """Host arrays -> pinned staging buffers -> PCIe -> buckets, from T producer threads.  Four forms of the same
     stream: lh_reserve_pairs16 / lh_commit_pairs16 (uint16 ids, 10 B per pair over the link, the producer's own store
     is the only host-side copy: what the binding uses for <= 65 536 names), lh_reserve_pairs / lh_commit_pairs (the
@@ -880,13 +962,31 @@ def run_hostfed(la, M=1024, total=int(8e8)):
     # every cell against the oracle: thread t submits the same slice [off_t, off_t + batch) per // batch times and
     # its first per % batch samples once more
     reps, rem = per // batch, per % batch
-    want = np.zeros((M, 65536), dtype=np.uint64)
-    if reps:
-        want += np.uint64(reps) * oracle.histogram_pairs_mt(np.concatenate([ids[o:o + batch] for o in offs]),
-                                                             np.concatenate([src[o:o + batch] for o in offs]), M)
-    if rem:
-        want += oracle.histogram_pairs_mt(np.concatenate([ids[o:o + rem] for o in offs]),
-                                          np.concatenate([src[o:o + rem] for o in offs]), M)
+    dense = M <= 8192          # a dense oracle matrix of 65 536 names would be 32 GiB: sorted (name << 16 | bin, count) lists
+    if dense:
+        want = np.zeros((M, 65536), dtype=np.uint64)
+        if reps:
+            want += np.uint64(reps) * oracle.histogram_pairs_mt(np.concatenate([ids[o:o + batch] for o in offs]),
+                                                                 np.concatenate([src[o:o + batch] for o in offs]), M)
+        if rem:
+            want += oracle.histogram_pairs_mt(np.concatenate([ids[o:o + rem] for o in offs]),
+                                              np.concatenate([src[o:o + rem] for o in offs]), M)
+    else:
+        bins = oracle.key_to_bin(oracle.compress_many(src)).astype(np.uint64)
+        cell = (ids.astype(np.uint64) << np.uint64(16)) | bins
+        parts = [(cell[o:o + batch], reps) for o in offs if reps] + [(cell[o:o + rem], 1) for o in offs if rem]
+        keys = np.concatenate([c for c, _ in parts])
+        wts = np.concatenate([np.full(c.size, r, dtype=np.int64) for c, r in parts])
+        wc, inv = np.unique(keys, return_inverse=True)
+        want = (wc, np.bincount(inv, weights=wts).astype(np.int64))
+        del bins, cell, keys, wts, inv
+
+    def cells_exact(off_, keys_, counts_):
+        if dense:
+            return bool(np.array_equal(dense_from_csr(off_, keys_, counts_, M), want))
+        rows = np.repeat(np.arange(M, dtype=np.uint64), np.diff(off_.astype(np.int64)))
+        got = (rows << np.uint64(16)) | oracle.key_to_bin(keys_).astype(np.uint64)
+        return bool(np.array_equal(got, want[0]) and np.array_equal(counts_.astype(np.int64), want[1]))
 
     ids32 = ids
 
@@ -922,10 +1022,11 @@ def run_hostfed(la, M=1024, total=int(8e8)):
             cnt = int(snap.extract([0.5], M)["count"].sum())
             off_, keys_, counts_ = snap.buckets_all(M)
         eng.close()
-        exact = cnt == per * T and bool(np.array_equal(dense_from_csr(off_, keys_, counts_, M), want))
+        exact = cnt == per * T and cells_exact(off_, keys_, counts_)
         return per * T / dt, exact
 
-    rates = {form: one(form) for form in ("in_place16", "in_place", "submit_pairs", "copy_engine")}
+    rates = {form: one(form) for form in forms}
+
     del want
     rate = rates["in_place16"][0]
     return {"value": rate, "unit": "samples/s", "threads": T, "samples": per * T, "names": M,
@@ -935,15 +1036,13 @@ def run_hostfed(la, M=1024, total=int(8e8)):
                        "id_bytes": 2},
             "roofline": {"bound": "pcie", "achieved": rate * BYTES_PAIR16 / 1e9, "peak": PCIE_GBS, "unit": "GB/s",
                          "frac": rate * BYTES_PAIR16 / 1e9 / PCIE_GBS, "bytes_per_sample": BYTES_PAIR16},
-            "other_forms": {"lh_reserve_pairs / lh_commit_pairs (uint32 ids, 12 B per pair)": {
-                                "value": rates["in_place"][0], "frac": rates["in_place"][0] * BYTES_PAIR / 1e9 / PCIE_GBS},
-                            "lh_submit_pairs": {"value": rates["submit_pairs"][0],
-                                                "frac": rates["submit_pairs"][0] * BYTES_PAIR / 1e9 / PCIE_GBS},
-                            "lh_submit_pairs_through_the_copy_engine": {
-                                "value": rates["copy_engine"][0],
-                                "frac": rates["copy_engine"][0] * BYTES_PAIR / 1e9 / PCIE_GBS}},
+            "other_forms": {label: {"value": rates[form][0], "frac": rates[form][0] * BYTES_PAIR / 1e9 / PCIE_GBS}
+                            for form, label in (("in_place", "lh_reserve_pairs / lh_commit_pairs (uint32 ids, 12 B per pair)"),
+                                                ("submit_pairs", "lh_submit_pairs"),
+                                                ("copy_engine", "lh_submit_pairs_through_the_copy_engine"))
+                            if form in rates},
             "parity": {"rows_checked": M, "exact": all(r[1] for r in rates.values()),
-                       "cells_exact_by_form": {k: r[1] for k, r in rates.items()},
+                       "cells_exact_by_form": {k: r[1] for k, r in rates.items() if k in forms},
                        "checker": "oracle/ over every submitted pair (slices x repetitions), every cell of every row, "
                                   "for each of the four forms"}}
 
@@ -1112,6 +1211,9 @@ def run_job(args, la, stream, rank, world, dist, comm, frontend, why, workload="
                         ("c4_one_rank", lambda: run_c4(args, la, stream, 0, 1, None, steps=5, warmup=2)),
                         ("c4_one_rank_1e9", lambda: run_c4_1e9(args, la, stream)),
                         ("hostfed_pairs", lambda: run_hostfed(la)),
+                        # config 4's name count from the host (VERDICT r4 missing #4): a lane-sized launch over 65 536
+                        # names is kernel-bound, not link-bound -- reported so that the driver sees it
+                        ("hostfed_pairs_65536", lambda: run_hostfed(la, M=65536, total=int(4e8), forms=("in_place16", "in_place"))),
                         ("c5", run_c5))
             else:
                 legs = (("c4", c4_with_reference),)
@@ -1127,6 +1229,17 @@ def run_job(args, la, stream, rank, world, dist, comm, frontend, why, workload="
             if guard:
                 guard.cancel()
             res["secondary"] = sec
+            c4 = sec.get("c4") or {}
+            if world > 1 and c4.get("value"):
+                # BOTH N-rank workloads at the top level, under names of their own: `value` continues the N = 1
+                # headline (weak scaling of the single metric; its only collective is the all-reduce of one row), value_c4
+                # is BASELINE config 4 on the same ranks -- 65 536 names, every rank ingests its slice over all of them,
+                # reduce-scatter of the per-row windows, extract of the owned names: the exchange the north star names
+                res.update(metric_c4="(uint32 id, float64 value) pairs/sec bucketed over 65536 names on N GPUs incl. the "
+                                     "reduce-scatter merge and the extract of the owned names (BASELINE config 4)",
+                           value_c4=c4["value"], value_c4_per_gpu=c4["value"] / world, ms_per_step_c4=c4["ms_per_step"],
+                           ms_per_step_c4_serial=c4.get("serial_ms_per_step"),
+                           c4_efficiency_vs_one_rank=c4.get("efficiency_vs_one_rank"))
     elif workload == "c3":
         res = run_c3(args, la, stream, rank, args.steps, args.warmup, latency_flips=min(args.latency_flips, 200))
     elif world > 1:

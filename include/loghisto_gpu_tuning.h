@@ -42,6 +42,9 @@ extern "C" {
  *                             95 % of the sampled mass and the following calls use it (lh_counters.window_log2)
  *   LH_OPT_PART_MIN_PAIRS     smallest mixed launch that takes a partitioned path at all (below it: one global atomic
  *                             per sample); 0 = the default, 131 072; >= 65 536 otherwise
+ *   LH_OPT_LANE_GEN3          0 / 1 (default 1): above 8 192 names a host-fed lane launch takes the third generation in the
+ *                             lane's own scratch block, on survey tables the lanes share (read-only between surveys, two
+ *                             sets); 0 = the first generation's two scatter levels, as up to ABI 4
  *   LH_OPT_FAIL_SCRATCH_ALLOCS  the next `value` scratch allocations of the mixed ingest fail as if the device were out
  *                             of memory (tests/test_gpu_faults.py: a call still counts every pair exactly once) */
 enum {
@@ -57,7 +60,8 @@ enum {
     LH_OPT_PART_V3_MIN_PAIRS = 13,
     LH_OPT_PART_V3_LOG_W = 14,
     LH_OPT_PART_MIN_PAIRS = 17,
-    LH_OPT_FAIL_SCRATCH_ALLOCS = 19
+    LH_OPT_FAIL_SCRATCH_ALLOCS = 19,
+    LH_OPT_LANE_GEN3 = 20
 };
 
 /* The path choice as a function: what an engine in the described state would do with a call of n pairs.  No device is
@@ -84,6 +88,7 @@ typedef struct lh_dispatch_query {
     uint32_t v2_off, v3_off, hot_off; /* 1 = LH_OPT_PART_V2 / _V3 / LH_OPT_HOT_WINDOWS set to 0 */
     uint32_t v2_shape_set, v2_shape;  /* v2_shape_set = 1: LH_OPT_PART_V2_SHAPE = v2_shape */
     uint32_t fail_allocs;     /* the first this-many scratch allocations fail */
+    uint32_t lane_gen3_off;   /* 1 = LH_OPT_LANE_GEN3 set to 0 */
 } lh_dispatch_query;
 
 typedef struct lh_dispatch_step {
@@ -97,6 +102,16 @@ typedef struct lh_dispatch_step {
 
 /* steps[0 .. *nsteps) in order; at most cap are written, *nsteps receives how many there are. */
 int lh_dispatch_probe(const lh_dispatch_query *q, lh_dispatch_step *steps, size_t cap, size_t *nsteps);
+
+/* Measurement helpers (bench.py; nothing on a product path calls them).
+ * lh_tool_device_alloc / _free: plain hipMalloc'ed memory for a bench's input stream (the allocator the engine's own
+ * buffers come from, not a framework's caching allocator).
+ * lh_tool_read_ceiling: average / minimum time of `reps` launches of a kernel that ONLY reads [d_ptr, d_ptr + bytes) with
+ * k_ingest_single's access pattern (three untimed launches first) -- what this box gives a pure read, measured in the
+ * process that measures the headline.  d_ptr 16-byte aligned, bytes >= 64 KiB. */
+int lh_tool_device_alloc(size_t bytes, void **d_ptr);
+int lh_tool_device_free(void *d_ptr);
+int lh_tool_read_ceiling(const void *d_ptr, size_t bytes, int reps, void *stream, float *avg_ms, float *min_ms);
 
 #ifdef __cplusplus
 }

@@ -55,6 +55,7 @@ OPT_SURVEY_EVERY = 16
 OPT_PART_MIN_PAIRS = 17
 OPT_LANE_SCRATCH_BLOCKS = 18
 OPT_FAIL_SCRATCH_ALLOCS = 19
+OPT_LANE_GEN3 = 20
 
 
 class LhDispatchQuery(C.Structure):
@@ -65,7 +66,8 @@ class LhDispatchQuery(C.Structure):
                 ("regions_disabled", C.c_uint32), ("v3_disabled", C.c_uint32), ("call_log_w", C.c_uint32),
                 ("scratch_cap", C.c_uint64), ("sublaunch_pairs", C.c_uint64), ("part_min_pairs", C.c_uint64),
                 ("v2_min_pairs", C.c_uint64), ("v3_min_pairs", C.c_uint64), ("v2_off", C.c_uint32), ("v3_off", C.c_uint32),
-                ("hot_off", C.c_uint32), ("v2_shape_set", C.c_uint32), ("v2_shape", C.c_uint32), ("fail_allocs", C.c_uint32)]
+                ("hot_off", C.c_uint32), ("v2_shape_set", C.c_uint32), ("v2_shape", C.c_uint32), ("fail_allocs", C.c_uint32),
+                ("lane_gen3_off", C.c_uint32)]
 
 
 class LhDispatchStep(C.Structure):
@@ -110,6 +112,9 @@ _i16p, _u8p = C.POINTER(C.c_int16), C.POINTER(C.c_uint8)
 # name -> (restype, argtypes): the test / tuning hooks of include/loghisto_gpu_tuning.h
 TUNING_SIGNATURES = {
     "lh_dispatch_probe": (C.c_int, [C.POINTER(LhDispatchQuery), C.POINTER(LhDispatchStep), _sz, C.POINTER(_sz)]),
+    "lh_tool_device_alloc": (C.c_int, [_sz, C.POINTER(_vp)]),
+    "lh_tool_device_free": (C.c_int, [_vp]),
+    "lh_tool_read_ceiling": (C.c_int, [_vp, _sz, C.c_int, _vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
 }
 
 # name -> (restype, argtypes): every symbol include/loghisto_gpu.h declares.

@@ -24,6 +24,7 @@ _UNITS = [
     ("lh_kernels_part.hip", ["--offload-arch=gfx950"]),
     ("lh_kernels_small.hip", ["--offload-arch=gfx950"]),
     ("lh_kernels_fmt.hip", ["--offload-arch=gfx950"]),
+    ("lh_tools.hip", ["--offload-arch=gfx950"]),   # measurement helpers (loghisto_gpu_tuning.h): read ceiling, hipMalloc'ed inputs
     ("lh_engine.cc", []),
     ("lh_dispatch.cc", []),         # the mixed ingest's path choice: pure functions (tests/test_dispatch.py)
     ("host/metric_system.cc", []),   # C++ host layer with the reference's MetricSystem API (include/loghisto.hpp)

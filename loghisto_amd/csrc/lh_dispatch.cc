@@ -31,6 +31,23 @@ Step choose_step(const DispatchState &st, uintptr_t ids, uint32_t id_width, uint
     // a lane's half-buffer (read over PCIe in place): first generation -- no tables that outlive the launch -- in a block
     // of the lanes' own, so that its later passes run beside another lane's link-bound read
     if (host_fed && aligned && take <= kLaneBlockMaxPairs && st.lane_blocks) {
+        // Above 8 192 names the first generation's two scatter levels cost a lane-sized launch more GPU time than its
+        // pairs take on the link (65 536 names, 2 M pairs: 0.58 ms against 0.4): the third generation (0.36 ms) runs in the
+        // lane's block too, with the survey's tables -- read-only between surveys -- shared by all lanes.
+        if (st.lane_gen3 && !st.v3_disabled && !st.regions_disabled) {
+            PartTuning t3 = st.tune;
+            t3.v3_log_w = st.call_log_w;
+            const size_t need3 = part3_records_bytes(take, M, st.num_cus, t3);
+            if (need3) {
+                r.kind = PATH_GEN3;
+                r.lane_block = true;
+                r.scratch = need3;
+                r.scratch_alloc = std::max(need3, part3_records_bytes(std::min(kLaneBlockMaxPairs, std::max(take, st.lane_samples)),
+                                                                      M, st.num_cus, t3));
+                r.tune = t3;
+                return r;
+            }
+        }
         const size_t need1 = part_scratch_bytes(take, M, st.num_cus, st.tune);
         if (need1) {
             r.kind = PATH_GEN1;

@@ -9,7 +9,8 @@
 //   GEN2    33 .. 8 192 names, >= 2^25 pairs: survey + region scatter of 2-byte records + reduce (lh_kernels_part2.h)
 //   GEN3    8 193 .. 65 536 names, >= 2^18 pairs: hashed survey + two scatter levels + reduce    (lh_kernels_part3.h)
 //   GEN1    >= 131 072 pairs: partition by name (4-byte records, one or two levels) + reduce     (lh_kernels_part.hip);
-//           also every host-fed lane launch (<= 2^22 pairs) when the lanes have scratch blocks of their own
+//           also a host-fed lane launch (<= 2^22 pairs) over <= 8 192 names when the lanes have scratch blocks of their
+//           own (above 8 192 names such a launch takes GEN3 there, on survey tables the lanes share)
 //   DIRECT  one global atomic per sample: small or misaligned launches, and any launch whose scratch cannot be had
 #pragma once
 
@@ -34,6 +35,8 @@ struct DispatchState {
     bool regions_disabled = false;
     bool v3_disabled = false;
     uint32_t lane_blocks = 0;      // scratch blocks of the host-fed lanes (0: they share the engine's block)
+    bool lane_gen3 = true;         // 8 193 .. 65 536 names: a lane's launch takes the third generation (records in the lane's
+                                   // block, the survey's tables shared by all lanes) instead of the first
     bool scratch_cap_set = false, sublaunch_set = false; // the caller bounded the block: LH_OPT_SCRATCH_CAP_BYTES / _SUBLAUNCH_PAIRS
     size_t scratch_cap = size_t(1536) << 20;
     size_t sublaunch_pairs = size_t(1) << 29;
@@ -49,7 +52,7 @@ struct Step {
     size_t scratch = 0;       // bytes of scratch the launch wrapper needs (0: none)
     size_t scratch_alloc = 0; // what to allocate when the block at hand is smaller (a lane's block is sized once, for the
                               // lanes' largest launch: their launches are all of about one size)
-    bool lane_block = false;  // GEN1 in one of the lanes' own blocks
+    bool lane_block = false;  // in one of the lanes' own blocks: GEN1, or GEN3 with the lanes' shared survey tables
     PartTuning tune;          // the tuning to call the launch wrapper with (adaptive switches and width applied)
 };
 

@@ -258,10 +258,24 @@ struct lh_engine {
         hipEvent_t done = nullptr;
         hipStream_t stream = nullptr;
         bool used = false;
+        int tables_set = -1; // third generation: which of the lanes' table sets its last launch read (-1: none)
     };
     static constexpr uint32_t kAuxBlocks = 8;
     AuxScratch aux[kAuxBlocks];
     uint32_t lane_blocks = kAuxBlocks, aux_next = 0;
+    // Above 8 192 names a lane's launch takes the third generation in its own block (lh_dispatch.h); the survey's tables
+    // are shared by the lanes and only READ between surveys.  Two sets: a survey writes the set that is not in use and
+    // becomes the active one; a set is rewritten only behind the launches that still read it (their blocks' events).
+    struct LaneTables {
+        void *p[2] = {nullptr, nullptr};
+        size_t bytes = 0;
+        lh::SurveyTables t[2];
+        hipEvent_t ready[2] = {nullptr, nullptr};   // recorded behind the launch that surveyed into the set
+        hipStream_t ready_stream[2] = {nullptr, nullptr};
+        int active = 0;
+        uint64_t seen_bad = 0, seen_pairs = 0;
+    } lane_tables;
+    bool lane_gen3 = true;                        // LH_OPT_LANE_GEN3
     size_t scratch_cap = size_t(1536) << 20;     // 1.5 GiB
     bool scratch_cap_set = false, sublaunch_set = false; // lh_set_option was called: the caller's bound wins
     size_t sublaunch_pairs = size_t(1) << 29;
@@ -418,8 +432,61 @@ int run_lane_block(lh_engine *e, EpochBuffer &b, PairsCall &c, const lh::Step &s
         a->bytes = st.scratch_alloc;
     }
     if (a->used && a->stream != s) HIPCHK(hipStreamWaitEvent(s, a->done, 0));
-    HIPCHK(lh::launch_ingest_pairs_part(d_ids, d_v, st.take, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx, e->d_err,
-                                        a->p, a->bytes, e->num_cus, st.tune, s));
+    if (st.kind == lh::PATH_GEN3) {
+        lh_engine::LaneTables &lt = e->lane_tables;
+        if (!lt.p[0]) { // both sets at once, on first use
+            const size_t tb = lh::part3_tables_bytes(e->cfg.max_metrics);
+            void *p0 = nullptr, *p1 = nullptr;
+            if (!tb || !scratch_alloc(e, &p0, tb)) return run_fallback(e, b, d_ids, d_v, st.take, s);
+            if (!scratch_alloc(e, &p1, tb)) { (void)hipFree(p0); return run_fallback(e, b, d_ids, d_v, st.take, s); }
+            lt.p[0] = p0;
+            lt.p[1] = p1;
+            lt.bytes = tb;
+            for (hipEvent_t &ev : lt.ready)
+                if (!ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        }
+        // what the third-generation launches completed since the last look reported (the device-resident calls' and the
+        // lanes' alike: k_v3_report adds to the same pinned words)
+        const uint64_t bad = __atomic_load_n(&e->h_rstat[0], __ATOMIC_RELAXED) + __atomic_load_n(&e->h_rstat[4], __ATOMIC_RELAXED) +
+                             __atomic_load_n(&e->h_rstat[5], __ATOMIC_RELAXED);
+        const uint64_t pairs = __atomic_load_n(&e->h_rstat[6], __ATOMIC_RELAXED);
+        const bool healthy = lh::healthy_share(bad - lt.seen_bad, pairs - lt.seen_pairs);
+        lt.seen_bad = bad;
+        lt.seen_pairs = pairs;
+        int set = lt.active;
+        size_t survey_n = 0;
+        if (lh::survey_reusable(lt.t[set], 3, st.tune.v3_log_w, c.tune_gen, e->survey_every, healthy)) {
+            lt.t[set].age++;
+            e->c_survey_reuse.fetch_add(1, std::memory_order_relaxed);
+            // (the tables are complete once the launch that surveyed them is: another lane's stream waits for that)
+            if (lt.ready_stream[set] != s) HIPCHK(hipStreamWaitEvent(s, lt.ready[set], 0));
+        } else {
+            set ^= 1; // this launch surveys its own pairs into the other set, behind whatever still reads that set
+            for (uint32_t i = 0; i < lh_engine::kAuxBlocks; i++)
+                if (&e->aux[i] != a && e->aux[i].used && e->aux[i].tables_set == set) HIPCHK(hipStreamWaitEvent(s, e->aux[i].done, 0));
+            survey_n = st.take;
+            lt.t[set].valid = true;
+            lt.t[set].gen = 3;
+            lt.t[set].log_w = st.tune.v3_log_w;
+            lt.t[set].tune_gen = c.tune_gen;
+            lt.t[set].age = 1;
+            lt.active = set;
+        }
+        HIPCHK(lh::launch_ingest_pairs_part3(d_ids, d_v, st.take, survey_n, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx,
+                                             e->d_err, a->p, a->bytes, lt.p[set], e->num_cus, st.tune, e->d_rstat,
+                                             e->d_rstat ? reinterpret_cast<uint32_t *>(e->d_rstat + 1) : nullptr, s));
+        a->tables_set = set;
+        if (survey_n) {
+            HIPCHK(hipEventRecord(lt.ready[set], s));
+            lt.ready_stream[set] = s;
+        }
+        e->region_samples.fetch_add(st.take, std::memory_order_relaxed);
+        e->c_part3.fetch_add(st.take, std::memory_order_relaxed);
+    } else {
+        HIPCHK(lh::launch_ingest_pairs_part(d_ids, d_v, st.take, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx, e->d_err,
+                                            a->p, a->bytes, e->num_cus, st.tune, s));
+        a->tables_set = -1;
+    }
     HIPCHK(hipEventRecord(a->done, s));
     a->stream = s;
     a->used = true;
@@ -528,7 +595,7 @@ int run_shared(lh_engine *e, EpochBuffer &b, PairsCall &c, const lh::Step &st, l
             e->c_part2.fetch_add(st.take, std::memory_order_relaxed);
         } else {
             HIPCHK(lh::launch_ingest_pairs_part3(d_ids, d_v, st.take, survey_n, b.counts, b.ranges, e->cfg.max_metrics,
-                                                 e->d_Tx, e->d_err, e->scratch_p, e->scratch_bytes, e->num_cus, st.tune,
+                                                 e->d_Tx, e->d_err, e->scratch_p, e->scratch_bytes, nullptr, e->num_cus, st.tune,
                                                  e->d_rstat, e->d_rstat ? reinterpret_cast<uint32_t *>(e->d_rstat + 1) : nullptr,
                                                  s));
             e->region_samples.fetch_add(st.take, std::memory_order_relaxed);
@@ -554,6 +621,7 @@ void snapshot_dispatch(lh_engine *e, PairsCall &c)
         c.st.tune = e->tune;
         c.tune_gen = e->tune_gen;
         c.st.lane_blocks = e->lane_blocks;
+        c.st.lane_gen3 = e->lane_gen3;
         c.st.scratch_cap = e->scratch_cap;
         c.st.scratch_cap_set = e->scratch_cap_set;
         c.st.sublaunch_pairs = e->sublaunch_pairs;
@@ -707,6 +775,10 @@ void free_engine(lh_engine *e)
         if (a.p) (void)hipFree(a.p);
         if (a.done) (void)hipEventDestroy(a.done);
     }
+    for (void *p : e->lane_tables.p)
+        if (p) (void)hipFree(p);
+    for (hipEvent_t ev : e->lane_tables.ready)
+        if (ev) (void)hipEventDestroy(ev);
     if (e->d_Tx) (void)hipFree(e->d_Tx);
     if (e->d_D) (void)hipFree(e->d_D);
     if (e->d_err) (void)hipFree(e->d_err);
@@ -2290,7 +2362,7 @@ static int set_tune(lh_engine *e, const std::function<void(lh::PartTuning &)> &f
     std::lock_guard<std::mutex> g(e->scratch_mu);
     f(e->tune);
     e->tune_gen++;
-    e->tables.valid = false;
+    e->tables.valid = false; // (the lanes' table sets carry the tune_gen they were planned under: not reused either)
     return LH_OK;
 }
 
@@ -2366,6 +2438,13 @@ int lh_set_option(lh_engine *e, int option, uint64_t value)
         std::lock_guard<std::mutex> g(e->scratch_mu);
         e->survey_every = (uint32_t)value;
         e->tables.valid = false;
+        e->lane_tables.t[0].valid = e->lane_tables.t[1].valid = false;
+        return LH_OK;
+    }
+    case LH_OPT_LANE_GEN3: {
+        if (value > 1) return LH_EINVAL;
+        std::lock_guard<std::mutex> g(e->scratch_mu);
+        e->lane_gen3 = value != 0;
         return LH_OK;
     }
     case LH_OPT_FAIL_SCRATCH_ALLOCS:
@@ -2440,6 +2519,7 @@ int lh_dispatch_probe(const lh_dispatch_query *q, lh_dispatch_step *steps, size_
     st.tune.v3 = !q->v3_off;
     st.tune.hot = !q->hot_off;
     if (q->v2_shape_set) st.tune.v2_shape = q->v2_shape & 3u;
+    st.lane_gen3 = !q->lane_gen3_off;
     uintptr_t ids = (uintptr_t)q->ids_addr, vals = (uintptr_t)q->vals_addr;
     size_t n = (size_t)q->n, k = 0, shared_bytes = 0, lane_bytes = 0;
     uint32_t fail = q->fail_allocs;

@@ -13,7 +13,10 @@
 // (tools/row_stride.hip, profiles/r05_row_stride.jsonl): the reduce passes' atomic flush 275 -> 238 us, the clear
 // 94 -> 66 us, the wave-per-row read 79 -> 74 us with rows 256 bytes further apart; packing the windows tightly buys
 // nothing beyond that.  Exposed to callers that index the device rows themselves as lh_row_stride().
-#define LH_ROW_STRIDE ((size_t)65536 + 32)
+#ifndef LH_ROW_SKEW_CELLS
+#define LH_ROW_SKEW_CELLS 32 /* (tools/build_tuning.py -DLH_ROW_SKEW_CELLS=0: the packed rows of ABI <= 4, for A/B runs) */
+#endif
+#define LH_ROW_STRIDE ((size_t)65536 + LH_ROW_SKEW_CELLS)
 
 namespace lh {
 
@@ -101,9 +104,13 @@ hipError_t launch_ingest_pairs_part2(Ids d_ids, const double *d_v, size_t n, siz
 // Third generation (lh_kernels_part3.h): 8 193 .. 65 536 names.  part3_scratch_bytes returns 0 when the launch should
 // take another path.  span_stat: device-visible word (pinned host memory) that receives the survey's window class.
 size_t part3_scratch_bytes(size_t n, uint32_t nmetrics, int num_cus, const PartTuning &tune);
+// The block in two parts (the host-fed lanes keep the records of their launches in blocks of their own and share one set
+// of survey tables): tables = a function of the name count only; records = the rest.  tables == nullptr below: one block.
+size_t part3_tables_bytes(uint32_t nmetrics);
+size_t part3_records_bytes(size_t n, uint32_t nmetrics, int num_cus, const PartTuning &tune);
 hipError_t launch_ingest_pairs_part3(Ids d_ids, const double *d_v, size_t n, size_t survey_n,
                                      uint64_t *counts, uint32_t *ranges, uint32_t nmetrics, const double *d_Tx,
-                                     uint32_t *d_err, void *scratch, size_t scratch_bytes, int num_cus,
+                                     uint32_t *d_err, void *scratch, size_t scratch_bytes, void *tables, int num_cus,
                                      const PartTuning &tune, unsigned long long *region_stat, uint32_t *span_stat,
                                      hipStream_t s);
 

@@ -1542,7 +1542,7 @@ struct Part3Plan {
     uint32_t region_words, cells, g1, chunks_per_wg, nchunks1, nchunks2;
     size_t lds_dyn;
     size_t off_stat, off_aux, off_hk, off_hs, off_hdr, off_pt, off_remap, off_inv, off_pt2;
-    size_t off_rec1, off_cd1, off_sorted1, off_small1, off_rec2, off_cd2, off_sorted2, off_small2, total;
+    size_t off_rec1, off_cd1, off_sorted1, off_small1, off_rec2, off_cd2, off_sorted2, off_small2, off_gstats, total;
 };
 
 static bool make_plan3(size_t n, uint32_t nmetrics, int num_cus, const PartTuning &tune, Part3Plan &P)
@@ -1603,6 +1603,7 @@ static bool make_plan3(size_t n, uint32_t nmetrics, int num_cus, const PartTunin
     P.off_cd2 = take((size_t)P.nchunks2 * sizeof(uint32_t));
     P.off_sorted2 = take((size_t)P.nchunks2 * sizeof(uint32_t));
     P.off_small2 = take(small_words(P.nq, P.extra2) * sizeof(uint32_t));
+    P.off_gstats = take(64); // the launch's self-metrics: with the records, not with the tables (launches may share tables)
     P.total = o;
     return true;
 }
@@ -1613,17 +1614,36 @@ size_t part3_scratch_bytes(size_t n, uint32_t nmetrics, int num_cus, const PartT
     return make_plan3(n, nmetrics, num_cus, tune, P) ? P.total : 0;
 }
 
+// The block in two parts: the survey's tables (everything before the level-1 records: a function of the name count
+// only) and the launch's own records, descriptors and plans.  Launches that keep their records in blocks of their own
+// can share ONE set of tables read-only (the host-fed lanes: lh_engine's LaneTables).
+size_t part3_tables_bytes(uint32_t nmetrics)
+{
+    Part3Plan P;
+    PartTuning t;
+    return make_plan3(V3_MIN_SAMPLES, nmetrics, 256, t, P) ? P.off_rec1 : 0;
+}
+
+size_t part3_records_bytes(size_t n, uint32_t nmetrics, int num_cus, const PartTuning &tune)
+{
+    Part3Plan P;
+    return make_plan3(n, nmetrics, num_cus, tune, P) ? P.total - P.off_rec1 : 0;
+}
+
 // survey_n / region_stat: as launch_ingest_pairs_part2.  span_stat: device-visible word (pinned host memory) that
-// receives the survey's window-width class, or null.
+// receives the survey's window-width class, or null.  tables: null = the survey's tables are the first part3_tables_bytes
+// of `scratch`; otherwise they live THERE (part3_tables_bytes large) and `scratch` holds only the launch's own
+// part3_records_bytes.
 template <typename IDT>
 static hipError_t launch_part3_t(const IDT *d_ids, const double *d_v, size_t n, size_t survey_n,
                                      uint64_t *counts, uint32_t *ranges, uint32_t nmetrics, const double *d_Tx,
-                                     uint32_t *d_err, void *scratch, size_t scratch_bytes, int num_cus,
+                                     uint32_t *d_err, void *scratch, size_t scratch_bytes, void *tables, int num_cus,
                                      const PartTuning &tune, unsigned long long *region_stat, uint32_t *span_stat,
                                      hipStream_t s)
 {
     Part3Plan P;
-    if (!make_plan3(n, nmetrics, num_cus, tune, P) || scratch_bytes < P.total || !scratch) return hipErrorInvalidValue;
+    if (!make_plan3(n, nmetrics, num_cus, tune, P) || !scratch) return hipErrorInvalidValue;
+    if (scratch_bytes < (tables ? P.total - P.off_rec1 : P.total)) return hipErrorInvalidValue;
     if (!part_aligned(d_ids, d_v)) return hipErrorInvalidValue;
     static std::atomic<bool> attr_set{false}; // benign if two threads race: both set the same attributes
     if (!attr_set) {
@@ -1650,9 +1670,12 @@ static hipError_t launch_part3_t(const IDT *d_ids, const double *d_v, size_t n, 
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    unsigned char *base = static_cast<unsigned char *>(scratch);
-    const LevelPtrs L1 = level_ptrs(base, P.off_rec1, P.off_cd1, P.off_sorted1, P.off_small1, V3_NP, P.extra1);
-    const LevelPtrs L2 = level_ptrs(base, P.off_rec2, P.off_cd2, P.off_sorted2, P.off_small2, P.nq, P.extra2);
+    // base: where the offsets of the tables apply; rec + (offset - r0): the records' part
+    unsigned char *base = static_cast<unsigned char *>(tables ? tables : scratch);
+    unsigned char *rec = static_cast<unsigned char *>(scratch);
+    const size_t r0 = tables ? P.off_rec1 : 0;
+    const LevelPtrs L1 = level_ptrs(rec, P.off_rec1 - r0, P.off_cd1 - r0, P.off_sorted1 - r0, P.off_small1 - r0, V3_NP, P.extra1);
+    const LevelPtrs L2 = level_ptrs(rec, P.off_rec2 - r0, P.off_cd2 - r0, P.off_sorted2 - r0, P.off_small2 - r0, P.nq, P.extra2);
     unsigned long long *g_cs = reinterpret_cast<unsigned long long *>(base + P.off_stat);
     uint32_t *g_mninv = reinterpret_cast<uint32_t *>(g_cs + nmetrics), *g_mx = g_mninv + nmetrics;
     const SurveyStat S{g_cs, g_mninv, g_mx};
@@ -1660,7 +1683,7 @@ static hipError_t launch_part3_t(const IDT *d_ids, const double *d_v, size_t n, 
     pu2_t *g_hk = reinterpret_cast<pu2_t *>(base + P.off_hk);
     pu4_t *g_hs = reinterpret_cast<pu4_t *>(base + P.off_hs);
     uint32_t *g_hdr = reinterpret_cast<uint32_t *>(base + P.off_hdr);
-    uint32_t *g_stats = g_hdr + 8; // self-metrics of the launch (zeroed below, read and zeroed by k_v3_report)
+    uint32_t *g_stats = reinterpret_cast<uint32_t *>(rec + (P.off_gstats - r0)); // self-metrics of the launch (zeroed below, read and zeroed by k_v3_report)
     pu2_t *g_pt = reinterpret_cast<pu2_t *>(base + P.off_pt);
     uint8_t *g_remap = base + P.off_remap, *g_inv = base + P.off_inv;
     pu2_t *g_pt2 = reinterpret_cast<pu2_t *>(base + P.off_pt2);
@@ -1713,12 +1736,12 @@ static hipError_t launch_part3_t(const IDT *d_ids, const double *d_v, size_t n, 
 
 hipError_t launch_ingest_pairs_part3(Ids d_ids, const double *d_v, size_t n, size_t survey_n,
                                      uint64_t *counts, uint32_t *ranges, uint32_t nmetrics, const double *d_Tx,
-                                     uint32_t *d_err, void *scratch, size_t scratch_bytes, int num_cus,
+                                     uint32_t *d_err, void *scratch, size_t scratch_bytes, void *tables, int num_cus,
                                      const PartTuning &tune, unsigned long long *region_stat, uint32_t *span_stat,
                                      hipStream_t s)
 {
     return d_ids.width == 2 ? launch_part3_t(d_ids.u16(), d_v, n, survey_n, counts, ranges, nmetrics, d_Tx, d_err, scratch,
-                                             scratch_bytes, num_cus, tune, region_stat, span_stat, s)
+                                             scratch_bytes, tables, num_cus, tune, region_stat, span_stat, s)
                             : launch_part3_t(d_ids.u32(), d_v, n, survey_n, counts, ranges, nmetrics, d_Tx, d_err, scratch,
-                                             scratch_bytes, num_cus, tune, region_stat, span_stat, s);
+                                             scratch_bytes, tables, num_cus, tune, region_stat, span_stat, s);
 }

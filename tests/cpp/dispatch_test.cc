@@ -107,7 +107,13 @@ static void test_choose_step_grid()
                                     CHECK(M >= 8193 && M <= 65536 && s.take >= (size_t(1) << 18) && !st.v3_disabled && !st.regions_disabled);
                                 if (s.kind == lh::PATH_GEN1) CHECK(M >= 2 && M <= 65536 && (M >= 33 || st.small_disabled) && s.take >= 131072);
                                 if (s.kind == lh::PATH_DIRECT) CHECK(s.take == (n < lh::kMaxLaunchPairs ? n : lh::kMaxLaunchPairs));
-                                if (s.lane_block) CHECK(host_fed && s.kind == lh::PATH_GEN1 && s.take <= lh::kLaneBlockMaxPairs);
+                                // a lane's block: the first generation up to 8 192 names, the third above (while neither
+                                // adaptive switch has it off)
+                                if (s.lane_block)
+                                    CHECK(host_fed && s.take <= lh::kLaneBlockMaxPairs &&
+                                          (s.kind == lh::PATH_GEN1 || (s.kind == lh::PATH_GEN3 && M > 8192)));
+                                if (s.lane_block && M > 8192 && s.take >= (size_t(1) << 18) && !st.v3_disabled && !st.regions_disabled)
+                                    CHECK(s.kind == lh::PATH_GEN3);
                                 if (host_fed && s.kind >= lh::PATH_GEN1 && s.take <= lh::kLaneBlockMaxPairs) CHECK(s.lane_block);
                                 // a bounded block: above the floor no sub-launch asks for more than the cap
                                 if (bound == 1 && s.kind >= lh::PATH_GEN1 && !s.lane_block && s.take > (M > 8192 ? size_t(1) << 28 : size_t(1) << 24))

@@ -105,8 +105,14 @@ def test_alignment(native_lib):
 def test_host_fed_lane_launches(native_lib):
     for names in (1024, 20000, 65536):
         s = probe(native_lib, max_metrics=names, n=1 << 20, host_fed=1, lane_blocks=8)
-        assert [(x.path, x.lane_block) for x in s] == [(GEN1, 1)]            # a half-buffer: first generation, a lane's block
+        # a half-buffer in a lane's block: first generation up to 8 192 names, third above (tables shared by the lanes)
+        assert [(x.path, x.lane_block) for x in s] == [(GEN1 if names <= 8192 else GEN3, 1)]
         assert s[0].scratch <= (64 << 20) or names > 8192
+        s = probe(native_lib, max_metrics=names, n=1 << 20, host_fed=1, lane_blocks=8, lane_gen3_off=1)
+        assert [(x.path, x.lane_block) for x in s] == [(GEN1, 1)]            # LH_OPT_LANE_GEN3 = 0: as up to ABI 4
+        for off in ({"v3_disabled": 1}, {"regions_disabled": 1}, {"v3_off": 1}):
+            s = probe(native_lib, max_metrics=names, n=1 << 20, host_fed=1, lane_blocks=8, **off)
+            assert [(x.path, x.lane_block) for x in s] == [(GEN1, 1)]
         s = probe(native_lib, max_metrics=names, n=1 << 20, host_fed=1, lane_blocks=0)
         assert not s[0].lane_block                                           # no lane blocks: the shared block's rules
         s = probe(native_lib, max_metrics=names, n=(1 << 22) + 2, host_fed=1, lane_blocks=8)

@@ -172,3 +172,22 @@ def test_host_fed_lanes_keep_every_pair_and_no_lane_stays_reserved(native_lib, t
         with e.flip() as snap:
             got = snap.extract(PCTS, M)
             assert int(got["count"][7]) == 64 and int(got["count"].sum()) == 64
+
+
+def test_lane_tables_that_cannot_be_had(native_lib, torch_cuda):
+    """65 536 names from the host: the first lane launch needs its block AND the lanes' two table sets (third generation);
+    with any of the three allocations failing the half-buffer goes through the direct kernel, and the next one tries again."""
+    import loghisto_amd
+    M, per = 65536, 1 << 18
+    ids, v = _stream(M, 4 * per, 5)
+    ids16 = ids.astype(np.uint16)
+    for fail in (1, 2, 3):
+        with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=per) as e:
+            e.set_option(N.OPT_FAIL_SCRATCH_ALLOCS, fail)
+            e.submit_pairs(ids16, v)
+            e.sync()
+            c = e.counters()
+            assert c["scratch_alloc_failures"] == fail and c["samples_fallback"] >= per, c
+            assert c["samples_partitioned_v3"] >= per and c["samples_partitioned_v3"] + c["samples_fallback"] == 4 * per, c
+            with e.flip() as snap:
+                _check(snap, ids, v, M)

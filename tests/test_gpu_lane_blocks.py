@@ -1,6 +1,7 @@
 """Host-fed mixed launches in the lanes' own scratch blocks (LH_OPT_LANE_SCRATCH_BLOCKS): lanes of several threads launch
-concurrently, each launch partitioned (first generation) in its own block -- every cell of every row against the oracle,
-with the blocks on (default) and off (the engine's one shared block), for both name-count classes and both id widths.
+concurrently, each launch partitioned in its own block (first generation up to 8 192 names; above, the third generation
+on survey tables the lanes share: LH_OPT_LANE_GEN3) -- every cell of every row against the oracle, with the blocks on
+(default) and off (the engine's one shared block), for both name-count classes and both id widths.
 Semantics: metrics.go:273-295 (lossless, one increment per sample whatever thread submitted it)."""
 import os
 import sys
@@ -104,7 +105,66 @@ def test_device_resident_launches_keep_the_shared_block(la, torch_cuda):
         want = calls * np.bincount(ids, minlength=M) + lanes.count * np.bincount(ids[:200_000], minlength=M)
         assert np.array_equal(got, want)
         c = eng.counters()
-        assert c["scratch_bytes"] > 0 and c["samples_partitioned_v3"] == calls * n
+        # (the lanes' own launches over this many names are third-generation launches too, on table sets of their own)
+        assert c["scratch_bytes"] > 0 and c["samples_partitioned_v3"] >= calls * n
         assert c["surveys_reused"] >= calls - 4                        # the lanes did not end the survey's reuse
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("gen3", [1, 0])
+def test_lanes_over_many_names_share_survey_tables(la, gen3):
+    """65 536 names from four producer threads: every half-buffer (262 144 pairs) is a third-generation launch whose
+    records live in the lane's own block while the survey's tables are shared, read-only, by all lanes -- two sets: a
+    launch that finds the active set used up (LH_OPT_SURVEY_EVERY) surveys its own pairs into the OTHER set while the
+    launches in flight keep reading the old one.  Half way the stream changes (other names frequent, values a million
+    times larger): the launches that still run on the old survey are slower, never wrong.  Every occupied cell of every
+    row against the oracle; LH_OPT_LANE_GEN3 = 0 is the first generation as before."""
+    from loghisto_amd import _native as N
+    M, T, batches, per = 65536, 4, 12, 1 << 18
+    rng = np.random.default_rng(77 + gen3)
+    w = 1.0 / np.arange(1, M + 1)
+    ids, vals = [], []
+    for t in range(T):
+        a = rng.choice(M, per * batches, p=w / w.sum()).astype(np.uint16)
+        v = rng.lognormal(np.log(1e5), 1.0, per * batches)
+        half = per * batches // 2
+        a[half:] = (M - 1) - a[half:]                    # the ranking reversed ...
+        v[half:] *= 1e6                                   # ... and every window somewhere else
+        ids.append(a)
+        vals.append(v)
+    eng = la.Engine(max_metrics=M, num_buffers=2, num_lanes=4, lane_samples=per)
+    try:
+        eng.set_option(N.OPT_LANE_GEN3, gen3)
+        eng.set_option(N.OPT_SURVEY_EVERY, 8)             # several surveys, into alternating sets, during the run
+        errors = []
+
+        def work(t):
+            try:
+                for k in range(batches):
+                    eng.submit_pairs_in_place(ids[t][k * per:(k + 1) * per], vals[t][k * per:(k + 1) * per])
+            except Exception as exc:  # noqa: BLE001
+                errors.append(exc)
+
+        th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+        [x.start() for x in th]
+        [x.join() for x in th]
+        assert not errors, errors
+        eng.sync()
+        c = eng.counters()
+        total = T * batches * per
+        if gen3:
+            assert c["samples_partitioned_v3"] == total and c["surveys_reused"] >= T * batches // 2, c
+        else:
+            assert c["samples_partitioned_v3"] == 0 and c["samples_partitioned"] == total, c
+        assert c["scratch_bytes"] == 0 and c["samples_fallback"] == 0, c   # the shared block was never needed
+        all_ids, all_v = np.concatenate(ids).astype(np.uint64), np.concatenate(vals)
+        bins = oracle.key_to_bin(oracle.compress_many(all_v)).astype(np.uint64)
+        want_cells, want_counts = np.unique((all_ids << np.uint64(16)) | bins, return_counts=True)
+        with eng.flip() as snap:
+            off, keys, counts = snap.buckets_all(M)
+        rows = np.repeat(np.arange(M, dtype=np.uint64), np.diff(off.astype(np.int64)))
+        cells = (rows << np.uint64(16)) | oracle.key_to_bin(keys).astype(np.uint64)
+        assert np.array_equal(cells, want_cells) and np.array_equal(counts.astype(np.int64), want_counts)
     finally:
         eng.close()

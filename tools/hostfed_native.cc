@@ -7,8 +7,9 @@
 // (lh_reserve_pairs16 / lh_reserve_pairs), stores its pairs there -- the one host-side copy -- and commits.
 // Checked: per-name counts of the interval against the generator's own counts.  Prints one JSON line per form.
 //
-//   usage: hostfed_native [threads=16] [pairs=8e8] [names=1024] [batch=1048576]
-#include "loghisto_gpu.h"
+//   usage: hostfed_native [threads=16] [pairs=8e8] [names=1024] [batch=1048576] [lane_gen3=1]
+//   (lane_gen3 = 0: the lanes' launches over more than 8 192 names take the first generation, as up to ABI 4)
+#include "loghisto_gpu_tuning.h"
 
 #include <atomic>
 #include <chrono>
@@ -26,6 +27,8 @@ static void die(const char *what, int rc)
     std::exit(1);
 }
 
+static int g_lane_gen3 = 1;
+
 template <typename IDT> static double run(uint32_t T, size_t total, uint32_t M, size_t batch, const std::vector<uint32_t> &ids,
                                           const std::vector<double> &vals, bool *exact)
 {
@@ -38,6 +41,7 @@ template <typename IDT> static double run(uint32_t T, size_t total, uint32_t M, 
     lh_engine *e = nullptr;
     int rc = lh_create(&cfg, &e);
     if (rc) die("lh_create", rc);
+    if ((rc = lh_set_option(e, LH_OPT_LANE_GEN3, (uint64_t)g_lane_gen3))) die("lh_set_option", rc);
     std::vector<IDT> nid(ids.begin(), ids.end()); // the producer's own id array in the width it ships
     const size_t per = total / T;
     auto put = [&](size_t off, size_t n) {
@@ -109,6 +113,7 @@ int main(int argc, char **argv)
     const size_t total = argc > 2 ? (size_t)std::atof(argv[2]) : (size_t)8e8;
     const uint32_t M = argc > 3 ? (uint32_t)std::atoi(argv[3]) : 1024u;
     const size_t batch = argc > 4 ? (size_t)std::atoll(argv[4]) : (size_t)1 << 20;
+    g_lane_gen3 = argc > 5 ? std::atoi(argv[5]) : 1;
     const size_t N = (size_t)1 << 24;
     std::vector<uint32_t> ids(N);
     std::vector<double> vals(N);
@@ -129,9 +134,9 @@ int main(int argc, char **argv)
                                       : run<uint32_t>(T, total, M, batch, ids, vals, &exact);
         const double bytes = form == 0 ? 10.0 : 12.0;
         std::printf("{\"what\": \"host-fed pairs from native threads, in place (%s)\", \"threads\": %u, \"pairs\": %zu, \"names\": %u, "
-                    "\"pairs_per_s\": %.4g, \"GBps_over_pcie\": %.2f, \"frac_of_63GBps\": %.4f, \"per_name_counts_exact\": %s}\n",
+                    "\"lane_gen3\": %d, \"pairs_per_s\": %.4g, \"GBps_over_pcie\": %.2f, \"frac_of_63GBps\": %.4f, \"per_name_counts_exact\": %s}\n",
                     form == 0 ? "lh_reserve_pairs16, uint16 ids, 10 B per pair" : "lh_reserve_pairs, uint32 ids, 12 B per pair", T,
-                    total / T * T, M, rate, rate * bytes / 1e9, rate * bytes / 1e9 / 63.0, exact ? "true" : "false");
+                    total / T * T, M, g_lane_gen3, rate, rate * bytes / 1e9, rate * bytes / 1e9 / 63.0, exact ? "true" : "false");
         std::fflush(stdout);
     }
     return 0;

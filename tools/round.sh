@@ -9,6 +9,7 @@
 #                           timed with the product library and with every build/liblhgpu_tuning_<suffix>.so
 #                           (tools/build_tuning.py -D... --name <suffix>), then the product's kernel split
 #   abl <tag> <suffix,...>  timing of ablation builds (wrong counts by construction) + tools/row_stride.hip
+#   lanes <tag>             host-fed path: tests + tools/hostfed_native.cc at 1 024 / 65 536 names (LH_OPT_LANE_GEN3 on / off)
 #   tests <tag> [pytest args]   the GPU suite (or a part of it) + smoke()
 #   profile <tag>           the round's evidence: tools/profile_round.sh (bench lines, kernel traces, PMC passes)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -56,8 +57,29 @@ abl)    # abl <tag> <suffix,...>: timing only (sweep.py --nocheck) of ablation b
     ;;
 tests)
     (timeout 2400 python -m pytest tests -m gpu -x -q "$@") > $OUT/pytest.log 2>&1
-    tail -6 $OUT/pytest.log | cut -c1-300
+    tail -6 $OUT/pytest.log | cut -c1-300; grep -E "^(FAILED|ERROR)|Error|assert" $OUT/pytest.log | head -20 | cut -c1-300
     (timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')") 2>&1 | tail -2 | tee $OUT/smoke.log
+    ;;
+tests_ab)   # tests_ab <tag> <suffix,...>: the GPU suite, then the ab timings (one call instead of two)
+    (timeout 2400 python -m pytest tests -m gpu -x -q) > $OUT/pytest.log 2>&1
+    tail -6 $OUT/pytest.log | cut -c1-300; grep -E "^(FAILED|ERROR)|Error|assert" $OUT/pytest.log | head -20 | cut -c1-300
+    for sfx in "" $(echo ${1:-} | tr ',' ' '); do
+        lib=""; [ -n "$sfx" ] && lib="--lib loghisto_amd/build/liblhgpu_tuning_$sfx.so"
+        echo "== ${sfx:-product}" | tee -a $OUT/ab.txt
+        sweep 1.25e8 65536 24 --dists lognormal $lib | tee -a $OUT/ab.txt
+        sweep 1e9 65536 5 --dists lognormal $lib | tee -a $OUT/ab.txt
+        sweep 1e9 1024 6 --dists lognormal,kvalues8 $lib | tee -a $OUT/ab.txt
+    done
+    ktrace 1.25e8 65536 $OUT/trace_slice.txt
+    ktrace 1e9 1024 $OUT/trace_c3.txt
+    ;;
+lanes)  # lanes <tag>: the host-fed path: its tests, then native producer threads at 1 024 and 65 536 names, the lanes'
+        # third-generation launches on and off
+    (timeout 1500 python -m pytest tests/test_gpu_lane_blocks.py tests/test_gpu_faults.py tests/test_gpu_pairs16.py -x -q) > $OUT/pytest.log 2>&1
+    tail -4 $OUT/pytest.log | cut -c1-300; grep -E "^(FAILED|ERROR)|Error|assert" $OUT/pytest.log | head -20 | cut -c1-300
+    for args in "16 8e8 1024 1048576 1" "16 8e8 65536 1048576 1" "16 8e8 65536 1048576 0" "8 8e8 65536 1048576 1" "16 8e8 65536 2097152 1" "16 8e8 20000 1048576 1"; do
+        loghisto_amd/build/hostfed_native $args 2>&1 | cut -c1-330 | tee -a $OUT/hostfed_native.jsonl
+    done
     ;;
 profile)
     bash tools/profile_round.sh $TAG "$@"
