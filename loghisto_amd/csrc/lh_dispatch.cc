@@ -37,6 +37,7 @@ Step choose_step(const DispatchState &st, uintptr_t ids, uint32_t id_width, uint
         if (st.lane_gen3 && !st.v3_disabled && !st.regions_disabled) {
             PartTuning t3 = st.tune;
             t3.v3_log_w = st.call_log_w;
+            t3.v3_g1_cap = st.lane_g1_cap;
             const size_t need3 = part3_records_bytes(take, M, st.num_cus, t3);
             if (need3) {
                 r.kind = PATH_GEN3;

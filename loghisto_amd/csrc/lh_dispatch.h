@@ -23,6 +23,10 @@ namespace lh {
 
 enum PathKind : uint32_t { PATH_DIRECT = 0, PATH_SMALL = 1, PATH_GEN1 = 2, PATH_GEN2 = 3, PATH_GEN3 = 4 };
 
+constexpr size_t kMaxLaunchPairs = size_t(1) << 30;   // one launch: LDS counters and record indices stay below 2^32
+constexpr size_t kLaneBlockMaxPairs = size_t(1) << 22; // larger host-fed launches amortise their passes: the shared block
+constexpr uint32_t kLaneLevel1Workgroups = 8;          // a lane's third-generation launch: level-1 workgroups (PartTuning::v3_g1_cap)
+
 // What the choice reads.  lh_engine fills it once per call (under its scratch lock: every option that feeds a launch
 // plan is written under that lock).
 struct DispatchState {
@@ -37,13 +41,12 @@ struct DispatchState {
     uint32_t lane_blocks = 0;      // scratch blocks of the host-fed lanes (0: they share the engine's block)
     bool lane_gen3 = true;         // 8 193 .. 65 536 names: a lane's launch takes the third generation (records in the lane's
                                    // block, the survey's tables shared by all lanes) instead of the first
+    uint32_t lane_g1_cap = kLaneLevel1Workgroups; // ... with at most this many level-1 workgroups
     bool scratch_cap_set = false, sublaunch_set = false; // the caller bounded the block: LH_OPT_SCRATCH_CAP_BYTES / _SUBLAUNCH_PAIRS
     size_t scratch_cap = size_t(1536) << 20;
     size_t sublaunch_pairs = size_t(1) << 29;
 };
 
-constexpr size_t kMaxLaunchPairs = size_t(1) << 30;   // one launch: LDS counters and record indices stay below 2^32
-constexpr size_t kLaneBlockMaxPairs = size_t(1) << 22; // larger host-fed launches amortise their passes: the shared block
 
 // One sub-launch: the first `take` of the n pairs at (ids, vals).
 struct Step {

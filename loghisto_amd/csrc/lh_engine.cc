@@ -258,14 +258,13 @@ struct lh_engine {
         hipEvent_t done = nullptr;
         hipStream_t stream = nullptr;
         bool used = false;
-        int tables_set = -1; // third generation: which of the lanes' table sets its last launch read (-1: none)
     };
-    static constexpr uint32_t kAuxBlocks = 8;
+    static constexpr uint32_t kAuxBlocks = 16;
     AuxScratch aux[kAuxBlocks];
-    uint32_t lane_blocks = kAuxBlocks, aux_next = 0;
+    uint32_t lane_blocks = 8, aux_next = 0;       // (LH_OPT_LANE_SCRATCH_BLOCKS: up to kAuxBlocks)
     // Above 8 192 names a lane's launch takes the third generation in its own block (lh_dispatch.h); the survey's tables
     // are shared by the lanes and only READ between surveys.  Two sets: a survey writes the set that is not in use and
-    // becomes the active one; a set is rewritten only behind the launches that still read it (their blocks' events).
+    // becomes the active one; a set is rewritten only behind every lane launch in flight (the blocks' events).
     struct LaneTables {
         void *p[2] = {nullptr, nullptr};
         size_t bytes = 0;
@@ -276,6 +275,7 @@ struct lh_engine {
         uint64_t seen_bad = 0, seen_pairs = 0;
     } lane_tables;
     bool lane_gen3 = true;                        // LH_OPT_LANE_GEN3
+    uint32_t lane_g1_cap = lh::kLaneLevel1Workgroups;
     size_t scratch_cap = size_t(1536) << 20;     // 1.5 GiB
     bool scratch_cap_set = false, sublaunch_set = false; // lh_set_option was called: the caller's bound wins
     size_t sublaunch_pairs = size_t(1) << 29;
@@ -461,9 +461,14 @@ int run_lane_block(lh_engine *e, EpochBuffer &b, PairsCall &c, const lh::Step &s
             // (the tables are complete once the launch that surveyed them is: another lane's stream waits for that)
             if (lt.ready_stream[set] != s) HIPCHK(hipStreamWaitEvent(s, lt.ready[set], 0));
         } else {
-            set ^= 1; // this launch surveys its own pairs into the other set, behind whatever still reads that set
+            // This launch surveys its own pairs into the OTHER set, behind whatever may still read that set: every block's
+            // last launch -- not only those that read this set themselves: a block's launches run one behind the other, and
+            // an earlier launch that reads the set may still be running under a later one that does not (with 16 lanes on
+            // 8 blocks and two surveys in quick succession that lost counts once in ten runs).  A survey is one launch in
+            // `survey_every`: the bubble does not show.
+            set ^= 1;
             for (uint32_t i = 0; i < lh_engine::kAuxBlocks; i++)
-                if (&e->aux[i] != a && e->aux[i].used && e->aux[i].tables_set == set) HIPCHK(hipStreamWaitEvent(s, e->aux[i].done, 0));
+                if (&e->aux[i] != a && e->aux[i].used) HIPCHK(hipStreamWaitEvent(s, e->aux[i].done, 0));
             survey_n = st.take;
             lt.t[set].valid = true;
             lt.t[set].gen = 3;
@@ -475,7 +480,6 @@ int run_lane_block(lh_engine *e, EpochBuffer &b, PairsCall &c, const lh::Step &s
         HIPCHK(lh::launch_ingest_pairs_part3(d_ids, d_v, st.take, survey_n, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx,
                                              e->d_err, a->p, a->bytes, lt.p[set], e->num_cus, st.tune, e->d_rstat,
                                              e->d_rstat ? reinterpret_cast<uint32_t *>(e->d_rstat + 1) : nullptr, s));
-        a->tables_set = set;
         if (survey_n) {
             HIPCHK(hipEventRecord(lt.ready[set], s));
             lt.ready_stream[set] = s;
@@ -485,7 +489,6 @@ int run_lane_block(lh_engine *e, EpochBuffer &b, PairsCall &c, const lh::Step &s
     } else {
         HIPCHK(lh::launch_ingest_pairs_part(d_ids, d_v, st.take, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx, e->d_err,
                                             a->p, a->bytes, e->num_cus, st.tune, s));
-        a->tables_set = -1;
     }
     HIPCHK(hipEventRecord(a->done, s));
     a->stream = s;
@@ -622,6 +625,7 @@ void snapshot_dispatch(lh_engine *e, PairsCall &c)
         c.tune_gen = e->tune_gen;
         c.st.lane_blocks = e->lane_blocks;
         c.st.lane_gen3 = e->lane_gen3;
+        c.st.lane_g1_cap = e->lane_g1_cap;
         c.st.scratch_cap = e->scratch_cap;
         c.st.scratch_cap_set = e->scratch_cap_set;
         c.st.sublaunch_pairs = e->sublaunch_pairs;
@@ -2442,9 +2446,11 @@ int lh_set_option(lh_engine *e, int option, uint64_t value)
         return LH_OK;
     }
     case LH_OPT_LANE_GEN3: {
-        if (value > 1) return LH_EINVAL;
+        if (value > 256) return LH_EINVAL; // 0 off, 1 on, 2 .. 256: on, with that many level-1 workgroups per launch (tuning runs)
         std::lock_guard<std::mutex> g(e->scratch_mu);
         e->lane_gen3 = value != 0;
+        e->lane_g1_cap = value > 1 ? (uint32_t)value : lh::kLaneLevel1Workgroups;
+        e->lane_tables.t[0].valid = e->lane_tables.t[1].valid = false;
         return LH_OK;
     }
     case LH_OPT_FAIL_SCRATCH_ALLOCS:

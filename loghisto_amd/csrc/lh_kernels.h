@@ -67,6 +67,11 @@ struct PartTuning {
     bool v3 = true;                 // hashed survey + region scatter + in-place second level (lh_kernels_part3.h) for 8 193 .. 65 536 names
     size_t v3_min_samples = 0;      // 0 = default (2^24)
     uint32_t v3_log_w = 10;         // log2 of the second level's window width, 10 .. 13: the engine follows the survey's report
+    uint32_t v3_g1_cap = 0;         // third generation: at most this many level-1 workgroups (0 = one per CU).  A host-fed
+                                    // launch reads its pairs over PCIe: 8 workgroups keep 0.6 MB in flight, several times
+                                    // what the link's latency needs, and every level-1 workgroup owns its CU's whole LDS --
+                                    // CUs the other lanes' later passes can use instead (measured 8 / 16 / 32 / 256:
+                                    // profiles/r05_hostfed_native.jsonl)
 };
 
 // Partitioned mixed ingest (lh_kernels_part.hip).  part_scratch_bytes returns 0 when the launch

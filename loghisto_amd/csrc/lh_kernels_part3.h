@@ -1313,7 +1313,7 @@ __global__ __launch_bounds__(1024, 4) void k_split_waves(const uint32_t *__restr
 // Reduce: one workgroup per fine-partition work slot.  Fine partition q = fine << 8 | p1 holds the names of ranks
 // fine * mpp2 .. + mpp2 - 1 of level-1 partition p1; record = fine << 24 | rank % mpp2 << 16 | bin.
 // ---------------------------------------------------------------------------
-constexpr size_t P3_LDS_BYTES = (P3_WINWORDS + 6 * 32 + 2 * OV_SLOTS) * sizeof(uint32_t) + 16;
+constexpr size_t P3_LDS_BYTES = (P3_WINWORDS + 6 * 32 + 2 * OV_SLOTS + 2) * sizeof(uint32_t) + 16;
 
 __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restrict__ records,
                                                          const uint32_t *__restrict__ cdesc,
@@ -1332,6 +1332,7 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
     uint32_t *s_org = h + P3_WINWORDS, *s_mn = s_org + 32, *s_mx = s_mn + 32, *s_name = s_mx + 32, *s_svc = s_name + 32,
              *s_svm = s_svc + 32;
     uint32_t *ov_key = s_svm + 32, *ov_cnt = ov_key + OV_SLOTS;
+    uint32_t *s_all = ov_cnt + OV_SLOTS; // [2]: lowest and highest bin of the slot's first chunk, whatever the name
     const uint32_t slot = blockIdx.x;
     if (slot >= *nslots) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1381,21 +1382,40 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
         s_mn[tid] = INVALID;
         s_mx[tid] = 0;
     }
+    if (tid == 0) { s_all[0] = INVALID; s_all[1] = 0; }
     __syncthreads();
     // windows from the slot's own records (what reaches this pass may be the tail that a level-2 window left over);
-    // a name the first chunk does not hold falls back to what the survey saw of it
-    if (tid < n0) {
-        const uint32_t l = (srec >> 16) & 0xffu, b = srec & 0xffffu;
-        if (b < s_mn[l]) atomicMin(&s_mn[l], b);
-        if (b > s_mx[l]) atomicMax(&s_mx[l], b);
+    // a name the first chunk does not hold falls back to what the survey saw of it, and a name neither of them knows
+    // -- the rule on a small launch: a lane-sized one over 65 536 names gives a tail name half a dozen records, the
+    // survey's sample none -- to where the slot's OTHER names have their values (names of one stream mostly live in the
+    // same decades; a window around key 0 sent 20 % of such a launch's forwarded records to the miss path)
+    {
+        uint32_t lo = INVALID, hi = 0;
+        if (tid < n0) {
+            const uint32_t l = (srec >> 16) & 0xffu, b = srec & 0xffffu;
+            if (b < s_mn[l]) atomicMin(&s_mn[l], b);
+            if (b > s_mx[l]) atomicMax(&s_mx[l], b);
+            lo = hi = b;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            lo = min(lo, (uint32_t)__shfl_xor(lo, d, 64));
+            hi = max(hi, (uint32_t)__shfl_xor(hi, d, 64));
+        }
+        if (lane == 0 && lo != INVALID) { atomicMin(&s_all[0], lo); atomicMax(&s_all[1], hi); }
     }
     __syncthreads();
     if (tid < mpp2) {
         uint32_t mn = s_mn[tid], mx = s_mx[tid];
         const uint32_t m = s_name[tid];
-        if (mn == INVALID && m != INVALID && s_svc[tid]) {
-            mn = 65535u - S.mninv[m];
-            mx = S.mx[m];
+        if (mn == INVALID && m != INVALID) {
+            if (s_svc[tid]) {
+                mn = 65535u - S.mninv[m];
+                mx = S.mx[m];
+            } else if (s_all[0] != INVALID) {
+                mn = s_all[0];
+                mx = s_all[1];
+            }
         }
         s_org[tid] = v3_place(mn, mx, s_svc[tid], s_svm[tid], W);
         s_mn[tid] = INVALID; // reused as the flush ranges
@@ -1575,6 +1595,7 @@ static bool make_plan3(size_t n, uint32_t nmetrics, int num_cus, const PartTunin
     const size_t ntiles = n / V3_TILE; // whole tiles; the rest goes through the direct kernel
     if (ntiles == 0) return false;
     size_t g1 = (size_t)num_cus;
+    if (tune.v3_g1_cap && g1 > tune.v3_g1_cap) g1 = tune.v3_g1_cap;
     if (g1 > (ntiles + 3) / 4) g1 = (ntiles + 3) / 4;
     if (g1 < 1) g1 = 1;
     P.g1 = (uint32_t)g1;

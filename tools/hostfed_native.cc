@@ -7,7 +7,7 @@
 // (lh_reserve_pairs16 / lh_reserve_pairs), stores its pairs there -- the one host-side copy -- and commits.
 // Checked: per-name counts of the interval against the generator's own counts.  Prints one JSON line per form.
 //
-//   usage: hostfed_native [threads=16] [pairs=8e8] [names=1024] [batch=1048576] [lane_gen3=1]
+//   usage: hostfed_native [threads=16] [pairs=8e8] [names=1024] [batch=1048576] [lane_gen3=1] [survey_every=0] [lane_blocks=-1]
 //   (lane_gen3 = 0: the lanes' launches over more than 8 192 names take the first generation, as up to ABI 4)
 #include "loghisto_gpu_tuning.h"
 
@@ -27,7 +27,7 @@ static void die(const char *what, int rc)
     std::exit(1);
 }
 
-static int g_lane_gen3 = 1;
+static int g_lane_gen3 = 1, g_survey_every = 0, g_blocks = -1;
 
 template <typename IDT> static double run(uint32_t T, size_t total, uint32_t M, size_t batch, const std::vector<uint32_t> &ids,
                                           const std::vector<double> &vals, bool *exact)
@@ -42,6 +42,8 @@ template <typename IDT> static double run(uint32_t T, size_t total, uint32_t M, 
     int rc = lh_create(&cfg, &e);
     if (rc) die("lh_create", rc);
     if ((rc = lh_set_option(e, LH_OPT_LANE_GEN3, (uint64_t)g_lane_gen3))) die("lh_set_option", rc);
+    if (g_survey_every && (rc = lh_set_option(e, LH_OPT_SURVEY_EVERY, (uint64_t)g_survey_every))) die("lh_set_option", rc);
+    if (g_blocks >= 0 && (rc = lh_set_option(e, LH_OPT_LANE_SCRATCH_BLOCKS, (uint64_t)g_blocks))) die("lh_set_option", rc);
     std::vector<IDT> nid(ids.begin(), ids.end()); // the producer's own id array in the width it ships
     const size_t per = total / T;
     auto put = [&](size_t off, size_t n) {
@@ -103,6 +105,15 @@ template <typename IDT> static double run(uint32_t T, size_t total, uint32_t M, 
     for (uint32_t m = 0; m < M; m++)
         if (st[m].count != want[m]) *exact = false;
     lh_release(s);
+    lh_counters c;
+    if (lh_get_counters(e, &c) == LH_OK)
+        std::fprintf(stderr, "counters: partitioned %llu (v3 %llu) direct %llu fallback %llu | launches %llu surveys_reused %llu | level-1 records %llu "
+                             "forwarded %llu | region overflows %llu level-2 overflows %llu reduce misses %llu | waits %llu\n",
+                     (unsigned long long)c.samples_partitioned, (unsigned long long)c.samples_partitioned_v3,
+                     (unsigned long long)c.samples_direct, (unsigned long long)c.samples_fallback, (unsigned long long)c.launches,
+                     (unsigned long long)c.surveys_reused, (unsigned long long)c.records_level1, (unsigned long long)c.records_level2,
+                     (unsigned long long)c.region_overflows, (unsigned long long)c.level2_overflows,
+                     (unsigned long long)c.reduce_window_misses, (unsigned long long)c.backpressure_waits);
     lh_destroy(e);
     return (double)(per * T) / dt;
 }
@@ -114,6 +125,8 @@ int main(int argc, char **argv)
     const uint32_t M = argc > 3 ? (uint32_t)std::atoi(argv[3]) : 1024u;
     const size_t batch = argc > 4 ? (size_t)std::atoll(argv[4]) : (size_t)1 << 20;
     g_lane_gen3 = argc > 5 ? std::atoi(argv[5]) : 1;
+    g_survey_every = argc > 6 ? std::atoi(argv[6]) : 0;   // LH_OPT_SURVEY_EVERY (0: default)
+    g_blocks = argc > 7 ? std::atoi(argv[7]) : -1;        // LH_OPT_LANE_SCRATCH_BLOCKS (-1: default)
     const size_t N = (size_t)1 << 24;
     std::vector<uint32_t> ids(N);
     std::vector<double> vals(N);

@@ -77,8 +77,24 @@ lanes)  # lanes <tag>: the host-fed path: its tests, then native producer thread
         # third-generation launches on and off
     (timeout 1500 python -m pytest tests/test_gpu_lane_blocks.py tests/test_gpu_faults.py tests/test_gpu_pairs16.py -x -q) > $OUT/pytest.log 2>&1
     tail -4 $OUT/pytest.log | cut -c1-300; grep -E "^(FAILED|ERROR)|Error|assert" $OUT/pytest.log | head -20 | cut -c1-300
-    for args in "16 8e8 1024 1048576 1" "16 8e8 65536 1048576 1" "16 8e8 65536 1048576 0" "8 8e8 65536 1048576 1" "16 8e8 65536 2097152 1" "16 8e8 20000 1048576 1"; do
+    for args in "16 8e8 1024 1048576 1" "16 8e8 65536 1048576 1" "16 8e8 65536 1048576 0" "16 8e8 65536 1048576 8" "16 8e8 65536 1048576 32" \
+                "16 8e8 65536 1048576 256" "8 8e8 65536 1048576 1" "16 8e8 20000 1048576 1" "16 8e8 65536 1048576 1" "16 8e8 65536 1048576 1"; do
         loghisto_amd/build/hostfed_native $args 2>&1 | cut -c1-330 | tee -a $OUT/hostfed_native.jsonl
+    done
+    ;;
+lanedbg)  # lanedbg <tag>: which ingredient of the lanes' third-generation launches breaks counts (diagnostic)
+    for args in "1 2e8 65536 1048576 1 0 8" "1 2e8 65536 1048576 1 1 8" "2 2e8 65536 1048576 1 1000 8" "16 4e8 65536 1048576 1 1000 1" \
+                "16 4e8 65536 1048576 1 1000 2" "16 4e8 65536 1048576 1 1000 8" "16 4e8 65536 1048576 1 1 8" "4 4e8 65536 1048576 1 2 8"; do
+        echo "== $args" | tee -a $OUT/dbg.txt
+        loghisto_amd/build/hostfed_native $args 2>&1 | sed -e 's/.*"threads"/"threads"/' | cut -c1-200 | tee -a $OUT/dbg.txt
+    done
+    ;;
+lanetrace)  # lanetrace <tag>: per-kernel durations of the host-fed path at 65 536 names, lanes' third generation on / off
+    for g3 in 1 0; do
+        (cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/pk
+         timeout 300 rocprofv3 --kernel-trace -d /tmp/pk -o t -- $R/loghisto_amd/build/hostfed_native 16 4e8 65536 1048576 $g3 > $OUT/run_$g3.txt 2>&1
+         python $R/profiles/summarize_rocpd.py stats /tmp/pk/t_results.db | cut -c1-170) | tee $OUT/trace_gen3_$g3.txt | head -24
+        cut -c1-300 $OUT/run_$g3.txt
     done
     ;;
 profile)
