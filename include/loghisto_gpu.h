@@ -366,10 +366,11 @@ int lh_get_counters(lh_engine *e, lh_counters *out);
  *                             is also repeated when the window width or scatter shape changed, when anything else used
  *                             the block, or when more than 2 % of the pairs of the calls completed since took an
  *                             overflow / window-miss path.  A stale survey costs speed, never exactness
- *   LH_OPT_LANE_SCRATCH_BLOCKS  0 .. 8 (default 8): host-fed mixed launches (lh_submit_pairs*, lh_commit_pairs*: one staging
- *                             half-buffer each, at most 2^22 pairs) take the first partitioned generation in one of this
- *                             many scratch blocks of their own, so that one lane's later passes run beside another
- *                             lane's link-bound read; 0 = every partitioned launch shares the engine's one block
+ *   LH_OPT_LANE_SCRATCH_BLOCKS  0 .. 16 (default 16): host-fed mixed launches (lh_submit_pairs*, lh_commit_pairs*: one staging
+ *                             half-buffer each, at most 2^22 pairs) run partitioned in one of this many scratch blocks
+ *                             of their own (first generation up to 8 192 names; above, the third generation on survey
+ *                             tables the lanes share), so that one lane's later passes run beside another lane's
+ *                             link-bound read; 0 = every partitioned launch shares the engine's one block
  *   LH_OPT_LANE_ZERO_COPY     0 / 1: the ingest kernels read the pinned staging buffers of lh_submit* / lh_reserve_pairs
  *                             in place over PCIe (default 1) instead of after a hipMemcpyAsync into HBM (0) */
 enum {

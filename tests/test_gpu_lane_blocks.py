@@ -23,7 +23,7 @@ def la(native_lib, torch_cuda):
 
 
 @pytest.mark.parametrize("M,width", [(1024, 4), (1024, 2), (20000, 4), (65536, 2)])
-@pytest.mark.parametrize("blocks", [8, 2, 0])
+@pytest.mark.parametrize("blocks", [16, 2, 0])
 def test_concurrent_lanes_in_their_own_blocks(la, M, width, blocks):
     from loghisto_amd import _native as N
     rng = np.random.default_rng(M + blocks)
