@@ -1,17 +1,22 @@
 #!/bin/bash
 # tools/round.sh -- the GPU calls of a round as sub-commands of ONE script (each is one `gpurun` call; outputs go to
-# gpurun_out/<tag>/ and the summaries worth keeping are copied into profiles/ by hand).
+# gpurun_out/<tag>/, and the summaries worth keeping are copied into profiles/ by hand).
 #
-#   gpurun --timeout 900 -- 'bash tools/round.sh <sub-command> [tag] [args...]'
+#   gpurun --timeout 1500 -- 'bash tools/round.sh <sub-command> [tag] [args...]'
 #
-#   ab <tag> <suffix,...>   mixed-ingest A/B on one box: the third generation's parity tests against the product
-#                           library, then config 4's slice and the 1e9-pair call (65 536 names) and config 3 (1 024 names)
-#                           timed with the product library and with every build/liblhgpu_tuning_<suffix>.so
-#                           (tools/build_tuning.py -D... --name <suffix>), then the product's kernel split
-#   abl <tag> <suffix,...>  timing of ablation builds (wrong counts by construction) + tools/row_stride.hip
-#   lanes <tag>             host-fed path: tests + tools/hostfed_native.cc at 1 024 / 65 536 names (LH_OPT_LANE_GEN3 on / off)
 #   tests <tag> [pytest args]   the GPU suite (or a part of it) + smoke()
-#   profile <tag>           the round's evidence: tools/profile_round.sh (bench lines, kernel traces, PMC passes)
+#   profile <tag>               the round's evidence (tools/profile_round.sh: bench lines, kernel traces, PMC passes;
+#                               written to gpurun_out/round/)
+#   ab <tag> <suffix,...>       mixed-ingest A/B on ONE box: config 4's slice and the 1e9-pair call (65 536 names) and
+#                               config 3 (1 024 names) timed with the product library and with every
+#                               build/liblhgpu_tuning_<suffix>.so (tools/build_tuning.py -D... --name <suffix>), then the
+#                               product's kernel split at the slice and at config 3
+#   abl <tag> <suffix,...>      timing of ablation builds (sweep.py --nocheck: their counts are wrong by construction)
+#   rows <tag>                  tools/row_stride.hip: the row store's access shapes at several row strides
+#   lanes <tag>                 host-fed path: its tests + tools/hostfed_native.cc at 1 024 / 20 000 / 65 536 names
+#                               (LH_OPT_LANE_GEN3 off / on / level-1 workgroup caps, 8 and 16 lane blocks)
+#   lanetrace <tag>             rocprofv3 --kernel-trace of hostfed_native at 65 536 names, lanes' third generation on / off
+#   counters <tag>              tools/sq_counters.sh: SQ instruction / LDS counters per distribution
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 SUB=$1; TAG=${2:-r5}; shift 2
 OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; cd $R
@@ -31,38 +36,20 @@ ktrace() { # ktrace <pairs> <names> <file>: per-kernel averages of a sweep under
      timeout 400 rocprofv3 --kernel-trace -d /tmp/pk -o t -- python $R/tools/sweep.py --samples $1 --pairs $2 --reps 4 --dists lognormal > /dev/null 2>&1
      python $R/profiles/summarize_rocpd.py stats /tmp/pk/t_results.db | grep -E "kernel|k_scatter|k_part|k_split|k_survey|k_plan|k_v3|k_ingest" | cut -c1-170) | tee $3
 }
+suite() { # suite <pytest args...>
+    (timeout 2400 python -m pytest "$@" -x -q) > $OUT/pytest.log 2>&1
+    tail -6 $OUT/pytest.log | cut -c1-300; grep -E "^(FAILED|ERROR)|Error|assert" $OUT/pytest.log | head -20 | cut -c1-300
+}
 
 case $SUB in
-ab)
-    (timeout 1200 python -m pytest tests/test_gpu_part3.py tests/test_gpu_options.py tests/test_gpu_pairs16.py -x -q) > $OUT/pytest.log 2>&1
-    tail -5 $OUT/pytest.log | cut -c1-300
-    for sfx in "" $(echo ${1:-} | tr ',' ' '); do
-        lib=""; [ -n "$sfx" ] && lib="--lib loghisto_amd/build/liblhgpu_tuning_$sfx.so"
-        echo "== ${sfx:-product}" | tee -a $OUT/ab.txt
-        sweep 1.25e8 65536 24 --dists lognormal $lib | tee -a $OUT/ab.txt
-        sweep 1e9 65536 5 --dists lognormal $lib | tee -a $OUT/ab.txt
-    done
-    sweep 1e9 65536 3 --dists constant,kvalues8,bimodal,lognormal25,loguniform | tee -a $OUT/ab.txt
-    sweep 1e9 1024 5 --dists lognormal,kvalues8 | tee -a $OUT/ab.txt
-    ktrace 1.25e8 65536 $OUT/trace_slice.txt
-    ktrace 1e9 65536 $OUT/trace_1e9.txt
-    ;;
-abl)    # abl <tag> <suffix,...>: timing only (sweep.py --nocheck) of ablation builds, beside the row-store access tool
-    loghisto_amd/build/row_stride --reps 10 2>&1 | cut -c1-250 | tee $OUT/row_stride.jsonl
-    for sfx in $(echo ${1:-} | tr ',' ' '); do
-        echo "== $sfx" | tee -a $OUT/abl.txt
-        sweep 1.25e8 65536 16 --dists lognormal --nocheck --lib loghisto_amd/build/liblhgpu_tuning_$sfx.so | tee -a $OUT/abl.txt
-        sweep 1e9 65536 4 --dists lognormal --nocheck --lib loghisto_amd/build/liblhgpu_tuning_$sfx.so | tee -a $OUT/abl.txt
-    done
-    ;;
 tests)
-    (timeout 2400 python -m pytest tests -m gpu -x -q "$@") > $OUT/pytest.log 2>&1
-    tail -6 $OUT/pytest.log | cut -c1-300; grep -E "^(FAILED|ERROR)|Error|assert" $OUT/pytest.log | head -20 | cut -c1-300
+    if [ $# -gt 0 ]; then suite "$@"; else suite tests -m gpu; fi
     (timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')") 2>&1 | tail -2 | tee $OUT/smoke.log
     ;;
-tests_ab)   # tests_ab <tag> <suffix,...>: the GPU suite, then the ab timings (one call instead of two)
-    (timeout 2400 python -m pytest tests -m gpu -x -q) > $OUT/pytest.log 2>&1
-    tail -6 $OUT/pytest.log | cut -c1-300; grep -E "^(FAILED|ERROR)|Error|assert" $OUT/pytest.log | head -20 | cut -c1-300
+profile)
+    bash tools/profile_round.sh
+    ;;
+ab)
     for sfx in "" $(echo ${1:-} | tr ',' ' '); do
         lib=""; [ -n "$sfx" ] && lib="--lib loghisto_amd/build/liblhgpu_tuning_$sfx.so"
         echo "== ${sfx:-product}" | tee -a $OUT/ab.txt
@@ -73,32 +60,35 @@ tests_ab)   # tests_ab <tag> <suffix,...>: the GPU suite, then the ab timings (o
     ktrace 1.25e8 65536 $OUT/trace_slice.txt
     ktrace 1e9 1024 $OUT/trace_c3.txt
     ;;
-lanes)  # lanes <tag>: the host-fed path: its tests, then native producer threads at 1 024 and 65 536 names, the lanes'
-        # third-generation launches on and off
-    (timeout 1500 python -m pytest tests/test_gpu_lane_blocks.py tests/test_gpu_faults.py tests/test_gpu_pairs16.py -x -q) > $OUT/pytest.log 2>&1
-    tail -4 $OUT/pytest.log | cut -c1-300; grep -E "^(FAILED|ERROR)|Error|assert" $OUT/pytest.log | head -20 | cut -c1-300
-    for args in "16 8e8 1024 1048576 1" "16 8e8 65536 1048576 1" "16 8e8 65536 1048576 0" "16 8e8 65536 1048576 8" "16 8e8 65536 1048576 32" \
-                "16 8e8 65536 1048576 256" "8 8e8 65536 1048576 1" "16 8e8 20000 1048576 1" "16 8e8 65536 1048576 1" "16 8e8 65536 1048576 1"; do
-        loghisto_amd/build/hostfed_native $args 2>&1 | cut -c1-330 | tee -a $OUT/hostfed_native.jsonl
+abl)
+    for sfx in $(echo ${1:-} | tr ',' ' '); do
+        echo "== $sfx" | tee -a $OUT/abl.txt
+        sweep 1.25e8 65536 16 --dists lognormal --nocheck --lib loghisto_amd/build/liblhgpu_tuning_$sfx.so | tee -a $OUT/abl.txt
+        sweep 1e9 65536 4 --dists lognormal --nocheck --lib loghisto_amd/build/liblhgpu_tuning_$sfx.so | tee -a $OUT/abl.txt
     done
     ;;
-lanedbg)  # lanedbg <tag>: which ingredient of the lanes' third-generation launches breaks counts (diagnostic)
-    for args in "1 2e8 65536 1048576 1 0 8" "1 2e8 65536 1048576 1 1 8" "2 2e8 65536 1048576 1 1000 8" "16 4e8 65536 1048576 1 1000 1" \
-                "16 4e8 65536 1048576 1 1000 2" "16 4e8 65536 1048576 1 1000 8" "16 4e8 65536 1048576 1 1 8" "4 4e8 65536 1048576 1 2 8"; do
-        echo "== $args" | tee -a $OUT/dbg.txt
-        loghisto_amd/build/hostfed_native $args 2>&1 | sed -e 's/.*"threads"/"threads"/' | cut -c1-200 | tee -a $OUT/dbg.txt
+rows)
+    loghisto_amd/build/row_stride --reps 10 2>&1 | cut -c1-250 | tee $OUT/row_stride.jsonl
+    ;;
+lanes)
+    suite tests/test_gpu_lane_blocks.py tests/test_gpu_faults.py tests/test_gpu_pairs16.py
+    # hostfed_native [threads] [pairs] [names] [batch] [lane_gen3: 0 off, 1 on, n >= 2: on with n level-1 workgroups] [survey_every] [lane_blocks]
+    for args in "16 8e8 1024 1048576 1 0 16" "16 8e8 1024 1048576 1 0 8" "16 8e8 20000 1048576 1 0 16" "16 8e8 65536 1048576 1 0 16" \
+                "16 8e8 65536 1048576 1 0 8" "16 8e8 65536 1048576 0 0 16" "16 8e8 65536 1048576 16 0 16" "16 8e8 65536 1048576 256 0 16" \
+                "8 8e8 65536 1048576 1 0 16"; do
+        loghisto_amd/build/hostfed_native $args 2>&1 | grep -v "^counters" | sed -e "s/^{/{\"args\": \"$args\", /" | cut -c1-360 | tee -a $OUT/hostfed_native.jsonl
     done
     ;;
-lanetrace)  # lanetrace <tag>: per-kernel durations of the host-fed path at 65 536 names, lanes' third generation on / off
+lanetrace)
     for g3 in 1 0; do
         (cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/pk
          timeout 300 rocprofv3 --kernel-trace -d /tmp/pk -o t -- $R/loghisto_amd/build/hostfed_native 16 4e8 65536 1048576 $g3 > $OUT/run_$g3.txt 2>&1
-         python $R/profiles/summarize_rocpd.py stats /tmp/pk/t_results.db | cut -c1-170) | tee $OUT/trace_gen3_$g3.txt | head -24
-        cut -c1-300 $OUT/run_$g3.txt
+         python $R/profiles/summarize_rocpd.py stats /tmp/pk/t_results.db | cut -c1-170) | grep -v "^[WE]2" | tee $OUT/trace_gen3_$g3.txt | head -24
+        grep -v "^[WE]2" $OUT/run_$g3.txt | cut -c1-400
     done
     ;;
-profile)
-    bash tools/profile_round.sh $TAG "$@"
+counters)
+    bash tools/sq_counters.sh $TAG
     ;;
 *)
     echo "unknown sub-command: $SUB"; exit 2;;

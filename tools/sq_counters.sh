@@ -1,10 +1,10 @@
-# Round 4: SQ counters of the ingest kernels on the few-valued and the usual value distributions.
+# SQ counters of the ingest kernels on the few-valued and the usual value distributions (tools/round.sh counters).
 #   K1 (k_ingest_single), n = 1e9: LDS bank conflicts / LDS instructions / VALU instructions per distribution  -> k1_lds_counters.jsonl
 #   1 024 names (k_scatter3, k_part_hist2) and 65 536 names (k_scatter4, k_split_waves, k_part_hist3), 1e9 pairs:
 #   instruction mix and LDS conflicts, lognormal + kvalues2                                        -> mixed_counters.jsonl
 # One rocprofv3 --pmc pass per (distribution, counter set); no tracing domains in the same run.
-# usage: [PARTS="k1 mixed"] bash tools/r4_counters.sh OUTDIR
-cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; OUTD=$R/gpurun_out/${1:-r4cnt}; mkdir -p $OUTD
+# usage: [PARTS="k1 mixed"] bash tools/sq_counters.sh OUTDIR   (round.sh counters <tag>)
+cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; OUTD=$R/gpurun_out/${1:-counters}; mkdir -p $OUTD
 PARTS=${PARTS:-k1 mixed}
 K1=$OUTD/k1_lds_counters.jsonl; MX=$OUTD/mixed_counters.jsonl
 
