@@ -664,7 +664,7 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=Non
     else:
         comm = comm_override
         frontend = frontend or "c-abi: lh_snapshot_merge -> RCCL"
-    t_ing, t_merge, t_ext, t_k2 = [], [], [], []
+    t_ing, t_merge, t_mwall, t_ext, t_k2 = [], [], [], [], []
     info = {}
 
     def step(timed):
@@ -684,6 +684,11 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=Non
             first, last = 0, M
         t1 = time.perf_counter()
         xs = torch.cuda.ExternalStream(snap.stream())            # the snapshot's own stream: K2 runs there
+        if timed:
+            # lh_snapshot_merge returns once its last kernel is enqueued: wait for the merge here, so that the extract
+            # time below is the extract's (round 4 charged it the merge's 0.34 ms of device time: "extract_owned_ms 0.75")
+            xs.synchronize()
+        t1b = time.perf_counter()
         k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         k0.record(xs)
         out = snap.extract_view(PCTS, last - first, first=first) # the names this rank owns, results in place (pinned)
@@ -697,7 +702,8 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=Non
             torch.cuda.synchronize()
             t_ing.append(a.elapsed_time(b))
             t_merge.append((t1 - t0) * 1e3)
-            t_ext.append((t2 - t1) * 1e3)
+            t_mwall.append((t1b - t0) * 1e3)
+            t_ext.append((t2 - t1b) * 1e3)
             t_k2.append(k0.elapsed_time(k1))
         return out, (first, last)
 
@@ -831,13 +837,19 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=Non
         "roofline": roofline(n * BYTES_PAIR, sum(t_ing) / len(t_ing),
                              "k_survey_count_h .. k_scatter4 + k_split_waves + k_part_hist3 (third generation of the "
                              "partitioned ingest: every launch of one lh_submit_pairs_device)", **c3_traffic(n, M, C4_PMC)),
-        "merge": {"host_call_ms": sum(t_merge) / len(t_merge),
+        "merge": {"host_call_ms": sum(t_merge) / len(t_merge), "wall_ms": sum(t_mwall) / len(t_mwall),
                   "device_ms": {k: info.get(k) for k in ("ranges_ms", "plan_ms", "pack_ms", "collective_ms",
                                                          "unpack_ms", "span_ms")},
-                  "packed_cells": info.get("packed_cells"), "padded_cells": info.get("padded_cells"),
-                  "padding_ratio": (info["padded_cells"] / info["packed_cells"]
-                                    if info.get("packed_cells") and info.get("padded_cells") else None),
+                  "packed_cells": info.get("packed_cells"), "packed_words": info.get("packed_words"),
+                  "padded_words": info.get("padded_words"),
+                  "padding_ratio": (info["padded_words"] / info["packed_words"]
+                                    if info.get("packed_words") and info.get("padded_words") else None),
                   "cell_bytes": info.get("cell_bytes"),
+                  # a row travels at 8 / 16 / 32 bits per cell, the narrowest that holds ranks x its largest per-rank
+                  # cell (LH_OPT_MERGE_NARROW_CELLS; one rank moves nothing between GPUs and skips the pass over the cells)
+                  "rows_8bit": info.get("rows_8bit"), "rows_16bit": info.get("rows_16bit"),
+                  "wire_bytes_per_cell": (info["packed_words"] * info["cell_bytes"] / info["packed_cells"]
+                                          if info.get("packed_cells") and info.get("packed_words") else None),
                   "send_bytes": info.get("send_bytes"), "recv_bytes": info.get("recv_bytes"),
                   "widest_row": info.get("widest_row"), "occupied_rows": info.get("occupied_rows"),
                   # how dense the windows that travel are: occupied cells of the rows this rank owns
@@ -849,7 +861,8 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=Non
                   "owned_rows_by_rank": bounds if world <= 16 else None,
                   "note": "device_ms: HIP events on the snapshot stream around the merge's steps of the last timed "
                           "step (dirty-range all-reduce, window plan, pack, collective, unpack; span includes the host "
-                          "round trip for the plan totals); host_call_ms: wall time of lh_snapshot_merge returning"},
+                          "round trip for the plan totals); host_call_ms: wall time of lh_snapshot_merge returning; "
+                          "wall_ms: until its last kernel has finished (extract_owned_ms starts there)"},
         "extract_owned_ms": sum(t_ext) / len(t_ext), "parity": parity, "scratch_bytes": c["scratch_bytes"],
     }
     if info.get("packed_cells") and t_k2:

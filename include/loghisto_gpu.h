@@ -242,22 +242,30 @@ enum { LH_MERGE_ALLREDUCE = 0, LH_MERGE_REDUCE_SCATTER = 1 };
 int lh_snapshot_merge(lh_snapshot *s, void *comm, int nranks, int rank, int plan, uint32_t nrows,
                       uint32_t *first_owned, uint32_t *last_owned);
 /* What the last lh_snapshot_merge on this engine moved.  Every row travels with its OWN merged window
- * [lo_r, hi_r] (packed back to back), so an outlier sample widens one row, never the matrix. */
+ * [lo_r, hi_r] (packed back to back), so an outlier sample widens one row, never the matrix -- and, when the wire word
+ * is uint32, at its own cell width: 8, 16 or 32 bits, the narrowest that holds nranks x (the largest cell any rank
+ * has in that row; all-reduced with the dirty ranges), so that the uint32 SUM of the collective never carries from one
+ * cell of a word into the next.  Most names of a skewed stream hold small counts per interval: config 4's windows
+ * (65 536 Zipf names, 8 ranks) travel at ~1.1 bytes per cell instead of 4. */
 typedef struct lh_merge_info {
-    uint64_t packed_cells;   /* sum over rows of the merged window widths                       */
-    uint64_t send_bytes;     /* bytes handed to the collective (reduce-scatter: nranks x largest block) */
-    uint64_t recv_bytes;     /* bytes this rank ends up with                                     */
-    uint32_t widest_row;     /* widest merged window, in cells                                   */
-    uint32_t occupied_rows;  /* rows with at least one cell on some rank                         */
-    uint64_t padded_cells;   /* reduce-scatter: nranks x largest owner block (>= packed_cells; the ratio is what
-                              * the equal-block collective costs over the packed matrix); all-reduce: packed_cells */
-    uint32_t cell_bytes;     /* 8, or 4 when no merged cell of the interval can reach 2^32 (nranks x the largest
-                              * per-rank sample count of the interval < 2^32: cells travel as uint32)            */
-    uint32_t reserved;
+    uint64_t packed_cells;   /* sum over rows of the merged window widths, in cells                          */
+    uint64_t send_bytes;     /* bytes handed to the collective (reduce-scatter: nranks x largest block)      */
+    uint64_t recv_bytes;     /* bytes this rank ends up with                                                  */
+    uint32_t widest_row;     /* widest merged window, in cells                                                */
+    uint32_t occupied_rows;  /* rows with at least one cell on some rank                                      */
+    uint64_t padded_words;   /* reduce-scatter: nranks x largest owner block, in wire words (>= packed_words; the
+                              * ratio is what the equal-block collective costs over the packed matrix);
+                              * all-reduce: packed_words */
+    uint32_t cell_bytes;     /* the wire word: 8 (one cell per word), or 4 when no merged cell of the interval can
+                              * reach 2^32 (nranks x the largest per-rank sample count of the interval < 2^32)  */
+    uint32_t rows_8bit;      /* occupied rows that travelled at 8 bits per cell (4 cells per word) ...          */
     /* Device time of the merge's steps, HIP events on the snapshot stream (lh_snapshot_merge_info waits for the
-     * last one): dirty-range all-reduce, window plan, pack, the collective, unpack; span = first event to last,
-     * host round trip for the plan totals included. */
+     * last one): dirty-range all-reduce (with the pass over the rows' largest cells), window plan, pack, the
+     * collective, unpack; span = first event to last, host round trip for the plan totals included. */
     float ranges_ms, plan_ms, pack_ms, collective_ms, unpack_ms, span_ms;
+    uint64_t packed_words;   /* sum over rows of ceil(window cells x bits / 32) (uint32 words), or packed_cells */
+    uint32_t rows_16bit;     /* ... and at 16 bits per cell (2 per word); the other occupied rows: one per word  */
+    uint32_t reserved;
 } lh_merge_info;
 int lh_snapshot_merge_info(lh_snapshot *s, lh_merge_info *out);
 /* Path (or soname) of the RCCL shared object the communicator comes from; default "librccl.so".
@@ -372,14 +380,19 @@ int lh_get_counters(lh_engine *e, lh_counters *out);
  *                             tables the lanes share), so that one lane's later passes run beside another lane's
  *                             link-bound read; 0 = every partitioned launch shares the engine's one block
  *   LH_OPT_LANE_ZERO_COPY     0 / 1: the ingest kernels read the pinned staging buffers of lh_submit* / lh_reserve_pairs
- *                             in place over PCIe (default 1) instead of after a hipMemcpyAsync into HBM (0) */
+ *                             in place over PCIe (default 1) instead of after a hipMemcpyAsync into HBM (0)
+ *   LH_OPT_MERGE_NARROW_CELLS 0 / 1 (default 1): lh_snapshot_merge over more than one rank sends a row at 8 or 16 bits per
+ *                             cell when nranks x its largest per-rank cell fits (lh_merge_info); 0 = every cell a whole
+ *                             word.  A rank that sets 0 makes every rank of that merge send whole words (the bound
+ *                             is all-reduced): ranks need not agree */
 enum {
     LH_OPT_EXTRACT_ZERO_COPY = 5,
     LH_OPT_SCRATCH_CAP_BYTES = 6,
     LH_OPT_SUBLAUNCH_PAIRS = 7,
     LH_OPT_LANE_ZERO_COPY = 15,
     LH_OPT_SURVEY_EVERY = 16,
-    LH_OPT_LANE_SCRATCH_BLOCKS = 18
+    LH_OPT_LANE_SCRATCH_BLOCKS = 18,
+    LH_OPT_MERGE_NARROW_CELLS = 22
 };
 int lh_set_option(lh_engine *e, int option, uint64_t value);
 

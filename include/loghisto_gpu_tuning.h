@@ -40,6 +40,10 @@ extern "C" {
  *   LH_OPT_PART_V3_LOG_W      log2 of its second-level window width, 10 .. 13 (32 .. 4 names per fine partition);
  *                             0 (default) = follow the survey: every call's survey reports the width that covers
  *                             95 % of the sampled mass and the following calls use it (lh_counters.window_log2)
+ *   LH_OPT_PART_V3_DIRECT_MAX_PAIRS  third generation: a launch of at most this many pairs ends in a reduce pass without
+ *                             LDS windows, one global atomic per forwarded record (a host-fed lane's half-buffer leaves a
+ *                             fine partition some hundred records: the windowed pass's fixed cost per slot bounded the lanes);
+ *                             0 = the default, 2^22 (the largest lane launch); 1 = never; <= 2^30
  *   LH_OPT_PART_MIN_PAIRS     smallest mixed launch that takes a partitioned path at all (below it: one global atomic
  *                             per sample); 0 = the default, 131 072; >= 65 536 otherwise
  *   LH_OPT_LANE_GEN3          0 / 1 (default 1): above 8 192 names a host-fed lane launch takes the third generation in the
@@ -61,7 +65,8 @@ enum {
     LH_OPT_PART_V3_LOG_W = 14,
     LH_OPT_PART_MIN_PAIRS = 17,
     LH_OPT_FAIL_SCRATCH_ALLOCS = 19,
-    LH_OPT_LANE_GEN3 = 20
+    LH_OPT_LANE_GEN3 = 20,
+    LH_OPT_PART_V3_DIRECT_MAX_PAIRS = 21
 };
 
 /* The path choice as a function: what an engine in the described state would do with a call of n pairs.  No device is

@@ -56,6 +56,8 @@ OPT_PART_MIN_PAIRS = 17
 OPT_LANE_SCRATCH_BLOCKS = 18
 OPT_FAIL_SCRATCH_ALLOCS = 19
 OPT_LANE_GEN3 = 20
+OPT_PART_V3_DIRECT_MAX_PAIRS = 21
+OPT_MERGE_NARROW_CELLS = 22
 
 
 class LhDispatchQuery(C.Structure):
@@ -85,9 +87,10 @@ class LhExtractView(C.Structure):
 
 class LhMergeInfo(C.Structure):
     _fields_ = [("packed_cells", C.c_uint64), ("send_bytes", C.c_uint64), ("recv_bytes", C.c_uint64),
-                ("widest_row", C.c_uint32), ("occupied_rows", C.c_uint32), ("padded_cells", C.c_uint64),
-                ("cell_bytes", C.c_uint32), ("reserved", C.c_uint32), ("ranges_ms", C.c_float), ("plan_ms", C.c_float),
-                ("pack_ms", C.c_float), ("collective_ms", C.c_float), ("unpack_ms", C.c_float), ("span_ms", C.c_float)]
+                ("widest_row", C.c_uint32), ("occupied_rows", C.c_uint32), ("padded_words", C.c_uint64),
+                ("cell_bytes", C.c_uint32), ("rows_8bit", C.c_uint32), ("ranges_ms", C.c_float), ("plan_ms", C.c_float),
+                ("pack_ms", C.c_float), ("collective_ms", C.c_float), ("unpack_ms", C.c_float), ("span_ms", C.c_float),
+                ("packed_words", C.c_uint64), ("rows_16bit", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class LhLineFormat(C.Structure):

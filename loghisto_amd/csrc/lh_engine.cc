@@ -173,6 +173,7 @@ struct lh_engine {
     lh_merge_info merge_info{};
     hipEvent_t merge_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // around the merge's steps (xmu)
     bool merge_events_pending = false;
+    bool merge_narrow = true;           // LH_OPT_MERGE_NARROW_CELLS: rows travel at 8 / 16 bits per cell where their counts allow
 
     // counters (metrics.go:112-117): their own name table, the lifetime store and the "ever touched" flags in HBM
     std::shared_mutex cnames_mu;
@@ -1765,41 +1766,48 @@ int lh_snapshot_merge(lh_snapshot *s, void *comm, int nranks, int rank, int plan
         if (!ev) HIPCHK(hipEventCreate(&ev));
     HIPCHK(hipEventRecord(e->merge_ev[0], st));
 
-    // plan arrays: P[max_metrics + 1], bstart[1025], info[8], brow[1025] (uint32) -- allocated once, never moved
+    // plan arrays: P[max_metrics + 1], bstart[1025], info[16], brow[1025] (uint32), the plan kernels' partial sums, the
+    // rows' wire classes (one byte each) -- allocated once, never moved
     const size_t M = e->cfg.max_metrics;
-    if (!e->d_mplan) HIPCHK(hipMalloc((void **)&e->d_mplan, (M + 1 + 1025 + 8 + 520 + 3072) * sizeof(uint64_t)));
+    if (!e->d_mplan) HIPCHK(hipMalloc((void **)&e->d_mplan, (M + 1 + 1025 + 16 + 520 + 5120 + (M + 7) / 8) * sizeof(uint64_t)));
     uint64_t *d_P = e->d_mplan, *d_bstart = d_P + M + 1, *d_info = d_bstart + 1025;
-    uint32_t *d_brow = reinterpret_cast<uint32_t *>(d_info + 8);
-    uint64_t *d_work = d_info + 8 + 520; // the plan kernels' per-row-block partial sums
+    uint32_t *d_brow = reinterpret_cast<uint32_t *>(d_info + 16);
+    uint64_t *d_work = d_info + 16 + 520; // the plan kernels' per-row-block partial sums
+    uint8_t *d_cls = reinterpret_cast<uint8_t *>(d_work + 5120);
 
-    // 1. dirty ranges: min(lo), max(hi) over the ranks with ONE MIN all-reduce on (lo, ~hi), in place.  One more
-    //    word rides along: this rank's sample count of the interval (clipped), so that every rank learns the largest
-    //    one and all of them pick the same cell type for the wire.
-    const size_t rbytes = ((size_t)nrows * 2 + 1) * sizeof(uint32_t);
-    rc = ensure_xbuf(e, rbytes + 256);
+    // 1. dirty ranges: min(lo), max(hi) over the ranks with ONE MIN all-reduce on (lo, ~hi), in place.  Two more things
+    //    ride along, complemented the same way: this rank's sample count of the interval (clipped) -- every rank learns the
+    //    largest one and all of them pick the same word type for the wire -- and, per row, the largest cell this rank
+    //    holds in it (one pass over the rank's own dirty windows): nranks x the all-reduced maximum bounds every merged
+    //    cell of the row, and a row whose bound fits 8 or 16 bits travels at that width (k_merge_widths).  A one-rank
+    //    merge moves nothing between GPUs: no pass over the cells for it.
+    const bool narrow = e->merge_narrow && nranks > 1;
+    const size_t rwords = (size_t)nrows * 3 + 1;
+    rc = ensure_xbuf(e, rwords * sizeof(uint32_t) + 256);
     if (rc) return rc;
     uint32_t *d_tmp = reinterpret_cast<uint32_t *>(e->d_xbuf);
     const uint64_t mine = __atomic_load_n(&b.nsamples, __ATOMIC_RELAXED);
-    HIPCHK(lh::launch_ranges_flip_hi(d_tmp, b.ranges, nrows, true, mine > 0xffffffffull ? 0xffffffffu : (uint32_t)mine,
-                                     st));
-    NCCLCHK(g_allreduce(d_tmp, d_tmp, (size_t)nrows * 2 + 1, kNcclUint32, kNcclMin, comm, st));
+    HIPCHK(lh::launch_merge_prep(d_tmp, b.ranges, b.counts, nrows, mine > 0xffffffffull ? 0xffffffffu : (uint32_t)mine,
+                                 narrow, st));
+    NCCLCHK(g_allreduce(d_tmp, d_tmp, rwords, kNcclUint32, kNcclMin, comm, st));
     HIPCHK(lh::launch_ranges_flip_hi(b.ranges, d_tmp, nrows, false, 0, st)); // (lo, ~~hi) back in place
     HIPCHK(hipEventRecord(e->merge_ev[1], st));
+    const uint32_t *d_extra = d_tmp + (size_t)nrows * 2, *d_rowmaxc = d_extra + 1;
 
     // 2. the window plan, on the device: every row keeps its OWN merged window [lo_r, hi_r]; the windows are
-    //    packed back to back (CSR) and cut into nranks owner blocks of equal packed size.  The host only needs a few
-    //    totals to size the collective; the plan kernel stores them straight into pinned memory and the host spins
-    //    on a completion word (no copy, no stream synchronisation unless the stream is still busy with the
+    //    packed back to back (CSR, in wire words) and cut into nranks owner blocks of equal packed size.  The host only
+    //    needs a few totals to size the collective; the plan kernel stores them straight into pinned memory and the host
+    //    spins on a completion word (no copy, no stream synchronisation unless the stream is still busy with the
     //    interval's ingest after 2 ms).
     const uint32_t nblocks = rs ? (uint32_t)nranks : 1u;
-    uint64_t info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t info[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (e->d_hxbuf) {
-        volatile uint32_t *flag = reinterpret_cast<volatile uint32_t *>(e->h_xbuf + 64);
+        volatile uint32_t *flag = reinterpret_cast<volatile uint32_t *>(e->h_xbuf + 128);
         if (++e->xseq == 0) e->xseq = 1;
         *flag = 0;
-        HIPCHK(lh::launch_merge_plan(b.ranges, nrows, nblocks, (uint32_t)rank, d_tmp + (size_t)nrows * 2, d_P, d_bstart,
-                                     d_brow, d_work, reinterpret_cast<uint64_t *>(e->d_hxbuf),
-                                     reinterpret_cast<uint32_t *>(e->d_hxbuf + 64), e->xseq, st));
+        HIPCHK(lh::launch_merge_plan(b.ranges, nrows, nblocks, (uint32_t)rank, (uint32_t)nranks, d_extra, d_rowmaxc, d_cls,
+                                     d_P, d_bstart, d_brow, d_work, reinterpret_cast<uint64_t *>(e->d_hxbuf),
+                                     reinterpret_cast<uint32_t *>(e->d_hxbuf + 128), e->xseq, st));
         HIPCHK(hipEventRecord(e->merge_ev[2], st));
         const auto t0 = std::chrono::steady_clock::now();
         uint32_t spins = 0;
@@ -1813,30 +1821,34 @@ int lh_snapshot_merge(lh_snapshot *s, void *comm, int nranks, int rank, int plan
         std::atomic_thread_fence(std::memory_order_acquire);
         std::memcpy(info, e->h_xbuf, sizeof(info));
     } else {
-        HIPCHK(lh::launch_merge_plan(b.ranges, nrows, nblocks, (uint32_t)rank, d_tmp + (size_t)nrows * 2, d_P, d_bstart,
-                                     d_brow, d_work, d_info, nullptr, 0, st));
+        HIPCHK(lh::launch_merge_plan(b.ranges, nrows, nblocks, (uint32_t)rank, (uint32_t)nranks, d_extra, d_rowmaxc, d_cls,
+                                     d_P, d_bstart, d_brow, d_work, d_info, nullptr, 0, st));
         HIPCHK(hipEventRecord(e->merge_ev[2], st));
         HIPCHK(hipMemcpyAsync(e->h_xbuf, d_info, sizeof(info), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         std::memcpy(info, e->h_xbuf, sizeof(info));
     }
-    const uint64_t total = info[0], bmax = info[1];
+    const uint64_t total = info[0], bmax = info[1]; // in wire words
     const uint32_t own_lo = rs ? (uint32_t)info[5] : 0u, own_hi = rs ? (uint32_t)info[6] : nrows;
     if (first_owned) *first_owned = own_lo;
     if (last_owned) *last_owned = own_hi;
-    // no merged cell can reach 2^32 when nranks x (the largest per-rank sample count) stays below it
-    const bool cells32 = info[4] < 0xffffffffull && info[4] * (uint64_t)nranks < (uint64_t(1) << 32);
-    const size_t cell = cells32 ? sizeof(uint32_t) : sizeof(uint64_t);
-    e->merge_info.packed_cells = total;
+    // no merged cell can reach 2^32 when nranks x (the largest per-rank sample count) stays below it (the same rule, on
+    // the same all-reduced word, as k_merge_widths applied on the device)
+    const bool words32 = info[4] < 0xffffffffull && info[4] * (uint64_t)nranks < (uint64_t(1) << 32);
+    const size_t word = words32 ? sizeof(uint32_t) : sizeof(uint64_t);
+    e->merge_info.packed_cells = info[7];
+    e->merge_info.packed_words = total;
     e->merge_info.widest_row = (uint32_t)info[2];
     e->merge_info.occupied_rows = (uint32_t)info[3];
-    e->merge_info.padded_cells = rs ? (uint64_t)nranks * bmax : total;
-    e->merge_info.cell_bytes = (uint32_t)cell;
+    e->merge_info.padded_words = rs ? (uint64_t)nranks * bmax : total;
+    e->merge_info.cell_bytes = (uint32_t)word;
+    e->merge_info.rows_8bit = (uint32_t)info[8];
+    e->merge_info.rows_16bit = (uint32_t)info[9];
     if (total == 0) return LH_OK; // nothing anywhere (every rank computes the same plan: no hang)
 
     // 3. pack -> collective -> unpack.  The pack buffer is its own grow-only allocation.
     const uint64_t send_elems = rs ? (uint64_t)nranks * bmax : total, recv_elems = rs ? bmax : 0;
-    const size_t need = (size_t)(send_elems + recv_elems) * cell;
+    const size_t need = (size_t)(send_elems + recv_elems) * word;
     if (need > e->mbuf_bytes) {
         if (e->d_mbuf) (void)hipFree(e->d_mbuf);
         e->d_mbuf = nullptr;
@@ -1845,23 +1857,23 @@ int lh_snapshot_merge(lh_snapshot *s, void *comm, int nranks, int rank, int plan
         HIPCHK(hipMalloc((void **)&e->d_mbuf, cap));
         e->mbuf_bytes = cap;
     }
-    unsigned char *send = reinterpret_cast<unsigned char *>(e->d_mbuf), *recv = send + (size_t)send_elems * cell;
-    e->merge_info.send_bytes = send_elems * cell;
-    e->merge_info.recv_bytes = (rs ? recv_elems : total) * cell;
-    HIPCHK(lh::launch_pack_rows(b.counts, b.ranges, d_P, d_bstart, d_brow, nrows, nblocks, rs ? bmax : total, send,
-                                cells32, st));
+    unsigned char *send = reinterpret_cast<unsigned char *>(e->d_mbuf), *recv = send + (size_t)send_elems * word;
+    e->merge_info.send_bytes = send_elems * word;
+    e->merge_info.recv_bytes = (rs ? recv_elems : total) * word;
+    HIPCHK(lh::launch_pack_rows(b.counts, b.ranges, d_cls, d_P, d_bstart, d_brow, nrows, nblocks, rs ? bmax : total, send,
+                                words32, st));
     HIPCHK(hipEventRecord(e->merge_ev[3], st));
-    const int dt = cells32 ? kNcclUint32 : kNcclUint64;
+    const int dt = words32 ? kNcclUint32 : kNcclUint64;
     if (!rs) {
         NCCLCHK(g_allreduce(send, send, (size_t)total, dt, kNcclSum, comm, st));
         HIPCHK(hipEventRecord(e->merge_ev[4], st));
-        HIPCHK(lh::launch_unpack_rows(b.counts, b.ranges, d_P, d_bstart, 0, 0, nrows, send, cells32, st));
+        HIPCHK(lh::launch_unpack_rows(b.counts, b.ranges, d_cls, d_P, d_bstart, 0, 0, nrows, send, words32, st));
     } else {
         // reduce-scatter by contiguous name blocks of equal packed size, every block padded to the largest one
         NCCLCHK(g_reducescatter(send, recv, (size_t)recv_elems, dt, kNcclSum, comm, st));
         HIPCHK(hipEventRecord(e->merge_ev[4], st));
-        HIPCHK(lh::launch_unpack_rows(b.counts, b.ranges, d_P, d_bstart, (uint32_t)rank, own_lo, own_hi - own_lo, recv,
-                                      cells32, st));
+        HIPCHK(lh::launch_unpack_rows(b.counts, b.ranges, d_cls, d_P, d_bstart, (uint32_t)rank, own_lo, own_hi - own_lo,
+                                      recv, words32, st));
     }
     HIPCHK(hipEventRecord(e->merge_ev[5], st));
     e->merge_events_pending = true;
@@ -2422,6 +2434,9 @@ int lh_set_option(lh_engine *e, int option, uint64_t value)
     case LH_OPT_PART_V3_MIN_PAIRS:
         if (value < (1u << 17) || value > (uint64_t(1) << 31)) return LH_EINVAL;
         return set_tune(e, [&](lh::PartTuning &t) { t.v3_min_samples = (size_t)value; });
+    case LH_OPT_PART_V3_DIRECT_MAX_PAIRS:
+        if (value > (uint64_t(1) << 30)) return LH_EINVAL;
+        return set_tune(e, [&](lh::PartTuning &t) { t.v3_direct_max = (size_t)value; });
     case LH_OPT_PART_V3_LOG_W:
         if (value != 0 && (value < 10 || value > 13)) return LH_EINVAL;
         return set_tune(e, [&](lh::PartTuning &t) {
@@ -2451,6 +2466,12 @@ int lh_set_option(lh_engine *e, int option, uint64_t value)
         e->lane_gen3 = value != 0;
         e->lane_g1_cap = value > 1 ? (uint32_t)value : lh::kLaneLevel1Workgroups;
         e->lane_tables.t[0].valid = e->lane_tables.t[1].valid = false;
+        return LH_OK;
+    }
+    case LH_OPT_MERGE_NARROW_CELLS: {
+        if (value > 1) return LH_EINVAL;
+        std::lock_guard<std::mutex> g(e->xmu);
+        e->merge_narrow = value != 0;
         return LH_OK;
     }
     case LH_OPT_FAIL_SCRATCH_ALLOCS:

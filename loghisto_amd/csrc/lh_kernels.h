@@ -67,6 +67,8 @@ struct PartTuning {
     bool v3 = true;                 // hashed survey + region scatter + in-place second level (lh_kernels_part3.h) for 8 193 .. 65 536 names
     size_t v3_min_samples = 0;      // 0 = default (2^24)
     uint32_t v3_log_w = 10;         // log2 of the second level's window width, 10 .. 13: the engine follows the survey's report
+    size_t v3_direct_max = 0;       // third generation: launches of at most this many pairs end in k_part_direct3 (one global
+                                    // atomic per forwarded record) instead of the windowed reduce pass; 0 = default (2^22), 1 = never
     uint32_t v3_g1_cap = 0;         // third generation: at most this many level-1 workgroups (0 = one per CU).  A host-fed
                                     // launch reads its pairs over PCIe: 8 workgroups keep 0.6 MB in flight, several times
                                     // what the link's latency needs, and every level-1 workgroup owns its CU's whole LDS --
@@ -140,21 +142,28 @@ hipError_t launch_compact_cells(const uint64_t *counts, const uint32_t *ranges, 
 // complement is the largest `extra` of any rank).
 hipError_t launch_ranges_flip_hi(uint32_t *dst, const uint32_t *src, uint32_t nrows, bool with_extra, uint32_t extra,
                                  hipStream_t s);
-// Per-row windows packed CSR: P[nrows+1] exclusive prefix of the merged window widths; the nblocks owner blocks are
-// contiguous row ranges of equal PACKED size: brow[nblocks+1] their first rows, bstart[nblocks+1] the prefix there.
-// info[8] = {total cells, largest block, widest row, occupied rows, ~extra_src[0], first row and end row of block
-// `rank`, 0}; host_flag (device mapping of pinned memory, or null) receives `seq` after info is stored.
-// work: scratch of 3 072 uint64 for the per-row-block partial sums (three kernels: widths, plan, finish).
-hipError_t launch_merge_plan(const uint32_t *ranges, uint32_t nrows, uint32_t nblocks, uint32_t rank,
-                             const uint32_t *extra_src, uint64_t *P, uint64_t *bstart, uint32_t *brow, uint64_t *work,
-                             uint64_t *info, uint32_t *host_flag, uint32_t seq, hipStream_t s);
-// buf[k * bstride + ...]: block k's rows back to back, the rest of each block zeroed; cells32: uint32 cells on the wire.
-hipError_t launch_pack_rows(const uint64_t *counts, const uint32_t *ranges, const uint64_t *P, const uint64_t *bstart,
-                            const uint32_t *brow, uint32_t nrows, uint32_t nblocks, uint64_t bstride, void *buf,
-                            bool cells32, hipStream_t s);
-hipError_t launch_unpack_rows(uint64_t *counts, const uint32_t *ranges, const uint64_t *P, const uint64_t *bstart,
-                              uint32_t kblock, uint32_t first_row, uint32_t nrows_out, const void *buf, bool cells32,
-                              hipStream_t s);
+// The merge's first step: dst = (lo, ~hi) per row | ~extra | ~(row r's largest cell on this rank, clipped to 2^32 - 1) per
+// row -- 3 * nrows + 1 words for ONE MIN all-reduce.  narrow == false: the third part is written as 0 (no cell is read).
+hipError_t launch_merge_prep(uint32_t *dst, const uint32_t *ranges, const uint64_t *counts, uint32_t nrows, uint32_t extra,
+                             bool narrow, hipStream_t s);
+// Per-row windows packed CSR, in WIRE WORDS: uint64 (one cell each), or uint32 when nranks x ~extra_src[0] < 2^32 -- then
+// row r travels at cls[r] = 8, 16 or 32 bits per cell, the narrowest that holds nranks x ~rowmaxc[r] (the all-reduced
+// largest per-rank cell of the row; rowmaxc null: 32).  P[nrows+1] = exclusive prefix of the rows' words; the nblocks
+// owner blocks are contiguous row ranges of equal PACKED size: brow[nblocks+1] their first rows, bstart[nblocks+1] the
+// prefix there.  info[16] = {total words, largest block (words), widest row (cells), occupied rows, ~extra_src[0], first
+// row and end row of block `rank`, total cells, rows at 8 bits, rows at 16 bits}; host_flag (device mapping of pinned
+// memory, or null) receives `seq` after info is stored.  work: scratch of 5 120 uint64 (per-row-block partial sums).
+hipError_t launch_merge_plan(const uint32_t *ranges, uint32_t nrows, uint32_t nblocks, uint32_t rank, uint32_t nranks,
+                             const uint32_t *extra_src, const uint32_t *rowmaxc, uint8_t *cls, uint64_t *P,
+                             uint64_t *bstart, uint32_t *brow, uint64_t *work, uint64_t *info, uint32_t *host_flag,
+                             uint32_t seq, hipStream_t s);
+// buf[k * bstride + ...]: block k's rows back to back, the rest of each block zeroed; words32: uint32 words on the wire.
+hipError_t launch_pack_rows(const uint64_t *counts, const uint32_t *ranges, const uint8_t *cls, const uint64_t *P,
+                            const uint64_t *bstart, const uint32_t *brow, uint32_t nrows, uint32_t nblocks,
+                            uint64_t bstride, void *buf, bool words32, hipStream_t s);
+hipError_t launch_unpack_rows(uint64_t *counts, const uint32_t *ranges, const uint8_t *cls, const uint64_t *P,
+                              const uint64_t *bstart, uint32_t kblock, uint32_t first_row, uint32_t nrows_out,
+                              const void *buf, bool words32, hipStream_t s);
 
 // K6 (lh_kernels_fmt.hip): ProcessedMetricSet keys + Go "%f" + wire lines, one thread per (metric, key).
 struct SerKey { uint16_t pre_off, pre_len, post_off, post_len; }; // key = pre + name + post, strings in the blob

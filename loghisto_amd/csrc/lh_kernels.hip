@@ -489,6 +489,13 @@ __device__ __forceinline__ uint64_t shfl_up_u64(uint64_t x, int d)
     hi = __shfl_up(hi, d, 64);
     return ((uint64_t)hi << 32) | lo;
 }
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t x, int d)
+{
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    lo = __shfl_xor(lo, d, 64);
+    hi = __shfl_xor(hi, d, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
 __device__ __forceinline__ uint64_t shfl_down_u64(uint64_t x, int d)
 {
     uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
@@ -962,6 +969,33 @@ __global__ void k_ranges_flip_hi(uint32_t *__restrict__ dst, const uint32_t *__r
     if (i == 0 && with_extra) dst[2 * (size_t)nrows] = ~extra;
 }
 
+// The same with one more word per row for the narrow wire cells (k_merge_widths): dst[2 * nrows + 1 + r] = ~(the largest
+// cell of row r on THIS rank, clipped to 2^32 - 1), so that the one MIN all-reduce also returns every row's largest
+// per-rank cell.  One wave per row over the row's own dirty window.  narrow == 0: the words are written as 0 ("unknown":
+// the all-reduced maximum reads 2^32 - 1 on EVERY rank, whichever rank switched the narrow cells off) and no cell is read.
+__global__ __launch_bounds__(256) void k_merge_prep(uint32_t *__restrict__ dst, const uint32_t *__restrict__ ranges,
+                                                    const uint64_t *__restrict__ counts, uint32_t nrows,
+                                                    uint32_t extra, uint32_t narrow)
+{
+    const uint32_t lane = threadIdx.x & 63u, r = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (r >= nrows) return;
+    const uint32_t lo = ranges[2 * (size_t)r], hi = ranges[2 * (size_t)r + 1];
+    unsigned long long m = 0;
+    if (narrow && lo <= hi) {
+        const uint64_t *src = counts + (size_t)r * LH_ROW_STRIDE + lo;
+        for (uint32_t i = lane; i <= hi - lo; i += 64u) m = max(m, (unsigned long long)src[i]);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m = max(m, shfl_xor_u64(m, d));
+    }
+    if (lane == 0) {
+        dst[2 * (size_t)r] = lo;
+        dst[2 * (size_t)r + 1] = ~hi;
+        const uint32_t clipped = m > 0xffffffffull ? 0xffffffffu : (uint32_t)m;
+        dst[2 * (size_t)nrows + 1 + r] = narrow ? ~clipped : 0u;
+        if (r == 0) dst[2 * (size_t)nrows] = ~extra;
+    }
+}
+
 // ---- per-row windows, packed CSR ---------------------------------------------------------------
 // After the range merge every rank holds the same [lo_r, hi_r] for every row r.  Only those cells
 // travel: row r contributes w_r = hi_r - lo_r + 1 cells (0 when empty), packed back to back.  A single
@@ -982,19 +1016,37 @@ constexpr int MP_BLOCK = 1024;
 // btot / bmaxw / bocc [block] = the block's total, widest window and occupied rows.  (One workgroup walking all
 // 65 536 rows with 64 rows per thread took 124 us: strided loads, twice.)
 __global__ __launch_bounds__(MP_BLOCK) void k_merge_widths(const uint32_t *__restrict__ ranges, uint32_t nrows,
+                                                           const uint32_t *__restrict__ extra_src,
+                                                           const uint32_t *__restrict__ rowmaxc, uint32_t nranks,
+                                                           uint8_t *__restrict__ cls,
                                                            unsigned long long *__restrict__ P,
                                                            unsigned long long *__restrict__ btot,
-                                                           uint32_t *__restrict__ bmaxw, uint32_t *__restrict__ bocc)
+                                                           unsigned long long *__restrict__ bcells,
+                                                           uint32_t *__restrict__ bmaxw, uint32_t *__restrict__ bocc,
+                                                           uint32_t *__restrict__ bn8, uint32_t *__restrict__ bn16)
 {
-    __shared__ uint32_t s_w[MP_BLOCK / 64], s_maxw[MP_BLOCK / 64], s_occ[MP_BLOCK / 64];
+    __shared__ uint32_t s_w[MP_BLOCK / 64], s_c[MP_BLOCK / 64], s_maxw[MP_BLOCK / 64], s_occ[MP_BLOCK / 64],
+        s_n8[MP_BLOCK / 64], s_n16[MP_BLOCK / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t r = blockIdx.x * MP_BLOCK + tid;
-    uint32_t w = 0;
+    // the wire word: uint32 when no merged cell of the interval can reach 2^32 (nranks x the largest per-rank sample
+    // count, which rides behind the ranges), else one uint64 per cell
+    const unsigned long long big = extra_src ? (unsigned long long)(~extra_src[0]) : ~0ull;
+    const bool words32 = big < 0xffffffffull && big * nranks < (1ull << 32);
+    uint32_t w = 0, ww = 0, bits = words32 ? 32u : 64u;
     if (r < nrows) {
         const uint32_t lo = ranges[2 * (size_t)r], hi = ranges[2 * (size_t)r + 1];
         w = lo <= hi ? hi - lo + 1 : 0u;
+        if (words32 && rowmaxc) {
+            // no merged cell of this row exceeds nranks x (the largest cell any rank holds in it)
+            const unsigned long long bound = (unsigned long long)(~rowmaxc[r]) * nranks;
+            bits = bound <= 0xffull ? 8u : bound <= 0xffffull ? 16u : 32u;
+        }
+        ww = bits == 64u ? w : (uint32_t)(((unsigned long long)w * bits + 31u) >> 5);
+        if (cls) cls[r] = (uint8_t)bits;
     }
-    uint32_t inc = w, maxw = w, occ = w != 0; // a block's total is at most 1 024 x 65 536 = 2^26
+    uint32_t inc = ww, cinc = w, maxw = w, occ = w != 0, n8 = w != 0 && bits == 8u, n16 = w != 0 && bits == 16u;
+    // (a block's total is at most 1 024 x 65 536 = 2^26 words or cells)
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const uint32_t y = __shfl_up(inc, d, 64);
@@ -1004,19 +1056,32 @@ __global__ __launch_bounds__(MP_BLOCK) void k_merge_widths(const uint32_t *__res
     for (int d = 32; d >= 1; d >>= 1) {
         maxw = max(maxw, (uint32_t)__shfl_xor(maxw, d, 64));
         occ += __shfl_xor(occ, d, 64);
+        cinc += __shfl_xor(cinc, d, 64);
+        n8 += __shfl_xor(n8, d, 64);
+        n16 += __shfl_xor(n16, d, 64);
     }
     if (lane == 63) s_w[wave] = inc;
-    if (lane == 0) { s_maxw[wave] = maxw; s_occ[wave] = occ; }
+    if (lane == 0) { s_maxw[wave] = maxw; s_occ[wave] = occ; s_c[wave] = cinc; s_n8[wave] = n8; s_n16[wave] = n16; }
     __syncthreads();
-    uint32_t base = 0, total = 0, gmax = 0, gocc = 0;
+    uint32_t base = 0, total = 0, ctotal = 0, gmax = 0, gocc = 0, g8 = 0, g16 = 0;
     for (uint32_t k = 0; k < MP_BLOCK / 64; k++) {
         if (k < wave) base += s_w[k];
         total += s_w[k];
+        ctotal += s_c[k];
         gmax = max(gmax, s_maxw[k]);
         gocc += s_occ[k];
+        g8 += s_n8[k];
+        g16 += s_n16[k];
     }
-    if (r < nrows) P[r] = base + inc - w;
-    if (tid == 0) { btot[blockIdx.x] = total; bmaxw[blockIdx.x] = gmax; bocc[blockIdx.x] = gocc; }
+    if (r < nrows) P[r] = base + inc - ww;
+    if (tid == 0) {
+        btot[blockIdx.x] = total;
+        bcells[blockIdx.x] = ctotal;
+        bmaxw[blockIdx.x] = gmax;
+        bocc[blockIdx.x] = gocc;
+        bn8[blockIdx.x] = g8;
+        bn16[blockIdx.x] = g16;
+    }
 }
 
 // Step 2 (one workgroup; at most MP_BLOCK row blocks = 2^20 rows): the row blocks' bases, the totals, and the nblocks
@@ -1036,19 +1101,23 @@ __global__ __launch_bounds__(MP_BLOCK) void k_merge_plan(uint32_t nrows, uint32_
                                                          const unsigned long long *__restrict__ btot,
                                                          const uint32_t *__restrict__ bmaxw,
                                                          const uint32_t *__restrict__ bocc,
+                                                         const unsigned long long *__restrict__ bcells,
+                                                         const uint32_t *__restrict__ bn8,
+                                                         const uint32_t *__restrict__ bn16,
                                                          unsigned long long *__restrict__ bbase,
                                                          unsigned long long *__restrict__ bstart /*[nblocks+1]*/,
                                                          uint32_t *__restrict__ brow /*[nblocks+1]*/,
-                                                         unsigned long long *__restrict__ info /*[8]*/,
+                                                         unsigned long long *__restrict__ info /*[16]*/,
                                                          uint32_t *__restrict__ host_flag, uint32_t seq)
 {
-    __shared__ unsigned long long s_base[MP_BLOCK], s_wsum[MP_BLOCK / 64], s_bmax;
-    __shared__ uint32_t s_maxw[MP_BLOCK / 64], s_occ[MP_BLOCK / 64];
+    __shared__ unsigned long long s_base[MP_BLOCK], s_wsum[MP_BLOCK / 64], s_csum[MP_BLOCK / 64], s_bmax;
+    __shared__ uint32_t s_maxw[MP_BLOCK / 64], s_occ[MP_BLOCK / 64], s_n8[MP_BLOCK / 64], s_n16[MP_BLOCK / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t nrb = (nrows + MP_BLOCK - 1) / MP_BLOCK; // row blocks (<= MP_BLOCK: the launcher checks)
     const unsigned long long mine = tid < nrb ? btot[tid] : 0ull;
     uint32_t maxw = tid < nrb ? bmaxw[tid] : 0u, occ = tid < nrb ? bocc[tid] : 0u;
-    unsigned long long inc = mine;
+    uint32_t n8 = tid < nrb ? bn8[tid] : 0u, n16 = tid < nrb ? bn16[tid] : 0u;
+    unsigned long long inc = mine, csum = tid < nrb ? bcells[tid] : 0ull;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const unsigned long long y = shfl_up_u64(inc, d);
@@ -1058,18 +1127,24 @@ __global__ __launch_bounds__(MP_BLOCK) void k_merge_plan(uint32_t nrows, uint32_
     for (int d = 32; d >= 1; d >>= 1) {
         maxw = max(maxw, (uint32_t)__shfl_xor(maxw, d, 64));
         occ += __shfl_xor(occ, d, 64);
+        n8 += __shfl_xor(n8, d, 64);
+        n16 += __shfl_xor(n16, d, 64);
+        csum += shfl_xor_u64(csum, d);
     }
     if (lane == 63) s_wsum[wave] = inc;
-    if (lane == 0) { s_maxw[wave] = maxw; s_occ[wave] = occ; }
+    if (lane == 0) { s_maxw[wave] = maxw; s_occ[wave] = occ; s_n8[wave] = n8; s_n16[wave] = n16; s_csum[wave] = csum; }
     if (tid == 0) s_bmax = 0;
     __syncthreads();
-    unsigned long long base = 0, total = 0;
-    uint32_t gmax = 0, gocc = 0;
+    unsigned long long base = 0, total = 0, ctotal = 0;
+    uint32_t gmax = 0, gocc = 0, g8 = 0, g16 = 0;
     for (uint32_t w = 0; w < MP_BLOCK / 64; w++) {
         if (w < wave) base += s_wsum[w];
         total += s_wsum[w];
+        ctotal += s_csum[w];
         gmax = max(gmax, s_maxw[w]);
         gocc += s_occ[w];
+        g8 += s_n8[w];
+        g16 += s_n16[w];
     }
     s_base[tid] = base + inc - mine;
     if (tid < nrb) bbase[tid] = base + inc - mine;
@@ -1101,7 +1176,9 @@ __global__ __launch_bounds__(MP_BLOCK) void k_merge_plan(uint32_t nrows, uint32_
         info[4] = extra_src ? (unsigned long long)(~extra_src[0]) : ~0ull;
         info[5] = brow[min(rank, nblocks)];
         info[6] = brow[min(rank + 1u, nblocks)];
-        info[7] = 0;
+        info[7] = ctotal;
+        info[8] = g8;
+        info[9] = g16;
         if (host_flag) {
             __threadfence_system();
             __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1131,52 +1208,98 @@ __device__ __forceinline__ uint32_t merge_block_of(const uint32_t *__restrict__ 
 }
 
 // Row r's window <-> buf[k * bstride + (P[r] - bstart[k]) ...], k = the row's owner block.  One workgroup per row.
-// CELL is the wire type: uint64_t, or uint32_t when no merged cell can reach 2^32 (lh_snapshot_merge decides).
-template <typename CELL>
+// WORD is the wire word: uint64_t (one cell per word), or uint32_t when no merged cell of the interval can reach 2^32.
+// In uint32 words a row travels at cls[r] = 8, 16 or 32 bits per cell (k_merge_widths: nranks x the largest cell any
+// rank holds in the row fits that many bits, so the collective's uint32 SUM never carries from one field of a word
+// into the next): cells 4j .. 4j + 3 (8 bits) or 2j, 2j + 1 (16 bits) of the window are word j, low field first.
+// Every thread loads / stores ONE cell (coalesced uint64 accesses on the row store's side); the 2 or 4 lanes of a word
+// combine their fields with DPP shuffles and the first of them writes it.
+template <typename WORD>
 __global__ __launch_bounds__(256) void k_pack_rows(const uint64_t *__restrict__ counts,
                                                    const uint32_t *__restrict__ ranges,
+                                                   const uint8_t *__restrict__ cls,
                                                    const unsigned long long *__restrict__ P,
                                                    const unsigned long long *__restrict__ bstart,
                                                    const uint32_t *__restrict__ brow, uint32_t nblocks,
-                                                   unsigned long long bstride, CELL *__restrict__ buf)
+                                                   unsigned long long bstride, WORD *__restrict__ buf)
 {
     const uint32_t r = blockIdx.x;
     const uint32_t lo = ranges[2 * (size_t)r], hi = ranges[2 * (size_t)r + 1];
     if (lo > hi) return;
     const uint32_t k = merge_block_of(brow, nblocks, r);
-    CELL *dst = buf + (size_t)k * bstride + (P[r] - bstart[k]);
+    WORD *dst = buf + (size_t)k * bstride + (P[r] - bstart[k]);
     const uint64_t *src = counts + (size_t)r * LH_ROW_STRIDE + lo;
-    for (uint32_t i = threadIdx.x; i <= hi - lo; i += 256) dst[i] = (CELL)src[i];
+    const uint32_t w = hi - lo + 1;
+    if constexpr (sizeof(WORD) == 8) {
+        for (uint32_t i = threadIdx.x; i < w; i += 256) dst[i] = src[i];
+    } else {
+        const uint32_t bits = cls[r];
+        if (bits == 32u) {
+            for (uint32_t i = threadIdx.x; i < w; i += 256) dst[i] = (uint32_t)src[i];
+        } else {
+            const uint32_t log_c = bits == 8u ? 2u : 1u, c = 1u << log_c; // cells per word
+            const uint32_t wpad = (w + c - 1u) & ~(c - 1u);                // (whole waves run the shuffles: 256 % c == 0)
+            for (uint32_t i0 = 0; i0 < wpad; i0 += 256) {
+                const uint32_t i = i0 + threadIdx.x;
+                uint32_t f = i < w ? (uint32_t)src[i] << ((i & (c - 1u)) * bits) : 0u;
+                f |= __shfl_xor(f, 1, 64);
+                if (log_c == 2u) f |= __shfl_xor(f, 2, 64);
+                if (i < wpad && (i & (c - 1u)) == 0u) dst[i >> log_c] = f;
+            }
+        }
+    }
 }
 
 // Zero the tail of every owner block of the send buffer (blocks are padded to the largest one).
-template <typename CELL>
+template <typename WORD>
 __global__ __launch_bounds__(256) void k_pack_pad(const unsigned long long *__restrict__ bstart, uint32_t nblocks,
-                                                  unsigned long long bstride, CELL *__restrict__ buf)
+                                                  unsigned long long bstride, WORD *__restrict__ buf)
 {
     const uint32_t k = blockIdx.y;
     if (k >= nblocks) return;
     const unsigned long long used = bstart[k + 1] - bstart[k];
-    CELL *dst = buf + (size_t)k * bstride;
+    WORD *dst = buf + (size_t)k * bstride;
     for (unsigned long long i = used + (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < bstride;
          i += (unsigned long long)gridDim.x * 256)
         dst[i] = 0;
 }
 
 // buf holds block `kblock` (rows first_row .. first_row + nrows_out) packed from offset 0.
-template <typename CELL>
+template <typename WORD>
 __global__ __launch_bounds__(256) void k_unpack_rows(uint64_t *__restrict__ counts,
                                                      const uint32_t *__restrict__ ranges,
+                                                     const uint8_t *__restrict__ cls,
                                                      const unsigned long long *__restrict__ P,
                                                      const unsigned long long *__restrict__ bstart, uint32_t kblock,
-                                                     uint32_t first_row, const CELL *__restrict__ buf)
+                                                     uint32_t first_row, const WORD *__restrict__ buf)
 {
     const uint32_t r = first_row + blockIdx.x;
     const uint32_t lo = ranges[2 * (size_t)r], hi = ranges[2 * (size_t)r + 1];
     if (lo > hi) return;
-    const CELL *src = buf + (P[r] - bstart[kblock]);
+    const WORD *src = buf + (P[r] - bstart[kblock]);
     uint64_t *dst = counts + (size_t)r * LH_ROW_STRIDE + lo;
-    for (uint32_t i = threadIdx.x; i <= hi - lo; i += 256) dst[i] = (uint64_t)src[i];
+    const uint32_t w = hi - lo + 1;
+    if constexpr (sizeof(WORD) == 8) {
+        for (uint32_t i = threadIdx.x; i < w; i += 256) dst[i] = src[i];
+    } else {
+        const uint32_t bits = cls[r];
+        if (bits == 32u) {
+            for (uint32_t i = threadIdx.x; i < w; i += 256) dst[i] = (uint64_t)src[i];
+        } else {
+            const uint32_t log_c = bits == 8u ? 2u : 1u, c = 1u << log_c, mask = (1u << bits) - 1u;
+            for (uint32_t i = threadIdx.x; i < w; i += 256)
+                dst[i] = (uint64_t)((src[i >> log_c] >> ((i & (c - 1u)) * bits)) & mask);
+        }
+    }
+}
+
+hipError_t launch_merge_prep(uint32_t *dst, const uint32_t *ranges, const uint64_t *counts, uint32_t nrows, uint32_t extra,
+                             bool narrow, hipStream_t s)
+{
+    if (!nrows) return hipSuccess;
+    hipLaunchKernelGGL(k_merge_prep, dim3((nrows + 3) / 4), dim3(256), 0, s, dst, ranges, counts, nrows, extra,
+                       narrow ? 1u : 0u);
+    return hipGetLastError();
 }
 
 hipError_t launch_ranges_flip_hi(uint32_t *dst, const uint32_t *src, uint32_t nrows, bool with_extra, uint32_t extra,
@@ -1188,39 +1311,43 @@ hipError_t launch_ranges_flip_hi(uint32_t *dst, const uint32_t *src, uint32_t nr
     return hipGetLastError();
 }
 
-hipError_t launch_merge_plan(const uint32_t *ranges, uint32_t nrows, uint32_t nblocks, uint32_t rank,
-                             const uint32_t *extra_src, uint64_t *P, uint64_t *bstart, uint32_t *brow, uint64_t *work,
-                             uint64_t *info, uint32_t *host_flag, uint32_t seq, hipStream_t s)
+hipError_t launch_merge_plan(const uint32_t *ranges, uint32_t nrows, uint32_t nblocks, uint32_t rank, uint32_t nranks,
+                             const uint32_t *extra_src, const uint32_t *rowmaxc, uint8_t *cls, uint64_t *P,
+                             uint64_t *bstart, uint32_t *brow, uint64_t *work, uint64_t *info, uint32_t *host_flag,
+                             uint32_t seq, hipStream_t s)
 {
     const uint32_t nrb = (nrows + MP_BLOCK - 1) / MP_BLOCK;
     if (nrows == 0 || nrb > (uint32_t)MP_BLOCK) return hipErrorInvalidValue; // more than 2^20 rows
-    // work: btot[1024] | bbase[1024] (uint64), bmaxw[1024] | bocc[1024] (uint32)
-    unsigned long long *btot = reinterpret_cast<unsigned long long *>(work), *bbase = btot + MP_BLOCK;
-    uint32_t *bmaxw = reinterpret_cast<uint32_t *>(bbase + MP_BLOCK), *bocc = bmaxw + MP_BLOCK;
+    // work: btot[1024] | bbase[1024] | bcells[1024] (uint64), bmaxw[1024] | bocc[1024] | bn8[1024] | bn16[1024] (uint32)
+    unsigned long long *btot = reinterpret_cast<unsigned long long *>(work), *bbase = btot + MP_BLOCK,
+                       *bcells = bbase + MP_BLOCK;
+    uint32_t *bmaxw = reinterpret_cast<uint32_t *>(bcells + MP_BLOCK), *bocc = bmaxw + MP_BLOCK, *bn8 = bocc + MP_BLOCK,
+             *bn16 = bn8 + MP_BLOCK;
     unsigned long long *Pp = reinterpret_cast<unsigned long long *>(P);
-    hipLaunchKernelGGL(k_merge_widths, dim3(nrb), dim3(MP_BLOCK), 0, s, ranges, nrows, Pp, btot, bmaxw, bocc);
+    hipLaunchKernelGGL(k_merge_widths, dim3(nrb), dim3(MP_BLOCK), 0, s, ranges, nrows, extra_src, rowmaxc, nranks, cls, Pp,
+                       btot, bcells, bmaxw, bocc, bn8, bn16);
     hipLaunchKernelGGL(k_merge_plan, dim3(1), dim3(MP_BLOCK), 0, s, nrows, nblocks, rank, extra_src, Pp, btot, bmaxw,
-                       bocc, bbase, reinterpret_cast<unsigned long long *>(bstart), brow,
+                       bocc, bcells, bn8, bn16, bbase, reinterpret_cast<unsigned long long *>(bstart), brow,
                        reinterpret_cast<unsigned long long *>(info), host_flag, seq);
     hipLaunchKernelGGL(k_merge_finish, dim3(nrb), dim3(MP_BLOCK), 0, s, Pp, bbase, btot, nrows);
     return hipGetLastError();
 }
 
-hipError_t launch_pack_rows(const uint64_t *counts, const uint32_t *ranges, const uint64_t *P, const uint64_t *bstart,
-                            const uint32_t *brow, uint32_t nrows, uint32_t nblocks, uint64_t bstride, void *buf,
-                            bool cells32, hipStream_t s)
+hipError_t launch_pack_rows(const uint64_t *counts, const uint32_t *ranges, const uint8_t *cls, const uint64_t *P,
+                            const uint64_t *bstart, const uint32_t *brow, uint32_t nrows, uint32_t nblocks,
+                            uint64_t bstride, void *buf, bool words32, hipStream_t s)
 {
     if (!nrows) return hipSuccess;
     const unsigned long long *Pp = reinterpret_cast<const unsigned long long *>(P);
     const unsigned long long *bs = reinterpret_cast<const unsigned long long *>(bstart);
-    if (cells32) {
-        hipLaunchKernelGGL(k_pack_rows<uint32_t>, dim3(nrows), dim3(256), 0, s, counts, ranges, Pp, bs, brow, nblocks,
+    if (words32) {
+        hipLaunchKernelGGL(k_pack_rows<uint32_t>, dim3(nrows), dim3(256), 0, s, counts, ranges, cls, Pp, bs, brow, nblocks,
                            (unsigned long long)bstride, static_cast<uint32_t *>(buf));
         if (nblocks > 1)
             hipLaunchKernelGGL(k_pack_pad<uint32_t>, dim3(64, nblocks), dim3(256), 0, s, bs, nblocks,
                                (unsigned long long)bstride, static_cast<uint32_t *>(buf));
     } else {
-        hipLaunchKernelGGL(k_pack_rows<uint64_t>, dim3(nrows), dim3(256), 0, s, counts, ranges, Pp, bs, brow, nblocks,
+        hipLaunchKernelGGL(k_pack_rows<uint64_t>, dim3(nrows), dim3(256), 0, s, counts, ranges, cls, Pp, bs, brow, nblocks,
                            (unsigned long long)bstride, static_cast<uint64_t *>(buf));
         if (nblocks > 1)
             hipLaunchKernelGGL(k_pack_pad<uint64_t>, dim3(64, nblocks), dim3(256), 0, s, bs, nblocks,
@@ -1229,18 +1356,18 @@ hipError_t launch_pack_rows(const uint64_t *counts, const uint32_t *ranges, cons
     return hipGetLastError();
 }
 
-hipError_t launch_unpack_rows(uint64_t *counts, const uint32_t *ranges, const uint64_t *P, const uint64_t *bstart,
-                              uint32_t kblock, uint32_t first_row, uint32_t nrows_out, const void *buf, bool cells32,
-                              hipStream_t s)
+hipError_t launch_unpack_rows(uint64_t *counts, const uint32_t *ranges, const uint8_t *cls, const uint64_t *P,
+                              const uint64_t *bstart, uint32_t kblock, uint32_t first_row, uint32_t nrows_out,
+                              const void *buf, bool words32, hipStream_t s)
 {
     if (!nrows_out) return hipSuccess;
     const unsigned long long *Pp = reinterpret_cast<const unsigned long long *>(P);
     const unsigned long long *bs = reinterpret_cast<const unsigned long long *>(bstart);
-    if (cells32)
-        hipLaunchKernelGGL(k_unpack_rows<uint32_t>, dim3(nrows_out), dim3(256), 0, s, counts, ranges, Pp, bs, kblock,
+    if (words32)
+        hipLaunchKernelGGL(k_unpack_rows<uint32_t>, dim3(nrows_out), dim3(256), 0, s, counts, ranges, cls, Pp, bs, kblock,
                            first_row, static_cast<const uint32_t *>(buf));
     else
-        hipLaunchKernelGGL(k_unpack_rows<uint64_t>, dim3(nrows_out), dim3(256), 0, s, counts, ranges, Pp, bs, kblock,
+        hipLaunchKernelGGL(k_unpack_rows<uint64_t>, dim3(nrows_out), dim3(256), 0, s, counts, ranges, cls, Pp, bs, kblock,
                            first_row, static_cast<const uint64_t *>(buf));
     return hipGetLastError();
 }

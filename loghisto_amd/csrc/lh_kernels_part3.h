@@ -57,6 +57,7 @@ constexpr uint32_t V3_MISSQ = 512;                      // records a tile can qu
 // 1 M / 2 M / 4 M / 8 M pairs 0.17 / 0.30 / 0.36 / 0.41 / 0.49 ms against 0.49 / 0.53 / 0.58 / 0.63 / 0.69) -- lane-sized
 // host-fed launches included.
 constexpr size_t V3_MIN_SAMPLES = size_t(1) << 18;
+constexpr size_t V3_DIRECT_MAX = size_t(1) << 22; // launches up to this many pairs: reduce pass without windows (k_part_direct3)
 constexpr uint32_t SVH_GRID = 256, SVH_SLOTS = 4096;    // hashed survey: 256 workgroups x 2 048 samples
 constexpr uint32_t V3_EXTRA1 = 768;                     // level-1 work slots beyond one per partition
 constexpr uint32_t V3_EXTRA2 = 1024;                    // fine work slots beyond one per fine partition
@@ -1519,6 +1520,42 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
     }
 }
 
+// Reduce pass of a SMALL launch (a host-fed lane's half-buffer: 1 - 2 M pairs over 65 536 names leave a fine partition
+// some hundred records): no windows at all.  k_part_hist3 gives every one of its >= 2 112 slots 128 KiB of LDS to
+// zero, place and flush and a chain of five dependent loads, whatever the slot holds -- 226 us per lane launch with every
+// CU's LDS taken (profiles/r05_hostfed_kernel_trace.txt), which held 16 lanes at 4.2 - 4.3 G pairs/s.  Here every wave
+// walks the level-2 chunk descriptors themselves (no plan, no slots: the tag of a descriptor is the fine partition) and
+// adds each record with three atomics that return nothing.  Alone, a call of 2^21 pairs takes 0.23 ms so against 0.29 ms
+// windowed, one of 2^22 the same either way (0.35 ms), and 16 lanes reach 4.5 - 4.6 G pairs/s (profiles/
+// r05_hostfed_direct_reduce.jsonl, r05_direct_reduce_sweep.txt): the launcher takes this pass up to
+// PartTuning::v3_direct_max pairs (2^22, the largest lane launch).
+__global__ __launch_bounds__(256) void k_part_direct3(const uint32_t *__restrict__ records,
+                                                      const uint32_t *__restrict__ cdesc, uint32_t nchunks,
+                                                      uint32_t nmetrics, uint32_t log_mpp2,
+                                                      const uint8_t *__restrict__ g_inv, uint64_t *__restrict__ counts,
+                                                      uint32_t *__restrict__ ranges)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = gridDim.x * 4u;
+    for (uint32_t c0 = wave * 64u; c0 < nchunks; c0 += nwaves * 64u) {
+        const uint32_t d = c0 + lane < nchunks ? cdesc[c0 + lane] : INVALID;
+        unsigned long long live = __builtin_amdgcn_ballot_w64(d != INVALID && (d & CD_MASK) != 0u);
+        while (live) {
+            const uint32_t k = (uint32_t)__builtin_ctzll(live);
+            live &= live - 1ull;
+            const uint32_t dk = __builtin_amdgcn_readlane(d, k), cn = dk & CD_MASK, q = dk >> CD_SHIFT;
+            const uint32_t p1 = q & (V3_NP - 1u), fine = q >> V3_LOG_NP;
+            const uint32_t *src = records + (size_t)(c0 + k) * CHUNK;
+            const uint8_t *inv = g_inv + p1 * 256u + (fine << log_mpp2);
+            for (uint32_t i = lane; i < cn; i += 64u) {
+                const uint32_t rec = src[i];
+                const uint32_t name = ((uint32_t)inv[(rec >> 16) & 0xffu] << V3_LOG_NP) | p1;
+                if (name < nmetrics) v3_global_add(counts, ranges, name, rec & 0xffffu, 1u); // three atomics, nothing returns
+            }
+        }
+    }
+}
+
 // Last kernel of a launch: the launch's self-metrics (g_stats, device memory, zero again afterwards) are added to the
 // engine's pinned words.  One thread: a system-scope atomic from every workgroup of the passes above cost 0.18 ms
 // per launch (256 of them on one host address).
@@ -1746,11 +1783,18 @@ static hipError_t launch_part3_t(const IDT *d_ids, const double *d_v, size_t n, 
                            L1.cdesc, L1.sorted, L1.part_start, L1.slots, L1.nslots, L1.pool_start, nmetrics, P.kp,
                            P.log_mpp2, P.log_w, P.ns, g_remap, g_inv, g_pt2, S, L2.records, L2.cdesc, counts, ranges,
                            g_stats);
-    e = run_plan(L2, P.nchunks2, P.nq, 0u, P.extra2, s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_part_hist3, dim3(P.nq + P.extra2), dim3(P2_BLOCK), P3_LDS_BYTES, s, L2.records, L2.cdesc,
-                       L2.sorted, L2.part_start, L2.slots, L2.nslots, L2.pc, nmetrics, P.log_mpp2, P.log_w, g_inv, S,
-                       counts, ranges, g_stats);
+    if (n <= (tune.v3_direct_max ? tune.v3_direct_max : V3_DIRECT_MAX)) {
+        // small launch: one global atomic per forwarded record, straight from the level-2 chunks (k_part_direct3)
+        const unsigned g = (unsigned)std::min<size_t>(1024, std::max<size_t>(1, (P.nchunks2 + 255) / 256)); // a wave per 64 descriptors
+        hipLaunchKernelGGL(k_part_direct3, dim3(g), dim3(256), 0, s, L2.records, L2.cdesc, P.nchunks2, nmetrics,
+                           P.log_mpp2, g_inv, counts, ranges);
+    } else {
+        e = run_plan(L2, P.nchunks2, P.nq, 0u, P.extra2, s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_part_hist3, dim3(P.nq + P.extra2), dim3(P2_BLOCK), P3_LDS_BYTES, s, L2.records, L2.cdesc,
+                           L2.sorted, L2.part_start, L2.slots, L2.nslots, L2.pc, nmetrics, P.log_mpp2, P.log_w, g_inv, S,
+                           counts, ranges, g_stats);
+    }
     hipLaunchKernelGGL(k_v3_report, dim3(1), dim3(64), 0, s, g_stats, region_stat, (unsigned long long)n);
     return hipGetLastError();
 }

@@ -61,20 +61,35 @@ def merge_ranges(ranges: torch.Tensor, group=None) -> torch.Tensor:
     return ranges
 
 
-def plan_windows(ranges: torch.Tensor, world: int, plan: str):
+def row_bits(rowmax: torch.Tensor, world: int, largest_rank_count: Optional[int] = None) -> torch.Tensor:
+    """Bits per cell every row travels at on the C-ABI front-end's wire (k_merge_widths): rowmax[r] = the largest cell any
+    rank holds in row r (all-reduced MAX of the per-rank maxima), so world x rowmax[r] bounds every merged cell of the row.
+    64 for every row when world x (the largest per-rank sample count of the interval) does not stay below 2^32."""
+    if largest_rank_count is not None and not (largest_rank_count < 0xffffffff and largest_rank_count * world < (1 << 32)):
+        return torch.full_like(rowmax, 64, dtype=torch.int64)
+    bound = rowmax.to(torch.int64).clamp(max=0xffffffff) * world
+    bits = torch.full_like(bound, 32)
+    bits[bound <= 0xffff] = 16
+    bits[bound <= 0xff] = 8
+    return bits
+
+
+def plan_windows(ranges: torch.Tensor, world: int, plan: str, bits: Optional[torch.Tensor] = None):
     """The window plan of a merge, from the MERGED ranges (identical on every rank).
 
     Every row keeps its own window [lo_r, hi_r]; the windows travel packed back to back, so one outlier
-    sample widens one row (at most 65 536 cells), never the whole matrix.  Returns a dict:
-      width[nrows]    cells of row r (0 when the row is empty everywhere)
-      P[nrows + 1]    exclusive prefix of the widths (P[nrows] = total cells)
+    sample widens one row (at most 65 536 cells), never the whole matrix.  bits[nrows] (row_bits; None: one word per
+    cell): the bits per cell a row travels at -- the plan is laid out in WIRE WORDS, row r taking
+    ceil(width_r x bits_r / 32) uint32 words (bits 64: width_r words of uint64).  Returns a dict:
+      width[nrows]    cells of row r (0 when the row is empty everywhere);  words[nrows] its wire words
+      P[nrows + 1]    exclusive prefix of the words (P[nrows] = total words);  Pc[nrows + 1] the same in cells
       nblocks         owner blocks (reduce-scatter: world; all-reduce: 1)
       brow[nb + 1]    first row of every owner block: brow[0] = 0, brow[nb] = nrows, and block k (0 < k < nb) starts
                       at the first row whose prefix reaches k / nb of the total, i.e. the smallest r with
                       P[r] >= total // nb * k + total % nb * k // nb -- contiguous name ranges of equal PACKED size
                       (RCCL's reduce-scatter pads every block to the largest; with equal name counts and names ranked
                       by frequency block 0 holds the widest windows: 1.2 x padding on config 4's slice, 1.0001 x so)
-      bstart[nb + 1]  P at the block boundaries;  bmax = largest block, in cells
+      bstart[nb + 1]  P at the block boundaries;  bmax = largest block, in words;  bstart_c / bmax_c / total_c: in cells
     The SAME rule as k_merge_plan computes on the device for the C-ABI front-end (lh_snapshot_merge returns
     brow[rank], brow[rank + 1]); tests/_stub_merge_driver.py compares the two at 2 .. 8 ranks.
     """
@@ -82,8 +97,15 @@ def plan_windows(ranges: torch.Tensor, world: int, plan: str):
     lo = ranges[:, 0].to(torch.int64)
     hi = ranges[:, 1].to(torch.int64)
     width = (hi - lo + 1).clamp_(min=0)
+    if bits is None:
+        words = width
+    else:
+        b = bits.to(torch.int64).to(width.device)
+        words = torch.where(b == 64, width, (width * b + 31) >> 5)
     P = torch.zeros(nrows + 1, dtype=torch.int64, device=ranges.device)
-    torch.cumsum(width, 0, out=P[1:])
+    torch.cumsum(words, 0, out=P[1:])
+    Pc = torch.zeros(nrows + 1, dtype=torch.int64, device=ranges.device)
+    torch.cumsum(width, 0, out=Pc[1:])
     total = int(P[-1].item())
     nb = world if plan == "reduce_scatter" else 1
     k = torch.arange(nb + 1, device=ranges.device, dtype=torch.int64)
@@ -91,8 +113,11 @@ def plan_windows(ranges: torch.Tensor, world: int, plan: str):
     brow = torch.searchsorted(P, target, right=False)      # smallest r in [0, nrows] with P[r] >= target
     brow[0], brow[nb] = 0, nrows
     bstart = P[brow]
+    bstart_c = Pc[brow]
     bmax = int((bstart[1:] - bstart[:-1]).max().item()) if nb else 0
-    return dict(lo=lo, width=width, P=P, nblocks=nb, brow=brow, bstart=bstart, bmax=bmax, total=total)
+    bmax_c = int((bstart_c[1:] - bstart_c[:-1]).max().item()) if nb else 0
+    return dict(lo=lo, width=width, words=words, P=P, Pc=Pc, nblocks=nb, brow=brow, bstart=bstart, bmax=bmax, total=total,
+                bstart_c=bstart_c, bmax_c=bmax_c, total_c=int(Pc[-1].item()))
 
 
 def block_of_rows(W: dict, rows: torch.Tensor) -> torch.Tensor:
@@ -118,7 +143,7 @@ last_info = {}   # what the last merge_rows call on this process moved (tests, b
 
 
 def merge_rows(rows: torch.Tensor, ranges: Optional[torch.Tensor] = None, plan: str = "allreduce",
-               group=None) -> Tuple[int, int]:
+               group=None, narrow: bool = True) -> Tuple[int, int]:
     """Sum `rows` (int64[nrows, 65536]) across ranks, in place, moving only each row's merged window.
 
     `rows` may be a strided view: a snapshot's rows are lh_row_stride() cells apart, not 65 536 (snapshot_tensors).
@@ -137,35 +162,51 @@ def merge_rows(rows: torch.Tensor, ranges: Optional[torch.Tensor] = None, plan: 
     last_info.clear()
     if world == 1:
         return 0, nrows
-    W = plan_windows(ranges, world, plan)
-    own = owned_rows(W, rank)
-    total, bmax = W["total"], W["bmax"]
-    last_info.update(packed_cells=total, widest_row=int(W["width"].max().item()) if nrows else 0)
+    # the cells of this rank inside the merged windows, packed position q (0 .. total) -> (row, column)
+    lo0 = ranges[:, 0].to(torch.int64)
+    width0 = (ranges[:, 1].to(torch.int64) - lo0 + 1).clamp_(min=0)
+    total = int(width0.sum().item())
+    last_info.update(packed_cells=total, widest_row=int(width0.max().item()) if nrows else 0)
     if total == 0:
-        return own
-    # packed position q (0 .. total) -> (row, column)
-    row_of = torch.repeat_interleave(torch.arange(nrows, device=rows.device), W["width"], output_size=total)
+        return owned_rows(plan_windows(ranges, world, plan), rank)
+    Pc0 = torch.zeros(nrows + 1, dtype=torch.int64, device=rows.device)
+    torch.cumsum(width0, 0, out=Pc0[1:])
+    row_of = torch.repeat_interleave(torch.arange(nrows, device=rows.device), width0, output_size=total)
     q = torch.arange(total, device=rows.device)
     row_stride = rows.stride(0) if nrows > 1 else NKEYS
-    flat = row_of * row_stride + (q - W["P"][row_of] + W["lo"][row_of])
+    flat = row_of * row_stride + (q - Pc0[row_of] + lo0[row_of])
     cells = torch.as_strided(rows, ((nrows - 1) * row_stride + NKEYS,), (1,))   # every cell from row 0 to the last row's end
+    mine = cells[flat]
+    # the owner blocks are those of the C-ABI front-end: equal shares of the WIRE WORDS, a row travelling at the narrowest
+    # of 8 / 16 / 32 bits per cell that holds world x (its largest per-rank cell) -- one more MAX all-reduce here (the
+    # C ABI lets it ride with the ranges).  This front-end itself moves int64 cells: only the block boundaries follow.
+    bits = None
+    if narrow:
+        rowmax = torch.zeros(nrows, dtype=torch.int64, device=rows.device)
+        rowmax.scatter_reduce_(0, row_of, mine, "amax", include_self=True)
+        dist.all_reduce(rowmax, op=dist.ReduceOp.MAX, group=group)
+        bits = row_bits(rowmax, world)
+    W = plan_windows(ranges, world, plan, bits)
+    own = owned_rows(W, rank)
+    last_info.update(packed_words=W["total"])
     if plan == "allreduce":
         buf = _buffer(rows.device, total)
-        torch.index_select(cells, 0, flat, out=buf)
+        buf.copy_(mine)
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
         cells[flat] = buf
         last_info.update(send_bytes=total * 8, recv_bytes=total * 8)
         return own
     # reduce-scatter by contiguous name blocks of equal packed size, every block padded to the largest one
+    bmax = W["bmax_c"]
     both = _buffer(rows.device, (world + 1) * bmax)
     send, recv = both[: world * bmax], both[world * bmax:]
     send.zero_()
     blk = block_of_rows(W, row_of)
-    send[blk * bmax + (q - W["bstart"][blk])] = cells[flat]
+    send[blk * bmax + (q - W["bstart_c"][blk])] = mine
     dist.reduce_scatter_tensor(recv, send, op=dist.ReduceOp.SUM, group=group)
-    mine = blk == rank
-    cells[flat[mine]] = recv[(q - W["bstart"][blk])[mine]]
-    last_info.update(send_bytes=world * bmax * 8, recv_bytes=bmax * 8, padded_cells=world * bmax,
+    sel = blk == rank
+    cells[flat[sel]] = recv[(q - W["bstart_c"][blk])[sel]]
+    last_info.update(send_bytes=world * bmax * 8, recv_bytes=bmax * 8, padded_words=world * W["bmax"],
                      owned_rows_by_rank=[(int(W["brow"][k]), int(W["brow"][k + 1])) for k in range(world)])
     return own
 

@@ -66,9 +66,16 @@ def run(rank, world, port, plan, nmetrics, n, out_dir, outliers=False):
         else:
             # the ownership the C-ABI front-end returns for the same merged ranges (equal packed cells per block):
             # the rule is stated in tests/test_merge_gloo.py::expected_blocks, independently of merge.py
-            from tests.test_merge_gloo import expected_blocks
+            # -- in WIRE WORDS: a row travels at the narrowest cell width that holds world x its largest per-rank cell
+            from tests.test_merge_gloo import expected_blocks, expected_words
             wr0 = want_ranges.astype(np.int64)
-            brow = expected_blocks(np.clip(wr0[:, 1] - wr0[:, 0] + 1, 0, None), world)
+            rowmax = np.zeros(nmetrics, dtype=np.int64)
+            for r in range(world):
+                a, b = n * r // world, n * (r + 1) // world
+                rowmax = np.maximum(rowmax, rows_and_ranges(ids[a:b], v[a:b], nmetrics)[0].max(axis=1).astype(np.int64))
+            words, _ = expected_words(np.clip(wr0[:, 1] - wr0[:, 0] + 1, 0, None), rowmax, world)
+            assert info["packed_words"] == int(words.sum()) < info["packed_cells"], info
+            brow = expected_blocks(words, world)
             assert (first, last) == (brow[rank], brow[rank + 1]), ((first, last), brow)
             assert info["owned_rows_by_rank"] == [(brow[k], brow[k + 1]) for k in range(world)]
         assert np.array_equal(got[first:last], want_rows[first:last]), "merged rows"

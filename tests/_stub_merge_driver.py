@@ -6,7 +6,10 @@ in-process stand-in for RCCL that reduces the threads' device buffers).  Checked
 WHOLE stream: merged ranges, every cell of the rows a rank ends up owning, extract on the owned rows, the
 bytes that travelled (per-row windows: outliers widen two rows, not the matrix).
 
-usage: python tests/_stub_merge_driver.py NRANKS NROWS PLAN OUTLIERS(0/1)
+The wire: a row travels at 8, 16 or 32 bits per cell, the narrowest that holds nranks x (its largest per-rank cell) --
+the expected class of every row, the packed words and the owner blocks cut on them come from the oracle's per-rank rows.
+
+usage: python tests/_stub_merge_driver.py NRANKS NROWS PLAN OUTLIERS(0/1) [NARROW: 1 on (default), 0 off, 2 off on rank 0 only]
 """
 import ctypes as C
 import json
@@ -23,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     nranks, M, plan, outliers = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
+    narrow = int(sys.argv[5]) if len(sys.argv) > 5 else 1
     import torch
     import loghisto_amd
     import oracle
@@ -41,6 +45,7 @@ def main():
     v = rng.lognormal(math.log(1e5) + 0.002 * ids, 1.0)
     if M > 4:
         ids[ids == 3] = 2                                   # row 3 is empty on every rank
+        v[ids == 1] = 1234.5                                # name 1 in ONE cell: the largest counts of the matrix
     if outliers:
         v[n // 3], ids[n // 3] = 1e140, 0                  # one +1e140 sample in name 0
         v[2 * n // 3], ids[2 * n // 3] = -5e6, M - 1       # one negative sample in the last name
@@ -54,10 +59,16 @@ def main():
     engines = [loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16)
                for _ in range(nranks)]
     snaps = []
+    rowmax = np.zeros(M, dtype=np.int64)                    # the largest cell any rank holds in a row
+    largest_rank = 0
     for r, e in enumerate(engines):
         lo, hi = n * r // nranks, n * (r + 1) // nranks    # data-parallel slice, all names
         if hi > lo:
             e.submit_pairs(ids[lo:hi], v[lo:hi])
+            rowmax = np.maximum(rowmax, oracle.histogram_pairs(ids[lo:hi], v[lo:hi], M).max(axis=1).astype(np.int64))
+        largest_rank = max(largest_rank, hi - lo)
+        if narrow == 0 or (narrow == 2 and r == 0):
+            e.set_option(N.OPT_MERGE_NARROW_CELLS, 0)       # one rank is enough: the bound is all-reduced
         snaps.append(e.flip())
     results, errors = [None] * nranks, []
 
@@ -80,8 +91,10 @@ def main():
     widths = np.where(want_ranges[:, 0] <= want_ranges[:, 1], want_ranges[:, 1] - want_ranges[:, 0] + 1, 0)
     # ONE merge plan: the torch front-end's plan (loghisto_amd.merge.plan_windows) from the same merged ranges must give
     # every rank the [first, last) that k_merge_plan gave it on the device, and the same padded block size
+    bits = merge.row_bits(torch.from_numpy(rowmax), nranks, largest_rank) if narrow == 1 else None
     W = merge.plan_windows(torch.from_numpy(want_ranges.astype(np.int32)), nranks,
-                           "allreduce" if plan == "allreduce" else "reduce_scatter")
+                           "allreduce" if plan == "allreduce" else "reduce_scatter", bits)
+    words = W["words"].numpy()
     for r in range(nranks):
         assert tuple(results[r]) == merge.owned_rows(W, r), (r, results[r], merge.owned_rows(W, r))
     for r in range(nranks):
@@ -89,25 +102,39 @@ def main():
         if plan == "allreduce":
             assert (first, last) == (0, M)
         else:
-            # owner blocks tile [0, M) in rank order and hold equal shares of the PACKED cells (at most one row's
+            # owner blocks tile [0, M) in rank order and hold equal shares of the PACKED words (at most one row's
             # window more or less), not equal numbers of names
             assert first == (results[r - 1][1] if r else 0) and last >= first, (r, results)
             if r == nranks - 1:
                 assert last == M
-            share = int(widths[first:last].sum())
-            assert abs(share - cells / nranks) <= int(widths.max()) + 1, (r, share, cells / nranks)
+            share = int(words[first:last].sum())
+            assert abs(share - W["total"] / nranks) <= int(words.max()) + 1, (r, share, W["total"] / nranks)
         covered.extend(range(first, last))
         snap = snaps[r]
         info = snap.merge_info()
         infos.append(info)
         assert info["packed_cells"] == cells, (info, cells)
-        # every test stream is far below 2^32 samples: cells travel as uint32, and the equal-block collective pays
+        # every test stream is far below 2^32 samples: the wire word is uint32, and the equal-block collective pays
         # at most one row's window per block over the packed matrix (ratio <= 1.3)
         assert info["cell_bytes"] == 4, info
-        assert info["padded_cells"] >= cells
-        assert info["padded_cells"] == W["bmax"] * W["nblocks"], (info, W["bmax"], W["nblocks"])
-        if plan != "allreduce" and cells > 100 * int(widths.max()):
-            assert info["padded_cells"] <= 1.3 * cells, info
+        assert info["packed_words"] == W["total"], (info, W["total"])
+        assert info["padded_words"] >= info["packed_words"]
+        assert info["padded_words"] == W["bmax"] * W["nblocks"], (info, W["bmax"], W["nblocks"])
+        if plan != "allreduce" and W["total"] > 100 * int(words.max()):
+            assert info["padded_words"] <= 1.3 * W["total"], info
+        occupied = widths > 0
+        if bits is None:
+            assert info["rows_8bit"] == 0 and info["rows_16bit"] == 0 and info["packed_words"] == cells, info
+        else:
+            b = bits.numpy()
+            assert info["rows_8bit"] == int((occupied & (b == 8)).sum()), (info, np.unique(b, return_counts=True))
+            assert info["rows_16bit"] == int((occupied & (b == 16)).sum()), (info, np.unique(b, return_counts=True))
+            assert info["rows_8bit"] + info["rows_16bit"] > 0 and info["packed_words"] <= 0.6 * cells, info
+            if M >= 37:
+                assert info["rows_8bit"] > 0.5 * M, info    # most names of a Zipf stream hold small counts
+            if M > 4:
+                assert b[1] > 8                             # the one-cell name travels wider than its neighbours
+        assert info["send_bytes"] == 4 * (info["padded_words"] if plan != "allreduce" else info["packed_words"]), info
         assert info["span_ms"] > 0 and info["collective_ms"] >= 0 and info["pack_ms"] >= 0, info
         assert info["occupied_rows"] == int((want_ranges[:, 0] <= want_ranges[:, 1]).sum())
         # merged ranges: identical on every rank, for every row
@@ -133,7 +160,8 @@ def main():
     for e in engines:
         e.close()
     stub.stub_comm_destroy(nranks, comms)
-    print(json.dumps({"ok": True, "nranks": nranks, "rows": M, "plan": plan, "outliers": outliers, **infos[0]}))
+    print(json.dumps({"ok": True, "nranks": nranks, "rows": M, "plan": plan, "outliers": outliers, "narrow": narrow,
+                      **infos[0]}))
 
 
 if __name__ == "__main__":

@@ -39,7 +39,8 @@ def test_the_public_header_keeps_only_the_operational_options():
         return dict((k, int(v)) for k, v in re.findall(r"\b(LH_OPT_[A-Z0-9_]+)\s*=\s*(\d+)", src))
     pub, tun = keys("loghisto_gpu.h"), keys("loghisto_gpu_tuning.h")
     assert sorted(pub) == ["LH_OPT_EXTRACT_ZERO_COPY", "LH_OPT_LANE_SCRATCH_BLOCKS", "LH_OPT_LANE_ZERO_COPY",
-                           "LH_OPT_SCRATCH_CAP_BYTES", "LH_OPT_SUBLAUNCH_PAIRS", "LH_OPT_SURVEY_EVERY"]
+                           "LH_OPT_MERGE_NARROW_CELLS", "LH_OPT_SCRATCH_CAP_BYTES", "LH_OPT_SUBLAUNCH_PAIRS",
+                           "LH_OPT_SURVEY_EVERY"]
     assert not set(pub) & set(tun) and len(set(pub.values()) | set(tun.values())) == len(pub) + len(tun)
     from loghisto_amd import _native
     for name, num in {**pub, **tun}.items():
@@ -57,7 +58,7 @@ def test_struct_layouts_match_header(native_lib):
     assert C.sizeof(_native.LhConfig) == 32
     assert C.sizeof(_native.LhStats) == 40
     assert C.sizeof(_native.LhLineFormat) == 32 and C.sizeof(_native.LhCounters) == 200
-    assert C.sizeof(_native.LhMergeInfo) == 72 and C.sizeof(_native.LhExtractView) == 48
+    assert C.sizeof(_native.LhMergeInfo) == 88 and C.sizeof(_native.LhExtractView) == 48
     cfg = _native.LhConfig()
     assert native_lib.lh_default_config(C.byref(cfg)) == 0
     assert cfg.struct_size == 32 and cfg.max_metrics >= 1 and cfg.num_buffers >= 2

@@ -122,16 +122,19 @@ def test_native_rccl_merge_through_the_c_abi(native_lib, torch_cuda):
         rccl.ncclCommDestroy(comm)
 
 
-@pytest.mark.parametrize("nranks,nrows,plan,outliers", [
-    (2, 5, "allreduce", 0),
-    (2, 5, "reduce_scatter", 0),        # ragged, one row empty everywhere
-    (4, 37, "reduce_scatter", 1),       # outliers in the first and the last row: those two rows are blocks of their own
-    (8, 64, "reduce_scatter", 1),       # config 4's rank count
-    (8, 5, "reduce_scatter", 0),        # more ranks than rows: some ranks own nothing
-    (8, 512, "reduce_scatter", 0),      # Zipf names ranked by id: equal-cell blocks keep the padding under 1.3 x
-    (4, 64, "allreduce", 1),
+@pytest.mark.parametrize("nranks,nrows,plan,outliers,narrow", [
+    (2, 5, "allreduce", 0, 1),
+    (2, 5, "reduce_scatter", 0, 1),     # ragged, one row empty everywhere; name 1's single cell needs 32 bits
+    (4, 37, "reduce_scatter", 1, 1),    # outliers in the first and the last row: those two rows are blocks of their own
+    (8, 64, "reduce_scatter", 1, 1),    # config 4's rank count; name 1's single cell needs 16 bits
+    (8, 5, "reduce_scatter", 0, 1),     # more ranks than rows: some ranks own nothing
+    (8, 512, "reduce_scatter", 0, 1),   # Zipf names ranked by id: equal-word blocks keep the padding under 1.3 x
+    (4, 64, "allreduce", 1, 1),
+    (3, 130, "reduce_scatter", 1, 1),   # odd window widths against 2- and 4-cell words
+    (4, 64, "reduce_scatter", 0, 0),    # LH_OPT_MERGE_NARROW_CELLS = 0 on every rank: every cell a whole word
+    (4, 64, "reduce_scatter", 0, 2),    # ... on ONE rank: the all-reduced bound makes every rank send whole words
 ])
-def test_c_abi_merge_with_n_ranks_on_one_gpu(native_lib, torch_cuda, nranks, nrows, plan, outliers):
+def test_c_abi_merge_with_n_ranks_on_one_gpu(native_lib, torch_cuda, nranks, nrows, plan, outliers, narrow):
     """lh_snapshot_merge beyond one rank.  N engines on the one reachable GPU play N ranks;
     tests/cpp/rccl_stub.cc stands in for RCCL (thread rendezvous + host reduction with RCCL's reduce-scatter
     placement).  Runs in a subprocess because the RCCL library of a process can be chosen only once."""
@@ -139,7 +142,7 @@ def test_c_abi_merge_with_n_ranks_on_one_gpu(native_lib, torch_cuda, nranks, nro
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "_stub_merge_driver.py"), str(nranks), str(nrows),
-                        plan, str(outliers)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+                        plan, str(outliers), str(narrow)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     print(r.stdout)
     assert r.returncode == 0, r.stdout
     import json

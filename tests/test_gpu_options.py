@@ -89,7 +89,7 @@ def test_option_validation(native_lib, torch_cuda):
         for opt, bad in ((N.OPT_TWO_LEVEL_ABOVE, 1000), (N.OPT_HOT_MIN_TILES, 0), (N.OPT_HOT_WINDOWS, 2),
                          (N.OPT_NAMES_PER_PARTITION, 0), (N.OPT_SCRATCH_CAP_BYTES, 1), (N.OPT_SUBLAUNCH_PAIRS, 5),
                          (N.OPT_PART_MIN_PAIRS, 1000), (N.OPT_PART_V3_MIN_PAIRS, 5), (N.OPT_LANE_SCRATCH_BLOCKS, 17),
-                         (N.OPT_LANE_GEN3, 257), (N.OPT_FAIL_SCRATCH_ALLOCS, 1 << 33), (99, 0), (100, 1)):
+                         (N.OPT_LANE_GEN3, 257), (N.OPT_PART_V3_DIRECT_MAX_PAIRS, (1 << 30) + 1), (N.OPT_FAIL_SCRATCH_ALLOCS, 1 << 33), (99, 0), (100, 1)):
             with pytest.raises(loghisto_amd.LhError):
                 e.set_option(opt, bad)
         e.set_option(N.OPT_PART_MIN_PAIRS, 1 << 20)

@@ -129,6 +129,7 @@ def test_third_generation_is_exact(native_lib, torch_cuda, M, n, kind, skew, per
     d_ids, d_v = _dev(torch_cuda, ids), _dev(torch_cuda, v)
     with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
         e.set_option(N.OPT_PART_V3_MIN_PAIRS, 1 << 17)
+        e.set_option(N.OPT_PART_V3_DIRECT_MAX_PAIRS, 1)    # launches this small keep the windowed reduce pass under test
         e.set_option(N.OPT_PART_V3_LOG_W, log_w)
         for rep in range(2):                     # scratch and survey tables are reused; rep 1 runs with rep 0's window report
             e.submit_pairs_device(d_ids, d_v)
@@ -136,6 +137,39 @@ def test_third_generation_is_exact(native_lib, torch_cuda, M, n, kind, skew, per
             c = e.counters()
             assert c["samples_partitioned_v3"] == n * (rep + 1), c
             assert 10 <= c["window_log2"] <= 13
+            with e.flip() as snap:
+                got = snap.extract(PCTS, M)
+                check(snap, ids, v, M, got)
+
+
+DIRECT_CASES = [CASES[i] for i in (0, 1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 13)]
+
+
+@pytest.mark.parametrize("M,n,kind,skew,permute,log_w", DIRECT_CASES)
+def test_small_launches_reduce_without_windows(native_lib, torch_cuda, M, n, kind, skew, permute, log_w):
+    """Launches of at most 2^22 pairs (a host-fed lane's half-buffer) end in k_part_direct3: the level-2 chunks' records
+    go to their cells with one global atomic each, no plan and no LDS windows.  The same stream shapes as above, once at
+    the default bound (the call in two slices) and once with the bound at its maximum."""
+    import loghisto_amd
+    rng = np.random.default_rng(M * 11 + n)
+    ids = _ids(rng, M, n, skew, permute)
+    v = _values(rng, kind, ids, n)
+    d_ids, d_v = _dev(torch_cuda, ids), _dev(torch_cuda, v)
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        e.set_option(N.OPT_PART_V3_MIN_PAIRS, 1 << 17)
+        e.set_option(N.OPT_PART_V3_LOG_W, log_w)
+        for rep, bound in enumerate((0, 1 << 30)):
+            e.set_option(N.OPT_PART_V3_DIRECT_MAX_PAIRS, bound)
+            if bound == 0:                       # default bound, two launches
+                h = (n // 2) & ~1
+                e.submit_pairs_device(d_ids[:h], d_v[:h])
+                e.submit_pairs_device(d_ids[h:], d_v[h:])
+            else:
+                e.submit_pairs_device(d_ids, d_v)
+            e.sync()
+            c = e.counters()
+            assert c["samples_partitioned_v3"] == n * (rep + 1), c
+            assert c["reduce_window_misses"] == 0, c      # nothing has a window to miss
             with e.flip() as snap:
                 got = snap.extract(PCTS, M)
                 check(snap, ids, v, M, got)
@@ -154,6 +188,7 @@ def test_one_bucket_of_a_frequent_name_without_hot_windows(native_lib, torch_cud
     d_ids, d_v = _dev(torch_cuda, ids), _dev(torch_cuda, v)
     with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
         e.set_option(N.OPT_PART_V3_MIN_PAIRS, 1 << 17)
+        e.set_option(N.OPT_PART_V3_DIRECT_MAX_PAIRS, 1)    # launches this small keep the windowed reduce pass under test
         e.set_option(N.OPT_HOT_WINDOWS, 0)
         for log_w in (10, 11):
             e.set_option(N.OPT_PART_V3_LOG_W, log_w)
@@ -176,6 +211,7 @@ def test_survey_is_reused_while_the_stream_looks_the_same(native_lib, torch_cuda
     v1 = _values(rng, "lognormal", ids, n)
     with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
         e.set_option(N.OPT_PART_V3_MIN_PAIRS, 1 << 17)
+        e.set_option(N.OPT_PART_V3_DIRECT_MAX_PAIRS, 1)    # launches this small keep the windowed reduce pass under test
         e.set_option(N.OPT_PART_V3_LOG_W, 10)
         d_ids, d_v1 = _dev(torch_cuda, ids), _dev(torch_cuda, v1)
         for rep in range(5):
@@ -217,6 +253,7 @@ def test_names_without_skew_go_back_to_the_first_generation(native_lib, torch_cu
     d_ids, d_v = _dev(torch_cuda, ids), _dev(torch_cuda, v)
     with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
         e.set_option(N.OPT_PART_V3_MIN_PAIRS, 1 << 17)
+        e.set_option(N.OPT_PART_V3_DIRECT_MAX_PAIRS, 1)    # launches this small keep the windowed reduce pass under test
         seen = []
         for rep in range(4):
             e.submit_pairs_device(d_ids, d_v)
@@ -236,6 +273,7 @@ def test_window_width_follows_the_stream(native_lib, torch_cuda):
     ids = _ids(rng, M, n, 1.0)
     with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
         e.set_option(N.OPT_PART_V3_MIN_PAIRS, 1 << 17)
+        e.set_option(N.OPT_PART_V3_DIRECT_MAX_PAIRS, 1)    # launches this small keep the windowed reduce pass under test
         e.set_option(N.OPT_SURVEY_EVERY, 1)      # every call surveys: the report follows the stream call by call
         for kind, want in (("lognormal", 10), ("loguniform", 13), ("sigma25", 12), ("lognormal", 10)):
             e.submit_pairs_device(_dev(torch_cuda, ids), _dev(torch_cuda, _values(rng, kind, ids, n)))
@@ -257,6 +295,7 @@ def test_bad_ids_sublaunches_and_two_launches_per_epoch(native_lib, torch_cuda):
     keep[where] = False
     with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
         e.set_option(N.OPT_PART_V3_MIN_PAIRS, 1 << 17)
+        e.set_option(N.OPT_PART_V3_DIRECT_MAX_PAIRS, 1)    # launches this small keep the windowed reduce pass under test
         e.set_option(N.OPT_SUBLAUNCH_PAIRS, 1 << 22)       # 3 sub-launches per call, one survey per call
         # (the device arrays must outlive the launches: the engine's stream is not one torch's allocator knows about)
         d_ids, d_bad, d_v = _dev(torch_cuda, ids), _dev(torch_cuda, bad), _dev(torch_cuda, v)
@@ -288,6 +327,7 @@ def test_threshold_fixture_through_the_hashed_scatter(native_lib, torch_cuda):
     ids = ((np.arange(v.size, dtype=np.uint64) * 7919) % M).astype(np.uint32)
     with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
         e.set_option(N.OPT_PART_V3_MIN_PAIRS, 1 << 17)
+        e.set_option(N.OPT_PART_V3_DIRECT_MAX_PAIRS, 1)    # launches this small keep the windowed reduce pass under test
         e.submit_pairs_device(_dev(torch_cuda, ids), _dev(torch_cuda, v))
         e.sync()
         assert e.counters()["samples_partitioned_v3"] == v.size
@@ -306,6 +346,7 @@ def test_clustered_stream_falls_back_to_the_first_generation(native_lib, torch_c
     d_ids, d_v = _dev(torch_cuda, ids), _dev(torch_cuda, v)
     with loghisto_amd.Engine(max_metrics=M, num_buffers=3, num_lanes=1, lane_samples=1 << 16) as e:
         e.set_option(N.OPT_PART_V3_MIN_PAIRS, 1 << 17)
+        e.set_option(N.OPT_PART_V3_DIRECT_MAX_PAIRS, 1)    # launches this small keep the windowed reduce pass under test
         seen_v3 = 0
         for rep in range(3):
             e.submit_pairs_device(d_ids, d_v)
@@ -339,6 +380,7 @@ def test_concurrent_streams_into_the_same_names(native_lib, torch_cuda):
     rounds, per_round = 3, 12
     with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=2, lane_samples=1 << 16) as e:
         e.set_option(N.OPT_PART_V3_MIN_PAIRS, 1 << 17)
+        e.set_option(N.OPT_PART_V3_DIRECT_MAX_PAIRS, 1)    # launches this small keep the windowed reduce pass under test
         torch.cuda.synchronize()
         for r in range(rounds):
             e.submit_pairs_device(d_ids, d_v, stream=sa)               # survey + three passes on stream A
@@ -373,6 +415,7 @@ def test_a_width_change_is_not_mistaken_for_names_without_skew(native_lib, torch
     d_ids, d_v1, d_v2 = _dev(torch_cuda, ids), _dev(torch_cuda, v1), _dev(torch_cuda, v2)
     with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
         e.set_option(N.OPT_PART_V3_MIN_PAIRS, 1 << 17)
+        e.set_option(N.OPT_PART_V3_DIRECT_MAX_PAIRS, 1)    # launches this small keep the windowed reduce pass under test
         for d_v, v in ((d_v1, v1), (d_v1, v1), (d_v2, v2), (d_v2, v2), (d_v2, v2), (d_v2, v2)):
             e.submit_pairs_device(d_ids, d_v)
             e.sync()

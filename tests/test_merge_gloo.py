@@ -60,6 +60,48 @@ def expected_blocks(width, world):
     return brow + [nrows]
 
 
+def expected_words(width, rowmax, world):
+    """Wire words of every row, stated independently of both front-ends: a row travels at 8, 16 or 32 bits
+    per cell, the narrowest that holds world x (the largest cell any rank holds in it), in uint32 words."""
+    import numpy as np
+    bound = np.asarray(rowmax, dtype=np.int64) * world
+    bits = np.where(bound <= 0xff, 8, np.where(bound <= 0xffff, 16, 32))
+    return (np.asarray(width, dtype=np.int64) * bits + 31) // 32, bits
+
+
+def test_window_plan_in_wire_words():
+    """plan_windows with per-row cell widths: the prefix, the totals and the owner blocks are those of the words."""
+    import numpy as np
+    import torch
+    from loghisto_amd import merge
+    rng = np.random.default_rng(5)
+    for nrows in (1, 6, 77, 1000):
+        lo = rng.integers(0, 60000, nrows)
+        width = rng.integers(0, 1500, nrows)
+        width[rng.random(nrows) < 0.15] = 0
+        hi = lo + width - 1
+        lo[width == 0], hi[width == 0] = 65536, 0
+        ranges = torch.from_numpy(np.stack([lo, hi], 1).astype(np.int32))
+        rowmax = (10.0 ** rng.uniform(0, 6, nrows)).astype(np.int64)
+        for world in (2, 3, 8):
+            words, bits = expected_words(width, rowmax, world)
+            got_bits = merge.row_bits(torch.from_numpy(rowmax), world, 1 << 20)
+            assert np.array_equal(got_bits.numpy(), bits)
+            assert set(np.unique(bits)) <= {8, 16, 32} and (nrows < 50 or len(set(np.unique(bits))) == 3)
+            W = merge.plan_windows(ranges, world, "reduce_scatter", got_bits)
+            assert np.array_equal(W["words"].numpy(), words) and W["total"] == int(words.sum())
+            assert W["total_c"] == int(width.sum()) and np.array_equal(W["width"].numpy(), width)
+            brow = expected_blocks(words, world)
+            assert W["brow"].tolist() == brow
+            assert W["bmax"] == max(int(words[brow[k]:brow[k + 1]].sum()) for k in range(world))
+            assert W["bmax_c"] == max(int(width[brow[k]:brow[k + 1]].sum()) for k in range(world))
+        # an interval whose largest per-rank sample count x ranks can reach 2^32: every cell a uint64 word
+        b64 = merge.row_bits(torch.from_numpy(rowmax), 8, 1 << 30)
+        assert bool((b64 == 64).all())
+        W = merge.plan_windows(ranges, 8, "reduce_scatter", b64)
+        assert np.array_equal(W["words"].numpy(), width)
+
+
 def test_window_plan_for_2_4_8_ranks():
     """Pure plan arithmetic: loghisto_amd.merge.plan_windows must give per-row widths, their prefix and the owner
     blocks of EQUAL PACKED CELLS that k_merge_plan computes on the device for lh_snapshot_merge (the device side of

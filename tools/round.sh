@@ -16,6 +16,9 @@
 #   lanes <tag>                 host-fed path: its tests + tools/hostfed_native.cc at 1 024 / 20 000 / 65 536 names
 #                               (LH_OPT_LANE_GEN3 off / on / level-1 workgroup caps, 8 and 16 lane blocks)
 #   lanetrace <tag>             rocprofv3 --kernel-trace of hostfed_native at 65 536 names, lanes' third generation on / off
+#   direct <tag>                the small launches' reduce pass without windows (k_part_direct3): its tests, hostfed_native with
+#                               it on / off, and where it stops paying (sweep at 2^20 .. 2^23 pairs, both passes)
+#   merge <tag>                 lh_snapshot_merge: its tests (stub ranks, bench ranks as threads), then the direct reduce pass again
 #   counters <tag>              tools/sq_counters.sh: SQ instruction / LDS counters per distribution
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 SUB=$1; TAG=${2:-r5}; shift 2
@@ -85,6 +88,31 @@ lanetrace)
          timeout 300 rocprofv3 --kernel-trace -d /tmp/pk -o t -- $R/loghisto_amd/build/hostfed_native 16 4e8 65536 1048576 $g3 > $OUT/run_$g3.txt 2>&1
          python $R/profiles/summarize_rocpd.py stats /tmp/pk/t_results.db | cut -c1-170) | grep -v "^[WE]2" | tee $OUT/trace_gen3_$g3.txt | head -24
         grep -v "^[WE]2" $OUT/run_$g3.txt | cut -c1-400
+    done
+    ;;
+direct)
+    suite tests/test_gpu_part3.py tests/test_gpu_lane_blocks.py tests/test_gpu_faults.py tests/test_gpu_pairs16.py tests/test_gpu_options.py
+    for args in "16 8e8 65536 1048576 1 0 16 0" "16 8e8 65536 1048576 1 0 16 1" "16 8e8 65536 2097152 1 0 16 0" "16 8e8 20000 1048576 1 0 16 0" \
+                "16 8e8 20000 1048576 1 0 16 1" "16 8e8 1024 1048576 1 0 16 0"; do
+        loghisto_amd/build/hostfed_native $args 2>&1 | grep -v "^counters" | sed -e "s/^{/{\"args\": \"$args\", /" | cut -c1-360 | tee -a $OUT/hostfed_native.jsonl
+    done
+    for n in 1048576 2097152 4194304 8388608; do
+        for dm in 1 1073741824; do
+            echo "direct_max=$dm" | tee -a $OUT/sweep.txt
+            sweep $n 65536 30 --dists lognormal --opt 21=$dm --opt 13=131072 | tee -a $OUT/sweep.txt
+        done
+    done
+    ;;
+merge)
+    suite tests/test_gpu_merge.py tests/test_gpu_bench_ranks.py tests/test_gpu_part3.py::test_small_launches_reduce_without_windows tests/test_gpu_lane_blocks.py
+    for args in "16 8e8 65536 1048576 1 0 16 0" "16 8e8 65536 1048576 1 0 16 1" "16 8e8 20000 1048576 1 0 16 0"; do
+        loghisto_amd/build/hostfed_native $args 2>&1 | grep -v "^counters" | sed -e "s/^{/{\"args\": \"$args\", /" | cut -c1-360 | tee -a $OUT/hostfed_native.jsonl
+    done
+    for n in 2097152 4194304; do
+        for dm in 1 1073741824; do
+            echo "direct_max=$dm" | tee -a $OUT/sweep.txt
+            sweep $n 65536 30 --dists lognormal --opt 21=$dm --opt 13=131072 | tee -a $OUT/sweep.txt
+        done
     done
     ;;
 counters)
