@@ -644,6 +644,8 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=Non
     torch.distributed fallback), or one the caller made (tests/_bench_ranks_driver.py: ranks as threads on one GPU over
     the stub RCCL, with a thread-rendezvous stand-in for torch.distributed as `dist`).  None: a one-rank communicator
     of its own (world == 1)."""
+    import ctypes as C
+    from loghisto_amd import _native as N
     from loghisto_amd import merge as tmerge
     from loghisto_amd import rccl
     M = args.names or 65536
@@ -664,7 +666,7 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=Non
     else:
         comm = comm_override
         frontend = frontend or "c-abi: lh_snapshot_merge -> RCCL"
-    t_ing, t_merge, t_mwall, t_ext, t_k2 = [], [], [], [], []
+    t_ing, t_merge, t_mwall, t_ext, t_k2, t_k2k, t_k2c = [], [], [], [], [], [], []
     info = {}
 
     def step(timed):
@@ -697,6 +699,10 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=Non
         t2 = time.perf_counter()
         if timed:
             info.update(snap.merge_info() if comm else dict(tmerge.last_info))
+            km, cm = C.c_float(0), C.c_float(0)
+            if N.lib().lh_tool_last_extract_ms(eng._h, C.byref(km), C.byref(cm)) == 0:
+                t_k2k.append(km.value)
+                t_k2c.append(cm.value)
         snap.release()
         if timed:
             torch.cuda.synchronize()
@@ -875,6 +881,12 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=Non
                                            "lh_extract_rows_view.  The kernel alone: profiles/r04_c4_kernel_trace.txt "
                                            "(107 - 127 us at 65 536 names = 2.5 - 2.9 TB/s over the windows)",
                                            window_cells=owned_cells)
+        if t_k2k:
+            # the two parts apart (lh_tool_last_extract_ms: HIP events inside lh_extract_rows_view): K2's own roofline is
+            # the kernel's; the copy is 139 B per name over PCIe
+            kms, cms = sum(t_k2k) / len(t_k2k), sum(t_k2c) / len(t_k2c)
+            res["extract_roofline"].update(kernel_ms=kms, copy_ms=cms, kernel_frac=8.0 * owned_cells / (kms * 1e-3) / 8e12,
+                                           copy_GBps=139.0 * (last - first) / (cms * 1e-3) / 1e9 if cms > 0 else None)
     if plan8:
         res["merge"]["simulated_plan"] = plan8
     if lat_c4:

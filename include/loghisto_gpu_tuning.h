@@ -117,6 +117,10 @@ int lh_dispatch_probe(const lh_dispatch_query *q, lh_dispatch_step *steps, size_
 int lh_tool_device_alloc(size_t bytes, void **d_ptr);
 int lh_tool_device_free(void *d_ptr);
 int lh_tool_read_ceiling(const void *d_ptr, size_t bytes, int reps, void *stream, float *avg_ms, float *min_ms);
+/* Device time of the engine's last extract whose results went through HBM and one copy (more than 32 KiB of results:
+ * from ~240 names on), HIP events on the snapshot stream: the K2 kernel(s) alone, and the device-to-host copy of the
+ * results behind them.  LH_ESTATE when the engine has not run such an extract. */
+int lh_tool_last_extract_ms(lh_engine *e, float *kernel_ms, float *copy_ms);
 
 #ifdef __cplusplus
 }

@@ -118,6 +118,7 @@ TUNING_SIGNATURES = {
     "lh_tool_device_alloc": (C.c_int, [_sz, C.POINTER(_vp)]),
     "lh_tool_device_free": (C.c_int, [_vp]),
     "lh_tool_read_ceiling": (C.c_int, [_vp, _sz, C.c_int, _vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "lh_tool_last_extract_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
 }
 
 # name -> (restype, argtypes): every symbol include/loghisto_gpu.h declares.

@@ -173,6 +173,8 @@ struct lh_engine {
     lh_merge_info merge_info{};
     hipEvent_t merge_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // around the merge's steps (xmu)
     bool merge_events_pending = false;
+    hipEvent_t xev[3] = {nullptr, nullptr, nullptr}; // large extracts: before the kernel, after it, after the copy (xmu)
+    bool xev_valid = false;
     bool merge_narrow = true;           // LH_OPT_MERGE_NARROW_CELLS: rows travel at 8 / 16 bits per cell where their counts allow
 
     // counters (metrics.go:112-117): their own name table, the lifetime store and the "ever touched" flags in HBM
@@ -796,6 +798,8 @@ void free_engine(lh_engine *e)
     if (e->d_text) (void)hipFree(e->d_text);
     if (e->d_blob) (void)hipFree(e->d_blob);
     if (e->d_mplan) (void)hipFree(e->d_mplan);
+    for (hipEvent_t ev : e->xev)
+        if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->merge_ev)
         if (ev) (void)hipEventDestroy(ev);
     if (e->d_cnames) (void)hipFree(e->d_cnames);
@@ -1496,6 +1500,20 @@ int lh_extract_rows_view(lh_snapshot *s, uint32_t first, size_t nmetrics, const 
     return extract_impl(s, first, nmetrics, p, np, nullptr, nullptr, nullptr, nullptr, view);
 }
 
+// Measurement helper (loghisto_gpu_tuning.h): device time of the engine's last LARGE extract (results through HBM and one
+// copy: more than 32 KiB), the kernel and the device-to-host copy apart.
+int lh_tool_last_extract_ms(lh_engine *e, float *kernel_ms, float *copy_ms)
+{
+    if (!e || !kernel_ms || !copy_ms) return LH_EINVAL;
+    std::lock_guard<std::mutex> g(e->xmu);
+    if (!e->xev_valid) return LH_ESTATE;
+    int rc = use_device(e);
+    if (rc) return rc;
+    HIPCHK(hipEventElapsedTime(kernel_ms, e->xev[0], e->xev[1]));
+    HIPCHK(hipEventElapsedTime(copy_ms, e->xev[1], e->xev[2]));
+    return LH_OK;
+}
+
 namespace {
 int extract_impl(lh_snapshot *s, uint32_t first, size_t nmetrics, const double *p, size_t np, lh_stats *stats,
                  double *pvals, int16_t *pkeys, uint8_t *pvalid, lh_extract_view *view)
@@ -1528,6 +1546,12 @@ int extract_impl(lh_snapshot *s, uint32_t first, size_t nmetrics, const double *
         nt.host_flag = reinterpret_cast<uint32_t *>(e->d_hxbuf + L.total);
         nt.seq = e->xseq;
     }
+    if (!zero_copy) { // (the small results' latency path records nothing)
+        for (hipEvent_t &ev : e->xev)
+            if (!ev) HIPCHK(hipEventCreate(&ev));
+        e->xev_valid = false;
+        HIPCHK(hipEventRecord(e->xev[0], e->xstream));
+    }
     HIPCHK(lh::launch_extract(b.counts + (size_t)first * LH_ROW_STRIDE, b.ranges + 2 * (size_t)first,
                               (uint32_t)nmetrics, p, (uint32_t)np, e->d_D,
                               reinterpret_cast<lh::ExtractOut *>(xb + L.off_stats),
@@ -1548,8 +1572,11 @@ int extract_impl(lh_snapshot *s, uint32_t first, size_t nmetrics, const double *
         }
         std::atomic_thread_fence(std::memory_order_acquire);
     } else {
+        HIPCHK(hipEventRecord(e->xev[1], e->xstream));
         HIPCHK(hipMemcpyAsync(e->h_xbuf, e->d_xbuf, L.total, hipMemcpyDeviceToHost, e->xstream));
+        HIPCHK(hipEventRecord(e->xev[2], e->xstream));
         HIPCHK(hipStreamSynchronize(e->xstream));
+        e->xev_valid = true;
     }
     return finish_extract(e, L, nmetrics, np, stats, pvals, pkeys, pvalid, view);
 }

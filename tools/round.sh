@@ -19,6 +19,8 @@
 #   direct <tag>                the small launches' reduce pass without windows (k_part_direct3): its tests, hostfed_native with
 #                               it on / off, and where it stops paying (sweep at 2^20 .. 2^23 pairs, both passes)
 #   merge <tag>                 lh_snapshot_merge: its tests (stub ranks, bench ranks as threads), then the direct reduce pass again
+#   hotwin <tag> <suffix>       the hot-window rule: tests of the second / third generation, then 1 024 names x 1e9 pairs over
+#                               lognormal / few-valued streams and 65 536 names, product against build/liblhgpu_tuning_<suffix>.so
 #   counters <tag>              tools/sq_counters.sh: SQ instruction / LDS counters per distribution
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 SUB=$1; TAG=${2:-r5}; shift 2
@@ -113,6 +115,15 @@ merge)
             echo "direct_max=$dm" | tee -a $OUT/sweep.txt
             sweep $n 65536 30 --dists lognormal --opt 21=$dm --opt 13=131072 | tee -a $OUT/sweep.txt
         done
+    done
+    ;;
+hotwin)
+    suite tests/test_gpu_part2.py tests/test_gpu_part3.py
+    for sfx in "" ${1:-}; do
+        lib=""; [ -n "$sfx" ] && lib="--lib loghisto_amd/build/liblhgpu_tuning_$sfx.so"
+        echo "== ${sfx:-product}" | tee -a $OUT/ab.txt
+        sweep 1e9 1024 5 --dists lognormal,kvalues4,kvalues8,kvalues16,lognormal25,bimodal $lib | tee -a $OUT/ab.txt
+        sweep 1e9 65536 4 --dists lognormal,kvalues8 $lib | tee -a $OUT/ab.txt
     done
     ;;
 counters)
