@@ -1,4 +1,4 @@
-# Per-round evidence under gpurun_out/round/ (copy into profiles/ as r04_* afterwards).  One gpurun call.
+# Per-round evidence under gpurun_out/round/ (copy into profiles/ as r05_* afterwards).  One gpurun call.
 # Every PMC summary records the hashes of the kernel sources it was measured on (bench.source_hashes): bench.py refuses a
 # summary whose hashes differ from the tree's (traffic_source: "stale ...").
 #   bench.json              python bench.py (default flags: headline C2 + secondary C3 / C4 / host-fed / C5)
