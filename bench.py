@@ -46,10 +46,10 @@ HBM_PEAK_GBS = 8000.0                                    # MI355X_MICROARCH.md: 
 PCIE_GBS = 63.0                                          # PCIe Gen5 x16 (spec)
 BYTES_SINGLE, BYTES_PAIR, BYTES_PAIR16 = 8, 12, 10        # float64 / float64 + uint32 id / + uint16 id
 METRIC = "float64 samples/sec bucketed (1 GPU) + % HBM roofline; p99 extract latency"
-K1_PMC = os.path.join("profiles", "r04_k1_pmc.json")
-C3_PMC = os.path.join("profiles", "r04_c3_pmc.json")
-C4_PMC = os.path.join("profiles", "r04_c4_pmc.json")
-C4_1E9_PMC = os.path.join("profiles", "r04_c4_names_1e9_pmc.json")
+K1_PMC = os.path.join("profiles", "r05_k1_pmc.json")
+C3_PMC = os.path.join("profiles", "r05_c3_pmc.json")
+C4_PMC = os.path.join("profiles", "r05_c4_pmc.json")
+C4_1E9_PMC = os.path.join("profiles", "r05_c4_names_1e9_pmc.json")
 PREWARM = 25                                             # untimed K1 launches before the warm-up steps (run_c2)
 
 
