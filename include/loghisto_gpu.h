@@ -349,6 +349,8 @@ typedef struct lh_counters {
     uint64_t surveys_reused;         /* calls that ran on an earlier call's survey (LH_OPT_SURVEY_EVERY)              */
     uint64_t scratch_alloc_failures; /* scratch blocks of the mixed ingest that could not be allocated (ABI 5)         */
     uint64_t samples_fallback;       /* samples that therefore went through the scratch-free kernel: exact, slower     */
+    uint64_t survey_stale_pairs;     /* pairs a kept survey's hot windows no longer took (the values moved under it: the
+                                        launch reports them, the next call surveys again)                              */
 } lh_counters;
 int lh_get_counters(lh_engine *e, lh_counters *out);
 

@@ -451,7 +451,7 @@ int run_lane_block(lh_engine *e, EpochBuffer &b, PairsCall &c, const lh::Step &s
         // what the third-generation launches completed since the last look reported (the device-resident calls' and the
         // lanes' alike: k_v3_report adds to the same pinned words)
         const uint64_t bad = __atomic_load_n(&e->h_rstat[0], __ATOMIC_RELAXED) + __atomic_load_n(&e->h_rstat[4], __ATOMIC_RELAXED) +
-                             __atomic_load_n(&e->h_rstat[5], __ATOMIC_RELAXED);
+                             __atomic_load_n(&e->h_rstat[5], __ATOMIC_RELAXED) + __atomic_load_n(&e->h_rstat[7], __ATOMIC_RELAXED);
         const uint64_t pairs = __atomic_load_n(&e->h_rstat[6], __ATOMIC_RELAXED);
         const bool healthy = lh::healthy_share(bad - lt.seen_bad, pairs - lt.seen_pairs);
         lt.seen_bad = bad;
@@ -539,8 +539,9 @@ void judge_tables(lh_engine *e, PairsCall &c, int gen, uint32_t layout)
     c.judged = true;
     bool healthy = true;
     if (gen == 3) {
+        // ([7]: pairs a STALE survey kept out of the hot windows -- the values moved under it; stale_judge, lh_kernels_part2.h)
         const uint64_t bad = __atomic_load_n(&e->h_rstat[0], __ATOMIC_RELAXED) + __atomic_load_n(&e->h_rstat[4], __ATOMIC_RELAXED) +
-                             __atomic_load_n(&e->h_rstat[5], __ATOMIC_RELAXED);
+                             __atomic_load_n(&e->h_rstat[5], __ATOMIC_RELAXED) + __atomic_load_n(&e->h_rstat[7], __ATOMIC_RELAXED);
         const uint64_t pairs = __atomic_load_n(&e->h_rstat[6], __ATOMIC_RELAXED); // of the launches that reported
         const uint64_t fwd = __atomic_load_n(&e->h_rstat[3], __ATOMIC_RELAXED);
         healthy = lh::healthy_share(bad - e->v3_seen_bad, pairs - e->v3_seen_pairs);
@@ -554,7 +555,9 @@ void judge_tables(lh_engine *e, PairsCall &c, int gen, uint32_t layout)
         // second generation: region overflows (k_scatter3 adds them to the pinned word as it retires) against the pairs
         // ENQUEUED through it since the last look -- an upper bound of what has completed, so the share is a lower
         // bound; lh_flip's per-interval judgement (regions_disabled) is the backstop
-        const uint64_t bad = __atomic_load_n(&e->h_rstat[0], __ATOMIC_RELAXED), pairs = e->c_part2.load(std::memory_order_relaxed);
+        // ... and the pairs a stale survey kept out of the hot windows (k_scatter3's last workgroup: stale_judge)
+        const uint64_t bad = __atomic_load_n(&e->h_rstat[0], __ATOMIC_RELAXED) + __atomic_load_n(&e->h_rstat[7], __ATOMIC_RELAXED),
+                       pairs = e->c_part2.load(std::memory_order_relaxed);
         healthy = lh::healthy_share(bad - e->v2_seen_bad, pairs - e->v2_seen_pairs);
         e->v2_seen_bad = bad;
         e->v2_seen_pairs = pairs;
@@ -861,7 +864,7 @@ int create_impl(const lh_config *cfg_in, lh_engine *e)
     HIPCHK(hipMalloc((void **)&e->d_Tx, sizeof(double) * LH_NTHRESH));
     HIPCHK(hipMalloc((void **)&e->d_D, sizeof(double) * LH_NKEYS));
     HIPCHK(hipHostMalloc((void **)&e->h_rstat, 64, hipHostMallocDefault));
-    for (int i = 0; i < 8; i++) e->h_rstat[i] = 0; // [0] level-1 region overflows [1] window class [2..5] part3 self-metrics [6] pairs they cover
+    for (int i = 0; i < 8; i++) e->h_rstat[i] = 0; // [0] level-1 region overflows [1] window class [2..5] part3 self-metrics [6] pairs they cover [7] pairs a stale survey cost its hot windows
     {
         void *dp = nullptr;
         HIPCHK(hipHostGetDevicePointer(&dp, e->h_rstat, 0));
@@ -2390,6 +2393,7 @@ int lh_get_counters(lh_engine *e, lh_counters *out)
     out->surveys_reused = e->c_survey_reuse.load();
     out->scratch_alloc_failures = e->c_alloc_fail.load();
     out->samples_fallback = e->c_fallback.load();
+    out->survey_stale_pairs = __atomic_load_n(&e->h_rstat[7], __ATOMIC_RELAXED);
     {
         const uint64_t lw = __atomic_load_n(&e->h_rstat[1], __ATOMIC_RELAXED);
         std::lock_guard<std::mutex> g(e->scratch_mu);

@@ -37,6 +37,7 @@ constexpr int V2_SPT = 8;                              // samples per thread per
 constexpr uint32_t LINE2 = 32;                         // records per line (64 B)
 constexpr uint32_t V2_MAX_NAMES = 8192;
 constexpr uint32_t V2_MAX_SLOTS = 512;                 // hot names
+constexpr uint32_t HOT_WHOLE_SPAN = 320;               // sampled spans up to this many bins get a hot window over all of it
 constexpr size_t V2_MIN_SAMPLES = size_t(1) << 25; // measured crossover with the first-generation path: profiles/r02_c3_sizes.txt
 constexpr uint32_t V2_LDS_TOTAL = 160 * 1024;
 constexpr uint32_t SV_GRID = 256;                      // survey workgroups (one 4 096-sample tile each)
@@ -73,6 +74,38 @@ template <int BLOCK, int NPT> struct Scatter2LdsT {
 // Per-name entry of the survey's plan, 8 bytes: cold origin | hot origin << 16, hot LDS base | hot width << 16.
 // A name without a hot window has width 0.
 struct NameEntry { uint32_t org; uint32_t hot; };
+
+// ---------------------------------------------------------------------------
+// Is the survey stale?  A survey is shared by up to LH_OPT_SURVEY_EVERY calls, and nothing the scatter kernels report
+// (region overflows, window misses) moves when the VALUES of a stream shift under it: the hot windows then sit where
+// the samples no longer are, every sample becomes a record, and the call costs half as much again (1 024 names,
+// lognormal survey, four-valued stream: 4.34 ms per 1e9 pairs instead of 3.0 -- profiles/r05_fewvalued.txt) for up
+// to 31 more calls.  So the launches keep the one number that does move: the share of their samples the hot windows
+// took.  The first launch on a survey's tables stores it (hdr[HDR_BASE]); a later launch whose share is more than
+// STALE_DROP below that adds the difference, in pairs, to the engine's pinned word rstat[RSTAT_STALE], which
+// lh_engine's judge_tables counts with the other signs of an unhealthy call: the next call surveys again.
+// Exactness does not depend on any of it.
+// ---------------------------------------------------------------------------
+constexpr uint32_t HDR_HITS = 8, HDR_TILES = 9, HDR_TICKET = 10, HDR_BASE = 11; // words of the 64-byte survey header
+constexpr uint32_t RSTAT_STALE = 7;                // engine's pinned words: [7] pairs a stale survey kept out of the hot windows
+constexpr uint32_t STALE_VALID = 0x80000000u;      // hdr[HDR_BASE] = STALE_VALID | share in 1/65 536ths
+constexpr uint32_t STALE_DROP = 65536u / 20u;      // 5 % of the launch's pairs
+
+// share: what the hot windows took of `pairs`, in 1/65 536ths (first level of the third generation: pairs that did NOT
+// become records).  One thread, after every workgroup's account is in.
+__device__ __forceinline__ void stale_judge(uint32_t *__restrict__ hdr, unsigned long long *__restrict__ rstat,
+                                            unsigned long long taken, unsigned long long pairs)
+{
+    if (!pairs) return;
+    const uint32_t share = (uint32_t)((taken << 16) / pairs);
+    const uint32_t base = hdr[HDR_BASE];
+    if (!(base & STALE_VALID)) {
+        hdr[HDR_BASE] = STALE_VALID | share;
+    } else if (share + STALE_DROP < (base & 0x1ffffu) && rstat) {
+        const unsigned long long lost = (((unsigned long long)((base & 0x1ffffu) - share)) * pairs) >> 16;
+        __hip_atomic_fetch_add(rstat + RSTAT_STALE, lost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 
 // ---------------------------------------------------------------------------
 // Survey
@@ -165,7 +198,7 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__rest
     const uint32_t m0 = tid * E;
     const uint32_t W = 1u << log_w;
     uint32_t cnt[EMAX], want[EMAX], mean[EMAX], corg[EMAX];
-    uint32_t mysum = 0;
+    uint32_t mysum = 0, whole = 0; // whole: bit e = name e of this thread keeps its whole sampled span
 #pragma unroll
     for (uint32_t e = 0; e < EMAX; e++) {
         cnt[e] = 0;
@@ -188,10 +221,19 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__rest
                 // hot window the name would like: 3/4 of the sampled span (the span of a few thousand samples of
                 // a bell-shaped bin distribution is ~ +-3.5 sigma; 3/4 of it keeps ~99 %), in steps of 64 bins
                 if (c >= 16) {
-                    // (the WHOLE span when it fits 512 bins was measured in round 4: few-valued streams gain -- k = 8: 3.74 ->
-                    // 3.43 ms per 1e9 pairs -- lognormal ones lose 3 % to the names that no longer fit; not kept)
                     uint32_t w = (((mx - mn + 1) * 3u / 4u) + 63u) & ~63u;
                     want[e] = w < 64u ? 64u : w;
+                    // A sampled span of at most HOT_WHOLE_SPAN bins is kept WHOLE, centred on the span and exempt from the
+                    // 256-bin cap below: the outer values of a few-valued stream carry as much as the inner ones (k = 8
+                    // values 40.5 bins apart, a 285-bin span: 3.76 -> 2.98 ms per 1e9 pairs; lognormal, k = 4 and k = 16
+                    // streams unchanged -- profiles/r05_fewvalued.txt, an A/B/A run on one box).  No name that gets a
+                    // window on a bell-shaped stream has so narrow a span: at sigma = 1 the span of the ~1 000 samples such
+                    // a name needs is ~660 bins.  (The whole span up to 512 bins cost lognormal streams 3 % in round 4.)
+                    if (mx - mn + 1 <= HOT_WHOLE_SPAN) {
+                        want[e] = ((mx - mn + 1) + 63u) & ~63u;
+                        mean[e] = (mn + mx + 1) >> 1;
+                        whole |= 1u << e;
+                    }
                 }
             }
         }
@@ -205,7 +247,7 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__rest
     for (uint32_t e = 0; e < EMAX; e++) {
         if (want[e]) {
             const uint32_t cap = cnt[e] >= big ? 512u : 256u;
-            if (want[e] > cap) want[e] = cap;
+            if (want[e] > cap && !(whole & (1u << e))) want[e] = cap;
         }
     }
     // the smallest tau >= 16 such that the windows of every name with cnt >= tau fit `cells` and the slot table
@@ -272,6 +314,10 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__rest
         hdr[1] = totw;
         hdr[2] = total_cnt;
         hdr[3] = hot_cnt_total;
+        hdr[HDR_HITS] = 0;  // k_scatter3's account of what the hot windows take (stale_report below)
+        hdr[HDR_TILES] = 0;
+        hdr[HDR_TICKET] = 0;
+        hdr[HDR_BASE] = 0;  // no launch has run on these tables yet
     }
 }
 
@@ -738,7 +784,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
                                                        const double *__restrict__ Tx,
                                                        const NameEntry *__restrict__ g_nt,
                                                        const pu4_t *__restrict__ g_hs,
-                                                       const uint32_t *__restrict__ g_hdr,
+                                                       uint32_t *__restrict__ g_hdr,
                                                        const pu2_t *__restrict__ g_pt, uint32_t region_recs,
                                                        uint32_t cells, rec16_t *__restrict__ records,
                                                        uint32_t *__restrict__ cdesc, uint32_t chunks_per_wg,
@@ -984,6 +1030,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
                 *reinterpret_cast<pu4_t *>(records + d + j * LINE2 + q * 8) =
                     *reinterpret_cast<const pu4_t *>(lds16 + L.pt[p].x + j * LINE2 + q * 8);
     }
+    if (tid == 0) L.dummy[0] = 0; // (no sample targets the dummy words any more) the workgroup's hot-window hits
     __syncthreads();
     if (tid < np && L.cbase[tid] != INVALID) cdesc[L.cbase[tid]] = (tid << CD_SHIFT) | L.cfill[tid];
     // the engine watches this count (pinned host memory): a stream whose tiles overflow the regions is clustered by
@@ -993,6 +1040,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
 
     // ---- flush the hot windows (one uint64 atomic per occupied bin) and the out-of-window table
     const uint32_t nhot = g_hdr[0];
+    uint32_t hits = 0; // (a workgroup sees fewer than 2^31 samples)
     for (uint32_t s = wave; s < nhot; s += BLOCK / 64) {
         const pu4_t h = g_hs[s];
         const uint32_t name = h.x, org = h.y & 0xffffu, width = h.y >> 16, base = h.z;
@@ -1005,6 +1053,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
                           (unsigned long long)c);
                 mn = min(mn, b);
                 mx = max(mx, b);
+                hits += c;
             }
         }
 #pragma unroll
@@ -1020,6 +1069,27 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
     }
     for (uint32_t i = tid; i < OV_SLOTS; i += BLOCK)
         if (L.ov_key[i] != OV_EMPTY) v2_global_add(counts, ranges, L.ov_key[i] >> 16, L.ov_key[i] & 0xffffu, L.ov_cnt[i]);
+
+    // ---- is the survey stale?  (stale_judge above.)  The last workgroup to hand its account in judges the launch.
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) hits += __shfl_xor(hits, d, 64);
+    if (lane == 0 && hits) atomicAdd(&L.dummy[0], hits);
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t mine = blockIdx.x < ntiles ? (uint32_t)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0u;
+        atomicAdd(&g_hdr[HDR_HITS], L.dummy[0]);
+        atomicAdd(&g_hdr[HDR_TILES], mine);
+        __threadfence();
+        if (atomicAdd(&g_hdr[HDR_TICKET], 1u) == gridDim.x - 1) {
+            __threadfence();
+            const unsigned long long taken = atomicAdd(&g_hdr[HDR_HITS], 0u);
+            const unsigned long long pairs = (unsigned long long)atomicAdd(&g_hdr[HDR_TILES], 0u) * V3_TILE;
+            stale_judge(g_hdr, rstat, taken, pairs);
+            g_hdr[HDR_HITS] = 0;
+            g_hdr[HDR_TILES] = 0;
+            g_hdr[HDR_TICKET] = 0;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------

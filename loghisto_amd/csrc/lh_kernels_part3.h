@@ -273,6 +273,7 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan_h(const SurveyStat S,
         // sample is small (the span of a few dozen samples underestimates the name's real span)
         lw = lw < 10u ? 10u : (lw > 13u ? 13u : lw);
         hdr[4] = lw;
+        hdr[HDR_BASE] = 0; // no launch has run on these tables yet (stale_judge, lh_kernels_part2.h)
         if (span_out && mass) __hip_atomic_store(span_out, lw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
@@ -1562,11 +1563,18 @@ __global__ __launch_bounds__(256) void k_part_direct3(const uint32_t *__restrict
 //   rstat[0] level-1 region overflows (the engine's clustered-stream switch)  [2] level-1 records  [3] records
 //   forwarded by level 2  [4] level-2 region overflows  [5] reduce-pass window misses
 __global__ void k_v3_report(uint32_t *__restrict__ g_stats, unsigned long long *__restrict__ rstat,
-                            unsigned long long pairs)
+                            unsigned long long pairs, uint32_t *__restrict__ hdr)
 {
     // rstat[6]: pairs of the launches that have reported (the engine judges the other words against THIS count, not
     // against what it has enqueued: the reports arrive when a launch completes)
     if (threadIdx.x == 5 && rstat) __hip_atomic_fetch_add(rstat + 6, pairs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // is the survey stale?  The pairs level 1 did NOT turn into records (its hot windows took them) against the same
+    // share of the first launch on these tables: stale_judge, lh_kernels_part2.h.  The lanes' launches share a set of
+    // tables read-only; only the first launch on a set writes its header word, behind the survey that filled the set.
+    if (threadIdx.x == 6) {
+        const unsigned long long rec = g_stats[1];
+        stale_judge(hdr, rstat, pairs > rec ? pairs - rec : 0ull, pairs);
+    }
     if (threadIdx.x < 5) {
         const uint32_t v = g_stats[threadIdx.x];
         g_stats[threadIdx.x] = 0;
@@ -1795,7 +1803,7 @@ static hipError_t launch_part3_t(const IDT *d_ids, const double *d_v, size_t n, 
                            L2.sorted, L2.part_start, L2.slots, L2.nslots, L2.pc, nmetrics, P.log_mpp2, P.log_w, g_inv, S,
                            counts, ranges, g_stats);
     }
-    hipLaunchKernelGGL(k_v3_report, dim3(1), dim3(64), 0, s, g_stats, region_stat, (unsigned long long)n);
+    hipLaunchKernelGGL(k_v3_report, dim3(1), dim3(64), 0, s, g_stats, region_stat, (unsigned long long)n, g_hdr);
     return hipGetLastError();
 }
 

@@ -243,3 +243,43 @@ def test_old_and_new_generation_agree(native_lib, torch_cuda):
                 out.append(snap.buckets_all(M))
     for a, b in zip(out[0], out[1]):
         assert np.array_equal(a, b)
+
+
+def test_a_value_shift_under_a_kept_survey_ends_its_reuse(native_lib, torch_cuda):
+    """A survey is shared by up to LH_OPT_SURVEY_EVERY calls, and no overflow count moves when only the VALUES of a
+    stream shift under it: the hot windows sit where the samples no longer are and every sample becomes a record (1 024
+    names, lognormal survey, four-valued stream: 4.34 instead of 3.0 ms per 1e9 pairs for up to 31 calls).  The launches
+    therefore compare the share of their pairs the hot windows took with the share of the first launch on the tables
+    (stale_judge, lh_kernels_part2.h): the call after a shifted one surveys again.  Exact at every step."""
+    import loghisto_amd
+    rng = np.random.default_rng(41)
+    M, n = 1024, 3_000_000
+    ids = _ids(rng, M, n, 1.0)
+    v1 = rng.lognormal(math.log(1e5), 1.0, n)
+    v2 = _values(rng, "kvalues4", ids, n)                      # bins 691 .. 812: below every window of the first survey
+    d_ids, d_v1, d_v2 = _dev(torch_cuda, ids), _dev(torch_cuda, v1), _dev(torch_cuda, v2)
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        e.set_option(N.OPT_PART_V2_MIN_PAIRS, 1 << 17)
+
+        def call(d_v, v):
+            e.submit_pairs_device(d_ids, d_v)
+            e.sync()
+            with e.flip() as snap:
+                _check(snap, ids, v, M, snap.extract(PCTS, M))
+            return e.counters()
+
+        for _ in range(4):
+            c = call(d_v1, v1)
+        assert c["surveys_reused"] == 3 and c["survey_stale_pairs"] == 0, c   # a stationary stream: one survey, nothing stale
+        c = call(d_v2, v2)                                    # runs on the lognormal survey: its windows take nothing
+        assert c["surveys_reused"] == 4 and c["survey_stale_pairs"] > n // 4, c
+        c = call(d_v2, v2)                                    # ... which the launch reported: this call surveys again
+        assert c["surveys_reused"] == 4, c
+        stale = c["survey_stale_pairs"]
+        for _ in range(3):
+            c = call(d_v2, v2)
+        assert c["surveys_reused"] == 7 and c["survey_stale_pairs"] == stale, c   # and its survey is kept
+        c = call(d_v1, v1)                                    # back again: the same
+        assert c["survey_stale_pairs"] > stale, c
+        before = c["surveys_reused"]
+        assert call(d_v1, v1)["surveys_reused"] == before

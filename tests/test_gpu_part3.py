@@ -424,3 +424,38 @@ def test_a_width_change_is_not_mistaken_for_names_without_skew(native_lib, torch
         c = e.counters()
         assert c["samples_partitioned_v3"] == 6 * n, sorted(c.items())   # every call took the third generation
         assert c["window_log2"] == 13, sorted(c.items())
+
+
+def test_a_value_shift_under_a_kept_survey_ends_its_reuse(native_lib, torch_cuda):
+    """As tests/test_gpu_part2.py's test of the same name, 65 536 names: the share of a launch's pairs that level 1 did
+    NOT turn into records against the first launch on the survey's tables (k_v3_report).  The shifted stream keeps its
+    values inside every reduce window (no overflow or miss count moves: only the new word tells), and every cell is exact."""
+    import loghisto_amd
+    rng = np.random.default_rng(43)
+    M, n = 65536, 3_000_000
+    ids = _ids(rng, M, n, 1.0)
+    v1 = rng.lognormal(math.log(1e5), 0.3, n)
+    v2 = rng.lognormal(math.log(1e3), 0.3, n)                  # 460 bins lower: outside the hot windows, inside 1 024 bins of them
+    d_ids, d_v1, d_v2 = _dev(torch_cuda, ids), _dev(torch_cuda, v1), _dev(torch_cuda, v2)
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        e.set_option(N.OPT_PART_V3_MIN_PAIRS, 1 << 17)
+        e.set_option(N.OPT_PART_V3_DIRECT_MAX_PAIRS, 1)
+
+        def call(d_v, v):
+            e.submit_pairs_device(d_ids, d_v)
+            e.sync()
+            with e.flip() as snap:
+                check(snap, ids, v, M, snap.extract(PCTS, M))
+            return e.counters()
+
+        for _ in range(4):
+            c = call(d_v1, v1)
+        assert c["surveys_reused"] == 3 and c["survey_stale_pairs"] == 0, c
+        c = call(d_v2, v2)
+        assert c["surveys_reused"] == 4 and c["survey_stale_pairs"] > n // 10, c
+        c = call(d_v2, v2)
+        assert c["surveys_reused"] == 4, c                     # surveyed again
+        stale = c["survey_stale_pairs"]
+        for _ in range(3):
+            c = call(d_v2, v2)
+        assert c["surveys_reused"] == 7 and c["survey_stale_pairs"] == stale, c

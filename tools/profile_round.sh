@@ -74,9 +74,10 @@ json.dump({"workload":"C3: 1e9 (uint32 id, float64 value) pairs over 1 024 Zipf(
  "commands":["rocprofv3 --pmc FETCH_SIZE -- $CMD3","rocprofv3 --pmc WRITE_SIZE -- $CMD3"], "corrections": CORR,
  "kernels": per, "hbm_read_bytes_per_call": rd, "hbm_write_bytes_per_call": wr, "hbm_bytes_per_call": rd+wr,
  "algorithmic_bytes_per_call": 12e9, "traffic_over_algorithmic": (rd+wr)/12e9}, open("$OUT/c3_pmc.json","w"), indent=1)
-# C4: every kernel of one lh_submit_pairs_device call of the slice.  The run makes 1 warm-up + 3 timed calls (the
-# extract-latency leg, whose small intervals take the same kernels since round 4, is switched off: --latency-flips 0).
-calls = 4
+# C4: every kernel of one lh_submit_pairs_device call of the slice.  The run makes 1 warm-up + 3 pipelined + a serial
+# pass of timed calls: one k_scatter4 launch per call (the extract-latency leg, whose small intervals take the same
+# kernels since round 4, is switched off: --latency-flips 0).
+calls = pmc("/tmp/pr_c4f/t_results.db", "k_scatter4")["FETCH_SIZE"]["launches"]
 k4 = ["k_survey_count_h", "k_survey_pick", "k_survey_plan_h", "k_survey_remap", "k_scatter4", "k_split_waves",
       "k_split_records", "k_part_hist3", "k_v3_report"]
 per = {}; rd = wr = 0.0
@@ -88,7 +89,7 @@ for k in k4:
               "avg_duration_us_under_pmc": cf["avg_duration_us_profiled"]}
     rd += r; wr += ww
 json.dump({"workload":"C4 one rank: 1.25e8 (uint32 id, float64 value) pairs over 65 536 Zipf(1.0) names, lognormal values",
- "pairs_per_call": 125000000, "names": 65536, "sources": bench.source_hashes("c4"),
+ "pairs_per_call": 125000000, "names": 65536, "calls_in_the_run": calls, "sources": bench.source_hashes("c4"),
  "commands":["rocprofv3 --pmc FETCH_SIZE -- $CMD4","rocprofv3 --pmc WRITE_SIZE -- $CMD4"], "corrections": CORR,
  "note": "the plan kernels (k_plan_count / k_plan_scan / k_plan_scatter: chunk descriptors only) and memsets are not in the sum",
  "kernels": per, "hbm_read_bytes_per_call": rd, "hbm_write_bytes_per_call": wr, "hbm_bytes_per_call": rd+wr,

@@ -21,6 +21,7 @@
 #   merge <tag>                 lh_snapshot_merge: its tests (stub ranks, bench ranks as threads), then the direct reduce pass again
 #   hotwin <tag> <suffix>       the hot-window rule: tests of the second / third generation, then 1 024 names x 1e9 pairs over
 #                               lognormal / few-valued streams and 65 536 names, product against build/liblhgpu_tuning_<suffix>.so
+#   order <tag> <libs> [pairs names reps dists]   one sweep with several builds in a given order (A/B/A: build or box?)
 #   counters <tag>              tools/sq_counters.sh: SQ instruction / LDS counters per distribution
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 SUB=$1; TAG=${2:-r5}; shift 2
@@ -118,12 +119,22 @@ merge)
     done
     ;;
 hotwin)
-    suite tests/test_gpu_part2.py tests/test_gpu_part3.py
+    suite tests/test_gpu_part2.py tests/test_gpu_part3.py tests/test_gpu_lane_blocks.py tests/test_gpu_options.py
     for sfx in "" ${1:-}; do
         lib=""; [ -n "$sfx" ] && lib="--lib loghisto_amd/build/liblhgpu_tuning_$sfx.so"
         echo "== ${sfx:-product}" | tee -a $OUT/ab.txt
         sweep 1e9 1024 5 --dists lognormal,kvalues4,kvalues8,kvalues16,lognormal25,bimodal $lib | tee -a $OUT/ab.txt
         sweep 1e9 65536 4 --dists lognormal,kvalues8 $lib | tee -a $OUT/ab.txt
+    done
+    ;;
+order)
+    # order <tag> <lib,lib,...> <pairs> <names> <reps> <dists>: the same sweep with several libraries IN THE GIVEN ORDER
+    # ("product" = loghisto_amd/liblhgpu.so, anything else = build/liblhgpu_tuning_<name>.so; a name may repeat): tells a
+    # difference between two builds from what the box does over the minutes of a call
+    for sfx in $(echo ${1:-product} | tr ',' ' '); do
+        lib=""; [ "$sfx" != product ] && lib="--lib loghisto_amd/build/liblhgpu_tuning_$sfx.so"
+        echo "== $sfx" | tee -a $OUT/order.txt
+        sweep ${2:-1e9} ${3:-1024} ${4:-5} --dists ${5:-lognormal} $lib | tee -a $OUT/order.txt
     done
     ;;
 counters)

@@ -30,6 +30,11 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="lh_set_option as ID=VALUE (repeatable), e.g. 9=0 turns "
                                                                "the survey + 2-byte-record path off")
     ap.add_argument("--nocheck", action="store_true", help="timing of an ablation build (tools/build_tuning.py -D...): counts are wrong")
+    ap.add_argument("--survey-every", type=int, default=32, help="LH_OPT_SURVEY_EVERY; set again before every distribution, which "
+                                                                 "ends the reuse of the previous distribution's survey")
+    ap.add_argument("--keep-survey", action="store_true",
+                    help="do NOT end the survey's reuse between distributions: every distribution after the first starts on a "
+                         "STALE survey (round 5 measured its few-valued streams that way without knowing: profiles/r05_fewvalued.txt)")
     a = ap.parse_args()
     n = int(a.samples)
     torch.cuda.set_device(0)
@@ -40,6 +45,8 @@ def main():
         k, val = kv.split("=")
         eng.set_option(int(k), int(val))
     for kind in a.dists.split(","):
+        if a.pairs and not a.keep_survey:
+            eng.set_option(16, a.survey_every)  # LH_OPT_SURVEY_EVERY: the tables of the previous distribution are not reused
         data = bench.make_samples(n, kind, 7)
         ids = None
         if a.pairs:
@@ -75,6 +82,8 @@ def main():
                           "v2_samples": eng.counters()["samples_partitioned_v2"],
                           "region_overflows": eng.counters()["region_overflows"],
                           "regions_disabled": eng.counters()["regions_disabled"],
+                          "surveys_reused": eng.counters()["surveys_reused"],
+                          "survey_stale_pairs": eng.counters()["survey_stale_pairs"],
                           "v3": {k: eng.counters()[k] for k in ("samples_partitioned_v3", "window_log2", "records_level1",
                                                                 "records_level2", "level2_overflows",
                                                                 "reduce_window_misses")}}), flush=True)
