@@ -862,7 +862,9 @@ int create_impl(const lh_config *cfg_in, lh_engine *e)
     for (auto &a : e->aux) HIPCHK(hipEventCreateWithFlags(&a.done, hipEventDisableTiming));
 
     HIPCHK(hipMalloc((void **)&e->d_Tx, sizeof(double) * LH_NTHRESH));
-    HIPCHK(hipMalloc((void **)&e->d_D, sizeof(double) * LH_NKEYS));
+    // (padded with zeros to a row's stride: k_extract_wave reads whole 4-bin groups of the table beside the cells)
+    HIPCHK(hipMalloc((void **)&e->d_D, sizeof(double) * LH_ROW_STRIDE));
+    HIPCHK(hipMemset(e->d_D, 0, sizeof(double) * LH_ROW_STRIDE));
     HIPCHK(hipHostMalloc((void **)&e->h_rstat, 64, hipHostMallocDefault));
     for (int i = 0; i < 8; i++) e->h_rstat[i] = 0; // [0] level-1 region overflows [1] window class [2..5] part3 self-metrics [6] pairs they cover [7] pairs a stale survey cost its hot windows
     {

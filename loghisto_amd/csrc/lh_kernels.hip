@@ -666,19 +666,224 @@ __global__ __launch_bounds__(K2_BLOCK) void k_extract(const uint64_t *__restrict
     }
 }
 
+// ---------------------------------------------------------------------------
+// Wave-level arithmetic that stays in the VALU (DPP): k_extract_wave's scans and reductions.  __shfl_up / __shfl_down
+// compile to ds_bpermute_b32 -- a round trip through the LDS crossbar each, two per 64-bit value -- and round 4's
+// wave kernel issued 216 of them per name.
+// ---------------------------------------------------------------------------
+#define LH_DPP32(x, ctrl, rows) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), (rows), 0xf, false))
+template <int CTRL, int ROWS> __device__ __forceinline__ uint64_t dpp_u64(uint64_t x)
+{
+    const uint32_t lo = LH_DPP32((uint32_t)x, CTRL, ROWS), hi = LH_DPP32((uint32_t)(x >> 32), CTRL, ROWS);
+    return ((uint64_t)hi << 32) | lo; // lanes without a source (or outside ROWS) get 0
+}
+// inclusive prefix sum over the 64 lanes: four steps inside the rows of 16 lanes (row_shr:1/2/4/8), then lane 15 of
+// rows 0 and 2 into rows 1 and 3 (row_bcast:15), then lane 31 into rows 2 and 3 (row_bcast:31)
+__device__ __forceinline__ uint64_t wave_scan_incl_u64(uint64_t x)
+{
+    x += dpp_u64<0x111, 0xf>(x);
+    x += dpp_u64<0x112, 0xf>(x);
+    x += dpp_u64<0x114, 0xf>(x);
+    x += dpp_u64<0x118, 0xf>(x);
+    x += dpp_u64<0x142, 0xa>(x);
+    x += dpp_u64<0x143, 0xc>(x);
+    return x;
+}
+__device__ __forceinline__ uint32_t wave_scan_incl_u32(uint32_t x)
+{
+    x += LH_DPP32(x, 0x111, 0xf);
+    x += LH_DPP32(x, 0x112, 0xf);
+    x += LH_DPP32(x, 0x114, 0xf);
+    x += LH_DPP32(x, 0x118, 0xf);
+    x += LH_DPP32(x, 0x142, 0xa);
+    x += LH_DPP32(x, 0x143, 0xc);
+    return x;
+}
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t x, uint32_t src) // src wave-uniform
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, (int)src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), (int)src);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ double readlane_f64(double x, uint32_t src)
+{
+    return __longlong_as_double((long long)readlane_u64((uint64_t)__double_as_longlong(x), src));
+}
+// x of lane + D for the lanes whose lane + D is in the same row of 16 (what the others get does not matter to the caller)
+template <int D> __device__ __forceinline__ double row_down_f64(double x)
+{
+    return __longlong_as_double((long long)dpp_u64<0x100 + D, 0xf>((uint64_t)__double_as_longlong(x))); // row_shl:D
+}
+
+// metrics.go:413 as an INTEGER threshold: float64(sofar) / float64(total) >= p is monotone in sofar, so there is a
+// smallest prefix count T in [1, total] that reaches percentile p, and "the first bucket that reaches p" is the first
+// bin whose inclusive prefix is >= T (that bin is occupied: the prefix moves there).  One to three IEEE divides per
+// (name, percentile) -- by the lane that owns the percentile -- instead of one per cell.  ~0: no prefix reaches p
+// (p > 1 or NaN: the key is omitted, metrics.go:417).
+__device__ __forceinline__ bool pct_reached(uint64_t s, double ft, double p) { return (double)s / ft >= p; }
+__device__ inline uint64_t pct_threshold(double p, uint64_t total)
+{
+    if (!(1.0 >= p)) return ~0ull; // the largest quotient is float64(total) / float64(total) == 1
+    if (p <= 0.0) return 1;        // the first occupied bucket
+    const double ft = (double)total, est = p * ft;
+    uint64_t s = est >= 18446744073709549568.0 ? total : (uint64_t)est;
+    if ((double)s < est) s++; // ceil(p * total): the threshold itself unless a rounding went the other way
+    s = s < 1 ? 1 : (s > total ? total : s);
+    if (pct_reached(s, ft, p) && (s == 1 || !pct_reached(s - 1, ft, p))) return s; // two divides: the usual case
+#pragma unroll 1
+    for (int it = 0; it < 4 && s > 1 && pct_reached(s - 1, ft, p); it++) s--;
+#pragma unroll 1
+    for (int it = 0; it < 4 && s < total && !pct_reached(s, ft, p); it++) s++;
+    if (pct_reached(s, ft, p) && (s == 1 || !pct_reached(s - 1, ft, p))) return s;
+    // not settled in four steps either way (totals beyond 2^53, where float64(s) moves in steps): bisection;
+    // reached(total) holds
+    uint64_t lo = 0, hi = total;
+#pragma unroll 1
+    while (hi - lo > 1) {
+        const uint64_t mid = lo + (hi - lo) / 2;
+        if (pct_reached(mid, ft, p)) hi = mid; else lo = mid;
+    }
+    return hi;
+}
+
+// 16 bytes at an 8-byte-aligned address as ONE load (global_load_dwordx4; unaligned vector access is on for HSA)
+struct __attribute__((packed, aligned(8))) u64x2_a8 { uint64_t a, b; };
+struct __attribute__((packed, aligned(8))) f64x2_a8 { double a, b; };
+
+// What k_extract_wave does with a span it holds in registers (32-bit cells, a total below 2^32): pass 1 of
+// processHistograms, the prefix scan, the percentile search.
+__device__ __forceinline__ uint32_t ew_scan(uint32_t x) { return wave_scan_incl_u32(x); }
+__device__ __forceinline__ uint32_t ew_readlane(uint32_t x, uint32_t src) { return (uint32_t)__builtin_amdgcn_readlane((int)x, (int)src); }
+
+typedef uint32_t CT; // (the cells' type in the registers)
+__device__ __forceinline__ void ew_reduce_and_search(const CT (&creg)[4][K2_PER_THREAD], const double *__restrict__ D,
+                                                     uint32_t lo, uint32_t hi, uint32_t lane, const PctArgs &pa, uint32_t np,
+                                                     uint64_t &total_out, double &tsum, uint32_t &tnb, uint32_t &found)
+{
+    constexpr uint32_t STEPS = 4;
+    // the decompressed values of the lane's bins: requested here, step by step, and consumed at once -- held beside
+    // the cells they cost 32 registers and two waves per SIMD (the table is 512 KiB: L2 at worst)
+    double dreg[STEPS][K2_PER_THREAD];
+#pragma unroll
+    for (uint32_t s = 0; s < STEPS; s++) {
+        const uint32_t b0 = lo + s * K2_BLOCK + lane * K2_PER_THREAD;
+        f64x2_a8 d01 = {0, 0}, d23 = {0, 0};
+        if (b0 <= hi && b0 + K2_PER_THREAD <= LH_ROW_STRIDE) {
+            const f64x2_a8 *dp = reinterpret_cast<const f64x2_a8 *>(D + b0);
+            d01 = dp[0];
+            d23 = dp[1];
+        }
+        dreg[s][0] = d01.a;
+        dreg[s][1] = d01.b;
+        dreg[s][2] = d23.a;
+        dreg[s][3] = d23.b;
+    }
+    // pass 1 (metrics.go:342-347) from the registers: psum[k] is k_extract's thread 4 * lane + k.  An empty cell
+    // adds +-0 (its table entry is finite), which leaves a partial sum that is not -0 as it is -- and none is: they
+    // start at +0 and no product of an occupied cell is -0.
+    uint32_t nb = 0; // occupied buckets of the span: counted on the scalar unit, a ballot per (step, k)
+    double psum[K2_PER_THREAD] = {0, 0, 0, 0};
+    CT stepc[STEPS]; // the lane's four cells of a step, summed
+#pragma unroll
+    for (uint32_t s = 0; s < STEPS; s++) {
+        stepc[s] = 0;
+#pragma unroll
+        for (int k = 0; k < K2_PER_THREAD; k++) {
+            const CT c = creg[s][k];
+            stepc[s] += c;
+            psum[k] += dreg[s][k] * (double)c; // value * float64(*count), metrics.go:344
+            nb += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(c != 0));
+        }
+    }
+    // inclusive prefix of the lanes' step sums (kept for the percentile search) and the steps' totals
+    CT inc[STEPS], stot[STEPS], total = 0;
+#pragma unroll
+    for (uint32_t s = 0; s < STEPS; s++) {
+        inc[s] = ew_scan(stepc[s]);
+        stot[s] = ew_readlane(inc[s], 63);
+        total += stot[s];
+    }
+    total_out = total;
+    tnb = nb;
+    // k_extract's tree over the 64 threads of each of its four waves (threads 64 w .. 64 w + 63 live in lanes
+    // 16 w .. 16 w + 15: one DPP row): distances 32, 16, 8, 4 threads are 8, 4, 2, 1 lanes; 2 and 1 stay inside the lane
+#pragma unroll
+    for (int k = 0; k < K2_PER_THREAD; k++) {
+        psum[k] += row_down_f64<8>(psum[k]);
+        psum[k] += row_down_f64<4>(psum[k]);
+        psum[k] += row_down_f64<2>(psum[k]);
+        psum[k] += row_down_f64<1>(psum[k]);
+    }
+    psum[0] += psum[2];
+    psum[1] += psum[3];
+    psum[0] += psum[1];
+#pragma unroll
+    for (int w = 0; w < K2_WAVES; w++) tsum += readlane_f64(psum[0], 16 * w); // ((w0 + w1) + w2) + w3, as k_extract
+
+    // ---- pass 2 (metrics.go:406-418): lane i < np owns percentile i; T = the prefix count that reaches it
+    if (total && np) {
+        uint64_t T64 = ~0ull;
+        if (lane < np) T64 = pct_threshold(pa.p[lane], (uint64_t)total);
+        uint32_t open = (uint32_t)__builtin_amdgcn_ballot_w64(T64 != ~0ull); // percentiles without a bin yet (np <= 32)
+        const CT T = (CT)T64; // (a threshold that exists is <= total)
+        CT carry = 0;
+#pragma unroll
+        for (uint32_t s = 0; s < STEPS; s++) {
+            if (!open || lo + s * K2_BLOCK > hi) break; // wave-uniform
+            const CT upto = carry + stot[s];            // prefix at the end of this step
+            CT pre[K2_PER_THREAD];                      // inclusive prefix at the lane's four bins
+            CT sofar = carry + (inc[s] - stepc[s]);
+#pragma unroll
+            for (int k = 0; k < K2_PER_THREAD; k++) {
+                sofar += creg[s][k];
+                pre[k] = sofar;
+            }
+            for (uint32_t todo = open; todo; todo &= todo - 1) {
+                const uint32_t i = (uint32_t)__builtin_ctz(todo);
+                const CT Ti = ew_readlane(T, i);
+                if (Ti > upto) continue; // reached in a later step
+                // the first lane whose last bin reaches Ti (lane 63's does), and how many of its bins stay below
+                const unsigned long long reach = __builtin_amdgcn_ballot_w64(pre[K2_PER_THREAD - 1] >= Ti);
+                const uint32_t f = (uint32_t)__builtin_ctzll(reach);
+                const uint32_t below = (pre[0] < Ti ? 1u : 0u) + (pre[1] < Ti ? 1u : 0u) + (pre[2] < Ti ? 1u : 0u);
+                const uint32_t bin = lo + s * K2_BLOCK + f * K2_PER_THREAD +
+                                     (uint32_t)__builtin_amdgcn_readlane((int)below, (int)f);
+                if (lane == i) found = bin;
+                open &= ~(1u << i);
+            }
+            carry = upto;
+        }
+    }
+}
+
 // The same, one WAVE per metric (four metrics per workgroup, no workgroup barriers): for thousands of names with
 // narrow spans the block-per-metric form is bound by workgroup dispatch and its six barriers, not by the scan
 // (65 536 names: ~290 us).  Results are BIT-IDENTICAL to k_extract, _sum included: the wave forms the partial sums of
 // the 256 k_extract threads it stands for (thread t accumulates bins lo + t, lo + t + 256, ... in that order), reduces
-// them with the same shuffle tree per 64 threads and adds the four wave totals in the same order; counts and the
-// percentile scan are integer arithmetic.
+// them with the same tree per 64 threads and adds the four wave totals in the same order; counts and the percentile
+// search are integer arithmetic.
 //
 // Spans of at most EW_REG bins (1 024: every window of the third generation's default width) are read ONCE: the row's
 // cells stay in registers between the count / sum pass and the prefix scan, and the decompress table entries are
 // requested with the cells instead of after them (round 3 read every window twice and took three dependent round
-// trips per name: 139 us for 65 536 names, 0.28 of the HBM roofline).  Layout: lane L holds bins
-// lo + 256 s + 4 L + k (s < 4, k < 4), i.e. the k_extract threads t = 4 L + k.  Wider spans take the two-pass loop.
+// trips per name: 139 us for 65 536 names).  Layout: lane L holds bins lo + 256 s + 4 L + k (s < 4, k < 4), i.e. the
+// k_extract threads t = 4 L + k.  Wider spans take the two-pass loop.
+//
+// Round 5 (65 536 names: 126 - 178 us for a 73 us read of the windows).  The in-register path was bound by what it did
+// with the cells, not by reading them: with the arithmetic removed the kernel takes 57 us, and every instruction of a
+// wave costs four cycles of its SIMD (65 536 waves on 1 024 SIMDs: 0.1 us per instruction) -- 32 eight-byte loads, a
+// branch per cell, an IEEE divide per cell (metrics.go:413 evaluated for every bucket), 216 ds_bpermute per name.
+// Now: 16-byte loads per 4-bin group, only by the lanes that have a bin inside the span; 32-BIT cells in the registers
+// (a span with a cell of 2^22 or more takes the two-pass loop); the table entries requested after the cells and
+// consumed at once; branch-free accumulation (adding the +-0 of an empty cell leaves every partial sum as it is);
+// occupied buckets counted by the scalar unit (a ballot per register); every scan and reduction in DPP; and the
+// percentiles as integer thresholds (pct_threshold): two divides per (name, percentile) by the lane that owns it, then
+// one ballot and three compares.  110 -> 96 us on a snapshot read repeatedly, 176 -> 128 us inside config 4's step
+// (profiles/r05_extract_wave.txt).
 constexpr uint32_t EW_STEPS = 4, EW_REG = EW_STEPS * K2_BLOCK;
+
+static_assert(LH_ROW_STRIDE >= LH_NKEYS + 4, "k_extract_wave reads whole 4-bin groups inside the row's stride");
+// (the decompress table is allocated LH_ROW_STRIDE entries long, zeros behind LH_NKEYS: lh_engine.cc)
 
 __global__ __launch_bounds__(K2_BLOCK) void k_extract_wave(const uint64_t *__restrict__ counts,
                                                            const uint32_t *__restrict__ ranges, uint32_t nmetrics,
@@ -699,60 +904,43 @@ __global__ __launch_bounds__(K2_BLOCK) void k_extract_wave(const uint64_t *__res
     if (m >= nmetrics) return; // wave-uniform
     const uint64_t *row = counts + (size_t)m * LH_ROW_STRIDE;
     const uint32_t lo = ranges[2 * (size_t)m], hi = ranges[2 * (size_t)m + 1];
-    const bool inreg = lo <= hi && hi - lo < EW_REG; // wave-uniform
+    bool inreg = lo <= hi && hi - lo < EW_REG; // wave-uniform
 
     uint64_t total = 0;
     double tsum = 0;
     uint32_t tnb = 0;
-    uint64_t creg[EW_STEPS][K2_PER_THREAD];
+    uint32_t found = 0xffffffffu; // lane i < np: the bin of percentile i
+    uint32_t c32[EW_STEPS][K2_PER_THREAD];
     if (inreg) {
-        // ---- one read of the span: cells and their decompressed values
-        double dreg[EW_STEPS][K2_PER_THREAD];
+        // ---- one read of the span, 4 consecutive bins per lane and step.  Cells outside [lo, hi] are zero (the range
+        // covers every cell ever written: it is all the clear kernels clear), so a 4-bin group that straddles hi needs
+        // no mask.  The span stays in registers as 32-BIT cells when every cell is below 2^22 (its total then fits 32
+        // bits: any interval short of ~10^9 samples in one name); a span with a larger cell takes the two-pass loop.
+        uint32_t hibits = 0; // OR of every cell's bits 22 .. 63, folded into one word
 #pragma unroll
         for (uint32_t s = 0; s < EW_STEPS; s++) {
             const uint32_t b0 = lo + s * K2_BLOCK + lane * K2_PER_THREAD;
-#pragma unroll
-            for (int k = 0; k < K2_PER_THREAD; k++) {
-                const bool in = b0 + k <= hi;
-                creg[s][k] = in ? row[b0 + k] : 0;
-                dreg[s][k] = in ? D[b0 + k] : 0.0;
+            u64x2_a8 c01 = {0, 0}, c23 = {0, 0};
+            // a lane whose four bins all lie beyond hi asks for nothing: a 600-bin window is three steps = 768 bins wide,
+            // and the lanes past its end were 22 % of the kernel's reads
+            if (b0 <= hi && b0 + K2_PER_THREAD <= LH_ROW_STRIDE) {
+                const u64x2_a8 *rp = reinterpret_cast<const u64x2_a8 *>(row + b0);
+                c01 = rp[0];
+                c23 = rp[1];
             }
+            c32[s][0] = (uint32_t)c01.a;
+            c32[s][1] = (uint32_t)c01.b;
+            c32[s][2] = (uint32_t)c23.a;
+            c32[s][3] = (uint32_t)c23.b;
+            hibits |= (uint32_t)(c01.a >> 32) | (uint32_t)(c01.b >> 32) | (uint32_t)(c23.a >> 32) | (uint32_t)(c23.b >> 32);
+            hibits |= (c32[s][0] | c32[s][1] | c32[s][2] | c32[s][3]) >> 22;
         }
-        // pass 1 (metrics.go:342-347) from the registers: psum[k] is k_extract's thread 4 * lane + k
-        uint64_t cnt = 0;
-        uint32_t nb = 0;
-        double psum[K2_PER_THREAD] = {0, 0, 0, 0};
-#pragma unroll
-        for (uint32_t s = 0; s < EW_STEPS; s++)
-#pragma unroll
-            for (int k = 0; k < K2_PER_THREAD; k++) {
-                const uint64_t c = creg[s][k];
-                if (c) {
-                    cnt += c;
-                    psum[k] += dreg[s][k] * (double)c; // value * float64(*count), metrics.go:344
-                    nb++;
-                }
-            }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            cnt += shfl_down_u64(cnt, d);
-            nb += __shfl_down(nb, d, 64);
-        }
-        // k_extract's tree over the 64 threads of each of its four waves (threads 64 w .. 64 w + 63 live in lanes
-        // 16 w .. 16 w + 15): distances 32, 16, 8, 4 threads are 8, 4, 2, 1 lanes; 2 and 1 stay inside the lane
-#pragma unroll
-        for (int d = 8; d >= 1; d >>= 1)
-#pragma unroll
-            for (int k = 0; k < K2_PER_THREAD; k++) psum[k] += shfl_down_f64(psum[k], d);
-        psum[0] += psum[2];
-        psum[1] += psum[3];
-        psum[0] += psum[1];
-        total = shfl_u64(cnt, 0);
-        tnb = __shfl(nb, 0, 64);
-#pragma unroll
-        for (int w = 0; w < K2_WAVES; w++) tsum += shfl_f64(psum[0], 16 * w); // ((w0 + w1) + w2) + w3, as k_extract
+        inreg = __builtin_amdgcn_ballot_w64(hibits != 0) == 0; // wave-uniform
+    }
+    if (inreg) {
+        ew_reduce_and_search(c32, D, lo, hi, lane, pa, np, total, tsum, tnb, found);
     } else {
-        // ---- pass 1, wide span: every bin read here and again by the scan below
+        // ---- wide span: every bin read here and again by the scan below
         uint64_t cnt = 0;
         double sum4[K2_WAVES] = {0, 0, 0, 0};
         uint32_t nb = 0;
@@ -783,6 +971,46 @@ __global__ __launch_bounds__(K2_BLOCK) void k_extract_wave(const uint64_t *__res
 #pragma unroll
         for (int v = 0; v < K2_WAVES; v++) tsum += shfl_f64(sum4[v], 0); // ((w0 + w1) + w2) + w3, as k_extract
         tnb = __shfl(nb, 0, 64);
+
+        // pass 2, 256 bins per step: the quotient of metrics.go:413 at every occupied bin
+        if (total && np) {
+            const double ftotal = (double)total;
+            uint64_t carry = 0;
+            uint32_t open = np; // percentiles without a bin yet (wave-uniform)
+            for (uint32_t base = lo; base <= hi && open; base += K2_TILE / K2_WAVES) {
+                const uint32_t b0 = base + lane * K2_PER_THREAD;
+                uint64_t c[K2_PER_THREAD];
+#pragma unroll
+                for (int k = 0; k < K2_PER_THREAD; k++) c[k] = (b0 + k <= hi) ? row[b0 + k] : 0;
+                uint64_t tsumc = 0;
+#pragma unroll
+                for (int k = 0; k < K2_PER_THREAD; k++) tsumc += c[k];
+                const uint64_t inc = wave_scan_incl_u64(tsumc);
+                uint64_t sofar = carry + (inc - tsumc);
+                double q[K2_PER_THREAD]; // float64(sofar)/float64(totalCount), metrics.go:413; -1 for empty buckets
+#pragma unroll
+                for (int k = 0; k < K2_PER_THREAD; k++) {
+                    sofar += c[k];
+                    q[k] = c[k] ? (double)sofar / ftotal : -1.0;
+                }
+                for (uint32_t i = 0; i < np; i++) {
+                    const uint32_t fi = __shfl(found, (int)i, 64);
+                    if (fi != 0xffffffffu) continue; // settled by an earlier step (wave-uniform)
+                    const double pi = pa.p[i];
+                    uint32_t hit = 0xffffffffu;
+#pragma unroll
+                    for (int k = K2_PER_THREAD - 1; k >= 0; k--)
+                        if (q[k] >= pi && q[k] >= 0.0) hit = b0 + k;
+                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit != 0xffffffffu);
+                    if (mask) {
+                        const uint32_t first_hit = __shfl(hit, (int)__builtin_ctzll(mask), 64);
+                        if (lane == i) found = first_hit;
+                        open--;
+                    }
+                }
+                carry += readlane_u64(inc, 63);
+            }
+        }
     }
     if (lane == 0) {
         ExtractOut o;
@@ -793,61 +1021,6 @@ __global__ __launch_bounds__(K2_BLOCK) void k_extract_wave(const uint64_t *__res
         o.nbuckets = tnb;
         o.present = total ? 1u : 0u;
         out[m] = o;
-    }
-
-    // ---- pass 2 (metrics.go:406-418): lane i < np owns percentile i and keeps the first bin that reaches it
-    uint32_t found = 0xffffffffu;
-    if (total && np) {
-        const double ftotal = (double)total;
-        uint64_t carry = 0;
-        uint32_t open = np; // percentiles without a bin yet (wave-uniform)
-        auto scan_step = [&](uint32_t b0, const uint64_t (&c)[K2_PER_THREAD]) {
-            uint64_t tsumc = 0;
-#pragma unroll
-            for (int k = 0; k < K2_PER_THREAD; k++) tsumc += c[k];
-            uint64_t inc = tsumc;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint64_t y = shfl_up_u64(inc, d);
-                if ((int)lane >= d) inc += y;
-            }
-            uint64_t sofar = carry + (inc - tsumc);
-            double q[K2_PER_THREAD]; // float64(sofar)/float64(totalCount), metrics.go:413; -1 for empty buckets
-#pragma unroll
-            for (int k = 0; k < K2_PER_THREAD; k++) {
-                sofar += c[k];
-                q[k] = c[k] ? (double)sofar / ftotal : -1.0;
-            }
-            for (uint32_t i = 0; i < np; i++) {
-                const uint32_t fi = __shfl(found, (int)i, 64);
-                if (fi != 0xffffffffu) continue; // settled by an earlier step (wave-uniform)
-                const double pi = pa.p[i];
-                uint32_t hit = 0xffffffffu;
-#pragma unroll
-                for (int k = K2_PER_THREAD - 1; k >= 0; k--)
-                    if (q[k] >= pi && q[k] >= 0.0) hit = b0 + k;
-                const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit != 0xffffffffu);
-                if (mask) {
-                    const uint32_t first_hit = __shfl(hit, (int)__builtin_ctzll(mask), 64);
-                    if (lane == i) found = first_hit;
-                    open--;
-                }
-            }
-            carry += shfl_u64(inc, 63);
-        };
-        if (inreg) {
-#pragma unroll
-            for (uint32_t s = 0; s < EW_STEPS; s++)
-                if (open && lo + s * K2_BLOCK <= hi) scan_step(lo + s * K2_BLOCK + lane * K2_PER_THREAD, creg[s]); // wave-uniform
-        } else {
-            for (uint32_t base = lo; base <= hi && open; base += K2_TILE / K2_WAVES) { // 256 bins per step
-                const uint32_t b0 = base + lane * K2_PER_THREAD;
-                uint64_t c[K2_PER_THREAD];
-#pragma unroll
-                for (int k = 0; k < K2_PER_THREAD; k++) c[k] = (b0 + k <= hi) ? row[b0 + k] : 0;
-                scan_step(b0, c);
-            }
-        }
     }
     if (lane < np) {
         const size_t o = (size_t)m * np + lane;
@@ -1214,16 +1387,24 @@ __device__ __forceinline__ uint32_t merge_block_of(const uint32_t *__restrict__ 
 // into the next): cells 4j .. 4j + 3 (8 bits) or 2j, 2j + 1 (16 bits) of the window are word j, low field first.
 // Every thread loads / stores ONE cell (coalesced uint64 accesses on the row store's side); the 2 or 4 lanes of a word
 // combine their fields with DPP shuffles and the first of them writes it.
-template <typename WORD>
+// TPR threads per row: 256 (one workgroup per row: few names, wide windows) or 64 (one WAVE per row, four rows per
+// workgroup: from 2 048 rows on -- 65 536 windows of ~600 cells are 2.3 cells per thread of a workgroup behind a chain
+// of dependent loads (range, owner block, offsets), and the kernels ran at the latency of 32 rounds of such chains:
+// pack 131 us + unpack 146 us for 157 MB of words at config 4's name count, round 4).
+template <typename WORD, int TPR>
 __global__ __launch_bounds__(256) void k_pack_rows(const uint64_t *__restrict__ counts,
                                                    const uint32_t *__restrict__ ranges,
                                                    const uint8_t *__restrict__ cls,
                                                    const unsigned long long *__restrict__ P,
                                                    const unsigned long long *__restrict__ bstart,
                                                    const uint32_t *__restrict__ brow, uint32_t nblocks,
-                                                   unsigned long long bstride, WORD *__restrict__ buf)
+                                                   unsigned long long bstride, WORD *__restrict__ buf, uint32_t nrows)
 {
-    const uint32_t r = blockIdx.x;
+    static_assert(TPR == 256 || TPR == 64, "a workgroup or a wave per row");
+    const uint32_t t = TPR == 256 ? threadIdx.x : (threadIdx.x & 63u);
+    uint32_t r = TPR == 256 ? blockIdx.x : blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (TPR == 64) r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r); // wave-uniform: the row's scalars by scalar loads
+    if (r >= nrows) return;
     const uint32_t lo = ranges[2 * (size_t)r], hi = ranges[2 * (size_t)r + 1];
     if (lo > hi) return;
     const uint32_t k = merge_block_of(brow, nblocks, r);
@@ -1231,16 +1412,18 @@ __global__ __launch_bounds__(256) void k_pack_rows(const uint64_t *__restrict__ 
     const uint64_t *src = counts + (size_t)r * LH_ROW_STRIDE + lo;
     const uint32_t w = hi - lo + 1;
     if constexpr (sizeof(WORD) == 8) {
-        for (uint32_t i = threadIdx.x; i < w; i += 256) dst[i] = src[i];
+#pragma unroll 4
+        for (uint32_t i = t; i < w; i += TPR) dst[i] = src[i];
     } else {
         const uint32_t bits = cls[r];
         if (bits == 32u) {
-            for (uint32_t i = threadIdx.x; i < w; i += 256) dst[i] = (uint32_t)src[i];
+#pragma unroll 4
+            for (uint32_t i = t; i < w; i += TPR) dst[i] = (uint32_t)src[i];
         } else {
             const uint32_t log_c = bits == 8u ? 2u : 1u, c = 1u << log_c; // cells per word
-            const uint32_t wpad = (w + c - 1u) & ~(c - 1u);                // (whole waves run the shuffles: 256 % c == 0)
-            for (uint32_t i0 = 0; i0 < wpad; i0 += 256) {
-                const uint32_t i = i0 + threadIdx.x;
+            const uint32_t wpad = (w + c - 1u) & ~(c - 1u);                // (whole waves run the shuffles: TPR % c == 0)
+            for (uint32_t i0 = 0; i0 < wpad; i0 += TPR) {
+                const uint32_t i = i0 + t;
                 uint32_t f = i < w ? (uint32_t)src[i] << ((i & (c - 1u)) * bits) : 0u;
                 f |= __shfl_xor(f, 1, 64);
                 if (log_c == 2u) f |= __shfl_xor(f, 2, 64);
@@ -1265,29 +1448,37 @@ __global__ __launch_bounds__(256) void k_pack_pad(const unsigned long long *__re
 }
 
 // buf holds block `kblock` (rows first_row .. first_row + nrows_out) packed from offset 0.
-template <typename WORD>
+template <typename WORD, int TPR>
 __global__ __launch_bounds__(256) void k_unpack_rows(uint64_t *__restrict__ counts,
                                                      const uint32_t *__restrict__ ranges,
                                                      const uint8_t *__restrict__ cls,
                                                      const unsigned long long *__restrict__ P,
                                                      const unsigned long long *__restrict__ bstart, uint32_t kblock,
-                                                     uint32_t first_row, const WORD *__restrict__ buf)
+                                                     uint32_t first_row, const WORD *__restrict__ buf, uint32_t nrows_out)
 {
-    const uint32_t r = first_row + blockIdx.x;
+    static_assert(TPR == 256 || TPR == 64, "a workgroup or a wave per row (k_pack_rows)");
+    const uint32_t t = TPR == 256 ? threadIdx.x : (threadIdx.x & 63u);
+    uint32_t q = TPR == 256 ? blockIdx.x : blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (TPR == 64) q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+    if (q >= nrows_out) return;
+    const uint32_t r = first_row + q;
     const uint32_t lo = ranges[2 * (size_t)r], hi = ranges[2 * (size_t)r + 1];
     if (lo > hi) return;
     const WORD *src = buf + (P[r] - bstart[kblock]);
     uint64_t *dst = counts + (size_t)r * LH_ROW_STRIDE + lo;
     const uint32_t w = hi - lo + 1;
     if constexpr (sizeof(WORD) == 8) {
-        for (uint32_t i = threadIdx.x; i < w; i += 256) dst[i] = src[i];
+#pragma unroll 4
+        for (uint32_t i = t; i < w; i += TPR) dst[i] = src[i];
     } else {
         const uint32_t bits = cls[r];
         if (bits == 32u) {
-            for (uint32_t i = threadIdx.x; i < w; i += 256) dst[i] = (uint64_t)src[i];
+#pragma unroll 4
+            for (uint32_t i = t; i < w; i += TPR) dst[i] = (uint64_t)src[i];
         } else {
             const uint32_t log_c = bits == 8u ? 2u : 1u, c = 1u << log_c, mask = (1u << bits) - 1u;
-            for (uint32_t i = threadIdx.x; i < w; i += 256)
+#pragma unroll 4
+            for (uint32_t i = t; i < w; i += TPR)
                 dst[i] = (uint64_t)((src[i >> log_c] >> ((i & (c - 1u)) * bits)) & mask);
         }
     }
@@ -1340,18 +1531,30 @@ hipError_t launch_pack_rows(const uint64_t *counts, const uint32_t *ranges, cons
     if (!nrows) return hipSuccess;
     const unsigned long long *Pp = reinterpret_cast<const unsigned long long *>(P);
     const unsigned long long *bs = reinterpret_cast<const unsigned long long *>(bstart);
+    const bool wave = nrows >= 2048; // a wave per row (k_extract_wave's and k_clear_rows_wave's switch-over)
+    const dim3 grid(wave ? (nrows + 3) / 4 : nrows);
     if (words32) {
-        hipLaunchKernelGGL(k_pack_rows<uint32_t>, dim3(nrows), dim3(256), 0, s, counts, ranges, cls, Pp, bs, brow, nblocks,
-                           (unsigned long long)bstride, static_cast<uint32_t *>(buf));
+        uint32_t *b32 = static_cast<uint32_t *>(buf);
+        if (wave)
+            hipLaunchKernelGGL((k_pack_rows<uint32_t, 64>), grid, dim3(256), 0, s, counts, ranges, cls, Pp, bs, brow, nblocks,
+                               (unsigned long long)bstride, b32, nrows);
+        else
+            hipLaunchKernelGGL((k_pack_rows<uint32_t, 256>), grid, dim3(256), 0, s, counts, ranges, cls, Pp, bs, brow, nblocks,
+                               (unsigned long long)bstride, b32, nrows);
         if (nblocks > 1)
             hipLaunchKernelGGL(k_pack_pad<uint32_t>, dim3(64, nblocks), dim3(256), 0, s, bs, nblocks,
-                               (unsigned long long)bstride, static_cast<uint32_t *>(buf));
+                               (unsigned long long)bstride, b32);
     } else {
-        hipLaunchKernelGGL(k_pack_rows<uint64_t>, dim3(nrows), dim3(256), 0, s, counts, ranges, cls, Pp, bs, brow, nblocks,
-                           (unsigned long long)bstride, static_cast<uint64_t *>(buf));
+        uint64_t *b64 = static_cast<uint64_t *>(buf);
+        if (wave)
+            hipLaunchKernelGGL((k_pack_rows<uint64_t, 64>), grid, dim3(256), 0, s, counts, ranges, cls, Pp, bs, brow, nblocks,
+                               (unsigned long long)bstride, b64, nrows);
+        else
+            hipLaunchKernelGGL((k_pack_rows<uint64_t, 256>), grid, dim3(256), 0, s, counts, ranges, cls, Pp, bs, brow, nblocks,
+                               (unsigned long long)bstride, b64, nrows);
         if (nblocks > 1)
             hipLaunchKernelGGL(k_pack_pad<uint64_t>, dim3(64, nblocks), dim3(256), 0, s, bs, nblocks,
-                               (unsigned long long)bstride, static_cast<uint64_t *>(buf));
+                               (unsigned long long)bstride, b64);
     }
     return hipGetLastError();
 }
@@ -1363,12 +1566,25 @@ hipError_t launch_unpack_rows(uint64_t *counts, const uint32_t *ranges, const ui
     if (!nrows_out) return hipSuccess;
     const unsigned long long *Pp = reinterpret_cast<const unsigned long long *>(P);
     const unsigned long long *bs = reinterpret_cast<const unsigned long long *>(bstart);
-    if (words32)
-        hipLaunchKernelGGL(k_unpack_rows<uint32_t>, dim3(nrows_out), dim3(256), 0, s, counts, ranges, cls, Pp, bs, kblock,
-                           first_row, static_cast<const uint32_t *>(buf));
-    else
-        hipLaunchKernelGGL(k_unpack_rows<uint64_t>, dim3(nrows_out), dim3(256), 0, s, counts, ranges, cls, Pp, bs, kblock,
-                           first_row, static_cast<const uint64_t *>(buf));
+    const bool wave = nrows_out >= 2048;
+    const dim3 grid(wave ? (nrows_out + 3) / 4 : nrows_out);
+    if (words32) {
+        const uint32_t *b32 = static_cast<const uint32_t *>(buf);
+        if (wave)
+            hipLaunchKernelGGL((k_unpack_rows<uint32_t, 64>), grid, dim3(256), 0, s, counts, ranges, cls, Pp, bs, kblock,
+                               first_row, b32, nrows_out);
+        else
+            hipLaunchKernelGGL((k_unpack_rows<uint32_t, 256>), grid, dim3(256), 0, s, counts, ranges, cls, Pp, bs, kblock,
+                               first_row, b32, nrows_out);
+    } else {
+        const uint64_t *b64 = static_cast<const uint64_t *>(buf);
+        if (wave)
+            hipLaunchKernelGGL((k_unpack_rows<uint64_t, 64>), grid, dim3(256), 0, s, counts, ranges, cls, Pp, bs, kblock,
+                               first_row, b64, nrows_out);
+        else
+            hipLaunchKernelGGL((k_unpack_rows<uint64_t, 256>), grid, dim3(256), 0, s, counts, ranges, cls, Pp, bs, kblock,
+                               first_row, b64, nrows_out);
+    }
     return hipGetLastError();
 }
 

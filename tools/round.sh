@@ -21,6 +21,7 @@
 #   merge <tag>                 lh_snapshot_merge: its tests (stub ranks, bench ranks as threads), then the direct reduce pass again
 #   hotwin <tag> <suffix>       the hot-window rule: tests of the second / third generation, then 1 024 names x 1e9 pairs over
 #                               lognormal / few-valued streams and 65 536 names, product against build/liblhgpu_tuning_<suffix>.so
+#   extract <tag>               K2 at 65 536 names: its tests, config 4's extract_roofline, the kernel under the tracer
 #   order <tag> <libs> [pairs names reps dists]   one sweep with several builds in a given order (A/B/A: build or box?)
 #   counters <tag>              tools/sq_counters.sh: SQ instruction / LDS counters per distribution
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -126,6 +127,22 @@ hotwin)
         sweep 1e9 1024 5 --dists lognormal,kvalues4,kvalues8,kvalues16,lognormal25,bimodal $lib | tee -a $OUT/ab.txt
         sweep 1e9 65536 4 --dists lognormal,kvalues8 $lib | tee -a $OUT/ab.txt
     done
+    ;;
+extract)
+    # K2 at 65 536 names: the tests that hold k_extract_wave against the oracle and against k_extract, then config 4 on one
+    # rank (extract_roofline: kernel and copy apart; extract latency over 300 flips) and the kernel under the tracer
+    suite tests/test_gpu_extract_thresholds.py tests/test_gpu_options.py tests/test_gpu_part3.py tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_merge.py
+    python bench.py --workload c4 --steps 5 --warmup 2 --no-parity --latency-flips 300 2> $OUT/c4.err | grep "^{" | tail -1 > $OUT/c4_bench.json
+    python - <<PY | tee $OUT/extract.txt
+import json
+j = json.load(open("$OUT/c4_bench.json"))
+x = j["extract_roofline"]
+print("k_extract_wave kernel_ms %.4f copy_ms %.4f kernel_frac %.3f  extract_owned_ms %.3f  latency %s" % (
+    x["kernel_ms"], x["copy_ms"], x["kernel_frac"], j.get("extract_owned_ms", -1), j.get("extract_latency_us")))
+PY
+    (cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/pk
+     timeout 300 rocprofv3 --kernel-trace -d /tmp/pk -o t -- python $R/bench.py --workload c4 --steps 3 --warmup 1 --no-parity --latency-flips 0 > /dev/null 2>&1
+     python $R/profiles/summarize_rocpd.py stats /tmp/pk/t_results.db | grep -E "^kernel|k_extract|k_clear|k_pack|k_unpack|k_merge" | cut -c1-170) | tee $OUT/trace.txt
     ;;
 order)
     # order <tag> <lib,lib,...> <pairs> <names> <reps> <dists>: the same sweep with several libraries IN THE GIVEN ORDER
