@@ -1538,7 +1538,9 @@ int extract_impl(lh_snapshot *s, uint32_t first, size_t nmetrics, const double *
     // host block through its device mapping: one launch + one sync, no separate copy.  Large ones go through
     // HBM and one DMA (fine-grained stores over PCIe would be slower than the copy engine); from 2 048 names on the
     // scan itself is the wave-per-metric kernel (65 536 names: ~290 -> ~60 us), so that the 9 MB transfer is what
-    // remains -- measured: cutting it into chunks pipelined behind the kernels gained nothing over one copy, and
+    // remains -- measured: cutting it into chunks pipelined behind the kernels gained nothing over one copy (round 2, on
+    // this stream; round 5, the copies on a stream of their own: 288 us for one block, 321 / 377 / 1 635 us for 2 / 4 / 8 --
+    // the copies do not overlap the kernels and every extra hipMemcpyAsync costs ~10 us, profiles/r05_extract_wave.txt), and
     // lh_extract_rows_view hands the pinned block out in place instead of copying it once more on the host.
     const bool zero_copy = e->d_hxbuf != nullptr && L.total <= e->zero_copy_max && e->zero_copy_enabled;
     unsigned char *xb = zero_copy ? e->d_hxbuf : e->d_xbuf;

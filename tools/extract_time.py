@@ -38,18 +38,24 @@ def main():
         eng.sync()
         snap = eng.flip()
         km, cm = C.c_float(0), C.c_float(0)
-        ks, cs = [], []
+        ks, cs, wall = [], [], []
+        import time
         for r in range(a.reps + 3):
+            t0 = time.perf_counter()
             st = snap.extract_view(P, M) if P else snap.extract_view([0.5], M)
+            if r >= 3:
+                wall.append((time.perf_counter() - t0) * 1e6)
             if N.lib().lh_tool_last_extract_ms(eng._h, C.byref(km), C.byref(cm)) == 0 and r >= 3:
                 ks.append(km.value)
                 cs.append(cm.value)
         total = int(st["count"].sum())
         snap.release()
     ks.sort()
+    wall.sort()
     print(json.dumps({"tool": "extract_time", "names": M, "pairs": n, "np": len(P), "lib": a.lib, "count_ok": total == n,
                       "kernel_us_avg": 1e3 * sum(ks) / len(ks), "kernel_us_min": 1e3 * ks[0], "kernel_us_median": 1e3 * ks[len(ks) // 2],
-                      "copy_us_avg": 1e3 * sum(cs) / len(cs)}), flush=True)
+                      "copy_us_avg": 1e3 * sum(cs) / len(cs),
+                      "call_wall_us_median": wall[len(wall) // 2], "call_wall_us_p90": wall[int(len(wall) * 0.9)]}), flush=True)
 
 
 if __name__ == "__main__":
