@@ -88,6 +88,9 @@ bool survey_reusable(const SurveyTables &t, int gen, uint32_t layout, uint64_t c
 // by HEALTHY calls at an unchanged window width (a stale survey forwards most records whatever the names' skew).
 bool names_without_skew(uint64_t pairs, uint64_t forwarded, bool healthy, bool same_width);
 
+// launches a set of the lanes' shared survey tables serves before a stale-survey report may end its reuse
+constexpr uint32_t kLaneStaleMinAge = 8;
+
 // fewer than 2 % of `pairs` took an exact-but-slow path
 inline bool healthy_share(uint64_t bad, uint64_t pairs) { return bad * 50 <= pairs; }
 

@@ -275,7 +275,7 @@ struct lh_engine {
         hipEvent_t ready[2] = {nullptr, nullptr};   // recorded behind the launch that surveyed into the set
         hipStream_t ready_stream[2] = {nullptr, nullptr};
         int active = 0;
-        uint64_t seen_bad = 0, seen_pairs = 0;
+        uint64_t seen_bad = 0, seen_pairs = 0, seen_stale = 0;
     } lane_tables;
     bool lane_gen3 = true;                        // LH_OPT_LANE_GEN3
     uint32_t lane_g1_cap = lh::kLaneLevel1Workgroups;
@@ -451,12 +451,18 @@ int run_lane_block(lh_engine *e, EpochBuffer &b, PairsCall &c, const lh::Step &s
         // what the third-generation launches completed since the last look reported (the device-resident calls' and the
         // lanes' alike: k_v3_report adds to the same pinned words)
         const uint64_t bad = __atomic_load_n(&e->h_rstat[0], __ATOMIC_RELAXED) + __atomic_load_n(&e->h_rstat[4], __ATOMIC_RELAXED) +
-                             __atomic_load_n(&e->h_rstat[5], __ATOMIC_RELAXED) + __atomic_load_n(&e->h_rstat[7], __ATOMIC_RELAXED);
+                             __atomic_load_n(&e->h_rstat[5], __ATOMIC_RELAXED);
+        const uint64_t stale = __atomic_load_n(&e->h_rstat[7], __ATOMIC_RELAXED);
         const uint64_t pairs = __atomic_load_n(&e->h_rstat[6], __ATOMIC_RELAXED);
-        const bool healthy = lh::healthy_share(bad - lt.seen_bad, pairs - lt.seen_pairs);
-        lt.seen_bad = bad;
-        lt.seen_pairs = pairs;
         int set = lt.active;
+        // A stale survey (h_rstat[7]: the hot windows take fewer pairs than when the tables were new) counts only once the
+        // set has served kLaneStaleMinAge launches: lanes may carry different streams, each a few per cent off the launch
+        // that surveyed, and a survey is a large part of a lane-sized launch -- they must not take turns re-surveying.
+        const bool heed_stale = lt.t[set].valid && lt.t[set].age >= lh::kLaneStaleMinAge;
+        const bool healthy = lh::healthy_share((bad - lt.seen_bad) + (heed_stale ? stale - lt.seen_stale : 0), pairs - lt.seen_pairs);
+        lt.seen_bad = bad;
+        lt.seen_stale = stale;
+        lt.seen_pairs = pairs;
         size_t survey_n = 0;
         if (lh::survey_reusable(lt.t[set], 3, st.tune.v3_log_w, c.tune_gen, e->survey_every, healthy)) {
             lt.t[set].age++;

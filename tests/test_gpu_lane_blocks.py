@@ -168,3 +168,40 @@ def test_lanes_over_many_names_share_survey_tables(la, gen3):
         assert np.array_equal(cells, want_cells) and np.array_equal(counts.astype(np.int64), want_counts)
     finally:
         eng.close()
+
+
+def test_lanes_that_carry_different_streams_do_not_take_turns_surveying(la):
+    """The launches report what a stale survey costs their hot windows (lh_counters.survey_stale_pairs) and the next call
+    surveys again -- but lanes share ONE set of survey tables, and two producers may carry streams whose values lie apart
+    for good (one thread times requests, another sizes payloads).  Each lane's launch would find the other's survey
+    stale; a survey is a large part of a lane-sized launch.  The lanes heed such a report only after a set has served
+    kLaneStaleMinAge = 8 launches: exact, and most launches still run on a kept survey."""
+    M, per, batches = 65536, 1 << 18, 20
+    rng = np.random.default_rng(123)
+    w = 1.0 / np.arange(1, M + 1)
+    ids = [rng.choice(M, per, p=w / w.sum()).astype(np.uint16) for _ in range(2)]
+    # 300 bins apart: outside each other's hot windows (~260 bins wide), inside the 1 024-bin windows of levels 2 and 3 --
+    # nothing overflows or misses (that WOULD be a reason to survey again at once), only the hot windows' share moves
+    vals = [rng.lognormal(np.log(1e5), 0.5, per), rng.lognormal(np.log(5e3), 0.5, per)]
+    eng = la.Engine(max_metrics=M, num_buffers=2, num_lanes=2, lane_samples=per)
+    try:
+        for k in range(batches):                          # one producer after the other: the worst case, strict alternation
+            for t in range(2):
+                eng.submit_pairs_in_place(ids[t], vals[t])
+        eng.sync()
+        c = eng.counters()
+        launches = 2 * batches
+        assert c["samples_partitioned_v3"] == launches * per, c
+        assert c["survey_stale_pairs"] > 0, c             # the reports are there ...
+        assert c["surveys_reused"] >= launches - 2 - launches // 8, c   # ... and end a set's reuse once in eight launches at most
+        with eng.flip() as snap:
+            got = snap.extract([0.5], M)["count"].astype(np.int64)
+            rows = {m: snap.dense_row(m) for m in (0, 1, 7, 100, 4097, 65535)}
+        assert np.array_equal(got, batches * (np.bincount(ids[0], minlength=M) + np.bincount(ids[1], minlength=M)))
+        for m, row in rows.items():
+            want = np.zeros(65536, dtype=np.uint64)
+            for t in range(2):
+                oracle.histogram_dense(vals[t][ids[t] == m], want)
+            assert np.array_equal(row, batches * want), m
+    finally:
+        eng.close()
