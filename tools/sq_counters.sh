@@ -3,7 +3,8 @@
 #   1 024 names (k_scatter3, k_part_hist2) and 65 536 names (k_scatter4, k_split_waves, k_part_hist3), 1e9 pairs:
 #   instruction mix and LDS conflicts, lognormal + kvalues2                                        -> mixed_counters.jsonl
 # One rocprofv3 --pmc pass per (distribution, counter set); no tracing domains in the same run.
-# usage: [PARTS="k1 mixed"] bash tools/sq_counters.sh OUTDIR   (round.sh counters <tag>)
+#   k_extract_wave at 65 536 names: instructions per name, VALU activity (PARTS=extract)             -> extract_counters.jsonl
+# usage: [PARTS="k1 mixed extract"] bash tools/sq_counters.sh OUTDIR   (round.sh counters <tag>)
 cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; OUTD=$R/gpurun_out/${1:-counters}; mkdir -p $OUTD
 PARTS=${PARTS:-k1 mixed}
 K1=$OUTD/k1_lds_counters.jsonl; MX=$OUTD/mixed_counters.jsonl
@@ -57,4 +58,22 @@ for D in lognormal kvalues2; do
     for k in k_scatter4 k_split_waves k_part_hist3; do row /tmp/kc/t_results.db $k 1e9 dist=$D names=65536 set=$S >> $MX; done
   done
 done
-cat $K1 $MX 2>/dev/null
+# k_extract_wave at 65 536 names (tools/extract_time.py: 33 extracts of one snapshot per run): instructions per name = per wave
+EX=$OUTD/extract_counters.jsonl
+case " $PARTS " in *" extract "*) : > $EX;; esac
+for NP in 9 1; do
+  case " $PARTS " in *" extract "*) ;; *) break;; esac
+  for S in A B; do
+    eval "SET=\$SET_$S"
+    rm -rf /tmp/kc; timeout 300 rocprofv3 --pmc $SET -d /tmp/kc -o t -- python $R/tools/extract_time.py --np $NP --reps 10 > /tmp/kc.out 2>&1
+    row /tmp/kc/t_results.db k_extract_wave 0 names=65536 percentiles=$NP set=$S | python -c "
+import sys, json
+for l in sys.stdin:
+    j = json.loads(l)
+    for k in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS'):
+        if k in j: j[k.lower() + '_per_name'] = round(j[k] / 65536.0, 1)
+    if 'SQ_ACTIVE_INST_VALU' in j and 'SQ_BUSY_CYCLES' in j: j['valu_active_over_busy'] = round(j['SQ_ACTIVE_INST_VALU'] / max(1.0, j['SQ_BUSY_CYCLES']), 3)
+    print(json.dumps(j))" >> $EX
+  done
+done
+cat $K1 $MX $EX 2>/dev/null
