@@ -199,9 +199,11 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__rest
     const uint32_t W = 1u << log_w;
     uint32_t cnt[EMAX], want[EMAX], mean[EMAX], corg[EMAX];
     uint32_t mysum = 0, whole = 0; // whole: bit e = name e of this thread keeps its whole sampled span
+    uint32_t lobe = 0, lo_end[EMAX], hi_end[EMAX]; // lobe: bit e = two lobes either side of key 0; the span's ends
 #pragma unroll
     for (uint32_t e = 0; e < EMAX; e++) {
         cnt[e] = 0;
+        lo_end[e] = hi_end[e] = 0;
         want[e] = 0;
         mean[e] = 32768u;
         corg[e] = 32768u - W / 2;
@@ -233,6 +235,15 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__rest
                         want[e] = ((mx - mn + 1) + 63u) & ~63u;
                         mean[e] = (mn + mx + 1) >> 1;
                         whole |= 1u << e;
+                    }
+                    // SIGNED values: two lobes of bins, one either side of key 0 (bin 32 768), and the mean bin lies in the
+                    // gap between them -- a window centred there takes nothing (normal(0, 1e3) over 1 024 names: 3.76 ms
+                    // per 1e9 pairs against 2.94 for one-signed values).  Such a name's window goes to the outer end of the
+                    // lobe the mean leans to: that is where a lobe's mass is (bins are logarithmic in |v|).
+                    if (mn + 64u < 32768u && mx > 32768u + 64u && mx - mn > 1024u) {
+                        lobe |= 1u << e;
+                        lo_end[e] = mn;
+                        hi_end[e] = mx;
                     }
                 }
             }
@@ -299,6 +310,7 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__rest
             if (want[e] && cnt[e] >= tau) {
                 const uint32_t w = want[e];
                 uint32_t o = mean[e] > w / 2 ? mean[e] - w / 2 : 0u;
+                if (lobe & (1u << e)) o = mean[e] >= 32768u ? (hi_end[e] + 1u > w ? hi_end[e] + 1u - w : 0u) : lo_end[e];
                 if (o > 65536u - w) o = 65536u - w;
                 ne.org |= o << 16;
                 ne.hot = cellpos | (w << 16);

@@ -184,14 +184,22 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan_h(const SurveyStat S,
     static_assert(V3_HN == V2_BLOCK, "one thread per hash slot");
     const uint32_t tid = threadIdx.x;
     const uint32_t claim = g_aux[AUX_CLAIM + tid];
-    uint32_t name = 0, cnt = 0, want = 0, mean = 32768u;
+    uint32_t name = 0, cnt = 0, want = 0, mean = 32768u, mn = 0, mx = 0;
+    bool whole = false, lobe = false; // as k_survey_plan: a narrow span kept whole; two lobes either side of key 0
     if (claim) {
         name = claim & 0xffffu;
         cnt = sv_count(S, name);
-        const uint32_t mn = 65535u - S.mninv[name], mx = S.mx[name];
+        mn = 65535u - S.mninv[name];
+        mx = S.mx[name];
         mean = sv_mean(S, name);
         const uint32_t w = (((mx - mn + 1u) * 3u / 4u) + 63u) & ~63u; // as k_survey_plan: 3/4 of the sampled span
         want = w < 64u ? 64u : w;
+        if (mx - mn + 1u <= HOT_WHOLE_SPAN) {
+            want = ((mx - mn + 1u) + 63u) & ~63u;
+            mean = (mn + mx + 1u) >> 1;
+            whole = true;
+        }
+        lobe = mn + 64u < 32768u && mx > 32768u + 64u && mx - mn > 1024u;
     }
     const uint32_t pc = tid < V3_NP ? g_aux[AUX_PC + tid] : 0u;
     uint32_t total_cnt, dummy;
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan_h(const SurveyStat S,
     const uint32_t big = total_cnt / 64u;
     if (want) {
         const uint32_t cap = cnt >= big ? 512u : 256u;
-        if (want > cap) want = cap;
+        if (want > cap && !whole) want = cap;
     }
     uint32_t flo = 15, fhi = (1u << 21) + 1;
     if (cells < 64) flo = fhi - 1;
@@ -236,6 +244,7 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan_h(const SurveyStat S,
     pu2_t e = (pu2_t){0xffffffffu, 0u};
     if (hot) {
         uint32_t o = mean > want / 2 ? mean - want / 2 : 0u;
+        if (lobe) o = mean >= 32768u ? (mx + 1u > want ? mx + 1u - want : 0u) : mn; // the outer end of the heavier lobe
         if (o > 65536u - want) o = 65536u - want;
         e = (pu2_t){name | (want << 20), cellpos | (o << 16)};
         g_hs[slot] = (pu4_t){name, o | (want << 16), cellpos, 0u};
