@@ -749,6 +749,7 @@ __device__ inline uint64_t pct_threshold(double p, uint64_t total)
 // 16 bytes at an 8-byte-aligned address as ONE load (global_load_dwordx4; unaligned vector access is on for HSA)
 struct __attribute__((packed, aligned(8))) u64x2_a8 { uint64_t a, b; };
 struct __attribute__((packed, aligned(8))) f64x2_a8 { double a, b; };
+struct __attribute__((packed, aligned(4))) u32x4_a4 { uint32_t a, b, c, d; };
 
 // What k_extract_wave does with a span it holds in registers (32-bit cells, a total below 2^32): pass 1 of
 // processHistograms, the prefix scan, the percentile search.
@@ -761,6 +762,7 @@ __device__ __forceinline__ void ew_reduce_and_search(const CT (&creg)[4][K2_PER_
                                                      uint64_t &total_out, double &tsum, uint32_t &tnb, uint32_t &found)
 {
     constexpr uint32_t STEPS = 4;
+    static_assert(STEPS == 4, "the percentile search compares a threshold with three step boundaries");
     // the decompressed values of the lane's bins: requested here, step by step, and consumed at once -- held beside
     // the cells they cost 32 registers and two waves per SIMD (the table is 512 KiB: L2 at worst)
     double dreg[STEPS][K2_PER_THREAD];
@@ -824,34 +826,37 @@ __device__ __forceinline__ void ew_reduce_and_search(const CT (&creg)[4][K2_PER_
     if (total && np) {
         uint64_t T64 = ~0ull;
         if (lane < np) T64 = pct_threshold(pa.p[lane], (uint64_t)total);
-        uint32_t open = (uint32_t)__builtin_amdgcn_ballot_w64(T64 != ~0ull); // percentiles without a bin yet (np <= 32)
-        const CT T = (CT)T64; // (a threshold that exists is <= total)
+        const bool has = T64 != ~0ull; // (np <= 32: lanes 32 .. 63 hold no percentile)
+        const CT T = (CT)T64;          // (a threshold that exists is <= total)
+        // the step a percentile ends in: the first whose running total reaches its threshold (one compare per boundary for
+        // all percentiles at once; a step then visits only its own)
+        const CT c1 = stot[0], c2 = c1 + stot[1], c3 = c2 + stot[2];
+        const uint32_t mystep = (T > c1 ? 1u : 0u) + (T > c2 ? 1u : 0u) + (T > c3 ? 1u : 0u);
         CT carry = 0;
 #pragma unroll
         for (uint32_t s = 0; s < STEPS; s++) {
-            if (!open || lo + s * K2_BLOCK > hi) break; // wave-uniform
-            const CT upto = carry + stot[s];            // prefix at the end of this step
-            CT pre[K2_PER_THREAD];                      // inclusive prefix at the lane's four bins
-            CT sofar = carry + (inc[s] - stepc[s]);
+            uint32_t todo = (uint32_t)__builtin_amdgcn_ballot_w64(has && mystep == s); // wave-uniform
+            if (todo) {
+                CT pre[K2_PER_THREAD];                  // inclusive prefix at the lane's four bins
+                CT sofar = carry + (inc[s] - stepc[s]);
 #pragma unroll
-            for (int k = 0; k < K2_PER_THREAD; k++) {
-                sofar += creg[s][k];
-                pre[k] = sofar;
+                for (int k = 0; k < K2_PER_THREAD; k++) {
+                    sofar += creg[s][k];
+                    pre[k] = sofar;
+                }
+                for (; todo; todo &= todo - 1) {
+                    const uint32_t i = (uint32_t)__builtin_ctz(todo);
+                    const CT Ti = ew_readlane(T, i);
+                    // the first lane whose last bin reaches Ti (lane 63's does), and how many of its bins stay below
+                    const unsigned long long reach = __builtin_amdgcn_ballot_w64(pre[K2_PER_THREAD - 1] >= Ti);
+                    const uint32_t f = (uint32_t)__builtin_ctzll(reach);
+                    const uint32_t below = (pre[0] < Ti ? 1u : 0u) + (pre[1] < Ti ? 1u : 0u) + (pre[2] < Ti ? 1u : 0u);
+                    const uint32_t bin = lo + s * K2_BLOCK + f * K2_PER_THREAD +
+                                         (uint32_t)__builtin_amdgcn_readlane((int)below, (int)f);
+                    if (lane == i) found = bin;
+                }
             }
-            for (uint32_t todo = open; todo; todo &= todo - 1) {
-                const uint32_t i = (uint32_t)__builtin_ctz(todo);
-                const CT Ti = ew_readlane(T, i);
-                if (Ti > upto) continue; // reached in a later step
-                // the first lane whose last bin reaches Ti (lane 63's does), and how many of its bins stay below
-                const unsigned long long reach = __builtin_amdgcn_ballot_w64(pre[K2_PER_THREAD - 1] >= Ti);
-                const uint32_t f = (uint32_t)__builtin_ctzll(reach);
-                const uint32_t below = (pre[0] < Ti ? 1u : 0u) + (pre[1] < Ti ? 1u : 0u) + (pre[2] < Ti ? 1u : 0u);
-                const uint32_t bin = lo + s * K2_BLOCK + f * K2_PER_THREAD +
-                                     (uint32_t)__builtin_amdgcn_readlane((int)below, (int)f);
-                if (lane == i) found = bin;
-                open &= ~(1u << i);
-            }
-            carry = upto;
+            carry += stot[s];
         }
     }
 }
@@ -1411,14 +1416,29 @@ __global__ __launch_bounds__(256) void k_pack_rows(const uint64_t *__restrict__ 
     WORD *dst = buf + (size_t)k * bstride + (P[r] - bstart[k]);
     const uint64_t *src = counts + (size_t)r * LH_ROW_STRIDE + lo;
     const uint32_t w = hi - lo + 1;
+    // whole-word cells: four consecutive cells per lane and step (two 16-byte loads; the row store's side is 8-byte
+    // aligned, the wire's 4-byte: unaligned vector access is on for HSA), the last partial group cell by cell
     if constexpr (sizeof(WORD) == 8) {
-#pragma unroll 4
-        for (uint32_t i = t; i < w; i += TPR) dst[i] = src[i];
+        for (uint32_t i = 4u * t; i < w; i += 4u * TPR) {
+            if (i + 4u <= w) {
+                const u64x2_a8 a = *reinterpret_cast<const u64x2_a8 *>(src + i), b = *reinterpret_cast<const u64x2_a8 *>(src + i + 2);
+                *reinterpret_cast<u64x2_a8 *>(dst + i) = a;
+                *reinterpret_cast<u64x2_a8 *>(dst + i + 2) = b;
+            } else {
+                for (uint32_t j = i; j < w; j++) dst[j] = src[j];
+            }
+        }
     } else {
         const uint32_t bits = cls[r];
         if (bits == 32u) {
-#pragma unroll 4
-            for (uint32_t i = t; i < w; i += TPR) dst[i] = (uint32_t)src[i];
+            for (uint32_t i = 4u * t; i < w; i += 4u * TPR) {
+                if (i + 4u <= w) {
+                    const u64x2_a8 a = *reinterpret_cast<const u64x2_a8 *>(src + i), b = *reinterpret_cast<const u64x2_a8 *>(src + i + 2);
+                    *reinterpret_cast<u32x4_a4 *>(dst + i) = (u32x4_a4){(uint32_t)a.a, (uint32_t)a.b, (uint32_t)b.a, (uint32_t)b.b};
+                } else {
+                    for (uint32_t j = i; j < w; j++) dst[j] = (uint32_t)src[j];
+                }
+            }
         } else {
             const uint32_t log_c = bits == 8u ? 2u : 1u, c = 1u << log_c; // cells per word
             const uint32_t wpad = (w + c - 1u) & ~(c - 1u);                // (whole waves run the shuffles: TPR % c == 0)
@@ -1467,14 +1487,28 @@ __global__ __launch_bounds__(256) void k_unpack_rows(uint64_t *__restrict__ coun
     const WORD *src = buf + (P[r] - bstart[kblock]);
     uint64_t *dst = counts + (size_t)r * LH_ROW_STRIDE + lo;
     const uint32_t w = hi - lo + 1;
-    if constexpr (sizeof(WORD) == 8) {
-#pragma unroll 4
-        for (uint32_t i = t; i < w; i += TPR) dst[i] = src[i];
+    if constexpr (sizeof(WORD) == 8) { // (four cells per lane and step, as k_pack_rows)
+        for (uint32_t i = 4u * t; i < w; i += 4u * TPR) {
+            if (i + 4u <= w) {
+                const u64x2_a8 a = *reinterpret_cast<const u64x2_a8 *>(src + i), b = *reinterpret_cast<const u64x2_a8 *>(src + i + 2);
+                *reinterpret_cast<u64x2_a8 *>(dst + i) = a;
+                *reinterpret_cast<u64x2_a8 *>(dst + i + 2) = b;
+            } else {
+                for (uint32_t j = i; j < w; j++) dst[j] = src[j];
+            }
+        }
     } else {
         const uint32_t bits = cls[r];
         if (bits == 32u) {
-#pragma unroll 4
-            for (uint32_t i = t; i < w; i += TPR) dst[i] = (uint64_t)src[i];
+            for (uint32_t i = 4u * t; i < w; i += 4u * TPR) {
+                if (i + 4u <= w) {
+                    const u32x4_a4 a = *reinterpret_cast<const u32x4_a4 *>(src + i);
+                    *reinterpret_cast<u64x2_a8 *>(dst + i) = (u64x2_a8){a.a, a.b};
+                    *reinterpret_cast<u64x2_a8 *>(dst + i + 2) = (u64x2_a8){a.c, a.d};
+                } else {
+                    for (uint32_t j = i; j < w; j++) dst[j] = (uint64_t)src[j];
+                }
+            }
         } else {
             const uint32_t log_c = bits == 8u ? 2u : 1u, c = 1u << log_c, mask = (1u << bits) - 1u;
 #pragma unroll 4
