@@ -375,7 +375,9 @@ int lh_get_counters(lh_engine *e, lh_counters *out);
  *                             it (default 32; 1 = every call surveys).  Only while the stream looks the same: a survey
  *                             is also repeated when the window width or scatter shape changed, when anything else used
  *                             the block, or when more than 2 % of the pairs of the calls completed since took an
- *                             overflow / window-miss path.  A stale survey costs speed, never exactness
+ *                             overflow / window-miss path or stayed out of the hot windows that took them when the
+ *                             survey was new (the stream's values moved: lh_counters.survey_stale_pairs).  A stale
+ *                             survey costs speed -- one call's worth -- never exactness
  *   LH_OPT_LANE_SCRATCH_BLOCKS  0 .. 16 (default 16): host-fed mixed launches (lh_submit_pairs*, lh_commit_pairs*: one staging
  *                             half-buffer each, at most 2^22 pairs) run partitioned in one of this many scratch blocks
  *                             of their own (first generation up to 8 192 names; above, the third generation on survey
