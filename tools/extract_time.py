@@ -7,6 +7,7 @@ import ctypes as C
 import json
 import os
 import sys
+import time
 
 import torch
 
@@ -39,7 +40,6 @@ def main():
         snap = eng.flip()
         km, cm = C.c_float(0), C.c_float(0)
         ks, cs, wall = [], [], []
-        import time
         for r in range(a.reps + 3):
             t0 = time.perf_counter()
             st = snap.extract_view(P, M) if P else snap.extract_view([0.5], M)
