@@ -726,6 +726,30 @@ template <int NPT> struct Scatter3LdsT {
     uint32_t pool_next, ovn; // ovn: records that found their region full (reported to the engine)
 };
 
+#ifndef LH_SC3_TRIM
+#define LH_SC3_TRIM 1
+#endif
+// LH_SC3_TRIM: the classification with fewer instructions per sample (round 6; 0 = round 5's form, kept for A/B builds).
+// What the SQ counters said of round 5's k_scatter3 (profiles/r04_mixed_counters.jsonl): 50.8 VALU + 24.4 SALU + 5.2 LDS
+// instructions per wave-sample and no unit busy more than half of the time -- the kernel is bound by what ONE wave
+// issues between its waits, so every instruction that leaves the straight-line path counts, VALU or not:
+//   * an id >= nmetrics is CLAMPED to the table's extra entry nt[nmetrics] (no window of either kind) instead of being
+//     tested and replaced per sample; one max3 + compare per batch finds the waves that hold one at all;
+//   * the per-sample conditions (hot / cold / fits) stay lane masks in SGPRs; the bit masks `miss`, `coldm`, `full`
+//     that were assembled in VGPRs with a v_cndmask + v_or per sample and condition are gone, the rare path tests
+//     the conditions themselves;
+//   * the LDS atomic and the record store are exec-masked instead of being pointed at dummy words;
+//   * the partition table holds the region's BYTE offset: the record's address is one v_lshl_add.
+constexpr bool SC3_TRIM = LH_SC3_TRIM != 0;
+// Ablation builds of the level-1 kernels (tools/build_tuning.py -DLH_ABL=bits; timing only, the counts are WRONG by
+// construction; the product is built with 0): 1 = the copy-out body removed (both barriers stay, the counters are
+// reset), 2 = no barriers and no copy-out at all (records wrap inside the first 16 slots of their region), 4 = the
+// copy-out without its global stores, 8 = no LDS atomics (the slot is the lane), 16 = the bucket index computed twice
+// (+19 VALU per sample: the slope of time over VALU work).
+#ifndef LH_ABL
+#define LH_ABL 0
+#endif
+constexpr uint32_t ABL = LH_ABL;
 #ifndef LH_SC3_BATCH
 #define LH_SC3_BATCH 4
 #endif
@@ -789,6 +813,9 @@ __global__ __launch_bounds__(256) void k_survey_parts(const uint32_t *__restrict
     }
 }
 
+// entries of k_scatter3's name table in LDS: one per name, the entry of ids >= nmetrics, padded to 16 bytes
+constexpr uint32_t sc3_nt_entries(uint32_t nmetrics) { return (nmetrics + 2u) & ~1u; }
+
 template <int BLOCK, int NPT, int BATCH, typename IDT>
 __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ ids,
                                                        const double *__restrict__ v, size_t ntiles, uint32_t nmetrics,
@@ -814,23 +841,29 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
     NameEntry *nt = reinterpret_cast<NameEntry *>(v2_smem + sizeof(LdsT));         // [nmetrics]
     uint32_t *lds32 = reinterpret_cast<uint32_t *>(v2_smem);
     rec16_t *lds16 = reinterpret_cast<rec16_t *>(v2_smem);
-    const uint32_t reg_h = (uint32_t)(sizeof(LdsT) / 2) + 4 * ((nmetrics + 1) & ~1u); // halfword offset of the regions (16-byte aligned)
+    const uint32_t reg_h = (uint32_t)(sizeof(LdsT) / 2) + 4 * sc3_nt_entries(nmetrics); // halfword offset of the regions (16-byte aligned)
     const uint32_t win_w = (reg_h + region_recs) / 2;                              // word offset of the hot windows
     uint32_t *win = lds32 + win_w;                                                 // [cells]
     constexpr uint32_t CNT_W = offsetof(LdsT, cnt) / 4, DUMMY_W = offsetof(LdsT, dummy) / 4;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t np = 1u << log_np, pmask = np - 1, W = 1u << log_w;
     const uint32_t pool_base = blockIdx.x * chunks_per_wg;
+    // the LDS address of the block (0 here; not a constant the compiler can fold)
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)v2_smem;
 
     for (uint32_t i = tid; i < nmetrics; i += BLOCK) {
         NameEntry ne = g_nt[i];
         ne.hot += win_w; // hot base as a word offset from the LDS base (< 40 960: fits the low half)
         nt[i] = ne;
     }
+    // the entry of an id >= nmetrics (SC3_TRIM clamps such an id to it): no hot window, cold origin 65 535 -- with the
+    // bin such a sample is given (0) it is neither hot nor cold and takes the rare path, which drops and reports it
+    if (tid == 0) nt[nmetrics] = (NameEntry){0xffffu, 0u};
     for (uint32_t i = tid; i < cells; i += BLOCK) win[i] = 0;
     if (tid < NPT) {
         pu2_t e = tid < np ? g_pt[tid] : (pu2_t){0u, 0u};
         e.x += reg_h;
+        if (SC3_TRIM) e.x = 2u * e.x + lds_base; // LDS address
         L.pt[tid] = e;
         L.cnt[tid] = 0;
         L.cfill[tid] = CHUNK;
@@ -839,7 +872,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
     ov_init(L.ov_key, L.ov_cnt, tid, BLOCK);
     if (tid == 0) { L.pool_next = 0; L.ovn = 0; L.missn[0] = 0; L.missn[1] = 0; }
     __syncthreads();
-    const pu2_t my_pt = L.pt[tid >> 2]; // the flush phase's partition (constant over the launch)
+    pu2_t my_pt = L.pt[tid >> 2]; // the flush phase's partition (constant over the launch)
+    if (SC3_TRIM) my_pt.x = (my_pt.x - lds_base) >> 1;  // (halfword index)
 
     const pd2_t *vp = reinterpret_cast<const pd2_t *>(v);
     typedef IdStream<IDT> IS;
@@ -865,7 +899,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
     static_assert(NPAIR == 4, "the asm above names four register pairs");
     load_tile((size_t)blockIdx.x + gridDim.x, idb, vab);
 
-    auto classify = [&](typename IS::raw_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
+    auto classify_r5 = [&](typename IS::raw_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
         uint32_t rare = 0;
         // ---- phase 1: classify and place.  Straight-line code, four samples at a time: their table reads, then
         // their LDS atomics, then their record stores are in flight together.
@@ -935,8 +969,97 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
         }
         if (rare) atomicOr(err, 1u); // an id >= nmetrics: reported by lh_sync / lh_extract
     };
+    // SC3_TRIM (see the switch's comment): the same classification with fewer instructions per sample.
+    auto classify_trim = [&](typename IS::raw_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
+#pragma unroll
+        for (int h = 0; h < V2_SPT; h += BATCH) {
+            uint32_t raw[BATCH], bin[BATCH], rank[BATCH], crel[BATCH];
+            NameEntry ne[BATCH];
+            pu2_t pe[BATCH];
+            bool unc[BATCH], hot[BATCH], cold[BATCH], bad[BATCH];
+            uint32_t idmax = 0;
+#pragma unroll
+            for (int k = 0; k < BATCH; k++) {
+                const int j = h + k;
+                raw[k] = (j & 1) ? IS::second(idv[j >> 1]) : IS::first(idv[j >> 1]);
+                idmax = max(idmax, raw[k]);
+                ne[k] = nt[min(raw[k], nmetrics)]; // an id >= nmetrics reads the extra entry
+                pe[k] = L.pt[raw[k] & pmask];
+            }
+            bool anyunc = false;
+#pragma unroll
+            for (int k = 0; k < BATCH; k++) {
+                const int j = h + k;
+                bin[k] = lh_bin_fast((j & 1) ? val[j >> 1].y : val[j >> 1].x, unc[k]);
+                if (ABL & 16u) { // the same index once more, on a value the compiler cannot tell from the first
+                    double x2 = (j & 1) ? val[j >> 1].y : val[j >> 1].x;
+                    asm volatile("" : "+v"(x2));
+                    bool u2;
+                    bin[k] = (bin[k] + lh_bin_fast(x2, u2)) >> 1;
+                }
+                anyunc |= unc[k];
+            }
+            if (anyunc) { // inside the guard band of a bucket threshold (1 sample in ~4 000): exact table compare
+#pragma unroll
+                for (int k = 0; k < BATCH; k++) {
+                    const int j = h + k;
+                    if (unc[k]) bin[k] = lh_bin_of((j & 1) ? val[j >> 1].y : val[j >> 1].x, Tx);
+                }
+            }
+            if (idmax >= nmetrics) { // this lane holds an id >= nmetrics: bin 0 is outside the extra entry's windows
+#pragma unroll
+                for (int k = 0; k < BATCH; k++)
+                    if (raw[k] >= nmetrics) bin[k] = 0;
+            }
+#pragma unroll
+            for (int k = 0; k < BATCH; k++) {
+                const uint32_t hrel = bin[k] - (ne[k].org >> 16);
+                crel[k] = bin[k] - (ne[k].org & 0xffffu);
+                hot[k] = hrel < (ne[k].hot >> 16);
+                cold[k] = !hot[k] && crel[k] < W;
+                uint32_t a = (ne[k].hot & 0xffffu) + hrel, b = raw[k] & pmask; // LDS words: the hot cell, the partition's counter (cnt[] is at word 0)
+                static_assert(CNT_W == 0, "the partition counters open the LDS block");
+                asm volatile("" : "=v"(rank[k])); // (no value for the lanes that skip the atomic: `fits` below needs none)
+                if (ABL & 8u) { rank[k] = lane & 15u; asm volatile("" : "+v"(a), "+v"(b)); }
+                else if (hot[k] || cold[k]) rank[k] = atomicAdd(lds32 + (hot[k] ? a : b), 1u);
+                if (ABL & 2u) rank[k] &= 15u;
+            }
+            bool anybad = false;
+#pragma unroll
+            for (int k = 0; k < BATCH; k++) {
+                const bool fits = cold[k] && rank[k] < pe[k].y;
+                bad[k] = !hot[k] && !fits; // outside the name's cold window, or the region is full, or no such name
+                anybad |= bad[k];
+                if (fits) // pe.x is the region's LDS ADDRESS: one shift-add per record
+                    *(__attribute__((address_space(3))) rec16_t *)(uintptr_t)(pe[k].x + 2u * rank[k]) =
+                        (rec16_t)(((raw[k] >> log_np) << log_w) | crel[k]);
+            }
+            if (anybad) { // queued, counted exactly by the flush phase
+#pragma unroll
+                for (int k = 0; k < BATCH; k++)
+                    if (bad[k]) {
+                        if (raw[k] >= nmetrics) { atomicOr(err, 1u); continue; } // reported by lh_sync / lh_extract, the sample skipped
+                        if (cold[k]) atomicAdd(&L.ovn, 1u); // the region is full: the engine watches this count
+                        const uint32_t key = (raw[k] << 16) | bin[k];
+                        const uint32_t at = atomicAdd(&L.missn[par], 1u);
+                        if (at < V2_MISSQ) L.missq[par][at] = key;
+                        else if (!ov_add(L.ov_key, L.ov_cnt, key, 1u)) v2_global_add(counts, ranges, raw[k], bin[k], 1);
+                    }
+            }
+        }
+    };
+    auto classify = [&](typename IS::raw_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
+        if constexpr (SC3_TRIM) classify_trim(idv, val, par); else classify_r5(idv, val, par);
+    };
     auto flush = [&](const uint32_t par) {
+        if (ABL & 2u) return;
         __syncthreads();                                   // barrier A: the records of the tile(s) are in the regions
+        if (ABL & 1u) {
+            if (tid < NPT) L.cnt[tid] = 0;
+            if (tid == BLOCK - 1) { L.missn[0] = 0; L.missn[1] = 0; }
+            __syncthreads();
+            return;
+        }
         // ---- phase 2: flush.  TPP threads per partition (p = tid / TPP; thread q copies the 16-byte pieces q, q + TPP,
         // .. of every line).  With TPP = 1 only the first NPT threads -- one wave per SIMD -- run this phase and the
         // other waves go straight to the barrier.
@@ -947,7 +1070,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
             uint32_t t2 = tid;
             asm volatile("" : "+v"(t2)); // keeps this phase's address arithmetic inside the loop (see k_scatter2)
             const uint32_t p = t2 / TPP, q = t2 % TPP;
-            const pu2_t e = TPP == 4 ? my_pt : L.pt[p];
+            pu2_t e = my_pt;
+            if (TPP != 4) { e = L.pt[p]; if (SC3_TRIM) e.x = (e.x - lds_base) >> 1; }
             // whole pieces only: `full` lines leave (a multiple of SC3_PIECE), fewer than PIECE2 records stay behind
             const uint32_t c = min(L.cnt[p], e.y), full = c / PIECE2 * SC3_PIECE, left = c - full * LINE2;
             if (full) {
@@ -979,7 +1103,10 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
                     for (uint32_t i = 0; i < 4 / TPP; i++)
                         r4[i] = *reinterpret_cast<const pu4_t *>(src + l * LINE2 + (q + i * TPP) * 8);
 #pragma unroll
-                    for (uint32_t i = 0; i < 4 / TPP; i++) hidden_store_u4(records + dst + (q + i * TPP) * 8, r4[i]);
+                    for (uint32_t i = 0; i < 4 / TPP; i++) {
+                        if (ABL & 4u) asm volatile("" : : "v"(r4[i]), "v"(dst));
+                        else hidden_store_u4(records + dst + (q + i * TPP) * 8, r4[i]);
+                    }
                 }
                 // the leftover (less than a piece) moves to the front of the region (its slots are this thread's own:
                 // source and destination are at least one piece apart)
@@ -1040,7 +1167,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
         for (uint32_t j = 0; j < SC3_PIECE; j++)
             if (left && j * LINE2 + q * 8 < left)
                 *reinterpret_cast<pu4_t *>(records + d + j * LINE2 + q * 8) =
-                    *reinterpret_cast<const pu4_t *>(lds16 + L.pt[p].x + j * LINE2 + q * 8);
+                    *reinterpret_cast<const pu4_t *>(lds16 + (SC3_TRIM ? (L.pt[p].x - lds_base) >> 1 : L.pt[p].x) + j * LINE2 + q * 8);
     }
     if (tid == 0) L.dummy[0] = 0; // (no sample targets the dummy words any more) the workgroup's hot-window hits
     __syncthreads();
@@ -1281,7 +1408,7 @@ static bool make_plan2(size_t n, uint32_t nmetrics, int num_cus, const PartTunin
     // hot windows: whatever LDS is left beside the scatter structures and the per-name table
     const size_t budget = V2_LDS_TOTAL / wgs_per_cu;
     P.region_recs = direct ? region_records(P.tile * SC3_TILES_PER_FLUSH, P.np) : 0u;
-    const size_t nt_bytes = (size_t)(direct ? (nmetrics + 1) & ~1u : nmetrics) * sizeof(NameEntry);
+    const size_t nt_bytes = (size_t)(direct ? sc3_nt_entries(nmetrics) : nmetrics) * sizeof(NameEntry);
     const size_t fixed = P.lds_fixed + nt_bytes + (size_t)P.region_recs * sizeof(rec16_t) + 256;
     P.cells = fixed + 4096 <= budget ? (uint32_t)((budget - fixed) / 4) & ~63u : 0u;
     if (P.cells > 40000u) P.cells = 40000u & ~63u; // LDS word offsets of the windows must stay below 65 536

@@ -168,7 +168,8 @@ __global__ __launch_bounds__(1024) void k_survey_pick(const SurveyStat S, uint32
 }
 
 // One workgroup, thread t owns hash slot t.  Output:
-//   g_hk[t]   hot entry {name | width << 20, LDS base (relative to the window area) | origin << 16}, x = ~0 when free
+//   g_hk[t]   hot entry {name | width << 16, LDS base (relative to the window area) | origin << 16}; a free slot is
+//             {0, 0}: width 0 matches no sample (names are < 65 536: both halves are what one SDWA operand selects)
 //   g_hs[s]   the same windows as a list for the flush {name, origin | width << 16, base, 0}
 //   g_pt[p]   level-1 region of partition p {first record relative to the region area, capacity}
 //   hdr       [0] hot names [1] cells used [2] surveyed samples [3] surveyed samples of hot names [4] log2 of the
@@ -241,12 +242,12 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan_h(const SurveyStat S,
     const uint32_t cellpos = basew + incw - sw, slot = basen + incn - sn;
     uint32_t hot_cnt_total, dummy2;
     block_sum2(hot ? cnt : 0u, 0, s_a, s_b, hot_cnt_total, dummy2);
-    pu2_t e = (pu2_t){0xffffffffu, 0u};
+    pu2_t e = (pu2_t){0u, 0u};
     if (hot) {
         uint32_t o = mean > want / 2 ? mean - want / 2 : 0u;
         if (lobe) o = mean >= 32768u ? (mx + 1u > want ? mx + 1u - want : 0u) : mn; // the outer end of the heavier lobe
         if (o > 65536u - want) o = 65536u - want;
-        e = (pu2_t){name | (want << 20), cellpos | (o << 16)};
+        e = (pu2_t){name | (want << 16), cellpos | (o << 16)};
         g_hs[slot] = (pu4_t){name, o | (want << 16), cellpos, 0u};
     }
     g_hk[tid] = e;
@@ -302,7 +303,10 @@ __global__ __launch_bounds__(256) void k_survey_remap(const SurveyStat S, const 
     const uint32_t m = (l << V3_LOG_NP) | p;
     uint32_t c = m < nmetrics ? sv_count(S, m) : 0u;
     // what reaches the second level: a name with a hot window in level 1 leaves it about a quarter of its samples
-    if (c && (g_hk[v3_hash(m)].x & 0xfffffu) == m) c = (c + 3u) / 4u;
+    if (c) {
+        const uint32_t hx = g_hk[v3_hash(m)].x;
+        if ((hx & 0xffffu) == m && (hx >> 16)) c = (c + 3u) / 4u;
+    }
     s_c[l] = c;
     if (l < V3_MAX_NS) s_w[l] = 0;
     if (l == 0) s_tot = 0;
@@ -387,6 +391,11 @@ static_assert(sizeof(Scatter4Lds) % 16 == 0, "the regions follow the struct in L
 // upper bound of the sum of the level-1 region capacities (k_survey_plan_h)
 constexpr uint32_t v3_region_words(uint32_t tile) { return 6u * tile / 4u + (12u + PIECE4) * V3_NP; }
 
+#ifndef LH_SC4_TRIM
+#define LH_SC4_TRIM 1
+#endif
+constexpr bool SC4_TRIM = LH_SC4_TRIM != 0; // the classification with fewer instructions per sample: see LH_SC3_TRIM (lh_kernels_part2.h)
+
 template <int BATCH, typename IDT>
 __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ ids, const double *__restrict__ v,
                                                       size_t ntiles, uint32_t nmetrics, const double *__restrict__ Tx,
@@ -411,6 +420,8 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
     constexpr uint32_t CNT_W = offsetof(Scatter4Lds, cnt) / 4, DUMMY_W = offsetof(Scatter4Lds, dummy) / 4;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t pool_base = blockIdx.x * chunks_per_wg;
+    // the LDS address of the block (0 here; not a constant the compiler can fold)
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)v3_smem;
 
     for (uint32_t i = tid; i < V3_HN; i += BLOCK) {
         pu2_t e = g_hk[i];
@@ -421,6 +432,7 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
     if (tid < NPT) {
         pu2_t e = g_pt[tid];
         e.x += REG_W;
+        if (SC4_TRIM) e.x = 4u * e.x + lds_base; // LDS address: a record's address is one shift-add
         L.pt[tid] = e;
         L.cnt[tid] = 0;
         L.cfill[tid] = CHUNK;
@@ -429,7 +441,8 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
     ov_init(L.ov_key, L.ov_cnt, tid, BLOCK);
     if (tid == 0) { L.pool_next = 0; L.ovn = 0; L.nrec = 0; L.missn[0] = 0; L.missn[1] = 0; }
     __syncthreads();
-    const pu2_t my_pt = L.pt[tid >> 2]; // the flush phase's partition (constant over the launch)
+    pu2_t my_pt = L.pt[tid >> 2];       // the flush phase's partition (constant over the launch)
+    if (SC4_TRIM) my_pt.x = (my_pt.x - lds_base) >> 2; // (word index)
     uint32_t nrec = 0;                  // records this thread's partition emitted (q == 0 counts)
 
     const pd2_t *vp = reinterpret_cast<const pd2_t *>(v);
@@ -456,7 +469,7 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
     static_assert(NPAIR == 4, "the asm above names four register pairs");
     load_tile((size_t)blockIdx.x + gridDim.x, idb, vab);
 
-    auto classify = [&](typename IS::raw_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
+    auto classify_r5 = [&](typename IS::raw_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
         uint32_t rare = 0;
         // ---- phase 1: classify and place.  Straight-line code, BATCH samples at a time: their table reads, then
         // their LDS atomics, then their record stores are in flight together.
@@ -493,7 +506,7 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
             for (int k = 0; k < BATCH; k++) {
                 const bool valid = id[k] != INVALID;
                 const uint32_t hrel = bin[k] - (he[k].y >> 16);
-                const bool hot = valid && (he[k].x & 0xfffffu) == id[k] && hrel < (he[k].x >> 20);
+                const bool hot = valid && (he[k].x & 0xffffu) == id[k] && hrel < (he[k].x >> 16);
                 const bool cold = valid && !hot;
                 const uint32_t p = id[k] & (NPT - 1u);
                 where[k] = hot ? (he[k].y & 0xffffu) + hrel : cold ? CNT_W + p : DUMMY_W + lane;
@@ -522,8 +535,100 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
         }
         if (rare) atomicOr(err, 1u); // an id >= nmetrics: reported by lh_sync / lh_extract
     };
+    // SC4_TRIM: the same classification with fewer instructions per sample (as k_scatter3's classify_trim).  An id >=
+    // nmetrics is not tested per sample: one max3 + compare per batch finds the lanes that hold one, and those lanes
+    // turn the sample into a hit of a dummy word (id 0, bin 0, a hot entry of name 0 over bin 0 at the dummy word).
+    auto classify_trim = [&](typename IS::raw_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
+#pragma unroll
+        for (int h = 0; h < V2_SPT; h += BATCH) {
+            uint32_t raw[BATCH], bin[BATCH], rank[BATCH];
+            pu2_t he[BATCH], pe[BATCH];
+            bool unc[BATCH], hot[BATCH], full[BATCH];
+            uint32_t idmax = 0;
+#pragma unroll
+            for (int k = 0; k < BATCH; k++) {
+                const int j = h + k;
+                raw[k] = (j & 1) ? IS::second(idv[j >> 1]) : IS::first(idv[j >> 1]);
+                idmax = max(idmax, raw[k]);
+                he[k] = L.hk[v3_hash(raw[k])];
+                pe[k] = L.pt[raw[k] & (NPT - 1u)];
+            }
+            bool anyunc = false;
+#pragma unroll
+            for (int k = 0; k < BATCH; k++) {
+                const int j = h + k;
+                bin[k] = lh_bin_fast((j & 1) ? val[j >> 1].y : val[j >> 1].x, unc[k]);
+                if (ABL & 16u) { // the same index once more, on a value the compiler cannot tell from the first
+                    double x2 = (j & 1) ? val[j >> 1].y : val[j >> 1].x;
+                    asm volatile("" : "+v"(x2));
+                    bool u2;
+                    bin[k] = (bin[k] + lh_bin_fast(x2, u2)) >> 1;
+                }
+                anyunc |= unc[k];
+            }
+            if (anyunc) { // inside the guard band of a bucket threshold (1 sample in ~4 000): Go's log, exactly
+#pragma unroll
+                for (int k = 0; k < BATCH; k++) {
+                    const int j = h + k;
+                    if (unc[k]) bin[k] = v3_bin_exact((j & 1) ? val[j >> 1].y : val[j >> 1].x);
+                }
+            }
+            if (idmax >= nmetrics) { // this lane holds an id >= nmetrics: reported by lh_sync / lh_extract, the sample skipped
+                atomicOr(err, 1u);
+#pragma unroll
+                for (int k = 0; k < BATCH; k++)
+                    if (raw[k] >= nmetrics) {
+                        raw[k] = 0;
+                        bin[k] = 0;
+                        he[k] = (pu2_t){1u << 16, DUMMY_W + lane};
+                    }
+            }
+#pragma unroll
+            for (int k = 0; k < BATCH; k++) {
+                const uint32_t hrel = bin[k] - (he[k].y >> 16);
+                hot[k] = (he[k].x & 0xffffu) == raw[k] && hrel < (he[k].x >> 16);
+                const uint32_t a = (he[k].y & 0xffffu) + hrel, b = raw[k] & (NPT - 1u); // LDS words: the hot cell, the partition's counter
+                static_assert(CNT_W == 0, "the partition counters open the LDS block");
+                if (ABL & 8u) { uint32_t w = hot[k] ? a : b; asm volatile("" : "+v"(w)); rank[k] = lane & 15u; }
+                else rank[k] = atomicAdd(lds32 + (hot[k] ? a : b), 1u);
+                if (ABL & 2u) rank[k] &= 15u;
+            }
+            bool anyfull = false;
+#pragma unroll
+            for (int k = 0; k < BATCH; k++) {
+                const bool fits = !hot[k] && rank[k] < pe[k].y;
+                full[k] = !hot[k] && !fits; // the region is full: counted exactly below
+                anyfull |= full[k];
+                // record: partition << 24 | local name << 16 | bin = the id's two bytes swapped above the bin
+                if (fits)
+                    *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)(pe[k].x + 4u * rank[k]) =
+                        __builtin_amdgcn_perm(raw[k], bin[k], 0x04050100u);
+            }
+            if (anyfull) { // no room: queued, counted exactly by the flush phase
+#pragma unroll
+                for (int k = 0; k < BATCH; k++)
+                    if (full[k]) {
+                        atomicAdd(&L.ovn, 1u);
+                        const uint32_t key = (raw[k] << 16) | bin[k];
+                        const uint32_t at = atomicAdd(&L.missn[par], 1u);
+                        if (at < V3_MISSQ) L.missq[par][at] = key;
+                        else if (!ov_add(L.ov_key, L.ov_cnt, key, 1u)) v3_global_add(counts, ranges, raw[k], bin[k], 1);
+                    }
+            }
+        }
+    };
+    auto classify = [&](typename IS::raw_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
+        if constexpr (SC4_TRIM) classify_trim(idv, val, par); else classify_r5(idv, val, par);
+    };
     auto flush = [&](const uint32_t par) {
+        if (ABL & 2u) return;
         __syncthreads();                                   // barrier A: the tile's records are in the regions
+        if (ABL & 1u) {
+            if (tid < NPT) L.cnt[tid] = 0;
+            if (tid == BLOCK - 1) { L.missn[0] = 0; L.missn[1] = 0; }
+            __syncthreads();
+            return;
+        }
         // ---- phase 2: four threads per partition (p = tid / 4; thread q copies 16-byte piece q of every line)
         if (tid == BLOCK - 1) L.missn[par ^ 1u] = 0; // the other parity's queue was drained in the previous tile
         {
@@ -557,7 +662,8 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
                 for (uint32_t l = 0; l < full; l++) {
                     const uint32_t dst = (l < room ? dA : dB) + l * LINE4;
                     const pu4_t r4 = *reinterpret_cast<const pu4_t *>(src + l * LINE4 + q * 4);
-                    hidden_store_u4(records + dst + q * 4, r4);
+                    if (ABL & 4u) asm volatile("" : : "v"(r4), "v"(dst));
+                    else hidden_store_u4(records + dst + q * 4, r4);
                 }
                 // the leftover (less than a piece) moves to the front of the region: thread q moves 16-byte pieces q,
                 // q + 4, .. -- source and destination are at least one piece apart, every slot is read by its writer
@@ -615,7 +721,7 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
         for (uint32_t j = 0; j < V3_PIECE; j++)
             if (j * LINE4 + q * 4 < left)
                 *reinterpret_cast<pu4_t *>(records + d + j * LINE4 + q * 4) =
-                    *reinterpret_cast<const pu4_t *>(lds32 + L.pt[p].x + j * LINE4 + q * 4);
+                    *reinterpret_cast<const pu4_t *>(lds32 + (SC4_TRIM ? (L.pt[p].x - lds_base) >> 2 : L.pt[p].x) + j * LINE4 + q * 4);
     }
     if (nrec) atomicAdd(&L.nrec, nrec);
     __syncthreads();
@@ -881,7 +987,8 @@ __global__ __launch_bounds__(1024, 4) void k_split_records(const uint32_t *__res
                 for (uint32_t l = lane >> 2; l < full; l += 16) {
                     const uint32_t dst = (l < room ? dA : dB) + l * LINE4;
                     const pu4_t r4 = *reinterpret_cast<const pu4_t *>(src + l * LINE4 + q * 4);
-                    hidden_store_u4(records + dst + q * 4, r4);
+                    if (ABL & 4u) asm volatile("" : : "v"(r4), "v"(dst));
+                    else hidden_store_u4(records + dst + q * 4, r4);
                 }
                 // the last partial line moves to the front (LDS operations of one wave execute in order: the reads of
                 // line 0 above are done)

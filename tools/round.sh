@@ -24,6 +24,11 @@
 #   extract <tag>               K2 at 65 536 names: its tests, config 4's extract_roofline, the kernel under the tracer
 #   order <tag> <libs> [pairs names reps dists]   one sweep with several builds in a given order (A/B/A: build or box?)
 #   counters <tag>              tools/sq_counters.sh: SQ instruction / LDS counters per distribution
+#   level1 <tag> <base> <abl,...>   level 1 of the mixed ingest (k_scatter3 / k_scatter4): its parity tests, an A/B/A/B of the
+#                               product against build/liblhgpu_tuning_<base>.so, then the level-1 kernel's time under
+#                               rocprofv3 --kernel-trace for the product and every ablation build
+#                               build/liblhgpu_tuning_<abl>.so (tools/build_tuning.py -DLH_ABL=bits --name <abl>), then
+#                               the kernel's SQ wait / issue counters (two --pmc passes)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 SUB=$1; TAG=${2:-r5}; shift 2
 OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; cd $R
@@ -156,6 +161,41 @@ order)
     ;;
 counters)
     bash tools/sq_counters.sh $TAG
+    ;;
+level1)
+    BASE=${1:-}; ABLS=$(echo ${2:-} | tr ',' ' ')
+    suite tests/test_gpu_part2.py tests/test_gpu_part3.py tests/test_gpu_lane_blocks.py tests/test_gpu_pairs16.py
+    if [ -n "$BASE" ]; then
+        for sfx in $BASE product $BASE product; do
+            lib=""; [ "$sfx" != product ] && lib="--lib loghisto_amd/build/liblhgpu_tuning_$sfx.so"
+            echo "== $sfx" | tee -a $OUT/ab.txt
+            sweep 1e9 1024 6 --dists lognormal $lib | tee -a $OUT/ab.txt
+            sweep 1e9 65536 5 --dists lognormal $lib | tee -a $OUT/ab.txt
+            sweep 1.25e8 65536 24 --dists lognormal $lib | tee -a $OUT/ab.txt
+        done
+    fi
+    l1trace() { # l1trace <label> <lib args...>: the level-1 kernels' rows of a kernel trace at both name counts
+        for m in 1024 65536; do
+            (cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/pk
+             timeout 300 rocprofv3 --kernel-trace -d /tmp/pk -o t -- python $R/tools/sweep.py --samples 1e9 --pairs $m --reps 4 --dists lognormal --nocheck "${@:2}" > /dev/null 2>&1
+             python $R/profiles/summarize_rocpd.py stats /tmp/pk/t_results.db | grep -E "k_scatter|k_part_hist|k_split" | cut -c1-150 | sed -e "s/^/$1 names=$m  /")
+        done
+    }
+    l1trace product | tee -a $OUT/l1trace.txt
+    for sfx in $ABLS; do l1trace $sfx --lib loghisto_amd/build/liblhgpu_tuning_$sfx.so | tee -a $OUT/l1trace.txt; done
+    # SQ counters of the product's level-1 kernels: what the waves wait for
+    SETS=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
+          "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA"
+          "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE")
+    for m in 1024 65536; do
+        for i in 0 1 2; do
+            (cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/kc
+             timeout 300 rocprofv3 --pmc ${SETS[$i]} -d /tmp/kc -o t -- python $R/tools/sweep.py --samples 1e9 --pairs $m --reps 2 --dists lognormal > /tmp/kc.out 2>&1
+             for k in k_scatter3 k_scatter4; do
+                 python $R/profiles/summarize_rocpd.py pmc /tmp/kc/t_results.db $k | cut -c1-1500 | sed -e "s/^/names=$m set=$i /"
+             done) | grep -v '"counters": {}' | tee -a $OUT/l1_counters.jsonl
+        done
+    done
     ;;
 *)
     echo "unknown sub-command: $SUB"; exit 2;;
