@@ -52,7 +52,8 @@
 extern "C" {
 #endif
 
-#define LH_ABI_VERSION 5           /* 5: lh_row_stride() (rows of lh_snapshot_rows are no longer 65 536 cells apart), the
+#define LH_ABI_VERSION 6           /* 6: lh_extract_rows_compact / lh_expand_compact (the results of many names at 42 B instead of
+                                      139 B per name); 5: lh_row_stride() (rows of lh_snapshot_rows are no longer 65 536 cells apart), the
                                       tuning / test options moved to loghisto_gpu_tuning.h, ingest falls back to the
                                       scratch-free kernel when scratch cannot be had; 4: uint16-id pairs (lh_*pairs16*) */
 #define LH_NKEYS 65536            /* int16 key space (metrics.go:316)        */
@@ -205,6 +206,31 @@ typedef struct lh_extract_view {
 } lh_extract_view;
 int lh_extract_rows_view(lh_snapshot *s, uint32_t first, size_t nmetrics, const double *p, size_t np,
                          lh_extract_view *view);
+/* The COMPACT form of the same results, for large name spaces (round 6).  processHistograms emits 3 + P floats per
+ * name (metrics.go:349-356, 378-385), but only count, sum and the P selected KEYS are information: avg is
+ * sum / float64(count), uint64(sum) a conversion, and every percentile value is exactly decompress(key) -- the table
+ * D[] that lh_codec_tables exports.  This call brings 8 + 8 + 4 + 4 + 2 P bytes per name to the host (42 B at the nine
+ * default percentiles against 139 B: at 65 536 names 2.75 MB instead of 9.1 MB over PCIe, which was more than half of
+ * the flip -> results latency), in place in the engine's pinned block under lh_extract_rows_view's lifetime rule.
+ *   count[nmetrics], sum[nmetrics], nbuckets[nmetrics]
+ *   pkeys[nmetrics * np]     the selected int16 keys (0 where the percentile has no bucket)
+ *   pvalid_bits[nmetrics]    bit i set iff percentile i has a bucket (np <= LH_MAX_PERCENTILES = 32)
+ * lh_expand_compact derives the full form from it ON THE HOST, bit for bit what lh_extract_rows returns for the same
+ * snapshot (present = count != 0, avg = sum / float64(count), agg_sum_add = uint64(sum) with the amd64 conversion,
+ * pvals = D[key]); a binding that formats keys itself reads D[] once (lh_codec_tables) and never expands.  Any of
+ * stats / pvals / pkeys / pvalid may be NULL. */
+typedef struct lh_extract_compact {
+    const uint64_t *count;
+    const double *sum;
+    const uint32_t *nbuckets;
+    const uint32_t *pvalid_bits;
+    const int16_t *pkeys;
+    size_t nmetrics, np;
+} lh_extract_compact;
+int lh_extract_rows_compact(lh_snapshot *s, uint32_t first, size_t nmetrics, const double *p, size_t np,
+                            lh_extract_compact *view);
+int lh_expand_compact(lh_engine *e, const lh_extract_compact *c, lh_stats *stats, double *pvals, int16_t *pkeys,
+                      uint8_t *pvalid);
 /* Occupied cells of one metric, ascending key. *n receives the number of
  * occupied cells even when it exceeds cap. */
 int lh_buckets(lh_snapshot *s, uint32_t id, int16_t *keys, uint64_t *counts, size_t cap, size_t *n);

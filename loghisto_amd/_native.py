@@ -11,7 +11,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblhgpu.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
+# tools/sweep.py --lib (A/B runs against a build of an earlier round): accept a library of an older ABI and bind
+# what it exports; never set by the product or the tests
+ALLOW_OLDER_ABI = False
 NKEYS = 65536
 NTHRESH = 70980
 MAX_PERCENTILES = 32
@@ -84,6 +87,11 @@ PATH_DIRECT, PATH_SMALL, PATH_GEN1, PATH_GEN2, PATH_GEN3 = range(5)
 class LhExtractView(C.Structure):
     _fields_ = [("stats", C.c_void_p), ("pvals", C.c_void_p), ("pkeys", C.c_void_p), ("pvalid", C.c_void_p),
                 ("nmetrics", C.c_size_t), ("np", C.c_size_t)]
+
+
+class LhExtractCompact(C.Structure):
+    _fields_ = [("count", C.c_void_p), ("sum", C.c_void_p), ("nbuckets", C.c_void_p), ("pvalid_bits", C.c_void_p),
+                ("pkeys", C.c_void_p), ("nmetrics", C.c_size_t), ("np", C.c_size_t)]
 
 
 class LhMergeInfo(C.Structure):
@@ -159,6 +167,8 @@ SIGNATURES = {
     "lh_extract": (C.c_int, [_vp, _dp, _sz, C.POINTER(LhStats), _dp, _i16p, _u8p, _sz]),
     "lh_extract_rows": (C.c_int, [_vp, C.c_uint32, _sz, _dp, _sz, C.POINTER(LhStats), _dp, _i16p, _u8p]),
     "lh_extract_rows_view": (C.c_int, [_vp, C.c_uint32, _sz, _dp, _sz, C.POINTER(LhExtractView)]),
+    "lh_extract_rows_compact": (C.c_int, [_vp, C.c_uint32, _sz, _dp, _sz, C.POINTER(LhExtractCompact)]),
+    "lh_expand_compact": (C.c_int, [_vp, C.POINTER(LhExtractCompact), C.POINTER(LhStats), _dp, _i16p, _u8p]),
     "lh_buckets": (C.c_int, [_vp, C.c_uint32, _i16p, _u64p, _sz, C.POINTER(_sz)]),
     "lh_buckets_all": (C.c_int, [_vp, C.c_uint32, _sz, _u64p, _i16p, _u64p, _sz, C.POINTER(_sz)]),
     "lh_snapshot_rows": (C.c_int, [_vp, C.POINTER(_vp), _u32p]),
@@ -220,10 +230,12 @@ def lib():
         try:
             fn = getattr(L, name)
         except AttributeError as exc:
+            if ALLOW_OLDER_ABI:
+                continue
             raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from exc
         fn.restype = res
         fn.argtypes = args
-    if L.lh_abi_version() != ABI_VERSION:
+    if L.lh_abi_version() != ABI_VERSION and not (ALLOW_OLDER_ABI and L.lh_abi_version() >= 5):
         raise NativeLibraryError(f"ABI mismatch: library {L.lh_abi_version()}, binding {ABI_VERSION}")
     _lib = L
     return L

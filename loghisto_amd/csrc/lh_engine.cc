@@ -104,7 +104,23 @@ struct LaneLock {
 // One D2H block per extract call.
 struct ExtractLayout {
     size_t off_stats, off_pvals, off_pkeys, off_pvalid, off_err, total;
+    size_t off_count = 0, off_sum = 0, off_nb = 0, off_vbits = 0; // compact form (off_pkeys is shared)
 };
+
+// lh_extract_rows_compact: count | sum | pkeys | nbuckets | valid bits | err
+ExtractLayout extract_layout_compact(size_t nmetrics, size_t np)
+{
+    ExtractLayout L{};
+    size_t o = 0;
+    L.off_count = o; o += nmetrics * sizeof(uint64_t);
+    L.off_sum = o; o += nmetrics * sizeof(double);
+    L.off_pkeys = o; o += (nmetrics * np * sizeof(int16_t) + 7) & ~size_t(7);
+    L.off_nb = o; o += (nmetrics * sizeof(uint32_t) + 7) & ~size_t(7);
+    L.off_vbits = o; o += (nmetrics * sizeof(uint32_t) + 7) & ~size_t(7);
+    L.off_err = o; o += 8;
+    L.total = o;
+    return L;
+}
 
 ExtractLayout extract_layout(size_t nmetrics, size_t np)
 {
@@ -287,6 +303,8 @@ struct lh_engine {
     lh::PartTuning tune;                  // lh_set_option; never the environment in the product build
     bool zero_copy_enabled = true;
     size_t zero_copy_max = 32768; // results up to this size are stored by the kernel straight into pinned memory
+    std::mutex hD_mu;             // lh_expand_compact: the decompress table on the host, read back once
+    std::vector<double> h_D;
     uint32_t flips_since_small_off = 0;   // adaptive dispatch re-arms the single-pass path every 64 flips (epoch_mu)
     bool small_forced_off = false;        // LH_OPT_SMALL_PATH = 0: never re-armed
 };
@@ -1493,7 +1511,22 @@ int finish_extract(lh_engine *e, const ExtractLayout &L, size_t nmetrics, size_t
 }
 
 int extract_impl(lh_snapshot *s, uint32_t first, size_t nmetrics, const double *p, size_t np, lh_stats *stats,
-                 double *pvals, int16_t *pkeys, uint8_t *pvalid, lh_extract_view *view);
+                 double *pvals, int16_t *pkeys, uint8_t *pvalid, lh_extract_view *view, lh_extract_compact *cview = nullptr);
+
+// uint64(float64) as Go compiles it for amd64 (metrics.go:374): the host-side twin of the kernels'
+// d_f64_to_u64_amd64, for lh_expand_compact
+uint64_t f64_to_u64_amd64(double f)
+{
+    const double two63 = 9223372036854775808.0;
+    if (f != f) return 0x8000000000000000ull;
+    if (f < two63) {
+        if (f <= -two63) return 0x8000000000000000ull;
+        return (uint64_t)(long long)f;
+    }
+    const double g = f - two63;
+    if (g >= two63) return 0;
+    return (uint64_t)(long long)g ^ 0x8000000000000000ull;
+}
 } // namespace
 
 int lh_extract_rows(lh_snapshot *s, uint32_t first, size_t nmetrics, const double *p, size_t np, lh_stats *stats,
@@ -1509,6 +1542,58 @@ int lh_extract_rows_view(lh_snapshot *s, uint32_t first, size_t nmetrics, const 
     if (!s || !view || (np && nmetrics && !p)) return LH_EINVAL;
     std::memset(view, 0, sizeof(*view));
     return extract_impl(s, first, nmetrics, p, np, nullptr, nullptr, nullptr, nullptr, view);
+}
+
+int lh_extract_rows_compact(lh_snapshot *s, uint32_t first, size_t nmetrics, const double *p, size_t np,
+                            lh_extract_compact *view)
+{
+    if (!s || !view || (np && nmetrics && !p)) return LH_EINVAL;
+    std::memset(view, 0, sizeof(*view));
+    return extract_impl(s, first, nmetrics, p, np, nullptr, nullptr, nullptr, nullptr, nullptr, view);
+}
+
+// The full form from the compact one, on the host: every field is a function of count, sum and the keys alone
+// (processHistograms, metrics.go:349-356, 374, 378-385), evaluated with the operations the kernels use -- an IEEE
+// divide, the amd64 conversion, a read of the device-generated table D[] -- so the results equal lh_extract_rows' bit
+// for bit (tests/test_gpu_extract_compact.py).
+int lh_expand_compact(lh_engine *e, const lh_extract_compact *c, lh_stats *stats, double *pvals, int16_t *pkeys,
+                      uint8_t *pvalid)
+{
+    if (!e || !c || (c->nmetrics && (!c->count || !c->sum || !c->nbuckets))) return LH_EINVAL;
+    if (c->np > LH_MAX_PERCENTILES || (c->np && c->nmetrics && (!c->pkeys || !c->pvalid_bits))) return LH_EINVAL;
+    const double *D = nullptr;
+    if (pvals && c->np) {
+        std::lock_guard<std::mutex> g(e->hD_mu);
+        if (e->h_D.empty()) {
+            int rc = use_device(e);
+            if (rc) return rc;
+            e->h_D.resize(LH_NKEYS);
+            hipError_t he = hipMemcpy(e->h_D.data(), e->d_D, sizeof(double) * LH_NKEYS, hipMemcpyDeviceToHost);
+            if (he != hipSuccess) { e->h_D.clear(); set_last_error("hipMemcpy(D)", he); return LH_EDEVICE; }
+        }
+        D = e->h_D.data();
+    }
+    const size_t n = c->nmetrics, np = c->np;
+    for (size_t m = 0; m < n; m++) {
+        if (stats) {
+            lh_stats &o = stats[m];
+            o.count = c->count[m];
+            o.sum = c->sum[m];
+            o.avg = c->sum[m] / (double)c->count[m]; // metrics.go:356 (0/0 = NaN when empty)
+            o.agg_sum_add = f64_to_u64_amd64(c->sum[m]);
+            o.nbuckets = c->nbuckets[m];
+            o.present = c->count[m] ? 1u : 0u;
+        }
+        const uint32_t bits = np ? c->pvalid_bits[m] : 0u;
+        for (size_t i = 0; i < np; i++) {
+            const bool ok = (bits >> i) & 1u;
+            const int16_t key = c->pkeys[m * np + i];
+            if (pvals) pvals[m * np + i] = ok ? D[(uint16_t)key ^ 0x8000u] : 0.0; // D is indexed by the dense bin
+            if (pkeys) pkeys[m * np + i] = ok ? key : (int16_t)0;
+            if (pvalid) pvalid[m * np + i] = ok ? 1 : 0;
+        }
+    }
+    return LH_OK;
 }
 
 // Measurement helper (loghisto_gpu_tuning.h): device time of the engine's last LARGE extract (results through HBM and one
@@ -1527,7 +1612,7 @@ int lh_tool_last_extract_ms(lh_engine *e, float *kernel_ms, float *copy_ms)
 
 namespace {
 int extract_impl(lh_snapshot *s, uint32_t first, size_t nmetrics, const double *p, size_t np, lh_stats *stats,
-                 double *pvals, int16_t *pkeys, uint8_t *pvalid, lh_extract_view *view)
+                 double *pvals, int16_t *pkeys, uint8_t *pvalid, lh_extract_view *view, lh_extract_compact *cview)
 {
     lh_engine *e = s->e;
     if (np > LH_MAX_PERCENTILES || (uint64_t)first + nmetrics > e->cfg.max_metrics) return LH_EINVAL;
@@ -1536,7 +1621,7 @@ int extract_impl(lh_snapshot *s, uint32_t first, size_t nmetrics, const double *
     if (rc) return rc;
     static_assert(sizeof(lh::ExtractOut) == sizeof(lh_stats), "lh_stats layout");
     std::lock_guard<std::mutex> g(e->xmu);
-    const ExtractLayout L = extract_layout(nmetrics, np);
+    const ExtractLayout L = cview ? extract_layout_compact(nmetrics, np) : extract_layout(nmetrics, np);
     rc = ensure_xbuf(e, L.total + 16);
     if (rc) return rc;
     EpochBuffer &b = e->bufs[(size_t)s->buf];
@@ -1565,12 +1650,20 @@ int extract_impl(lh_snapshot *s, uint32_t first, size_t nmetrics, const double *
         e->xev_valid = false;
         HIPCHK(hipEventRecord(e->xev[0], e->xstream));
     }
+    lh::ExtractCompact cx;
+    if (cview) {
+        cx.count = reinterpret_cast<uint64_t *>(xb + L.off_count);
+        cx.sum = reinterpret_cast<double *>(xb + L.off_sum);
+        cx.nbuckets = reinterpret_cast<uint32_t *>(xb + L.off_nb);
+        cx.vbits = reinterpret_cast<uint32_t *>(xb + L.off_vbits);
+        cx.pkeys = reinterpret_cast<int16_t *>(xb + L.off_pkeys);
+    }
     HIPCHK(lh::launch_extract(b.counts + (size_t)first * LH_ROW_STRIDE, b.ranges + 2 * (size_t)first,
                               (uint32_t)nmetrics, p, (uint32_t)np, e->d_D,
                               reinterpret_cast<lh::ExtractOut *>(xb + L.off_stats),
                               reinterpret_cast<double *>(xb + L.off_pvals),
                               reinterpret_cast<int16_t *>(xb + L.off_pkeys), xb + L.off_pvalid,
-                              e->d_err, reinterpret_cast<uint32_t *>(xb + L.off_err), e->xstream, nt));
+                              e->d_err, reinterpret_cast<uint32_t *>(xb + L.off_err), e->xstream, nt, cx));
     if (zero_copy) {
         // spin on the completion word the last workgroup stores after its system-scope release: no driver call
         // on the latency path; after 2 ms (a flip queued behind long ingest kernels) fall back to the stream
@@ -1590,6 +1683,19 @@ int extract_impl(lh_snapshot *s, uint32_t first, size_t nmetrics, const double *
         HIPCHK(hipEventRecord(e->xev[2], e->xstream));
         HIPCHK(hipStreamSynchronize(e->xstream));
         e->xev_valid = true;
+    }
+    if (cview) {
+        cview->count = reinterpret_cast<const uint64_t *>(e->h_xbuf + L.off_count);
+        cview->sum = reinterpret_cast<const double *>(e->h_xbuf + L.off_sum);
+        cview->nbuckets = reinterpret_cast<const uint32_t *>(e->h_xbuf + L.off_nb);
+        cview->pvalid_bits = reinterpret_cast<const uint32_t *>(e->h_xbuf + L.off_vbits);
+        cview->pkeys = reinterpret_cast<const int16_t *>(e->h_xbuf + L.off_pkeys);
+        cview->nmetrics = nmetrics;
+        cview->np = np;
+        uint32_t err, nfall;
+        std::memcpy(&err, e->h_xbuf + L.off_err, 4);
+        std::memcpy(&nfall, e->h_xbuf + L.off_err + 4, 4);
+        return after_extract(e, err, nfall);
     }
     return finish_extract(e, L, nmetrics, np, stats, pvals, pkeys, pvalid, view);
 }

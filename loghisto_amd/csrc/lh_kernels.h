@@ -126,10 +126,22 @@ hipError_t launch_ingest_pairs_part3(Ids d_ids, const double *d_v, size_t n, siz
 // `seq` into *host_flag (system-scope release after every workgroup's results), so the host can spin on a word
 // of pinned memory instead of going through a stream synchronisation.  done_ctr: device uint32, zero between calls.
 struct ExtractNotify { uint32_t *done_ctr = nullptr; uint32_t *host_flag = nullptr; uint32_t seq = 0; };
+// The COMPACT form of the results (lh_extract_rows_compact): what cannot be derived on the host, as separate arrays --
+// count, sum, occupied buckets, the selected keys and one word of valid bits per metric (bit i: percentile i has a
+// bucket).  avg, uint64(sum), present and the percentile VALUES (D[key]) follow from these bit for bit.  With
+// count == nullptr the kernels write the full form (out / pvals / pkeys / pvalid).
+struct ExtractCompact {
+    uint64_t *count = nullptr;
+    double *sum = nullptr;
+    uint32_t *nbuckets = nullptr;
+    uint32_t *vbits = nullptr;
+    int16_t *pkeys = nullptr;
+};
 hipError_t launch_extract(const uint64_t *counts, const uint32_t *ranges, uint32_t nmetrics,
                           const double *h_p /* host */, uint32_t np, const double *d_D, ExtractOut *out,
                           double *pvals, int16_t *pkeys, uint8_t *pvalid, const uint32_t *err_in,
-                          uint32_t *err_out, hipStream_t s, ExtractNotify notify = ExtractNotify());
+                          uint32_t *err_out, hipStream_t s, ExtractNotify notify = ExtractNotify(),
+                          ExtractCompact compact = ExtractCompact());
 
 // K5: occupied cells of every row as CSR arrays (ascending key within a row).
 hipError_t launch_count_cells(const uint64_t *counts, const uint32_t *ranges, uint32_t nmetrics, uint32_t *ncells,

@@ -529,7 +529,8 @@ __global__ __launch_bounds__(K2_BLOCK) void k_extract(const uint64_t *__restrict
                                                       double *__restrict__ pvals, int16_t *__restrict__ pkeys,
                                                       uint8_t *__restrict__ pvalid,
                                                       const uint32_t *__restrict__ err_in,
-                                                      uint32_t *__restrict__ err_out, const ExtractNotify nt)
+                                                      uint32_t *__restrict__ err_out, const ExtractNotify nt,
+                                                      const ExtractCompact cx)
 {
     __shared__ uint64_t s_cnt[K2_WAVES];
     __shared__ double s_sum[K2_WAVES];
@@ -580,14 +581,20 @@ __global__ __launch_bounds__(K2_BLOCK) void k_extract(const uint64_t *__restrict
     for (int w = 0; w < K2_WAVES; w++) { total += s_cnt[w]; tsum += s_sum[w]; tnb += s_nb[w]; }
 
     if (tid == 0) {
-        ExtractOut o;
-        o.count = total;
-        o.sum = tsum;
-        o.avg = tsum / (double)total; // metrics.go:356 (0/0 = NaN when empty)
-        o.agg_sum_add = d_f64_to_u64_amd64(tsum);
-        o.nbuckets = tnb;
-        o.present = total ? 1u : 0u;
-        out[m] = o;
+        if (cx.count) { // compact form: the host derives avg, uint64(sum) and present
+            cx.count[m] = total;
+            cx.sum[m] = tsum;
+            cx.nbuckets[m] = tnb;
+        } else {
+            ExtractOut o;
+            o.count = total;
+            o.sum = tsum;
+            o.avg = tsum / (double)total; // metrics.go:356 (0/0 = NaN when empty)
+            o.agg_sum_add = d_f64_to_u64_amd64(tsum);
+            o.nbuckets = tnb;
+            o.present = total ? 1u : 0u;
+            out[m] = o;
+        }
     }
 
     // ---- pass 2: percentile (metrics.go:406-418) as a prefix scan in bin order
@@ -642,7 +649,14 @@ __global__ __launch_bounds__(K2_BLOCK) void k_extract(const uint64_t *__restrict
         }
     }
     __syncthreads();
-    if (tid < np) {
+    if (cx.count) {
+        if (wave == 0) { // (np <= 32: the percentiles' threads are lanes of wave 0)
+            const uint32_t fb = tid < np ? s_found[tid] : 0xffffffffu;
+            const unsigned long long ok = __builtin_amdgcn_ballot_w64(fb != 0xffffffffu);
+            if (tid < np) cx.pkeys[(size_t)m * np + tid] = fb != 0xffffffffu ? (int16_t)bin_to_key(fb) : (int16_t)0;
+            if (tid == 0) cx.vbits[m] = (uint32_t)ok;
+        }
+    } else if (tid < np) {
         const uint32_t fb = s_found[tid];
         const size_t o = (size_t)m * np + tid;
         if (fb != 0xffffffffu) {
@@ -898,7 +912,7 @@ __global__ __launch_bounds__(K2_BLOCK) void k_extract_wave(const uint64_t *__res
                                                            double *__restrict__ pvals, int16_t *__restrict__ pkeys,
                                                            uint8_t *__restrict__ pvalid,
                                                            const uint32_t *__restrict__ err_in,
-                                                           uint32_t *__restrict__ err_out)
+                                                           uint32_t *__restrict__ err_out, const ExtractCompact cx)
 {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t m = blockIdx.x * K2_WAVES + wave;
@@ -977,45 +991,63 @@ __global__ __launch_bounds__(K2_BLOCK) void k_extract_wave(const uint64_t *__res
         for (int v = 0; v < K2_WAVES; v++) tsum += shfl_f64(sum4[v], 0); // ((w0 + w1) + w2) + w3, as k_extract
         tnb = __shfl(nb, 0, 64);
 
-        // pass 2, 256 bins per step: the quotient of metrics.go:413 at every occupied bin
+        // pass 2, 256 bins per step, as the in-register path does it (round 6; round 4's loop evaluated the quotient of
+        // metrics.go:413 with an IEEE divide at every cell and moved `found` and the hits through ds_bpermute): lane
+        // i < np owns percentile i and the smallest prefix count T that reaches it (pct_threshold); a step looks only at
+        // the percentiles whose threshold falls inside it -- one 64-bit compare per lane and step -- and finds each one's
+        // bin with a ballot and three compares.  Cells beyond hi are zero, so a 4-bin group that straddles hi needs no mask.
         if (total && np) {
-            const double ftotal = (double)total;
+            uint64_t T64 = ~0ull;
+            if (lane < np) T64 = pct_threshold(pa.p[lane], total);
+            uint32_t todo = (uint32_t)__builtin_amdgcn_ballot_w64(T64 != ~0ull); // percentiles without a bin yet (np <= 32)
             uint64_t carry = 0;
-            uint32_t open = np; // percentiles without a bin yet (wave-uniform)
-            for (uint32_t base = lo; base <= hi && open; base += K2_TILE / K2_WAVES) {
+            for (uint32_t base = lo; base <= hi && todo; base += K2_TILE / K2_WAVES) {
                 const uint32_t b0 = base + lane * K2_PER_THREAD;
-                uint64_t c[K2_PER_THREAD];
-#pragma unroll
-                for (int k = 0; k < K2_PER_THREAD; k++) c[k] = (b0 + k <= hi) ? row[b0 + k] : 0;
-                uint64_t tsumc = 0;
-#pragma unroll
-                for (int k = 0; k < K2_PER_THREAD; k++) tsumc += c[k];
-                const uint64_t inc = wave_scan_incl_u64(tsumc);
-                uint64_t sofar = carry + (inc - tsumc);
-                double q[K2_PER_THREAD]; // float64(sofar)/float64(totalCount), metrics.go:413; -1 for empty buckets
-#pragma unroll
-                for (int k = 0; k < K2_PER_THREAD; k++) {
-                    sofar += c[k];
-                    q[k] = c[k] ? (double)sofar / ftotal : -1.0;
+                u64x2_a8 c01 = {0, 0}, c23 = {0, 0};
+                if (b0 <= hi && b0 + K2_PER_THREAD <= LH_ROW_STRIDE) {
+                    const u64x2_a8 *rp = reinterpret_cast<const u64x2_a8 *>(row + b0);
+                    c01 = rp[0];
+                    c23 = rp[1];
                 }
-                for (uint32_t i = 0; i < np; i++) {
-                    const uint32_t fi = __shfl(found, (int)i, 64);
-                    if (fi != 0xffffffffu) continue; // settled by an earlier step (wave-uniform)
-                    const double pi = pa.p[i];
-                    uint32_t hit = 0xffffffffu;
+                const uint64_t c[K2_PER_THREAD] = {c01.a, c01.b, c23.a, c23.b};
+                const uint64_t tsumc = (c[0] + c[1]) + (c[2] + c[3]);
+                const uint64_t inc = wave_scan_incl_u64(tsumc);
+                const uint64_t end = carry + readlane_u64(inc, 63);
+                // (every open threshold is > carry: it would have ended in an earlier step otherwise)
+                uint32_t here = (uint32_t)__builtin_amdgcn_ballot_w64(T64 <= end) & todo; // wave-uniform
+                todo &= ~here;
+                if (here) {
+                    uint64_t pre[K2_PER_THREAD], sofar = carry + (inc - tsumc);
 #pragma unroll
-                    for (int k = K2_PER_THREAD - 1; k >= 0; k--)
-                        if (q[k] >= pi && q[k] >= 0.0) hit = b0 + k;
-                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit != 0xffffffffu);
-                    if (mask) {
-                        const uint32_t first_hit = __shfl(hit, (int)__builtin_ctzll(mask), 64);
-                        if (lane == i) found = first_hit;
-                        open--;
+                    for (int k = 0; k < K2_PER_THREAD; k++) {
+                        sofar += c[k];
+                        pre[k] = sofar;
+                    }
+                    for (; here; here &= here - 1) {
+                        const uint32_t i = (uint32_t)__builtin_ctz(here);
+                        const uint64_t Ti = readlane_u64(T64, i);
+                        // the first lane whose last bin reaches Ti (lane 63's does), and how many of its bins stay below
+                        const unsigned long long reach = __builtin_amdgcn_ballot_w64(pre[K2_PER_THREAD - 1] >= Ti);
+                        const uint32_t f = (uint32_t)__builtin_ctzll(reach);
+                        const uint32_t below = (pre[0] < Ti ? 1u : 0u) + (pre[1] < Ti ? 1u : 0u) + (pre[2] < Ti ? 1u : 0u);
+                        const uint32_t bin = base + f * K2_PER_THREAD + (uint32_t)__builtin_amdgcn_readlane((int)below, (int)f);
+                        if (lane == i) found = bin;
                     }
                 }
-                carry += readlane_u64(inc, 63);
+                carry = end;
             }
         }
+    }
+    if (cx.count) { // compact form (wave-uniform): no table gather, no divide, 42 B per name at nine percentiles
+        const unsigned long long ok = __builtin_amdgcn_ballot_w64(lane < np && found != 0xffffffffu);
+        if (lane == 0) {
+            cx.count[m] = total;
+            cx.sum[m] = tsum;
+            cx.nbuckets[m] = tnb;
+            cx.vbits[m] = (uint32_t)ok;
+        }
+        if (lane < np) cx.pkeys[(size_t)m * np + lane] = found != 0xffffffffu ? (int16_t)bin_to_key(found) : (int16_t)0;
+        return;
     }
     if (lane == 0) {
         ExtractOut o;
@@ -1044,7 +1076,7 @@ __global__ __launch_bounds__(K2_BLOCK) void k_extract_wave(const uint64_t *__res
 hipError_t launch_extract(const uint64_t *counts, const uint32_t *ranges, uint32_t nmetrics,
                           const double *h_p, uint32_t np, const double *d_D, ExtractOut *out,
                           double *pvals, int16_t *pkeys, uint8_t *pvalid, const uint32_t *err_in,
-                          uint32_t *err_out, hipStream_t s, ExtractNotify notify)
+                          uint32_t *err_out, hipStream_t s, ExtractNotify notify, ExtractCompact compact)
 {
     if (nmetrics == 0) return hipSuccess;
     PctArgs pa;
@@ -1052,11 +1084,11 @@ hipError_t launch_extract(const uint64_t *counts, const uint32_t *ranges, uint32
     // many names: one wave per metric (bit-identical results; see k_extract_wave)
     if (nmetrics >= 2048 && !notify.host_flag) {
         hipLaunchKernelGGL(k_extract_wave, dim3((nmetrics + K2_WAVES - 1) / K2_WAVES), dim3(K2_BLOCK), 0, s, counts,
-                           ranges, nmetrics, pa, np, d_D, out, pvals, pkeys, pvalid, err_in, err_out);
+                           ranges, nmetrics, pa, np, d_D, out, pvals, pkeys, pvalid, err_in, err_out, compact);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_extract, dim3(nmetrics), dim3(K2_BLOCK), 0, s, counts, ranges, pa, np, d_D, out,
-                       pvals, pkeys, pvalid, err_in, err_out, notify);
+                       pvals, pkeys, pvalid, err_in, err_out, notify, compact);
     return hipGetLastError();
 }
 

@@ -745,7 +745,8 @@ constexpr bool SC3_TRIM = LH_SC3_TRIM != 0;
 // construction; the product is built with 0): 1 = the copy-out body removed (both barriers stay, the counters are
 // reset), 2 = no barriers and no copy-out at all (records wrap inside the first 16 slots of their region), 4 = the
 // copy-out without its global stores, 8 = no LDS atomics (the slot is the lane), 16 = the bucket index computed twice
-// (+19 VALU per sample: the slope of time over VALU work).
+// (+19 VALU per sample: the slope of time over VALU work), 32 = every workgroup re-reads its first tile (the input
+// comes from the L2 instead of HBM).
 #ifndef LH_ABL
 #define LH_ABL 0
 #endif
@@ -885,12 +886,13 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
     pd2_t vaa[NPAIR], vab[NPAIR];
     auto load_tile = [&](size_t tile, typename IS::raw_t (&di)[NPAIR], pd2_t (&dv)[NPAIR]) {
         if (tile >= ntiles) tile = ntiles - 1; // the two tiles past the end that the pipeline touches (uniform)
+        if (ABL & 32u) tile = blockIdx.x;
         const size_t it = tile * (V3_TILE / 2) + tid;
         const pd2_t *vt = vp + tile * (V3_TILE / 2) + tid;
 #pragma unroll
         for (int j = 0; j < NPAIR; j++) {
-            di[j] = ip.ld_nt(it + (size_t)j * BLOCK);
-            dv[j] = __builtin_nontemporal_load(vt + j * BLOCK);
+            di[j] = (ABL & 32u) ? ip.ld(it + (size_t)j * BLOCK) : ip.ld_nt(it + (size_t)j * BLOCK);
+            dv[j] = (ABL & 32u) ? vt[j * BLOCK] : __builtin_nontemporal_load(vt + j * BLOCK);
         }
     };
     load_tile(blockIdx.x, ida, vaa);

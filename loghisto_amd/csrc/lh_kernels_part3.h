@@ -455,12 +455,13 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
     pd2_t vaa[NPAIR], vab[NPAIR];
     auto load_tile = [&](size_t tile, typename IS::raw_t (&di)[NPAIR], pd2_t (&dv)[NPAIR]) {
         if (tile >= ntiles) tile = ntiles - 1; // the two tiles past the end that the pipeline touches (uniform)
+        if (ABL & 32u) tile = blockIdx.x;
         const size_t it = tile * (V3_TILE / 2) + tid;
         const pd2_t *vt = vp + tile * (V3_TILE / 2) + tid;
 #pragma unroll
         for (int j = 0; j < NPAIR; j++) {
-            di[j] = ip.ld_nt(it + (size_t)j * BLOCK);
-            dv[j] = __builtin_nontemporal_load(vt + j * BLOCK);
+            di[j] = (ABL & 32u) ? ip.ld(it + (size_t)j * BLOCK) : ip.ld_nt(it + (size_t)j * BLOCK);
+            dv[j] = (ABL & 32u) ? vt[j * BLOCK] : __builtin_nontemporal_load(vt + j * BLOCK);
         }
     };
     load_tile(blockIdx.x, ida, vaa);

@@ -48,7 +48,7 @@ def test_the_public_header_keeps_only_the_operational_options():
 
 
 def test_abi_version_and_strerror(native_lib):
-    assert native_lib.lh_abi_version() == 5
+    assert native_lib.lh_abi_version() == 6
     msgs = {native_lib.lh_strerror(c).decode() for c in range(8)}
     assert len(msgs) == 8 and "ok" in msgs
 

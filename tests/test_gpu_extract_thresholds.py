@@ -24,7 +24,7 @@ def _rows(rng, M):
     rows = []
     big = [2 ** 32 - 1, 2 ** 32, 2 ** 32 + 1, 2 ** 53 - 1, 2 ** 53, 2 ** 53 + 1, 2 ** 63, 2 ** 64 - 1]
     for m in range(M):
-        kind = m % 12
+        kind = m % 13
         lo = int(rng.integers(0, 65536 - 1100))
         if kind == 0:      # a handful of cells, total 1 .. 10: every p in P_A lands on or beside a quotient
             k = int(rng.integers(1, 6))
@@ -36,7 +36,7 @@ def _rows(rng, M):
         elif kind == 2:    # one cell
             r = {lo: int(rng.integers(1, 2 ** 40))}
         elif kind == 3:    # huge totals, exact: cells that add up to one of `big`
-            t = big[(m // 12) % len(big)]
+            t = big[(m // 13) % len(big)]
             k = int(rng.integers(1, 5))
             parts = sorted(int(x) for x in rng.integers(1, max(2, min(t, 2 ** 62)), size=k - 1)) if k > 1 else []
             parts = [p for p in parts if 0 < p < t]
@@ -62,7 +62,7 @@ def _rows(rng, M):
             c = rng.integers(0, 50, w)
             r = {i: int(c[i]) + (1 if i == 0 else 0) for i in range(w) if c[i] or i == 0}
         elif kind == 8:    # exactly 1 024 bins (the widest in-register span) and 1 025 (the narrowest wide one)
-            w = 1024 + (m // 12) % 2
+            w = 1024 + (m // 13) % 2
             r = {lo: 3, lo + w - 1: 5, lo + w // 2: 1}
         elif kind == 9:    # one dominant cell among many (prefix jumps over several thresholds at once)
             w = int(rng.integers(10, 1000))
@@ -72,6 +72,15 @@ def _rows(rng, M):
             w = int(rng.integers(50, 1000))
             c = (rng.lognormal(10, 4, w)).astype(np.uint64) % (2 ** 36)
             r = {lo + i: int(c[i]) for i in range(w) if c[i]}
+        elif kind == 11:   # a WIDE span (the two-pass loop, 64-bit prefix counts) whose cells add up to one of `big`
+            lo = int(rng.integers(0, 65536 - 9100))
+            t = big[(m // 13) % len(big)]
+            k = int(rng.integers(2, 40))
+            cuts = [0] + sorted(set(int(x) for x in rng.integers(1, max(2, min(t, 2 ** 62)), size=k - 1) if 0 < x < t)) + [t]
+            cs = [b - a for a, b in zip(cuts, cuts[1:]) if b > a]
+            bins = np.sort(rng.choice(np.arange(lo, lo + int(rng.integers(1100, 9000))), size=len(cs), replace=False))
+            bins[-1] = max(bins[-1], lo + 1100)   # (wider than the in-register path whatever was drawn)
+            r = {int(b): int(c) for b, c in zip(np.sort(bins), cs)}
         else:              # empty row
             r = {}
         rows.append(r)

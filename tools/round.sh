@@ -164,7 +164,7 @@ counters)
     ;;
 level1)
     BASE=${1:-}; ABLS=$(echo ${2:-} | tr ',' ' ')
-    suite tests/test_gpu_part2.py tests/test_gpu_part3.py tests/test_gpu_lane_blocks.py tests/test_gpu_pairs16.py
+    if [ -n "${L1_TESTS:-}" ]; then suite $L1_TESTS; else suite tests/test_gpu_part2.py tests/test_gpu_part3.py tests/test_gpu_lane_blocks.py tests/test_gpu_pairs16.py; fi
     if [ -n "$BASE" ]; then
         for sfx in $BASE product $BASE product; do
             lib=""; [ "$sfx" != product ] && lib="--lib loghisto_amd/build/liblhgpu_tuning_$sfx.so"
@@ -182,7 +182,7 @@ level1)
         done
     }
     l1trace product | tee -a $OUT/l1trace.txt
-    for sfx in $ABLS; do l1trace $sfx --lib loghisto_amd/build/liblhgpu_tuning_$sfx.so | tee -a $OUT/l1trace.txt; done
+    for sfx in $ABLS; do l1trace $sfx --lib $R/loghisto_amd/build/liblhgpu_tuning_$sfx.so | tee -a $OUT/l1trace.txt; done
     # SQ counters of the product's level-1 kernels: what the waves wait for
     SETS=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA"
@@ -192,7 +192,7 @@ level1)
             (cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/kc
              timeout 300 rocprofv3 --pmc ${SETS[$i]} -d /tmp/kc -o t -- python $R/tools/sweep.py --samples 1e9 --pairs $m --reps 2 --dists lognormal > /tmp/kc.out 2>&1
              for k in k_scatter3 k_scatter4; do
-                 python $R/profiles/summarize_rocpd.py pmc /tmp/kc/t_results.db $k | cut -c1-1500 | sed -e "s/^/names=$m set=$i /"
+                 python $R/profiles/summarize_rocpd.py pmc /tmp/kc/t_results.db $k | python -c "import sys, json; j = json.load(sys.stdin); print(json.dumps(dict(names=$m, kernel=j['kernel'], counters={k: round(v['avg']) for k, v in j['counters'].items()}, avg_us=(list(j['counters'].values()) or [dict(avg_duration_us_profiled=0)])[0]['avg_duration_us_profiled'])))"
              done) | grep -v '"counters": {}' | tee -a $OUT/l1_counters.jsonl
         done
     done

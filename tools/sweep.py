@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if "--lib" in sys.argv:  # a -DLH_TUNING build of the library (ablation bits): tools only, never the product
     from loghisto_amd import _native
     _native.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
+    _native.ALLOW_OLDER_ABI = True  # (an A/B against the library of an earlier round)
 import bench  # noqa: E402
 import loghisto_amd  # noqa: E402
 
