@@ -208,6 +208,7 @@ private:
     int note(int rc, const char *where); // returns rc
     void serializeHistograms(RawMetricSet &raw, const std::vector<std::string> &labels, const std::vector<double> &ps,
                              WireFormat wf, std::string &text);
+    const double *decompressTable(); // decompress(key) for every key, by dense bin (lh_codec_tables, read back once)
 
     std::chrono::nanoseconds interval_;
     Options opt_;
@@ -221,6 +222,8 @@ private:
     std::atomic<int> wire_format_{0};
     std::atomic<bool> wire_keep_map_{true};
     std::atomic<size_t> wire_bytes_hint_{0};
+    std::once_flag dtable_once_;
+    std::vector<double> dtable_;
 
     // histogramMu (metrics.go:121): submitters shared, the flip exclusive
     std::shared_mutex histogram_mu_;

@@ -503,27 +503,42 @@ std::shared_ptr<ProcessedMetricSet> MetricSystem::processMetrics(const std::shar
             std::lock_guard<std::mutex> g(percentiles_mu_);
             for (auto &kv : percentiles_) { labels.push_back(kv.first); ps.push_back(kv.second); }
         }
+        // The COMPACT results (lh_extract_rows_compact, round 6): count, sum and the selected keys are all that crosses
+        // PCIe -- 42 B per name instead of 139 -- and the keys of the map are derived here exactly as processHistograms
+        // derives them: _avg = sum / float64(count) (metrics.go:356), a percentile's value = decompress(key)
+        // (metrics.go:326-332, 413-415: the device-generated table, read back once per MetricSystem).
         const size_t n = n_map, np = ps.size();
-        std::vector<lh_stats> st(n);
-        std::vector<double> pv(n * np);
-        std::vector<uint8_t> ok(n * np);
+        std::vector<uint64_t> cnt(n);
+        std::vector<double> sum(n);
+        std::vector<int16_t> keys(n * np);
+        std::vector<uint32_t> bits(n);
         int rc;
         {
             std::lock_guard<std::mutex> g(raw->mu);
-            rc = raw->snapshot ? lh_extract(raw->snapshot, ps.data(), np, st.data(), pv.data(), nullptr, ok.data(), n)
-                               : LH_ESTATE;
+            lh_extract_compact c{};
+            rc = raw->snapshot ? lh_extract_rows_compact(raw->snapshot, 0, n, ps.data(), np, &c) : LH_ESTATE;
+            if (rc == LH_OK || rc == LH_ERANGE) { // the view lives in the engine's pinned block: copy out under the lock
+                std::memcpy(cnt.data(), c.count, n * sizeof(uint64_t));
+                std::memcpy(sum.data(), c.sum, n * sizeof(double));
+                if (np) {
+                    std::memcpy(keys.data(), c.pkeys, n * np * sizeof(int16_t));
+                    std::memcpy(bits.data(), c.pvalid_bits, n * sizeof(uint32_t));
+                }
+            }
         }
-        note(rc, "lh_extract");
+        note(rc, "lh_extract_rows_compact");
         if (rc == LH_OK || rc == LH_ERANGE) {
+            const double *D = decompressTable();
             for (size_t id = 0; id < n; id++) {
-                if (!st[id].present) continue;
+                if (!cnt[id]) continue;
                 const std::string &name = raw->names[id];
-                m[name + "_count"] = (double)st[id].count;
-                m[name + "_sum"] = st[id].sum;
-                m[name + "_avg"] = st[id].avg;
+                m[name + "_count"] = (double)cnt[id];
+                m[name + "_sum"] = sum[id];
+                m[name + "_avg"] = sum[id] / (double)cnt[id];
                 for (size_t i = 0; i < np; i++) {
-                    if (ok[id * np + i]) m[fmt_label(labels[i], name)] = pv[id * np + i];
-                    else std::fprintf(stderr, "loghisto: unable to calculate percentile: Invalid percentile.  "
+                    const bool ok = (bits[id] >> i) & 1u;
+                    if (ok && D) m[fmt_label(labels[i], name)] = D[(uint16_t)keys[id * np + i] ^ 0x8000u];
+                    else if (!ok) std::fprintf(stderr, "loghisto: unable to calculate percentile: Invalid percentile.  "
                                               "Should be between 0 and 1.\n"); // metrics.go:379-384
                 }
             }
@@ -540,6 +555,18 @@ std::shared_ptr<ProcessedMetricSet> MetricSystem::processMetrics(const std::shar
         out->wire += out->wire_format == WireFormat::Graphite ? GraphiteProtocol(rest) : OpenTSDBProtocol(rest);
     }
     return out;
+}
+
+// decompress (metrics.go:326-332) of every int16 key as the DEVICE generated it (lh_codec.h: d_go_exp), indexed by the
+// dense bin key ^ 0x8000: what a compact extract's keys are turned into values with.  nullptr if it cannot be read.
+const double *MetricSystem::decompressTable()
+{
+    std::call_once(dtable_once_, [this] {
+        if (!engine_) return;
+        dtable_.resize(LH_NKEYS);
+        if (note(lh_codec_tables(engine_, nullptr, dtable_.data()), "lh_codec_tables") != LH_OK) dtable_.clear();
+    });
+    return dtable_.empty() ? nullptr : dtable_.data();
 }
 
 void MetricSystem::SetWireFormat(WireFormat f, bool histogram_keys_in_map)

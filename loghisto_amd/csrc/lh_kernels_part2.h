@@ -442,6 +442,11 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter2(const IDT *__restrict__ i
                       "+v"(vaa[3]));
     static_assert(NPAIR == 4, "the asm above names four register pairs");
     load_tile((size_t)blockIdx.x + gridDim.x, idb, vab);
+    // The first two tiles arrive before the loop starts (once per workgroup).  What it buys: the compiler schedules these
+    // sixteen loads in another order than the loop's, and its s_waitcnt pass must cover both orders -- it then waits for a
+    // whole register set (vmcnt(8)) where the set's first load would do (vmcnt(15)), and with the copy-out's stores in the
+    // counter but not in its books (hidden_store_*) that stricter wait reaches into the loads issued a moment ago.
+    __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): the waitcnt pass takes it into account
 
     // One tile.  `di` / `dv` hold the tile's samples; once they have been classified (after barrier A) the same
     // registers receive the loads of the tile two steps ahead.  The loop below alternates between the two register
@@ -900,6 +905,11 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
                       "+v"(vaa[3]));
     static_assert(NPAIR == 4, "the asm above names four register pairs");
     load_tile((size_t)blockIdx.x + gridDim.x, idb, vab);
+    // The first two tiles arrive before the loop starts (once per workgroup).  What it buys: the compiler schedules these
+    // sixteen loads in another order than the loop's, and its s_waitcnt pass must cover both orders -- it then waits for a
+    // whole register set (vmcnt(8)) where the set's first load would do (vmcnt(15)), and with the copy-out's stores in the
+    // counter but not in its books (hidden_store_*) that stricter wait reaches into the loads issued a moment ago.
+    __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): the waitcnt pass takes it into account
 
     auto classify_r5 = [&](typename IS::raw_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
         uint32_t rare = 0;
@@ -1132,19 +1142,32 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
         }
         __syncthreads();                                   // barrier B: counters and regions are ready for the next tile
     };
-    // Each register set receives the tile two steps ahead as soon as its samples are classified.  With
-    // SC3_TILES_PER_FLUSH = 2 both tiles of an iteration are classified back to back (no barrier between them: the
-    // LDS atomics and record stores of the second simply continue the first) and flushed together.
+    // Each register set receives the tile two steps ahead as soon as its samples are classified.
+    //
+    // The loop takes the tiles in PAIRS and both halves of its body are unconditional (a last single tile is peeled off
+    // below).  Round 6 found why: until then the second half sat under `if (tile + gridDim.x < ntiles)`, and the
+    // compiler's s_waitcnt pass must assume the path on which that half did not run -- so it counted 8 loads in flight
+    // where 16 are, and opened every classification with s_waitcnt vmcnt(7): a wait for the FIRST LOAD OF THE OTHER
+    // REGISTER SET, issued one flush earlier, i.e. a whole memory round trip exposed per tile (with the input re-read
+    // from the L2 the kernel was 23 % faster; profiles/r06_level1_ablations.txt).  With an unconditional body the count
+    // is exact (vmcnt(15): the loads of the tile at hand only).
+    static_assert(SC3_TILES_PER_FLUSH == 1, "two tiles per flush were measured (round 2: no gain) and removed");
     uint32_t par = 0; // out-of-window queue of this flush group (the flush resets the other one)
-    for (size_t tile = blockIdx.x; tile < ntiles; tile += 2 * (size_t)gridDim.x) {
+    size_t tile = blockIdx.x;
+    const size_t G = gridDim.x;
+    for (; tile + G < ntiles; tile += 2 * G) {
         classify(ida, vaa, par);
-        load_tile(tile + 2 * (size_t)gridDim.x, ida, vaa);
-        if (SC3_TILES_PER_FLUSH == 1) { flush(par); par ^= 1u; }
-        if (tile + gridDim.x < ntiles) { // workgroup-uniform
-            classify(idb, vab, par);
-            load_tile(tile + 3 * (size_t)gridDim.x, idb, vab);
-        }
-        flush(par); // (with one tile per flush and no second tile: finds nothing new, harmless)
+        load_tile(tile + 2 * G, ida, vaa);
+        flush(par);
+        par ^= 1u;
+        classify(idb, vab, par);
+        load_tile(tile + 3 * G, idb, vab);
+        flush(par);
+        par ^= 1u;
+    }
+    if (tile < ntiles) { // (workgroup-uniform) the workgroup's last tile when it has an odd number of them
+        classify(ida, vaa, par);
+        flush(par);
         par ^= 1u;
     }
 

@@ -469,6 +469,11 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
                       "+v"(vaa[3]));
     static_assert(NPAIR == 4, "the asm above names four register pairs");
     load_tile((size_t)blockIdx.x + gridDim.x, idb, vab);
+    // The first two tiles arrive before the loop starts (once per workgroup).  What it buys: the compiler schedules these
+    // sixteen loads in another order than the loop's, and its s_waitcnt pass must cover both orders -- it then waits for a
+    // whole register set (vmcnt(8)) where the set's first load would do (vmcnt(15)), and with the copy-out's stores in the
+    // counter but not in its books (hidden_store_*) that stricter wait reaches into the loads issued a moment ago.
+    __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): the waitcnt pass takes it into account
 
     auto classify_r5 = [&](typename IS::raw_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
         uint32_t rare = 0;
@@ -686,17 +691,25 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
         }
         __syncthreads();                                   // barrier B: counters and regions are ready for the next tile
     };
+    // Tiles in PAIRS, both halves of the body unconditional, a last single tile peeled off: see k_scatter3 (the
+    // compiler's count of the loads in flight must be exact, or every classification opens with a wait for the OTHER
+    // register set's loads)
     uint32_t par = 0;
-    for (size_t tile = blockIdx.x; tile < ntiles; tile += 2 * (size_t)gridDim.x) {
+    size_t tile = blockIdx.x;
+    const size_t G = gridDim.x;
+    for (; tile + G < ntiles; tile += 2 * G) {
         classify(ida, vaa, par);
-        load_tile(tile + 2 * (size_t)gridDim.x, ida, vaa);
+        load_tile(tile + 2 * G, ida, vaa);
         flush(par);
         par ^= 1u;
-        if (tile + gridDim.x < ntiles) { // workgroup-uniform
-            classify(idb, vab, par);
-            load_tile(tile + 3 * (size_t)gridDim.x, idb, vab);
-        }
-        flush(par); // (without a second tile: finds nothing new, harmless)
+        classify(idb, vab, par);
+        load_tile(tile + 3 * G, idb, vab);
+        flush(par);
+        par ^= 1u;
+    }
+    if (tile < ntiles) { // (workgroup-uniform) the workgroup's last tile when it has an odd number of them
+        classify(ida, vaa, par);
+        flush(par);
         par ^= 1u;
     }
 
