@@ -47,6 +47,23 @@ constexpr uint32_t P2V2_SLOT_EXTRA = 256;              // P2 work slots beyond o
 
 typedef uint16_t rec16_t;
 
+#ifndef LH_SC3_CAP_NUM
+#define LH_SC3_CAP_NUM 6
+#endif
+constexpr uint32_t SC3_CAP_NUM = LH_SC3_CAP_NUM; // region capacity = expected records * CAP_NUM / 4 + 8 + one piece (6: 1.5 x)
+#ifndef LH_SC3_PIECE
+#define LH_SC3_PIECE 1
+#endif
+// The region scatter copies whole PIECES of SC3_PIECE consecutive 64-byte lines out of a partition's region (see
+// V3_PIECE in lh_kernels_part3.h); up to SC3_PIECE * 32 - 1 records stay behind.  Measured at 1 024 names
+// (profiles/r04_level1_experiments.txt): 128-byte pieces are SLOWER here (2.89 -> 3.04 ms per 1e9 pairs) -- with 2-byte
+// records and 45 % of the pairs cold a partition gathers a piece only every fifth tile, and the 16 KiB of LDS come out
+// of the hot windows -- so this path stays at one line; the third generation (4-byte records, 67 % cold) gains 8 %.
+constexpr uint32_t SC3_PIECE = LH_SC3_PIECE, PIECE2 = SC3_PIECE * LINE2;
+// upper bound of the sum of the partitions' capacities; `tile` = samples between two flushes
+constexpr uint32_t region_records(uint32_t tile, uint32_t np) { return SC3_CAP_NUM * tile / 4u + (40u + PIECE2) * np; }
+
+
 // Two shapes of the scatter pass (both exact; lh_set_option(LH_OPT_PART_V2_SHAPE) picks one):
 //   <1024, 256>  one 1 024-thread workgroup per CU, 8 192-sample tiles, up to 256 partitions (4 names each at
 //                1 024 names -> 8 192-bin cold windows); the workgroup owns all of the CU's LDS
@@ -87,6 +104,7 @@ struct NameEntry { uint32_t org; uint32_t hot; };
 // Exactness does not depend on any of it.
 // ---------------------------------------------------------------------------
 constexpr uint32_t HDR_HITS = 8, HDR_TILES = 9, HDR_TICKET = 10, HDR_BASE = 11; // words of the 64-byte survey header
+constexpr uint32_t HDR_REGION = 5, HDR_CELLS = 6; // LDS the plan gave the level-1 regions (records) and the hot windows (cells)
 constexpr uint32_t RSTAT_STALE = 7;                // engine's pinned words: [7] pairs a stale survey kept out of the hot windows
 constexpr uint32_t STALE_VALID = 0x80000000u;      // hdr[HDR_BASE] = STALE_VALID | share in 1/65 536ths
 constexpr uint32_t STALE_DROP = 65536u / 20u;      // 5 % of the launch's pairs
@@ -181,17 +199,37 @@ __device__ __forceinline__ void block_sum2(uint32_t a, uint32_t b, uint32_t *s_a
     for (int w = 0; w < V2_BLOCK / 64; w++) { ta += s_a[w]; tb += s_b[w]; }
 }
 
+// What the plan needs to know of the region scatter (k_scatter3) to lay out ITS share of the LDS as well: round 6.
+// Until then the host reserved the regions' upper bound (1.5 x a tile in which EVERY sample is a record + 72 records per
+// partition: 60 KiB at 256 partitions) and the windows got the rest; the regions a Zipf stream needs are a third smaller,
+// because the names with hot windows leave only their tails as records.  The plan now sizes the regions from the names'
+// counts with the hot names' halved (a hot window keeps 80 - 99 % of its name; half is the allowance for a survey gone
+// stale, which the launches detect: stale_judge), and gives what that frees to the windows: tile = 0 -> no regions
+// (k_scatter2's exact layout), cells as given.
+struct RegionFit {
+    uint32_t tile;        // samples between two flushes (0: the kernel has no regions)
+    uint32_t log_np;
+    uint32_t avail_bytes; // LDS for regions + hot windows together
+    uint32_t cell_bytes;  // 2 (k_scatter3: 16-bit cells) or 4
+    uint32_t cell_gap;    // unused cells between two windows (equal bins of different names on different banks)
+    uint32_t max_cells;
+};
+
 // One workgroup.  Thread t owns names [t * E, (t + 1) * E), E = ceil(M / 1024) <= 8.
-// hdr: [0] hot names, [1] cells used, [2] surveyed samples, [3] surveyed samples of the hot names
+// hdr: [0] hot names, [1] cells used, [2] surveyed samples, [3] surveyed samples of the hot names, [HDR_REGION] records of
+// LDS of the regions, [HDR_CELLS] cells of the window area; g_pt[p] = {first record of partition p's region, capacity}
 __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__restrict__ g_cnt,
                                                           const uint32_t *__restrict__ g_mninv,
                                                           const uint32_t *__restrict__ g_mx,
                                                           const unsigned long long *__restrict__ g_sum,
-                                                          uint32_t nmetrics, uint32_t log_w, uint32_t cells,
+                                                          uint32_t nmetrics, uint32_t log_w, uint32_t cells_in,
+                                                          const RegionFit rf,
                                                           NameEntry *__restrict__ nt, pu4_t *__restrict__ hs,
-                                                          uint32_t *__restrict__ hdr)
+                                                          uint32_t *__restrict__ hdr, pu2_t *__restrict__ g_pt)
 {
     __shared__ uint32_t s_a[V2_BLOCK / 64], s_b[V2_BLOCK / 64];
+    __shared__ uint32_t s_pc[256], s_cap[256];
+    const uint32_t gap = rf.cell_gap;
     constexpr uint32_t EMAX = V2_MAX_NAMES / V2_BLOCK;
     const uint32_t tid = threadIdx.x;
     const uint32_t E = (nmetrics + V2_BLOCK - 1) / V2_BLOCK;
@@ -262,23 +300,56 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__rest
         }
     }
     // the smallest tau >= 16 such that the windows of every name with cnt >= tau fit `cells` and the slot table
-    uint32_t flo = 15, fhi = (1u << 21) + 1; // fhi selects nothing: feasible
-    if (cells < 64) flo = fhi - 1;           // no LDS for hot windows at all
-    while (fhi - flo > 1) {
-        const uint32_t mid = flo + (fhi - flo) / 2;
-        uint32_t sw = 0, sn = 0;
+    auto pick = [&](uint32_t cells) {
+        uint32_t flo = 15, fhi = (1u << 21) + 1; // fhi selects nothing: feasible
+        if (cells < 64) flo = fhi - 1;           // no LDS for hot windows at all
+        while (fhi - flo > 1) {
+            const uint32_t mid = flo + (fhi - flo) / 2;
+            uint32_t sw = 0, sn = 0;
+#pragma unroll
+            for (uint32_t e = 0; e < EMAX; e++)
+                if (want[e] && cnt[e] >= mid) { sw += want[e] + gap; sn++; }
+            uint32_t tw, tn;
+            block_sum2(sw, sn, s_a, s_b, tw, tn);
+            if (tw <= cells && tn <= V2_MAX_SLOTS) fhi = mid; else flo = mid;
+        }
+        return fhi;
+    };
+    uint32_t cells = cells_in, region_recs = 0;
+    uint32_t tau = pick(cells);
+    if (rf.tile) {
+        // the regions for THIS choice of hot names, then the windows once more with what the regions leave (a superset of
+        // the first choice, so the regions stay large enough)
+        const uint32_t np = 1u << rf.log_np;
+        if (tid < 256) s_pc[tid] = 0;
+        __syncthreads();
 #pragma unroll
         for (uint32_t e = 0; e < EMAX; e++)
-            if (want[e] && cnt[e] >= mid) { sw += want[e] + 1u; sn++; }
-        uint32_t tw, tn;
-        block_sum2(sw, sn, s_a, s_b, tw, tn);
-        if (tw <= cells && tn <= V2_MAX_SLOTS) fhi = mid; else flo = mid;
+            if (cnt[e]) atomicAdd(&s_pc[(m0 + e) & (np - 1u)], (want[e] && cnt[e] >= tau) ? (cnt[e] + 1u) / 2u : cnt[e]);
+        __syncthreads();
+        uint32_t cap = 0;
+        if (tid < np) {
+            const uint32_t est = total_cnt ? (uint32_t)(((unsigned long long)s_pc[tid] * rf.tile) / total_cnt) : rf.tile / np;
+            cap = (est * SC3_CAP_NUM / 4u + 8u + PIECE2 + 31u) & ~31u;
+            if (cap > rf.tile + PIECE2) cap = rf.tile + PIECE2; // leftover (< one piece) + a whole tile
+        }
+        if (tid < 256) s_cap[tid] = cap;
+        __syncthreads();
+        uint32_t base = 0;
+        for (uint32_t i = 0; i < np; i++) {
+            if (i == tid && tid < np) g_pt[tid] = (pu2_t){base, cap};
+            base += s_cap[i];
+        }
+        region_recs = base; // (a multiple of 32: every capacity is)
+        const uint32_t left = rf.avail_bytes > region_recs * 2u ? rf.avail_bytes - region_recs * 2u : 0u;
+        cells = (left / rf.cell_bytes) & ~63u;
+        if (cells > rf.max_cells) cells = rf.max_cells; // (at least cells_in: the capacities add up to less than the bound)
+        tau = pick(cells);
     }
-    const uint32_t tau = fhi;
     uint32_t sw = 0, sn = 0, sc = 0;
 #pragma unroll
     for (uint32_t e = 0; e < EMAX; e++)
-        if (want[e] && cnt[e] >= tau) { sw += want[e] + 1u; sn++; sc += cnt[e]; }
+        if (want[e] && cnt[e] >= tau) { sw += want[e] + gap; sn++; sc += cnt[e]; }
     // exclusive scans of (cells, slots) in name order
     uint32_t incw = sw, incn = sn;
     const uint32_t lane = tid & 63, wave = tid >> 6;
@@ -315,7 +386,7 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__rest
                 ne.org |= o << 16;
                 ne.hot = cellpos | (w << 16);
                 hs[slot] = (pu4_t){m, o | (w << 16), cellpos, 0u};
-                cellpos += w + 1u; // one unused cell: windows of equal width do not start in the same LDS bank
+                cellpos += w + gap; // unused cells: windows of equal width do not start in the same LDS bank
                 slot++;
             }
             nt[m] = ne;
@@ -326,6 +397,8 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__rest
         hdr[1] = totw;
         hdr[2] = total_cnt;
         hdr[3] = hot_cnt_total;
+        hdr[HDR_REGION] = region_recs;
+        hdr[HDR_CELLS] = cells;
         hdr[HDR_HITS] = 0;  // k_scatter3's account of what the hot windows take (stale_report below)
         hdr[HDR_TILES] = 0;
         hdr[HDR_TICKET] = 0;
@@ -355,6 +428,17 @@ __device__ __forceinline__ void hidden_store_u4(void *p, pu4_t v)
 __device__ __forceinline__ void hidden_store_u32(void *p, uint32_t v)
 {
     asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
+// counts[m][bin] += c and the row's range, for use INSIDE the tile loops: three atomics that return nothing, issued from
+// inline asm and without v2_global_add's look at the range first (a visible global operation in a rarely taken branch
+// makes the compiler wait for vmcnt(0) at the join, and the pre-check's load stalls the wave for a memory round trip)
+__device__ __forceinline__ void hidden_global_add(uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges, uint32_t m,
+                                                  uint32_t bin, uint32_t c)
+{
+    const unsigned long long c64 = c;
+    asm volatile("global_atomic_add_x2 %0, %1, off" : : "v"(&counts[(size_t)m * LH_ROW_STRIDE + bin]), "v"(c64) : "memory");
+    uint32_t *r = ranges + 2 * (size_t)m;
+    asm volatile("global_atomic_umin %0, %1, off\n\tglobal_atomic_umax %0, %1, off offset:4" : : "v"(r), "v"(bin) : "memory");
 }
 
 template <int BLOCK, int NPT, typename IDT>
@@ -446,7 +530,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter2(const IDT *__restrict__ i
     // sixteen loads in another order than the loop's, and its s_waitcnt pass must cover both orders -- it then waits for a
     // whole register set (vmcnt(8)) where the set's first load would do (vmcnt(15)), and with the copy-out's stores in the
     // counter but not in its books (hidden_store_*) that stricter wait reaches into the loads issued a moment ago.
-    __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): the waitcnt pass takes it into account
+    asm volatile("" : "+v"(idb[0]), "+v"(idb[1]), "+v"(idb[2]), "+v"(idb[3]), "+v"(vab[0]), "+v"(vab[1]), "+v"(vab[2]),
+                      "+v"(vab[3])); // (an empty asm that reads the registers: the compiler waits for their loads here)
 
     // One tile.  `di` / `dv` hold the tile's samples; once they have been classified (after barrier A) the same
     // registers receive the loads of the tile two steps ahead.  The loop below alternates between the two register
@@ -729,23 +814,15 @@ template <int NPT> struct Scatter3LdsT {
     uint32_t missn[2];
     uint32_t dummy[64];
     uint32_t pool_next, ovn; // ovn: records that found their region full (reported to the engine)
+    uint32_t spills, pad0[3]; // spills: hot cells that handed 2^15 counts on to the row (16-bit cells, see k_scatter3)
 };
 
-#ifndef LH_SC3_TRIM
-#define LH_SC3_TRIM 1
-#endif
-// LH_SC3_TRIM: the classification with fewer instructions per sample (round 6; 0 = round 5's form, kept for A/B builds).
-// What the SQ counters said of round 5's k_scatter3 (profiles/r04_mixed_counters.jsonl): 50.8 VALU + 24.4 SALU + 5.2 LDS
-// instructions per wave-sample and no unit busy more than half of the time -- the kernel is bound by what ONE wave
-// issues between its waits, so every instruction that leaves the straight-line path counts, VALU or not:
-//   * an id >= nmetrics is CLAMPED to the table's extra entry nt[nmetrics] (no window of either kind) instead of being
-//     tested and replaced per sample; one max3 + compare per batch finds the waves that hold one at all;
-//   * the per-sample conditions (hot / cold / fits) stay lane masks in SGPRs; the bit masks `miss`, `coldm`, `full`
-//     that were assembled in VGPRs with a v_cndmask + v_or per sample and condition are gone, the rare path tests
-//     the conditions themselves;
-//   * the LDS atomic and the record store are exec-masked instead of being pointed at dummy words;
-//   * the partition table holds the region's BYTE offset: the record's address is one v_lshl_add.
-constexpr bool SC3_TRIM = LH_SC3_TRIM != 0;
+// The classification's instruction count (round 6: 50.8 -> 45 VALU, 24 -> 19 SALU per wave-sample against round 5): ids >=
+// nmetrics are CLAMPED to the table's extra entry nt[nmetrics] instead of tested per sample (one max3 + compare per batch
+// finds the waves that hold one); the per-sample conditions stay lane masks in SGPRs; the LDS atomic and the record store
+// are exec-masked instead of pointed at dummy words; the partition table holds the region's LDS ADDRESS.  Measured: the
+// kernel's time does not move with its instruction count either way (+19 VALU per sample: +-0) -- see "what bounds the
+// kernel" at k_scatter3.
 // Ablation builds of the level-1 kernels (tools/build_tuning.py -DLH_ABL=bits; timing only, the counts are WRONG by
 // construction; the product is built with 0): 1 = the copy-out body removed (both barriers stay, the counters are
 // reset), 2 = no barriers and no copy-out at all (records wrap inside the first 16 slots of their region), 4 = the
@@ -768,57 +845,6 @@ constexpr uint32_t SC3_FLUSH_TPP = LH_SC3_FLUSH_TPP; // flush-phase threads per 
 #define LH_SC3_TILES_PER_FLUSH 1
 #endif
 constexpr uint32_t SC3_TILES_PER_FLUSH = LH_SC3_TILES_PER_FLUSH; // tiles classified between two flushes (1 or 2)
-#ifndef LH_SC3_CAP_NUM
-#define LH_SC3_CAP_NUM 6
-#endif
-constexpr uint32_t SC3_CAP_NUM = LH_SC3_CAP_NUM; // region capacity = expected records * CAP_NUM / 4 + 8 + one piece (6: 1.5 x)
-#ifndef LH_SC3_PIECE
-#define LH_SC3_PIECE 1
-#endif
-// The region scatter copies whole PIECES of SC3_PIECE consecutive 64-byte lines out of a partition's region (see
-// V3_PIECE in lh_kernels_part3.h); up to SC3_PIECE * 32 - 1 records stay behind.  Measured at 1 024 names
-// (profiles/r04_level1_experiments.txt): 128-byte pieces are SLOWER here (2.89 -> 3.04 ms per 1e9 pairs) -- with 2-byte
-// records and 45 % of the pairs cold a partition gathers a piece only every fifth tile, and the 16 KiB of LDS come out
-// of the hot windows -- so this path stays at one line; the third generation (4-byte records, 67 % cold) gains 8 %.
-constexpr uint32_t SC3_PIECE = LH_SC3_PIECE, PIECE2 = SC3_PIECE * LINE2;
-// upper bound of the sum of the partitions' capacities; `tile` = samples between two flushes
-constexpr uint32_t region_records(uint32_t tile, uint32_t np) { return SC3_CAP_NUM * tile / 4u + (40u + PIECE2) * np; }
-
-// Region sizes from the survey: g_pt[p] = {first record of the region (relative to the region area), capacity}.
-// One workgroup of 256 threads, after k_survey_plan.
-__global__ __launch_bounds__(256) void k_survey_parts(const uint32_t *__restrict__ g_cnt, uint32_t nmetrics,
-                                                      uint32_t log_np, uint32_t tile, pu2_t *__restrict__ g_pt)
-{
-    __shared__ uint32_t s_pc[256], s_cap[256];
-    __shared__ uint32_t s_total;
-    const uint32_t tid = threadIdx.x, np = 1u << log_np;
-    s_pc[tid] = 0;
-    if (tid == 0) s_total = 0;
-    __syncthreads();
-    uint32_t mine = 0;
-    for (uint32_t m = tid; m < nmetrics; m += 256) { // m & (np - 1) == tid & (np - 1): np divides 256
-        const uint32_t c = g_cnt[m];
-        mine += c;
-    }
-    atomicAdd(&s_pc[tid & (np - 1)], mine);
-    atomicAdd(&s_total, mine);
-    __syncthreads();
-    const uint32_t total = s_total;
-    uint32_t cap = 0;
-    if (tid < np) {
-        const uint32_t est = total ? (uint32_t)(((unsigned long long)s_pc[tid] * tile) / total) : tile / np;
-        cap = (est * SC3_CAP_NUM / 4u + 8u + PIECE2 + 31u) & ~31u;
-        if (cap > tile + PIECE2) cap = tile + PIECE2; // leftover (< one piece) + a whole tile
-    }
-    s_cap[tid] = cap;
-    __syncthreads();
-    if (tid < np) {
-        uint32_t base = 0;
-        for (uint32_t i = 0; i < tid; i++) base += s_cap[i];
-        g_pt[tid] = (pu2_t){base, cap};
-    }
-}
-
 // entries of k_scatter3's name table in LDS: one per name, the entry of ids >= nmetrics, padded to 16 bytes
 constexpr uint32_t sc3_nt_entries(uint32_t nmetrics) { return (nmetrics + 2u) & ~1u; }
 
@@ -830,8 +856,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
                                                        const NameEntry *__restrict__ g_nt,
                                                        const pu4_t *__restrict__ g_hs,
                                                        uint32_t *__restrict__ g_hdr,
-                                                       const pu2_t *__restrict__ g_pt, uint32_t region_recs,
-                                                       uint32_t cells, rec16_t *__restrict__ records,
+                                                       const pu2_t *__restrict__ g_pt, rec16_t *__restrict__ records,
                                                        uint32_t *__restrict__ cdesc, uint32_t chunks_per_wg,
                                                        uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
                                                        uint32_t *__restrict__ err,
@@ -847,39 +872,43 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
     NameEntry *nt = reinterpret_cast<NameEntry *>(v2_smem + sizeof(LdsT));         // [nmetrics]
     uint32_t *lds32 = reinterpret_cast<uint32_t *>(v2_smem);
     rec16_t *lds16 = reinterpret_cast<rec16_t *>(v2_smem);
+    // the plan's split of the LDS behind the name table (k_survey_plan: RegionFit): regions, then the hot windows
+    const uint32_t region_recs = g_hdr[HDR_REGION], cells = g_hdr[HDR_CELLS];
     const uint32_t reg_h = (uint32_t)(sizeof(LdsT) / 2) + 4 * sc3_nt_entries(nmetrics); // halfword offset of the regions (16-byte aligned)
-    const uint32_t win_w = (reg_h + region_recs) / 2;                              // word offset of the hot windows
-    uint32_t *win = lds32 + win_w;                                                 // [cells]
-    constexpr uint32_t CNT_W = offsetof(LdsT, cnt) / 4, DUMMY_W = offsetof(LdsT, dummy) / 4;
+    // HOT WINDOWS OF 16-BIT CELLS (round 6), two to an LDS word: twice the cells in the same bytes -- under Zipf(1) over
+    // 1 024 names 43 % -> 32 % of the pairs become records, and records are what the kernel pays for (see "what bounds the
+    // kernel").  A sample adds 1 << 16 * (cell & 1) to the word; the atomic returns the word as it was, and the lane that
+    // sees its own field at 2^15 - 1 (its add made it 2^15) takes 2^15 off the field and adds them to the row in HBM:
+    // between that add and the subtraction at most one tile's other samples (8 191) can land on the field, so no field
+    // ever carries into its neighbour, and every count is in exactly one place.  Exact for any stream; a spill is one in
+    // 32 768 hits of ONE cell (a constant stream: 120 spills per workgroup and launch).
+    const uint32_t win_h = reg_h + region_recs;                                    // halfword offset of the hot windows (even)
+    uint32_t *win = lds32 + win_h / 2;                                             // [cells / 2] words
+    constexpr uint32_t CNT_W = offsetof(LdsT, cnt) / 4;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t np = 1u << log_np, pmask = np - 1, W = 1u << log_w;
     const uint32_t pool_base = blockIdx.x * chunks_per_wg;
     // the LDS address of the block (0 here; not a constant the compiler can fold)
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)v2_smem;
 
-    for (uint32_t i = tid; i < nmetrics; i += BLOCK) {
-        NameEntry ne = g_nt[i];
-        ne.hot += win_w; // hot base as a word offset from the LDS base (< 40 960: fits the low half)
-        nt[i] = ne;
-    }
-    // the entry of an id >= nmetrics (SC3_TRIM clamps such an id to it): no hot window, cold origin 65 535 -- with the
+    for (uint32_t i = tid; i < nmetrics; i += BLOCK) nt[i] = g_nt[i]; // (hot base: a CELL index inside the window area)
+    // the entry of an id >= nmetrics (such an id is clamped to it): no hot window, cold origin 65 535 -- with the
     // bin such a sample is given (0) it is neither hot nor cold and takes the rare path, which drops and reports it
     if (tid == 0) nt[nmetrics] = (NameEntry){0xffffu, 0u};
-    for (uint32_t i = tid; i < cells; i += BLOCK) win[i] = 0;
+    for (uint32_t i = tid; i < cells / 2; i += BLOCK) win[i] = 0;
     if (tid < NPT) {
         pu2_t e = tid < np ? g_pt[tid] : (pu2_t){0u, 0u};
-        e.x += reg_h;
-        if (SC3_TRIM) e.x = 2u * e.x + lds_base; // LDS address
+        e.x = 2u * (e.x + reg_h) + lds_base; // the region's LDS address: a record's address is one shift-add
         L.pt[tid] = e;
         L.cnt[tid] = 0;
         L.cfill[tid] = CHUNK;
         L.cbase[tid] = INVALID;
     }
     ov_init(L.ov_key, L.ov_cnt, tid, BLOCK);
-    if (tid == 0) { L.pool_next = 0; L.ovn = 0; L.missn[0] = 0; L.missn[1] = 0; }
+    if (tid == 0) { L.pool_next = 0; L.ovn = 0; L.spills = 0; L.missn[0] = 0; L.missn[1] = 0; }
     __syncthreads();
     pu2_t my_pt = L.pt[tid >> 2]; // the flush phase's partition (constant over the launch)
-    if (SC3_TRIM) my_pt.x = (my_pt.x - lds_base) >> 1;  // (halfword index)
+    my_pt.x = (my_pt.x - lds_base) >> 1;  // (halfword index)
 
     const pd2_t *vp = reinterpret_cast<const pd2_t *>(v);
     typedef IdStream<IDT> IS;
@@ -909,86 +938,19 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
     // sixteen loads in another order than the loop's, and its s_waitcnt pass must cover both orders -- it then waits for a
     // whole register set (vmcnt(8)) where the set's first load would do (vmcnt(15)), and with the copy-out's stores in the
     // counter but not in its books (hidden_store_*) that stricter wait reaches into the loads issued a moment ago.
-    __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): the waitcnt pass takes it into account
+    asm volatile("" : "+v"(idb[0]), "+v"(idb[1]), "+v"(idb[2]), "+v"(idb[3]), "+v"(vab[0]), "+v"(vab[1]), "+v"(vab[2]),
+                      "+v"(vab[3])); // (an empty asm that reads the registers: the compiler waits for their loads here)
 
-    auto classify_r5 = [&](typename IS::raw_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
-        uint32_t rare = 0;
-        // ---- phase 1: classify and place.  Straight-line code, four samples at a time: their table reads, then
-        // their LDS atomics, then their record stores are in flight together.
-#pragma unroll
-        for (int h = 0; h < V2_SPT; h += BATCH) {
-            uint32_t id[BATCH], bin[BATCH], where[BATCH], rank[BATCH], rec[BATCH];
-            NameEntry ne[BATCH];
-            pu2_t pe[BATCH];
-            uint32_t unc = 0, miss = 0, coldm = 0, full = 0;
-#pragma unroll
-            for (int k = 0; k < BATCH; k++) {
-                const int j = h + k;
-                const uint32_t raw = (j & 1) ? IS::second(idv[j >> 1]) : IS::first(idv[j >> 1]);
-                const bool ok = raw < nmetrics; // an id >= nmetrics is reported, the sample skipped
-                rare |= ok ? 0u : 1u;
-                id[k] = ok ? raw : INVALID;
-                ne[k] = nt[ok ? raw : 0u];
-                pe[k] = L.pt[raw & pmask];
-            }
-#pragma unroll
-            for (int k = 0; k < BATCH; k++) {
-                const int j = h + k;
-                const double x = (j & 1) ? val[j >> 1].y : val[j >> 1].x;
-                bool u;
-                bin[k] = lh_bin_fast(x, u);
-                if (u) unc |= 1u << k;
-            }
-            if (unc) { // inside the guard band of a bucket threshold (1 sample in ~4 000): exact table compare
-#pragma unroll
-                for (int k = 0; k < BATCH; k++) {
-                    const int j = h + k;
-                    if (unc & (1u << k)) bin[k] = lh_bin_of((j & 1) ? val[j >> 1].y : val[j >> 1].x, Tx);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < BATCH; k++) {
-                const uint32_t hrel = bin[k] - (ne[k].org >> 16), crel = bin[k] - (ne[k].org & 0xffffu);
-                const bool valid = id[k] != INVALID;
-                const bool hot = valid && hrel < (ne[k].hot >> 16);
-                const bool cold = valid && !hot && crel < W;
-                where[k] = hot ? (ne[k].hot & 0xffffu) + hrel : cold ? CNT_W + (id[k] & pmask) : DUMMY_W + lane;
-                rec[k] = ((id[k] >> log_np) << log_w) | crel;
-                if (cold) coldm |= 1u << k;
-                if (valid && !hot && !cold) miss |= 1u << k;
-            }
-#pragma unroll
-            for (int k = 0; k < BATCH; k++) {
-                rank[k] = atomicAdd(lds32 + where[k], 1u);
-            }
-#pragma unroll
-            for (int k = 0; k < BATCH; k++) {
-                const bool fits = (coldm & (1u << k)) && rank[k] < pe[k].y;
-                if ((coldm & (1u << k)) && !fits) full |= 1u << k; // the region is full: counted exactly below
-                lds16[fits ? pe[k].x + rank[k] : 2 * DUMMY_W + lane] = (rec16_t)rec[k];
-            }
-            if (full) { atomicAdd(&L.ovn, (uint32_t)__popc(full)); miss |= full; }
-            if (miss) { // outside the name's cold window, or no room: queued, counted exactly by the flush phase
-#pragma unroll
-                for (int k = 0; k < BATCH; k++)
-                    if (miss & (1u << k)) {
-                        const uint32_t key = (id[k] << 16) | bin[k];
-                        const uint32_t at = atomicAdd(&L.missn[par], 1u);
-                        if (at < V2_MISSQ) L.missq[par][at] = key;
-                        else if (!ov_add(L.ov_key, L.ov_cnt, key, 1u)) v2_global_add(counts, ranges, id[k], bin[k], 1);
-                    }
-            }
-        }
-        if (rare) atomicOr(err, 1u); // an id >= nmetrics: reported by lh_sync / lh_extract
-    };
-    // SC3_TRIM (see the switch's comment): the same classification with fewer instructions per sample.
-    auto classify_trim = [&](typename IS::raw_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
+    // ---- phase 1: classify and place.  Straight-line code, BATCH samples at a time: their table reads, then their LDS
+    // atomics, then their record stores are in flight together.
+    auto classify = [&](typename IS::raw_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
 #pragma unroll
         for (int h = 0; h < V2_SPT; h += BATCH) {
             uint32_t raw[BATCH], bin[BATCH], rank[BATCH], crel[BATCH];
             NameEntry ne[BATCH];
             pu2_t pe[BATCH];
             bool unc[BATCH], hot[BATCH], cold[BATCH], bad[BATCH];
+            uint32_t waddr[BATCH], sh[BATCH];
             uint32_t idmax = 0;
 #pragma unroll
             for (int k = 0; k < BATCH; k++) {
@@ -1029,22 +991,38 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
                 crel[k] = bin[k] - (ne[k].org & 0xffffu);
                 hot[k] = hrel < (ne[k].hot >> 16);
                 cold[k] = !hot[k] && crel[k] < W;
-                uint32_t a = (ne[k].hot & 0xffffu) + hrel, b = raw[k] & pmask; // LDS words: the hot cell, the partition's counter (cnt[] is at word 0)
+                // the hot cell (a halfword of the window area: word cell / 2, field cell & 1) or the partition's counter
+                // (a word: cnt[] opens the LDS block)
+                const uint32_t cell = (ne[k].hot & 0xffffu) + hrel + win_h;
                 static_assert(CNT_W == 0, "the partition counters open the LDS block");
+                waddr[k] = hot[k] ? cell >> 1 : raw[k] & pmask;
+                sh[k] = hot[k] ? (cell & 1u) << 4 : 0u;
                 asm volatile("" : "=v"(rank[k])); // (no value for the lanes that skip the atomic: `fits` below needs none)
-                if (ABL & 8u) { rank[k] = lane & 15u; asm volatile("" : "+v"(a), "+v"(b)); }
-                else if (hot[k] || cold[k]) rank[k] = atomicAdd(lds32 + (hot[k] ? a : b), 1u);
+                if (ABL & 8u) { rank[k] = lane & 15u; asm volatile("" : "+v"(waddr[k]), "+v"(sh[k])); }
+                else if (hot[k] || cold[k]) rank[k] = atomicAdd(lds32 + waddr[k], 1u << sh[k]);
                 if (ABL & 2u) rank[k] &= 15u;
             }
-            bool anybad = false;
+            bool anybad = false, anyspill = false;
+            bool spill[BATCH];
 #pragma unroll
             for (int k = 0; k < BATCH; k++) {
                 const bool fits = cold[k] && rank[k] < pe[k].y;
                 bad[k] = !hot[k] && !fits; // outside the name's cold window, or the region is full, or no such name
                 anybad |= bad[k];
+                spill[k] = hot[k] && ((rank[k] >> sh[k]) & 0xffffu) == 0x7fffu; // this add made the cell 2^15
+                anyspill |= spill[k];
                 if (fits) // pe.x is the region's LDS ADDRESS: one shift-add per record
                     *(__attribute__((address_space(3))) rec16_t *)(uintptr_t)(pe[k].x + 2u * rank[k]) =
                         (rec16_t)(((raw[k] >> log_np) << log_w) | crel[k]);
+            }
+            if (anyspill && !(ABL & 8u)) { // 2^15 counts of the cell move to the row in HBM
+#pragma unroll
+                for (int k = 0; k < BATCH; k++)
+                    if (spill[k]) {
+                        atomicSub(lds32 + waddr[k], 0x8000u << sh[k]);
+                        hidden_global_add(counts, ranges, raw[k], bin[k], 0x8000u);
+                        atomicAdd(&L.spills, 1u);
+                    }
             }
             if (anybad) { // queued, counted exactly by the flush phase
 #pragma unroll
@@ -1059,9 +1037,6 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
                     }
             }
         }
-    };
-    auto classify = [&](typename IS::raw_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
-        if constexpr (SC3_TRIM) classify_trim(idv, val, par); else classify_r5(idv, val, par);
     };
     auto flush = [&](const uint32_t par) {
         if (ABL & 2u) return;
@@ -1083,7 +1058,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
             asm volatile("" : "+v"(t2)); // keeps this phase's address arithmetic inside the loop (see k_scatter2)
             const uint32_t p = t2 / TPP, q = t2 % TPP;
             pu2_t e = my_pt;
-            if (TPP != 4) { e = L.pt[p]; if (SC3_TRIM) e.x = (e.x - lds_base) >> 1; }
+            if (TPP != 4) { e = L.pt[p]; e.x = (e.x - lds_base) >> 1; }
             // whole pieces only: `full` lines leave (a multiple of SC3_PIECE), fewer than PIECE2 records stay behind
             const uint32_t c = min(L.cnt[p], e.y), full = c / PIECE2 * SC3_PIECE, left = c - full * LINE2;
             if (full) {
@@ -1192,7 +1167,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
         for (uint32_t j = 0; j < SC3_PIECE; j++)
             if (left && j * LINE2 + q * 8 < left)
                 *reinterpret_cast<pu4_t *>(records + d + j * LINE2 + q * 8) =
-                    *reinterpret_cast<const pu4_t *>(lds16 + (SC3_TRIM ? (L.pt[p].x - lds_base) >> 1 : L.pt[p].x) + j * LINE2 + q * 8);
+                    *reinterpret_cast<const pu4_t *>(lds16 + ((L.pt[p].x - lds_base) >> 1) + j * LINE2 + q * 8);
     }
     if (tid == 0) L.dummy[0] = 0; // (no sample targets the dummy words any more) the workgroup's hot-window hits
     __syncthreads();
@@ -1204,13 +1179,13 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
 
     // ---- flush the hot windows (one uint64 atomic per occupied bin) and the out-of-window table
     const uint32_t nhot = g_hdr[0];
-    uint32_t hits = 0; // (a workgroup sees fewer than 2^31 samples)
+    uint32_t hits = tid == 0 ? L.spills << 15 : 0u; // (a workgroup sees fewer than 2^31 samples)
     for (uint32_t s = wave; s < nhot; s += BLOCK / 64) {
         const pu4_t h = g_hs[s];
         const uint32_t name = h.x, org = h.y & 0xffffu, width = h.y >> 16, base = h.z;
         uint32_t mn = INVALID, mx = 0;
         for (uint32_t i = lane; i < width; i += 64) {
-            const uint32_t c = win[base + i];
+            const uint32_t c = lds16[win_h + base + i];
             if (c) {
                 const uint32_t b = org + i;
                 atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)name * LH_ROW_STRIDE + b]),
@@ -1403,7 +1378,8 @@ struct Part2Plan {
     uint32_t shape;            // bit 0: 0 = <1024, 256>, 1 = <512, 128>; bit 1: direct record stores (k_scatter3)
     uint32_t block, tile, lds_fixed;
     uint32_t log_np, np, mpp, log_w, cells, g1, chunks_per_wg, nchunks;
-    uint32_t region_recs;      // shapes 2, 3: records of LDS the partitions' regions take
+    uint32_t region_recs;      // shapes 2, 3: upper bound of the records of LDS the partitions' regions take
+    RegionFit fit;             // shapes 2, 3: what k_survey_plan needs to split the LDS between regions and hot windows
     size_t lds_dyn;            // dynamic LDS of the scatter kernel
     size_t off_rec, off_cd, off_sorted, off_small, off_stat, off_nt, off_hs, off_hdr, off_pt, total;
 };
@@ -1435,10 +1411,20 @@ static bool make_plan2(size_t n, uint32_t nmetrics, int num_cus, const PartTunin
     P.region_recs = direct ? region_records(P.tile * SC3_TILES_PER_FLUSH, P.np) : 0u;
     const size_t nt_bytes = (size_t)(direct ? sc3_nt_entries(nmetrics) : nmetrics) * sizeof(NameEntry);
     const size_t fixed = P.lds_fixed + nt_bytes + (size_t)P.region_recs * sizeof(rec16_t) + 256;
-    P.cells = fixed + 4096 <= budget ? (uint32_t)((budget - fixed) / 4) & ~63u : 0u;
-    if (P.cells > 40000u) P.cells = 40000u & ~63u; // LDS word offsets of the windows must stay below 65 536
+    // k_scatter3 (direct): 16-bit cells, and the plan sizes the regions itself (RegionFit) -- P.cells is what the windows
+    // get if the regions need their upper bound; k_scatter2: 32-bit cells
+    const uint32_t cell_bytes = direct ? 2u : 4u, max_cells = direct ? 65472u : 40000u & ~63u; // (cell offsets are 16-bit fields)
+    P.cells = fixed + 4096 <= budget ? (uint32_t)((budget - fixed) / cell_bytes) & ~63u : 0u;
+    if (P.cells > max_cells) P.cells = max_cells;
     if (!tune.hot) P.cells = 0;
-    P.lds_dyn = fixed - 256 + (size_t)P.cells * 4;
+    P.fit = RegionFit{0u, P.log_np, 0u, cell_bytes, direct ? 2u : 1u, tune.hot ? max_cells : 0u};
+    if (direct) {
+        P.fit.tile = P.tile * SC3_TILES_PER_FLUSH;
+        P.fit.avail_bytes = (uint32_t)(budget - (fixed - (size_t)P.region_recs * sizeof(rec16_t)));
+        P.lds_dyn = budget - 256; // regions + windows share what the fixed parts leave: the plan decides how
+    } else {
+        P.lds_dyn = fixed - 256 + (size_t)P.cells * 4;
+    }
     const size_t ntiles = (n + P.tile - 1) / P.tile;
     size_t g1 = (size_t)num_cus * wgs_per_cu; // the workgroups of a CU own its LDS between them
     if (g1 > (ntiles + 3) / 4) g1 = (ntiles + 3) / 4;
@@ -1534,20 +1520,17 @@ static hipError_t launch_part2_t(const IDT *d_ids, const double *d_v, size_t n, 
         hipLaunchKernelGGL(k_survey_count<IDT>, dim3(sv_grid), dim3(V2_BLOCK), sv_dyn, s, d_ids, d_v, survey_n, nmetrics,
                            d_Tx, g_cnt, g_mninv, g_mx, g_sum);
         hipLaunchKernelGGL(k_survey_plan, dim3(1), dim3(V2_BLOCK), 0, s, g_cnt, g_mninv, g_mx, g_sum, nmetrics,
-                           P.log_w, P.cells, g_nt, g_hs, g_hdr);
-        if (P.shape & 2u)
-            hipLaunchKernelGGL(k_survey_parts, dim3(1), dim3(256), 0, s, g_cnt, nmetrics, P.log_np,
-                               P.tile * SC3_TILES_PER_FLUSH, g_pt);
+                           P.log_w, P.cells, P.fit, g_nt, g_hs, g_hdr, g_pt);
     }
     if (P.shape & 2u) { // whole tiles through the region kernel, the last n % tile pairs through the plain kernel
         const size_t nt_full = n / P.tile, done = nt_full * P.tile;
         if (P.shape == 3)
             hipLaunchKernelGGL((k_scatter3<512, 128, SC3_BATCH, IDT>), dim3(P.g1), dim3(512), p1_dyn, s, d_ids, d_v, nt_full, nmetrics,
-                               P.log_np, P.log_w, d_Tx, g_nt, g_hs, g_hdr, g_pt, P.region_recs, P.cells, records,
+                               P.log_np, P.log_w, d_Tx, g_nt, g_hs, g_hdr, g_pt, records,
                                L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, region_stat);
         else
             hipLaunchKernelGGL((k_scatter3<1024, 256, SC3_BATCH, IDT>), dim3(P.g1), dim3(1024), p1_dyn, s, d_ids, d_v, nt_full,
-                               nmetrics, P.log_np, P.log_w, d_Tx, g_nt, g_hs, g_hdr, g_pt, P.region_recs, P.cells,
+                               nmetrics, P.log_np, P.log_w, d_Tx, g_nt, g_hs, g_hdr, g_pt,
                                records, L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, region_stat);
         if (done < n) {
             e = launch_ingest_pairs(d_ids + done, d_v + done, n - done, counts, ranges, nmetrics, d_Tx, d_err, num_cus, s);

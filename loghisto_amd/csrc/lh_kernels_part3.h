@@ -174,14 +174,18 @@ __global__ __launch_bounds__(1024) void k_survey_pick(const SurveyStat S, uint32
 //   g_pt[p]   level-1 region of partition p {first record relative to the region area, capacity}
 //   hdr       [0] hot names [1] cells used [2] surveyed samples [3] surveyed samples of hot names [4] log2 of the
 //             window width that covers 95 % of the sampled mass (10 .. 13), also stored to *span_out (pinned)
+//             [HDR_REGION] words of LDS of the level-1 regions, [HDR_CELLS] 16-bit cells of the window area (the plan
+//             splits `avail_bytes` of LDS between the two: RegionFit in lh_kernels_part2.h)
 __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan_h(const SurveyStat S,
-                                                            const uint32_t *__restrict__ g_aux, uint32_t cells,
-                                                            uint32_t tile, pu2_t *__restrict__ g_hk,
+                                                            const uint32_t *__restrict__ g_aux, uint32_t cells_in,
+                                                            uint32_t tile, uint32_t avail_bytes, uint32_t max_cells,
+                                                            pu2_t *__restrict__ g_hk,
                                                             pu4_t *__restrict__ g_hs, pu2_t *__restrict__ g_pt,
                                                             uint32_t *__restrict__ hdr, uint32_t *span_out)
 {
     __shared__ uint32_t s_a[V2_BLOCK / 64], s_b[V2_BLOCK / 64];
-    __shared__ uint32_t s_cap[V3_NP];
+    __shared__ uint32_t s_cap[V3_NP], s_pcw[V3_NP];
+    constexpr uint32_t GAP = 2; // unused 16-bit cells between two windows: equal bins of different names on different banks
     static_assert(V3_HN == V2_BLOCK, "one thread per hash slot");
     const uint32_t tid = threadIdx.x;
     const uint32_t claim = g_aux[AUX_CLAIM + tid];
@@ -210,18 +214,46 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan_h(const SurveyStat S,
         const uint32_t cap = cnt >= big ? 512u : 256u;
         if (want > cap && !whole) want = cap;
     }
-    uint32_t flo = 15, fhi = (1u << 21) + 1;
-    if (cells < 64) flo = fhi - 1;
-    while (fhi - flo > 1) {
-        const uint32_t mid = flo + (fhi - flo) / 2;
-        const bool in = want && cnt >= mid;
-        uint32_t tw, tn;
-        block_sum2(in ? want + 1u : 0u, in ? 1u : 0u, s_a, s_b, tw, tn);
-        if (tw <= cells && tn <= V2_MAX_SLOTS) fhi = mid; else flo = mid;
+    auto pick = [&](uint32_t cells) {
+        uint32_t flo = 15, fhi = (1u << 21) + 1;
+        if (cells < 64) flo = fhi - 1;
+        while (fhi - flo > 1) {
+            const uint32_t mid = flo + (fhi - flo) / 2;
+            const bool in = want && cnt >= mid;
+            uint32_t tw, tn;
+            block_sum2(in ? want + GAP : 0u, in ? 1u : 0u, s_a, s_b, tw, tn);
+            if (tw <= cells && tn <= V2_MAX_SLOTS) fhi = mid; else flo = mid;
+        }
+        return fhi;
+    };
+    uint32_t tau = pick(cells_in);
+    // level-1 regions: 1.5 x the partition's expected records per tile + 8 + one piece (the leftover), from the names'
+    // counts with the hot names' HALVED (a hot window keeps 80 - 99 % of its name; half is the allowance for a survey
+    // gone stale, which the launches detect and end: k_v3_report / stale_judge) -- round 6; until then every name
+    // counted in full and the regions took their upper bound of the LDS.  What that frees goes to the windows: they are
+    // chosen once more with the larger budget (a superset of the first choice, so the regions stay large enough).
+    if (tid < V3_NP) s_pcw[tid] = pc;
+    __syncthreads();
+    if (want && cnt >= tau) atomicSub(&s_pcw[name & (V3_NP - 1u)], cnt / 2u);
+    __syncthreads();
+    uint32_t cap = 0;
+    if (tid < V3_NP) {
+        const uint32_t est = total_cnt ? (uint32_t)(((unsigned long long)s_pcw[tid] * tile) / total_cnt) : tile / V3_NP;
+        cap = (est * 6u / 4u + 8u + PIECE4 + 3u) & ~3u; // (the leftover is < PIECE4)
+        if (cap > tile + PIECE4) cap = tile + PIECE4;
+        s_cap[tid] = cap;
     }
-    const uint32_t tau = fhi;
+    __syncthreads();
+    uint32_t region_words = 0;
+    for (uint32_t i = 0; i < V3_NP; i++) {
+        if (i == tid) g_pt[tid] = (pu2_t){region_words, cap};
+        region_words += s_cap[i];
+    }
+    uint32_t cells = avail_bytes > region_words * 4u ? ((avail_bytes - region_words * 4u) / 2u) & ~63u : 0u;
+    if (cells > max_cells) cells = max_cells;
+    tau = pick(cells);
     const bool hot = want && cnt >= tau;
-    const uint32_t sw = hot ? want + 1u : 0u, sn = hot ? 1u : 0u;
+    const uint32_t sw = hot ? want + GAP : 0u, sn = hot ? 1u : 0u;
     uint32_t incw = sw, incn = sn;
     const uint32_t lane = tid & 63, wave = tid >> 6;
 #pragma unroll
@@ -251,22 +283,9 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan_h(const SurveyStat S,
         g_hs[slot] = (pu4_t){name, o | (want << 16), cellpos, 0u};
     }
     g_hk[tid] = e;
-    // level-1 regions: 1.5 x the partition's expected records per tile + 8 + one piece (the leftover), the
-    // names' TOTAL counts (hot samples included: a mispredicted hot window must not overflow a region)
-    uint32_t cap = 0;
-    if (tid < V3_NP) {
-        const uint32_t est = total_cnt ? (uint32_t)(((unsigned long long)pc * tile) / total_cnt) : tile / V3_NP;
-        cap = (est * 6u / 4u + 8u + PIECE4 + 3u) & ~3u; // (the leftover is < PIECE4)
-        if (cap > tile + PIECE4) cap = tile + PIECE4;
-        s_cap[tid] = cap;
-    }
-    __syncthreads();
-    if (tid < V3_NP) {
-        uint32_t base = 0;
-        for (uint32_t i = 0; i < tid; i++) base += s_cap[i];
-        g_pt[tid] = (pu2_t){base, cap};
-    }
     if (tid == 0) {
+        hdr[HDR_REGION] = region_words;
+        hdr[HDR_CELLS] = cells;
         hdr[0] = totn;
         hdr[1] = totw;
         hdr[2] = total_cnt;
@@ -384,25 +403,19 @@ struct Scatter4Lds {
     uint32_t missq[2][V3_MISSQ];
     uint32_t missn[2];
     uint32_t dummy[64];
-    uint32_t pool_next, ovn, nrec, pad[3];
+    uint32_t pool_next, ovn, nrec, spills, pad[2]; // spills: hot cells that handed 2^15 counts on to the row (k_scatter3)
     pu2_t hk[V3_HN];                     // hot-name hash table
 };
 static_assert(sizeof(Scatter4Lds) % 16 == 0, "the regions follow the struct in LDS");
 // upper bound of the sum of the level-1 region capacities (k_survey_plan_h)
 constexpr uint32_t v3_region_words(uint32_t tile) { return 6u * tile / 4u + (12u + PIECE4) * V3_NP; }
 
-#ifndef LH_SC4_TRIM
-#define LH_SC4_TRIM 1
-#endif
-constexpr bool SC4_TRIM = LH_SC4_TRIM != 0; // the classification with fewer instructions per sample: see LH_SC3_TRIM (lh_kernels_part2.h)
-
 template <int BATCH, typename IDT>
 __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ ids, const double *__restrict__ v,
                                                       size_t ntiles, uint32_t nmetrics, const double *__restrict__ Tx,
                                                       const pu2_t *__restrict__ g_hk, const pu4_t *__restrict__ g_hs,
                                                       const uint32_t *__restrict__ g_hdr,
-                                                      const pu2_t *__restrict__ g_pt, uint32_t region_words,
-                                                      uint32_t cells, uint32_t *__restrict__ records,
+                                                      const pu2_t *__restrict__ g_pt, uint32_t *__restrict__ records,
                                                       uint32_t *__restrict__ cdesc, uint32_t chunks_per_wg,
                                                       uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
                                                       uint32_t *__restrict__ err, uint32_t *__restrict__ g_stats)
@@ -415,34 +428,33 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
     Scatter4Lds &L = *reinterpret_cast<Scatter4Lds *>(v3_smem);
     uint32_t *lds32 = reinterpret_cast<uint32_t *>(v3_smem);
     constexpr uint32_t REG_W = sizeof(Scatter4Lds) / 4;                 // word offset of the regions
-    const uint32_t win_w = REG_W + region_words;                        // word offset of the hot windows
-    uint32_t *win = lds32 + win_w;                                      // [cells]
-    constexpr uint32_t CNT_W = offsetof(Scatter4Lds, cnt) / 4, DUMMY_W = offsetof(Scatter4Lds, dummy) / 4;
+    // the plan's split of the LDS behind the struct (k_survey_plan_h): regions, then the hot windows -- 16-BIT cells, two
+    // to a word, handled exactly as k_scatter3's (a cell that reaches 2^15 hands them on to the row in HBM)
+    const uint32_t region_words = g_hdr[HDR_REGION], cells = g_hdr[HDR_CELLS];
+    const uint32_t win_h = 2u * (REG_W + region_words);                 // halfword offset of the hot windows
+    uint32_t *win = lds32 + win_h / 2;                                  // [cells / 2] words
+    const uint16_t *lds16 = reinterpret_cast<const uint16_t *>(v3_smem);
+    constexpr uint32_t CNT_W = offsetof(Scatter4Lds, cnt) / 4;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t pool_base = blockIdx.x * chunks_per_wg;
     // the LDS address of the block (0 here; not a constant the compiler can fold)
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)v3_smem;
 
-    for (uint32_t i = tid; i < V3_HN; i += BLOCK) {
-        pu2_t e = g_hk[i];
-        e.y += win_w; // hot base as a word offset from the LDS base (< 40 960: fits the low half)
-        L.hk[i] = e;
-    }
-    for (uint32_t i = tid; i < cells; i += BLOCK) win[i] = 0;
+    for (uint32_t i = tid; i < V3_HN; i += BLOCK) L.hk[i] = g_hk[i]; // (hot base: a CELL index inside the window area)
+    for (uint32_t i = tid; i < cells / 2; i += BLOCK) win[i] = 0;
     if (tid < NPT) {
         pu2_t e = g_pt[tid];
-        e.x += REG_W;
-        if (SC4_TRIM) e.x = 4u * e.x + lds_base; // LDS address: a record's address is one shift-add
+        e.x = 4u * (e.x + REG_W) + lds_base; // LDS address: a record's address is one shift-add
         L.pt[tid] = e;
         L.cnt[tid] = 0;
         L.cfill[tid] = CHUNK;
         L.cbase[tid] = INVALID;
     }
     ov_init(L.ov_key, L.ov_cnt, tid, BLOCK);
-    if (tid == 0) { L.pool_next = 0; L.ovn = 0; L.nrec = 0; L.missn[0] = 0; L.missn[1] = 0; }
+    if (tid == 0) { L.pool_next = 0; L.ovn = 0; L.nrec = 0; L.spills = 0; L.missn[0] = 0; L.missn[1] = 0; }
     __syncthreads();
     pu2_t my_pt = L.pt[tid >> 2];       // the flush phase's partition (constant over the launch)
-    if (SC4_TRIM) my_pt.x = (my_pt.x - lds_base) >> 2; // (word index)
+    my_pt.x = (my_pt.x - lds_base) >> 2; // (word index)
     uint32_t nrec = 0;                  // records this thread's partition emitted (q == 0 counts)
 
     const pd2_t *vp = reinterpret_cast<const pd2_t *>(v);
@@ -473,83 +485,20 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
     // sixteen loads in another order than the loop's, and its s_waitcnt pass must cover both orders -- it then waits for a
     // whole register set (vmcnt(8)) where the set's first load would do (vmcnt(15)), and with the copy-out's stores in the
     // counter but not in its books (hidden_store_*) that stricter wait reaches into the loads issued a moment ago.
-    __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): the waitcnt pass takes it into account
+    asm volatile("" : "+v"(idb[0]), "+v"(idb[1]), "+v"(idb[2]), "+v"(idb[3]), "+v"(vab[0]), "+v"(vab[1]), "+v"(vab[2]),
+                      "+v"(vab[3])); // (an empty asm that reads the registers: the compiler waits for their loads here)
 
-    auto classify_r5 = [&](typename IS::raw_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
-        uint32_t rare = 0;
-        // ---- phase 1: classify and place.  Straight-line code, BATCH samples at a time: their table reads, then
-        // their LDS atomics, then their record stores are in flight together.
-#pragma unroll
-        for (int h = 0; h < V2_SPT; h += BATCH) {
-            uint32_t id[BATCH], bin[BATCH], where[BATCH], rank[BATCH], rec[BATCH];
-            pu2_t he[BATCH], pe[BATCH];
-            uint32_t unc = 0, coldm = 0, full = 0;
-#pragma unroll
-            for (int k = 0; k < BATCH; k++) {
-                const int j = h + k;
-                const uint32_t raw = (j & 1) ? IS::second(idv[j >> 1]) : IS::first(idv[j >> 1]);
-                const bool ok = raw < nmetrics; // an id >= nmetrics is reported, the sample skipped
-                rare |= ok ? 0u : 1u;
-                id[k] = ok ? raw : INVALID;
-                he[k] = L.hk[v3_hash(raw)];
-                pe[k] = L.pt[raw & (NPT - 1u)];
-            }
-#pragma unroll
-            for (int k = 0; k < BATCH; k++) {
-                const int j = h + k;
-                bool u;
-                bin[k] = lh_bin_fast((j & 1) ? val[j >> 1].y : val[j >> 1].x, u);
-                if (u) unc |= 1u << k;
-            }
-            if (unc) { // inside the guard band of a bucket threshold (1 sample in ~4 000): Go's log, exactly
-#pragma unroll
-                for (int k = 0; k < BATCH; k++) {
-                    const int j = h + k;
-                    if (unc & (1u << k)) bin[k] = v3_bin_exact((j & 1) ? val[j >> 1].y : val[j >> 1].x);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < BATCH; k++) {
-                const bool valid = id[k] != INVALID;
-                const uint32_t hrel = bin[k] - (he[k].y >> 16);
-                const bool hot = valid && (he[k].x & 0xffffu) == id[k] && hrel < (he[k].x >> 16);
-                const bool cold = valid && !hot;
-                const uint32_t p = id[k] & (NPT - 1u);
-                where[k] = hot ? (he[k].y & 0xffffu) + hrel : cold ? CNT_W + p : DUMMY_W + lane;
-                rec[k] = (p << 24) | (((id[k] >> V3_LOG_NP) & 0xffu) << 16) | bin[k];
-                if (cold) coldm |= 1u << k;
-            }
-#pragma unroll
-            for (int k = 0; k < BATCH; k++) rank[k] = atomicAdd(lds32 + where[k], 1u);
-#pragma unroll
-            for (int k = 0; k < BATCH; k++) {
-                const bool fits = (coldm & (1u << k)) && rank[k] < pe[k].y;
-                if ((coldm & (1u << k)) && !fits) full |= 1u << k; // the region is full: counted exactly below
-                lds32[fits ? pe[k].x + rank[k] : DUMMY_W + lane] = rec[k];
-            }
-            if (full) { // no room: queued, counted exactly by the flush phase
-                atomicAdd(&L.ovn, (uint32_t)__popc(full));
-#pragma unroll
-                for (int k = 0; k < BATCH; k++)
-                    if (full & (1u << k)) {
-                        const uint32_t key = (id[k] << 16) | bin[k];
-                        const uint32_t at = atomicAdd(&L.missn[par], 1u);
-                        if (at < V3_MISSQ) L.missq[par][at] = key;
-                        else if (!ov_add(L.ov_key, L.ov_cnt, key, 1u)) v3_global_add(counts, ranges, id[k], bin[k], 1);
-                    }
-            }
-        }
-        if (rare) atomicOr(err, 1u); // an id >= nmetrics: reported by lh_sync / lh_extract
-    };
-    // SC4_TRIM: the same classification with fewer instructions per sample (as k_scatter3's classify_trim).  An id >=
-    // nmetrics is not tested per sample: one max3 + compare per batch finds the lanes that hold one, and those lanes
-    // turn the sample into a hit of a dummy word (id 0, bin 0, a hot entry of name 0 over bin 0 at the dummy word).
-    auto classify_trim = [&](typename IS::raw_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
+    // ---- phase 1: classify and place.  Straight-line code, BATCH samples at a time: their table reads, then their LDS
+    // atomics, then their record stores are in flight together.  An id >= nmetrics is not tested per sample: one max3 +
+    // compare per batch finds the lanes that hold one, and only those lanes mark the sample (no table entry matches such
+    // an id, so it is not hot; the mark keeps it from becoming a record).
+    auto classify = [&](typename IS::raw_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
 #pragma unroll
         for (int h = 0; h < V2_SPT; h += BATCH) {
             uint32_t raw[BATCH], bin[BATCH], rank[BATCH];
             pu2_t he[BATCH], pe[BATCH];
-            bool unc[BATCH], hot[BATCH], full[BATCH];
+            bool unc[BATCH], hot[BATCH], full[BATCH], spill[BATCH], inval[BATCH];
+            uint32_t waddr[BATCH], sh[BATCH];
             uint32_t idmax = 0;
 #pragma unroll
             for (int k = 0; k < BATCH; k++) {
@@ -579,31 +528,43 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
                     if (unc[k]) bin[k] = v3_bin_exact((j & 1) ? val[j >> 1].y : val[j >> 1].x);
                 }
             }
+#pragma unroll
+            for (int k = 0; k < BATCH; k++) inval[k] = false;
             if (idmax >= nmetrics) { // this lane holds an id >= nmetrics: reported by lh_sync / lh_extract, the sample skipped
                 atomicOr(err, 1u);
 #pragma unroll
-                for (int k = 0; k < BATCH; k++)
-                    if (raw[k] >= nmetrics) {
-                        raw[k] = 0;
-                        bin[k] = 0;
-                        he[k] = (pu2_t){1u << 16, DUMMY_W + lane};
-                    }
+                for (int k = 0; k < BATCH; k++) inval[k] = raw[k] >= nmetrics;
             }
 #pragma unroll
             for (int k = 0; k < BATCH; k++) {
                 const uint32_t hrel = bin[k] - (he[k].y >> 16);
                 hot[k] = (he[k].x & 0xffffu) == raw[k] && hrel < (he[k].x >> 16);
-                const uint32_t a = (he[k].y & 0xffffu) + hrel, b = raw[k] & (NPT - 1u); // LDS words: the hot cell, the partition's counter
+                // the hot cell (a halfword of the window area: word cell / 2, field cell & 1) or the partition's counter
+                const uint32_t cell = (he[k].y & 0xffffu) + hrel + win_h;
                 static_assert(CNT_W == 0, "the partition counters open the LDS block");
-                if (ABL & 8u) { uint32_t w = hot[k] ? a : b; asm volatile("" : "+v"(w)); rank[k] = lane & 15u; }
-                else rank[k] = atomicAdd(lds32 + (hot[k] ? a : b), 1u);
+                waddr[k] = hot[k] ? cell >> 1 : raw[k] & (NPT - 1u);
+                sh[k] = hot[k] ? (cell & 1u) << 4 : 0u;
+                asm volatile("" : "=v"(rank[k])); // (no value for the lanes that skip the atomic)
+                if (ABL & 8u) { asm volatile("" : "+v"(waddr[k]), "+v"(sh[k])); rank[k] = lane & 15u; }
+                else if (!inval[k]) rank[k] = atomicAdd(lds32 + waddr[k], 1u << sh[k]);
                 if (ABL & 2u) rank[k] &= 15u;
+                spill[k] = hot[k] && ((rank[k] >> sh[k]) & 0xffffu) == 0x7fffu; // this add made the cell 2^15
+            }
+            if ((spill[0] || spill[1] || spill[2] || spill[3]) && !(ABL & 8u)) { // 2^15 counts of the cell move to the row in HBM
+                static_assert(BATCH == 4, "the test above names four samples");
+#pragma unroll
+                for (int k = 0; k < BATCH; k++)
+                    if (spill[k]) {
+                        atomicSub(lds32 + waddr[k], 0x8000u << sh[k]);
+                        hidden_global_add(counts, ranges, raw[k], bin[k], 0x8000u);
+                        atomicAdd(&L.spills, 1u);
+                    }
             }
             bool anyfull = false;
 #pragma unroll
             for (int k = 0; k < BATCH; k++) {
-                const bool fits = !hot[k] && rank[k] < pe[k].y;
-                full[k] = !hot[k] && !fits; // the region is full: counted exactly below
+                const bool fits = !hot[k] && !inval[k] && rank[k] < pe[k].y;
+                full[k] = !hot[k] && !inval[k] && !fits; // the region is full: counted exactly below
                 anyfull |= full[k];
                 // record: partition << 24 | local name << 16 | bin = the id's two bytes swapped above the bin
                 if (fits)
@@ -622,9 +583,6 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
                     }
             }
         }
-    };
-    auto classify = [&](typename IS::raw_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
-        if constexpr (SC4_TRIM) classify_trim(idv, val, par); else classify_r5(idv, val, par);
     };
     auto flush = [&](const uint32_t par) {
         if (ABL & 2u) return;
@@ -735,7 +693,7 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
         for (uint32_t j = 0; j < V3_PIECE; j++)
             if (j * LINE4 + q * 4 < left)
                 *reinterpret_cast<pu4_t *>(records + d + j * LINE4 + q * 4) =
-                    *reinterpret_cast<const pu4_t *>(lds32 + (SC4_TRIM ? (L.pt[p].x - lds_base) >> 2 : L.pt[p].x) + j * LINE4 + q * 4);
+                    *reinterpret_cast<const pu4_t *>(lds32 + ((L.pt[p].x - lds_base) >> 2) + j * LINE4 + q * 4);
     }
     if (nrec) atomicAdd(&L.nrec, nrec);
     __syncthreads();
@@ -754,7 +712,7 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
         const uint32_t name = h.x, org = h.y & 0xffffu, width = h.y >> 16, base = h.z;
         uint32_t mn = INVALID, mx = 0;
         for (uint32_t i = lane; i < width; i += 64) {
-            const uint32_t c = win[base + i];
+            const uint32_t c = lds16[win_h + base + i];
             if (c) {
                 const uint32_t b = org + i;
                 atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)name * LH_ROW_STRIDE + b]),
@@ -1734,7 +1692,7 @@ __global__ __launch_bounds__(256) void k_v3_prepare(uint32_t *__restrict__ cd1, 
 struct Part3Plan {
     uint32_t log_w, log_mpp2, mpp2, kp, mpp, ns, log_ns, nq, extra1, extra2, pool_extra;
     bool waves; // level 2 by k_split_waves (<= 16 fine partitions per partition)
-    uint32_t region_words, cells, g1, chunks_per_wg, nchunks1, nchunks2;
+    uint32_t region_words, cells, max_cells, avail_bytes, g1, chunks_per_wg, nchunks1, nchunks2;
     size_t lds_dyn;
     size_t off_stat, off_aux, off_hk, off_hs, off_hdr, off_pt, off_remap, off_inv, off_pt2;
     size_t off_rec1, off_cd1, off_sorted1, off_small1, off_rec2, off_cd2, off_sorted2, off_small2, off_gstats, total;
@@ -1762,11 +1720,15 @@ static bool make_plan3(size_t n, uint32_t nmetrics, int num_cus, const PartTunin
     P.extra2 = (uint32_t)std::min<size_t>(V3_EXTRA2, std::max<size_t>(64, n >> 20));
     // chunks a level-2 slot may strand partially filled: one per fine partition, and per wave in k_split_waves
     P.pool_extra = (P.waves ? SW_WAVES : 1u) * P.ns + 1u;
+    // the LDS behind the struct is shared by the level-1 regions and the hot windows (16-bit cells): the plan sizes the
+    // regions from the survey and gives the windows the rest (k_survey_plan_h); P.cells is the windows' share if the
+    // regions needed their upper bound
     P.region_words = v3_region_words(V3_TILE);
     const size_t fixed = sizeof(Scatter4Lds) + (size_t)P.region_words * 4;
-    P.cells = (uint32_t)((V2_LDS_TOTAL - fixed) / 4) & ~63u;
-    if (!tune.hot) P.cells = 0;
-    P.lds_dyn = fixed + (size_t)P.cells * 4;
+    P.max_cells = tune.hot ? 65472u : 0u; // (cell offsets are 16-bit fields)
+    P.cells = std::min<uint32_t>((uint32_t)((V2_LDS_TOTAL - fixed) / 2) & ~63u, P.max_cells);
+    P.avail_bytes = (uint32_t)(V2_LDS_TOTAL - sizeof(Scatter4Lds));
+    P.lds_dyn = V2_LDS_TOTAL;
     const size_t ntiles = n / V3_TILE; // whole tiles; the rest goes through the direct kernel
     if (ntiles == 0) return false;
     size_t g1 = (size_t)num_cus;
@@ -1897,14 +1859,14 @@ static hipError_t launch_part3_t(const IDT *d_ids, const double *d_v, size_t n, 
         hipLaunchKernelGGL(k_survey_count_h<IDT>, dim3(sv_grid), dim3(1024), 5 * SVH_SLOTS * 4, s, d_ids, d_v, survey_n,
                            nmetrics, d_Tx, g_cs, g_mninv, g_mx);
         hipLaunchKernelGGL(k_survey_pick, dim3((nmetrics + 1023) / 1024), dim3(1024), 0, s, S, nmetrics, g_aux);
-        hipLaunchKernelGGL(k_survey_plan_h, dim3(1), dim3(V2_BLOCK), 0, s, S, g_aux, P.cells, V3_TILE, g_hk, g_hs, g_pt,
+        hipLaunchKernelGGL(k_survey_plan_h, dim3(1), dim3(V2_BLOCK), 0, s, S, g_aux, P.cells, V3_TILE, P.avail_bytes, P.max_cells, g_hk, g_hs, g_pt,
                            g_hdr, span_stat);
         hipLaunchKernelGGL(k_survey_remap, dim3(V3_NP), dim3(256), 0, s, S, g_hk, nmetrics, P.kp, P.log_mpp2, P.ns,
                            g_remap, g_inv, g_pt2);
     }
     const size_t nt_full = n / V3_TILE, done = nt_full * V3_TILE;
     hipLaunchKernelGGL((k_scatter4<4, IDT>), dim3(P.g1), dim3(1024), P.lds_dyn, s, d_ids, d_v, nt_full, nmetrics, d_Tx, g_hk,
-                       g_hs, g_hdr, g_pt, P.region_words, P.cells, L1.records, L1.cdesc, P.chunks_per_wg, counts, ranges,
+                       g_hs, g_hdr, g_pt, L1.records, L1.cdesc, P.chunks_per_wg, counts, ranges,
                        d_err, g_stats);
     if (done < n) {
         e = launch_ingest_pairs(d_ids + done, d_v + done, n - done, counts, ranges, nmetrics, d_Tx, d_err, num_cus, s);
