@@ -856,7 +856,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
                                                        const NameEntry *__restrict__ g_nt,
                                                        const pu4_t *__restrict__ g_hs,
                                                        uint32_t *__restrict__ g_hdr,
-                                                       const pu2_t *__restrict__ g_pt, rec16_t *__restrict__ records,
+                                                       const pu2_t *__restrict__ g_pt, uint32_t *__restrict__ g_hot,
+                                                       rec16_t *__restrict__ records,
                                                        uint32_t *__restrict__ cdesc, uint32_t chunks_per_wg,
                                                        uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
                                                        uint32_t *__restrict__ err,
@@ -885,7 +886,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
     const uint32_t win_h = reg_h + region_recs;                                    // halfword offset of the hot windows (even)
     uint32_t *win = lds32 + win_h / 2;                                             // [cells / 2] words
     constexpr uint32_t CNT_W = offsetof(LdsT, cnt) / 4;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t np = 1u << log_np, pmask = np - 1, W = 1u << log_w;
     const uint32_t pool_base = blockIdx.x * chunks_per_wg;
     // the LDS address of the block (0 here; not a constant the compiler can fold)
@@ -1177,52 +1178,83 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
     if (tid == 0 && L.ovn && rstat)
         __hip_atomic_fetch_add(rstat, (unsigned long long)L.ovn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 
-    // ---- flush the hot windows (one uint64 atomic per occupied bin) and the out-of-window table
-    const uint32_t nhot = g_hdr[0];
-    uint32_t hits = tid == 0 ? L.spills << 15 : 0u; // (a workgroup sees fewer than 2^31 samples)
-    for (uint32_t s = wave; s < nhot; s += BLOCK / 64) {
-        const pu4_t h = g_hs[s];
+    // ---- the hot windows leave as they are: one coalesced copy of the window area into the workgroup's slice of g_hot.
+    // k_hot_reduce adds the workgroups' copies up and touches every row cell ONCE.  (Until round 6 every workgroup
+    // flushed its windows with one uint64 atomic per occupied cell: 256 workgroups x 19 000 cells were ~100 us at the END
+    // of every launch -- device-scope atomics of 256 workgroups on the same few thousand lines -- and the cost grew with
+    // the very cells that save records.)
+    {
+        pu4_t *dst = reinterpret_cast<pu4_t *>(g_hot + (size_t)blockIdx.x * (cells / 2));
+        const pu4_t *src = reinterpret_cast<const pu4_t *>(win);
+        for (uint32_t i = tid; i < cells / 8; i += BLOCK) dst[i] = src[i]; // (cells is a multiple of 64, the area 16-byte aligned)
+    }
+    for (uint32_t i = tid; i < OV_SLOTS; i += BLOCK)
+        if (L.ov_key[i] != OV_EMPTY) v2_global_add(counts, ranges, L.ov_key[i] >> 16, L.ov_key[i] & 0xffffu, L.ov_cnt[i]);
+    // the workgroup's part of the launch's account (stale_judge, by k_hot_reduce): its tiles, and the hits its cells
+    // handed on to the rows already
+    if (tid == 0) {
+        const uint32_t mine = blockIdx.x < ntiles ? (uint32_t)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0u;
+        if (L.spills) atomicAdd(&g_hdr[HDR_HITS], L.spills << 15);
+        atomicAdd(&g_hdr[HDR_TILES], mine);
+    }
+}
+
+// The hot windows of a launch's G workgroups, added up: one workgroup per hot name (g_hs), a thread per cell walks the
+// G copies (consecutive threads read consecutive halfwords of one copy: coalesced), then ONE uint64 atomic per occupied
+// cell and one range update per name.  With tile > 0 the kernel also closes the launch's account of what the hot windows
+// took (stale_judge): the last workgroup to finish judges.
+__global__ __launch_bounds__(256) void k_hot_reduce(const uint32_t *__restrict__ g_hot, uint32_t G,
+                                                    const pu4_t *__restrict__ g_hs, uint32_t *__restrict__ g_hdr,
+                                                    uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
+                                                    uint32_t tile, unsigned long long *__restrict__ rstat)
+{
+    __shared__ uint32_t s_mn, s_mx, s_hits;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t nhot = g_hdr[0], cells = g_hdr[HDR_CELLS];
+    if (tid == 0) { s_mn = INVALID; s_mx = 0; s_hits = 0; }
+    __syncthreads();
+    uint32_t hits = 0;
+    if (blockIdx.x < nhot) {
+        const pu4_t h = g_hs[blockIdx.x];
         const uint32_t name = h.x, org = h.y & 0xffffu, width = h.y >> 16, base = h.z;
+        const uint16_t *hot16 = reinterpret_cast<const uint16_t *>(g_hot);
         uint32_t mn = INVALID, mx = 0;
-        for (uint32_t i = lane; i < width; i += 64) {
-            const uint32_t c = lds16[win_h + base + i];
-            if (c) {
+        for (uint32_t i = tid; i < width; i += 256) {
+            const uint16_t *c = hot16 + base + i;
+            uint32_t sum = 0;
+#pragma unroll 8
+            for (uint32_t w = 0; w < G; w++) sum += c[(size_t)w * cells];
+            if (sum) {
                 const uint32_t b = org + i;
                 atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)name * LH_ROW_STRIDE + b]),
-                          (unsigned long long)c);
+                          (unsigned long long)sum);
                 mn = min(mn, b);
                 mx = max(mx, b);
-                hits += c;
+                hits += sum;
             }
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
             mn = min(mn, (uint32_t)__shfl_xor(mn, d, 64));
             mx = max(mx, (uint32_t)__shfl_xor(mx, d, 64));
+            hits += __shfl_xor(hits, d, 64);
         }
-        if (lane == 0 && mn != INVALID) {
+        if (lane == 0 && mn != INVALID) { atomicMin(&s_mn, mn); atomicMax(&s_mx, mx); }
+        if (lane == 0 && hits) atomicAdd(&s_hits, hits);
+        __syncthreads();
+        if (tid == 0 && s_mn != INVALID) {
             uint32_t *r = ranges + 2 * (size_t)name;
-            if (mn < r[0]) atomicMin(&r[0], mn);
-            if (mx > r[1]) atomicMax(&r[1], mx);
+            if (s_mn < r[0]) atomicMin(&r[0], s_mn);
+            if (s_mx > r[1]) atomicMax(&r[1], s_mx);
         }
     }
-    for (uint32_t i = tid; i < OV_SLOTS; i += BLOCK)
-        if (L.ov_key[i] != OV_EMPTY) v2_global_add(counts, ranges, L.ov_key[i] >> 16, L.ov_key[i] & 0xffffu, L.ov_cnt[i]);
-
-    // ---- is the survey stale?  (stale_judge above.)  The last workgroup to hand its account in judges the launch.
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) hits += __shfl_xor(hits, d, 64);
-    if (lane == 0 && hits) atomicAdd(&L.dummy[0], hits);
-    __syncthreads();
-    if (tid == 0) {
-        const uint32_t mine = blockIdx.x < ntiles ? (uint32_t)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0u;
-        atomicAdd(&g_hdr[HDR_HITS], L.dummy[0]);
-        atomicAdd(&g_hdr[HDR_TILES], mine);
+    if (tile && tid == 0) { // is the survey stale?  (stale_judge above.)
+        if (s_hits) atomicAdd(&g_hdr[HDR_HITS], s_hits);
         __threadfence();
         if (atomicAdd(&g_hdr[HDR_TICKET], 1u) == gridDim.x - 1) {
             __threadfence();
             const unsigned long long taken = atomicAdd(&g_hdr[HDR_HITS], 0u);
-            const unsigned long long pairs = (unsigned long long)atomicAdd(&g_hdr[HDR_TILES], 0u) * V3_TILE;
+            const unsigned long long pairs = (unsigned long long)atomicAdd(&g_hdr[HDR_TILES], 0u) * tile;
             stale_judge(g_hdr, rstat, taken, pairs);
             g_hdr[HDR_HITS] = 0;
             g_hdr[HDR_TILES] = 0;
@@ -1381,7 +1413,7 @@ struct Part2Plan {
     uint32_t region_recs;      // shapes 2, 3: upper bound of the records of LDS the partitions' regions take
     RegionFit fit;             // shapes 2, 3: what k_survey_plan needs to split the LDS between regions and hot windows
     size_t lds_dyn;            // dynamic LDS of the scatter kernel
-    size_t off_rec, off_cd, off_sorted, off_small, off_stat, off_nt, off_hs, off_hdr, off_pt, total;
+    size_t off_rec, off_cd, off_sorted, off_small, off_stat, off_nt, off_hs, off_hdr, off_pt, off_hot, total;
 };
 
 static bool make_plan2(size_t n, uint32_t nmetrics, int num_cus, const PartTuning &tune, Part2Plan &P)
@@ -1419,9 +1451,13 @@ static bool make_plan2(size_t n, uint32_t nmetrics, int num_cus, const PartTunin
     if (!tune.hot) P.cells = 0;
     P.fit = RegionFit{0u, P.log_np, 0u, cell_bytes, direct ? 2u : 1u, tune.hot ? max_cells : 0u};
     if (direct) {
+        // regions + windows share what the fixed parts leave of the budget (the plan decides how) -- or, when the name
+        // table leaves less than the regions' upper bound (8 192 names in half a CU's LDS), exactly that bound
+        const size_t fixed0 = P.lds_fixed + nt_bytes, bound = (size_t)P.region_recs * sizeof(rec16_t);
+        const size_t avail = std::max(budget > fixed0 + 256 ? budget - 256 - fixed0 : 0, bound);
         P.fit.tile = P.tile * SC3_TILES_PER_FLUSH;
-        P.fit.avail_bytes = (uint32_t)(budget - (fixed - (size_t)P.region_recs * sizeof(rec16_t)));
-        P.lds_dyn = budget - 256; // regions + windows share what the fixed parts leave: the plan decides how
+        P.fit.avail_bytes = (uint32_t)avail;
+        P.lds_dyn = fixed0 + avail;
     } else {
         P.lds_dyn = fixed - 256 + (size_t)P.cells * 4;
     }
@@ -1442,6 +1478,7 @@ static bool make_plan2(size_t n, uint32_t nmetrics, int num_cus, const PartTunin
     P.off_hs = take((size_t)V2_MAX_SLOTS * sizeof(pu4_t));
     P.off_hdr = take(64);
     P.off_pt = take(256 * sizeof(pu2_t));
+    P.off_hot = take(direct ? (size_t)P.fit.max_cells * 2 * ((size_t)num_cus * wgs_per_cu) : 0); // k_scatter3's windows, one copy per workgroup
     P.off_rec = take((size_t)P.nchunks * CHUNK * sizeof(rec16_t));
     P.off_cd = take((size_t)P.nchunks * sizeof(uint32_t));
     P.off_sorted = take((size_t)P.nchunks * sizeof(uint32_t));
@@ -1507,6 +1544,7 @@ static hipError_t launch_part2_t(const IDT *d_ids, const double *d_v, size_t n, 
     pu4_t *g_hs = reinterpret_cast<pu4_t *>(base + P.off_hs);
     uint32_t *g_hdr = reinterpret_cast<uint32_t *>(base + P.off_hdr);
     pu2_t *g_pt = reinterpret_cast<pu2_t *>(base + P.off_pt);
+    uint32_t *g_hot = reinterpret_cast<uint32_t *>(base + P.off_hot);
 
     hipError_t e = hipMemsetAsync(L1.cdesc, 0xff, (size_t)P.nchunks * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
@@ -1526,12 +1564,14 @@ static hipError_t launch_part2_t(const IDT *d_ids, const double *d_v, size_t n, 
         const size_t nt_full = n / P.tile, done = nt_full * P.tile;
         if (P.shape == 3)
             hipLaunchKernelGGL((k_scatter3<512, 128, SC3_BATCH, IDT>), dim3(P.g1), dim3(512), p1_dyn, s, d_ids, d_v, nt_full, nmetrics,
-                               P.log_np, P.log_w, d_Tx, g_nt, g_hs, g_hdr, g_pt, records,
+                               P.log_np, P.log_w, d_Tx, g_nt, g_hs, g_hdr, g_pt, g_hot, records,
                                L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, region_stat);
         else
             hipLaunchKernelGGL((k_scatter3<1024, 256, SC3_BATCH, IDT>), dim3(P.g1), dim3(1024), p1_dyn, s, d_ids, d_v, nt_full,
-                               nmetrics, P.log_np, P.log_w, d_Tx, g_nt, g_hs, g_hdr, g_pt,
+                               nmetrics, P.log_np, P.log_w, d_Tx, g_nt, g_hs, g_hdr, g_pt, g_hot,
                                records, L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, region_stat);
+        hipLaunchKernelGGL(k_hot_reduce, dim3(V2_MAX_SLOTS), dim3(256), 0, s, g_hot, P.g1, g_hs, g_hdr, counts, ranges, P.tile,
+                           region_stat);
         if (done < n) {
             e = launch_ingest_pairs(d_ids + done, d_v + done, n - done, counts, ranges, nmetrics, d_Tx, d_err, num_cus, s);
             if (e != hipSuccess) return e;

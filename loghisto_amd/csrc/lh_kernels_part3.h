@@ -415,7 +415,8 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
                                                       size_t ntiles, uint32_t nmetrics, const double *__restrict__ Tx,
                                                       const pu2_t *__restrict__ g_hk, const pu4_t *__restrict__ g_hs,
                                                       const uint32_t *__restrict__ g_hdr,
-                                                      const pu2_t *__restrict__ g_pt, uint32_t *__restrict__ records,
+                                                      const pu2_t *__restrict__ g_pt, uint32_t *__restrict__ g_hot,
+                                                      uint32_t *__restrict__ records,
                                                       uint32_t *__restrict__ cdesc, uint32_t chunks_per_wg,
                                                       uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
                                                       uint32_t *__restrict__ err, uint32_t *__restrict__ g_stats)
@@ -433,9 +434,8 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
     const uint32_t region_words = g_hdr[HDR_REGION], cells = g_hdr[HDR_CELLS];
     const uint32_t win_h = 2u * (REG_W + region_words);                 // halfword offset of the hot windows
     uint32_t *win = lds32 + win_h / 2;                                  // [cells / 2] words
-    const uint16_t *lds16 = reinterpret_cast<const uint16_t *>(v3_smem);
     constexpr uint32_t CNT_W = offsetof(Scatter4Lds, cnt) / 4;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t pool_base = blockIdx.x * chunks_per_wg;
     // the LDS address of the block (0 here; not a constant the compiler can fold)
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)v3_smem;
@@ -705,32 +705,12 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
         atomicAdd(&g_stats[1], L.nrec);
     }
 
-    // ---- flush the hot windows (one uint64 atomic per occupied bin) and the overflow table
-    const uint32_t nhot = g_hdr[0];
-    for (uint32_t s = wave; s < nhot; s += BLOCK / 64) {
-        const pu4_t h = g_hs[s];
-        const uint32_t name = h.x, org = h.y & 0xffffu, width = h.y >> 16, base = h.z;
-        uint32_t mn = INVALID, mx = 0;
-        for (uint32_t i = lane; i < width; i += 64) {
-            const uint32_t c = lds16[win_h + base + i];
-            if (c) {
-                const uint32_t b = org + i;
-                atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)name * LH_ROW_STRIDE + b]),
-                          (unsigned long long)c);
-                mn = min(mn, b);
-                mx = max(mx, b);
-            }
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            mn = min(mn, (uint32_t)__shfl_xor(mn, d, 64));
-            mx = max(mx, (uint32_t)__shfl_xor(mx, d, 64));
-        }
-        if (lane == 0 && mn != INVALID) {
-            uint32_t *r = ranges + 2 * (size_t)name;
-            if (mn < r[0]) atomicMin(&r[0], mn);
-            if (mx > r[1]) atomicMax(&r[1], mx);
-        }
+    // ---- the hot windows leave as one coalesced copy into the workgroup's slice of g_hot; k_hot_reduce adds the
+    // workgroups' copies up and touches every row cell once (see k_scatter3); the overflow table
+    {
+        pu4_t *dst = reinterpret_cast<pu4_t *>(g_hot + (size_t)blockIdx.x * (cells / 2));
+        const pu4_t *src = reinterpret_cast<const pu4_t *>(win);
+        for (uint32_t i = tid; i < cells / 8; i += BLOCK) dst[i] = src[i];
     }
     for (uint32_t i = tid; i < OV_SLOTS; i += BLOCK)
         if (L.ov_key[i] != OV_EMPTY) v2_global_add(counts, ranges, L.ov_key[i] >> 16, L.ov_key[i] & 0xffffu, L.ov_cnt[i]);
@@ -1694,7 +1674,7 @@ struct Part3Plan {
     bool waves; // level 2 by k_split_waves (<= 16 fine partitions per partition)
     uint32_t region_words, cells, max_cells, avail_bytes, g1, chunks_per_wg, nchunks1, nchunks2;
     size_t lds_dyn;
-    size_t off_stat, off_aux, off_hk, off_hs, off_hdr, off_pt, off_remap, off_inv, off_pt2;
+    size_t off_stat, off_aux, off_hk, off_hs, off_hdr, off_pt, off_remap, off_inv, off_pt2, off_hot;
     size_t off_rec1, off_cd1, off_sorted1, off_small1, off_rec2, off_cd2, off_sorted2, off_small2, off_gstats, total;
 };
 
@@ -1762,6 +1742,7 @@ static bool make_plan3(size_t n, uint32_t nmetrics, int num_cus, const PartTunin
     P.off_sorted2 = take((size_t)P.nchunks2 * sizeof(uint32_t));
     P.off_small2 = take(small_words(P.nq, P.extra2) * sizeof(uint32_t));
     P.off_gstats = take(64); // the launch's self-metrics: with the records, not with the tables (launches may share tables)
+    P.off_hot = take((size_t)P.max_cells * 2 * P.g1); // level 1's hot windows, one copy per workgroup (k_hot_reduce)
     P.total = o;
     return true;
 }
@@ -1845,6 +1826,7 @@ static hipError_t launch_part3_t(const IDT *d_ids, const double *d_v, size_t n, 
     pu2_t *g_pt = reinterpret_cast<pu2_t *>(base + P.off_pt);
     uint8_t *g_remap = base + P.off_remap, *g_inv = base + P.off_inv;
     pu2_t *g_pt2 = reinterpret_cast<pu2_t *>(base + P.off_pt2);
+    uint32_t *g_hot = reinterpret_cast<uint32_t *>(rec + (P.off_hot - r0));
 
     hipLaunchKernelGGL(k_v3_prepare, dim3(1024), dim3(256), 0, s, L1.cdesc, P.nchunks1, L1.pc,
                        (uint32_t)small_words(V3_NP, P.extra1), L2.cdesc, P.nchunks2, L2.pc,
@@ -1866,8 +1848,9 @@ static hipError_t launch_part3_t(const IDT *d_ids, const double *d_v, size_t n, 
     }
     const size_t nt_full = n / V3_TILE, done = nt_full * V3_TILE;
     hipLaunchKernelGGL((k_scatter4<4, IDT>), dim3(P.g1), dim3(1024), P.lds_dyn, s, d_ids, d_v, nt_full, nmetrics, d_Tx, g_hk,
-                       g_hs, g_hdr, g_pt, L1.records, L1.cdesc, P.chunks_per_wg, counts, ranges,
+                       g_hs, g_hdr, g_pt, g_hot, L1.records, L1.cdesc, P.chunks_per_wg, counts, ranges,
                        d_err, g_stats);
+    hipLaunchKernelGGL(k_hot_reduce, dim3(V2_MAX_SLOTS), dim3(256), 0, s, g_hot, P.g1, g_hs, g_hdr, counts, ranges, 0u, nullptr);
     if (done < n) {
         e = launch_ingest_pairs(d_ids + done, d_v + done, n - done, counts, ranges, nmetrics, d_Tx, d_err, num_cus, s);
         if (e != hipSuccess) return e;
