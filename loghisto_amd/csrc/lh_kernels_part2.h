@@ -105,16 +105,18 @@ struct NameEntry { uint32_t org; uint32_t hot; };
 // ---------------------------------------------------------------------------
 constexpr uint32_t HDR_HITS = 8, HDR_TILES = 9, HDR_TICKET = 10, HDR_BASE = 11; // words of the 64-byte survey header
 constexpr uint32_t HDR_REGION = 5, HDR_CELLS = 6; // LDS the plan gave the level-1 regions (records) and the hot windows (cells)
+constexpr uint32_t HDR_OVF = 7;                   // k_scatter3: records of the launch that found their region full
 constexpr uint32_t RSTAT_STALE = 7;                // engine's pinned words: [7] pairs a stale survey kept out of the hot windows
 constexpr uint32_t STALE_VALID = 0x80000000u;      // hdr[HDR_BASE] = STALE_VALID | share in 1/65 536ths
 constexpr uint32_t STALE_DROP = 65536u / 20u;      // 5 % of the launch's pairs
 
 // share: what the hot windows took of `pairs`, in 1/65 536ths (first level of the third generation: pairs that did NOT
 // become records).  One thread, after every workgroup's account is in.
-__device__ __forceinline__ void stale_judge(uint32_t *__restrict__ hdr, unsigned long long *__restrict__ rstat,
+// Returns true when the launch ran on a stale survey (and said so).
+__device__ __forceinline__ bool stale_judge(uint32_t *__restrict__ hdr, unsigned long long *__restrict__ rstat,
                                             unsigned long long taken, unsigned long long pairs)
 {
-    if (!pairs) return;
+    if (!pairs) return false;
     const uint32_t share = (uint32_t)((taken << 16) / pairs);
     const uint32_t base = hdr[HDR_BASE];
     if (!(base & STALE_VALID)) {
@@ -122,7 +124,9 @@ __device__ __forceinline__ void stale_judge(uint32_t *__restrict__ hdr, unsigned
     } else if (share + STALE_DROP < (base & 0x1ffffu) && rstat) {
         const unsigned long long lost = (((unsigned long long)((base & 0x1ffffu) - share)) * pairs) >> 16;
         __hip_atomic_fetch_add(rstat + RSTAT_STALE, lost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return true;
     }
+    return false;
 }
 
 // ---------------------------------------------------------------------------
@@ -203,9 +207,21 @@ __device__ __forceinline__ void block_sum2(uint32_t a, uint32_t b, uint32_t *s_a
 // Until then the host reserved the regions' upper bound (1.5 x a tile in which EVERY sample is a record + 72 records per
 // partition: 60 KiB at 256 partitions) and the windows got the rest; the regions a Zipf stream needs are a third smaller,
 // because the names with hot windows leave only their tails as records.  The plan now sizes the regions from the names'
-// counts with the hot names' halved (a hot window keeps 80 - 99 % of its name; half is the allowance for a survey gone
-// stale, which the launches detect: stale_judge), and gives what that frees to the windows: tile = 0 -> no regions
-// (k_scatter2's exact layout), cells as given.
+// counts with the hot names' reduced (cold_share), and gives what that frees to the windows: tile = 0 -> no regions
+// (k_scatter2's exact layout), cells as given.  A survey gone stale (the values moved, every sample is a record) then
+// overflows the regions -- the launch says so itself (stale_judge) and its overflow count is NOT passed on to the engine,
+// which would read it as a stream clustered by name.
+// What a name with a hot window of `want` bins still sends to its partition's region, of `cnt` sampled values over a span
+// of `span` bins: everything but 3/4 of the window's share of the span.  (A bell-shaped name keeps 80 - 99 % in a window
+// of 3/4 of its span and is charged ~45 %; a name spread evenly over 21 decades keeps an eighth in its 512 bins and is
+// charged 91 %: the regions must not overflow on a HEALTHY survey -- the engine reads overflows as a stream clustered by
+// name and leaves the region kernel for 64 flips.)
+__device__ __forceinline__ uint32_t cold_share(uint32_t cnt, uint32_t want, uint32_t span)
+{
+    const uint32_t w = want < span ? want : span;
+    return cnt - (uint32_t)(((unsigned long long)cnt * 3u * w) / (4ull * span));
+}
+
 struct RegionFit {
     uint32_t tile;        // samples between two flushes (0: the kernel has no regions)
     uint32_t log_np;
@@ -238,9 +254,11 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__rest
     uint32_t cnt[EMAX], want[EMAX], mean[EMAX], corg[EMAX];
     uint32_t mysum = 0, whole = 0; // whole: bit e = name e of this thread keeps its whole sampled span
     uint32_t lobe = 0, lo_end[EMAX], hi_end[EMAX]; // lobe: bit e = two lobes either side of key 0; the span's ends
+    uint32_t span[EMAX];                           // the sampled span in bins
 #pragma unroll
     for (uint32_t e = 0; e < EMAX; e++) {
         cnt[e] = 0;
+        span[e] = 1;
         lo_end[e] = hi_end[e] = 0;
         want[e] = 0;
         mean[e] = 32768u;
@@ -252,6 +270,7 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__rest
             mysum += c;
             if (c) {
                 const uint32_t mn = 65535u - g_mninv[m], mx = g_mx[m];
+                span[e] = mx - mn + 1u;
                 mean[e] = (uint32_t)(g_sum[m] / c);
                 // cold window: centred on the sampled span when it fits, on the mean bin otherwise
                 const uint32_t centre = (mx - mn < W) ? (mn + mx + 1) >> 1 : mean[e];
@@ -325,7 +344,7 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__rest
         __syncthreads();
 #pragma unroll
         for (uint32_t e = 0; e < EMAX; e++)
-            if (cnt[e]) atomicAdd(&s_pc[(m0 + e) & (np - 1u)], (want[e] && cnt[e] >= tau) ? (cnt[e] + 1u) / 2u : cnt[e]);
+            if (cnt[e]) atomicAdd(&s_pc[(m0 + e) & (np - 1u)], (want[e] && cnt[e] >= tau) ? cold_share(cnt[e], want[e], span[e]) : cnt[e]);
         __syncthreads();
         uint32_t cap = 0;
         if (tid < np) {
@@ -399,6 +418,7 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__rest
         hdr[3] = hot_cnt_total;
         hdr[HDR_REGION] = region_recs;
         hdr[HDR_CELLS] = cells;
+        hdr[HDR_OVF] = 0;
         hdr[HDR_HITS] = 0;  // k_scatter3's account of what the hot windows take (stale_report below)
         hdr[HDR_TILES] = 0;
         hdr[HDR_TICKET] = 0;
@@ -1175,8 +1195,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
     if (tid < np && L.cbase[tid] != INVALID) cdesc[L.cbase[tid]] = (tid << CD_SHIFT) | L.cfill[tid];
     // the engine watches this count (pinned host memory): a stream whose tiles overflow the regions is clustered by
     // name, and later calls take the exact-layout kernel instead
-    if (tid == 0 && L.ovn && rstat)
-        __hip_atomic_fetch_add(rstat, (unsigned long long)L.ovn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0 && L.ovn) atomicAdd(&g_hdr[HDR_OVF], L.ovn); // (k_hot_reduce's judge passes it on)
 
     // ---- the hot windows leave as they are: one coalesced copy of the window area into the workgroup's slice of g_hot.
     // k_hot_reduce adds the workgroups' copies up and touches every row cell ONCE.  (Until round 6 every workgroup
@@ -1203,44 +1222,57 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
 // G copies (consecutive threads read consecutive halfwords of one copy: coalesced), then ONE uint64 atomic per occupied
 // cell and one range update per name.  With tile > 0 the kernel also closes the launch's account of what the hot windows
 // took (stale_judge): the last workgroup to finish judges.
-__global__ __launch_bounds__(256) void k_hot_reduce(const uint32_t *__restrict__ g_hot, uint32_t G,
-                                                    const pu4_t *__restrict__ g_hs, uint32_t *__restrict__ g_hdr,
-                                                    uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
-                                                    uint32_t tile, unsigned long long *__restrict__ rstat)
+__global__ __launch_bounds__(1024) void k_hot_reduce(const uint32_t *__restrict__ g_hot, uint32_t G,
+                                                     const pu4_t *__restrict__ g_hs, uint32_t *__restrict__ g_hdr,
+                                                     uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
+                                                     uint32_t tile, unsigned long long *__restrict__ rstat)
 {
+    // 1 024 threads = 256 cells x 4 groups of copies: thread (c, q) adds the copies q, q + 4, .. of cell c (64 loads in
+    // flight eight at a time instead of 256), the four partial sums meet in LDS
+    __shared__ uint32_t s_part[4][256];
     __shared__ uint32_t s_mn, s_mx, s_hits;
-    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, c = tid & 255u, q = tid >> 8;
     const uint32_t nhot = g_hdr[0], cells = g_hdr[HDR_CELLS];
     if (tid == 0) { s_mn = INVALID; s_mx = 0; s_hits = 0; }
     __syncthreads();
-    uint32_t hits = 0;
     if (blockIdx.x < nhot) {
         const pu4_t h = g_hs[blockIdx.x];
         const uint32_t name = h.x, org = h.y & 0xffffu, width = h.y >> 16, base = h.z;
         const uint16_t *hot16 = reinterpret_cast<const uint16_t *>(g_hot);
-        uint32_t mn = INVALID, mx = 0;
-        for (uint32_t i = tid; i < width; i += 256) {
-            const uint16_t *c = hot16 + base + i;
+        uint32_t mn = INVALID, mx = 0, hits = 0;
+        for (uint32_t i0 = 0; i0 < width; i0 += 256) { // (block-uniform trip count)
+            const uint32_t i = i0 + c;
             uint32_t sum = 0;
+            if (i < width) {
+                const uint16_t *p = hot16 + base + i;
 #pragma unroll 8
-            for (uint32_t w = 0; w < G; w++) sum += c[(size_t)w * cells];
-            if (sum) {
-                const uint32_t b = org + i;
-                atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)name * LH_ROW_STRIDE + b]),
-                          (unsigned long long)sum);
-                mn = min(mn, b);
-                mx = max(mx, b);
-                hits += sum;
+                for (uint32_t w = q; w < G; w += 4) sum += p[(size_t)w * cells];
             }
+            s_part[q][c] = sum;
+            __syncthreads();
+            if (q == 0) {
+                sum += s_part[1][c] + s_part[2][c] + s_part[3][c];
+                if (sum) {
+                    const uint32_t b = org + i;
+                    atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)name * LH_ROW_STRIDE + b]),
+                              (unsigned long long)sum);
+                    mn = min(mn, b);
+                    mx = max(mx, b);
+                    hits += sum;
+                }
+            }
+            __syncthreads();
         }
+        if (q == 0) {
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            mn = min(mn, (uint32_t)__shfl_xor(mn, d, 64));
-            mx = max(mx, (uint32_t)__shfl_xor(mx, d, 64));
-            hits += __shfl_xor(hits, d, 64);
+            for (int d = 32; d >= 1; d >>= 1) {
+                mn = min(mn, (uint32_t)__shfl_xor(mn, d, 64));
+                mx = max(mx, (uint32_t)__shfl_xor(mx, d, 64));
+                hits += __shfl_xor(hits, d, 64);
+            }
+            if (lane == 0 && mn != INVALID) { atomicMin(&s_mn, mn); atomicMax(&s_mx, mx); }
+            if (lane == 0 && hits) atomicAdd(&s_hits, hits);
         }
-        if (lane == 0 && mn != INVALID) { atomicMin(&s_mn, mn); atomicMax(&s_mx, mx); }
-        if (lane == 0 && hits) atomicAdd(&s_hits, hits);
         __syncthreads();
         if (tid == 0 && s_mn != INVALID) {
             uint32_t *r = ranges + 2 * (size_t)name;
@@ -1255,7 +1287,13 @@ __global__ __launch_bounds__(256) void k_hot_reduce(const uint32_t *__restrict__
             __threadfence();
             const unsigned long long taken = atomicAdd(&g_hdr[HDR_HITS], 0u);
             const unsigned long long pairs = (unsigned long long)atomicAdd(&g_hdr[HDR_TILES], 0u) * tile;
-            stale_judge(g_hdr, rstat, taken, pairs);
+            const bool stale = stale_judge(g_hdr, rstat, taken, pairs);
+            // the engine watches the region overflows (pinned host memory): a stream whose tiles overflow the regions is
+            // clustered by name, and later calls take the exact-layout kernel instead -- unless the survey was stale
+            const uint32_t ovf = atomicAdd(&g_hdr[HDR_OVF], 0u);
+            if (ovf && !stale && rstat)
+                __hip_atomic_fetch_add(rstat, (unsigned long long)ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            g_hdr[HDR_OVF] = 0;
             g_hdr[HDR_HITS] = 0;
             g_hdr[HDR_TILES] = 0;
             g_hdr[HDR_TICKET] = 0;
@@ -1570,7 +1608,7 @@ static hipError_t launch_part2_t(const IDT *d_ids, const double *d_v, size_t n, 
             hipLaunchKernelGGL((k_scatter3<1024, 256, SC3_BATCH, IDT>), dim3(P.g1), dim3(1024), p1_dyn, s, d_ids, d_v, nt_full,
                                nmetrics, P.log_np, P.log_w, d_Tx, g_nt, g_hs, g_hdr, g_pt, g_hot,
                                records, L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, region_stat);
-        hipLaunchKernelGGL(k_hot_reduce, dim3(V2_MAX_SLOTS), dim3(256), 0, s, g_hot, P.g1, g_hs, g_hdr, counts, ranges, P.tile,
+        hipLaunchKernelGGL(k_hot_reduce, dim3(V2_MAX_SLOTS), dim3(1024), 0, s, g_hot, P.g1, g_hs, g_hdr, counts, ranges, P.tile,
                            region_stat);
         if (done < n) {
             e = launch_ingest_pairs(d_ids + done, d_v + done, n - done, counts, ranges, nmetrics, d_Tx, d_err, num_cus, s);

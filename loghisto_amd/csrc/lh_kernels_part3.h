@@ -228,13 +228,12 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan_h(const SurveyStat S,
     };
     uint32_t tau = pick(cells_in);
     // level-1 regions: 1.5 x the partition's expected records per tile + 8 + one piece (the leftover), from the names'
-    // counts with the hot names' HALVED (a hot window keeps 80 - 99 % of its name; half is the allowance for a survey
-    // gone stale, which the launches detect and end: k_v3_report / stale_judge) -- round 6; until then every name
-    // counted in full and the regions took their upper bound of the LDS.  What that frees goes to the windows: they are
+    // counts with the hot names' reduced to what their windows leave (cold_share, lh_kernels_part2.h) -- round 6; until
+    // then every name counted in full and the regions took their upper bound of the LDS.  What that frees goes to the windows: they are
     // chosen once more with the larger budget (a superset of the first choice, so the regions stay large enough).
     if (tid < V3_NP) s_pcw[tid] = pc;
     __syncthreads();
-    if (want && cnt >= tau) atomicSub(&s_pcw[name & (V3_NP - 1u)], cnt / 2u);
+    if (want && cnt >= tau) atomicSub(&s_pcw[name & (V3_NP - 1u)], cnt - cold_share(cnt, want, mx - mn + 1u));
     __syncthreads();
     uint32_t cap = 0;
     if (tid < V3_NP) {
@@ -1850,7 +1849,7 @@ static hipError_t launch_part3_t(const IDT *d_ids, const double *d_v, size_t n, 
     hipLaunchKernelGGL((k_scatter4<4, IDT>), dim3(P.g1), dim3(1024), P.lds_dyn, s, d_ids, d_v, nt_full, nmetrics, d_Tx, g_hk,
                        g_hs, g_hdr, g_pt, g_hot, L1.records, L1.cdesc, P.chunks_per_wg, counts, ranges,
                        d_err, g_stats);
-    hipLaunchKernelGGL(k_hot_reduce, dim3(V2_MAX_SLOTS), dim3(256), 0, s, g_hot, P.g1, g_hs, g_hdr, counts, ranges, 0u, nullptr);
+    hipLaunchKernelGGL(k_hot_reduce, dim3(V2_MAX_SLOTS), dim3(1024), 0, s, g_hot, P.g1, g_hs, g_hdr, counts, ranges, 0u, nullptr);
     if (done < n) {
         e = launch_ingest_pairs(d_ids + done, d_v + done, n - done, counts, ranges, nmetrics, d_Tx, d_err, num_cus, s);
         if (e != hipSuccess) return e;

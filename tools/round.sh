@@ -178,7 +178,7 @@ level1)
         for m in 1024 65536; do
             (cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/pk
              timeout 300 rocprofv3 --kernel-trace -d /tmp/pk -o t -- python $R/tools/sweep.py --samples 1e9 --pairs $m --reps 4 --dists lognormal --nocheck "${@:2}" > /dev/null 2>&1
-             python $R/profiles/summarize_rocpd.py stats /tmp/pk/t_results.db | grep -E "k_scatter|k_part_hist|k_split" | cut -c1-150 | sed -e "s/^/$1 names=$m  /")
+             python $R/profiles/summarize_rocpd.py stats /tmp/pk/t_results.db | grep -E "k_scatter|k_part_hist|k_split|k_hot|k_survey" | cut -c1-150 | sed -e "s/^/$1 names=$m  /")
         done
     }
     l1trace product | tee -a $OUT/l1trace.txt
