@@ -1638,15 +1638,20 @@ __global__ void k_v3_report(uint32_t *__restrict__ g_stats, unsigned long long *
     // is the survey stale?  The pairs level 1 did NOT turn into records (its hot windows took them) against the same
     // share of the first launch on these tables: stale_judge, lh_kernels_part2.h.  The lanes' launches share a set of
     // tables read-only; only the first launch on a set writes its header word, behind the survey that filled the set.
-    if (threadIdx.x == 6) {
+    // A launch on a stale survey keeps its level-1 region overflows to itself: the regions are sized for what the hot
+    // windows leave (k_survey_plan_h), so a survey whose windows take nothing any more overflows them -- and the engine
+    // reads rstat[0] as a stream clustered by name (it leaves the region kernels for 64 flips).  The stale word alone
+    // makes the next call survey again.
+    bool stale = false;
+    if (threadIdx.x == 0) {
         const unsigned long long rec = g_stats[1];
-        stale_judge(hdr, rstat, pairs > rec ? pairs - rec : 0ull, pairs);
+        stale = stale_judge(hdr, rstat, pairs > rec ? pairs - rec : 0ull, pairs);
     }
     if (threadIdx.x < 5) {
         const uint32_t v = g_stats[threadIdx.x];
         g_stats[threadIdx.x] = 0;
         const uint32_t at = threadIdx.x == 0 ? 0u : threadIdx.x + 1u;
-        if (v && rstat) __hip_atomic_fetch_add(rstat + at, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (v && rstat && !stale) __hip_atomic_fetch_add(rstat + at, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
