@@ -736,7 +736,7 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=Non
             f, l = tmerge.merge_snapshot(snap, M, plan="reduce_scatter")
         else:
             f, l = 0, M
-        o = snap.extract_view(PCTS, l - f, first=f)
+        o = snap.extract_compact(PCTS, l - f, first=f)   # the compact results (42 B per name): what the host layers take
         o = {k: v.copy() for k, v in o.items() if k in ("count", "nbuckets")}
         snap.release()
         return o, (f, l)
@@ -866,7 +866,9 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=Non
                    "step_pipelining": "value / ms_per_step: ingest of step i + 1 enqueued after flip i, before the host "
                                       "waits for merge i and extract i (the reference's reaper overlaps reduction with "
                                       "ingest, metrics.go:530-639); serial_ms_per_step and the per-phase times: the same "
-                                      "K steps with every phase drained before the next",
+                                      "K steps with every phase drained before the next (the serial steps extract the "
+                                      "full form, lh_extract_rows_view, so that their phase times compare with earlier "
+                                      "rounds; the pipelined steps the compact one, lh_extract_rows_compact)",
                    "names": M, "pairs_per_gpu_per_step": n, "ranks": world, "owned_rows": [first, last],
                    "merge": frontend, "percentiles": PCTS},
         "roofline": roofline(n * BYTES_PAIR, sum(t_ing) / len(t_ing),
