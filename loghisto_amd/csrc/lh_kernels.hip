@@ -100,7 +100,6 @@ constexpr int K1_UNROLL = LH_K1_UNROLL;             // 16-B loads in flight per 
 #endif
 constexpr uint32_t K1_COPIES = LH_K1_COPIES;
 constexpr uint32_t K1_WIN = 16384 / K1_COPIES;     // bins per copy
-constexpr uint32_t K1_WIN_LO = 32768 - K1_WIN / 2; // first bin of the default window
 // copy k starts K1_PAD words past a multiple of the 32 banks: the same bin of two copies must not share a bank, or
 // the copies would serialise on the bank what they no longer serialise on the word
 constexpr uint32_t K1_PAD = 16;
@@ -131,22 +130,23 @@ __device__ __forceinline__ void global_cell_add(uint64_t *row, uint32_t *range, 
 // [win_lo, + K1_WIN): ADJACENT to the main window when the sample is within K1_OVF bins of it -- the bins right next to
 // the main window are the dense ones of a stream slightly wider than it, and a window centred on a first miss 512 ..
 // 1 023 bins out would leave a gap of them on the global row -- centred on the sample only beyond that.
-__device__ __forceinline__ uint32_t k1_anchor(uint32_t bin, uint32_t win_lo)
+__device__ __forceinline__ uint32_t k1_anchor(uint32_t bin, uint32_t win_lo, uint32_t win_len)
 {
-    const uint32_t centred = bin >= K1_OVF / 2 ? bin - K1_OVF / 2 : 0u, win_hi = win_lo + K1_WIN;
+    const uint32_t centred = bin >= K1_OVF / 2 ? bin - K1_OVF / 2 : 0u, win_hi = win_lo + win_len;
     if (bin >= win_hi) return min(bin < win_hi + K1_OVF ? win_hi : centred, (uint32_t)LH_NKEYS - K1_OVF);
     const uint32_t below = win_lo >= K1_OVF ? win_lo - K1_OVF : 0u;
     return bin >= below ? below : centred;
 }
 
 // the sample missed the main window.  h0: the workgroup's LDS block.
-__device__ __forceinline__ void k1_miss(uint32_t *h0, uint32_t win_lo, uint64_t *row, uint32_t *range, uint32_t bin, uint32_t c)
+__device__ __forceinline__ void k1_miss(uint32_t *h0, uint32_t win_lo, uint32_t win_len, uint64_t *row, uint32_t *range,
+                                        uint32_t bin, uint32_t c)
 {
-    const uint32_t side = bin >= win_lo + K1_WIN ? 1u : 0u;
+    const uint32_t side = bin >= win_lo + win_len ? 1u : 0u;
     uint32_t *anchor = h0 + K1_MAIN_WORDS + 2 * K1_OVF + 2 + side;
     uint32_t lo = __atomic_load_n(anchor, __ATOMIC_RELAXED);
     if (lo == K1_OVF_NONE) {
-        const uint32_t want = k1_anchor(bin, win_lo);
+        const uint32_t want = k1_anchor(bin, win_lo, win_len);
         const uint32_t seen = atomicCAS(anchor, K1_OVF_NONE, want);
         lo = seen == K1_OVF_NONE ? want : seen;
     }
@@ -155,18 +155,21 @@ __device__ __forceinline__ void k1_miss(uint32_t *h0, uint32_t win_lo, uint64_t 
     else global_cell_add(row, range, bin, c);
 }
 
-// the workgroup's window state, wave-uniform: h0 = its LDS block, win_lo = first bin of its main window
+// the workgroup's window state, wave-uniform: h0 = its LDS block, win_lo = first bin of its main window, win_len = its
+// length: K1_WIN bins in K1_COPIES copies, or -- WIDE mode -- K1_WIDE bins in ONE copy that takes the copies' room
 struct K1Win {
     uint32_t *h0;
-    uint32_t win_lo;
+    uint32_t win_lo, win_len;
 };
+constexpr uint32_t K1_WIDE = K1_WIN * K1_COPIES; // 16 384 bins
+static_assert(K1_WIDE <= K1_MAIN_WORDS, "the wide window lies in the copies' words");
 
-// hc: this lane's copy of the main window
+// hc: this lane's copy of the main window (h0 for every lane in wide mode)
 __device__ __forceinline__ void k1_add(const K1Win w, uint32_t *hc, uint64_t *row, uint32_t *range, uint32_t bin, uint32_t c = 1u)
 {
     const uint32_t rel = bin - w.win_lo;
-    if (rel < K1_WIN) atomicAdd(&hc[rel], c);
-    else k1_miss(w.h0, w.win_lo, row, range, bin, c);
+    if (rel < w.win_len) atomicAdd(&hc[rel], c);
+    else k1_miss(w.h0, w.win_lo, w.win_len, row, range, bin, c);
 }
 
 // All 64 lanes active.  A wave whose samples mostly share ONE bucket (a constant stream; a stream dominated by one
@@ -201,7 +204,6 @@ __global__ __launch_bounds__(K1_BLOCK) void k_ingest_single(const double *__rest
     uint32_t *h0 = reinterpret_cast<uint32_t *>(smem);
     uint32_t *s_ctl = h0 + K1_MAIN_WORDS + 2 * K1_OVF; // [0] min bin, [1] max bin of the flush, [2] [3] floating anchors, [4] win_lo
     const uint32_t tid = threadIdx.x;
-    uint32_t *h = h0 + (tid % K1_COPIES) * K1_STRIDE;   // this lane's copy
 
     // 16-B alignment: at most one scalar head sample, then pairs, then an odd tail.
     const size_t head = (((uintptr_t)v & 8) && n) ? 1 : 0;
@@ -211,25 +213,38 @@ __global__ __launch_bounds__(K1_BLOCK) void k_ingest_single(const double *__rest
     const size_t nfull = npair / tile;
 
     for (uint32_t i = tid; i < K1_MAIN_WORDS + 2 * K1_OVF; i += K1_BLOCK) h0[i] = 0;
-    if (tid == 0) {
-        s_ctl[0] = 0xffffffffu;
-        s_ctl[1] = 0;
-        s_ctl[2] = s_ctl[3] = K1_OVF_NONE;
-        // the main window: the default one unless the first three samples of this workgroup's share all lie beyond the
-        // same end of it -- then the stream lives elsewhere and the window is centred on their median key.  (One or two
-        // of three is not enough: measured with the median alone deciding, a two-signed stream reaching 1e20 lost its
-        // other half to the global row in every tenth workgroup, 1.7 -> 6.3 ms per 1e9 samples.)
-        const size_t i0 = min(head + (size_t)blockIdx.x * tile * 2, n - 1);
-        const uint32_t b0 = lh_bin_of(v[i0], Tx), b1 = lh_bin_of(v[min(i0 + 1, n - 1)], Tx), b2 = lh_bin_of(v[min(i0 + 2, n - 1)], Tx);
-        const uint32_t lowest = min(b0, min(b1, b2)), highest = max(b0, max(b1, b2));
-        const uint32_t med = max(min(b0, b1), min(max(b0, b1), b2));
-        uint32_t lo = K1_WIN_LO;
-        if (lowest >= K1_WIN_LO + K1_WIN || highest < K1_WIN_LO)
-            lo = min(med >= K1_WIN / 2 ? med - K1_WIN / 2 : 0u, (uint32_t)LH_NKEYS - K1_WIN);
-        s_ctl[4] = lo;
+    // The main window follows the stream (round 6; rounds 4 - 5 looked at three samples and only moved the window when all
+    // three lay beyond the same end of the default one): wave 0 buckets 64 samples spread over the workgroup's first tile.
+    //   * their span fits a copy with room to spare (<= 7/8 K1_WIN bins): two copies of K1_WIN bins centred on the span --
+    //     every stream of the sweep but the two below, wherever it lives;
+    //   * it does not (a stream over 21 decades of one sign ends a few bins past the default window; one of both signs
+    //     to +-1e20 spans 9 211 bins): WIDE mode, ONE copy of 16 384 bins centred on the span.  The second copy is there
+    //     for few-valued streams (same-address atomics); a stream this wide has no such lanes to separate.
+    // What still falls outside goes to the floating windows as before.  loguniform[1e-3, 1e18] and +-10^U(-3, 20) ran at
+    // 1.58 ms per 1e9 samples (0.63 of peak) through the floating windows' branch; profiles/r06_k1_wide.txt.
+    if (tid < 64) {
+        const size_t i0 = min(head + (size_t)blockIdx.x * tile * 2 + (size_t)tid * (tile * 2 / 64), n - 1);
+        const uint32_t b = lh_bin_of(v[i0], Tx);
+        uint32_t lowest = b, highest = b;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            lowest = min(lowest, (uint32_t)__shfl_xor(lowest, d, 64));
+            highest = max(highest, (uint32_t)__shfl_xor(highest, d, 64));
+        }
+        if (tid == 0) {
+            s_ctl[0] = 0xffffffffu;
+            s_ctl[1] = 0;
+            s_ctl[2] = s_ctl[3] = K1_OVF_NONE;
+            const uint32_t len = highest - lowest < K1_WIN - K1_WIN / 8 ? K1_WIN : K1_WIDE;
+            const uint32_t mid = lowest + (highest - lowest) / 2;
+            s_ctl[4] = min(mid >= len / 2 ? mid - len / 2 : 0u, (uint32_t)LH_NKEYS - len);
+            s_ctl[5] = len;
+        }
     }
     __syncthreads();
-    const K1Win w = {h0, (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ctl[4])};
+    const K1Win w = {h0, (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ctl[4]),
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ctl[5])};
+    uint32_t *h = h0 + (w.win_len == K1_WIN ? (tid % K1_COPIES) * K1_STRIDE : 0u); // this lane's copy
 
     // (register double buffering -- tile t + grid in flight while tile t is bucketed -- measured slower,
     // profiles/r02_k1_variants.txt: two workgroups per CU already overlap each other's loads; a rolling refill of the
@@ -262,10 +277,12 @@ __global__ __launch_bounds__(K1_BLOCK) void k_ingest_single(const double *__rest
 
     // flush: one u64 atomic per occupied bin (the copies summed), then the floating windows that were anchored
     uint32_t lmin = 0xffffffffu, lmax = 0;
-    for (uint32_t i = tid; i < K1_WIN; i += K1_BLOCK) {
+    for (uint32_t i = tid; i < w.win_len; i += K1_BLOCK) {
         uint32_t c = h0[i];
+        if (w.win_len == K1_WIN) { // (wave-uniform; the wide window is one array)
 #pragma unroll
-        for (uint32_t k = 1; k < K1_COPIES; k++) c += h0[k * K1_STRIDE + i];
+            for (uint32_t k = 1; k < K1_COPIES; k++) c += h0[k * K1_STRIDE + i];
+        }
         if (c) {
             atomicAdd(reinterpret_cast<unsigned long long *>(&row[w.win_lo + i]), (unsigned long long)c);
             lmin = min(lmin, w.win_lo + i);
