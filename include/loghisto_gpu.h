@@ -377,6 +377,10 @@ typedef struct lh_counters {
     uint64_t samples_fallback;       /* samples that therefore went through the scratch-free kernel: exact, slower     */
     uint64_t survey_stale_pairs;     /* pairs a kept survey's hot windows no longer took (the values moved under it: the
                                         launch reports them, the next call surveys again)                              */
+    uint64_t lane_scratch_bytes;     /* (ABI 6) HBM the host-fed lanes' launches hold beside scratch_bytes: their scratch
+                                        blocks (up to LH_OPT_LANE_SCRATCH_BLOCKS of them, ~0.2 GiB each at 65 536 names;
+                                        LH_OPT_SCRATCH_CAP_BYTES bounds the shared block only) and the two sets of survey
+                                        tables the lanes share                                                         */
 } lh_counters;
 int lh_get_counters(lh_engine *e, lh_counters *out);
 
@@ -388,7 +392,9 @@ int lh_get_counters(lh_engine *e, lh_counters *out);
  *   LH_OPT_EXTRACT_ZERO_COPY  0 / 1: small extract results (<= 32 KiB) are stored by the kernel straight into pinned
  *                             host memory (default 1); a value >= 4096 also sets that size limit (measured: beyond
  *                             32 KiB the copy engine wins -- 1 024 names, 158 KB: 48 us by copy, 95 us by stores)
- *   LH_OPT_SCRATCH_CAP_BYTES  upper bound of the mixed ingest's scratch block (default 1.5 GiB, >= 64 MiB)
+ *   LH_OPT_SCRATCH_CAP_BYTES  upper bound of the mixed ingest's SHARED scratch block (default 1.5 GiB, >= 64 MiB); the
+ *                             host-fed lanes' own blocks are bounded by LH_OPT_LANE_SCRATCH_BLOCKS x a lane-sized launch's
+ *                             need and reported as lh_counters.lane_scratch_bytes
  *   LH_OPT_SUBLAUNCH_PAIRS    largest partitioned sub-launch, 2^22 .. 2^30 pairs, rounded down to a power of two
  *                             (default 2^29; a sub-launch is halved until its scratch fits the cap).
  *                             Engines with more than 8 192 names (two scatter levels: ~1.2 GB of chunk pools and

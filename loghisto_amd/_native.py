@@ -47,7 +47,8 @@ class LhCounters(C.Structure):
                                                                ("surveys_reused", C.c_uint64),
                                                                ("scratch_alloc_failures", C.c_uint64),
                                                                ("samples_fallback", C.c_uint64),
-                                                               ("survey_stale_pairs", C.c_uint64)]
+                                                               ("survey_stale_pairs", C.c_uint64),
+                                                               ("lane_scratch_bytes", C.c_uint64)]
 
 # lh_set_option keys (include/loghisto_gpu.h; the path-steering ones and the fault hook: include/loghisto_gpu_tuning.h)
 OPT_TWO_LEVEL_ABOVE, OPT_HOT_MIN_TILES, OPT_HOT_WINDOWS, OPT_NAMES_PER_PARTITION = 1, 2, 3, 4

@@ -504,12 +504,22 @@ int run_lane_block(lh_engine *e, EpochBuffer &b, PairsCall &c, const lh::Step &s
             lt.t[set].age = 1;
             lt.active = set;
         }
-        HIPCHK(lh::launch_ingest_pairs_part3(d_ids, d_v, st.take, survey_n, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx,
-                                             e->d_err, a->p, a->bytes, lt.p[set], e->num_cus, st.tune, e->d_rstat,
-                                             e->d_rstat ? reinterpret_cast<uint32_t *>(e->d_rstat + 1) : nullptr, s));
-        if (survey_n) {
-            HIPCHK(hipEventRecord(lt.ready[set], s));
-            lt.ready_stream[set] = s;
+        {
+            //  a surveying launch that fails leaves the set it was to fill unwritten: the set must not stay
+            // marked valid, or later launches would wait on an event that was never recorded and take their names from
+            // whatever the fresh allocation holds
+            hipError_t le = lh::launch_ingest_pairs_part3(d_ids, d_v, st.take, survey_n, b.counts, b.ranges, e->cfg.max_metrics,
+                                                          e->d_Tx, e->d_err, a->p, a->bytes, lt.p[set], e->num_cus, st.tune,
+                                                          e->d_rstat,
+                                                          e->d_rstat ? reinterpret_cast<uint32_t *>(e->d_rstat + 1) : nullptr, s);
+            if (le == hipSuccess && survey_n) {
+                le = hipEventRecord(lt.ready[set], s);
+                lt.ready_stream[set] = s;
+            }
+            if (le != hipSuccess) {
+                if (survey_n) lt.t[set].valid = false;
+                HIPCHK(le);
+            }
         }
         e->region_samples.fetch_add(st.take, std::memory_order_relaxed);
         e->c_part3.fetch_add(st.take, std::memory_order_relaxed);
@@ -620,17 +630,27 @@ int run_shared(lh_engine *e, EpochBuffer &b, PairsCall &c, const lh::Step &st, l
         // layout has no per-partition regions)
         if (!c.judged) judge_tables(e, c, gen, gen == 3 ? st.tune.v3_log_w : (st.tune.v2_shape & 3u));
         const size_t survey_n = c.surveyed ? 0 : n_left;
+        //  judge_tables has marked the tables valid for the launch that is about to fill them: if that launch
+        // cannot be enqueued they are not
+        hipError_t le;
         if (gen == 2) {
-            HIPCHK(lh::launch_ingest_pairs_part2(d_ids, d_v, st.take, survey_n, b.counts, b.ranges, e->cfg.max_metrics,
-                                                 e->d_Tx, e->d_err, e->scratch_p, e->scratch_bytes, e->num_cus, st.tune,
-                                                 e->d_rstat, s));
+            le = lh::launch_ingest_pairs_part2(d_ids, d_v, st.take, survey_n, b.counts, b.ranges, e->cfg.max_metrics,
+                                               e->d_Tx, e->d_err, e->scratch_p, e->scratch_bytes, e->num_cus, st.tune,
+                                               e->d_rstat, s);
+        } else {
+            le = lh::launch_ingest_pairs_part3(d_ids, d_v, st.take, survey_n, b.counts, b.ranges, e->cfg.max_metrics,
+                                               e->d_Tx, e->d_err, e->scratch_p, e->scratch_bytes, nullptr, e->num_cus, st.tune,
+                                               e->d_rstat, e->d_rstat ? reinterpret_cast<uint32_t *>(e->d_rstat + 1) : nullptr,
+                                               s);
+        }
+        if (le != hipSuccess) {
+            if (survey_n) { e->tables.valid = false; c.surveyed = false; }
+            HIPCHK(le);
+        }
+        if (gen == 2) {
             if (st.tune.v2_shape & 2u) e->region_samples.fetch_add(st.take, std::memory_order_relaxed);
             e->c_part2.fetch_add(st.take, std::memory_order_relaxed);
         } else {
-            HIPCHK(lh::launch_ingest_pairs_part3(d_ids, d_v, st.take, survey_n, b.counts, b.ranges, e->cfg.max_metrics,
-                                                 e->d_Tx, e->d_err, e->scratch_p, e->scratch_bytes, nullptr, e->num_cus, st.tune,
-                                                 e->d_rstat, e->d_rstat ? reinterpret_cast<uint32_t *>(e->d_rstat + 1) : nullptr,
-                                                 s));
             e->region_samples.fetch_add(st.take, std::memory_order_relaxed);
             e->c_part3.fetch_add(st.take, std::memory_order_relaxed);
         }
@@ -2497,6 +2517,13 @@ int lh_get_counters(lh_engine *e, lh_counters *out)
     out->small_path_disabled = e->small_disabled.load() ? 1u : 0u;
     out->regions_disabled = e->regions_disabled.load() ? 1u : 0u;
     out->scratch_bytes = e->c_scratch.load();
+    {   //  the lanes' blocks and their shared survey tables were reported nowhere
+        std::lock_guard<std::mutex> g(e->scratch_mu);
+        uint64_t lane = 0;
+        for (const lh_engine::AuxScratch &a : e->aux) lane += a.bytes;
+        if (e->lane_tables.p[0]) lane += 2 * (uint64_t)e->lane_tables.bytes;
+        out->lane_scratch_bytes = lane;
+    }
     out->sublaunches = e->c_sublaunches.load();
     out->samples_partitioned_v2 = e->c_part2.load();
     out->counter_events = e->c_counts.load();

@@ -14,7 +14,9 @@
 // 94 -> 66 us, the wave-per-row read 79 -> 74 us with rows 256 bytes further apart; packing the windows tightly buys
 // nothing beyond that.  Exposed to callers that index the device rows themselves as lh_row_stride().
 #ifndef LH_ROW_SKEW_CELLS
-#define LH_ROW_SKEW_CELLS 32 /* (tools/build_tuning.py -DLH_ROW_SKEW_CELLS=0: the packed rows of ABI <= 4, for A/B runs) */
+#define LH_ROW_SKEW_CELLS 32 /* (>= 4: k_extract_wave reads whole 4-bin groups past bin 65 535 and relies on the zero padding
+                                 behind the row and behind the D table -- lh_kernels.hip asserts it; an A/B build against
+                                 the packed rows of ABI <= 4 is -DLH_ROW_SKEW_CELLS=4, not 0) */
 #endif
 #define LH_ROW_STRIDE ((size_t)65536 + LH_ROW_SKEW_CELLS)
 

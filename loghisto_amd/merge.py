@@ -180,8 +180,11 @@ def merge_rows(rows: torch.Tensor, ranges: Optional[torch.Tensor] = None, plan: 
     # the owner blocks are those of the C-ABI front-end: equal shares of the WIRE WORDS, a row travelling at the narrowest
     # of 8 / 16 / 32 bits per cell that holds world x (its largest per-rank cell) -- one more MAX all-reduce here (the
     # C ABI lets it ride with the ranges).  This front-end itself moves int64 cells: only the block boundaries follow.
+    # (They follow the C ABI's while its wire words are uint32, i.e. while ranks x the largest per-rank sample count of the
+    # interval is below 2^32 -- every stream the tests and the bench merge; beyond that the C ABI sends uint64 words and
+    # cuts its blocks on those, which this front-end does not model.)
     bits = None
-    if narrow:
+    if narrow and plan != "allreduce":   # (with one owner block the widths only fed last_info -- no collective for that)
         rowmax = torch.zeros(nrows, dtype=torch.int64, device=rows.device)
         rowmax.scatter_reduce_(0, row_of, mine, "amax", include_self=True)
         dist.all_reduce(rowmax, op=dist.ReduceOp.MAX, group=group)

@@ -57,7 +57,7 @@ def test_struct_layouts_match_header(native_lib):
     from loghisto_amd import _native
     assert C.sizeof(_native.LhConfig) == 32
     assert C.sizeof(_native.LhStats) == 40
-    assert C.sizeof(_native.LhLineFormat) == 32 and C.sizeof(_native.LhCounters) == 208
+    assert C.sizeof(_native.LhLineFormat) == 32 and C.sizeof(_native.LhCounters) == 216
     assert C.sizeof(_native.LhMergeInfo) == 88 and C.sizeof(_native.LhExtractView) == 48
     cfg = _native.LhConfig()
     assert native_lib.lh_default_config(C.byref(cfg)) == 0
