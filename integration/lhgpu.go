@@ -52,6 +52,7 @@ type gpuEngine struct {
 	all    []*stage   // every stage ever handed out, for the flush at the flip
 	allMu  sync.Mutex
 	narrow bool       // <= 65 536 names: ids cross PCIe as uint16 (lh_reserve_pairs16: 10 B per sample, not 12)
+	decompress [65536]float64 // decompress(key) by dense bin uint16(key) ^ 0x8000, as the device generated it (lh_codec_tables)
 }
 
 func newGPUEngine(maxMetrics int) *gpuEngine {
@@ -63,6 +64,10 @@ func newGPUEngine(maxMetrics int) *gpuEngine {
 	if rc := C.lh_create(&cfg, &g.e); rc != C.LH_OK {
 		glog.Errorf("lh_create: %s (%s)", C.GoString(C.lh_strerror(rc)), C.GoString(C.lh_last_error()))
 		return nil // caller falls back to refusing Histogram; there is no CPU path in the library
+	}
+	// the decompress table, once: what a compact extract's keys are turned into values with (processHistogramsGPU)
+	if rc := C.lh_codec_tables(g.e, nil, (*C.double)(unsafe.Pointer(&g.decompress[0]))); rc != C.LH_OK {
+		glog.Errorf("lh_codec_tables: %s", C.GoString(C.lh_strerror(rc)))
 	}
 	g.pool.New = func() interface{} {
 		s := new(stage)
@@ -167,27 +172,39 @@ func (ms *MetricSystem) processHistogramsGPU(raw *RawMetricSet, out map[string]f
 	for l, p := range ms.percentiles { labels = append(labels, l); ps = append(ps, C.double(p)) }
 	n := len(ms.gpu.names)
 	if raw.snap == nil || n == 0 { return }
-	stats := make([]C.lh_stats, n)
-	pvals := make([]C.double, n*len(ps))
-	pvalid := make([]C.uint8_t, n*len(ps))
-	rc := C.lh_extract(raw.snap, &ps[0], C.size_t(len(ps)), &stats[0], &pvals[0], nil, &pvalid[0], C.size_t(n))
-	C.lh_release(raw.snap)
-	if rc != C.LH_OK { glog.Errorf("lh_extract: %s", C.GoString(C.lh_strerror(rc))); return }
+	// The COMPACT results (ABI 6, lh_extract_rows_compact): count, sum, the selected keys and a word of valid bits per
+	// name, in place in the engine's pinned block -- 42 B per name instead of 139 B.  Everything else processHistograms
+	// emits is a function of these: _avg = sum / float64(count) (metrics.go:356), the lifetime add uint64(sum)
+	// (metrics.go:374), a percentile's value = decompress(key) (metrics.go:326-332) = the device-generated table
+	// D[] that newGPUEngine read once with lh_codec_tables.
+	var c C.lh_extract_compact
+	rc := C.lh_extract_rows_compact(raw.snap, 0, C.size_t(n), &ps[0], C.size_t(len(ps)), &c)
+	if rc != C.LH_OK {
+		C.lh_release(raw.snap)
+		glog.Errorf("lh_extract_rows_compact: %s", C.GoString(C.lh_strerror(rc)))
+		return
+	}
+	np := len(ps)
+	count := unsafe.Slice((*uint64)(unsafe.Pointer(c.count)), n) // views of C memory: valid until the next
+	sum := unsafe.Slice((*float64)(unsafe.Pointer(c.sum)), n)     // lh_extract* / lh_release on this engine
+	keys := unsafe.Slice((*int16)(unsafe.Pointer(c.pkeys)), n*np)
+	valid := unsafe.Slice((*uint32)(unsafe.Pointer(c.pvalid_bits)), n)
+	D := &ms.gpu.decompress // [65536]float64, indexed by the dense bin uint16(key) ^ 0x8000
 	for id, name := range ms.gpu.names {
-		st := stats[id]
-		if st.present == 0 { continue }            // name absent from this interval
-		out[name+"_count"] = float64(st.count)
-		out[name+"_sum"] = float64(st.sum)
-		out[name+"_avg"] = float64(st.avg)
-		ms.addAggregates(name, uint64(st.agg_sum_add), uint64(st.count)) // metrics.go:359-376
+		if count[id] == 0 { continue }            // name absent from this interval
+		out[name+"_count"] = float64(count[id])
+		out[name+"_sum"] = sum[id]
+		out[name+"_avg"] = sum[id] / float64(count[id])
+		ms.addAggregates(name, uint64(sum[id]), count[id]) // metrics.go:359-376
 		for i, l := range labels {
-			if pvalid[id*len(ps)+i] != 0 {
-				out[fmt.Sprintf(l, name)] = float64(pvals[id*len(ps)+i])
+			if valid[id]>>uint(i)&1 != 0 {
+				out[fmt.Sprintf(l, name)] = D[uint16(keys[id*np+i])^0x8000]
 			} else {
 				glog.Errorf("unable to calculate percentile: %s", "Invalid percentile.  Should be between 0 and 1.")
 			}
 		}
 	}
+	C.lh_release(raw.snap)
 }
 
 func (raw *RawMetricSet) fillHistograms(g *gpuEngine) {
