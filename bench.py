@@ -46,10 +46,10 @@ HBM_PEAK_GBS = 8000.0                                    # MI355X_MICROARCH.md: 
 PCIE_GBS = 63.0                                          # PCIe Gen5 x16 (spec)
 BYTES_SINGLE, BYTES_PAIR, BYTES_PAIR16 = 8, 12, 10        # float64 / float64 + uint32 id / + uint16 id
 METRIC = "float64 samples/sec bucketed (1 GPU) + % HBM roofline; p99 extract latency"
-K1_PMC = os.path.join("profiles", "r05_k1_pmc.json")
-C3_PMC = os.path.join("profiles", "r05_c3_pmc.json")
-C4_PMC = os.path.join("profiles", "r05_c4_pmc.json")
-C4_1E9_PMC = os.path.join("profiles", "r05_c4_names_1e9_pmc.json")
+K1_PMC = os.path.join("profiles", "r06_k1_pmc.json")
+C3_PMC = os.path.join("profiles", "r06_c3_pmc.json")
+C4_PMC = os.path.join("profiles", "r06_c4_pmc.json")
+C4_1E9_PMC = os.path.join("profiles", "r06_c4_names_1e9_pmc.json")
 PREWARM = 25                                             # untimed K1 launches before the warm-up steps (run_c2)
 
 
@@ -70,6 +70,24 @@ def source_hashes(kind):
         with open(os.path.join(ROOT, "loghisto_amd", "csrc", f), "rb") as fh:
             out[f] = hashlib.sha256(fh.read()).hexdigest()[:16]
     return out
+
+
+# Every measurement that claims to describe THIS tree carries one short stamp of the sources a result can depend on: the
+# bench line has it (`tree_stamp`), tools/profile_round.sh writes it into every file it produces, and
+# tests/test_profiles_fresh.py holds the committed profiles/r06_* evidence to it (a sweep committed
+# before two later kernel changes was still quoted as "final").
+STAMP_SOURCES = ["lh_kernels.hip", "lh_kernels_part.hip", "lh_kernels_part2.h", "lh_kernels_part3.h", "lh_kernels_small.hip",
+                 "lh_kernels_fmt.hip", "lh_codec.h", "lh_windows.h", "lh_ids.h", "lh_kernels.h", "lh_dispatch.cc",
+                 "lh_dispatch.h", "lh_engine.cc"]
+
+
+def tree_stamp():
+    import hashlib
+    h = hashlib.sha256()
+    for f in STAMP_SOURCES:
+        with open(os.path.join(ROOT, "loghisto_amd", "csrc", f), "rb") as fh:
+            h.update(hashlib.sha256(fh.read()).digest())
+    return h.hexdigest()[:16]
 
 
 def pmc_stale(j, kind):
@@ -1170,7 +1188,8 @@ def main():
         raise SystemExit("several GPUs run the C2 headline (auto / c2) or config 4 (c4)")
 
     base = {"metric": METRIC, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "tree_stamp": tree_stamp()}
     comm, frontend, why = (0, "none", "")
     if world > 1:
         comm, frontend, why = make_comm(world, rank, dist)   # ONE communicator for the job: headline and secondary.c4
