@@ -42,7 +42,11 @@ rocprofv3 --pmc WRITE_SIZE -d /tmp/pr_c3w -o t -- $CMD3 > /dev/null 2>&1
 CMD4="python $R/bench.py --workload c4 --steps 3 --warmup 1 --no-parity --latency-flips 0"
 rm -rf /tmp/pr_c4t /tmp/pr_c4f /tmp/pr_c4w
 rocprofv3 --kernel-trace -d /tmp/pr_c4t -o t -- $CMD4 > $OUT/c4_under_trace.json 2>/dev/null
-{ echo "# tree_stamp: $STAMP"; echo "# rocprofv3 --kernel-trace -- $CMD4"; python $R/profiles/summarize_rocpd.py stats /tmp/pr_c4t/t_results.db | grep -E "^#|^kernel|lh::" | cut -c1-170; } > $OUT/c4_kernel_trace.txt
+{ echo "# tree_stamp: $STAMP"; echo "# rocprofv3 --kernel-trace -- $CMD4"; python $R/profiles/summarize_rocpd.py stats /tmp/pr_c4t/t_results.db | grep -E "^#|^kernel|lh::" | cut -c1-170
+  # the small merge / plan kernels launch by launch, in start order (10 - 60 x spreads): the run makes 4 SERIAL
+  # steps (every phase drained: the kernel alone on the GPU) and then 4 PIPELINED ones (the kernel beside the next step's level 1,
+  # which holds every CU's LDS: its workgroups wait for a CU)
+  for k in k_merge_widths k_merge_prep k_plan_scan; do python $R/profiles/summarize_rocpd.py list /tmp/pr_c4t/t_results.db $k | cut -c1-200; done; } > $OUT/c4_kernel_trace.txt
 rocprofv3 --pmc FETCH_SIZE -d /tmp/pr_c4f -o t -- $CMD4 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE -d /tmp/pr_c4w -o t -- $CMD4 > /dev/null 2>&1
 python - <<PY
