@@ -1063,6 +1063,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
             }
         }
     };
+    uint32_t seq_lines = tid >> 2; // (ABL 64: this thread group's position in the workgroup's sequential stream)
     auto flush = [&](const uint32_t par) {
         if (ABL & 2u) return;
         __syncthreads();                                   // barrier A: the records of the tile(s) are in the regions
@@ -1117,6 +1118,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
 #pragma unroll
                     for (uint32_t i = 0; i < 4 / TPP; i++) {
                         if (ABL & 4u) asm volatile("" : : "v"(r4[i]), "v"(dst));
+                        else if (ABL & 64u) // the same bytes to ONE sequential stream per workgroup (its pool, front to back)
+                            hidden_store_u4(records + (size_t)pool_base * CHUNK + ((seq_lines += BLOCK / 4) % (chunks_per_wg * (CHUNK / LINE2))) * LINE2 + (q + i * TPP) * 8, r4[i]);
                         else hidden_store_u4(records + dst + (q + i * TPP) * 8, r4[i]);
                     }
                 }

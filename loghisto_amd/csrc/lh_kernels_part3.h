@@ -583,6 +583,7 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
             }
         }
     };
+    uint32_t seq_lines = tid >> 2; // (ABL 64: this thread group's position in the workgroup's sequential stream)
     auto flush = [&](const uint32_t par) {
         if (ABL & 2u) return;
         __syncthreads();                                   // barrier A: the tile's records are in the regions
@@ -626,6 +627,8 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
                     const uint32_t dst = (l < room ? dA : dB) + l * LINE4;
                     const pu4_t r4 = *reinterpret_cast<const pu4_t *>(src + l * LINE4 + q * 4);
                     if (ABL & 4u) asm volatile("" : : "v"(r4), "v"(dst));
+                    else if (ABL & 64u) // the same bytes to ONE sequential stream per workgroup (its pool, front to back)
+                        hidden_store_u4(records + (size_t)pool_base * CHUNK + ((seq_lines += BLOCK / 4) % (chunks_per_wg * (CHUNK / LINE4))) * LINE4 + q * 4, r4);
                     else hidden_store_u4(records + dst + q * 4, r4);
                 }
                 // the leftover (less than a piece) moves to the front of the region: thread q moves 16-byte pieces q,
@@ -938,8 +941,7 @@ __global__ __launch_bounds__(1024, 4) void k_split_records(const uint32_t *__res
                 for (uint32_t l = lane >> 2; l < full; l += 16) {
                     const uint32_t dst = (l < room ? dA : dB) + l * LINE4;
                     const pu4_t r4 = *reinterpret_cast<const pu4_t *>(src + l * LINE4 + q * 4);
-                    if (ABL & 4u) asm volatile("" : : "v"(r4), "v"(dst));
-                    else hidden_store_u4(records + dst + q * 4, r4);
+                    hidden_store_u4(records + dst + q * 4, r4);
                 }
                 // the last partial line moves to the front (LDS operations of one wave execute in order: the reads of
                 // line 0 above are done)
