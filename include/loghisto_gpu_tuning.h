@@ -30,6 +30,9 @@ extern "C" {
  *   LH_OPT_PART_V2_SHAPE      bit 0: two 512-thread scatter workgroups per CU over <= 128 partitions instead of one
  *                             1 024-thread workgroup over <= 256; bit 1: fixed per-partition LDS regions (records
  *                             placed by the classifying phase) instead of the exact per-tile layout.  Default 2.
+ *                             6 (bits 1 + 2, <= 1 024 names): the WIDE shape, 512 partitions of two names with 16 384-bin
+ *                             reduce windows -- the engine takes it by itself while the survey reports value spans wider
+ *                             than 8 192 bins (two-signed streams over 40 decades); setting 6 forces it.
  *                             With bit 1 set the engine falls back to the exact layout while more than 2 % of an
  *                             interval's samples overflow their regions (a stream clustered by name), see
  *                             lh_counters.regions_disabled

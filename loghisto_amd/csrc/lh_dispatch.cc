@@ -69,7 +69,9 @@ Step choose_step(const DispatchState &st, uintptr_t ids, uint32_t id_width, uint
         const bool bounded = !two_level || st.scratch_cap_set || st.sublaunch_set;
         size_t sub = (bounded && take > st.sublaunch_pairs) ? st.sublaunch_pairs : take;
         PartTuning tune = st.tune;
-        if (st.regions_disabled) tune.v2_shape &= ~2u; // clustered stream: the exact-layout scatter
+        // wide value spans over few names: 512 partitions of two names x 16 384 bins instead of 256 x four names x 8 192
+        if (st.call_wide && M <= 1024u && (tune.v2_shape & 7u) == 2u) tune.v2_shape |= 4u;
+        if (st.regions_disabled) tune.v2_shape &= ~6u; // clustered stream: the exact-layout scatter
         if (st.v3_disabled) tune.v3 = false;            // skew-free names: first generation
         tune.v3_log_w = st.call_log_w;
         // generation 2 (survey + 2-byte records) for <= 8 192 names, generation 3 above, when the launch is large enough;

@@ -35,6 +35,7 @@ struct DispatchState {
     size_t lane_samples = 0;       // lh_config.lane_samples: the lanes' blocks are sized for it
     PartTuning tune;               // lh_set_option
     uint32_t call_log_w = 10;      // third generation: the window width this call runs with (the last survey's report)
+    bool call_wide = false;        // second generation: the last survey saw spans wider than the 8 192-bin reduce windows
     bool small_disabled = false;   // adaptive switches (lh_engine: window misses / region overflows / forwarded share)
     bool regions_disabled = false;
     bool v3_disabled = false;

@@ -628,7 +628,7 @@ int run_shared(lh_engine *e, EpochBuffer &b, PairsCall &c, const lh::Step &st, l
     } else {
         // what the tables were laid out for: the window width (third generation) / the scatter shape (second: the exact
         // layout has no per-partition regions)
-        if (!c.judged) judge_tables(e, c, gen, gen == 3 ? st.tune.v3_log_w : (st.tune.v2_shape & 3u));
+        if (!c.judged) judge_tables(e, c, gen, gen == 3 ? st.tune.v3_log_w : (st.tune.v2_shape & 7u));
         const size_t survey_n = c.surveyed ? 0 : n_left;
         //  judge_tables has marked the tables valid for the launch that is about to fill them: if that launch
         // cannot be enqueued they are not
@@ -692,9 +692,12 @@ void snapshot_dispatch(lh_engine *e, PairsCall &c)
     // the sub-launches of a call share the survey's per-partition tables, which are laid out for one width, and the
     // call's own survey stores its report while later sub-launches are still being enqueued.
     c.st.call_log_w = c.st.tune.v3_log_w;
-    if (!log_w_fixed) {
+    {
         const uint32_t lw = (uint32_t)__atomic_load_n(&e->h_rstat[1], __ATOMIC_RELAXED);
-        if (lw >= 10 && lw <= 13) c.st.call_log_w = lw;
+        if (!log_w_fixed && lw >= 10 && lw <= 13) c.st.call_log_w = lw;
+        // second generation (<= 8 192 names): its survey reports 13 / 14 in the same word -- 14: spans wider than the
+        // 8 192-bin reduce windows carry at least 5 % of the sampled mass
+        c.st.call_wide = e->cfg.max_metrics <= 8192 && lw == 14;
     }
 }
 
@@ -2597,7 +2600,7 @@ int lh_set_option(lh_engine *e, int option, uint64_t value)
         if (value > 1) return LH_EINVAL;
         return set_tune(e, [&](lh::PartTuning &t) { t.v2 = value != 0; });
     case LH_OPT_PART_V2_SHAPE:
-        if (value > 3) return LH_EINVAL;
+        if (value > 3 && value != 6) return LH_EINVAL; // (6: the wide shape forced; the engine picks it itself from the survey's report)
         return set_tune(e, [&](lh::PartTuning &t) { t.v2_shape = (uint32_t)value; });
     case LH_OPT_PART_V2_MIN_PAIRS:
         if (value < (1u << 17) || value > (uint64_t(1) << 31)) return LH_EINVAL;

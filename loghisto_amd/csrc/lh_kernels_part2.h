@@ -241,10 +241,11 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__rest
                                                           uint32_t nmetrics, uint32_t log_w, uint32_t cells_in,
                                                           const RegionFit rf,
                                                           NameEntry *__restrict__ nt, pu4_t *__restrict__ hs,
-                                                          uint32_t *__restrict__ hdr, pu2_t *__restrict__ g_pt)
+                                                          uint32_t *__restrict__ hdr, pu2_t *__restrict__ g_pt,
+                                                          uint32_t *span_out)
 {
     __shared__ uint32_t s_a[V2_BLOCK / 64], s_b[V2_BLOCK / 64];
-    __shared__ uint32_t s_pc[256], s_cap[256];
+    __shared__ uint32_t s_pc[512], s_cap[512];
     const uint32_t gap = rf.cell_gap;
     constexpr uint32_t EMAX = V2_MAX_NAMES / V2_BLOCK;
     const uint32_t tid = threadIdx.x;
@@ -306,8 +307,20 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__rest
             }
         }
     }
-    uint32_t total_cnt, dummy;
-    block_sum2(mysum, 0, s_a, s_b, total_cnt, dummy);
+    uint32_t total_cnt, wide_cnt;
+    {   // the sampled mass of the names whose span is wider than the 8 192-bin reduce window of four names per partition
+        uint32_t mywide = 0;
+#pragma unroll
+        for (uint32_t e = 0; e < EMAX; e++)
+            if (cnt[e] >= 16u && span[e] > 8192u) mywide += cnt[e];
+        block_sum2(mysum, mywide, s_a, s_b, total_cnt, wide_cnt);
+    }
+    // ... reported to the engine (pinned word, as the third generation reports its window class): 14 = at least 5 % of the
+    // sampled mass would miss 8 192-bin windows -- the following calls over <= 1 024 names take the WIDE shape (512
+    // partitions of two names x 16 384 bins); 13 otherwise
+    if (tid == 0 && span_out && total_cnt)
+        __hip_atomic_store(span_out, (unsigned long long)wide_cnt * 20ull >= total_cnt ? 14u : 13u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
 
     // names that carry at least 1/64 of the surveyed samples may have 512-bin windows, the others 256
     const uint32_t big = total_cnt / 64u;
@@ -340,7 +353,7 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__rest
         // the regions for THIS choice of hot names, then the windows once more with what the regions leave (a superset of
         // the first choice, so the regions stay large enough)
         const uint32_t np = 1u << rf.log_np;
-        if (tid < 256) s_pc[tid] = 0;
+        if (tid < 512) s_pc[tid] = 0;
         __syncthreads();
 #pragma unroll
         for (uint32_t e = 0; e < EMAX; e++)
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__rest
             cap = (est * SC3_CAP_NUM / 4u + 8u + PIECE2 + 31u) & ~31u;
             if (cap > rf.tile + PIECE2) cap = rf.tile + PIECE2; // leftover (< one piece) + a whole tile
         }
-        if (tid < 256) s_cap[tid] = cap;
+        if (tid < 512) s_cap[tid] = cap;
         __syncthreads();
         uint32_t base = 0;
         for (uint32_t i = 0; i < np; i++) {
@@ -861,10 +874,6 @@ constexpr uint32_t ABL = LH_ABL;
 #define LH_SC3_BATCH 4
 #endif
 constexpr int SC3_BATCH = LH_SC3_BATCH;              // samples classified together (4 or 8)
-#ifndef LH_SC3_FLUSH_TPP
-#define LH_SC3_FLUSH_TPP 4
-#endif
-constexpr uint32_t SC3_FLUSH_TPP = LH_SC3_FLUSH_TPP; // flush-phase threads per partition (1, 2 or 4)
 #ifndef LH_SC3_TILES_PER_FLUSH
 #define LH_SC3_TILES_PER_FLUSH 1
 #endif
@@ -890,7 +899,9 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
     // ONE LDS allocation: [Scatter3Lds][name table][regions][hot windows]
     typedef Scatter3LdsT<NPT> LdsT;
     static_assert(sizeof(LdsT) % 16 == 0, "the name table follows the struct in LDS");
-    static_assert(BLOCK == 4 * NPT, "flush: four threads per partition");
+    // copy-out threads per partition: four (a 16-byte piece of a line each) -- or two, in the WIDE shape <1024, 512>
+    constexpr uint32_t TPP = BLOCK / NPT;
+    static_assert(BLOCK == (int)(TPP * NPT) && (TPP == 2 || TPP == 4), "copy-out: two or four threads per partition");
     constexpr int V3_TILE = BLOCK * V2_SPT;
     extern __shared__ __attribute__((aligned(16))) unsigned char v2_smem[];
     LdsT &L = *reinterpret_cast<LdsT *>(v2_smem);
@@ -932,7 +943,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
     ov_init(L.ov_key, L.ov_cnt, tid, BLOCK);
     if (tid == 0) { L.pool_next = 0; L.ovn = 0; L.spills = 0; L.missn[0] = 0; L.missn[1] = 0; }
     __syncthreads();
-    pu2_t my_pt = L.pt[tid >> 2]; // the flush phase's partition (constant over the launch)
+    pu2_t my_pt = L.pt[tid / TPP]; // the flush phase's partition (constant over the launch)
     my_pt.x = (my_pt.x - lds_base) >> 1;  // (halfword index)
 
     const pd2_t *vp = reinterpret_cast<const pd2_t *>(v);
@@ -1063,7 +1074,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
             }
         }
     };
-    uint32_t seq_lines = tid >> 2; // (ABL 64: this thread group's position in the workgroup's sequential stream)
+    uint32_t seq_lines = tid / TPP; // (ABL 64: this thread group's position in the workgroup's sequential stream)
     auto flush = [&](const uint32_t par) {
         if (ABL & 2u) return;
         __syncthreads();                                   // barrier A: the records of the tile(s) are in the regions
@@ -1077,14 +1088,11 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
         // .. of every line).  With TPP = 1 only the first NPT threads -- one wave per SIMD -- run this phase and the
         // other waves go straight to the barrier.
         if (tid == BLOCK - 1) L.missn[par ^ 1u] = 0; // the other parity's queue was drained in the previous tile
-        constexpr uint32_t TPP = SC3_FLUSH_TPP;
-        static_assert(TPP == 1 || TPP == 2 || TPP == 4, "pieces of a 64-byte line per thread: 4 / TPP");
         if (tid < NPT * TPP) {
             uint32_t t2 = tid;
             asm volatile("" : "+v"(t2)); // keeps this phase's address arithmetic inside the loop (see k_scatter2)
             const uint32_t p = t2 / TPP, q = t2 % TPP;
-            pu2_t e = my_pt;
-            if (TPP != 4) { e = L.pt[p]; e.x = (e.x - lds_base) >> 1; }
+            const pu2_t e = my_pt;
             // whole pieces only: `full` lines leave (a multiple of SC3_PIECE), fewer than PIECE2 records stay behind
             const uint32_t c = min(L.cnt[p], e.y), full = c / PIECE2 * SC3_PIECE, left = c - full * LINE2;
             if (full) {
@@ -1176,7 +1184,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
 
     // ---- drain: the regions' leftovers (< one line each) and the open chunks' descriptors
     {
-        const uint32_t p = tid >> 2, q = tid & 3u;
+        const uint32_t p = tid / TPP, q = tid % TPP;
         const uint32_t left = L.cnt[p]; // < PIECE2 after a flush
         uint32_t d = INVALID;
         if (left && q == 0) {
@@ -1190,12 +1198,17 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
             d = cb * CHUNK + cf;
             L.cfill[p] = cf + left;
         }
-        d = __builtin_amdgcn_mov_dpp(d, 0x00, 0xf, 0xf, false);
+        d = TPP == 4 ? __builtin_amdgcn_mov_dpp(d, 0x00, 0xf, 0xf, false)   // quad_perm [0,0,0,0]: q == 0's value
+                     : __builtin_amdgcn_mov_dpp(d, 0xa0, 0xf, 0xf, false);  // quad_perm [0,0,2,2]
 #pragma unroll
         for (uint32_t j = 0; j < SC3_PIECE; j++)
-            if (left && j * LINE2 + q * 8 < left)
-                *reinterpret_cast<pu4_t *>(records + d + j * LINE2 + q * 8) =
-                    *reinterpret_cast<const pu4_t *>(lds16 + ((L.pt[p].x - lds_base) >> 1) + j * LINE2 + q * 8);
+#pragma unroll
+            for (uint32_t i = 0; i < 4 / TPP; i++) {
+                const uint32_t piece = q + i * TPP; // 16-byte pieces 0 .. 3 of the line
+                if (left && j * LINE2 + piece * 8 < left)
+                    *reinterpret_cast<pu4_t *>(records + d + j * LINE2 + piece * 8) =
+                        *reinterpret_cast<const pu4_t *>(lds16 + my_pt.x + j * LINE2 + piece * 8);
+            }
     }
     if (tid == 0) L.dummy[0] = 0; // (no sample targets the dummy words any more) the workgroup's hot-window hits
     __syncthreads();
@@ -1452,7 +1465,9 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist2(const rec16_t *__restri
 // plan + launcher
 // ---------------------------------------------------------------------------
 struct Part2Plan {
-    uint32_t shape;            // bit 0: 0 = <1024, 256>, 1 = <512, 128>; bit 1: direct record stores (k_scatter3)
+    uint32_t shape;            // bit 0: 0 = <1024, 256>, 1 = <512, 128>; bit 1: direct record stores (k_scatter3);
+                               // bit 2 (with bit 1, without bit 0, <= 1 024 names): WIDE, <1024, 512> -- two names per
+                               // partition, 16 384-bin reduce windows
     uint32_t block, tile, lds_fixed;
     uint32_t log_np, np, mpp, log_w, cells, g1, chunks_per_wg, nchunks;
     uint32_t region_recs;      // shapes 2, 3: upper bound of the records of LDS the partitions' regions take
@@ -1465,23 +1480,24 @@ static bool make_plan2(size_t n, uint32_t nmetrics, int num_cus, const PartTunin
 {
     if (!tune.v2 || n < (tune.v2_min_samples ? tune.v2_min_samples : V2_MIN_SAMPLES) || n > (size_t(1) << 31)) return false;
     if (nmetrics < 2 || nmetrics > V2_MAX_NAMES) return false;
-    P.shape = tune.v2_shape & 3u;
-    const bool half = P.shape & 1u, direct = P.shape & 2u;
-    const uint32_t npt = half ? 128u : 256u, wgs_per_cu = half ? 2u : 1u;
+    P.shape = tune.v2_shape & 7u;
+    if ((P.shape & 4u) && ((P.shape & 3u) != 2u || nmetrics > 1024u)) P.shape &= 3u; // wide: the region kernel, one workgroup per CU, few names
+    const bool half = P.shape & 1u, direct = P.shape & 2u, wide = P.shape & 4u;
+    const uint32_t npt = wide ? 512u : half ? 128u : 256u, wgs_per_cu = half ? 2u : 1u;
     P.block = half ? 512u : 1024u;
     P.tile = P.block * V2_SPT;
     if (direct)
-        P.lds_fixed = (uint32_t)(half ? sizeof(Scatter3LdsT<128>) : sizeof(Scatter3LdsT<256>));
+        P.lds_fixed = (uint32_t)(wide ? sizeof(Scatter3LdsT<512>) : half ? sizeof(Scatter3LdsT<128>) : sizeof(Scatter3LdsT<256>));
     else
         P.lds_fixed = (uint32_t)(half ? sizeof(Scatter2LdsT<512, 128>) : sizeof(Scatter2LdsT<1024, 256>));
-    const uint32_t names_per_part = half ? 8u : 4u;
+    const uint32_t names_per_part = wide ? 2u : half ? 8u : 4u;
     const uint32_t want_np = (nmetrics + names_per_part - 1) / names_per_part;
     P.log_np = std::min(ilog2_ceil(npt), ilog2_ceil(want_np));
     P.np = 1u << P.log_np;
     P.mpp = (nmetrics + P.np - 1) >> P.log_np;
     if (P.mpp > PART_MAX_MPP) return false;
     uint32_t lw = 0;
-    while ((P.mpp << (lw + 1)) <= P2V2_WINWORDS && lw < 13) lw++;
+    while ((P.mpp << (lw + 1)) <= P2V2_WINWORDS && lw < (wide ? 14u : 13u)) lw++;
     P.log_w = lw; // cold window = 2^log_w bins per name; the record (local << log_w | offset) is < 32 768
     // hot windows: whatever LDS is left beside the scatter structures and the per-name table
     const size_t budget = V2_LDS_TOTAL / wgs_per_cu;
@@ -1522,7 +1538,7 @@ static bool make_plan2(size_t n, uint32_t nmetrics, int num_cus, const PartTunin
     P.off_nt = take((size_t)nmetrics * sizeof(NameEntry));
     P.off_hs = take((size_t)V2_MAX_SLOTS * sizeof(pu4_t));
     P.off_hdr = take(64);
-    P.off_pt = take(256 * sizeof(pu2_t));
+    P.off_pt = take(512 * sizeof(pu2_t));
     P.off_hot = take(direct ? (size_t)P.fit.max_cells * 2 * ((size_t)num_cus * wgs_per_cu) : 0); // k_scatter3's windows, one copy per workgroup
     P.off_rec = take((size_t)P.nchunks * CHUNK * sizeof(rec16_t));
     P.off_cd = take((size_t)P.nchunks * sizeof(uint32_t));
@@ -1568,6 +1584,9 @@ static hipError_t launch_part2_t(const IDT *d_ids, const double *d_v, size_t n, 
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter3<512, 128, SC3_BATCH, IDT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(V2_LDS_TOTAL / 2));
         if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter3<1024, 512, SC3_BATCH, IDT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)V2_LDS_TOTAL);
+        if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_survey_count<IDT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(V2_MAX_NAMES * 16));
         if (e == hipSuccess)
@@ -1603,7 +1622,8 @@ static hipError_t launch_part2_t(const IDT *d_ids, const double *d_v, size_t n, 
         hipLaunchKernelGGL(k_survey_count<IDT>, dim3(sv_grid), dim3(V2_BLOCK), sv_dyn, s, d_ids, d_v, survey_n, nmetrics,
                            d_Tx, g_cnt, g_mninv, g_mx, g_sum);
         hipLaunchKernelGGL(k_survey_plan, dim3(1), dim3(V2_BLOCK), 0, s, g_cnt, g_mninv, g_mx, g_sum, nmetrics,
-                           P.log_w, P.cells, P.fit, g_nt, g_hs, g_hdr, g_pt);
+                           P.log_w, P.cells, P.fit, g_nt, g_hs, g_hdr, g_pt,
+                           region_stat ? reinterpret_cast<uint32_t *>(region_stat + 1) : nullptr);
     }
     if (P.shape & 2u) { // whole tiles through the region kernel, the last n % tile pairs through the plain kernel
         const size_t nt_full = n / P.tile, done = nt_full * P.tile;
@@ -1611,6 +1631,10 @@ static hipError_t launch_part2_t(const IDT *d_ids, const double *d_v, size_t n, 
             hipLaunchKernelGGL((k_scatter3<512, 128, SC3_BATCH, IDT>), dim3(P.g1), dim3(512), p1_dyn, s, d_ids, d_v, nt_full, nmetrics,
                                P.log_np, P.log_w, d_Tx, g_nt, g_hs, g_hdr, g_pt, g_hot, records,
                                L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, region_stat);
+        else if (P.shape & 4u)
+            hipLaunchKernelGGL((k_scatter3<1024, 512, SC3_BATCH, IDT>), dim3(P.g1), dim3(1024), p1_dyn, s, d_ids, d_v, nt_full,
+                               nmetrics, P.log_np, P.log_w, d_Tx, g_nt, g_hs, g_hdr, g_pt, g_hot,
+                               records, L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, region_stat);
         else
             hipLaunchKernelGGL((k_scatter3<1024, 256, SC3_BATCH, IDT>), dim3(P.g1), dim3(1024), p1_dyn, s, d_ids, d_v, nt_full,
                                nmetrics, P.log_np, P.log_w, d_Tx, g_nt, g_hs, g_hdr, g_pt, g_hot,

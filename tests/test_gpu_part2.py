@@ -99,7 +99,8 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("shape", [0, 1, 2, 3], ids=["1024x256", "512x128", "1024x256-direct", "512x128-direct"])
+@pytest.mark.parametrize("shape", [0, 1, 2, 3, 6],
+                         ids=["1024x256", "512x128", "1024x256-direct", "512x128-direct", "1024x512-direct-wide"])
 @pytest.mark.parametrize("M,n,kind,skew", CASES)
 def test_survey_path_is_exact(native_lib, torch_cuda, M, n, kind, skew, shape):
     import loghisto_amd
@@ -120,7 +121,8 @@ def test_survey_path_is_exact(native_lib, torch_cuda, M, n, kind, skew, shape):
                 _check(snap, ids, v, M, got)
 
 
-@pytest.mark.parametrize("shape", [0, 1, 2, 3], ids=["1024x256", "512x128", "1024x256-direct", "512x128-direct"])
+@pytest.mark.parametrize("shape", [0, 1, 2, 3, 6],
+                         ids=["1024x256", "512x128", "1024x256-direct", "512x128-direct", "1024x512-direct-wide"])
 def test_survey_path_bad_ids_sublaunches_and_two_launches_per_epoch(native_lib, torch_cuda, shape):
     import loghisto_amd
     rng = np.random.default_rng(77)
@@ -283,3 +285,37 @@ def test_a_value_shift_under_a_kept_survey_ends_its_reuse(native_lib, torch_cuda
         assert c["survey_stale_pairs"] > stale, c
         before = c["surveys_reused"]
         assert call(d_v1, v1)["surveys_reused"] == before
+
+
+def test_wide_value_spans_take_the_wide_shape_by_themselves(native_lib, torch_cuda):
+    """A two-signed stream over 40 decades (+-10^U(-3, 20): 9 211 bins per name) does not fit the 8 192-bin reduce windows of
+    four names per partition: a tenth of its pairs took the window-miss path, global atomics (1 024 names: 7.2 ms per 1e9
+    pairs against 2.9 for lognormal values).  The survey reports the spans it saw (k_survey_plan -> the engine's pinned word),
+    and the calls that follow run 512 partitions of two names x 16 384 bins (shape 6) -- until a survey reports narrow spans
+    again.  Every cell exact at every step; `window_misses` tells the two shapes apart."""
+    import loghisto_amd
+    rng = np.random.default_rng(91)
+    M, n = 1024, 3_000_000
+    ids = _ids(rng, M, n, 1.0)
+    wide = 10.0 ** rng.uniform(-3, 20, n) * np.where(rng.random(n) < 0.5, -1.0, 1.0)
+    narrow = rng.lognormal(math.log(1e5), 1.0, n)
+    d_ids, d_w, d_n = _dev(torch_cuda, ids), _dev(torch_cuda, wide), _dev(torch_cuda, narrow)
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        e.set_option(N.OPT_PART_V2_MIN_PAIRS, 1 << 17)
+
+        def call(d_v, v):
+            e.submit_pairs_device(d_ids, d_v)
+            e.sync()
+            with e.flip() as snap:
+                _check(snap, ids, v, M, snap.extract(PCTS, M))
+            return e.counters()
+
+        c0 = call(d_w, wide)                       # surveyed on the default shape: reports wide spans
+        c1 = call(d_w, wide)                       # the shape changed: surveys again, on 512 partitions
+        c2 = call(d_w, wide)
+        assert c2["surveys_reused"] == c1["surveys_reused"] + 1, (c1, c2)   # ... and keeps that survey
+        assert c0["samples_partitioned_v2"] == n and c2["samples_partitioned_v2"] == 3 * n, c2
+        c3 = call(d_n, narrow)                     # narrow values under the wide survey: stale, or simply all in window
+        c4 = call(d_n, narrow)
+        c5 = call(d_n, narrow)
+        assert c5["samples_partitioned_v2"] == 6 * n, c5
