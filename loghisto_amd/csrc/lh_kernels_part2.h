@@ -870,30 +870,6 @@ template <int NPT> struct Scatter3LdsT {
 #define LH_ABL 0
 #endif
 constexpr uint32_t ABL = LH_ABL;
-// LH_PREBIN: the bucket indices of the NEXT tile are computed inside the copy-out phase, before its closing barrier -- the
-// waves that have issued their part of the copy-out (or had none) fill the wait for the others with the 19 VALU per sample
-// of lh_bin_fast instead of starting them behind the barrier, where the classification's chain of LDS round trips waits for
-// them.  The values were loaded a tile period earlier; nine registers carry the eight indices and their guard-band flags
-// across the barrier.  (0: the indices are computed where they are used, for A/B builds.)
-#ifndef LH_PREBIN
-#define LH_PREBIN 1
-#endif
-constexpr bool PREBIN = LH_PREBIN != 0;
-struct TileBins { uint32_t b[V2_SPT]; uint32_t unc; };
-__device__ __forceinline__ void tile_bins(const pd2_t (&val)[V2_SPT / 2], TileBins &tb)
-{
-    tb.unc = 0;
-#pragma unroll
-    for (int j = 0; j < V2_SPT; j++) {
-        bool u;
-        tb.b[j] = lh_bin_fast((j & 1) ? val[j >> 1].y : val[j >> 1].x, u);
-        tb.unc |= u ? 1u << j : 0u;
-    }
-    // (the indices stay where they were computed: nothing may sink them behind the barrier that follows)
-    asm volatile("" : "+v"(tb.b[0]), "+v"(tb.b[1]), "+v"(tb.b[2]), "+v"(tb.b[3]), "+v"(tb.b[4]), "+v"(tb.b[5]), "+v"(tb.b[6]),
-                      "+v"(tb.b[7]), "+v"(tb.unc));
-    static_assert(V2_SPT == 8, "the asm above names eight indices");
-}
 #ifndef LH_SC3_BATCH
 #define LH_SC3_BATCH 4
 #endif
@@ -1003,7 +979,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
 
     // ---- phase 1: classify and place.  Straight-line code, BATCH samples at a time: their table reads, then their LDS
     // atomics, then their record stores are in flight together.
-    auto classify = [&](typename IS::raw_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const TileBins &tb, const uint32_t par) {
+    auto classify = [&](typename IS::raw_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
 #pragma unroll
         for (int h = 0; h < V2_SPT; h += BATCH) {
             uint32_t raw[BATCH], bin[BATCH], rank[BATCH], crel[BATCH];
@@ -1024,12 +1000,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
 #pragma unroll
             for (int k = 0; k < BATCH; k++) {
                 const int j = h + k;
-                if (PREBIN) {
-                    bin[k] = tb.b[j];
-                    unc[k] = (tb.unc >> j) & 1u;
-                } else {
-                    bin[k] = lh_bin_fast((j & 1) ? val[j >> 1].y : val[j >> 1].x, unc[k]);
-                }
+                bin[k] = lh_bin_fast((j & 1) ? val[j >> 1].y : val[j >> 1].x, unc[k]);
                 if (ABL & 16u) { // the same index once more, on a value the compiler cannot tell from the first
                     double x2 = (j & 1) ? val[j >> 1].y : val[j >> 1].x;
                     asm volatile("" : "+v"(x2));
@@ -1104,13 +1075,12 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
         }
     };
     uint32_t seq_lines = tid / TPP; // (ABL 64: this thread group's position in the workgroup's sequential stream)
-    auto flush = [&](const uint32_t par, const pd2_t (&nextval)[NPAIR], TileBins &nexttb) {
-        if (ABL & 2u) { if (PREBIN) tile_bins(nextval, nexttb); return; }
+    auto flush = [&](const uint32_t par) {
+        if (ABL & 2u) return;
         __syncthreads();                                   // barrier A: the records of the tile(s) are in the regions
         if (ABL & 1u) {
             if (tid < NPT) L.cnt[tid] = 0;
             if (tid == BLOCK - 1) { L.missn[0] = 0; L.missn[1] = 0; }
-            if (PREBIN) tile_bins(nextval, nexttb);
             __syncthreads();
             return;
         }
@@ -1181,7 +1151,6 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
                 if (!ov_add(L.ov_key, L.ov_cnt, key, 1u)) v2_global_add(counts, ranges, key >> 16, key & 0xffffu, 1);
             }
         }
-        if (PREBIN) tile_bins(nextval, nexttb);            // the next tile's bucket indices, while the copy-out drains
         __syncthreads();                                   // barrier B: counters and regions are ready for the next tile
     };
     // Each register set receives the tile two steps ahead as soon as its samples are classified.
@@ -1197,21 +1166,19 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
     uint32_t par = 0; // out-of-window queue of this flush group (the flush resets the other one)
     size_t tile = blockIdx.x;
     const size_t G = gridDim.x;
-    TileBins tba, tbb;
-    if (PREBIN) tile_bins(vaa, tba);
     for (; tile + G < ntiles; tile += 2 * G) {
-        classify(ida, vaa, tba, par);
+        classify(ida, vaa, par);
         load_tile(tile + 2 * G, ida, vaa);
-        flush(par, vab, tbb);
+        flush(par);
         par ^= 1u;
-        classify(idb, vab, tbb, par);
+        classify(idb, vab, par);
         load_tile(tile + 3 * G, idb, vab);
-        flush(par, vaa, tba);
+        flush(par);
         par ^= 1u;
     }
     if (tile < ntiles) { // (workgroup-uniform) the workgroup's last tile when it has an odd number of them
-        classify(ida, vaa, tba, par);
-        flush(par, vab, tbb);
+        classify(ida, vaa, par);
+        flush(par);
         par ^= 1u;
     }
 

@@ -491,7 +491,7 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
     // atomics, then their record stores are in flight together.  An id >= nmetrics is not tested per sample: one max3 +
     // compare per batch finds the lanes that hold one, and only those lanes mark the sample (no table entry matches such
     // an id, so it is not hot; the mark keeps it from becoming a record).
-    auto classify = [&](typename IS::raw_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const TileBins &tb, const uint32_t par) {
+    auto classify = [&](typename IS::raw_t (&idv)[NPAIR], pd2_t (&val)[NPAIR], const uint32_t par) {
 #pragma unroll
         for (int h = 0; h < V2_SPT; h += BATCH) {
             uint32_t raw[BATCH], bin[BATCH], rank[BATCH];
@@ -511,12 +511,7 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
 #pragma unroll
             for (int k = 0; k < BATCH; k++) {
                 const int j = h + k;
-                if (PREBIN) { // (computed inside the previous copy-out phase: LH_PREBIN, lh_kernels_part2.h)
-                    bin[k] = tb.b[j];
-                    unc[k] = (tb.unc >> j) & 1u;
-                } else {
-                    bin[k] = lh_bin_fast((j & 1) ? val[j >> 1].y : val[j >> 1].x, unc[k]);
-                }
+                bin[k] = lh_bin_fast((j & 1) ? val[j >> 1].y : val[j >> 1].x, unc[k]);
                 if (ABL & 16u) { // the same index once more, on a value the compiler cannot tell from the first
                     double x2 = (j & 1) ? val[j >> 1].y : val[j >> 1].x;
                     asm volatile("" : "+v"(x2));
@@ -589,13 +584,12 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
         }
     };
     uint32_t seq_lines = tid >> 2; // (ABL 64: this thread group's position in the workgroup's sequential stream)
-    auto flush = [&](const uint32_t par, const pd2_t (&nextval)[NPAIR], TileBins &nexttb) {
-        if (ABL & 2u) { if (PREBIN) tile_bins(nextval, nexttb); return; }
+    auto flush = [&](const uint32_t par) {
+        if (ABL & 2u) return;
         __syncthreads();                                   // barrier A: the tile's records are in the regions
         if (ABL & 1u) {
             if (tid < NPT) L.cnt[tid] = 0;
             if (tid == BLOCK - 1) { L.missn[0] = 0; L.missn[1] = 0; }
-            if (PREBIN) tile_bins(nextval, nexttb);
             __syncthreads();
             return;
         }
@@ -655,7 +649,6 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
                 if (!ov_add(L.ov_key, L.ov_cnt, key, 1u)) v3_global_add(counts, ranges, key >> 16, key & 0xffffu, 1);
             }
         }
-        if (PREBIN) tile_bins(nextval, nexttb);            // the next tile's bucket indices, while the copy-out drains
         __syncthreads();                                   // barrier B: counters and regions are ready for the next tile
     };
     // Tiles in PAIRS, both halves of the body unconditional, a last single tile peeled off: see k_scatter3 (the
@@ -664,21 +657,19 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
     uint32_t par = 0;
     size_t tile = blockIdx.x;
     const size_t G = gridDim.x;
-    TileBins tba, tbb;
-    if (PREBIN) tile_bins(vaa, tba);
     for (; tile + G < ntiles; tile += 2 * G) {
-        classify(ida, vaa, tba, par);
+        classify(ida, vaa, par);
         load_tile(tile + 2 * G, ida, vaa);
-        flush(par, vab, tbb);
+        flush(par);
         par ^= 1u;
-        classify(idb, vab, tbb, par);
+        classify(idb, vab, par);
         load_tile(tile + 3 * G, idb, vab);
-        flush(par, vaa, tba);
+        flush(par);
         par ^= 1u;
     }
     if (tile < ntiles) { // (workgroup-uniform) the workgroup's last tile when it has an odd number of them
-        classify(ida, vaa, tba, par);
-        flush(par, vab, tbb);
+        classify(ida, vaa, par);
+        flush(par);
         par ^= 1u;
     }
 
