@@ -46,7 +46,7 @@ rocprofv3 --kernel-trace -d /tmp/pr_c4t -o t -- $CMD4 > $OUT/c4_under_trace.json
   # the small merge / plan kernels launch by launch, in start order (10 - 60 x spreads): the run makes 4 SERIAL
   # steps (every phase drained: the kernel alone on the GPU) and then 4 PIPELINED ones (the kernel beside the next step's level 1,
   # which holds every CU's LDS: its workgroups wait for a CU)
-  for k in k_merge_widths k_merge_prep k_plan_scan; do python $R/profiles/summarize_rocpd.py list /tmp/pr_c4t/t_results.db $k | cut -c1-200; done; } > $OUT/c4_kernel_trace.txt
+  for k in k_merge_widths k_merge_prep k_plan_scan k_extract_wave; do python $R/profiles/summarize_rocpd.py list /tmp/pr_c4t/t_results.db $k | cut -c1-200; done; } > $OUT/c4_kernel_trace.txt
 rocprofv3 --pmc FETCH_SIZE -d /tmp/pr_c4f -o t -- $CMD4 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE -d /tmp/pr_c4w -o t -- $CMD4 > /dev/null 2>&1
 python - <<PY
