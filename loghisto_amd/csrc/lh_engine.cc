@@ -137,6 +137,8 @@ ExtractLayout extract_layout(size_t nmetrics, size_t np)
 
 } // namespace
 
+constexpr uint32_t kLaneRstat = 8; // first word of the host-fed lanes' report block in h_rstat (lh_create)
+
 struct lh_engine {
     lh_config cfg{};
     int device = 0;
@@ -214,7 +216,7 @@ struct lh_engine {
     std::atomic<bool> small_disabled{false};
     // the region scatter reports records that found their LDS region full (a stream clustered by name); above 2 % of
     // an interval's samples later calls take the exact-layout scatter, and the regions get another try every 64 flips
-    unsigned long long *h_rstat = nullptr, *d_rstat = nullptr; // pinned, device-visible
+    unsigned long long *h_rstat = nullptr, *d_rstat = nullptr; // pinned, device-visible: two blocks of 8 words (lh_create)
     std::atomic<bool> regions_disabled{false};
     std::atomic<uint64_t> region_samples{0}, c_region_ovf{0}, c_survey_reuse{0};
     uint64_t rstat_seen = 0, win_ovf = 0, win_samples = 0; // lh_flip only (under the epoch lock)
@@ -466,12 +468,13 @@ int run_lane_block(lh_engine *e, EpochBuffer &b, PairsCall &c, const lh::Step &s
             for (hipEvent_t &ev : lt.ready)
                 if (!ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         }
-        // what the third-generation launches completed since the last look reported (the device-resident calls' and the
-        // lanes' alike: k_v3_report adds to the same pinned words)
-        const uint64_t bad = __atomic_load_n(&e->h_rstat[0], __ATOMIC_RELAXED) + __atomic_load_n(&e->h_rstat[4], __ATOMIC_RELAXED) +
-                             __atomic_load_n(&e->h_rstat[5], __ATOMIC_RELAXED);
-        const uint64_t stale = __atomic_load_n(&e->h_rstat[7], __ATOMIC_RELAXED);
-        const uint64_t pairs = __atomic_load_n(&e->h_rstat[6], __ATOMIC_RELAXED);
+        // what the lanes' third-generation launches completed since the last look reported (their own block of pinned words)
+        // (pairs first: a report that lands between the reads then shows as pairs without their overflows, never the reverse)
+        const unsigned long long *lr = e->h_rstat + kLaneRstat;
+        const uint64_t pairs = __atomic_load_n(&lr[6], __ATOMIC_ACQUIRE);
+        const uint64_t bad = __atomic_load_n(&lr[0], __ATOMIC_RELAXED) + __atomic_load_n(&lr[4], __ATOMIC_RELAXED) +
+                             __atomic_load_n(&lr[5], __ATOMIC_RELAXED);
+        const uint64_t stale = __atomic_load_n(&lr[7], __ATOMIC_RELAXED);
         int set = lt.active;
         // A stale survey (h_rstat[7]: the hot windows take fewer pairs than when the tables were new) counts only once the
         // set has served kLaneStaleMinAge launches: lanes may carry different streams, each a few per cent off the launch
@@ -510,7 +513,7 @@ int run_lane_block(lh_engine *e, EpochBuffer &b, PairsCall &c, const lh::Step &s
             // whatever the fresh allocation holds
             hipError_t le = lh::launch_ingest_pairs_part3(d_ids, d_v, st.take, survey_n, b.counts, b.ranges, e->cfg.max_metrics,
                                                           e->d_Tx, e->d_err, a->p, a->bytes, lt.p[set], e->num_cus, st.tune,
-                                                          e->d_rstat,
+                                                          e->d_rstat ? e->d_rstat + kLaneRstat : nullptr,
                                                           e->d_rstat ? reinterpret_cast<uint32_t *>(e->d_rstat + 1) : nullptr, s);
             if (le == hipSuccess && survey_n) {
                 le = hipEventRecord(lt.ready[set], s);
@@ -574,9 +577,9 @@ void judge_tables(lh_engine *e, PairsCall &c, int gen, uint32_t layout)
     bool healthy = true;
     if (gen == 3) {
         // ([7]: pairs a STALE survey kept out of the hot windows -- the values moved under it; stale_judge, lh_kernels_part2.h)
+        const uint64_t pairs = __atomic_load_n(&e->h_rstat[6], __ATOMIC_ACQUIRE); // of the shared block's launches that reported
         const uint64_t bad = __atomic_load_n(&e->h_rstat[0], __ATOMIC_RELAXED) + __atomic_load_n(&e->h_rstat[4], __ATOMIC_RELAXED) +
                              __atomic_load_n(&e->h_rstat[5], __ATOMIC_RELAXED) + __atomic_load_n(&e->h_rstat[7], __ATOMIC_RELAXED);
-        const uint64_t pairs = __atomic_load_n(&e->h_rstat[6], __ATOMIC_RELAXED); // of the launches that reported
         const uint64_t fwd = __atomic_load_n(&e->h_rstat[3], __ATOMIC_RELAXED);
         healthy = lh::healthy_share(bad - e->v3_seen_bad, pairs - e->v3_seen_pairs);
         if (lh::names_without_skew(pairs - e->v3_seen_pairs, fwd - e->v3_seen_fwd, healthy, c.st.call_log_w == e->v3_last_call_log_w))
@@ -912,8 +915,10 @@ int create_impl(const lh_config *cfg_in, lh_engine *e)
     // (padded with zeros to a row's stride: k_extract_wave reads whole 4-bin groups of the table beside the cells)
     HIPCHK(hipMalloc((void **)&e->d_D, sizeof(double) * LH_ROW_STRIDE));
     HIPCHK(hipMemset(e->d_D, 0, sizeof(double) * LH_ROW_STRIDE));
-    HIPCHK(hipHostMalloc((void **)&e->h_rstat, 64, hipHostMallocDefault));
-    for (int i = 0; i < 8; i++) e->h_rstat[i] = 0; // [0] level-1 region overflows [1] window class [2..5] part3 self-metrics [6] pairs they cover [7] pairs a stale survey cost its hot windows
+    // Two report blocks of 8 words: [0..7] the launches on the shared block, [8..15] the host-fed lanes' launches (ADVICE r5:
+    // each judge reads only its own producers' reports).  Word [1] (the survey's window class) is shared by both.
+    HIPCHK(hipHostMalloc((void **)&e->h_rstat, 128, hipHostMallocDefault));
+    for (int i = 0; i < 16; i++) e->h_rstat[i] = 0; // [0] level-1 region overflows [1] window class [2..5] part3 self-metrics [6] pairs they cover [7] pairs a stale survey cost its hot windows
     {
         void *dp = nullptr;
         HIPCHK(hipHostGetDevicePointer(&dp, e->h_rstat, 0));
@@ -1463,7 +1468,7 @@ int lh_flip(lh_engine *e, lh_snapshot **out)
         // launch's overflows can arrive one flip after its samples were counted, so both are accumulated and the ratio
         // is judged only over windows of at least 2^21 region-path samples: an idle interval that merely collects a
         // late count must not switch the path.
-        const uint64_t now = __atomic_load_n(e->h_rstat, __ATOMIC_RELAXED);
+        const uint64_t now = __atomic_load_n(e->h_rstat, __ATOMIC_RELAXED) + __atomic_load_n(e->h_rstat + kLaneRstat, __ATOMIC_RELAXED);
         const uint64_t ov = now - e->rstat_seen;
         e->rstat_seen = now;
         if (ov) e->c_region_ovf.fetch_add(ov, std::memory_order_relaxed);
@@ -2532,14 +2537,14 @@ int lh_get_counters(lh_engine *e, lh_counters *out)
     out->counter_events = e->c_counts.load();
     out->region_overflows = e->c_region_ovf.load();
     out->samples_partitioned_v3 = e->c_part3.load();
-    out->records_level1 = __atomic_load_n(&e->h_rstat[2], __ATOMIC_RELAXED);
-    out->records_level2 = __atomic_load_n(&e->h_rstat[3], __ATOMIC_RELAXED);
-    out->level2_overflows = __atomic_load_n(&e->h_rstat[4], __ATOMIC_RELAXED);
-    out->reduce_window_misses = __atomic_load_n(&e->h_rstat[5], __ATOMIC_RELAXED);
+    out->records_level1 = __atomic_load_n(&e->h_rstat[2], __ATOMIC_RELAXED) + __atomic_load_n(&e->h_rstat[kLaneRstat + 2], __ATOMIC_RELAXED);
+    out->records_level2 = __atomic_load_n(&e->h_rstat[3], __ATOMIC_RELAXED) + __atomic_load_n(&e->h_rstat[kLaneRstat + 3], __ATOMIC_RELAXED);
+    out->level2_overflows = __atomic_load_n(&e->h_rstat[4], __ATOMIC_RELAXED) + __atomic_load_n(&e->h_rstat[kLaneRstat + 4], __ATOMIC_RELAXED);
+    out->reduce_window_misses = __atomic_load_n(&e->h_rstat[5], __ATOMIC_RELAXED) + __atomic_load_n(&e->h_rstat[kLaneRstat + 5], __ATOMIC_RELAXED);
     out->surveys_reused = e->c_survey_reuse.load();
     out->scratch_alloc_failures = e->c_alloc_fail.load();
     out->samples_fallback = e->c_fallback.load();
-    out->survey_stale_pairs = __atomic_load_n(&e->h_rstat[7], __ATOMIC_RELAXED);
+    out->survey_stale_pairs = __atomic_load_n(&e->h_rstat[7], __ATOMIC_RELAXED) + __atomic_load_n(&e->h_rstat[kLaneRstat + 7], __ATOMIC_RELAXED);
     {
         const uint64_t lw = __atomic_load_n(&e->h_rstat[1], __ATOMIC_RELAXED);
         std::lock_guard<std::mutex> g(e->scratch_mu);
