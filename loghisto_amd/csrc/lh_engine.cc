@@ -266,6 +266,8 @@ struct lh_engine {
     // Third generation (8 193 .. 65 536 names): the survey reports the window width that covers the stream's spans
     // (h_rstat[1], pinned); later calls use it.  A width that is too small only costs speed.
     bool v3_log_w_fixed = false;             // lh_set_option(LH_OPT_PART_V3_LOG_W) pinned it
+    std::mutex probe_mu;                     // probe_width: once per engine
+    bool probe_done = false;
     // Host-fed lane launches (one half-buffer of pairs each, read over PCIe in place) are link-bound in their first
     // pass and leave the link idle in the passes behind it.  On the ONE block above they run one after another -- the
     // link idles a third of the time (measured: 44 of the 52 GB/s lh_submit's single pass gets, and 2.3 G pairs/s at
@@ -416,6 +418,7 @@ struct PairsCall {
     uint64_t tune_gen = 0;
     bool surveyed = false; // the block holds the survey this call runs on (its own, or a reused one)
     bool judged = false;   // the reuse decision is made once per call, at its first surveyed-generation launch
+    bool log_w_fixed = false; // lh_set_option pinned the third generation's window width
     std::unique_lock<std::mutex> lock;
 };
 
@@ -685,6 +688,7 @@ void snapshot_dispatch(lh_engine *e, PairsCall &c)
         c.st.sublaunch_set = e->sublaunch_set;
         log_w_fixed = e->v3_log_w_fixed;
     }
+    c.log_w_fixed = log_w_fixed;
     c.st.max_metrics = e->cfg.max_metrics;
     c.st.num_cus = e->num_cus;
     c.st.lane_samples = (size_t)e->cfg.lane_samples;
@@ -704,11 +708,43 @@ void snapshot_dispatch(lh_engine *e, PairsCall &c)
     }
 }
 
+// The engine's first large third-generation call: no survey has reported a window width yet, and a wide stream on the
+// default (narrowest) width counts most of its records through the overflow paths -- exact, but a 1e9-pair call of
+// 21-decade values took 636 ms instead of 8.9 (profiles/r06_first_call.txt).  The survey's first three kernels run
+// alone on the call's pairs and the host WAITS for the class they report (~0.3 ms behind whatever the stream still
+// holds).  Once per engine: later changes of the stream are followed by the surveys' reports as before (one or two
+// slow calls; the health judge re-surveys).  Device-resident calls only: a lane's half-buffer is too small to matter.
+void probe_width(lh_engine *e, PairsCall &c, lh::Ids d_ids, const double *d_v, size_t n, hipStream_t s)
+{
+    constexpr size_t kProbeMinPairs = size_t(1) << 24;
+    if (c.st.max_metrics <= 8192 || c.log_w_fixed || n < kProbeMinPairs || !c.st.tune.v3 || c.st.v3_disabled) return;
+    if (__atomic_load_n(&e->h_rstat[1], __ATOMIC_RELAXED) != 0 || !e->d_rstat) return;
+    if (lh::peel_first((uintptr_t)d_ids.p, d_ids.width, (uintptr_t)d_v, n)) { d_ids = d_ids.plus(1); d_v += 1; n -= 1; }
+    std::lock_guard<std::mutex> g(e->probe_mu);
+    if (e->probe_done) return;
+    e->probe_done = true; // (whatever happens below: the probe is an optimisation, tried once)
+    const size_t tb = lh::part3_tables_bytes(e->cfg.max_metrics);
+    void *p = nullptr;
+    if (!tb || hipMalloc(&p, tb) != hipSuccess) { (void)hipGetLastError(); return; }
+    n = std::min(n, size_t(1) << 30);
+    if (lh::launch_part3_probe(d_ids, d_v, n, e->cfg.max_metrics, e->d_Tx, p, e->num_cus, c.st.tune,
+                               reinterpret_cast<uint32_t *>(e->d_rstat + 1), s) == hipSuccess &&
+        hipStreamSynchronize(s) == hipSuccess) {
+        const uint32_t lw = (uint32_t)__atomic_load_n(&e->h_rstat[1], __ATOMIC_ACQUIRE);
+        if (lw >= 10 && lw <= 13) c.st.call_log_w = lw;
+    } else {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(s); // (the block below is freed: nothing may still write it)
+    }
+    (void)hipFree(p);
+}
+
 int launch_pairs(lh_engine *e, lh::Ids d_ids, const double *d_v, size_t n, hipStream_t s, bool host_fed = false)
 {
     EpochBuffer &b = e->bufs[(size_t)e->cur];
     PairsCall c;
     snapshot_dispatch(e, c);
+    if (!host_fed) probe_width(e, c, d_ids, d_v, n, s);
     bool peel = lh::peel_first((uintptr_t)d_ids.p, d_ids.width, (uintptr_t)d_v, n);
     while (n) {
         lh::Step st;

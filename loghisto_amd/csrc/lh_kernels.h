@@ -123,6 +123,11 @@ hipError_t launch_ingest_pairs_part3(Ids d_ids, const double *d_v, size_t n, siz
                                      const PartTuning &tune, unsigned long long *region_stat, uint32_t *span_stat,
                                      hipStream_t s);
 
+// The survey's window-width class of n pairs, alone (-> *span_stat): for a call that must choose a width before any survey
+// has reported one.  `tables`: part3_tables_bytes(nmetrics) of device memory, scratch of the probe.
+hipError_t launch_part3_probe(Ids d_ids, const double *d_v, size_t n, uint32_t nmetrics, const double *d_Tx, void *tables,
+                              int num_cus, const PartTuning &tune, uint32_t *span_stat, hipStream_t s);
+
 // K2: extract.  One workgroup per metric.
 // ExtractNotify (optional): when the outputs live in host-mapped memory the last workgroup to finish stores
 // `seq` into *host_flag (system-scope release after every workgroup's results), so the host can spin on a word

@@ -902,7 +902,7 @@ __global__ __launch_bounds__(1024, 4) void k_split_records(const uint32_t *__res
                         const uint32_t at = atomicAdd(&L.missn[par], 1u);
                         if (at < V3_MISSQ) L.missq[par][at] = key;
                         else if (!ov_add(L.ov_key, L.ov_cnt, key, 1u))
-                            v3_global_add(counts, ranges, key >> 16, bin, 1);
+                            v2_global_add(counts, ranges, key >> 16, bin, 1); // (see k_split_waves)
                     }
             }
         }
@@ -1209,7 +1209,10 @@ __global__ __launch_bounds__(1024, 4) void k_split_waves(const uint32_t *__restr
                     if (full & (1u << k)) {
                         const uint32_t old = (rr[k] >> 16) & 0xffu, bin = rr[k] & 0xffffu;
                         const uint32_t id = (old << V3_LOG_NP) | p1;
-                        if (!ov_add(L.ov_key, L.ov_cnt, (id << 16) | bin, 1u)) v3_global_add(counts, ranges, id, bin, 1);
+                        // (v2_global_add: its range update LOOKS before it adds.  v3_global_add's unconditional min / max
+                        // pair on the name's two range words serialises when a whole stream takes this path -- a wide
+                        // stream's first call, on the default width: 593 ms of a 1e9-pair call, 25 ms with the look)
+                        if (!ov_add(L.ov_key, L.ov_cnt, (id << 16) | bin, 1u)) v2_global_add(counts, ranges, id, bin, 1);
                     }
             }
         }
@@ -1886,6 +1889,43 @@ static hipError_t launch_part3_t(const IDT *d_ids, const double *d_v, size_t n, 
     }
     hipLaunchKernelGGL(k_v3_report, dim3(1), dim3(64), 0, s, g_stats, region_stat, (unsigned long long)n, g_hdr);
     return hipGetLastError();
+}
+
+// The survey's first three kernels alone: the window-width class of the n pairs lands in *span_stat (pinned).  For the
+// engine's FIRST third-generation call, whose sub-launches must be laid out for a width before any survey has reported
+// one.  `tables`: part3_tables_bytes(nmetrics) of device memory (scratch of the probe; nothing is kept).
+template <typename IDT>
+static hipError_t launch_part3_probe_t(const IDT *d_ids, const double *d_v, size_t n, uint32_t nmetrics, const double *d_Tx,
+                                       void *tables, int num_cus, const PartTuning &tune, uint32_t *span_stat, hipStream_t s)
+{
+    Part3Plan P;
+    if (!make_plan3(n, nmetrics, num_cus, tune, P) || !tables || !part_aligned(d_ids, d_v)) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_survey_count_h<IDT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(5 * SVH_SLOTS * 4));
+    if (e != hipSuccess) return e;
+    unsigned char *base = static_cast<unsigned char *>(tables);
+    unsigned long long *g_cs = reinterpret_cast<unsigned long long *>(base + P.off_stat);
+    uint32_t *g_mninv = reinterpret_cast<uint32_t *>(g_cs + nmetrics), *g_mx = g_mninv + nmetrics;
+    const SurveyStat S{g_cs, g_mninv, g_mx};
+    uint32_t *g_aux = reinterpret_cast<uint32_t *>(base + P.off_aux);
+    e = hipMemsetAsync(base + P.off_stat, 0, P.off_hk - P.off_stat, s);
+    if (e != hipSuccess) return e;
+    const size_t sv_tiles = (n / 2 + 1023) / 1024;
+    const unsigned sv_grid = (unsigned)std::min<size_t>(SVH_GRID, std::max<size_t>(1, sv_tiles));
+    hipLaunchKernelGGL(k_survey_count_h<IDT>, dim3(sv_grid), dim3(1024), 5 * SVH_SLOTS * 4, s, d_ids, d_v, n, nmetrics, d_Tx,
+                       g_cs, g_mninv, g_mx);
+    hipLaunchKernelGGL(k_survey_pick, dim3((nmetrics + 1023) / 1024), dim3(1024), 0, s, S, nmetrics, g_aux);
+    hipLaunchKernelGGL(k_survey_plan_h, dim3(1), dim3(V2_BLOCK), 0, s, S, g_aux, P.cells, V3_TILE, P.avail_bytes, P.max_cells,
+                       reinterpret_cast<pu2_t *>(base + P.off_hk), reinterpret_cast<pu4_t *>(base + P.off_hs),
+                       reinterpret_cast<pu2_t *>(base + P.off_pt), reinterpret_cast<uint32_t *>(base + P.off_hdr), span_stat);
+    return hipGetLastError();
+}
+
+hipError_t launch_part3_probe(Ids d_ids, const double *d_v, size_t n, uint32_t nmetrics, const double *d_Tx, void *tables,
+                              int num_cus, const PartTuning &tune, uint32_t *span_stat, hipStream_t s)
+{
+    return d_ids.width == 2 ? launch_part3_probe_t(d_ids.u16(), d_v, n, nmetrics, d_Tx, tables, num_cus, tune, span_stat, s)
+                            : launch_part3_probe_t(d_ids.u32(), d_v, n, nmetrics, d_Tx, tables, num_cus, tune, span_stat, s);
 }
 
 hipError_t launch_ingest_pairs_part3(Ids d_ids, const double *d_v, size_t n, size_t survey_n,

@@ -459,3 +459,33 @@ def test_a_value_shift_under_a_kept_survey_ends_its_reuse(native_lib, torch_cuda
         for _ in range(3):
             c = call(d_v2, v2)
         assert c["surveys_reused"] == 7 and c["survey_stale_pairs"] == stale, c
+
+
+def test_the_first_large_call_takes_the_width_of_its_own_stream(native_lib, torch_cuda):
+    """Before any survey has reported, the engine has no window width to lay a call out for.  A wide stream (21 decades:
+    4 147 bins per name) on the default 1 024-bin windows is exact but counts most of its records through the overflow
+    tables and global atomics (a 1e9-pair call took 636 ms instead of 8.9: profiles/r06_first_call.txt).  The first call of
+    at least 2^24 device-resident pairs therefore runs the survey's first kernels alone and waits for their report
+    (lh_engine.cc: probe_width): this call already runs at 8 192-bin windows, and nearly nothing misses them."""
+    import loghisto_amd
+    rng = np.random.default_rng(77)
+    M, n = 16384, (1 << 24) + 3
+    ids = _ids(rng, M, n, 1.0)
+    v = _values(rng, "loguniform", ids, n)
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        e.submit_pairs_device(_dev(torch_cuda, ids), _dev(torch_cuda, v))
+        e.sync()
+        c = e.counters()
+        assert c["samples_partitioned_v3"] >= n - 8192 and c["window_log2"] == 13, sorted(c.items())
+        assert c["reduce_window_misses"] + c["level2_overflows"] < n // 50, sorted(c.items())
+        with e.flip() as snap:
+            check(snap, ids, v, M, snap.extract(PCTS, M))
+    # a pinned width is the caller's: no probe, the call runs on it (and stays exact)
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        e.set_option(N.OPT_PART_V3_LOG_W, 10)
+        e.submit_pairs_device(_dev(torch_cuda, ids), _dev(torch_cuda, v))
+        e.sync()
+        c = e.counters()
+        assert c["window_log2"] == 10 and c["reduce_window_misses"] > n // 4, sorted(c.items())
+        with e.flip() as snap:
+            check(snap, ids, v, M, snap.extract(PCTS, M))
