@@ -374,8 +374,14 @@ __device__ __forceinline__ void v3_global_add(uint64_t *__restrict__ counts, uin
 {
     const unsigned long long c64 = c;
     asm volatile("global_atomic_add_x2 %0, %1, off" : : "v"(&counts[(size_t)m * LH_ROW_STRIDE + bin]), "v"(c64) : "memory");
+    // The range: LOOK, then widen (an unconditional min / max pair per record serialises on the name's two words when a
+    // whole stream takes this path: profiles/r06_first_call.txt).  The look is a load the compiler does not see either,
+    // with its own wait -- which also waits for the tile loop's prefetch; this path is off the loop's fast path.
     uint32_t *r = ranges + 2 * (size_t)m;
-    asm volatile("global_atomic_umin %0, %1, off\n\tglobal_atomic_umax %0, %1, off offset:4" : : "v"(r), "v"(bin) : "memory");
+    pu2_t rg;
+    asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(rg) : "v"(r) : "memory");
+    if (bin < rg.x) asm volatile("global_atomic_umin %0, %1, off" : : "v"(r), "v"(bin) : "memory");
+    if (bin > rg.y) asm volatile("global_atomic_umax %0, %1, off offset:4" : : "v"(r), "v"(bin) : "memory");
 }
 
 // compress of a sample inside the guard band of a threshold (or not finite), without touching memory: Go's log
@@ -418,7 +424,8 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
                                                       uint32_t *__restrict__ records,
                                                       uint32_t *__restrict__ cdesc, uint32_t chunks_per_wg,
                                                       uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
-                                                      uint32_t *__restrict__ err, uint32_t *__restrict__ g_stats)
+                                                      uint32_t *__restrict__ err, uint32_t *__restrict__ g_stats,
+                                                      uint32_t *__restrict__ g_resume)
 {
     constexpr int BLOCK = 1024, NPT = V3_NP;
     static_assert(BLOCK == 4 * NPT, "flush: four threads per partition");
@@ -648,13 +655,27 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
                 const uint32_t key = L.missq[par][i];
                 if (!ov_add(L.ov_key, L.ov_cnt, key, 1u)) v3_global_add(counts, ranges, key >> 16, key & 0xffffu, 1);
             }
+            if (L.missn[par] > V3_MISSQ) { // (uniform) the tile overflowed past its queue, straight into the table: emptied
+                __syncthreads();           // here, the table takes the next tile's cells too instead of staying full
+                for (uint32_t i = tid; i < OV_SLOTS; i += BLOCK)
+                    if (L.ov_key[i] != OV_EMPTY) {
+                        v2_global_add(counts, ranges, L.ov_key[i] >> 16, L.ov_key[i] & 0xffffu, L.ov_cnt[i]);
+                        L.ov_key[i] = OV_EMPTY;
+                        L.ov_cnt[i] = 0;
+                    }
+            }
         }
         __syncthreads();                                   // barrier B: counters and regions are ready for the next tile
     };
     // Tiles in PAIRS, both halves of the body unconditional, a last single tile peeled off: see k_scatter3 (the
     // compiler's count of the loads in flight must be exact, or every classification opens with a wait for the OTHER
     // register set's loads)
-    uint32_t par = 0;
+    // A stream CLUSTERED BY NAME (sorted by name, or whole batches of one producer) fills one partition's region with
+    // every tile and sends the rest -- most of the tile -- through the exact overflow path: a 1e9-pair call took 1.9 s
+    // (profiles/r06_first_call.txt).  A workgroup whose last two tiles overflowed by more than half stops here; the tiles
+    // it leaves are counted by k_scatter4_clustered (its turn in g_resume), whose whole LDS is one (name, bin) table.
+    uint32_t par = 0, ovn_seen = 0;
+    bool gave_up = false;
     size_t tile = blockIdx.x;
     const size_t G = gridDim.x;
     for (; tile + G < ntiles; tile += 2 * G) {
@@ -666,12 +687,22 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
         load_tile(tile + 3 * G, idb, vab);
         flush(par);
         par ^= 1u;
+        // (uniform: L.ovn is at rest between flush's last barrier and the next tile)
+        const uint32_t ovn_now = (uint32_t)__builtin_amdgcn_readfirstlane(L.ovn);
+        if (ovn_now - ovn_seen > V3_TILE) { // more than half of the two tiles just done
+            tile += 2 * G;
+            gave_up = true;
+            break;
+        }
+        ovn_seen = ovn_now;
     }
-    if (tile < ntiles) { // (workgroup-uniform) the workgroup's last tile when it has an odd number of them
+    if (!gave_up && tile < ntiles) { // (workgroup-uniform) the workgroup's last tile when it has an odd number of them
         classify(ida, vaa, par);
         flush(par);
         par ^= 1u;
+        tile += G;
     }
+    if (tid == 0) g_resume[blockIdx.x] = (uint32_t)min(tile, ntiles); // the first tile of this workgroup's turn left undone
 
     // ---- drain: the regions' leftovers (< one line each) and the open chunks' descriptors
     {
@@ -716,6 +747,79 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
     }
     for (uint32_t i = tid; i < OV_SLOTS; i += BLOCK)
         if (L.ov_key[i] != OV_EMPTY) v2_global_add(counts, ranges, L.ov_key[i] >> 16, L.ov_key[i] & 0xffffu, L.ov_cnt[i]);
+}
+
+// ---------------------------------------------------------------------------
+// What k_scatter4's workgroups left undone when they found the stream clustered by name (g_resume[workgroup] = its first
+// undone tile; >= ntiles: nothing, the workgroup returns at once -- every launch of an ordinary stream).  The same turn
+// of tiles, counted in ONE open-addressed LDS table of (name << 16 | bin) -> count: a clustered tile holds a few names,
+// i.e. a few hundred distinct cells, and the table (16 384 slots) is emptied into the rows whenever it is half full.
+// Exact like every other path: a sample that finds its eight probe slots taken by other cells is one global atomic.
+// ---------------------------------------------------------------------------
+constexpr uint32_t CL_SLOTS = 16384, CL_PROBES = 8;
+constexpr size_t CL_LDS_BYTES = (size_t)CL_SLOTS * 8 + 16;
+
+template <typename IDT>
+__global__ __launch_bounds__(1024) void k_scatter4_clustered(const IDT *__restrict__ ids, const double *__restrict__ v,
+                                                             size_t ntiles, uint32_t nmetrics,
+                                                             const uint32_t *__restrict__ g_resume,
+                                                             uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
+                                                             uint32_t *__restrict__ err)
+{
+    size_t tile = g_resume[blockIdx.x];
+    if (tile >= ntiles) return;
+    constexpr uint32_t BLOCK = 1024;
+    extern __shared__ __attribute__((aligned(16))) unsigned char v3_smem[];
+    uint32_t *key = reinterpret_cast<uint32_t *>(v3_smem), *cnt = key + CL_SLOTS, *used = cnt + CL_SLOTS;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < CL_SLOTS; i += BLOCK) { key[i] = OV_EMPTY; cnt[i] = 0; }
+    if (tid == 0) *used = 0;
+    __syncthreads();
+    auto drain = [&]() {
+        for (uint32_t i = tid; i < CL_SLOTS; i += BLOCK) {
+            const uint32_t k = key[i];
+            if (k != OV_EMPTY) {
+                v2_global_add(counts, ranges, k >> 16, k & 0xffffu, cnt[i]);
+                key[i] = OV_EMPTY;
+                cnt[i] = 0;
+            }
+        }
+        if (tid == 0) *used = 0;
+    };
+    for (; tile < ntiles; tile += gridDim.x) {
+        const size_t base = tile * V3_TILE + tid;
+        uint32_t id[V2_SPT];
+        double x[V2_SPT];
+#pragma unroll
+        for (int j = 0; j < V2_SPT; j++) {
+            id[j] = ids[base + (size_t)j * BLOCK];
+            x[j] = __builtin_nontemporal_load(v + base + (size_t)j * BLOCK);
+        }
+#pragma unroll
+        for (int j = 0; j < V2_SPT; j++) {
+            bool unc;
+            uint32_t bin = lh_bin_fast(x[j], unc);
+            if (unc) bin = v3_bin_exact(x[j]);
+            if (id[j] >= nmetrics) { atomicOr(err, 1u); continue; }
+            const uint32_t k = (id[j] << 16) | bin;
+            const uint32_t h0 = (k * 2654435761u) >> 18; // 14 bits
+            bool placed = false;
+#pragma unroll 1
+            for (uint32_t probe = 0; probe < CL_PROBES && !placed; probe++) {
+                const uint32_t sl = (h0 + probe) & (CL_SLOTS - 1u);
+                const uint32_t prev = atomicCAS(&key[sl], OV_EMPTY, k);
+                if (prev == OV_EMPTY) atomicAdd(used, 1u);
+                if (prev == OV_EMPTY || prev == k) { atomicAdd(&cnt[sl], 1u); placed = true; }
+            }
+            if (!placed) v2_global_add(counts, ranges, id[j], bin, 1);
+        }
+        __syncthreads();
+        if (*used > CL_SLOTS / 2u) { // (uniform: nothing adds between the barriers)
+            drain();
+        }
+        __syncthreads();
+    }
+    drain();
 }
 
 // ---------------------------------------------------------------------------
@@ -1683,7 +1787,7 @@ struct Part3Plan {
     bool waves; // level 2 by k_split_waves (<= 16 fine partitions per partition)
     uint32_t region_words, cells, max_cells, avail_bytes, g1, chunks_per_wg, nchunks1, nchunks2;
     size_t lds_dyn;
-    size_t off_stat, off_aux, off_hk, off_hs, off_hdr, off_pt, off_remap, off_inv, off_pt2, off_hot;
+    size_t off_stat, off_aux, off_hk, off_hs, off_hdr, off_pt, off_remap, off_inv, off_pt2, off_hot, off_resume;
     size_t off_rec1, off_cd1, off_sorted1, off_small1, off_rec2, off_cd2, off_sorted2, off_small2, off_gstats, total;
 };
 
@@ -1752,6 +1856,7 @@ static bool make_plan3(size_t n, uint32_t nmetrics, int num_cus, const PartTunin
     P.off_small2 = take(small_words(P.nq, P.extra2) * sizeof(uint32_t));
     P.off_gstats = take(64); // the launch's self-metrics: with the records, not with the tables (launches may share tables)
     P.off_hot = take((size_t)P.max_cells * 2 * P.g1); // level 1's hot windows, one copy per workgroup (k_hot_reduce)
+    P.off_resume = take((size_t)P.g1 * 4);            // level 1: the first tile each workgroup left to k_scatter4_clustered
     P.total = o;
     return true;
 }
@@ -1810,6 +1915,9 @@ static hipError_t launch_part3_t(const IDT *d_ids, const double *d_v, size_t n, 
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_survey_count_h<IDT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(5 * SVH_SLOTS * 4));
         if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter4_clustered<IDT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)CL_LDS_BYTES);
+        if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_plan_count),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NQMAX * sizeof(uint32_t)));
         if (e == hipSuccess)
@@ -1836,6 +1944,7 @@ static hipError_t launch_part3_t(const IDT *d_ids, const double *d_v, size_t n, 
     uint8_t *g_remap = base + P.off_remap, *g_inv = base + P.off_inv;
     pu2_t *g_pt2 = reinterpret_cast<pu2_t *>(base + P.off_pt2);
     uint32_t *g_hot = reinterpret_cast<uint32_t *>(rec + (P.off_hot - r0));
+    uint32_t *g_resume = reinterpret_cast<uint32_t *>(rec + (P.off_resume - r0));
 
     hipLaunchKernelGGL(k_v3_prepare, dim3(1024), dim3(256), 0, s, L1.cdesc, P.nchunks1, L1.pc,
                        (uint32_t)small_words(V3_NP, P.extra1), L2.cdesc, P.nchunks2, L2.pc,
@@ -1858,7 +1967,9 @@ static hipError_t launch_part3_t(const IDT *d_ids, const double *d_v, size_t n, 
     const size_t nt_full = n / V3_TILE, done = nt_full * V3_TILE;
     hipLaunchKernelGGL((k_scatter4<4, IDT>), dim3(P.g1), dim3(1024), P.lds_dyn, s, d_ids, d_v, nt_full, nmetrics, d_Tx, g_hk,
                        g_hs, g_hdr, g_pt, g_hot, L1.records, L1.cdesc, P.chunks_per_wg, counts, ranges,
-                       d_err, g_stats);
+                       d_err, g_stats, g_resume);
+    hipLaunchKernelGGL(k_scatter4_clustered<IDT>, dim3(P.g1), dim3(1024), CL_LDS_BYTES, s, d_ids, d_v, nt_full, nmetrics,
+                       g_resume, counts, ranges, d_err);
     hipLaunchKernelGGL(k_hot_reduce, dim3(V2_MAX_SLOTS), dim3(1024), 0, s, g_hot, P.g1, g_hs, g_hdr, counts, ranges, 0u, nullptr);
     if (done < n) {
         e = launch_ingest_pairs(d_ids + done, d_v + done, n - done, counts, ranges, nmetrics, d_Tx, d_err, num_cus, s);

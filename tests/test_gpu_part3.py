@@ -489,3 +489,40 @@ def test_the_first_large_call_takes_the_width_of_its_own_stream(native_lib, torc
         assert c["window_log2"] == 10 and c["reduce_window_misses"] > n // 4, sorted(c.items())
         with e.flip() as snap:
             check(snap, ids, v, M, snap.extract(PCTS, M))
+
+
+@pytest.mark.parametrize("id16", [False, True])
+def test_a_clustered_call_is_finished_by_the_cell_table(native_lib, torch_cuda, id16):
+    """Inside ONE call: a level-1 workgroup whose last two tiles overflowed by more than half leaves the rest of its turn
+    to k_scatter4_clustered, whose LDS is a (name, bin) -> count table (a 1e9-pair call sorted by name took 1.9 s through
+    the overflow path: profiles/r06_first_call.txt).  25 M pairs = 12 tiles per workgroup.  Every cell exact; bad ids in
+    the part the table counts are reported and skipped like everywhere else."""
+    import loghisto_amd
+    rng = np.random.default_rng(123)
+    M, n = (16384, 3 << 23) if not id16 else (12000, 3 << 23)
+    ids = np.sort(_ids(rng, M, n, 1.0))
+    v = rng.lognormal(10, 1.0, n)
+    v[-5000:] = 10.0 ** rng.uniform(-3, 18, 5000)             # wide tail inside the table's part
+    bad = np.arange(n - 100_000, n - 99_000)                  # ids out of range inside the table's part
+    ids_in = ids.copy()
+    ids_in[bad] = M + 7
+    keep = np.ones(n, bool)
+    keep[bad] = False
+    d_ids = _dev(torch_cuda, ids_in.astype(np.uint16) if id16 else ids_in)
+    d_v = _dev(torch_cuda, v)
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        e.submit_pairs_device(d_ids, d_v)
+        with pytest.raises(loghisto_amd.LhError) as ei:
+            e.sync()
+        assert ei.value.code == 6                              # ids out of range were seen (and skipped)
+        c = e.counters()
+        assert c["samples_partitioned_v3"] >= n - 8192, sorted(c.items())
+        with e.flip() as snap:
+            try:
+                got = snap.extract(PCTS, M)
+            except loghisto_amd.LhError:
+                got = snap.extract(PCTS, M)
+            check(snap, ids[keep], v[keep], M, got)
+        c = e.counters()
+        # (a workgroup stops after the first two tiles in a row that overflow: at most a few tiles each, of 12)
+        assert 8192 < c["region_overflows"] <= 256 * 4 * 8192, sorted(c.items())
