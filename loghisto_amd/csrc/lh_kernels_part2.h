@@ -894,7 +894,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
                                                        uint32_t *__restrict__ cdesc, uint32_t chunks_per_wg,
                                                        uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
                                                        uint32_t *__restrict__ err,
-                                                       unsigned long long *__restrict__ rstat)
+                                                       unsigned long long *__restrict__ rstat,
+                                                       uint32_t *__restrict__ g_resume)
 {
     // ONE LDS allocation: [Scatter3Lds][name table][regions][hot windows]
     typedef Scatter3LdsT<NPT> LdsT;
@@ -1150,6 +1151,15 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
                 const uint32_t key = L.missq[par][i];
                 if (!ov_add(L.ov_key, L.ov_cnt, key, 1u)) v2_global_add(counts, ranges, key >> 16, key & 0xffffu, 1);
             }
+            if (L.missn[par] > V2_MISSQ) { // (uniform) the tile overflowed past its queue, straight into the table: emptied
+                __syncthreads();           // here, the table takes the next tile's cells too instead of staying full
+                for (uint32_t i = tid; i < OV_SLOTS; i += BLOCK)
+                    if (L.ov_key[i] != OV_EMPTY) {
+                        v2_global_add(counts, ranges, L.ov_key[i] >> 16, L.ov_key[i] & 0xffffu, L.ov_cnt[i]);
+                        L.ov_key[i] = OV_EMPTY;
+                        L.ov_cnt[i] = 0;
+                    }
+            }
         }
         __syncthreads();                                   // barrier B: counters and regions are ready for the next tile
     };
@@ -1163,7 +1173,13 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
     // from the L2 the kernel was 23 % faster; profiles/r06_level1_ablations.txt).  With an unconditional body the count
     // is exact (vmcnt(15): the loads of the tile at hand only).
     static_assert(SC3_TILES_PER_FLUSH == 1, "two tiles per flush were measured (round 2: no gain) and removed");
+    // A stream CLUSTERED BY NAME (sorted by name, whole batches of one producer) fills one partition's region with every
+    // tile and sends the rest of the tile through the exact overflow path.  A workgroup whose last two tiles overflowed by
+    // more than an eighth stops here; the tiles it leaves are counted by k_scatter_clustered (its turn in g_resume).  Only the
+    // 1 024-thread shapes: that kernel's tile is theirs.
     uint32_t par = 0; // out-of-window queue of this flush group (the flush resets the other one)
+    uint32_t ovn_seen = 0, my_tiles = 0;
+    bool gave_up = false;
     size_t tile = blockIdx.x;
     const size_t G = gridDim.x;
     for (; tile + G < ntiles; tile += 2 * G) {
@@ -1175,11 +1191,32 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
         load_tile(tile + 3 * G, idb, vab);
         flush(par);
         par ^= 1u;
+        my_tiles += 2;
+        if (BLOCK == 1024) {
+            // (uniform: L.ovn is at rest between flush's last barrier and the next tile)
+            const uint32_t ovn_now = (uint32_t)__builtin_amdgcn_readfirstlane(L.ovn);
+            if (ovn_now - ovn_seen > (uint32_t)V3_TILE / 4u) { // more than an eighth of the two tiles just done
+                tile += 2 * G;
+                gave_up = true;
+                break;
+            }
+            ovn_seen = ovn_now;
+        }
     }
-    if (tile < ntiles) { // (workgroup-uniform) the workgroup's last tile when it has an odd number of them
+    if (!gave_up && tile < ntiles) { // (workgroup-uniform) the workgroup's last tile when it has an odd number of them
         classify(ida, vaa, par);
         flush(par);
         par ^= 1u;
+        tile += G;
+        my_tiles += 1;
+    }
+    if (tid == 0) {
+        g_resume[blockIdx.x] = BLOCK == 1024 ? (uint32_t)min(tile, ntiles) : 0xffffffffu; // this workgroup's first undone tile
+        // Up to 1 024 names the exact-layout scatter is the better STEADY state for such a stream (per 1e9 sorted pairs:
+        // 4.9 ms / 8.6 ms at 21 decades, against 5.3 / 19.5 through the table), so what this workgroup leaves is reported
+        // as overflow and the engine changes the path at the next flip, as it always did.  Above that it is not (8 192
+        // names: 42 / 108 ms against 6.5 / 39) and only what really overflowed is reported.  profiles/r06_first_call.txt
+        if (gave_up && nmetrics <= 1024u && tile < ntiles) L.ovn += (uint32_t)((ntiles - tile + G - 1) / G) * (uint32_t)V3_TILE;
     }
 
     // ---- drain: the regions' leftovers (< one line each) and the open chunks' descriptors
@@ -1232,10 +1269,85 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
     // the workgroup's part of the launch's account (stale_judge, by k_hot_reduce): its tiles, and the hits its cells
     // handed on to the rows already
     if (tid == 0) {
-        const uint32_t mine = blockIdx.x < ntiles ? (uint32_t)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0u;
+        const uint32_t mine = my_tiles; // (the tiles THIS kernel counted: a workgroup that gave up leaves the rest of its turn)
         if (L.spills) atomicAdd(&g_hdr[HDR_HITS], L.spills << 15);
         atomicAdd(&g_hdr[HDR_TILES], mine);
     }
+}
+
+// ---------------------------------------------------------------------------
+// What the workgroups of k_scatter3 / k_scatter4 left undone when they found the stream clustered by name
+// (g_resume[workgroup] = its first undone tile; >= ntiles: nothing, the workgroup returns at once -- every launch of an
+// ordinary stream).  The same turn
+// of tiles, counted in ONE open-addressed LDS table of (name << 16 | bin) -> count: a clustered tile holds a few names,
+// i.e. a few hundred distinct cells, and the table (16 384 slots) is emptied into the rows whenever it is half full.
+// Exact like every other path: a sample that finds its eight probe slots taken by other cells is one global atomic.
+// ---------------------------------------------------------------------------
+constexpr uint32_t CL_SLOTS = 16384, CL_PROBES = 8, CL_TILE = 8192; // (the tile of the 1 024-thread scatter kernels)
+constexpr size_t CL_LDS_BYTES = (size_t)CL_SLOTS * 8 + 16;
+
+template <typename IDT>
+__global__ __launch_bounds__(1024) void k_scatter_clustered(const IDT *__restrict__ ids, const double *__restrict__ v,
+                                                            size_t ntiles, uint32_t nmetrics,
+                                                            const double *__restrict__ Tx,
+                                                            const uint32_t *__restrict__ g_resume,
+                                                            uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
+                                                            uint32_t *__restrict__ err)
+{
+    size_t tile = g_resume[blockIdx.x];
+    if (tile >= ntiles) return;
+    constexpr uint32_t BLOCK = 1024;
+    extern __shared__ __attribute__((aligned(16))) unsigned char v3_smem[];
+    uint32_t *key = reinterpret_cast<uint32_t *>(v3_smem), *cnt = key + CL_SLOTS, *used = cnt + CL_SLOTS;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < CL_SLOTS; i += BLOCK) { key[i] = OV_EMPTY; cnt[i] = 0; }
+    if (tid == 0) *used = 0;
+    __syncthreads();
+    auto drain = [&]() {
+        for (uint32_t i = tid; i < CL_SLOTS; i += BLOCK) {
+            const uint32_t k = key[i];
+            if (k != OV_EMPTY) {
+                v2_global_add(counts, ranges, k >> 16, k & 0xffffu, cnt[i]);
+                key[i] = OV_EMPTY;
+                cnt[i] = 0;
+            }
+        }
+        if (tid == 0) *used = 0;
+    };
+    for (; tile < ntiles; tile += gridDim.x) {
+        const size_t base = tile * CL_TILE + tid;
+        uint32_t id[V2_SPT];
+        double x[V2_SPT];
+#pragma unroll
+        for (int j = 0; j < V2_SPT; j++) {
+            id[j] = ids[base + (size_t)j * BLOCK];
+            x[j] = __builtin_nontemporal_load(v + base + (size_t)j * BLOCK);
+        }
+#pragma unroll
+        for (int j = 0; j < V2_SPT; j++) {
+            bool unc;
+            uint32_t bin = lh_bin_fast(x[j], unc);
+            if (unc) bin = lh_bin_of(x[j], Tx); // (inside a threshold's guard band: the table compare)
+            if (id[j] >= nmetrics) { atomicOr(err, 1u); continue; }
+            const uint32_t k = (id[j] << 16) | bin;
+            const uint32_t h0 = (k * 2654435761u) >> 18; // 14 bits
+            bool placed = false;
+#pragma unroll 1
+            for (uint32_t probe = 0; probe < CL_PROBES && !placed; probe++) {
+                const uint32_t sl = (h0 + probe) & (CL_SLOTS - 1u);
+                const uint32_t prev = atomicCAS(&key[sl], OV_EMPTY, k);
+                if (prev == OV_EMPTY) atomicAdd(used, 1u);
+                if (prev == OV_EMPTY || prev == k) { atomicAdd(&cnt[sl], 1u); placed = true; }
+            }
+            if (!placed) v2_global_add(counts, ranges, id[j], bin, 1);
+        }
+        __syncthreads();
+        if (*used > CL_SLOTS / 2u) { // (uniform: nothing adds between the barriers)
+            drain();
+        }
+        __syncthreads();
+    }
+    drain();
 }
 
 // The hot windows of a launch's G workgroups, added up: one workgroup per hot name (g_hs), a thread per cell walks the
@@ -1473,7 +1585,7 @@ struct Part2Plan {
     uint32_t region_recs;      // shapes 2, 3: upper bound of the records of LDS the partitions' regions take
     RegionFit fit;             // shapes 2, 3: what k_survey_plan needs to split the LDS between regions and hot windows
     size_t lds_dyn;            // dynamic LDS of the scatter kernel
-    size_t off_rec, off_cd, off_sorted, off_small, off_stat, off_nt, off_hs, off_hdr, off_pt, off_hot, total;
+    size_t off_rec, off_cd, off_sorted, off_small, off_stat, off_nt, off_hs, off_hdr, off_pt, off_hot, off_resume, total;
 };
 
 static bool make_plan2(size_t n, uint32_t nmetrics, int num_cus, const PartTuning &tune, Part2Plan &P)
@@ -1540,6 +1652,7 @@ static bool make_plan2(size_t n, uint32_t nmetrics, int num_cus, const PartTunin
     P.off_hdr = take(64);
     P.off_pt = take(512 * sizeof(pu2_t));
     P.off_hot = take(direct ? (size_t)P.fit.max_cells * 2 * ((size_t)num_cus * wgs_per_cu) : 0); // k_scatter3's windows, one copy per workgroup
+    P.off_resume = take((size_t)num_cus * wgs_per_cu * 4); // k_scatter3: the first tile each workgroup left to k_scatter_clustered
     P.off_rec = take((size_t)P.nchunks * CHUNK * sizeof(rec16_t));
     P.off_cd = take((size_t)P.nchunks * sizeof(uint32_t));
     P.off_sorted = take((size_t)P.nchunks * sizeof(uint32_t));
@@ -1587,6 +1700,9 @@ static hipError_t launch_part2_t(const IDT *d_ids, const double *d_v, size_t n, 
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter3<1024, 512, SC3_BATCH, IDT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)V2_LDS_TOTAL);
         if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_clustered<IDT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)CL_LDS_BYTES);
+        if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_survey_count<IDT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(V2_MAX_NAMES * 16));
         if (e == hipSuccess)
@@ -1609,6 +1725,7 @@ static hipError_t launch_part2_t(const IDT *d_ids, const double *d_v, size_t n, 
     uint32_t *g_hdr = reinterpret_cast<uint32_t *>(base + P.off_hdr);
     pu2_t *g_pt = reinterpret_cast<pu2_t *>(base + P.off_pt);
     uint32_t *g_hot = reinterpret_cast<uint32_t *>(base + P.off_hot);
+    uint32_t *g_resume = reinterpret_cast<uint32_t *>(base + P.off_resume);
 
     hipError_t e = hipMemsetAsync(L1.cdesc, 0xff, (size_t)P.nchunks * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
@@ -1630,15 +1747,18 @@ static hipError_t launch_part2_t(const IDT *d_ids, const double *d_v, size_t n, 
         if (P.shape == 3)
             hipLaunchKernelGGL((k_scatter3<512, 128, SC3_BATCH, IDT>), dim3(P.g1), dim3(512), p1_dyn, s, d_ids, d_v, nt_full, nmetrics,
                                P.log_np, P.log_w, d_Tx, g_nt, g_hs, g_hdr, g_pt, g_hot, records,
-                               L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, region_stat);
+                               L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, region_stat, g_resume);
         else if (P.shape & 4u)
             hipLaunchKernelGGL((k_scatter3<1024, 512, SC3_BATCH, IDT>), dim3(P.g1), dim3(1024), p1_dyn, s, d_ids, d_v, nt_full,
                                nmetrics, P.log_np, P.log_w, d_Tx, g_nt, g_hs, g_hdr, g_pt, g_hot,
-                               records, L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, region_stat);
+                               records, L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, region_stat, g_resume);
         else
             hipLaunchKernelGGL((k_scatter3<1024, 256, SC3_BATCH, IDT>), dim3(P.g1), dim3(1024), p1_dyn, s, d_ids, d_v, nt_full,
                                nmetrics, P.log_np, P.log_w, d_Tx, g_nt, g_hs, g_hdr, g_pt, g_hot,
-                               records, L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, region_stat);
+                               records, L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, region_stat, g_resume);
+        if (P.shape != 3)
+            hipLaunchKernelGGL(k_scatter_clustered<IDT>, dim3(P.g1), dim3(1024), CL_LDS_BYTES, s, d_ids, d_v, nt_full, nmetrics,
+                               d_Tx, g_resume, counts, ranges, d_err);
         hipLaunchKernelGGL(k_hot_reduce, dim3(V2_MAX_SLOTS), dim3(1024), 0, s, g_hot, P.g1, g_hs, g_hdr, counts, ranges, P.tile,
                            region_stat);
         if (done < n) {

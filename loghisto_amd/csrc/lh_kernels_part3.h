@@ -672,8 +672,8 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
     // register set's loads)
     // A stream CLUSTERED BY NAME (sorted by name, or whole batches of one producer) fills one partition's region with
     // every tile and sends the rest -- most of the tile -- through the exact overflow path: a 1e9-pair call took 1.9 s
-    // (profiles/r06_first_call.txt).  A workgroup whose last two tiles overflowed by more than half stops here; the tiles
-    // it leaves are counted by k_scatter4_clustered (its turn in g_resume), whose whole LDS is one (name, bin) table.
+    // (profiles/r06_first_call.txt).  A workgroup whose last two tiles overflowed by more than an eighth stops here; the tiles
+    // it leaves are counted by k_scatter_clustered (its turn in g_resume), whose whole LDS is one (name, bin) table.
     uint32_t par = 0, ovn_seen = 0;
     bool gave_up = false;
     size_t tile = blockIdx.x;
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
         par ^= 1u;
         // (uniform: L.ovn is at rest between flush's last barrier and the next tile)
         const uint32_t ovn_now = (uint32_t)__builtin_amdgcn_readfirstlane(L.ovn);
-        if (ovn_now - ovn_seen > V3_TILE) { // more than half of the two tiles just done
+        if (ovn_now - ovn_seen > V3_TILE / 4u) { // more than an eighth of the two tiles just done
             tile += 2 * G;
             gave_up = true;
             break;
@@ -747,79 +747,6 @@ __global__ __launch_bounds__(1024, 4) void k_scatter4(const IDT *__restrict__ id
     }
     for (uint32_t i = tid; i < OV_SLOTS; i += BLOCK)
         if (L.ov_key[i] != OV_EMPTY) v2_global_add(counts, ranges, L.ov_key[i] >> 16, L.ov_key[i] & 0xffffu, L.ov_cnt[i]);
-}
-
-// ---------------------------------------------------------------------------
-// What k_scatter4's workgroups left undone when they found the stream clustered by name (g_resume[workgroup] = its first
-// undone tile; >= ntiles: nothing, the workgroup returns at once -- every launch of an ordinary stream).  The same turn
-// of tiles, counted in ONE open-addressed LDS table of (name << 16 | bin) -> count: a clustered tile holds a few names,
-// i.e. a few hundred distinct cells, and the table (16 384 slots) is emptied into the rows whenever it is half full.
-// Exact like every other path: a sample that finds its eight probe slots taken by other cells is one global atomic.
-// ---------------------------------------------------------------------------
-constexpr uint32_t CL_SLOTS = 16384, CL_PROBES = 8;
-constexpr size_t CL_LDS_BYTES = (size_t)CL_SLOTS * 8 + 16;
-
-template <typename IDT>
-__global__ __launch_bounds__(1024) void k_scatter4_clustered(const IDT *__restrict__ ids, const double *__restrict__ v,
-                                                             size_t ntiles, uint32_t nmetrics,
-                                                             const uint32_t *__restrict__ g_resume,
-                                                             uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
-                                                             uint32_t *__restrict__ err)
-{
-    size_t tile = g_resume[blockIdx.x];
-    if (tile >= ntiles) return;
-    constexpr uint32_t BLOCK = 1024;
-    extern __shared__ __attribute__((aligned(16))) unsigned char v3_smem[];
-    uint32_t *key = reinterpret_cast<uint32_t *>(v3_smem), *cnt = key + CL_SLOTS, *used = cnt + CL_SLOTS;
-    const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i < CL_SLOTS; i += BLOCK) { key[i] = OV_EMPTY; cnt[i] = 0; }
-    if (tid == 0) *used = 0;
-    __syncthreads();
-    auto drain = [&]() {
-        for (uint32_t i = tid; i < CL_SLOTS; i += BLOCK) {
-            const uint32_t k = key[i];
-            if (k != OV_EMPTY) {
-                v2_global_add(counts, ranges, k >> 16, k & 0xffffu, cnt[i]);
-                key[i] = OV_EMPTY;
-                cnt[i] = 0;
-            }
-        }
-        if (tid == 0) *used = 0;
-    };
-    for (; tile < ntiles; tile += gridDim.x) {
-        const size_t base = tile * V3_TILE + tid;
-        uint32_t id[V2_SPT];
-        double x[V2_SPT];
-#pragma unroll
-        for (int j = 0; j < V2_SPT; j++) {
-            id[j] = ids[base + (size_t)j * BLOCK];
-            x[j] = __builtin_nontemporal_load(v + base + (size_t)j * BLOCK);
-        }
-#pragma unroll
-        for (int j = 0; j < V2_SPT; j++) {
-            bool unc;
-            uint32_t bin = lh_bin_fast(x[j], unc);
-            if (unc) bin = v3_bin_exact(x[j]);
-            if (id[j] >= nmetrics) { atomicOr(err, 1u); continue; }
-            const uint32_t k = (id[j] << 16) | bin;
-            const uint32_t h0 = (k * 2654435761u) >> 18; // 14 bits
-            bool placed = false;
-#pragma unroll 1
-            for (uint32_t probe = 0; probe < CL_PROBES && !placed; probe++) {
-                const uint32_t sl = (h0 + probe) & (CL_SLOTS - 1u);
-                const uint32_t prev = atomicCAS(&key[sl], OV_EMPTY, k);
-                if (prev == OV_EMPTY) atomicAdd(used, 1u);
-                if (prev == OV_EMPTY || prev == k) { atomicAdd(&cnt[sl], 1u); placed = true; }
-            }
-            if (!placed) v2_global_add(counts, ranges, id[j], bin, 1);
-        }
-        __syncthreads();
-        if (*used > CL_SLOTS / 2u) { // (uniform: nothing adds between the barriers)
-            drain();
-        }
-        __syncthreads();
-    }
-    drain();
 }
 
 // ---------------------------------------------------------------------------
@@ -1856,7 +1783,7 @@ static bool make_plan3(size_t n, uint32_t nmetrics, int num_cus, const PartTunin
     P.off_small2 = take(small_words(P.nq, P.extra2) * sizeof(uint32_t));
     P.off_gstats = take(64); // the launch's self-metrics: with the records, not with the tables (launches may share tables)
     P.off_hot = take((size_t)P.max_cells * 2 * P.g1); // level 1's hot windows, one copy per workgroup (k_hot_reduce)
-    P.off_resume = take((size_t)P.g1 * 4);            // level 1: the first tile each workgroup left to k_scatter4_clustered
+    P.off_resume = take((size_t)P.g1 * 4);            // level 1: the first tile each workgroup left to k_scatter_clustered
     P.total = o;
     return true;
 }
@@ -1915,7 +1842,7 @@ static hipError_t launch_part3_t(const IDT *d_ids, const double *d_v, size_t n, 
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_survey_count_h<IDT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(5 * SVH_SLOTS * 4));
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter4_clustered<IDT>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_clustered<IDT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)CL_LDS_BYTES);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_plan_count),
@@ -1968,8 +1895,8 @@ static hipError_t launch_part3_t(const IDT *d_ids, const double *d_v, size_t n, 
     hipLaunchKernelGGL((k_scatter4<4, IDT>), dim3(P.g1), dim3(1024), P.lds_dyn, s, d_ids, d_v, nt_full, nmetrics, d_Tx, g_hk,
                        g_hs, g_hdr, g_pt, g_hot, L1.records, L1.cdesc, P.chunks_per_wg, counts, ranges,
                        d_err, g_stats, g_resume);
-    hipLaunchKernelGGL(k_scatter4_clustered<IDT>, dim3(P.g1), dim3(1024), CL_LDS_BYTES, s, d_ids, d_v, nt_full, nmetrics,
-                       g_resume, counts, ranges, d_err);
+    hipLaunchKernelGGL(k_scatter_clustered<IDT>, dim3(P.g1), dim3(1024), CL_LDS_BYTES, s, d_ids, d_v, nt_full, nmetrics,
+                       d_Tx, g_resume, counts, ranges, d_err);
     hipLaunchKernelGGL(k_hot_reduce, dim3(V2_MAX_SLOTS), dim3(1024), 0, s, g_hot, P.g1, g_hs, g_hdr, counts, ranges, 0u, nullptr);
     if (done < n) {
         e = launch_ingest_pairs(d_ids + done, d_v + done, n - done, counts, ranges, nmetrics, d_Tx, d_err, num_cus, s);

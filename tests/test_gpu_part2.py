@@ -319,3 +319,46 @@ def test_wide_value_spans_take_the_wide_shape_by_themselves(native_lib, torch_cu
         c4 = call(d_n, narrow)
         c5 = call(d_n, narrow)
         assert c5["samples_partitioned_v2"] == 6 * n, c5
+
+
+@pytest.mark.parametrize("M,shape,kind", [(8192, 2, "lognormal"), (1024, 2, "sigma25"), (1024, 6, "loguniform"), (3000, 0, "lognormal")],
+                         ids=["8192-direct", "1024-direct", "1024-wide", "3000-exact-layout"])
+def test_a_clustered_call_is_finished_by_the_cell_table(native_lib, torch_cuda, M, shape, kind):
+    """Inside ONE call (as at 8 193+ names, tests/test_gpu_part3.py): a region-scatter workgroup whose last two tiles
+    overflowed by more than an eighth leaves the rest of its turn to k_scatter_clustered (an LDS table of (name, bin) -> count).
+    1e9 pairs sorted by name over 8 192 names took 68 ms on their first call and 42 ms per call on the exact layout after
+    it (profiles/r06_first_call.txt).  25 M pairs = 12 tiles per workgroup; every cell exact, bad ids reported and skipped.
+    The exact-layout shape (0) has no regions: nothing overflows, the table never runs."""
+    import loghisto_amd
+    rng = np.random.default_rng(321)
+    n = 3 << 23
+    ids = np.sort(_ids(rng, M, n, 1.0))
+    v = _values(rng, kind, ids, n)
+    bad = np.arange(n - 100_000, n - 99_000)
+    ids_in = ids.copy()
+    ids_in[bad] = M + 7
+    keep = np.ones(n, bool)
+    keep[bad] = False
+    d_ids, d_v = _dev(torch_cuda, ids_in), _dev(torch_cuda, v)
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        e.set_option(N.OPT_PART_V2_SHAPE, shape)
+        e.set_option(N.OPT_PART_V2_MIN_PAIRS, 1 << 17)
+        e.submit_pairs_device(d_ids, d_v)
+        with pytest.raises(loghisto_amd.LhError) as ei:
+            e.sync()
+        assert ei.value.code == 6
+        c = e.counters()
+        assert c["samples_partitioned_v2"] == n, sorted(c.items())
+        with e.flip() as snap:
+            try:
+                got = snap.extract(PCTS, M)
+            except loghisto_amd.LhError:
+                got = snap.extract(PCTS, M)
+            _check(snap, ids[keep], v[keep], M, got)
+        c = e.counters()
+        if shape & 2 and M > 1024:
+            assert 8192 < c["region_overflows"] <= 256 * 4 * 8192, sorted(c.items())
+        elif shape & 2:     # up to 1 024 names the tiles left to the table are reported too: the engine leaves the path
+            assert c["region_overflows"] > n // 4 and c["regions_disabled"] == 1, sorted(c.items())
+        else:
+            assert c["region_overflows"] == 0, sorted(c.items())

@@ -493,7 +493,7 @@ def test_the_first_large_call_takes_the_width_of_its_own_stream(native_lib, torc
 
 @pytest.mark.parametrize("id16", [False, True])
 def test_a_clustered_call_is_finished_by_the_cell_table(native_lib, torch_cuda, id16):
-    """Inside ONE call: a level-1 workgroup whose last two tiles overflowed by more than half leaves the rest of its turn
+    """Inside ONE call: a level-1 workgroup whose last two tiles overflowed by more than an eighth leaves the rest of its turn
     to k_scatter4_clustered, whose LDS is a (name, bin) -> count table (a 1e9-pair call sorted by name took 1.9 s through
     the overflow path: profiles/r06_first_call.txt).  25 M pairs = 12 tiles per workgroup.  Every cell exact; bad ids in
     the part the table counts are reported and skipped like everywhere else."""

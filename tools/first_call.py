@@ -7,13 +7,16 @@ import torch, bench, loghisto_amd
 torch.cuda.set_device(0)
 stream = torch.cuda.Stream(); torch.cuda.set_stream(stream)
 M = int(os.environ.get('NAMES', '65536'))
-IDS = sys.argv[2] if len(sys.argv) > 2 else "zipf"   # "sorted": the stream ordered by name (clustered)
+IDS = sys.argv[2] if len(sys.argv) > 2 else "zipf"   # sorted | uniform | drift | runs: see below
 NS = [int(float(x)) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [int(1e8), int(1e9)]
 w = torch.arange(1, M + 1, dtype=torch.float64, device="cuda") ** -1.0
 for dist in sys.argv[1].split(","):
   for n in NS:
     ids = torch.multinomial(w / w.sum(), n, replacement=True).to(torch.int32)
     if IDS == "sorted": ids = torch.sort(ids).values.contiguous()
+    if IDS == "uniform": ids = torch.randint(0, M, (n,), device="cuda", dtype=torch.int32)
+    if IDS == "drift": ids[n // 2:] = (M - 1) - ids[n // 2:]
+    if IDS == "runs": ids = ids.view(-1, 4096)[:, :1].expand(-1, 4096).contiguous().view(-1)   # 4 096 pairs of one name in a row
     data = bench.make_samples(n, dist, 7)
     for logw in ((0, 10, 13) if M > 8192 and not os.environ.get("ONLY0") else (0,)):
         eng = loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16)
