@@ -1284,7 +1284,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
 // Exact like every other path: a sample that finds its eight probe slots taken by other cells is one global atomic.
 // ---------------------------------------------------------------------------
 constexpr uint32_t CL_SLOTS = 16384, CL_PROBES = 8, CL_TILE = 8192; // (the tile of the 1 024-thread scatter kernels)
-constexpr size_t CL_LDS_BYTES = (size_t)CL_SLOTS * 8 + 16;
+constexpr size_t CL_LDS_BYTES = (size_t)CL_SLOTS * 8 + 16; // + `used`, `gadds`
 
 template <typename IDT>
 __global__ __launch_bounds__(1024) void k_scatter_clustered(const IDT *__restrict__ ids, const double *__restrict__ v,
@@ -1292,28 +1292,33 @@ __global__ __launch_bounds__(1024) void k_scatter_clustered(const IDT *__restric
                                                             const double *__restrict__ Tx,
                                                             const uint32_t *__restrict__ g_resume,
                                                             uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
-                                                            uint32_t *__restrict__ err)
+                                                            uint32_t *__restrict__ err, uint32_t *__restrict__ g_ovf)
 {
     size_t tile = g_resume[blockIdx.x];
     if (tile >= ntiles) return;
     constexpr uint32_t BLOCK = 1024;
     extern __shared__ __attribute__((aligned(16))) unsigned char v3_smem[];
     uint32_t *key = reinterpret_cast<uint32_t *>(v3_smem), *cnt = key + CL_SLOTS, *used = cnt + CL_SLOTS;
+    uint32_t *gadds = used + 1; // global adds this workgroup has made: emptied slots + samples that found no slot
     const uint32_t tid = threadIdx.x;
     for (uint32_t i = tid; i < CL_SLOTS; i += BLOCK) { key[i] = OV_EMPTY; cnt[i] = 0; }
-    if (tid == 0) *used = 0;
+    if (tid == 0) { *used = 0; *gadds = 0; }
     __syncthreads();
     auto drain = [&]() {
+        uint32_t mine = 0;
         for (uint32_t i = tid; i < CL_SLOTS; i += BLOCK) {
             const uint32_t k = key[i];
             if (k != OV_EMPTY) {
                 v2_global_add(counts, ranges, k >> 16, k & 0xffffu, cnt[i]);
                 key[i] = OV_EMPTY;
                 cnt[i] = 0;
+                mine++;
             }
         }
+        if (mine) atomicAdd(gadds, mine);
         if (tid == 0) *used = 0;
     };
+    const size_t first_tile = tile;
     for (; tile < ntiles; tile += gridDim.x) {
         const size_t base = tile * CL_TILE + tid;
         uint32_t id[V2_SPT];
@@ -1339,7 +1344,7 @@ __global__ __launch_bounds__(1024) void k_scatter_clustered(const IDT *__restric
                 if (prev == OV_EMPTY) atomicAdd(used, 1u);
                 if (prev == OV_EMPTY || prev == k) { atomicAdd(&cnt[sl], 1u); placed = true; }
             }
-            if (!placed) v2_global_add(counts, ranges, id[j], bin, 1);
+            if (!placed) { v2_global_add(counts, ranges, id[j], bin, 1); atomicAdd(gadds, 1u); }
         }
         __syncthreads();
         if (*used > CL_SLOTS / 2u) { // (uniform: nothing adds between the barriers)
@@ -1348,6 +1353,16 @@ __global__ __launch_bounds__(1024) void k_scatter_clustered(const IDT *__restric
         __syncthreads();
     }
     drain();
+    __syncthreads();
+    // The table pays when a tile's samples meet in few cells -- long runs of one name (a sorted stream: one global add per
+    // 20 samples).  Runs of 64 .. 256 pairs put 32 .. 128 names into every tile: nearly every sample is its own cell (0.7 ..
+    // 0.9 adds per sample, 35 .. 43 ms per 1e9 pairs where the exact-layout path takes 10).  Such a launch reports what it
+    // counted here as overflow, and the engine leaves the region scatter at the next flip as it did before this kernel
+    // existed (profiles/r06_first_call.txt, section F).
+    if (tid == 0 && g_ovf) {
+        const size_t mine = ((tile - first_tile) / gridDim.x) * CL_TILE;
+        if ((size_t)*gadds * 2 > mine) atomicAdd(g_ovf, (uint32_t)mine);
+    }
 }
 
 // The hot windows of a launch's G workgroups, added up: one workgroup per hot name (g_hs), a thread per cell walks the
@@ -1758,7 +1773,7 @@ static hipError_t launch_part2_t(const IDT *d_ids, const double *d_v, size_t n, 
                                records, L1.cdesc, P.chunks_per_wg, counts, ranges, d_err, region_stat, g_resume);
         if (P.shape != 3)
             hipLaunchKernelGGL(k_scatter_clustered<IDT>, dim3(P.g1), dim3(1024), CL_LDS_BYTES, s, d_ids, d_v, nt_full, nmetrics,
-                               d_Tx, g_resume, counts, ranges, d_err);
+                               d_Tx, g_resume, counts, ranges, d_err, g_hdr + HDR_OVF);
         hipLaunchKernelGGL(k_hot_reduce, dim3(V2_MAX_SLOTS), dim3(1024), 0, s, g_hot, P.g1, g_hs, g_hdr, counts, ranges, P.tile,
                            region_stat);
         if (done < n) {

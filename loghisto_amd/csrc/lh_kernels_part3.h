@@ -1896,7 +1896,7 @@ static hipError_t launch_part3_t(const IDT *d_ids, const double *d_v, size_t n, 
                        g_hs, g_hdr, g_pt, g_hot, L1.records, L1.cdesc, P.chunks_per_wg, counts, ranges,
                        d_err, g_stats, g_resume);
     hipLaunchKernelGGL(k_scatter_clustered<IDT>, dim3(P.g1), dim3(1024), CL_LDS_BYTES, s, d_ids, d_v, nt_full, nmetrics,
-                       d_Tx, g_resume, counts, ranges, d_err);
+                       d_Tx, g_resume, counts, ranges, d_err, g_stats);
     hipLaunchKernelGGL(k_hot_reduce, dim3(V2_MAX_SLOTS), dim3(1024), 0, s, g_hot, P.g1, g_hs, g_hdr, counts, ranges, 0u, nullptr);
     if (done < n) {
         e = launch_ingest_pairs(d_ids + done, d_v + done, n - done, counts, ranges, nmetrics, d_Tx, d_err, num_cus, s);

@@ -16,11 +16,15 @@ for dist in sys.argv[1].split(","):
     if IDS == "sorted": ids = torch.sort(ids).values.contiguous()
     if IDS == "uniform": ids = torch.randint(0, M, (n,), device="cuda", dtype=torch.int32)
     if IDS == "drift": ids[n // 2:] = (M - 1) - ids[n // 2:]
-    if IDS == "runs": ids = ids.view(-1, 4096)[:, :1].expand(-1, 4096).contiguous().view(-1)   # 4 096 pairs of one name in a row
+    if IDS.startswith("runs"):  # runsR: R pairs of one name in a row
+        R = int(IDS[4:] or 4096)
+        ids = ids[::R].repeat_interleave(R)[:n].contiguous()
     data = bench.make_samples(n, dist, 7)
     for logw in ((0, 10, 13) if M > 8192 and not os.environ.get("ONLY0") else (0,)):
         eng = loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16)
         if logw: eng.set_option(14, logw)  # LH_OPT_PART_V3_LOG_W
+        for kv in os.environ.get("OPTS", "").split(","):
+            if kv: eng.set_option(int(kv.split("=")[0]), int(kv.split("=")[1]))
         prev = eng.counters()
         for r in range(4):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
