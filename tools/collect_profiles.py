@@ -17,7 +17,7 @@ FILES = {  # gpurun_out/round/<src> -> profiles/<tag>_<dst>
     "bench_under_trace.json": "bench_under_trace.json", "kernel_trace.txt": "kernel_trace.txt", "k1_pmc.json": "k1_pmc.json",
     "c3_kernel_trace.txt": "c3_kernel_trace.txt", "c3_pmc.json": "c3_pmc.json", "c4_kernel_trace.txt": "c4_kernel_trace.txt",
     "c4_pmc.json": "c4_pmc.json", "c4_names_1e9_kernel_trace.txt": "c4_names_1e9_kernel_trace.txt",
-    "c4_names_1e9_pmc.json": "c4_names_1e9_pmc.json", "read_ceiling.jsonl": "read_ceiling.jsonl", "sweep_final.jsonl": "sweep_final.jsonl",
+    "c4_names_1e9_pmc.json": "c4_names_1e9_pmc.json", "read_ceiling.jsonl": "read_ceiling.jsonl", "sweep_final.jsonl": "sweep_final.jsonl", "first_calls.txt": "first_calls.txt",
 }
 
 

@@ -13,6 +13,7 @@
 #   c3_pmc.json             FETCH_SIZE / WRITE_SIZE passes of the same command, every kernel of the call summed
 #   c4_bench.json           bench.py --workload c4 (one rank)
 #   c4_kernel_trace.txt / c4_pmc.json   the same for bench.py --workload c4 (65 536 names, one rank's 1.25e8-pair slice)
+#   first_calls.txt         tools/first_call.py: calls 0 .. 3 of fresh engines on wide, sorted and run-clustered streams
 # PMC passes are separate runs with no tracing domain mixed in.
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/round; mkdir -p $OUT; cd $R
 STAMP=$(python -c "import bench; print(bench.tree_stamp())")
@@ -70,7 +71,7 @@ out={"kernel":"lh::k_ingest_single","workload":"1e9 float64 samples, lognormal(l
 json.dump(out, open("$OUT/k1_pmc.json","w"), indent=1)
 # C3: every kernel of one lh_submit_pairs_device call (4 calls in the run: 1 warmup + 3 timed)
 calls = 4
-kernels = ["k_survey_count", "k_survey_plan", "k_scatter3", "k_scatter2", "k_hot_reduce", "k_plan_count", "k_plan_scan",
+kernels = ["k_survey_count", "k_survey_plan", "k_scatter3", "k_scatter2", "k_scatter_clustered", "k_hot_reduce", "k_plan_count", "k_plan_scan",
            "k_plan_scatter", "k_part_hist2", "k_ingest_pairs"]
 per = {}; rd = wr = 0.0
 for k in kernels:
@@ -89,7 +90,7 @@ json.dump({"workload":"C3: 1e9 (uint32 id, float64 value) pairs over 1 024 Zipf(
 # pass of timed calls: one k_scatter4 launch per call (the extract-latency leg, whose small intervals take the same
 # kernels since round 4, is switched off: --latency-flips 0).
 calls = pmc("/tmp/pr_c4f/t_results.db", "k_scatter4")["FETCH_SIZE"]["launches"]
-k4 = ["k_survey_count_h", "k_survey_pick", "k_survey_plan_h", "k_survey_remap", "k_scatter4", "k_hot_reduce", "k_split_waves",
+k4 = ["k_survey_count_h", "k_survey_pick", "k_survey_plan_h", "k_survey_remap", "k_scatter4", "k_scatter_clustered", "k_hot_reduce", "k_split_waves",
       "k_split_records", "k_part_hist3", "k_v3_report"]
 per = {}; rd = wr = 0.0
 for k in k4:
@@ -120,7 +121,7 @@ sys.path.insert(0, R)
 import bench
 def pmc(db, k):
     return json.loads(subprocess.check_output(["python", R+"/profiles/summarize_rocpd.py", "pmc", db, k]))["counters"]
-ks = ["k_survey_count_h", "k_survey_pick", "k_survey_plan_h", "k_survey_remap", "k_v3_prepare", "k_scatter4", "k_hot_reduce", "k_split_waves",
+ks = ["k_survey_count_h", "k_survey_pick", "k_survey_plan_h", "k_survey_remap", "k_v3_prepare", "k_scatter4", "k_scatter_clustered", "k_hot_reduce", "k_split_waves",
       "k_split_records", "k_part_hist3", "k_plan_count", "k_plan_scan", "k_plan_scatter", "k_v3_report", "k_ingest_pairs"]
 per = {}; rd = wr = 0.0
 calls = pmc("/tmp/pr_5f/t_results.db", "k_scatter4")["FETCH_SIZE"]["launches"]
@@ -139,6 +140,12 @@ json.dump({"workload": "65 536 Zipf(1.0) names, 1e9 (uint32 id, float64 value) p
  "algorithmic_bytes_per_call": 12e9, "traffic_over_algorithmic": (rd+wr)/12e9}, open("$OUT/c4_names_1e9_pmc.json", "w"), indent=1)
 print(json.dumps({"c4 1e9 read": rd, "write": wr, "ratio": (rd+wr)/12e9, "calls": calls}))
 PY
+# first calls of fresh engines and clustered streams (sweeps drop their first calls): per-call times of four calls each
+cd $R
+{ echo "# tree_stamp: $STAMP"; echo "# tools/first_call.py <dists> <ids> 1e9 (NAMES=..., ONLY0=1): ms per call, calls 0 .. 3 of a fresh engine"
+  for c in "65536 zipf lognormal,loguniform" "65536 sorted lognormal,loguniform" "65536 runs256 lognormal" "8192 sorted lognormal,loguniform" "1024 sorted lognormal"; do
+    set -- $c; echo "== names $1, ids $2"; NAMES=$1 ONLY0=1 timeout 300 python tools/first_call.py $3 $2 1e9 2>&1 | grep " call " | sed -e "s/ logw_opt 0//" -e "s/'records_level2'.*'region_overflows'/'region_overflows'/" | cut -c1-200
+  done; } > $OUT/first_calls.txt
 # LAST: the final kernels over the value distributions, each on its own survey, behind a warm-up series (40 K1 launches)
 cd $R
 python tools/sweep.py --samples 1e9 --reps 40 --dists lognormal > /dev/null 2>&1
@@ -146,6 +153,8 @@ python tools/sweep.py --samples 1e9 --reps 40 --dists lognormal > /dev/null 2>&1
   python tools/sweep.py --samples 1e9 --reps 5 2>/dev/null
   python tools/sweep.py --samples 1e9 --pairs 1024 --reps 4 --dists lognormal,constant,uniform,exponential,normal,loguniform,lognormal25,kvalues2,kvalues4,kvalues8,kvalues16,bimodal,signed_wide 2>/dev/null
   python tools/sweep.py --samples 1e9 --pairs 65536 --reps 4 --dists lognormal,constant,kvalues2,kvalues8,bimodal,lognormal25,loguniform 2>/dev/null
+  python tools/sweep.py --samples 1e9 --pairs 65536 --reps 4 --ids sorted --dists lognormal 2>/dev/null
+  python tools/sweep.py --samples 1e9 --pairs 1024 --reps 4 --ids sorted --dists lognormal 2>/dev/null
 } | cut -c1-700 > $OUT/sweep_final.jsonl
 cat $OUT/c4_kernel_trace.txt | cut -c1-150
 ls -la $OUT; tail -c 1500 $OUT/bench.json; grep -E "k_ingest_single" $OUT/kernel_trace.txt | cut -c1-140; cat $OUT/c3_kernel_trace.txt | cut -c1-150; python -c "
