@@ -17,9 +17,6 @@
 # PMC passes are separate runs with no tracing domain mixed in.
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/round; mkdir -p $OUT; cd $R
 STAMP=$(python -c "import bench; print(bench.tree_stamp())")
-python bench.py 2> $OUT/bench.err | grep "^{" | tail -1 > $OUT/bench.json
-python bench.py --gpus 1 --steps 20 --warmup 5 2> $OUT/bench20.err | grep "^{" | tail -1 > $OUT/bench_steps20_warmup5.json
-python bench.py --workload c4 2> $OUT/c4_bench.err | grep "^{" | tail -1 > $OUT/c4_bench.json
 { echo "{\"tree_stamp\": \"$STAMP\"}"; loghisto_amd/build/read_ceiling --reps 20 2>&1; } > $OUT/read_ceiling.jsonl
 cd /tmp; export TMPDIR=/tmp
 CMD="python $R/bench.py --workload c2 --no-secondary --steps 30 --warmup 5 --no-cpu-baseline --no-parity --latency-flips 0"
@@ -140,6 +137,13 @@ json.dump({"workload": "65 536 Zipf(1.0) names, 1e9 (uint32 id, float64 value) p
  "algorithmic_bytes_per_call": 12e9, "traffic_over_algorithmic": (rd+wr)/12e9}, open("$OUT/c4_names_1e9_pmc.json", "w"), indent=1)
 print(json.dumps({"c4 1e9 read": rd, "write": wr, "ratio": (rd+wr)/12e9, "calls": calls}))
 PY
+# The bench lines, AFTER the counter passes: bench.py takes its `traffic` fields from profiles/r06_*_pmc.json and refuses
+# summaries measured on other kernel sources -- the ones just written are this tree's.
+cd $R
+for f in k1_pmc c3_pmc c4_pmc c4_names_1e9_pmc; do cp $OUT/$f.json $R/profiles/r06_$f.json; done
+python bench.py 2> $OUT/bench.err | grep "^{" | tail -1 > $OUT/bench.json
+python bench.py --gpus 1 --steps 20 --warmup 5 2> $OUT/bench20.err | grep "^{" | tail -1 > $OUT/bench_steps20_warmup5.json
+python bench.py --workload c4 2> $OUT/c4_bench.err | grep "^{" | tail -1 > $OUT/c4_bench.json
 # first calls of fresh engines and clustered streams (sweeps drop their first calls): per-call times of four calls each
 cd $R
 { echo "# tree_stamp: $STAMP"; echo "# tools/first_call.py <dists> <ids> 1e9 (NAMES=..., ONLY0=1): ms per call, calls 0 .. 3 of a fresh engine"
