@@ -150,15 +150,15 @@ cd $R
   for c in "65536 zipf lognormal,loguniform" "65536 sorted lognormal,loguniform" "65536 runs256 lognormal" "8192 sorted lognormal,loguniform" "1024 sorted lognormal"; do
     set -- $c; echo "== names $1, ids $2"; NAMES=$1 ONLY0=1 timeout 300 python tools/first_call.py $3 $2 1e9 2>&1 | grep " call " | sed -e "s/ logw_opt 0//" -e "s/'records_level2'.*'region_overflows'/'region_overflows'/" | cut -c1-200
   done; } > $OUT/first_calls.txt
-# LAST: the final kernels over the value distributions, each on its own survey, behind a warm-up series (40 K1 launches)
+# LAST: the final kernels over the value distributions, each on its own survey, every sweep process behind its own
+# warm-up series (--warmup 40: K1 launches in the SAME process -- a warm-up in a process of its own left the next one cold)
 cd $R
-python tools/sweep.py --samples 1e9 --reps 40 --dists lognormal > /dev/null 2>&1
 { echo "{\"tree_stamp\": \"$STAMP\"}"
-  python tools/sweep.py --samples 1e9 --reps 5 2>/dev/null
-  python tools/sweep.py --samples 1e9 --pairs 1024 --reps 4 --dists lognormal,constant,uniform,exponential,normal,loguniform,lognormal25,kvalues2,kvalues4,kvalues8,kvalues16,bimodal,signed_wide 2>/dev/null
-  python tools/sweep.py --samples 1e9 --pairs 65536 --reps 4 --dists lognormal,constant,kvalues2,kvalues8,bimodal,lognormal25,loguniform 2>/dev/null
-  python tools/sweep.py --samples 1e9 --pairs 65536 --reps 4 --ids sorted --dists lognormal 2>/dev/null
-  python tools/sweep.py --samples 1e9 --pairs 1024 --reps 4 --ids sorted --dists lognormal 2>/dev/null
+  python tools/sweep.py --warmup 40 --samples 1e9 --reps 5 2>/dev/null
+  python tools/sweep.py --warmup 40 --samples 1e9 --pairs 1024 --reps 4 --dists lognormal,constant,uniform,exponential,normal,loguniform,lognormal25,kvalues2,kvalues4,kvalues8,kvalues16,bimodal,signed_wide 2>/dev/null
+  python tools/sweep.py --warmup 40 --samples 1e9 --pairs 65536 --reps 4 --dists lognormal,constant,kvalues2,kvalues8,bimodal,lognormal25,loguniform 2>/dev/null
+  python tools/sweep.py --warmup 40 --samples 1e9 --pairs 65536 --reps 4 --ids sorted --dists lognormal 2>/dev/null
+  python tools/sweep.py --warmup 40 --samples 1e9 --pairs 1024 --reps 4 --ids sorted --dists lognormal 2>/dev/null
 } | cut -c1-700 > $OUT/sweep_final.jsonl
 cat $OUT/c4_kernel_trace.txt | cut -c1-150
 ls -la $OUT; tail -c 1500 $OUT/bench.json; grep -E "k_ingest_single" $OUT/kernel_trace.txt | cut -c1-140; cat $OUT/c3_kernel_trace.txt | cut -c1-150; python -c "

@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--nocheck", action="store_true", help="timing of an ablation build (tools/build_tuning.py -D...): counts are wrong")
     ap.add_argument("--survey-every", type=int, default=32, help="LH_OPT_SURVEY_EVERY; set again before every distribution, which "
                                                                  "ends the reuse of the previous distribution's survey")
+    ap.add_argument("--warmup", type=int, default=0,
+                    help="untimed single-metric launches of 1e9 lognormal samples IN THIS PROCESS before the first distribution "
+                         "(a fresh process starts on idle clocks: its first line used to read 10 %% slow)")
     ap.add_argument("--keep-survey", action="store_true",
                     help="do NOT end the survey's reuse between distributions: every distribution after the first starts on a "
                          "STALE survey (round 5 measured its few-valued streams that way without knowing: profiles/r05_fewvalued.txt)")
@@ -45,6 +48,16 @@ def main():
     for kv in a.opt:
         k, val = kv.split("=")
         eng.set_option(int(k), int(val))
+    if a.warmup:
+        wdata = bench.make_samples(int(1e9), "lognormal", 3)
+        for r in range(a.warmup):
+            eng.submit_device(0, wdata, int(1e9), stream=stream)
+            if r % 8 == 7:
+                torch.cuda.synchronize()
+                eng.flip().release()
+        torch.cuda.synchronize()
+        eng.flip().release()
+        del wdata
     for kind in a.dists.split(","):
         if a.pairs and not a.keep_survey:
             eng.set_option(16, a.survey_every)  # LH_OPT_SURVEY_EVERY: the tables of the previous distribution are not reused
