@@ -31,11 +31,14 @@ Step choose_step(const DispatchState &st, uintptr_t ids, uint32_t id_width, uint
     // a lane's half-buffer (read over PCIe in place): first generation -- no tables that outlive the launch -- in a block
     // of the lanes' own, so that its later passes run beside another lane's link-bound read
     if (host_fed && aligned && take <= kLaneBlockMaxPairs && st.lane_blocks) {
+        PartTuning tl = st.tune; // the lanes' own thresholds, unless the caller set them
+        if (!tl.part_min_samples) tl.part_min_samples = kLanePartMinPairs;
+        if (!tl.v3_min_samples) tl.v3_min_samples = kLaneV3MinPairs;
         // Above 8 192 names the first generation's two scatter levels cost a lane-sized launch more GPU time than its
         // pairs take on the link (65 536 names, 2 M pairs: 0.58 ms against 0.4): the third generation (0.36 ms) runs in the
         // lane's block too, with the survey's tables -- read-only between surveys -- shared by all lanes.
         if (st.lane_gen3 && !st.v3_disabled && !st.regions_disabled) {
-            PartTuning t3 = st.tune;
+            PartTuning t3 = tl;
             t3.v3_log_w = st.call_log_w;
             t3.v3_g1_cap = st.lane_g1_cap;
             const size_t need3 = part3_records_bytes(take, M, st.num_cus, t3);
@@ -49,17 +52,18 @@ Step choose_step(const DispatchState &st, uintptr_t ids, uint32_t id_width, uint
                 return r;
             }
         }
-        const size_t need1 = part_scratch_bytes(take, M, st.num_cus, st.tune);
+        const size_t need1 = part_scratch_bytes(take, M, st.num_cus, tl);
         if (need1) {
             r.kind = PATH_GEN1;
             r.lane_block = true;
             r.scratch = need1;
             r.scratch_alloc = std::max(need1, part_scratch_bytes(std::min(kLaneBlockMaxPairs, std::max(take, st.lane_samples)),
-                                                                 M, st.num_cus, st.tune));
+                                                                 M, st.num_cus, tl));
+            r.tune = tl;
             return r;
         }
     }
-    if (aligned && part_scratch_bytes(take, M, st.num_cus, st.tune)) {
+    if (aligned) {
         // Large launch over many names: partition by name, then reduce in LDS.  Sub-launches keep the scratch block
         // bounded: at most `sublaunch_pairs` pairs each, halved until the block fits `scratch_cap` (power-of-two cuts
         // keep both arrays on their vector alignment).  Above 8 192 names the second scatter level carries its chunk
@@ -74,9 +78,12 @@ Step choose_step(const DispatchState &st, uintptr_t ids, uint32_t id_width, uint
         if (st.regions_disabled) tune.v2_shape &= ~6u; // clustered stream: the exact-layout scatter
         if (st.v3_disabled) tune.v3 = false;            // skew-free names: first generation
         tune.v3_log_w = st.call_log_w;
-        // generation 2 (survey + 2-byte records) for <= 8 192 names, generation 3 above, when the launch is large enough;
-        // otherwise the first generation
-        auto scratch_need = [&](size_t m, PathKind *kind) {
+        // generation 2 (survey + 2-byte records) for <= 8 192 names, generation 3 above, when the launch is large enough for
+        // it (each generation has its own minimum; an option may lower one below the others'); otherwise the first
+        // generation; a launch none of them takes is the direct path's
+        auto scratch_need = [&](size_t m, PathKind *kind) -> size_t {
+            *kind = PATH_DIRECT;
+            if (tune.part_min_samples && m < tune.part_min_samples) return 0; // LH_OPT_PART_MIN_PAIRS bounds every generation
             size_t bytes = part2_scratch_bytes(m, M, st.num_cus, tune);
             *kind = PATH_GEN2;
             if (!bytes) { bytes = part3_scratch_bytes(m, M, st.num_cus, tune); *kind = PATH_GEN3; }
@@ -92,7 +99,7 @@ Step choose_step(const DispatchState &st, uintptr_t ids, uint32_t id_width, uint
             sub = half;
             need = scratch_need(sub, &kind);
         }
-        if (need) { // (always: sub is above the partitioned path's minimum)
+        if (need) {
             r.kind = kind;
             r.take = sub;
             r.scratch = r.scratch_alloc = need;

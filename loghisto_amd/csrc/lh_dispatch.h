@@ -25,6 +25,9 @@ enum PathKind : uint32_t { PATH_DIRECT = 0, PATH_SMALL = 1, PATH_GEN1 = 2, PATH_
 
 constexpr size_t kMaxLaunchPairs = size_t(1) << 30;   // one launch: LDS counters and record indices stay below 2^32
 constexpr size_t kLaneBlockMaxPairs = size_t(1) << 22; // larger host-fed launches amortise their passes: the shared block
+// A host-fed lane's half-buffer keeps the thresholds it was tuned with (profiles/r05_hostfed_native.jsonl): its launches are
+// link-bound in their first pass whatever the kernel, and the lanes' blocks exist so that later passes run beside the next read.
+constexpr size_t kLanePartMinPairs = size_t(1) << 17, kLaneV3MinPairs = size_t(1) << 18;
 constexpr uint32_t kLaneLevel1Workgroups = 8;          // a lane's third-generation launch: level-1 workgroups (PartTuning::v3_g1_cap)
 
 // What the choice reads.  lh_engine fills it once per call (under its scratch lock: every option that feeds a launch

@@ -388,8 +388,9 @@ bool scratch_alloc(lh_engine *e, void **p, size_t bytes)
 
 int run_direct(lh_engine *e, EpochBuffer &b, lh::Ids d_ids, const double *d_v, size_t take, hipStream_t s)
 {
-    HIPCHK(lh::launch_ingest_pairs(d_ids, d_v, take, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx, e->d_err,
-                                   e->num_cus, s));
+    // (round 6: whole tiles through a per-workgroup LDS table of cells, the rest one global atomic per sample)
+    HIPCHK(lh::launch_ingest_pairs_cells(d_ids, d_v, take, b.counts, b.ranges, e->cfg.max_metrics, e->d_Tx, e->d_err,
+                                         e->num_cus, s));
     e->c_direct.fetch_add(take, std::memory_order_relaxed);
     return LH_OK;
 }

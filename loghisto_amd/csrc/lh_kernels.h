@@ -53,6 +53,11 @@ hipError_t launch_ingest_single(const double *d_v, size_t n, uint64_t *row, uint
 hipError_t launch_ingest_pairs(Ids d_ids, const double *d_v, size_t n, uint64_t *counts,
                                uint32_t *ranges, uint32_t nmetrics, const double *d_Tx, uint32_t *d_err,
                                int num_cus, hipStream_t s);
+// The same without scratch or survey, but through a per-workgroup LDS table of (name, bin) -> count (lh_kernels_part2.h:
+// k_scatter_clustered on its own): what the engine's "direct" path launches.  Exact; robust against streams that fall into
+// few cells, where one global atomic per sample serialises.
+hipError_t launch_ingest_pairs_cells(Ids d_ids, const double *d_v, size_t n, uint64_t *counts, uint32_t *ranges,
+                                     uint32_t nmetrics, const double *d_Tx, uint32_t *d_err, int num_cus, hipStream_t s);
 
 // Dispatch settings of the partitioned mixed ingest (lh_set_option).  Every setting only chooses among
 // exact kernel paths; none of them is read from the environment in the product build.

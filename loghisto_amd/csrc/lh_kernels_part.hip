@@ -56,7 +56,10 @@ constexpr uint32_t INVALID = 0xffffffffu;
 constexpr int P2_BLOCK = 1024;         // 16 waves: two workgroups (64 KiB windows each) fill a CU
 constexpr uint32_t P2_WINWORDS = 16384; // 64 KiB of uint32 windows per workgroup
 constexpr uint32_t SLOT_EXTRA = 1024;  // work slots beyond one per partition (measured: 512 is 25 % slower)
-constexpr size_t PART_MIN_SAMPLES = 131072;
+// Smallest launch that takes a partitioned path by default (round 6, profiles/r06_small_calls.txt: below it the cell-table
+// kernel -- launch_ingest_pairs_cells, no scratch, no survey -- is faster): 2^20 pairs up to 8 192 names, 3 * 2^20 above
+// (two scatter levels: ~0.15 ms of fixed work per launch).  Until round 6: 131 072 for both.
+constexpr size_t PART_MIN_SAMPLES = size_t(1) << 20, PART_MIN_SAMPLES_2L = size_t(3) << 20;
 constexpr uint32_t PART_MAX_MPP = 256;
 // chunk descriptor: partition tag << 11 | records in the chunk (1..1024); INVALID = unused
 constexpr uint32_t CD_SHIFT = 11, CD_MASK = (1u << CD_SHIFT) - 1;
@@ -83,11 +86,14 @@ static uint32_t ilog2_ceil(uint32_t x)
 static size_t small_words(uint32_t nq, uint32_t extra) { return (size_t)3 * nq + 3 * (nq + extra) + 1 + (nq + extra + 1) + 16; }
 
 // Smallest launch worth partitioning (below it: one global atomic per sample, k_ingest_pairs).
-static size_t part_min_samples(const PartTuning &tune) { return tune.part_min_samples ? tune.part_min_samples : PART_MIN_SAMPLES; }
+static size_t part_min_samples(const PartTuning &tune, uint32_t nmetrics)
+{
+    return tune.part_min_samples ? tune.part_min_samples : nmetrics > 8192u ? PART_MIN_SAMPLES_2L : PART_MIN_SAMPLES;
+}
 
 static bool make_plan(size_t n, uint32_t nmetrics, int num_cus, const PartTuning &tune, PartPlan &P)
 {
-    if (n < part_min_samples(tune) || n > (size_t(1) << 31) || nmetrics < 2) return false;
+    if (n < part_min_samples(tune, nmetrics) || n > (size_t(1) << 31) || nmetrics < 2) return false;
     // names per partition: 4 gives every name a 4 096-bin LDS window in P2.  Fewer partitions mean longer
     // contiguous runs in P1 but narrower windows in P2 (measured at 1 024 names, profiles/r01c: 4 is the best
     // overall).

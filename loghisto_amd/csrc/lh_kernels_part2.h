@@ -38,7 +38,10 @@ constexpr uint32_t LINE2 = 32;                         // records per line (64 B
 constexpr uint32_t V2_MAX_NAMES = 8192;
 constexpr uint32_t V2_MAX_SLOTS = 512;                 // hot names
 constexpr uint32_t HOT_WHOLE_SPAN = 320;               // sampled spans up to this many bins get a hot window over all of it
-constexpr size_t V2_MIN_SAMPLES = size_t(1) << 25; // measured crossover with the first-generation path: profiles/r02_c3_sizes.txt
+// smallest launch that takes this path: where it overtakes the cell-table kernel (profiles/r06_small_calls.txt).  Until round 6
+// 2^25, the crossover with the first generation while every call surveyed itself (profiles/r02_c3_sizes.txt); with one survey
+// per 32 calls this path is the faster one at every size the first generation takes.
+constexpr size_t V2_MIN_SAMPLES = size_t(1) << 20;
 constexpr uint32_t V2_LDS_TOTAL = 160 * 1024;
 constexpr uint32_t SV_GRID = 256;                      // survey workgroups (one 4 096-sample tile each)
 constexpr uint32_t P2V2_WINWORDS = 32768;              // 128 KiB of uint32 windows per P2 workgroup
@@ -1285,8 +1288,10 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter3(const IDT *__restrict__ i
 // ---------------------------------------------------------------------------
 constexpr uint32_t CL_SLOTS = 16384, CL_PROBES = 8, CL_TILE = 8192; // (the tile of the 1 024-thread scatter kernels)
 constexpr size_t CL_LDS_BYTES = (size_t)CL_SLOTS * 8 + 16; // + `used`, `gadds`
+constexpr uint32_t CL_SMALL_SLOTS = 4096;                  // tiles of 1 024 pairs (small calls): two workgroups per CU
+constexpr size_t CL_SMALL_LDS_BYTES = (size_t)CL_SMALL_SLOTS * 8 + 16;
 
-template <typename IDT>
+template <typename IDT, int SPT = V2_SPT, uint32_t SLOTS = CL_SLOTS>
 __global__ __launch_bounds__(1024) void k_scatter_clustered(const IDT *__restrict__ ids, const double *__restrict__ v,
                                                             size_t ntiles, uint32_t nmetrics,
                                                             const double *__restrict__ Tx,
@@ -1294,52 +1299,75 @@ __global__ __launch_bounds__(1024) void k_scatter_clustered(const IDT *__restric
                                                             uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
                                                             uint32_t *__restrict__ err, uint32_t *__restrict__ g_ovf)
 {
-    size_t tile = g_resume[blockIdx.x];
+    // (g_resume == null: the kernel on its own, every workgroup from its first tile -- launch_ingest_pairs_cells)
+    size_t tile = g_resume ? g_resume[blockIdx.x] : blockIdx.x;
     if (tile >= ntiles) return;
-    constexpr uint32_t BLOCK = 1024;
+    constexpr uint32_t BLOCK = 1024, TILE = BLOCK * SPT;
+    static_assert(SPT == 1 || TILE == CL_TILE, "behind the scatter kernels the tile is theirs");
     extern __shared__ __attribute__((aligned(16))) unsigned char v3_smem[];
-    uint32_t *key = reinterpret_cast<uint32_t *>(v3_smem), *cnt = key + CL_SLOTS, *used = cnt + CL_SLOTS;
+    uint32_t *key = reinterpret_cast<uint32_t *>(v3_smem), *cnt = key + SLOTS, *used = cnt + SLOTS;
     uint32_t *gadds = used + 1; // global adds this workgroup has made: emptied slots + samples that found no slot
     const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i < CL_SLOTS; i += BLOCK) { key[i] = OV_EMPTY; cnt[i] = 0; }
+    for (uint32_t i = tid; i < SLOTS; i += BLOCK) { key[i] = OV_EMPTY; cnt[i] = 0; }
     if (tid == 0) { *used = 0; *gadds = 0; }
     __syncthreads();
+    // Emptying the table: a thread's slots in three sweeps -- every count's atomic, then every range's look, then the
+    // widenings -- so that the slots' memory round trips overlap instead of queueing behind one another (v2_global_add slot by
+    // slot: a 1 024-pair call spent 9 of its 15 us here).
     auto drain = [&]() {
-        uint32_t mine = 0;
-        for (uint32_t i = tid; i < CL_SLOTS; i += BLOCK) {
-            const uint32_t k = key[i];
-            if (k != OV_EMPTY) {
-                v2_global_add(counts, ranges, k >> 16, k & 0xffffu, cnt[i]);
+        constexpr uint32_t PER = SLOTS / BLOCK;
+        uint32_t k[PER], mine = 0;
+        pu2_t rg[PER];
+#pragma unroll
+        for (uint32_t j = 0; j < PER; j++) {
+            const uint32_t i = tid + j * BLOCK;
+            k[j] = key[i];
+            if (k[j] != OV_EMPTY) {
+                atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)(k[j] >> 16) * LH_ROW_STRIDE + (k[j] & 0xffffu)]),
+                          (unsigned long long)cnt[i]);
                 key[i] = OV_EMPTY;
                 cnt[i] = 0;
                 mine++;
             }
         }
-        if (mine) atomicAdd(gadds, mine);
+        if (mine) { // (most threads of a small call hold nothing)
+#pragma unroll
+            for (uint32_t j = 0; j < PER; j++)
+                if (k[j] != OV_EMPTY) rg[j] = *reinterpret_cast<const pu2_t *>(ranges + 2 * (size_t)(k[j] >> 16));
+#pragma unroll
+            for (uint32_t j = 0; j < PER; j++)
+                if (k[j] != OV_EMPTY) {
+                    uint32_t *r = ranges + 2 * (size_t)(k[j] >> 16);
+                    const uint32_t bin = k[j] & 0xffffu;
+                    if (bin < rg[j].x) atomicMin(&r[0], bin);
+                    if (bin > rg[j].y) atomicMax(&r[1], bin);
+                }
+            atomicAdd(gadds, mine);
+        }
         if (tid == 0) *used = 0;
     };
     const size_t first_tile = tile;
     for (; tile < ntiles; tile += gridDim.x) {
-        const size_t base = tile * CL_TILE + tid;
-        uint32_t id[V2_SPT];
-        double x[V2_SPT];
+        const size_t base = tile * TILE + tid;
+        uint32_t id[SPT];
+        double x[SPT];
 #pragma unroll
-        for (int j = 0; j < V2_SPT; j++) {
+        for (int j = 0; j < SPT; j++) {
             id[j] = ids[base + (size_t)j * BLOCK];
             x[j] = __builtin_nontemporal_load(v + base + (size_t)j * BLOCK);
         }
 #pragma unroll
-        for (int j = 0; j < V2_SPT; j++) {
+        for (int j = 0; j < SPT; j++) {
             bool unc;
             uint32_t bin = lh_bin_fast(x[j], unc);
             if (unc) bin = lh_bin_of(x[j], Tx); // (inside a threshold's guard band: the table compare)
             if (id[j] >= nmetrics) { atomicOr(err, 1u); continue; }
             const uint32_t k = (id[j] << 16) | bin;
-            const uint32_t h0 = (k * 2654435761u) >> 18; // 14 bits
+            const uint32_t h0 = (k * 2654435761u) >> 16; // (the slot mask takes its low bits: 12 or 14 of the product's top 16)
             bool placed = false;
 #pragma unroll 1
             for (uint32_t probe = 0; probe < CL_PROBES && !placed; probe++) {
-                const uint32_t sl = (h0 + probe) & (CL_SLOTS - 1u);
+                const uint32_t sl = (h0 + probe) & (SLOTS - 1u);
                 const uint32_t prev = atomicCAS(&key[sl], OV_EMPTY, k);
                 if (prev == OV_EMPTY) atomicAdd(used, 1u);
                 if (prev == OV_EMPTY || prev == k) { atomicAdd(&cnt[sl], 1u); placed = true; }
@@ -1347,7 +1375,7 @@ __global__ __launch_bounds__(1024) void k_scatter_clustered(const IDT *__restric
             if (!placed) { v2_global_add(counts, ranges, id[j], bin, 1); atomicAdd(gadds, 1u); }
         }
         __syncthreads();
-        if (*used > CL_SLOTS / 2u) { // (uniform: nothing adds between the barriers)
+        if (*used > SLOTS / 2u) { // (uniform: nothing adds between the barriers)
             drain();
         }
         __syncthreads();
@@ -1360,9 +1388,66 @@ __global__ __launch_bounds__(1024) void k_scatter_clustered(const IDT *__restric
     // counted here as overflow, and the engine leaves the region scatter at the next flip as it did before this kernel
     // existed (profiles/r06_first_call.txt, section F).
     if (tid == 0 && g_ovf) {
-        const size_t mine = ((tile - first_tile) / gridDim.x) * CL_TILE;
+        const size_t mine = ((tile - first_tile) / gridDim.x) * TILE;
         if ((size_t)*gadds * 2 > mine) atomicAdd(g_ovf, (uint32_t)mine);
     }
+}
+
+// The cell table ON ITS OWN: the path of calls too small for a partitioned path (and of calls whose scratch block cannot be
+// had).  No scratch, no survey, exact.  Against one global atomic per sample (k_ingest_pairs: 8 - 11 G pairs/s on a Zipf /
+// lognormal stream, but 0.6 G/s when the values are constant and 0.08 G/s -- 12 ns per sample -- when they all fall into ONE
+// cell: same-address atomics serialise) the table adds what meets in a cell BEFORE it goes to memory.  Tiles of 8 192 pairs
+// when there are enough of them to fill the device, of 1 024 otherwise; the pairs behind the last whole tile take
+// k_ingest_pairs.  profiles/r06_small_calls.txt
+template <typename IDT>
+static hipError_t launch_cells_t(const IDT *d_ids, const double *d_v, size_t n, uint64_t *counts, uint32_t *ranges,
+                                 uint32_t nmetrics, const double *d_Tx, uint32_t *d_err, int num_cus, hipStream_t s, size_t *done)
+{
+    static std::atomic<bool> attr_set{false}; // benign if two threads race: both set the same attributes
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_clustered<IDT, V2_SPT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)CL_LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_clustered<IDT, 1, CL_SLOTS>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)CL_LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_clustered<IDT, 1, CL_SMALL_SLOTS>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)CL_SMALL_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    *done = 0;
+    // (measured per call size, Zipf names x lognormal values: the large table adds up hot cells across a workgroup's tiles and
+    // wins from 2^17 pairs; below, its 128 KiB to initialise and scan are most of a call)
+    if (n / CL_TILE >= 2 * (size_t)num_cus) {
+        const size_t nt = n / CL_TILE;
+        hipLaunchKernelGGL((k_scatter_clustered<IDT, V2_SPT>), dim3((unsigned)std::min<size_t>(nt, (size_t)num_cus)), dim3(1024),
+                           CL_LDS_BYTES, s, d_ids, d_v, nt, nmetrics, d_Tx, nullptr, counts, ranges, d_err, nullptr);
+        *done = nt * CL_TILE;
+    } else if (n >= (size_t(1) << 17)) {
+        const size_t nt = n / 1024;
+        hipLaunchKernelGGL((k_scatter_clustered<IDT, 1, CL_SLOTS>), dim3((unsigned)std::min<size_t>(nt, (size_t)num_cus)), dim3(1024),
+                           CL_LDS_BYTES, s, d_ids, d_v, nt, nmetrics, d_Tx, nullptr, counts, ranges, d_err, nullptr);
+        *done = nt * 1024;
+    } else if (n >= 1024) {
+        const size_t nt = n / 1024;
+        hipLaunchKernelGGL((k_scatter_clustered<IDT, 1, CL_SMALL_SLOTS>), dim3((unsigned)std::min<size_t>(nt, 2 * (size_t)num_cus)),
+                           dim3(1024), CL_SMALL_LDS_BYTES, s, d_ids, d_v, nt, nmetrics, d_Tx, nullptr, counts, ranges, d_err, nullptr);
+        *done = nt * 1024;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_ingest_pairs_cells(Ids d_ids, const double *d_v, size_t n, uint64_t *counts, uint32_t *ranges,
+                                     uint32_t nmetrics, const double *d_Tx, uint32_t *d_err, int num_cus, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    size_t done = 0;
+    hipError_t e = d_ids.width == 2 ? launch_cells_t(d_ids.u16(), d_v, n, counts, ranges, nmetrics, d_Tx, d_err, num_cus, s, &done)
+                                    : launch_cells_t(d_ids.u32(), d_v, n, counts, ranges, nmetrics, d_Tx, d_err, num_cus, s, &done);
+    if (e != hipSuccess) return e;
+    if (done < n) e = launch_ingest_pairs(d_ids.plus(done), d_v + done, n - done, counts, ranges, nmetrics, d_Tx, d_err, num_cus, s);
+    return e;
 }
 
 // The hot windows of a launch's G workgroups, added up: one workgroup per hot name (g_hs), a thread per cell walks the

@@ -56,7 +56,8 @@ constexpr uint32_t V3_MISSQ = 512;                      // records a tile can qu
 // generation beats the first at every size measured (round 4, profiles/r04_level1_experiments.txt: 65 536 names, 0.26 M /
 // 1 M / 2 M / 4 M / 8 M pairs 0.17 / 0.30 / 0.36 / 0.41 / 0.49 ms against 0.49 / 0.53 / 0.58 / 0.63 / 0.69) -- lane-sized
 // host-fed launches included.
-constexpr size_t V3_MIN_SAMPLES = size_t(1) << 18;
+constexpr size_t V3_MIN_SAMPLES = size_t(3) << 20;     // device-resident calls: below, the cell-table kernel is faster (r06_small_calls.txt)
+constexpr size_t V3_TABLES_SAMPLES = size_t(1) << 18;  // (the launch size the survey tables' offsets are computed at: any valid one)
 constexpr size_t V3_DIRECT_MAX = size_t(1) << 22; // launches up to this many pairs: reduce pass without windows (k_part_direct3)
 constexpr uint32_t SVH_GRID = 256, SVH_SLOTS = 4096;    // hashed survey: 256 workgroups x 2 048 samples
 constexpr uint32_t V3_EXTRA1 = 768;                     // level-1 work slots beyond one per partition
@@ -1801,7 +1802,8 @@ size_t part3_tables_bytes(uint32_t nmetrics)
 {
     Part3Plan P;
     PartTuning t;
-    return make_plan3(V3_MIN_SAMPLES, nmetrics, 256, t, P) ? P.off_rec1 : 0;
+    t.v3_min_samples = V3_TABLES_SAMPLES;
+    return make_plan3(V3_TABLES_SAMPLES, nmetrics, 256, t, P) ? P.off_rec1 : 0;
 }
 
 size_t part3_records_bytes(size_t n, uint32_t nmetrics, int num_cus, const PartTuning &tune)

@@ -72,7 +72,8 @@ static void test_health_and_peel()
 static void test_choose_step_grid()
 {
     const uint32_t names[] = {1, 2, 32, 33, 1000, 8192, 8193, 40000, 65536, 65537};
-    const size_t sizes[] = {1, 1000, 65535, 65536, 131071, 131072, (size_t(1) << 18) - 1, size_t(1) << 18, size_t(1) << 22,
+    const size_t sizes[] = {1, 1000, 65535, 65536, 131071, 131072, (size_t(1) << 18) - 1, size_t(1) << 18, (size_t(1) << 20) - 2,
+                            size_t(1) << 20, (size_t(3) << 20) - 2, size_t(3) << 20, size_t(1) << 22,
                             (size_t(1) << 22) + 2, size_t(1) << 25, size_t(125000000), size_t(1000000000), size_t(3) << 30};
     int states = 0;
     for (uint32_t M : names)
@@ -102,10 +103,23 @@ static void test_choose_step_grid()
                                 CHECK(s.scratch_alloc >= s.scratch);
                                 if (s.kind == lh::PATH_SMALL) CHECK(M <= 32 && s.take >= 65536 && !st.small_disabled);
                                 // (few names reach the partitioned paths only while adaptive dispatch has the single pass off)
-                                if (s.kind == lh::PATH_GEN2) CHECK(M >= 2 && M <= 8192 && (M >= 33 || st.small_disabled) && s.take >= (size_t(1) << 25));
+                                // round 6: a device-resident launch is partitioned from 2^20 pairs (<= 8 192 names; the second
+                                // generation at once) / 3 * 2^20 (above); below, the direct path's cell table is faster.  A
+                                // lane's half-buffer keeps 2^17 / 2^18.
+                                const size_t min12 = s.lane_block ? lh::kLanePartMinPairs : M > 8192 ? size_t(3) << 20 : size_t(1) << 20;
+                                const size_t min3 = s.lane_block ? lh::kLaneV3MinPairs : size_t(3) << 20;
+                                if (s.kind == lh::PATH_GEN2) CHECK(M >= 2 && M <= 8192 && (M >= 33 || st.small_disabled) && s.take >= min12 && !s.lane_block);
                                 if (s.kind == lh::PATH_GEN3)
-                                    CHECK(M >= 8193 && M <= 65536 && s.take >= (size_t(1) << 18) && !st.v3_disabled && !st.regions_disabled);
-                                if (s.kind == lh::PATH_GEN1) CHECK(M >= 2 && M <= 65536 && (M >= 33 || st.small_disabled) && s.take >= 131072);
+                                    CHECK(M >= 8193 && M <= 65536 && s.take >= min3 && !st.v3_disabled && !st.regions_disabled);
+                                if (s.kind == lh::PATH_GEN1) CHECK(M >= 2 && M <= 65536 && (M >= 33 || st.small_disabled) && s.take >= min12);
+                                // ... and takes the second generation whenever it is partitioned at all (the first only on a
+                                // lane's block, or when an adaptive switch sent it there)
+                                if (!s.lane_block && s.kind == lh::PATH_GEN1 && M <= 8192) CHECK(!"the first generation below 8 193 names");
+                                if (!host_fed && M >= 33 && M <= 8192 && s.take >= (size_t(1) << 20)) CHECK(s.kind == lh::PATH_GEN2);
+                                if (!host_fed && M >= 8193 && M <= 65536 && s.take >= (size_t(3) << 20) && !st.v3_disabled && !st.regions_disabled)
+                                    CHECK(s.kind == lh::PATH_GEN3);
+                                if (!host_fed && M >= 33 && M <= 65536 && s.take < (M > 8192 ? size_t(3) << 20 : size_t(1) << 20))
+                                    CHECK(s.kind == lh::PATH_DIRECT);
                                 if (s.kind == lh::PATH_DIRECT) CHECK(s.take == (n < lh::kMaxLaunchPairs ? n : lh::kMaxLaunchPairs));
                                 // a lane's block: the first generation up to 8 192 names, the third above (while neither
                                 // adaptive switch has it off)

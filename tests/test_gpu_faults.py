@@ -12,6 +12,8 @@ import threading
 import numpy as np
 import pytest
 
+from tests.conftest import thresholds_until_round_6
+
 import oracle
 from loghisto_amd import _native as N
 
@@ -53,7 +55,7 @@ def _check(snap, ids, v, M):
 @pytest.mark.parametrize("M,n,opts,counter", [
     (1024, 1_500_001, {N.OPT_PART_V2_MIN_PAIRS: 1 << 17}, "samples_partitioned_v2"),    # second generation
     (65536, 2_000_000, {N.OPT_PART_V3_MIN_PAIRS: 1 << 17}, "samples_partitioned_v3"),   # third
-    (300, 900_000, {}, "samples_partitioned"),                                          # first
+    (300, 900_000, {N.OPT_PART_V2: 0, N.OPT_PART_MIN_PAIRS: 1 << 17}, "samples_partitioned"),   # first (no call's default since round 6)
 ])
 def test_device_resident_call_falls_back_and_recovers(native_lib, torch_cuda, M, n, opts, counter):
     import loghisto_amd
@@ -104,6 +106,7 @@ def test_a_block_that_cannot_grow(native_lib, torch_cuda):
     M = 1024
     small, big = _stream(M, 400_000, 1), _stream(M, 3_000_000, 2)
     with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        thresholds_until_round_6(e)
         e.submit_pairs_device(_dev(torch_cuda, small[0]), _dev(torch_cuda, small[1]))
         e.sync()
         first = e.counters()["scratch_bytes"]

@@ -8,6 +8,8 @@ import math
 import numpy as np
 import pytest
 
+from tests.conftest import thresholds_until_round_6
+
 import oracle
 from loghisto_amd import _native as N
 
@@ -64,6 +66,7 @@ def test_hot_windows_are_exact(native_lib, torch_cuda, M, n, kind, skew, monkeyp
     sample = sorted({int(order[0]), int(order[1]), int(order[7]), int(order[15]), int(order[16]), int(order[40 % M]),
                      int(order[M // 2]), int(order[-1]), 0, M - 1})
     with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        thresholds_until_round_6(e)
         e.set_option(N.OPT_HOT_MIN_TILES, 1)
         e.set_option(N.OPT_HOT_WINDOWS, 1)
         e.set_option(N.OPT_PART_V3, 0)      # this file is about the FIRST generation's hot windows (above 8 192 names the third takes >= 2^18 pairs)

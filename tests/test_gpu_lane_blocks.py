@@ -10,6 +10,8 @@ import threading
 import numpy as np
 import pytest
 
+from tests.conftest import thresholds_until_round_6
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oracle  # noqa: E402
 
@@ -31,6 +33,8 @@ def test_concurrent_lanes_in_their_own_blocks(la, M, width, blocks):
     eng = la.Engine(max_metrics=M, num_buffers=2, num_lanes=4, lane_samples=1 << 18)
     try:
         eng.set_option(N.OPT_LANE_SCRATCH_BLOCKS, blocks)
+        if not blocks:
+            thresholds_until_round_6(eng)   # (without blocks of their own the lanes' launches follow the shared block's rules)
         w = 1.0 / np.arange(1, M + 1)
         ids = [rng.choice(M, per, p=w / w.sum()).astype(np.uint16 if width == 2 else np.uint32) for _ in range(T)]
         vals = [rng.lognormal(np.log(1e5), 1.0, per) * (1.0 + 1e-4 * ids[t]) for t in range(T)]
@@ -78,6 +82,7 @@ def test_device_resident_launches_keep_the_shared_block(la, torch_cuda):
     M, n = 20000, 600_000
     eng = la.Engine(max_metrics=M, num_buffers=2, num_lanes=2, lane_samples=1 << 18)
     try:
+        thresholds_until_round_6(eng)            # (600 000 pairs per call: a third-generation launch under them)
         w = 1.0 / np.arange(1, M + 1)
         ids = rng.choice(M, n, p=w / w.sum()).astype(np.uint32)
         v = rng.lognormal(np.log(1e5), 1.0, n)

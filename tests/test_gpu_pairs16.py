@@ -30,11 +30,11 @@ def _dev(torch, a):
 
 # names, pairs, values, options {id: value}, counter that must have moved (the path taken)
 PATHS = [
-    (700, 100_001, "lognormal", {}, "samples_direct"),                                    # < 131 072 pairs: direct atomics
+    (700, 100_001, "lognormal", {}, "samples_direct"),                                    # small call: the direct path (cell table)
     (20, 1_500_001, "lognormal", {}, "samples_small"),                                     # <= 32 names: single-pass kernel
     (5, 400_000, "kvalues2", {}, "samples_small"),
-    (1000, 600_001, "lognormal", {}, "samples_partitioned"),                               # first generation
-    (30000, 1_000_001, "edge", {N.OPT_PART_V3: 0}, "samples_partitioned"),                 # ... with its second level
+    (1000, 600_001, "lognormal", {N.OPT_PART_MIN_PAIRS: 1 << 17, N.OPT_PART_V2: 0}, "samples_partitioned"),   # first generation
+    (30000, 1_000_001, "edge", {N.OPT_PART_MIN_PAIRS: 1 << 17, N.OPT_PART_V3: 0}, "samples_partitioned"),     # ... with its second level
     (1024, 2_000_001, "lognormal", {N.OPT_PART_V2_MIN_PAIRS: 1 << 17, N.OPT_PART_V2_SHAPE: 2}, "samples_partitioned_v2"),
     (1024, 2_000_000, "edge", {N.OPT_PART_V2_MIN_PAIRS: 1 << 17, N.OPT_PART_V2_SHAPE: 3}, "samples_partitioned_v2"),
     (3000, 2_000_001, "signed", {N.OPT_PART_V2_MIN_PAIRS: 1 << 17, N.OPT_PART_V2_SHAPE: 0}, "samples_partitioned_v2"),

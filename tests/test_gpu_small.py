@@ -5,6 +5,8 @@ import math
 import numpy as np
 import pytest
 
+from tests.conftest import thresholds_until_round_6
+
 import oracle
 
 pytestmark = pytest.mark.gpu
@@ -98,6 +100,7 @@ def test_adaptive_dispatch_and_counters(native_lib, torch_cuda):
     want = oracle.histogram_pairs(ids, v, M)
     d_ids, d_v = _dev(torch_cuda, ids), _dev(torch_cuda, v)
     with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        thresholds_until_round_6(e)
         for interval in range(3):
             e.submit_pairs_device(d_ids, d_v)
             with e.flip() as snap:

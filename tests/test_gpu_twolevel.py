@@ -6,6 +6,8 @@ import math
 import numpy as np
 import pytest
 
+from tests.conftest import thresholds_until_round_6
+
 import oracle
 from loghisto_amd import _native as N
 
@@ -47,6 +49,8 @@ def test_two_level_partitioned_ingest(native_lib, torch_cuda, M, n, kind, monkey
         ids[5000:6000] = M - 256          # same sub-partition pattern, partition 0
     sample = sorted({0, 1, 2, 255, 256, 257, 1023, 1024, M // 2, M // 2 + 1, M - 257, M - 256, M - 2, M - 1} & set(range(M)))
     with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        thresholds_until_round_6(e)
+        e.set_option(N.OPT_PART_V2, 0)
         e.set_option(N.OPT_TWO_LEVEL_ABOVE, 0)
         e.set_option(N.OPT_PART_V3, 0)      # the first generation's second level is what this file tests
         e.submit_pairs_device(_dev(torch_cuda, ids), _dev(torch_cuda, v))
