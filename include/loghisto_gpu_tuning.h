@@ -25,8 +25,9 @@ extern "C" {
  *   LH_OPT_SMALL_PATH         0 / 1: the single-pass kernel for <= 32 names (1 also re-arms it after adaptive
  *                             dispatch turned it off)
  *   LH_OPT_PART_V2            0 / 1: the second generation (survey + 2-byte records; 33 .. 8 192 names; default 1)
- *   LH_OPT_PART_V2_MIN_PAIRS  smallest launch that takes it (default 2^25, the measured crossover with the first
- *                             generation; >= 2^17)
+ *   LH_OPT_PART_V2_MIN_PAIRS  smallest launch that takes it (default 2^20, where it overtakes the direct path's cell table;
+ *                             2^25 until round 6, the crossover with the first generation while every call surveyed
+ *                             itself; >= 2^17)
  *   LH_OPT_PART_V2_SHAPE      bit 0: two 512-thread scatter workgroups per CU over <= 128 partitions instead of one
  *                             1 024-thread workgroup over <= 256; bit 1: fixed per-partition LDS regions (records
  *                             placed by the classifying phase) instead of the exact per-tile layout.  Default 2.
@@ -39,7 +40,8 @@ extern "C" {
  *   LH_OPT_PART_V3            0 / 1: the third generation (hashed survey, region scatter of 4-byte records, a second
  *                             level that counts each partition's frequent names in place; 8 193 .. 65 536 names --
  *                             BASELINE config 4's name count; default 1)
- *   LH_OPT_PART_V3_MIN_PAIRS  smallest launch that takes it (default 2^18; >= 2^17)
+ *   LH_OPT_PART_V3_MIN_PAIRS  smallest launch that takes it (default 3 * 2^20 for device-resident calls -- below, the direct
+ *                             path's cell table is faster -- and 2^18 for a host-fed lane's half-buffer; >= 2^17)
  *   LH_OPT_PART_V3_LOG_W      log2 of its second-level window width, 10 .. 13 (32 .. 4 names per fine partition);
  *                             0 (default) = follow the survey: every call's survey reports the width that covers
  *                             95 % of the sampled mass and the following calls use it (lh_counters.window_log2)
@@ -47,8 +49,11 @@ extern "C" {
  *                             LDS windows, one global atomic per forwarded record (a host-fed lane's half-buffer leaves a
  *                             fine partition some hundred records: the windowed pass's fixed cost per slot bounded the lanes);
  *                             0 = the default, 2^22 (the largest lane launch); 1 = never; <= 2^30
- *   LH_OPT_PART_MIN_PAIRS     smallest mixed launch that takes a partitioned path at all (below it: one global atomic
- *                             per sample); 0 = the default, 131 072; >= 65 536 otherwise
+ *   LH_OPT_PART_MIN_PAIRS     smallest mixed launch that takes a partitioned path at all, whatever the generation (below it:
+ *                             the direct path -- no scratch, no survey: whole tiles through a per-workgroup LDS table of
+ *                             cells, the rest one global atomic per sample); 0 = the defaults: 2^20 pairs up to 8 192 names,
+ *                             3 * 2^20 above, 2^17 for a host-fed lane's half-buffer (131 072 for all until round 6:
+ *                             profiles/r06_small_calls.txt); >= 65 536 otherwise
  *   LH_OPT_LANE_GEN3          0 / 1 (default 1): above 8 192 names a host-fed lane launch takes the third generation in the
  *                             lane's own scratch block, on survey tables the lanes share (read-only between surveys, two
  *                             sets); 0 = the first generation's two scatter levels, as up to ABI 4

@@ -6,12 +6,15 @@
 //
 // The paths, fastest applicable first (measured crossovers: DESIGN.md 5):
 //   SMALL   <= 32 names, >= 65 536 pairs: one streaming pass, every name's window in LDS       (lh_kernels_small.hip)
-//   GEN2    33 .. 8 192 names, >= 2^25 pairs: survey + region scatter of 2-byte records + reduce (lh_kernels_part2.h)
-//   GEN3    8 193 .. 65 536 names, >= 2^18 pairs: hashed survey + two scatter levels + reduce    (lh_kernels_part3.h)
-//   GEN1    >= 131 072 pairs: partition by name (4-byte records, one or two levels) + reduce     (lh_kernels_part.hip);
-//           also a host-fed lane launch (<= 2^22 pairs) over <= 8 192 names when the lanes have scratch blocks of their
-//           own (above 8 192 names such a launch takes GEN3 there, on survey tables the lanes share)
-//   DIRECT  one global atomic per sample: small or misaligned launches, and any launch whose scratch cannot be had
+//   GEN2    33 .. 8 192 names, >= 2^20 pairs: survey + region scatter of 2-byte records + reduce (lh_kernels_part2.h)
+//   GEN3    8 193 .. 65 536 names, >= 3 * 2^20 pairs: hashed survey + two scatter levels + reduce (lh_kernels_part3.h)
+//   GEN1    partition by name (4-byte records, one or two levels) + reduce (lh_kernels_part.hip): since round 6 no
+//           device-resident call's default -- names without skew above 8 192, a generation switched off by option -- and a
+//           host-fed lane launch (2^17 .. 2^22 pairs) over <= 8 192 names when the lanes have scratch blocks of their own
+//           (above 8 192 names such a launch takes GEN3 there from 2^18 pairs, on survey tables the lanes share)
+//   DIRECT  no scratch, no survey: whole tiles through a per-workgroup LDS table of (name, bin) cells, the rest one global
+//           atomic per sample (launch_ingest_pairs_cells): small or misaligned launches, and any launch whose scratch
+//           cannot be had.  The minimum sizes are where each path overtakes it: profiles/r06_small_calls.txt
 #pragma once
 
 #include "lh_kernels.h"

@@ -65,10 +65,10 @@ struct PartTuning {
     uint32_t names_per_part = 4;    // names per LDS-reduce partition: 4 gives every name a 4 096-bin window in P2
     uint32_t two_level_above = 32;  // second scatter level when a level-1 partition holds more names than this
     uint32_t hot_min_tiles = 32;    // hot-name windows in P1 when every workgroup gets at least this many tiles
-    size_t part_min_samples = 0;    // smallest launch that is partitioned at all (0 = the default, 131 072); below: direct atomics
+    size_t part_min_samples = 0;    // smallest launch that is partitioned at all (0 = the defaults: 2^20, 3 * 2^20 above 8 192 names); below: the direct path
     bool hot = true;                // hot-name windows allowed at all
     bool v2 = true;                 // survey + 2-byte-record path (lh_kernels_part2.h) for <= 8 192 names
-    size_t v2_min_samples = 0;      // 0 = default (2^25): smaller launches do not amortise the survey
+    size_t v2_min_samples = 0;      // 0 = default (2^20: where it overtakes the direct path's cell table)
     uint32_t v2_shape = 2;          // bit 0: two 512-thread workgroups per CU (128 partitions) instead of one 1 024-thread (256);
                                     // bit 1: fixed per-partition regions (k_scatter3) instead of the exact per-tile layout
     bool v3 = true;                 // hashed survey + region scatter + in-place second level (lh_kernels_part3.h) for 8 193 .. 65 536 names
