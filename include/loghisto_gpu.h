@@ -410,11 +410,13 @@ int lh_get_counters(lh_engine *e, lh_counters *out);
  *                             overflow / window-miss path or stayed out of the hot windows that took them when the
  *                             survey was new (the stream's values moved: lh_counters.survey_stale_pairs).  A stale
  *                             survey costs speed -- one call's worth -- never exactness
- *   LH_OPT_LANE_SCRATCH_BLOCKS  0 .. 16 (default 16): host-fed mixed launches (lh_submit_pairs*, lh_commit_pairs*: one staging
- *                             half-buffer each, at most 2^22 pairs) run partitioned in one of this many scratch blocks
+ *   LH_OPT_LANE_SCRATCH_BLOCKS  0 .. 16 (default 0 since round 6; 16 before): 0 = a host-fed mixed launch (lh_submit_pairs*,
+ *                             lh_commit_pairs*: one staging half-buffer, at most 2^22 pairs) takes the direct path -- one
+ *                             link-bound pass through a per-workgroup LDS table of cells, no scratch: 0.89 - 0.90 of the
+ *                             link at every name count.  n > 0 = such launches run partitioned in one of n scratch blocks
  *                             of their own (first generation up to 8 192 names; above, the third generation on survey
- *                             tables the lanes share), so that one lane's later passes run beside another lane's
- *                             link-bound read; 0 = every partitioned launch shares the engine's one block
+ *                             tables the lanes share), one lane's later passes beside another lane's read (0.84 - 0.87 of
+ *                             the link up to 8 192 names, 0.75 - 0.78 above; lh_counters.lane_scratch_bytes)
  *   LH_OPT_LANE_ZERO_COPY     0 / 1: the ingest kernels read the pinned staging buffers of lh_submit* / lh_reserve_pairs
  *                             in place over PCIe (default 1) instead of after a hipMemcpyAsync into HBM (0)
  *   LH_OPT_MERGE_NARROW_CELLS 0 / 1 (default 1): lh_snapshot_merge over more than one rank sends a row at 8 or 16 bits per

@@ -30,6 +30,13 @@ Step choose_step(const DispatchState &st, uintptr_t ids, uint32_t id_width, uint
     const bool aligned = part_aligned(I, V);
     // a lane's half-buffer (read over PCIe in place): first generation -- no tables that outlive the launch -- in a block
     // of the lanes' own, so that its later passes run beside another lane's link-bound read
+    if (host_fed && take <= kLaneBlockMaxPairs && !st.lane_blocks) {
+        // A lane's half-buffer (read over PCIe in place) by default: the direct path.  Its one pass is link-bound, needs no
+        // scratch and no survey, and leaves the GPU to the other lanes' launches: 0.89 - 0.90 of the link at 300 .. 65 536
+        // names (round 6; the partitioned launches below held 0.84 - 0.87 up to 8 192 names, 0.75 - 0.78 above).
+        r.kind = PATH_DIRECT;
+        return r;
+    }
     if (host_fed && aligned && take <= kLaneBlockMaxPairs && st.lane_blocks) {
         PartTuning tl = st.tune; // the lanes' own thresholds, unless the caller set them
         if (!tl.part_min_samples) tl.part_min_samples = kLanePartMinPairs;

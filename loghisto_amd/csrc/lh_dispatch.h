@@ -45,7 +45,7 @@ struct DispatchState {
     bool small_disabled = false;   // adaptive switches (lh_engine: window misses / region overflows / forwarded share)
     bool regions_disabled = false;
     bool v3_disabled = false;
-    uint32_t lane_blocks = 0;      // scratch blocks of the host-fed lanes (0: they share the engine's block)
+    uint32_t lane_blocks = 0;      // scratch blocks of the host-fed lanes (0, the default: a half-buffer takes the direct path)
     bool lane_gen3 = true;         // 8 193 .. 65 536 names: a lane's launch takes the third generation (records in the lane's
                                    // block, the survey's tables shared by all lanes) instead of the first
     uint32_t lane_g1_cap = kLaneLevel1Workgroups; // ... with at most this many level-1 workgroups

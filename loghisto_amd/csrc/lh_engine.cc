@@ -284,7 +284,10 @@ struct lh_engine {
     };
     static constexpr uint32_t kAuxBlocks = 16;
     AuxScratch aux[kAuxBlocks];
-    uint32_t lane_blocks = kAuxBlocks, aux_next = 0; // (LH_OPT_LANE_SCRATCH_BLOCKS; 16 against 8: 65 536 names 4.0 -> 4.3 G pairs/s)
+    // (LH_OPT_LANE_SCRATCH_BLOCKS.  0 since round 6: a lane's half-buffer takes the direct path's cell table -- one pass, no
+    // scratch -- which holds 0.89 - 0.90 of the link at every name count; in blocks of their own the lanes' partitioned launches
+    // held 0.84 - 0.87 up to 8 192 names and 0.75 - 0.78 above: profiles/r06_hostfed_cells.jsonl)
+    uint32_t lane_blocks = 0, aux_next = 0;
     // Above 8 192 names a lane's launch takes the third generation in its own block (lh_dispatch.h); the survey's tables
     // are shared by the lanes and only READ between surveys.  Two sets: a survey writes the set that is not in use and
     // becomes the active one; a set is rewritten only behind every lane launch in flight (the blocks' events).

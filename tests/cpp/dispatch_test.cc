@@ -78,15 +78,16 @@ static void test_choose_step_grid()
     int states = 0;
     for (uint32_t M : names)
         for (size_t n0 : sizes)
-            for (int host_fed = 0; host_fed < 2; host_fed++)
+            for (int hf = 0; hf < 3; hf++) // device-resident; host-fed with lane blocks; host-fed without (the default)
                 for (uint32_t width : {2u, 4u})
                     for (int flags = 0; flags < 8; flags++)         // small_disabled | regions_disabled << 1 | v3_disabled << 2
                         for (int bound = 0; bound < 3; bound++) {   // no bound, scratch cap 256 MiB, sub-launches of 2^24
                             if (width == 2 && M > 65536) continue;
+                            const int host_fed = hf != 0;
                             lh::DispatchState st;
                             st.max_metrics = M;
                             st.lane_samples = size_t(1) << 20;
-                            st.lane_blocks = host_fed ? 8 : 0;
+                            st.lane_blocks = hf == 1 ? 8 : 0;
                             st.small_disabled = flags & 1;
                             st.regions_disabled = flags & 2;
                             st.v3_disabled = flags & 4;
@@ -128,7 +129,10 @@ static void test_choose_step_grid()
                                           (s.kind == lh::PATH_GEN1 || (s.kind == lh::PATH_GEN3 && M > 8192)));
                                 if (s.lane_block && M > 8192 && s.take >= (size_t(1) << 18) && !st.v3_disabled && !st.regions_disabled)
                                     CHECK(s.kind == lh::PATH_GEN3);
-                                if (host_fed && s.kind >= lh::PATH_GEN1 && s.take <= lh::kLaneBlockMaxPairs) CHECK(s.lane_block);
+                                if (hf == 1 && s.kind >= lh::PATH_GEN1 && s.take <= lh::kLaneBlockMaxPairs) CHECK(s.lane_block);
+                                // without blocks of their own (the default since round 6) a half-buffer takes the direct path
+                                if (hf == 2 && n <= lh::kLaneBlockMaxPairs) CHECK(s.kind == lh::PATH_DIRECT || s.kind == lh::PATH_SMALL);
+                                if (hf == 2) CHECK(!s.lane_block);
                                 // a bounded block: above the floor no sub-launch asks for more than the cap
                                 if (bound == 1 && s.kind >= lh::PATH_GEN1 && !s.lane_block && s.take > (M > 8192 ? size_t(1) << 28 : size_t(1) << 24))
                                     CHECK(s.scratch <= st.scratch_cap);

@@ -41,7 +41,7 @@ def test_cpp_table_test_of_the_decision_functions(native_lib):
     assert os.path.exists(exe), "python -m loghisto_amd.build builds tests/cpp/dispatch_test.cc"
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
-    assert "0 failed" in r.stdout and "choose_step: 16416 states" in r.stdout, r.stdout
+    assert "0 failed" in r.stdout and "choose_step: 24624 states" in r.stdout, r.stdout
 
 
 # DESIGN.md 5, "Dispatch": (names, pairs) -> the path of the call's first sub-launch, all options at their defaults,
@@ -116,7 +116,11 @@ def test_host_fed_lane_launches(native_lib):
             s = probe(native_lib, max_metrics=names, n=1 << 20, host_fed=1, lane_blocks=8, **off)
             assert [(x.path, x.lane_block) for x in s] == [(GEN1, 1)]
         s = probe(native_lib, max_metrics=names, n=1 << 20, host_fed=1, lane_blocks=0)
-        assert not s[0].lane_block                                           # no lane blocks: the shared block's rules
+        assert (s[0].path, s[0].lane_block, s[0].scratch) == (DIRECT, 0, 0)  # no lane blocks (the default since round 6): the direct path
+        s = probe(native_lib, max_metrics=names, n=1 << 22, host_fed=1, lane_blocks=0)
+        assert (s[0].path, s[0].scratch) == (DIRECT, 0)
+        s = probe(native_lib, max_metrics=names, n=(1 << 22) + 2, host_fed=1, lane_blocks=0)
+        assert s[0].path >= GEN1                                             # a buffer larger than that: the shared block's rules
         s = probe(native_lib, max_metrics=names, n=(1 << 22) + 2, host_fed=1, lane_blocks=8)
         assert not s[0].lane_block                                           # larger than a lane block serves
     s = probe(native_lib, max_metrics=8, n=1 << 20, host_fed=1, lane_blocks=8)

@@ -135,6 +135,7 @@ def test_host_fed_lanes_keep_every_pair_and_no_lane_stays_reserved(native_lib, t
     M, per = 2000, 700_000
     parts = [_stream(M, per, 100 + t) for t in range(4)]
     with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=4, lane_samples=1 << 18) as e:
+        e.set_option(N.OPT_LANE_SCRATCH_BLOCKS, 16)             # (the default, 0, needs no block at all since round 6)
         e.set_option(N.OPT_FAIL_SCRATCH_ALLOCS, 5)
         errs = []
 
@@ -186,6 +187,7 @@ def test_lane_tables_that_cannot_be_had(native_lib, torch_cuda):
     ids16 = ids.astype(np.uint16)
     for fail in (1, 2, 3):
         with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=per) as e:
+            e.set_option(N.OPT_LANE_SCRATCH_BLOCKS, 16)
             e.set_option(N.OPT_FAIL_SCRATCH_ALLOCS, fail)
             e.submit_pairs(ids16, v)
             e.sync()

@@ -33,8 +33,6 @@ def test_concurrent_lanes_in_their_own_blocks(la, M, width, blocks):
     eng = la.Engine(max_metrics=M, num_buffers=2, num_lanes=4, lane_samples=1 << 18)
     try:
         eng.set_option(N.OPT_LANE_SCRATCH_BLOCKS, blocks)
-        if not blocks:
-            thresholds_until_round_6(eng)   # (without blocks of their own the lanes' launches follow the shared block's rules)
         w = 1.0 / np.arange(1, M + 1)
         ids = [rng.choice(M, per, p=w / w.sum()).astype(np.uint16 if width == 2 else np.uint32) for _ in range(T)]
         vals = [rng.lognormal(np.log(1e5), 1.0, per) * (1.0 + 1e-4 * ids[t]) for t in range(T)]
@@ -65,11 +63,12 @@ def test_concurrent_lanes_in_their_own_blocks(la, M, width, blocks):
                 oracle.histogram_dense(vals[t][ids[t] == m], want)
             assert np.array_equal(rows[m], batches * want), m
         c = eng.counters()
-        assert c["samples_partitioned"] >= T * batches * per * 0.8     # the full half-buffers were partitioned launches
+        assert c["scratch_bytes"] == 0                                 # none of them used the shared block
         if blocks:
-            assert c["scratch_bytes"] == 0                             # ... and none of them used the shared block
-        else:
-            assert c["scratch_bytes"] > 0
+            assert c["samples_partitioned"] >= T * batches * per * 0.8 # the full half-buffers were partitioned launches
+            assert c["lane_scratch_bytes"] > 0
+        else:                                                          # the default since round 6: the direct path, no scratch at all
+            assert c["samples_partitioned"] == 0 and c["samples_direct"] == T * batches * per and c["lane_scratch_bytes"] == 0
     finally:
         eng.close()
 
@@ -82,7 +81,9 @@ def test_device_resident_launches_keep_the_shared_block(la, torch_cuda):
     M, n = 20000, 600_000
     eng = la.Engine(max_metrics=M, num_buffers=2, num_lanes=2, lane_samples=1 << 18)
     try:
+        from loghisto_amd import _native as N
         thresholds_until_round_6(eng)            # (600 000 pairs per call: a third-generation launch under them)
+        eng.set_option(N.OPT_LANE_SCRATCH_BLOCKS, 16) # (the lanes beside it: partitioned launches in blocks of their own)
         w = 1.0 / np.arange(1, M + 1)
         ids = rng.choice(M, n, p=w / w.sum()).astype(np.uint32)
         v = rng.lognormal(np.log(1e5), 1.0, n)
@@ -140,6 +141,7 @@ def test_lanes_over_many_names_share_survey_tables(la, gen3):
         vals.append(v)
     eng = la.Engine(max_metrics=M, num_buffers=2, num_lanes=4, lane_samples=per)
     try:
+        eng.set_option(N.OPT_LANE_SCRATCH_BLOCKS, 16)     # (0, the default since round 6, is the direct path: test above)
         eng.set_option(N.OPT_LANE_GEN3, gen3)
         eng.set_option(N.OPT_SURVEY_EVERY, 8)             # several surveys, into alternating sets, during the run
         errors = []
@@ -190,6 +192,8 @@ def test_lanes_that_carry_different_streams_do_not_take_turns_surveying(la):
     vals = [rng.lognormal(np.log(1e5), 0.5, per), rng.lognormal(np.log(5e3), 0.5, per)]
     eng = la.Engine(max_metrics=M, num_buffers=2, num_lanes=2, lane_samples=per)
     try:
+        from loghisto_amd import _native as N
+        eng.set_option(N.OPT_LANE_SCRATCH_BLOCKS, 16)     # (0, the default since round 6, is the direct path: no survey at all)
         for k in range(batches):                          # one producer after the other: the worst case, strict alternation
             for t in range(2):
                 eng.submit_pairs_in_place(ids[t], vals[t])

@@ -7,7 +7,7 @@
 // (lh_reserve_pairs16 / lh_reserve_pairs), stores its pairs there -- the one host-side copy -- and commits.
 // Checked: per-name counts of the interval against the generator's own counts.  Prints one JSON line per form.
 //
-//   usage: hostfed_native [threads=16] [pairs=8e8] [names=1024] [batch=1048576] [lane_gen3=1] [survey_every=0] [lane_blocks=-1] [direct_max=0]
+//   usage: hostfed_native [threads=16] [pairs=8e8] [names=1024] [batch=1048576] [lane_gen3=1] [survey_every=0] [lane_blocks=-1] [direct_max=0] [part_min=0]
 //   (lane_gen3 = 0: the lanes' launches over more than 8 192 names take the first generation, as up to ABI 4)
 #include "loghisto_gpu_tuning.h"
 
@@ -28,7 +28,7 @@ static void die(const char *what, int rc)
 }
 
 static int g_lane_gen3 = 1, g_survey_every = 0, g_blocks = -1;
-static long long g_direct_max = 0;
+static long long g_direct_max = 0, g_part_min = 0;
 
 template <typename IDT> static double run(uint32_t T, size_t total, uint32_t M, size_t batch, const std::vector<uint32_t> &ids,
                                           const std::vector<double> &vals, bool *exact)
@@ -46,6 +46,7 @@ template <typename IDT> static double run(uint32_t T, size_t total, uint32_t M, 
     if (g_survey_every && (rc = lh_set_option(e, LH_OPT_SURVEY_EVERY, (uint64_t)g_survey_every))) die("lh_set_option", rc);
     if (g_blocks >= 0 && (rc = lh_set_option(e, LH_OPT_LANE_SCRATCH_BLOCKS, (uint64_t)g_blocks))) die("lh_set_option", rc);
     if (g_direct_max && (rc = lh_set_option(e, LH_OPT_PART_V3_DIRECT_MAX_PAIRS, (uint64_t)g_direct_max))) die("lh_set_option", rc);
+    if (g_part_min && (rc = lh_set_option(e, LH_OPT_PART_MIN_PAIRS, (uint64_t)g_part_min))) die("lh_set_option", rc);
     std::vector<IDT> nid(ids.begin(), ids.end()); // the producer's own id array in the width it ships
     const size_t per = total / T;
     auto put = [&](size_t off, size_t n) {
@@ -129,6 +130,7 @@ int main(int argc, char **argv)
     g_lane_gen3 = argc > 5 ? std::atoi(argv[5]) : 1;
     g_survey_every = argc > 6 ? std::atoi(argv[6]) : 0;   // LH_OPT_SURVEY_EVERY (0: default)
     g_blocks = argc > 7 ? std::atoi(argv[7]) : -1;        // LH_OPT_LANE_SCRATCH_BLOCKS (-1: default)
+    g_part_min = argc > 9 ? std::atoll(argv[9]) : 0;      // LH_OPT_PART_MIN_PAIRS (0: default; 2^30: every lane launch takes the direct path)
     g_direct_max = argc > 8 ? std::atoll(argv[8]) : 0;    // LH_OPT_PART_V3_DIRECT_MAX_PAIRS (0: default, 1: the windowed reduce pass always)
     const size_t N = (size_t)1 << 24;
     std::vector<uint32_t> ids(N);
