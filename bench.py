@@ -813,7 +813,7 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=Non
             # what an 8-rank reduce-scatter of this interval would pad: equal packed cells per block (this library)
             # against equal name counts per block (round 2), from the snapshot's merged ranges
             torch.cuda.synchronize()
-            rg = tmerge.snapshot_tensors(snap, M)[1].cpu().numpy().view(np.uint32).astype(np.int64)
+            rg = tmerge.snapshot_ranges(snap, M).cpu().numpy().view(np.uint32).astype(np.int64)
             wd = np.where(rg[:, 0] <= rg[:, 1], rg[:, 1] - rg[:, 0] + 1, 0)
             P = np.concatenate([[0], np.cumsum(wd)])
             cut = [int(np.searchsorted(P, P[-1] * k // 8, side="left")) for k in range(9)]

@@ -52,7 +52,10 @@
 extern "C" {
 #endif
 
-#define LH_ABI_VERSION 6           /* 6: lh_extract_rows_compact / lh_expand_compact (the results of many names at 42 B instead of
+#define LH_ABI_VERSION 7           /* 7: uint32 cells above 8 192 names (lh_config.cell_bits, lh_snapshot_cells, lh_cell_bytes;
+                                      lh_counters.widenings / store_bytes): half the lines under every flush, clear, extract
+                                      read and merge pack, lh_create(65 536 names) 32 GiB instead of 64; lh_snapshot_rows still
+                                      hands out uint64 rows; 6: lh_extract_rows_compact / lh_expand_compact (the results of many names at 42 B instead of
                                       139 B per name); 5: lh_row_stride() (rows of lh_snapshot_rows are no longer 65 536 cells apart), the
                                       tuning / test options moved to loghisto_gpu_tuning.h, ingest falls back to the
                                       scratch-free kernel when scratch cannot be had; 4: uint16-id pairs (lh_*pairs16*) */
@@ -82,6 +85,12 @@ typedef struct lh_config {
     uint32_t num_lanes;     /* host staging lanes (one HIP stream each)       */
     uint32_t max_counters;  /* counter names (metrics.go:115), 8 B each per epoch buffer; 0 = no counters */
     uint64_t lane_samples;  /* samples per pinned half-buffer of a lane       */
+    uint32_t cell_bits;     /* (ABI 7) width of a bucket cell in HBM: 64 = the reference's uint64 (metrics.go:278); 32 = an
+                               epoch buffer counts in uint32 cells while its interval holds fewer than 2^32 samples -- no cell
+                               can wrap -- and moves to a uint64 store of its own (allocated then, kept) before a submit could
+                               pass that: exact for any stream, half the HBM and half the lines per window until then;
+                               0 = default: 64 up to 8 192 names, 32 above.  A struct_size without this field means 0. */
+    uint32_t reserved0;     /* 0 */
 } lh_config;
 
 /* Per-metric result of processHistograms (metrics.go:336-376). */
@@ -247,7 +256,14 @@ int lh_buckets_all(lh_snapshot *s, uint32_t first, size_t nmetrics, uint64_t *of
  * After an in-place reduction the caller must call lh_snapshot_mark_dirty so that
  * extract/clear cover the merged cells. */
 int lh_snapshot_rows(lh_snapshot *s, void **d_counts, uint32_t *nrows);
-size_t lh_row_stride(void); /* in uint64 cells */
+size_t lh_row_stride(void); /* in cells */
+/* (ABI 7) On an engine of 32-bit cells (lh_config.cell_bits) lh_snapshot_rows first moves the snapshot to its uint64 store
+ * (one pass over the occupied windows; the store is allocated the first time: LH_ENOMEM if it cannot be had), so that the
+ * view above stays what it was.  lh_snapshot_cells hands out the cells as they are: row r is at
+ * (char *)d_cells + r * lh_row_stride() * cell_bytes, cell_bytes = 4 or 8.  lh_cell_bytes: the width an engine's epoch
+ * buffers START every interval with (4 or 8). */
+int lh_snapshot_cells(lh_snapshot *s, void **d_cells, uint32_t *nrows, uint32_t *cell_bytes);
+int lh_cell_bytes(lh_engine *e);
 int lh_snapshot_ranges(lh_snapshot *s, void **d_ranges /* uint32[nrows][2] lo,hi bins */);
 int lh_snapshot_mark_dirty(lh_snapshot *s, uint32_t first_row, uint32_t nrows, uint32_t lo_bin, uint32_t hi_bin);
 /* K4 -- multi-GPU merge of a snapshot across the ranks of an RCCL communicator (one process per GPU).
@@ -381,6 +397,9 @@ typedef struct lh_counters {
                                         blocks (up to LH_OPT_LANE_SCRATCH_BLOCKS of them, ~0.2 GiB each at 65 536 names;
                                         LH_OPT_SCRATCH_CAP_BYTES bounds the shared block only) and the two sets of survey
                                         tables the lanes share                                                         */
+    uint64_t widenings;              /* (ABI 7) epoch buffers of 32-bit cells that moved to uint64 cells (an interval about to
+                                        hold 2^32 samples, a merge whose sums may pass it, lh_snapshot_rows)                */
+    uint64_t store_bytes;            /* (ABI 7) HBM of the epoch buffers' cell stores, wide stores of narrow engines included */
 } lh_counters;
 int lh_get_counters(lh_engine *e, lh_counters *out);
 

@@ -58,7 +58,9 @@ extern "C" {
  *                             lane's own scratch block, on survey tables the lanes share (read-only between surveys, two
  *                             sets); 0 = the first generation's two scatter levels, as up to ABI 4
  *   LH_OPT_FAIL_SCRATCH_ALLOCS  the next `value` scratch allocations of the mixed ingest fail as if the device were out
- *                             of memory (tests/test_gpu_faults.py: a call still counts every pair exactly once) */
+ *                             of memory (tests/test_gpu_faults.py: a call still counts every pair exactly once)
+ *   LH_OPT_WIDEN_AT_SAMPLES   1 .. 2^32 - 1 (the default): an epoch buffer of 32-bit cells moves to uint64 cells before the
+ *                             interval's samples pass this (tests/test_gpu_cells32.py: the widening without 2^32 samples) */
 enum {
     LH_OPT_TWO_LEVEL_ABOVE = 1,
     LH_OPT_HOT_MIN_TILES = 2,
@@ -74,7 +76,8 @@ enum {
     LH_OPT_PART_MIN_PAIRS = 17,
     LH_OPT_FAIL_SCRATCH_ALLOCS = 19,
     LH_OPT_LANE_GEN3 = 20,
-    LH_OPT_PART_V3_DIRECT_MAX_PAIRS = 21
+    LH_OPT_PART_V3_DIRECT_MAX_PAIRS = 21,
+    LH_OPT_WIDEN_AT_SAMPLES = 23
 };
 
 /* The path choice as a function: what an engine in the described state would do with a call of n pairs.  No device is

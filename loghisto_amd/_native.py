@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblhgpu.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 # tools/sweep.py --lib (A/B runs against a build of an earlier round): accept a library of an older ABI and bind
 # what it exports; never set by the product or the tests
 ALLOW_OLDER_ABI = False
@@ -25,7 +25,7 @@ OK, EINVAL, ENOMEM, EDEVICE, ENODEVICE, EBUSY, ERANGE, ESTATE = range(8)
 class LhConfig(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("max_metrics", C.c_uint32),
                 ("num_buffers", C.c_uint32), ("num_lanes", C.c_uint32), ("max_counters", C.c_uint32),
-                ("lane_samples", C.c_uint64)]
+                ("lane_samples", C.c_uint64), ("cell_bits", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 class LhCounters(C.Structure):
@@ -48,7 +48,9 @@ class LhCounters(C.Structure):
                                                                ("scratch_alloc_failures", C.c_uint64),
                                                                ("samples_fallback", C.c_uint64),
                                                                ("survey_stale_pairs", C.c_uint64),
-                                                               ("lane_scratch_bytes", C.c_uint64)]
+                                                               ("lane_scratch_bytes", C.c_uint64),
+                                                               ("widenings", C.c_uint64),
+                                                               ("store_bytes", C.c_uint64)]
 
 # lh_set_option keys (include/loghisto_gpu.h; the path-steering ones and the fault hook: include/loghisto_gpu_tuning.h)
 OPT_TWO_LEVEL_ABOVE, OPT_HOT_MIN_TILES, OPT_HOT_WINDOWS, OPT_NAMES_PER_PARTITION = 1, 2, 3, 4
@@ -63,6 +65,7 @@ OPT_FAIL_SCRATCH_ALLOCS = 19
 OPT_LANE_GEN3 = 20
 OPT_PART_V3_DIRECT_MAX_PAIRS = 21
 OPT_MERGE_NARROW_CELLS = 22
+OPT_WIDEN_AT_SAMPLES = 23
 
 
 class LhDispatchQuery(C.Structure):
@@ -174,6 +177,8 @@ SIGNATURES = {
     "lh_buckets_all": (C.c_int, [_vp, C.c_uint32, _sz, _u64p, _i16p, _u64p, _sz, C.POINTER(_sz)]),
     "lh_snapshot_rows": (C.c_int, [_vp, C.POINTER(_vp), _u32p]),
     "lh_row_stride": (C.c_size_t, []),
+    "lh_snapshot_cells": (C.c_int, [_vp, C.POINTER(_vp), _u32p, _u32p]),
+    "lh_cell_bytes": (C.c_int, [_vp]),
     "lh_snapshot_ranges": (C.c_int, [_vp, C.POINTER(_vp)]),
     "lh_snapshot_mark_dirty": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "lh_snapshot_merge": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_uint32, _u32p, _u32p]),

@@ -60,7 +60,14 @@ void set_last_error(const char *what, hipError_t e)
 enum BufState { BUF_FREE = 0, BUF_CURRENT = 1, BUF_SNAPSHOT = 2 };
 
 struct EpochBuffer {
-    uint64_t *counts = nullptr;  // [max_metrics][65536]
+    // [max_metrics][LH_ROW_STRIDE] cells.  `counts` is what the kernels take: the store in use, its width in bit 0
+    // (lh_cells.h).  A wide engine has store64 only.  A narrow engine (above 8 192 names, or lh_config.cell_bits = 32)
+    // counts in store32 while the interval holds fewer than 2^32 samples -- no cell can wrap -- and moves to store64
+    // (allocated the first time it is needed, kept) before an enqueue could pass that: widen_buffer.
+    uint64_t *counts = nullptr;
+    uint32_t *store32 = nullptr;
+    uint64_t *store64 = nullptr;
+    uint64_t reserved = 0;       // narrow store: samples of the launches enqueued or about to be (atomic builtins)
     uint32_t *ranges = nullptr;  // [max_metrics][2]
     uint64_t *ccur = nullptr;    // [max_counters] the interval's counter amounts (metrics.go:425-433)
     uint32_t *cflag = nullptr;   // [max_counters] touched this interval
@@ -151,6 +158,12 @@ struct lh_engine {
     std::vector<EpochBuffer> bufs;
     int cur = 0;
     std::shared_mutex epoch_mu; // submitters shared, flip unique (histogramMu, metrics.go:121)
+    // Narrow engines: an ingest step holds it shared from reading the current buffer's `counts` until its launches are
+    // enqueued; widen_buffer holds it unique.  Lock order: epoch, lane, cells.
+    std::shared_mutex cells_mu;
+    bool narrow = false;                    // the epoch buffers start every interval on uint32 cells
+    uint64_t widen_at = 0xffffffffull;      // LH_OPT_WIDEN_AT_SAMPLES (tests): a narrow buffer holds at most this many samples
+    std::atomic<uint64_t> c_widenings{0};
 
     std::mutex streams_mu;
     std::vector<hipStream_t> epoch_streams; // streams that touched the current epoch buffer
@@ -352,16 +365,66 @@ void count_samples(EpochBuffer &b, size_t n)
     } while (!__atomic_compare_exchange_n(&b.nsamples, &old, now, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
 }
 
+// A narrow buffer moves to uint64 cells: every row's dirty span is copied into the wide store and zeroed behind the copy
+// (k_widen_rows), and the kernels take the wide store from here on -- until the buffer is cleared, which returns it to
+// its (clean) narrow store.  `quiesce`: the buffer is the CURRENT one and launches on other streams may still be adding
+// to the narrow store -- wait for the device first (cells_mu is held unique: nothing new is enqueued meanwhile) and for
+// the copy afterwards.  A snapshot's buffer is widened in stream order on the extract stream.
+int widen_buffer(lh_engine *e, EpochBuffer &b, hipStream_t st, bool quiesce)
+{
+    if (!lh::cells_narrow(b.counts)) return LH_OK;
+    const size_t M = e->cfg.max_metrics;
+    if (quiesce) HIPCHK(hipDeviceSynchronize());
+    if (!b.store64) {
+        HIPCHK(hipMalloc((void **)&b.store64, M * LH_ROW_STRIDE * sizeof(uint64_t)));
+        hipError_t me = hipMemsetAsync(b.store64, 0, M * LH_ROW_STRIDE * sizeof(uint64_t), st);
+        if (me != hipSuccess) {
+            (void)hipFree(b.store64);
+            b.store64 = nullptr;
+            HIPCHK(me);
+        }
+    }
+    HIPCHK(lh::launch_widen_rows(b.store32, b.store64, b.ranges, (uint32_t)M, st));
+    if (quiesce) HIPCHK(hipStreamSynchronize(st));
+    b.counts = b.store64;
+    e->c_widenings.fetch_add(1, std::memory_order_relaxed);
+    return LH_OK;
+}
+
+// One ingest step's hold on the current buffer's cells (narrow engines only; a wide engine's pointer never changes).
+// Taken BEFORE the step's launches are enqueued: the samples are reserved first, and a step that would take the narrow
+// store past `widen_at` samples widens the buffer instead.
+struct CellsHold {
+    std::shared_lock<std::shared_mutex> g;
+    int rc = LH_OK;
+    CellsHold(lh_engine *e, EpochBuffer &b, size_t take, hipStream_t s)
+    {
+        if (!e->narrow) return;
+        g = std::shared_lock<std::shared_mutex>(e->cells_mu);
+        if (!lh::cells_narrow(b.counts)) return;
+        const uint64_t r = __atomic_add_fetch(&b.reserved, (uint64_t)take, __ATOMIC_RELAXED);
+        if (r <= e->widen_at && r >= take) return;
+        g.unlock();
+        {
+            std::unique_lock<std::shared_mutex> u(e->cells_mu);
+            rc = widen_buffer(e, b, s, true);
+        }
+        g.lock();
+    }
+};
+
 int launch_single(lh_engine *e, uint32_t id, const double *d_v, size_t n, hipStream_t s)
 {
     EpochBuffer &b = e->bufs[(size_t)e->cur];
+    CellsHold hold(e, b, n, s);
+    if (hold.rc) return hold.rc;
     count_samples(b, n);
     // a workgroup's uint32 LDS bins must not wrap even if every sample of the launch lands in one
     // bucket: keep one launch below 2^32 samples
     const size_t kMaxLaunch = size_t(1) << 31;
     while (n) {
         const size_t take = n < kMaxLaunch ? n : kMaxLaunch;
-        HIPCHK(lh::launch_ingest_single(d_v, take, b.counts + (size_t)id * LH_ROW_STRIDE, b.ranges + 2 * (size_t)id,
+        HIPCHK(lh::launch_ingest_single(d_v, take, lh::cells_at(b.counts, (size_t)id * LH_ROW_STRIDE), b.ranges + 2 * (size_t)id,
                                         e->d_Tx, e->num_cus, s));
         e->c_single.fetch_add(take, std::memory_order_relaxed);
         e->c_launches.fetch_add(1, std::memory_order_relaxed);
@@ -758,6 +821,8 @@ int launch_pairs(lh_engine *e, lh::Ids d_ids, const double *d_v, size_t n, hipSt
         } else {
             st = lh::choose_step(c.st, (uintptr_t)d_ids.p, d_ids.width, (uintptr_t)d_v, n, host_fed);
         }
+        CellsHold hold(e, b, st.take, s);
+        if (hold.rc) return hold.rc;
         int rc;
         if (st.kind == lh::PATH_SMALL) {
             rc = run_small(e, b, d_ids, d_v, st.take, s);
@@ -862,7 +927,8 @@ void free_engine(lh_engine *e)
         if (lp->stream) (void)hipStreamDestroy(lp->stream);
     }
     for (auto &b : e->bufs) {
-        if (b.counts) (void)hipFree(b.counts);
+        if (b.store32) (void)hipFree(b.store32);
+        if (b.store64) (void)hipFree(b.store64);
         if (b.ranges) (void)hipFree(b.ranges);
         if (b.ccur) (void)hipFree(b.ccur);
         if (b.cflag) (void)hipFree(b.cflag);
@@ -979,6 +1045,8 @@ int create_impl(const lh_config *cfg_in, lh_engine *e)
         HIPCHK(hipMemsetAsync(e->d_clife, 0, NC * sizeof(uint64_t), e->xstream));
         HIPCHK(hipMemsetAsync(e->d_cknown, 0, NC * sizeof(uint32_t), e->xstream));
     }
+    // the cell width of the epoch buffers (lh_cells.h): 32-bit above 8 192 names unless the caller chose
+    e->narrow = e->cfg.cell_bits == 32 || (e->cfg.cell_bits == 0 && e->cfg.max_metrics > 8192);
     e->bufs.resize(e->cfg.num_buffers);
     for (auto &b : e->bufs) {
         if (NC) {
@@ -987,9 +1055,16 @@ int create_impl(const lh_config *cfg_in, lh_engine *e)
             HIPCHK(hipMemsetAsync(b.ccur, 0, NC * sizeof(uint64_t), e->xstream));
             HIPCHK(hipMemsetAsync(b.cflag, 0, NC * sizeof(uint32_t), e->xstream));
         }
-        HIPCHK(hipMalloc((void **)&b.counts, M * LH_ROW_STRIDE * sizeof(uint64_t)));
+        if (e->narrow) {
+            HIPCHK(hipMalloc((void **)&b.store32, M * LH_ROW_STRIDE * sizeof(uint32_t)));
+            HIPCHK(hipMemsetAsync(b.store32, 0, M * LH_ROW_STRIDE * sizeof(uint32_t), e->xstream));
+            b.counts = lh::cells_tagged(b.store32, 4);
+        } else {
+            HIPCHK(hipMalloc((void **)&b.store64, M * LH_ROW_STRIDE * sizeof(uint64_t)));
+            HIPCHK(hipMemsetAsync(b.store64, 0, M * LH_ROW_STRIDE * sizeof(uint64_t), e->xstream));
+            b.counts = b.store64;
+        }
         HIPCHK(hipMalloc((void **)&b.ranges, M * 2 * sizeof(uint32_t)));
-        HIPCHK(hipMemsetAsync(b.counts, 0, M * LH_ROW_STRIDE * sizeof(uint64_t), e->xstream));
         HIPCHK(lh::launch_init_ranges(b.ranges, (uint32_t)M, e->xstream));
         HIPCHK(hipEventCreateWithFlags(&b.cleared, hipEventDisableTiming));
         HIPCHK(hipEventRecord(b.cleared, e->xstream));
@@ -1060,14 +1135,20 @@ int lh_create(const lh_config *cfg, lh_engine **out)
 {
     if (!cfg || !out) return LH_EINVAL;
     *out = nullptr;
-    if (cfg->struct_size != sizeof(lh_config)) return LH_EINVAL;
+    // (ABI <= 6 callers pass the struct without cell_bits: the default width)
+    constexpr uint32_t kConfigV6 = (uint32_t)offsetof(lh_config, cell_bits);
+    if (cfg->struct_size != sizeof(lh_config) && cfg->struct_size != kConfigV6) return LH_EINVAL;
+    const uint32_t cell_bits = cfg->struct_size == sizeof(lh_config) ? cfg->cell_bits : 0u;
+    if (cell_bits != 0 && cell_bits != 32 && cell_bits != 64) return LH_EINVAL;
     if (cfg->max_metrics == 0 || cfg->num_buffers < 2 || cfg->num_buffers > 16 || cfg->num_lanes == 0 ||
         cfg->num_lanes > 256 || cfg->lane_samples < 2 || cfg->lane_samples > (1ull << 28) ||
         cfg->max_counters > (1u << 24))
         return LH_EINVAL;
     lh_engine *e = new (std::nothrow) lh_engine();
     if (!e) return LH_ENOMEM;
-    e->cfg = *cfg;
+    std::memcpy(&e->cfg, cfg, cfg->struct_size);
+    e->cfg.struct_size = (uint32_t)sizeof(lh_config);
+    e->cfg.cell_bits = cell_bits;
     int rc = create_impl(cfg, e);
     if (rc != LH_OK) {
         free_engine(e);
@@ -1726,7 +1807,7 @@ int extract_impl(lh_snapshot *s, uint32_t first, size_t nmetrics, const double *
         cx.vbits = reinterpret_cast<uint32_t *>(xb + L.off_vbits);
         cx.pkeys = reinterpret_cast<int16_t *>(xb + L.off_pkeys);
     }
-    HIPCHK(lh::launch_extract(b.counts + (size_t)first * LH_ROW_STRIDE, b.ranges + 2 * (size_t)first,
+    HIPCHK(lh::launch_extract(lh::cells_at(b.counts, (size_t)first * LH_ROW_STRIDE), b.ranges + 2 * (size_t)first,
                               (uint32_t)nmetrics, p, (uint32_t)np, e->d_D,
                               reinterpret_cast<lh::ExtractOut *>(xb + L.off_stats),
                               reinterpret_cast<double *>(xb + L.off_pvals),
@@ -1808,16 +1889,19 @@ int lh_buckets(lh_snapshot *s, uint32_t id, int16_t *keys, uint64_t *counts, siz
     const size_t span = (size_t)r[1] - r[0] + 1;
     rc = ensure_xbuf(e, span * sizeof(uint64_t));
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(e->h_xbuf, b.counts + (size_t)id * LH_ROW_STRIDE + r[0], span * sizeof(uint64_t),
+    const size_t cb = lh::cell_bytes_of(b.counts);
+    HIPCHK(hipMemcpyAsync(e->h_xbuf, lh::cells_base(lh::cells_at(b.counts, (size_t)id * LH_ROW_STRIDE + r[0])), span * cb,
                           hipMemcpyDeviceToHost, e->xstream));
     HIPCHK(hipStreamSynchronize(e->xstream));
-    const uint64_t *row = reinterpret_cast<const uint64_t *>(e->h_xbuf);
+    const uint64_t *row64 = reinterpret_cast<const uint64_t *>(e->h_xbuf);
+    const uint32_t *row32 = reinterpret_cast<const uint32_t *>(e->h_xbuf);
     size_t k = 0;
     for (size_t i = 0; i < span; i++) {
-        if (!row[i]) continue;
+        const uint64_t c = cb == 4 ? row32[i] : row64[i];
+        if (!c) continue;
         if (k < cap) {
             keys[k] = (int16_t)(uint16_t)((r[0] + i) ^ 0x8000u);
-            counts[k] = row[i];
+            counts[k] = c;
         }
         k++;
     }
@@ -1838,7 +1922,7 @@ int lh_buckets_all(lh_snapshot *s, uint32_t first, size_t nmetrics, uint64_t *of
     if (rc) return rc;
     std::lock_guard<std::mutex> g(e->xmu);
     EpochBuffer &b = e->bufs[(size_t)s->buf];
-    const uint64_t *rows = b.counts + (size_t)first * LH_ROW_STRIDE;
+    const uint64_t *rows = lh::cells_at(b.counts, (size_t)first * LH_ROW_STRIDE);
     const uint32_t *rng = b.ranges + 2 * (size_t)first;
     // pass 1: occupied cells per row
     const size_t off_bytes = (nmetrics + 1) * sizeof(uint64_t);
@@ -1880,10 +1964,36 @@ int lh_buckets_all(lh_snapshot *s, uint32_t first, size_t nmetrics, uint64_t *of
 int lh_snapshot_rows(lh_snapshot *s, void **d_counts, uint32_t *nrows)
 {
     if (!s || !d_counts) return LH_EINVAL;
-    *d_counts = s->e->bufs[(size_t)s->buf].counts;
-    if (nrows) *nrows = s->e->cfg.max_metrics;
+    lh_engine *e = s->e;
+    EpochBuffer &b = e->bufs[(size_t)s->buf];
+    if (e->narrow) { // the caller indexes uint64 rows: the snapshot moves to its wide store first (lh_snapshot_cells does not)
+        int rc = use_device(e);
+        if (rc) return rc;
+        std::lock_guard<std::mutex> g(e->xmu);
+        const bool moves = lh::cells_narrow(b.counts);
+        rc = widen_buffer(e, b, e->xstream, false);
+        if (rc) return rc;
+        // the view is the caller's from here on, on whatever stream: the move must have happened
+        if (moves) HIPCHK(hipStreamSynchronize(e->xstream));
+    }
+    *d_counts = b.counts;
+    if (nrows) *nrows = e->cfg.max_metrics;
     return LH_OK;
 }
+
+int lh_snapshot_cells(lh_snapshot *s, void **d_cells, uint32_t *nrows, uint32_t *cell_bytes)
+{
+    if (!s || !d_cells || !cell_bytes) return LH_EINVAL;
+    lh_engine *e = s->e;
+    std::lock_guard<std::mutex> g(e->xmu);
+    const EpochBuffer &b = e->bufs[(size_t)s->buf];
+    *d_cells = lh::cells_base(b.counts);
+    *cell_bytes = lh::cell_bytes_of(b.counts);
+    if (nrows) *nrows = e->cfg.max_metrics;
+    return LH_OK;
+}
+
+int lh_cell_bytes(lh_engine *e) { return !e ? LH_EINVAL : (e->narrow ? 4 : 8); }
 
 size_t lh_row_stride(void) { return LH_ROW_STRIDE; }
 
@@ -2059,6 +2169,11 @@ int lh_snapshot_merge(lh_snapshot *s, void *comm, int nranks, int rank, int plan
     e->merge_info.rows_8bit = (uint32_t)info[8];
     e->merge_info.rows_16bit = (uint32_t)info[9];
     if (total == 0) return LH_OK; // nothing anywhere (every rank computes the same plan: no hang)
+    // a merged cell may not fit a narrow store's uint32: the snapshot moves to uint64 cells first (in stream order)
+    if (!words32) {
+        rc = widen_buffer(e, b, st, false);
+        if (rc) return rc;
+    }
 
     // 3. pack -> collective -> unpack.  The pack buffer is its own grow-only allocation.
     const uint64_t send_elems = rs ? (uint64_t)nranks * bmax : total, recv_elems = rs ? bmax : 0;
@@ -2249,7 +2364,7 @@ int lh_serialize(lh_snapshot *s, uint32_t first, size_t nmetrics, const double *
 
     EpochBuffer &b = e->bufs[(size_t)s->buf];
     HIPCHK(hipMemcpyAsync(e->d_blob, bb.bytes.data(), bb.bytes.size(), hipMemcpyHostToDevice, e->xstream));
-    HIPCHK(lh::launch_extract(b.counts + (size_t)first * LH_ROW_STRIDE, b.ranges + 2 * (size_t)first, (uint32_t)nmetrics,
+    HIPCHK(lh::launch_extract(lh::cells_at(b.counts, (size_t)first * LH_ROW_STRIDE), b.ranges + 2 * (size_t)first, (uint32_t)nmetrics,
                               p, (uint32_t)np, e->d_D, reinterpret_cast<lh::ExtractOut *>(e->d_xbuf + L.off_stats),
                               reinterpret_cast<double *>(e->d_xbuf + L.off_pvals),
                               reinterpret_cast<int16_t *>(e->d_xbuf + L.off_pkeys), e->d_xbuf + L.off_pvalid,
@@ -2533,12 +2648,16 @@ int lh_release(lh_snapshot *s)
         // them (metrics.go:435-458): a snapshot released before any counter call still folds
         keep(fold_counters(s));
         hip(lh::launch_clear(b.counts, b.ranges, e->cfg.max_metrics, e->xstream));
+        // a widened buffer starts its next interval on its narrow store again (left clean by the widening; the wide store
+        // is clean behind this clear and kept for the next time)
+        if (e->narrow) b.counts = lh::cells_tagged(b.store32, 4);
         if (e->cfg.max_counters) {
             hip(hipMemsetAsync(b.ccur, 0, (size_t)e->cfg.max_counters * sizeof(uint64_t), e->xstream));
             hip(hipMemsetAsync(b.cflag, 0, (size_t)e->cfg.max_counters * sizeof(uint32_t), e->xstream));
         }
         hip(hipEventRecord(b.cleared, e->xstream));
         __atomic_store_n(&b.nsamples, 0, __ATOMIC_RELAXED);
+        __atomic_store_n(&b.reserved, 0, __ATOMIC_RELAXED);
     }
     {
         std::unique_lock<std::shared_mutex> eg(e->epoch_mu);
@@ -2571,6 +2690,15 @@ int lh_get_counters(lh_engine *e, lh_counters *out)
         for (const lh_engine::AuxScratch &a : e->aux) lane += a.bytes;
         if (e->lane_tables.p[0]) lane += 2 * (uint64_t)e->lane_tables.bytes;
         out->lane_scratch_bytes = lane;
+    }
+    out->widenings = e->c_widenings.load();
+    {
+        std::shared_lock<std::shared_mutex> cg(e->cells_mu);
+        std::lock_guard<std::mutex> xg(e->xmu); // (a snapshot's buffer is widened under xmu)
+        uint64_t sb = 0;
+        for (const EpochBuffer &b : e->bufs)
+            sb += (uint64_t)e->cfg.max_metrics * LH_ROW_STRIDE * ((b.store32 ? 4u : 0u) + (b.store64 ? 8u : 0u));
+        out->store_bytes = sb;
     }
     out->sublaunches = e->c_sublaunches.load();
     out->samples_partitioned_v2 = e->c_part2.load();
@@ -2700,6 +2828,12 @@ int lh_set_option(lh_engine *e, int option, uint64_t value)
         if (value > 0xffffffffull) return LH_EINVAL;
         e->fail_allocs.store((uint32_t)value);
         return LH_OK;
+    case LH_OPT_WIDEN_AT_SAMPLES: {
+        if (value < 1 || value > 0xffffffffull) return LH_EINVAL;
+        std::unique_lock<std::shared_mutex> u(e->cells_mu);
+        e->widen_at = value;
+        return LH_OK;
+    }
     case LH_OPT_LANE_ZERO_COPY:
         if (value > 1) return LH_EINVAL;
         e->lane_zero_copy = value != 0;

@@ -7,6 +7,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "lh_cells.h"
+
 // Cells from one row of an epoch buffer to the next.  A row is uint64[65536] (bin = key ^ 0x8000), but the rows are NOT
 // packed back to back: names with similar value distributions keep their occupied windows at the same offset inside the
 // row, and windows exactly 512 KiB apart share the low 19 address bits -- measured on 65 536 windows of 600 cells
@@ -47,7 +49,8 @@ struct Ids {
 // Table generation (once per engine).
 hipError_t launch_gen_tables(double *d_Tx, double *d_D, hipStream_t s);
 
-// K1: ingest.  counts: [nmetrics][65536] u64; ranges: [nmetrics][2] u32 (lo,hi bin).
+// K1: ingest.  counts: [nmetrics][LH_ROW_STRIDE] cells -- uint64, or uint32 when bit 0 of the pointer is set (lh_cells.h:
+// every `counts` / `row` below is such a tagged pointer); ranges: [nmetrics][2] u32 (lo,hi bin).
 hipError_t launch_ingest_single(const double *d_v, size_t n, uint64_t *row, uint32_t *range,
                                 const double *d_Tx, int num_cus, hipStream_t s);
 hipError_t launch_ingest_pairs(Ids d_ids, const double *d_v, size_t n, uint64_t *counts,
@@ -223,6 +226,8 @@ hipError_t launch_format_f(const double *d_v, char *d_out, uint32_t *d_lens, uin
 
 // K3: clear the dirty span of every row and reset the ranges.
 hipError_t launch_clear(uint64_t *counts, uint32_t *ranges, uint32_t nmetrics, hipStream_t s);
+// A narrow store's dirty spans into the (zeroed) wide store, and zeroed behind the copy (lh_cells.h).
+hipError_t launch_widen_rows(uint32_t *narrow, uint64_t *wide, const uint32_t *ranges, uint32_t nmetrics, hipStream_t s);
 hipError_t launch_init_ranges(uint32_t *ranges, uint32_t nmetrics, hipStream_t s);
 hipError_t launch_mark_dirty(uint32_t *ranges, uint32_t first, uint32_t nrows, uint32_t lo, uint32_t hi, hipStream_t s);
 

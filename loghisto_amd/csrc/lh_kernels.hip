@@ -121,7 +121,7 @@ static_assert(K1_OVF >= 64 && K1_OVF <= K1_WIN, "anchor arithmetic");
 // a redundant atomic, never miss one.
 __device__ __forceinline__ void global_cell_add(uint64_t *row, uint32_t *range, uint32_t bin, uint64_t c)
 {
-    atomicAdd(reinterpret_cast<unsigned long long *>(&row[bin]), (unsigned long long)c);
+    lh::cell_add(row, bin, c);
     if (bin < range[0]) atomicMin(&range[0], bin);
     if (bin > range[1]) atomicMax(&range[1], bin);
 }
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(K1_BLOCK) void k_ingest_single(const double *__rest
             for (uint32_t k = 1; k < K1_COPIES; k++) c += h0[k * K1_STRIDE + i];
         }
         if (c) {
-            atomicAdd(reinterpret_cast<unsigned long long *>(&row[w.win_lo + i]), (unsigned long long)c);
+            lh::cell_add(row, w.win_lo + i, c);
             lmin = min(lmin, w.win_lo + i);
             lmax = max(lmax, w.win_lo + i);
         }
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(K1_BLOCK) void k_ingest_single(const double *__rest
         for (uint32_t i = tid; i < K1_OVF; i += K1_BLOCK) {
             const uint32_t c = h0[K1_MAIN_WORDS + side * K1_OVF + i];
             if (c) {
-                atomicAdd(reinterpret_cast<unsigned long long *>(&row[ovf_lo + i]), (unsigned long long)c);
+                lh::cell_add(row, ovf_lo + i, c);
                 lmin = min(lmin, ovf_lo + i);
                 lmax = max(lmax, ovf_lo + i);
             }
@@ -340,7 +340,7 @@ __device__ __forceinline__ void kp_add(uint64_t *__restrict__ counts, uint32_t *
 {
     if (id >= nmetrics) { atomicOr(err, 1u); return; }
     const uint32_t bin = lh_bin_of(v, Tx);
-    atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)id * LH_ROW_STRIDE + bin]), 1ull);
+    lh::cell_add(counts, (size_t)id * LH_ROW_STRIDE + bin, 1ull);
     // ranges only widen: a stale read can cost a redundant atomic, never miss one
     uint32_t *r = ranges + 2 * (size_t)id;
     if (bin < r[0]) atomicMin(&r[0], bin);
@@ -538,7 +538,8 @@ __device__ __forceinline__ double shfl_down_f64(double x, int d)
 
 struct PctArgs { double p[K2_MAXP]; }; // percentile list by value: no H2D copy on the extract path
 
-__global__ __launch_bounds__(K2_BLOCK) void k_extract(const uint64_t *__restrict__ counts,
+template <typename CELL> // the store's cell: uint64_t, or uint32_t (lh_cells.h)
+__global__ __launch_bounds__(K2_BLOCK) void k_extract(const CELL *__restrict__ counts,
                                                       const uint32_t *__restrict__ ranges,
                                                       const PctArgs pa, uint32_t np,
                                                       const double *__restrict__ D,
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(K2_BLOCK) void k_extract(const uint64_t *__restrict
     __shared__ double s_p[K2_MAXP];
 
     const uint32_t m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint64_t *row = counts + (size_t)m * LH_ROW_STRIDE;
+    const CELL *row = counts + (size_t)m * LH_ROW_STRIDE;
     const uint32_t lo = ranges[2 * (size_t)m], hi = ranges[2 * (size_t)m + 1];
 
     if (tid < K2_MAXP) {
@@ -921,7 +922,8 @@ constexpr uint32_t EW_STEPS = 4, EW_REG = EW_STEPS * K2_BLOCK;
 static_assert(LH_ROW_STRIDE >= LH_NKEYS + 4, "k_extract_wave reads whole 4-bin groups inside the row's stride");
 // (the decompress table is allocated LH_ROW_STRIDE entries long, zeros behind LH_NKEYS: lh_engine.cc)
 
-__global__ __launch_bounds__(K2_BLOCK) void k_extract_wave(const uint64_t *__restrict__ counts,
+template <typename CELL>
+__global__ __launch_bounds__(K2_BLOCK) void k_extract_wave(const CELL *__restrict__ counts,
                                                            const uint32_t *__restrict__ ranges, uint32_t nmetrics,
                                                            const PctArgs pa, uint32_t np,
                                                            const double *__restrict__ D,
@@ -938,7 +940,7 @@ __global__ __launch_bounds__(K2_BLOCK) void k_extract_wave(const uint64_t *__res
         err_out[1] = err_in[1];
     }
     if (m >= nmetrics) return; // wave-uniform
-    const uint64_t *row = counts + (size_t)m * LH_ROW_STRIDE;
+    const CELL *row = counts + (size_t)m * LH_ROW_STRIDE;
     const uint32_t lo = ranges[2 * (size_t)m], hi = ranges[2 * (size_t)m + 1];
     bool inreg = lo <= hi && hi - lo < EW_REG; // wave-uniform
 
@@ -956,19 +958,29 @@ __global__ __launch_bounds__(K2_BLOCK) void k_extract_wave(const uint64_t *__res
 #pragma unroll
         for (uint32_t s = 0; s < EW_STEPS; s++) {
             const uint32_t b0 = lo + s * K2_BLOCK + lane * K2_PER_THREAD;
-            u64x2_a8 c01 = {0, 0}, c23 = {0, 0};
             // a lane whose four bins all lie beyond hi asks for nothing: a 600-bin window is three steps = 768 bins wide,
             // and the lanes past its end were 22 % of the kernel's reads
-            if (b0 <= hi && b0 + K2_PER_THREAD <= LH_ROW_STRIDE) {
-                const u64x2_a8 *rp = reinterpret_cast<const u64x2_a8 *>(row + b0);
-                c01 = rp[0];
-                c23 = rp[1];
+            const bool mine = b0 <= hi && b0 + K2_PER_THREAD <= LH_ROW_STRIDE;
+            if constexpr (sizeof(CELL) == 4) { // a narrow store: the four cells are ONE 16-byte load
+                u32x4_a4 c = {0, 0, 0, 0};
+                if (mine) c = *reinterpret_cast<const u32x4_a4 *>(row + b0);
+                c32[s][0] = c.a;
+                c32[s][1] = c.b;
+                c32[s][2] = c.c;
+                c32[s][3] = c.d;
+            } else {
+                u64x2_a8 c01 = {0, 0}, c23 = {0, 0};
+                if (mine) {
+                    const u64x2_a8 *rp = reinterpret_cast<const u64x2_a8 *>(row + b0);
+                    c01 = rp[0];
+                    c23 = rp[1];
+                }
+                c32[s][0] = (uint32_t)c01.a;
+                c32[s][1] = (uint32_t)c01.b;
+                c32[s][2] = (uint32_t)c23.a;
+                c32[s][3] = (uint32_t)c23.b;
+                hibits |= (uint32_t)(c01.a >> 32) | (uint32_t)(c01.b >> 32) | (uint32_t)(c23.a >> 32) | (uint32_t)(c23.b >> 32);
             }
-            c32[s][0] = (uint32_t)c01.a;
-            c32[s][1] = (uint32_t)c01.b;
-            c32[s][2] = (uint32_t)c23.a;
-            c32[s][3] = (uint32_t)c23.b;
-            hibits |= (uint32_t)(c01.a >> 32) | (uint32_t)(c01.b >> 32) | (uint32_t)(c23.a >> 32) | (uint32_t)(c23.b >> 32);
             hibits |= (c32[s][0] | c32[s][1] | c32[s][2] | c32[s][3]) >> 22;
         }
         inreg = __builtin_amdgcn_ballot_w64(hibits != 0) == 0; // wave-uniform
@@ -1020,13 +1032,17 @@ __global__ __launch_bounds__(K2_BLOCK) void k_extract_wave(const uint64_t *__res
             uint64_t carry = 0;
             for (uint32_t base = lo; base <= hi && todo; base += K2_TILE / K2_WAVES) {
                 const uint32_t b0 = base + lane * K2_PER_THREAD;
-                u64x2_a8 c01 = {0, 0}, c23 = {0, 0};
+                uint64_t c[K2_PER_THREAD] = {0, 0, 0, 0};
                 if (b0 <= hi && b0 + K2_PER_THREAD <= LH_ROW_STRIDE) {
-                    const u64x2_a8 *rp = reinterpret_cast<const u64x2_a8 *>(row + b0);
-                    c01 = rp[0];
-                    c23 = rp[1];
+                    if constexpr (sizeof(CELL) == 4) {
+                        const u32x4_a4 q = *reinterpret_cast<const u32x4_a4 *>(row + b0);
+                        c[0] = q.a; c[1] = q.b; c[2] = q.c; c[3] = q.d;
+                    } else {
+                        const u64x2_a8 *rp = reinterpret_cast<const u64x2_a8 *>(row + b0);
+                        const u64x2_a8 c01 = rp[0], c23 = rp[1];
+                        c[0] = c01.a; c[1] = c01.b; c[2] = c23.a; c[3] = c23.b;
+                    }
                 }
-                const uint64_t c[K2_PER_THREAD] = {c01.a, c01.b, c23.a, c23.b};
                 const uint64_t tsumc = (c[0] + c[1]) + (c[2] + c[3]);
                 const uint64_t inc = wave_scan_incl_u64(tsumc);
                 const uint64_t end = carry + readlane_u64(inc, 63);
@@ -1099,13 +1115,24 @@ hipError_t launch_extract(const uint64_t *counts, const uint32_t *ranges, uint32
     PctArgs pa;
     for (uint32_t i = 0; i < (uint32_t)K2_MAXP; i++) pa.p[i] = i < np ? h_p[i] : 2.0;
     // many names: one wave per metric (bit-identical results; see k_extract_wave)
+    const bool narrow = cells_narrow(counts);
+    const uint32_t *c32 = reinterpret_cast<const uint32_t *>(cells_base(counts));
     if (nmetrics >= 2048 && !notify.host_flag) {
-        hipLaunchKernelGGL(k_extract_wave, dim3((nmetrics + K2_WAVES - 1) / K2_WAVES), dim3(K2_BLOCK), 0, s, counts,
-                           ranges, nmetrics, pa, np, d_D, out, pvals, pkeys, pvalid, err_in, err_out, compact);
+        const dim3 grid((nmetrics + K2_WAVES - 1) / K2_WAVES);
+        if (narrow)
+            hipLaunchKernelGGL(k_extract_wave<uint32_t>, grid, dim3(K2_BLOCK), 0, s, c32, ranges, nmetrics, pa, np, d_D, out,
+                               pvals, pkeys, pvalid, err_in, err_out, compact);
+        else
+            hipLaunchKernelGGL(k_extract_wave<uint64_t>, grid, dim3(K2_BLOCK), 0, s, counts, ranges, nmetrics, pa, np, d_D,
+                               out, pvals, pkeys, pvalid, err_in, err_out, compact);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_extract, dim3(nmetrics), dim3(K2_BLOCK), 0, s, counts, ranges, pa, np, d_D, out,
-                       pvals, pkeys, pvalid, err_in, err_out, notify, compact);
+    if (narrow)
+        hipLaunchKernelGGL(k_extract<uint32_t>, dim3(nmetrics), dim3(K2_BLOCK), 0, s, c32, ranges, pa, np, d_D, out, pvals,
+                           pkeys, pvalid, err_in, err_out, notify, compact);
+    else
+        hipLaunchKernelGGL(k_extract<uint64_t>, dim3(nmetrics), dim3(K2_BLOCK), 0, s, counts, ranges, pa, np, d_D, out,
+                           pvals, pkeys, pvalid, err_in, err_out, notify, compact);
     return hipGetLastError();
 }
 
@@ -1113,7 +1140,8 @@ hipError_t launch_extract(const uint64_t *counts, const uint32_t *ranges, uint32
 // K5 occupied-cell listing (RawMetricSet.Histograms, metrics.go:54-60): the sparse
 // map[int16]*uint64 of every name, as CSR arrays, compacted on the device.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_count_cells(const uint64_t *__restrict__ counts,
+template <typename CELL>
+__global__ __launch_bounds__(256) void k_count_cells(const CELL *__restrict__ counts,
                                                      const uint32_t *__restrict__ ranges,
                                                      uint32_t *__restrict__ ncells)
 {
@@ -1124,7 +1152,7 @@ __global__ __launch_bounds__(256) void k_count_cells(const uint64_t *__restrict_
     __syncthreads();
     uint32_t n = 0;
     if (lo <= hi) {
-        const uint64_t *row = counts + (size_t)m * LH_ROW_STRIDE;
+        const CELL *row = counts + (size_t)m * LH_ROW_STRIDE;
         for (uint32_t b = lo + threadIdx.x; b <= hi; b += 256) n += row[b] != 0;
     }
 #pragma unroll
@@ -1134,7 +1162,8 @@ __global__ __launch_bounds__(256) void k_count_cells(const uint64_t *__restrict_
     if (threadIdx.x == 0) ncells[m] = s_n;
 }
 
-__global__ __launch_bounds__(256) void k_compact_cells(const uint64_t *__restrict__ counts,
+template <typename CELL>
+__global__ __launch_bounds__(256) void k_compact_cells(const CELL *__restrict__ counts,
                                                        const uint32_t *__restrict__ ranges,
                                                        const uint64_t *__restrict__ offsets,
                                                        int16_t *__restrict__ keys, uint64_t *__restrict__ vals)
@@ -1143,7 +1172,7 @@ __global__ __launch_bounds__(256) void k_compact_cells(const uint64_t *__restric
     const uint32_t m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t lo = ranges[2 * (size_t)m], hi = ranges[2 * (size_t)m + 1];
     if (lo > hi) return;
-    const uint64_t *row = counts + (size_t)m * LH_ROW_STRIDE;
+    const CELL *row = counts + (size_t)m * LH_ROW_STRIDE;
     uint64_t base = offsets[m];
     for (uint32_t t0 = lo; t0 <= hi; t0 += 256) { // ascending bin == ascending key
         const uint32_t b = t0 + tid;
@@ -1171,7 +1200,11 @@ hipError_t launch_count_cells(const uint64_t *counts, const uint32_t *ranges, ui
                               hipStream_t s)
 {
     if (nmetrics == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_count_cells, dim3(nmetrics), dim3(256), 0, s, counts, ranges, ncells);
+    if (cells_narrow(counts))
+        hipLaunchKernelGGL(k_count_cells<uint32_t>, dim3(nmetrics), dim3(256), 0, s,
+                           reinterpret_cast<const uint32_t *>(cells_base(counts)), ranges, ncells);
+    else
+        hipLaunchKernelGGL(k_count_cells<uint64_t>, dim3(nmetrics), dim3(256), 0, s, counts, ranges, ncells);
     return hipGetLastError();
 }
 
@@ -1179,7 +1212,11 @@ hipError_t launch_compact_cells(const uint64_t *counts, const uint32_t *ranges, 
                                 const uint64_t *offsets, int16_t *keys, uint64_t *vals, hipStream_t s)
 {
     if (nmetrics == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_compact_cells, dim3(nmetrics), dim3(256), 0, s, counts, ranges, offsets, keys, vals);
+    if (cells_narrow(counts))
+        hipLaunchKernelGGL(k_compact_cells<uint32_t>, dim3(nmetrics), dim3(256), 0, s,
+                           reinterpret_cast<const uint32_t *>(cells_base(counts)), ranges, offsets, keys, vals);
+    else
+        hipLaunchKernelGGL(k_compact_cells<uint64_t>, dim3(nmetrics), dim3(256), 0, s, counts, ranges, offsets, keys, vals);
     return hipGetLastError();
 }
 
@@ -1200,8 +1237,9 @@ __global__ void k_ranges_flip_hi(uint32_t *__restrict__ dst, const uint32_t *__r
 // cell of row r on THIS rank, clipped to 2^32 - 1), so that the one MIN all-reduce also returns every row's largest
 // per-rank cell.  One wave per row over the row's own dirty window.  narrow == 0: the words are written as 0 ("unknown":
 // the all-reduced maximum reads 2^32 - 1 on EVERY rank, whichever rank switched the narrow cells off) and no cell is read.
+template <typename CELL>
 __global__ __launch_bounds__(256) void k_merge_prep(uint32_t *__restrict__ dst, const uint32_t *__restrict__ ranges,
-                                                    const uint64_t *__restrict__ counts, uint32_t nrows,
+                                                    const CELL *__restrict__ counts, uint32_t nrows,
                                                     uint32_t extra, uint32_t narrow)
 {
     const uint32_t lane = threadIdx.x & 63u, r = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -1209,7 +1247,7 @@ __global__ __launch_bounds__(256) void k_merge_prep(uint32_t *__restrict__ dst, 
     const uint32_t lo = ranges[2 * (size_t)r], hi = ranges[2 * (size_t)r + 1];
     unsigned long long m = 0;
     if (narrow && lo <= hi) {
-        const uint64_t *src = counts + (size_t)r * LH_ROW_STRIDE + lo;
+        const CELL *src = counts + (size_t)r * LH_ROW_STRIDE + lo;
         for (uint32_t i = lane; i <= hi - lo; i += 64u) m = max(m, (unsigned long long)src[i]);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) m = max(m, shfl_xor_u64(m, d));
@@ -1445,8 +1483,30 @@ __device__ __forceinline__ uint32_t merge_block_of(const uint32_t *__restrict__ 
 // workgroup: from 2 048 rows on -- 65 536 windows of ~600 cells are 2.3 cells per thread of a workgroup behind a chain
 // of dependent loads (range, owner block, offsets), and the kernels ran at the latency of 32 rounds of such chains:
 // pack 131 us + unpack 146 us for 157 MB of words at config 4's name count, round 4).
-template <typename WORD, int TPR>
-__global__ __launch_bounds__(256) void k_pack_rows(const uint64_t *__restrict__ counts,
+// four consecutive cells of a row store as vector loads / stores (uint64 cells: two 16-byte accesses at an 8-byte-aligned
+// address; uint32 cells: one at a 4-byte-aligned address)
+template <typename CELL> __device__ __forceinline__ void cells_load4(const CELL *p, uint64_t (&v)[4])
+{
+    if constexpr (sizeof(CELL) == 4) {
+        const u32x4_a4 q = *reinterpret_cast<const u32x4_a4 *>(p);
+        v[0] = q.a; v[1] = q.b; v[2] = q.c; v[3] = q.d;
+    } else {
+        const u64x2_a8 a = *reinterpret_cast<const u64x2_a8 *>(p), b = *reinterpret_cast<const u64x2_a8 *>(p + 2);
+        v[0] = a.a; v[1] = a.b; v[2] = b.a; v[3] = b.b;
+    }
+}
+template <typename CELL> __device__ __forceinline__ void cells_store4(CELL *p, const uint64_t (&v)[4])
+{
+    if constexpr (sizeof(CELL) == 4) {
+        *reinterpret_cast<u32x4_a4 *>(p) = (u32x4_a4){(uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]};
+    } else {
+        *reinterpret_cast<u64x2_a8 *>(p) = (u64x2_a8){v[0], v[1]};
+        *reinterpret_cast<u64x2_a8 *>(p + 2) = (u64x2_a8){v[2], v[3]};
+    }
+}
+
+template <typename WORD, int TPR, typename CELL>
+__global__ __launch_bounds__(256) void k_pack_rows(const CELL *__restrict__ counts,
                                                    const uint32_t *__restrict__ ranges,
                                                    const uint8_t *__restrict__ cls,
                                                    const unsigned long long *__restrict__ P,
@@ -1463,16 +1523,16 @@ __global__ __launch_bounds__(256) void k_pack_rows(const uint64_t *__restrict__ 
     if (lo > hi) return;
     const uint32_t k = merge_block_of(brow, nblocks, r);
     WORD *dst = buf + (size_t)k * bstride + (P[r] - bstart[k]);
-    const uint64_t *src = counts + (size_t)r * LH_ROW_STRIDE + lo;
+    const CELL *src = counts + (size_t)r * LH_ROW_STRIDE + lo;
     const uint32_t w = hi - lo + 1;
-    // whole-word cells: four consecutive cells per lane and step (two 16-byte loads; the row store's side is 8-byte
-    // aligned, the wire's 4-byte: unaligned vector access is on for HSA), the last partial group cell by cell
+    // whole-word cells: four consecutive cells per lane and step (16-byte accesses; the row store's side is aligned to
+    // its cell, the wire's 4-byte: unaligned vector access is on for HSA), the last partial group cell by cell
     if constexpr (sizeof(WORD) == 8) {
         for (uint32_t i = 4u * t; i < w; i += 4u * TPR) {
             if (i + 4u <= w) {
-                const u64x2_a8 a = *reinterpret_cast<const u64x2_a8 *>(src + i), b = *reinterpret_cast<const u64x2_a8 *>(src + i + 2);
-                *reinterpret_cast<u64x2_a8 *>(dst + i) = a;
-                *reinterpret_cast<u64x2_a8 *>(dst + i + 2) = b;
+                uint64_t v[4];
+                cells_load4(src + i, v);
+                cells_store4(dst + i, v);
             } else {
                 for (uint32_t j = i; j < w; j++) dst[j] = src[j];
             }
@@ -1482,8 +1542,9 @@ __global__ __launch_bounds__(256) void k_pack_rows(const uint64_t *__restrict__ 
         if (bits == 32u) {
             for (uint32_t i = 4u * t; i < w; i += 4u * TPR) {
                 if (i + 4u <= w) {
-                    const u64x2_a8 a = *reinterpret_cast<const u64x2_a8 *>(src + i), b = *reinterpret_cast<const u64x2_a8 *>(src + i + 2);
-                    *reinterpret_cast<u32x4_a4 *>(dst + i) = (u32x4_a4){(uint32_t)a.a, (uint32_t)a.b, (uint32_t)b.a, (uint32_t)b.b};
+                    uint64_t v[4];
+                    cells_load4(src + i, v);
+                    cells_store4(dst + i, v);
                 } else {
                     for (uint32_t j = i; j < w; j++) dst[j] = (uint32_t)src[j];
                 }
@@ -1517,8 +1578,8 @@ __global__ __launch_bounds__(256) void k_pack_pad(const unsigned long long *__re
 }
 
 // buf holds block `kblock` (rows first_row .. first_row + nrows_out) packed from offset 0.
-template <typename WORD, int TPR>
-__global__ __launch_bounds__(256) void k_unpack_rows(uint64_t *__restrict__ counts,
+template <typename WORD, int TPR, typename CELL>
+__global__ __launch_bounds__(256) void k_unpack_rows(CELL *__restrict__ counts,
                                                      const uint32_t *__restrict__ ranges,
                                                      const uint8_t *__restrict__ cls,
                                                      const unsigned long long *__restrict__ P,
@@ -1534,16 +1595,16 @@ __global__ __launch_bounds__(256) void k_unpack_rows(uint64_t *__restrict__ coun
     const uint32_t lo = ranges[2 * (size_t)r], hi = ranges[2 * (size_t)r + 1];
     if (lo > hi) return;
     const WORD *src = buf + (P[r] - bstart[kblock]);
-    uint64_t *dst = counts + (size_t)r * LH_ROW_STRIDE + lo;
+    CELL *dst = counts + (size_t)r * LH_ROW_STRIDE + lo;
     const uint32_t w = hi - lo + 1;
     if constexpr (sizeof(WORD) == 8) { // (four cells per lane and step, as k_pack_rows)
         for (uint32_t i = 4u * t; i < w; i += 4u * TPR) {
             if (i + 4u <= w) {
-                const u64x2_a8 a = *reinterpret_cast<const u64x2_a8 *>(src + i), b = *reinterpret_cast<const u64x2_a8 *>(src + i + 2);
-                *reinterpret_cast<u64x2_a8 *>(dst + i) = a;
-                *reinterpret_cast<u64x2_a8 *>(dst + i + 2) = b;
+                uint64_t v[4];
+                cells_load4(src + i, v);
+                cells_store4(dst + i, v);
             } else {
-                for (uint32_t j = i; j < w; j++) dst[j] = src[j];
+                for (uint32_t j = i; j < w; j++) dst[j] = (CELL)src[j];
             }
         }
     } else {
@@ -1551,18 +1612,18 @@ __global__ __launch_bounds__(256) void k_unpack_rows(uint64_t *__restrict__ coun
         if (bits == 32u) {
             for (uint32_t i = 4u * t; i < w; i += 4u * TPR) {
                 if (i + 4u <= w) {
-                    const u32x4_a4 a = *reinterpret_cast<const u32x4_a4 *>(src + i);
-                    *reinterpret_cast<u64x2_a8 *>(dst + i) = (u64x2_a8){a.a, a.b};
-                    *reinterpret_cast<u64x2_a8 *>(dst + i + 2) = (u64x2_a8){a.c, a.d};
+                    uint64_t v[4];
+                    cells_load4(src + i, v);
+                    cells_store4(dst + i, v);
                 } else {
-                    for (uint32_t j = i; j < w; j++) dst[j] = (uint64_t)src[j];
+                    for (uint32_t j = i; j < w; j++) dst[j] = (CELL)src[j];
                 }
             }
         } else {
             const uint32_t log_c = bits == 8u ? 2u : 1u, c = 1u << log_c, mask = (1u << bits) - 1u;
 #pragma unroll 4
             for (uint32_t i = t; i < w; i += TPR)
-                dst[i] = (uint64_t)((src[i >> log_c] >> ((i & (c - 1u)) * bits)) & mask);
+                dst[i] = (CELL)((src[i >> log_c] >> ((i & (c - 1u)) * bits)) & mask);
         }
     }
 }
@@ -1571,8 +1632,12 @@ hipError_t launch_merge_prep(uint32_t *dst, const uint32_t *ranges, const uint64
                              bool narrow, hipStream_t s)
 {
     if (!nrows) return hipSuccess;
-    hipLaunchKernelGGL(k_merge_prep, dim3((nrows + 3) / 4), dim3(256), 0, s, dst, ranges, counts, nrows, extra,
-                       narrow ? 1u : 0u);
+    if (cells_narrow(counts))
+        hipLaunchKernelGGL(k_merge_prep<uint32_t>, dim3((nrows + 3) / 4), dim3(256), 0, s, dst, ranges,
+                           reinterpret_cast<const uint32_t *>(cells_base(counts)), nrows, extra, narrow ? 1u : 0u);
+    else
+        hipLaunchKernelGGL(k_merge_prep<uint64_t>, dim3((nrows + 3) / 4), dim3(256), 0, s, dst, ranges, counts, nrows, extra,
+                           narrow ? 1u : 0u);
     return hipGetLastError();
 }
 
@@ -1607,6 +1672,25 @@ hipError_t launch_merge_plan(const uint32_t *ranges, uint32_t nrows, uint32_t nb
     return hipGetLastError();
 }
 
+// (WORD x rows-per-workgroup x CELL; uint64 wire words carry sums that may not fit a narrow store's cells: the engine widens the
+// buffer before it merges on them, lh_engine.cc)
+template <typename WORD, typename CELL>
+static void pack_rows_t(const CELL *counts, const uint32_t *ranges, const uint8_t *cls, const unsigned long long *Pp,
+                        const unsigned long long *bs, const uint32_t *brow, uint32_t nrows, uint32_t nblocks, uint64_t bstride,
+                        WORD *buf, hipStream_t s)
+{
+    const bool wave = nrows >= 2048; // a wave per row (k_extract_wave's and k_clear_rows_wave's switch-over)
+    const dim3 grid(wave ? (nrows + 3) / 4 : nrows);
+    if (wave)
+        hipLaunchKernelGGL((k_pack_rows<WORD, 64, CELL>), grid, dim3(256), 0, s, counts, ranges, cls, Pp, bs, brow, nblocks,
+                           (unsigned long long)bstride, buf, nrows);
+    else
+        hipLaunchKernelGGL((k_pack_rows<WORD, 256, CELL>), grid, dim3(256), 0, s, counts, ranges, cls, Pp, bs, brow, nblocks,
+                           (unsigned long long)bstride, buf, nrows);
+    if (nblocks > 1)
+        hipLaunchKernelGGL(k_pack_pad<WORD>, dim3(64, nblocks), dim3(256), 0, s, bs, nblocks, (unsigned long long)bstride, buf);
+}
+
 hipError_t launch_pack_rows(const uint64_t *counts, const uint32_t *ranges, const uint8_t *cls, const uint64_t *P,
                             const uint64_t *bstart, const uint32_t *brow, uint32_t nrows, uint32_t nblocks,
                             uint64_t bstride, void *buf, bool words32, hipStream_t s)
@@ -1614,32 +1698,28 @@ hipError_t launch_pack_rows(const uint64_t *counts, const uint32_t *ranges, cons
     if (!nrows) return hipSuccess;
     const unsigned long long *Pp = reinterpret_cast<const unsigned long long *>(P);
     const unsigned long long *bs = reinterpret_cast<const unsigned long long *>(bstart);
-    const bool wave = nrows >= 2048; // a wave per row (k_extract_wave's and k_clear_rows_wave's switch-over)
-    const dim3 grid(wave ? (nrows + 3) / 4 : nrows);
-    if (words32) {
-        uint32_t *b32 = static_cast<uint32_t *>(buf);
-        if (wave)
-            hipLaunchKernelGGL((k_pack_rows<uint32_t, 64>), grid, dim3(256), 0, s, counts, ranges, cls, Pp, bs, brow, nblocks,
-                               (unsigned long long)bstride, b32, nrows);
-        else
-            hipLaunchKernelGGL((k_pack_rows<uint32_t, 256>), grid, dim3(256), 0, s, counts, ranges, cls, Pp, bs, brow, nblocks,
-                               (unsigned long long)bstride, b32, nrows);
-        if (nblocks > 1)
-            hipLaunchKernelGGL(k_pack_pad<uint32_t>, dim3(64, nblocks), dim3(256), 0, s, bs, nblocks,
-                               (unsigned long long)bstride, b32);
-    } else {
-        uint64_t *b64 = static_cast<uint64_t *>(buf);
-        if (wave)
-            hipLaunchKernelGGL((k_pack_rows<uint64_t, 64>), grid, dim3(256), 0, s, counts, ranges, cls, Pp, bs, brow, nblocks,
-                               (unsigned long long)bstride, b64, nrows);
-        else
-            hipLaunchKernelGGL((k_pack_rows<uint64_t, 256>), grid, dim3(256), 0, s, counts, ranges, cls, Pp, bs, brow, nblocks,
-                               (unsigned long long)bstride, b64, nrows);
-        if (nblocks > 1)
-            hipLaunchKernelGGL(k_pack_pad<uint64_t>, dim3(64, nblocks), dim3(256), 0, s, bs, nblocks,
-                               (unsigned long long)bstride, b64);
-    }
+    const bool narrow = cells_narrow(counts);
+    const uint32_t *c32 = reinterpret_cast<const uint32_t *>(cells_base(counts));
+    if (narrow && !words32) return hipErrorInvalidValue;
+    if (words32 && narrow) pack_rows_t(c32, ranges, cls, Pp, bs, brow, nrows, nblocks, bstride, static_cast<uint32_t *>(buf), s);
+    else if (words32) pack_rows_t(counts, ranges, cls, Pp, bs, brow, nrows, nblocks, bstride, static_cast<uint32_t *>(buf), s);
+    else pack_rows_t(counts, ranges, cls, Pp, bs, brow, nrows, nblocks, bstride, static_cast<uint64_t *>(buf), s);
     return hipGetLastError();
+}
+
+template <typename WORD, typename CELL>
+static void unpack_rows_t(CELL *counts, const uint32_t *ranges, const uint8_t *cls, const unsigned long long *Pp,
+                          const unsigned long long *bs, uint32_t kblock, uint32_t first_row, uint32_t nrows_out,
+                          const WORD *buf, hipStream_t s)
+{
+    const bool wave = nrows_out >= 2048;
+    const dim3 grid(wave ? (nrows_out + 3) / 4 : nrows_out);
+    if (wave)
+        hipLaunchKernelGGL((k_unpack_rows<WORD, 64, CELL>), grid, dim3(256), 0, s, counts, ranges, cls, Pp, bs, kblock,
+                           first_row, buf, nrows_out);
+    else
+        hipLaunchKernelGGL((k_unpack_rows<WORD, 256, CELL>), grid, dim3(256), 0, s, counts, ranges, cls, Pp, bs, kblock,
+                           first_row, buf, nrows_out);
 }
 
 hipError_t launch_unpack_rows(uint64_t *counts, const uint32_t *ranges, const uint8_t *cls, const uint64_t *P,
@@ -1649,25 +1729,15 @@ hipError_t launch_unpack_rows(uint64_t *counts, const uint32_t *ranges, const ui
     if (!nrows_out) return hipSuccess;
     const unsigned long long *Pp = reinterpret_cast<const unsigned long long *>(P);
     const unsigned long long *bs = reinterpret_cast<const unsigned long long *>(bstart);
-    const bool wave = nrows_out >= 2048;
-    const dim3 grid(wave ? (nrows_out + 3) / 4 : nrows_out);
-    if (words32) {
-        const uint32_t *b32 = static_cast<const uint32_t *>(buf);
-        if (wave)
-            hipLaunchKernelGGL((k_unpack_rows<uint32_t, 64>), grid, dim3(256), 0, s, counts, ranges, cls, Pp, bs, kblock,
-                               first_row, b32, nrows_out);
-        else
-            hipLaunchKernelGGL((k_unpack_rows<uint32_t, 256>), grid, dim3(256), 0, s, counts, ranges, cls, Pp, bs, kblock,
-                               first_row, b32, nrows_out);
-    } else {
-        const uint64_t *b64 = static_cast<const uint64_t *>(buf);
-        if (wave)
-            hipLaunchKernelGGL((k_unpack_rows<uint64_t, 64>), grid, dim3(256), 0, s, counts, ranges, cls, Pp, bs, kblock,
-                               first_row, b64, nrows_out);
-        else
-            hipLaunchKernelGGL((k_unpack_rows<uint64_t, 256>), grid, dim3(256), 0, s, counts, ranges, cls, Pp, bs, kblock,
-                               first_row, b64, nrows_out);
-    }
+    const bool narrow = cells_narrow(counts);
+    uint32_t *c32 = reinterpret_cast<uint32_t *>(cells_base(counts));
+    if (narrow && !words32) return hipErrorInvalidValue;
+    if (words32 && narrow)
+        unpack_rows_t(c32, ranges, cls, Pp, bs, kblock, first_row, nrows_out, static_cast<const uint32_t *>(buf), s);
+    else if (words32)
+        unpack_rows_t(counts, ranges, cls, Pp, bs, kblock, first_row, nrows_out, static_cast<const uint32_t *>(buf), s);
+    else
+        unpack_rows_t(counts, ranges, cls, Pp, bs, kblock, first_row, nrows_out, static_cast<const uint64_t *>(buf), s);
     return hipGetLastError();
 }
 
@@ -1676,7 +1746,8 @@ hipError_t launch_unpack_rows(uint64_t *counts, const uint32_t *ranges, const ui
 // ---------------------------------------------------------------------------
 constexpr int K3_SPLIT = 8; // blocks per row; each owns 8192 bins
 
-__global__ __launch_bounds__(256) void k_clear_spans(uint64_t *__restrict__ counts,
+template <typename CELL>
+__global__ __launch_bounds__(256) void k_clear_spans(CELL *__restrict__ counts,
                                                      const uint32_t *__restrict__ ranges)
 {
     const uint32_t m = blockIdx.x;
@@ -1684,23 +1755,42 @@ __global__ __launch_bounds__(256) void k_clear_spans(uint64_t *__restrict__ coun
     if (lo > hi) return;
     const uint32_t seg = LH_NKEYS / K3_SPLIT;
     const uint32_t a = max(lo, blockIdx.y * seg), b = min(hi, (blockIdx.y + 1) * seg - 1);
-    uint64_t *row = counts + (size_t)m * LH_ROW_STRIDE;
+    CELL *row = counts + (size_t)m * LH_ROW_STRIDE;
     for (uint32_t i = a + threadIdx.x; i <= b && i >= a; i += 256) row[i] = 0;
 }
 
 // Many names with narrow spans: one WAVE per row clears the span and resets the row's range (the block form above
 // launches 8 workgroups per row -- 524 288 of them at 65 536 names, 135 us of dispatch for 0.3 GB of stores -- and
 // needs k_init_ranges behind it).
-__global__ __launch_bounds__(256) void k_clear_rows_wave(uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
+template <typename CELL>
+__global__ __launch_bounds__(256) void k_clear_rows_wave(CELL *__restrict__ counts, uint32_t *__restrict__ ranges,
                                                          uint32_t nmetrics)
 {
     const uint32_t lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= nmetrics) return; // wave-uniform
     const uint32_t lo = ranges[2 * (size_t)m], hi = ranges[2 * (size_t)m + 1];
     if (lo > hi) return;       // nothing was counted and the range is already empty
-    uint64_t *row = counts + (size_t)m * LH_ROW_STRIDE;
+    CELL *row = counts + (size_t)m * LH_ROW_STRIDE;
     for (uint32_t i = lo + lane; i <= hi; i += 64) row[i] = 0;
     if (lane == 0) { ranges[2 * (size_t)m] = LH_NKEYS; ranges[2 * (size_t)m + 1] = 0; }
+}
+
+// A narrow epoch buffer about to hold 2^32 samples moves to uint64 cells (lh_engine.cc, widen_buffer): every row's
+// dirty span is copied into the wide store (zero outside the spans, like the narrow one) and zeroed behind the copy, so
+// that the narrow store is clean again for the buffer's next interval.  One wave per row; the ranges stay as they are.
+__global__ __launch_bounds__(256) void k_widen_rows(uint32_t *__restrict__ narrow, uint64_t *__restrict__ wide,
+                                                    const uint32_t *__restrict__ ranges, uint32_t nmetrics)
+{
+    const uint32_t lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= nmetrics) return; // wave-uniform
+    const uint32_t lo = ranges[2 * (size_t)m], hi = ranges[2 * (size_t)m + 1];
+    if (lo > hi) return;
+    uint32_t *src = narrow + (size_t)m * LH_ROW_STRIDE;
+    uint64_t *dst = wide + (size_t)m * LH_ROW_STRIDE;
+    for (uint32_t i = lo + lane; i <= hi; i += 64) {
+        dst[i] = src[i];
+        src[i] = 0;
+    }
 }
 
 __global__ void k_init_ranges(uint32_t *__restrict__ ranges, uint32_t nmetrics)
@@ -1722,12 +1812,23 @@ __global__ void k_mark_dirty(uint32_t *__restrict__ ranges, uint32_t first, uint
 hipError_t launch_clear(uint64_t *counts, uint32_t *ranges, uint32_t nmetrics, hipStream_t s)
 {
     if (nmetrics == 0) return hipSuccess;
+    const bool narrow = cells_narrow(counts);
+    uint32_t *c32 = reinterpret_cast<uint32_t *>(cells_base(counts));
     if (nmetrics >= 2048) {
-        hipLaunchKernelGGL(k_clear_rows_wave, dim3((nmetrics + 3) / 4), dim3(256), 0, s, counts, ranges, nmetrics);
+        if (narrow) hipLaunchKernelGGL(k_clear_rows_wave<uint32_t>, dim3((nmetrics + 3) / 4), dim3(256), 0, s, c32, ranges, nmetrics);
+        else hipLaunchKernelGGL(k_clear_rows_wave<uint64_t>, dim3((nmetrics + 3) / 4), dim3(256), 0, s, counts, ranges, nmetrics);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_clear_spans, dim3(nmetrics, K3_SPLIT), dim3(256), 0, s, counts, ranges);
+    if (narrow) hipLaunchKernelGGL(k_clear_spans<uint32_t>, dim3(nmetrics, K3_SPLIT), dim3(256), 0, s, c32, ranges);
+    else hipLaunchKernelGGL(k_clear_spans<uint64_t>, dim3(nmetrics, K3_SPLIT), dim3(256), 0, s, counts, ranges);
     hipLaunchKernelGGL(k_init_ranges, dim3((nmetrics + 255) / 256), dim3(256), 0, s, ranges, nmetrics);
+    return hipGetLastError();
+}
+
+hipError_t launch_widen_rows(uint32_t *narrow, uint64_t *wide, const uint32_t *ranges, uint32_t nmetrics, hipStream_t s)
+{
+    if (nmetrics == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_widen_rows, dim3((nmetrics + 3) / 4), dim3(256), 0, s, narrow, wide, ranges, nmetrics);
     return hipGetLastError();
 }
 

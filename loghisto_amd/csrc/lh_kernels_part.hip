@@ -570,8 +570,7 @@ __global__ __launch_bounds__(P1_BLOCK, HOT ? 4 : 6) void k_scatter_samples(const
             const uint32_t c = H.win[i];
             if (c) {
                 const uint32_t hs = i >> HOT_LOGW, b = H.org[hs] + (i & (HOT_W - 1));
-                atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)H.name[hs] * LH_ROW_STRIDE + b]),
-                          (unsigned long long)c);
+                lh::cell_add(counts, (size_t)H.name[hs] * LH_ROW_STRIDE + b, c);
                 atomicMin(&H.mn[hs], b);
                 atomicMax(&H.mx[hs], b);
             }
@@ -814,7 +813,7 @@ constexpr size_t P2_LDS_BYTES = (P2_WINWORDS + 3 * PART_MAX_MPP + 2 * OV_SLOTS) 
 __device__ __forceinline__ void p2_global_add(uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
                                               uint32_t m, uint32_t bin, uint64_t c)
 {
-    atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)m * LH_ROW_STRIDE + bin]), (unsigned long long)c);
+    lh::cell_add(counts, (size_t)m * LH_ROW_STRIDE + bin, c);
     uint32_t *r = ranges + 2 * (size_t)m;
     if (bin < r[0]) atomicMin(&r[0], bin);
     if (bin > r[1]) atomicMax(&r[1], bin);
@@ -965,8 +964,7 @@ __global__ __launch_bounds__(P2_BLOCK, 8) void k_part_hist(const uint32_t *__res
         const uint32_t c = h[i];
         const uint32_t l = i >> log_w, b = s_org[l] + (i & (W - 1));
         if (c)
-            atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)((l << log_nq) | p) * LH_ROW_STRIDE + b]),
-                      (unsigned long long)c);
+            lh::cell_add(counts, (size_t)((l << log_nq) | p) * LH_ROW_STRIDE + b, c);
         if (W >= 64u) {
             const unsigned long long occ = __builtin_amdgcn_ballot_w64(c != 0);
             if (occ != 0ull && (tid & 63u) == 0u) {

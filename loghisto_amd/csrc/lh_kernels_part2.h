@@ -448,7 +448,7 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__rest
 __device__ __forceinline__ void v2_global_add(uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
                                               uint32_t m, uint32_t bin, uint64_t c)
 {
-    atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)m * LH_ROW_STRIDE + bin]), (unsigned long long)c);
+    lh::cell_add(counts, (size_t)m * LH_ROW_STRIDE + bin, c);
     uint32_t *r = ranges + 2 * (size_t)m;
     if (bin < r[0]) atomicMin(&r[0], bin);
     if (bin > r[1]) atomicMax(&r[1], bin);
@@ -475,8 +475,7 @@ __device__ __forceinline__ void hidden_store_u32(void *p, uint32_t v)
 __device__ __forceinline__ void hidden_global_add(uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges, uint32_t m,
                                                   uint32_t bin, uint32_t c)
 {
-    const unsigned long long c64 = c;
-    asm volatile("global_atomic_add_x2 %0, %1, off" : : "v"(&counts[(size_t)m * LH_ROW_STRIDE + bin]), "v"(c64) : "memory");
+    lh::cell_add_hidden(counts, (size_t)m * LH_ROW_STRIDE + bin, c);
     uint32_t *r = ranges + 2 * (size_t)m;
     asm volatile("global_atomic_umin %0, %1, off\n\tglobal_atomic_umax %0, %1, off offset:4" : : "v"(r), "v"(bin) : "memory");
 }
@@ -803,8 +802,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_scatter2(const IDT *__restrict__ i
             const uint32_t c = win[base + i];
             if (c) {
                 const uint32_t b = org + i;
-                atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)name * LH_ROW_STRIDE + b]),
-                          (unsigned long long)c);
+                lh::cell_add(counts, (size_t)name * LH_ROW_STRIDE + b, c);
                 mn = min(mn, b);
                 mx = max(mx, b);
             }
@@ -1323,8 +1321,7 @@ __global__ __launch_bounds__(1024) void k_scatter_clustered(const IDT *__restric
             const uint32_t i = tid + j * BLOCK;
             k[j] = key[i];
             if (k[j] != OV_EMPTY) {
-                atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)(k[j] >> 16) * LH_ROW_STRIDE + (k[j] & 0xffffu)]),
-                          (unsigned long long)cnt[i]);
+                lh::cell_add(counts, (size_t)(k[j] >> 16) * LH_ROW_STRIDE + (k[j] & 0xffffu), cnt[i]);
                 key[i] = OV_EMPTY;
                 cnt[i] = 0;
                 mine++;
@@ -1486,8 +1483,7 @@ __global__ __launch_bounds__(1024) void k_hot_reduce(const uint32_t *__restrict_
                 sum += s_part[1][c] + s_part[2][c] + s_part[3][c];
                 if (sum) {
                     const uint32_t b = org + i;
-                    atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)name * LH_ROW_STRIDE + b]),
-                              (unsigned long long)sum);
+                    lh::cell_add(counts, (size_t)name * LH_ROW_STRIDE + b, sum);
                     mn = min(mn, b);
                     mx = max(mx, b);
                     hits += sum;
@@ -1652,8 +1648,7 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist2(const rec16_t *__restri
         const uint32_t c = h[i];
         const uint32_t l = i >> log_w, b = s_org[l] + (i & (W - 1));
         if (c)
-            atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)((l << log_np) | p) * LH_ROW_STRIDE + b]),
-                      (unsigned long long)c);
+            lh::cell_add(counts, (size_t)((l << log_np) | p) * LH_ROW_STRIDE + b, c);
         if (W >= 64u) {
             const unsigned long long occ = __builtin_amdgcn_ballot_w64(c != 0);
             if (occ != 0ull && (tid & 63u) == 0u) {

@@ -373,8 +373,7 @@ __global__ __launch_bounds__(256) void k_survey_remap(const SurveyStat S, const 
 __device__ __forceinline__ void v3_global_add(uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges, uint32_t m,
                                               uint32_t bin, uint32_t c)
 {
-    const unsigned long long c64 = c;
-    asm volatile("global_atomic_add_x2 %0, %1, off" : : "v"(&counts[(size_t)m * LH_ROW_STRIDE + bin]), "v"(c64) : "memory");
+    lh::cell_add_hidden(counts, (size_t)m * LH_ROW_STRIDE + bin, c);
     // The range: LOOK, then widen (an unconditional min / max pair per record serialises on the name's two words when a
     // whole stream takes this path: profiles/r06_first_call.txt).  The look is a load the compiler does not see either,
     // with its own wait -- which also waits for the tile loop's prefetch; this path is off the loop's fast path.
@@ -1044,8 +1043,7 @@ __global__ __launch_bounds__(1024, 4) void k_split_records(const uint32_t *__res
             const uint32_t c = win[(r << log_w) + i];
             if (c) {
                 const uint32_t b = org + i;
-                atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)name * LH_ROW_STRIDE + b]),
-                          (unsigned long long)c);
+                lh::cell_add(counts, (size_t)name * LH_ROW_STRIDE + b, c);
                 mn = min(mn, b);
                 mx = max(mx, b);
             }
@@ -1394,8 +1392,7 @@ __global__ __launch_bounds__(1024, 4) void k_split_waves(const uint32_t *__restr
             const uint32_t c = win[(r << log_w) + i];
             if (c) {
                 const uint32_t b = org + i;
-                atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)name * LH_ROW_STRIDE + b]),
-                          (unsigned long long)c);
+                lh::cell_add(counts, (size_t)name * LH_ROW_STRIDE + b, c);
                 mn = min(mn, b);
                 mx = max(mx, b);
             }
@@ -1612,8 +1609,7 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
             atomicMax(&s_mx[l], b + 63u - (uint32_t)__builtin_clzll(occ));
         }
         if (c)
-            atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)s_name[l] * LH_ROW_STRIDE + b]),
-                      (unsigned long long)c);
+            lh::cell_add(counts, (size_t)s_name[l] * LH_ROW_STRIDE + b, c);
     }
     for (uint32_t i = tid; i < OV_SLOTS; i += P2_BLOCK)
         if (ov_key[i] != OV_EMPTY) p2_global_add(counts, ranges, s_name[ov_key[i] >> 16], ov_key[i] & 0xffffu, ov_cnt[i]);

@@ -38,7 +38,7 @@ bool small_supported(size_t n, uint32_t nmetrics, Ids d_ids, const double *d_v)
 __device__ __forceinline__ void ks_global_add(uint64_t *__restrict__ counts, uint32_t *__restrict__ ranges,
                                               uint32_t m, uint32_t bin, uint64_t c)
 {
-    atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)m * LH_ROW_STRIDE + bin]), (unsigned long long)c);
+    lh::cell_add(counts, (size_t)m * LH_ROW_STRIDE + bin, c);
     uint32_t *r = ranges + 2 * (size_t)m;
     if (bin < r[0]) atomicMin(&r[0], bin);
     if (bin > r[1]) atomicMax(&r[1], bin);
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(KS_BLOCK) void k_ingest_pairs_small(const IDT *__re
         const uint32_t c = h[i];
         if (c) {
             const uint32_t l = i >> log_w, b = s_org[l] + (i & (W - 1));
-            atomicAdd(reinterpret_cast<unsigned long long *>(&counts[(size_t)l * LH_ROW_STRIDE + b]), (unsigned long long)c);
+            lh::cell_add(counts, (size_t)l * LH_ROW_STRIDE + b, c);
             atomicMin(&s_mn[l], b);
             atomicMax(&s_mx[l], b);
         }

@@ -6,6 +6,7 @@ Reference counterparts are cited on the C declarations in include/loghisto_gpu.h
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import numpy as np
@@ -237,6 +238,13 @@ class Snapshot:
         N.check(N.lib().lh_snapshot_rows(self._h, C.byref(p), C.byref(n)), "lh_snapshot_rows")
         return int(p.value), int(n.value)
 
+    def device_cells(self):
+        """(device pointer of row 0, nrows, cell_bytes): the cells as they are (lh_snapshot_cells) -- uint32 on an engine of
+        32-bit cells whose interval stayed below 2^32 samples; row r starts row_stride() * cell_bytes bytes after row r - 1."""
+        p, n, cb = C.c_void_p(0), C.c_uint32(0), C.c_uint32(0)
+        N.check(N.lib().lh_snapshot_cells(self._h, C.byref(p), C.byref(n), C.byref(cb)), "lh_snapshot_cells")
+        return int(p.value), int(n.value), int(cb.value)
+
     def device_ranges(self) -> int:
         p = C.c_void_p(0)
         N.check(N.lib().lh_snapshot_ranges(self._h, C.byref(p)), "lh_snapshot_ranges")
@@ -280,16 +288,27 @@ class Snapshot:
 
 class Engine:
     def __init__(self, device: int = 0, max_metrics: int = 1024, num_buffers: int = 2, num_lanes: int = 4,
-                 lane_samples: int = 1 << 20, max_counters: int = 1024):
+                 lane_samples: int = 1 << 20, max_counters: int = 1024, cell_bits: Optional[int] = None):
+        """cell_bits: 0 = the library's default (uint64 cells up to 8 192 names, uint32 above), 32, 64.  None reads the TEST
+        HARNESS's knobs -- this wrapper's, not the library's (liblhgpu.so never reads the environment): LH_TEST_CELL_BITS, and
+        LH_TEST_WIDEN_AT (LH_OPT_WIDEN_AT_SAMPLES), so that the whole GPU suite can be run on engines of 32-bit cells, and on
+        ones that move to uint64 cells in the middle of every test (tools/round.sh cells32)."""
         L = N.lib()
         cfg = N.LhConfig()
         N.check(L.lh_default_config(C.byref(cfg)), "lh_default_config")
         cfg.device, cfg.max_metrics, cfg.num_buffers = device, max_metrics, num_buffers
         cfg.num_lanes, cfg.lane_samples, cfg.max_counters = num_lanes, lane_samples, max_counters
+        widen_at = 0
+        if cell_bits is None:
+            cell_bits = int(os.environ.get("LH_TEST_CELL_BITS", "0"))
+            widen_at = int(os.environ.get("LH_TEST_WIDEN_AT", "0"))
+        cfg.cell_bits = cell_bits
         h = C.c_void_p(0)
         N.check(L.lh_create(C.byref(cfg), C.byref(h)), "lh_create")
         self._h = h
         self.max_metrics = max_metrics
+        if widen_at:
+            N.check(L.lh_set_option(h, N.OPT_WIDEN_AT_SAMPLES, widen_at), "lh_set_option")
 
     # -- names -------------------------------------------------------------
     def intern(self, name: str) -> int:

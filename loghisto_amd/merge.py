@@ -222,6 +222,13 @@ class _DeviceArray:
                                          "version": 3, "strides": None}
 
 
+def snapshot_ranges(snap, nrows: int, device: Optional[int] = None):
+    """ranges int32[nrows,2] aliasing the snapshot's HBM (the rows are not touched: on an engine of 32-bit cells
+    snapshot_tensors moves the snapshot to its uint64 store first, lh_snapshot_rows)."""
+    dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+    return torch.as_tensor(_DeviceArray(snap.device_ranges(), (nrows, 2), "<i4"), device=dev)
+
+
 def snapshot_tensors(snap, nrows: Optional[int] = None, device: Optional[int] = None):
     """(rows int64[nrows,65536] -- a view with row stride lh_row_stride() --, ranges int32[nrows,2]) aliasing the snapshot's HBM."""
     ptr, total = snap.device_rows()
@@ -230,8 +237,7 @@ def snapshot_tensors(snap, nrows: Optional[int] = None, device: Optional[int] = 
     stride = snap.row_stride()
     flat = torch.as_tensor(_DeviceArray(ptr, ((nrows - 1) * stride + NKEYS,), "<i8"), device=dev)
     rows = torch.as_strided(flat, (nrows, NKEYS), (stride, 1))
-    ranges = torch.as_tensor(_DeviceArray(snap.device_ranges(), (nrows, 2), "<i4"), device=dev)
-    return rows, ranges
+    return rows, snapshot_ranges(snap, nrows, device)
 
 
 def merge_snapshot(snap, nrows: int, plan: str = "allreduce", group=None) -> Tuple[int, int]:

@@ -139,7 +139,7 @@ def main():
         assert info["occupied_rows"] == int((want_ranges[:, 0] <= want_ranges[:, 1]).sum())
         # merged ranges: identical on every rank, for every row
         torch.cuda.synchronize()
-        got_ranges = merge.snapshot_tensors(snap, M)[1].cpu().numpy().view(np.uint32)
+        got_ranges = merge.snapshot_ranges(snap, M).cpu().numpy().view(np.uint32)
         assert np.array_equal(got_ranges.astype(np.int64), want_ranges), r
         if last > first:
             off, keys, counts = snap.buckets_all(last - first, first=first)

@@ -48,20 +48,20 @@ def test_the_public_header_keeps_only_the_operational_options():
 
 
 def test_abi_version_and_strerror(native_lib):
-    assert native_lib.lh_abi_version() == 6
+    assert native_lib.lh_abi_version() == 7
     msgs = {native_lib.lh_strerror(c).decode() for c in range(8)}
     assert len(msgs) == 8 and "ok" in msgs
 
 
 def test_struct_layouts_match_header(native_lib):
     from loghisto_amd import _native
-    assert C.sizeof(_native.LhConfig) == 32
+    assert C.sizeof(_native.LhConfig) == 40
     assert C.sizeof(_native.LhStats) == 40
-    assert C.sizeof(_native.LhLineFormat) == 32 and C.sizeof(_native.LhCounters) == 216
+    assert C.sizeof(_native.LhLineFormat) == 32 and C.sizeof(_native.LhCounters) == 232
     assert C.sizeof(_native.LhMergeInfo) == 88 and C.sizeof(_native.LhExtractView) == 48
     cfg = _native.LhConfig()
     assert native_lib.lh_default_config(C.byref(cfg)) == 0
-    assert cfg.struct_size == 32 and cfg.max_metrics >= 1 and cfg.num_buffers >= 2
+    assert cfg.struct_size == 40 and cfg.max_metrics >= 1 and cfg.num_buffers >= 2 and cfg.cell_bits == 0
 
 
 def test_argument_validation_needs_no_gpu(native_lib):
@@ -72,6 +72,11 @@ def test_argument_validation_needs_no_gpu(native_lib):
     assert native_lib.lh_create(None, C.byref(h)) == _native.EINVAL
     cfg.num_buffers = 1
     assert native_lib.lh_create(C.byref(cfg), C.byref(h)) == _native.EINVAL
+    cfg.num_buffers, cfg.cell_bits = 2, 16  # (ABI 7) 0, 32 or 64
+    assert native_lib.lh_create(C.byref(cfg), C.byref(h)) == _native.EINVAL
+    cfg.cell_bits, cfg.struct_size = 0, 36  # the ABI-6 struct (32 bytes) and this one are the sizes there are
+    assert native_lib.lh_create(C.byref(cfg), C.byref(h)) == _native.EINVAL
+    assert native_lib.lh_snapshot_cells(None, None, None, None) == _native.EINVAL and native_lib.lh_cell_bytes(None) == _native.EINVAL
     assert native_lib.lh_flush(None) == _native.EINVAL
     assert native_lib.lh_release(None) == _native.EINVAL
     # K6 entry points

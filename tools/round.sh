@@ -5,6 +5,7 @@
 #   gpurun --timeout 1500 -- 'bash tools/round.sh <sub-command> [tag] [args...]'
 #
 #   tests <tag> [pytest args]   the GPU suite (or a part of it) + smoke()
+#   cells32 <tag>               the GPU suite on engines of 32-bit cells, and on ones that widen in the middle of every test
 #   profile <tag>               the round's evidence (tools/profile_round.sh: bench lines, kernel traces, PMC passes;
 #                               written to gpurun_out/round/)
 #   ab <tag> <suffix,...>       mixed-ingest A/B on ONE box: config 4's slice and the 1e9-pair call (65 536 names) and
@@ -60,6 +61,17 @@ tests)
     ;;
 profile)
     bash tools/profile_round.sh
+    ;;
+cells32)
+    # the GPU suite on engines of 32-bit cells at EVERY name count, and on ones that move to uint64 cells in the middle of every
+    # test (the knobs are the Python test wrapper's, loghisto_amd/engine.py; the library reads no environment).  Not in the
+    # second run: four 65 536-name engines on one GPU, each with a wide store beside its narrow ones, do not fit 288 GB.
+    (LH_TEST_CELL_BITS=32 timeout 1200 python -m pytest tests -m gpu -q) > $OUT/bits32.log 2>&1
+    echo "LH_TEST_CELL_BITS=32: $(tail -1 $OUT/bits32.log)" | tee $OUT/summary.txt
+    (LH_TEST_CELL_BITS=32 LH_TEST_WIDEN_AT=200000 timeout 1200 python -m pytest tests -m gpu -q \
+        --deselect "tests/test_gpu_bench_ranks.py::test_c4_step_with_ranks_as_threads[4-65536]") > $OUT/widen.log 2>&1
+    echo "LH_TEST_CELL_BITS=32 LH_TEST_WIDEN_AT=200000: $(tail -1 $OUT/widen.log)" | tee -a $OUT/summary.txt
+    grep -hE "^(FAILED|ERROR)" $OUT/bits32.log $OUT/widen.log | cut -c1-250 | tee -a $OUT/summary.txt
     ;;
 ab)
     for sfx in "" $(echo ${1:-} | tr ',' ' '); do
