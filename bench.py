@@ -924,8 +924,11 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=Non
     if info.get("packed_cells") and t_k2:
         # K2's roofline: every cell of every owned row's window read once (8 B x row_len per metric);
         # after a reduce-scatter the owned rows' windows are packed_cells / ranks on average
+        # (ABI 7: above 8 192 names the store's cells are uint32 -- the bytes K2 has to read are the store's, not the reference's 8)
         owned_cells = info["packed_cells"] / world
-        res["extract_roofline"] = roofline(8.0 * owned_cells, sum(t_k2) / len(t_k2),
+        cell_b = float(N.lib().lh_cell_bytes(eng._h))
+        res["store_cell_bytes"] = int(cell_b)
+        res["extract_roofline"] = roofline(cell_b * owned_cells, sum(t_k2) / len(t_k2),
                                            "k_extract_wave over the owned rows + the device-to-host copy of the results "
                                            "(139 B per name) behind it: HIP events on the snapshot's stream around "
                                            "lh_extract_rows_view (the pipelined steps' form; the compact form's latency is "
@@ -935,7 +938,7 @@ def run_c4(args, la, stream, rank, world, dist, steps, warmup, comm_override=Non
             # the two parts apart (lh_tool_last_extract_ms: HIP events inside lh_extract_rows_view): K2's own roofline is
             # the kernel's; the copy is 139 B per name over PCIe
             kms, cms = sum(t_k2k) / len(t_k2k), sum(t_k2c) / len(t_k2c)
-            res["extract_roofline"].update(kernel_ms=kms, copy_ms=cms, kernel_frac=8.0 * owned_cells / (kms * 1e-3) / 8e12,
+            res["extract_roofline"].update(kernel_ms=kms, copy_ms=cms, kernel_frac=cell_b * owned_cells / (kms * 1e-3) / 8e12,
                                            copy_GBps=139.0 * (last - first) / (cms * 1e-3) / 1e9 if cms > 0 else None)
     if plan8:
         res["merge"]["simulated_plan"] = plan8

@@ -68,6 +68,11 @@ struct EpochBuffer {
     uint32_t *store32 = nullptr;
     uint64_t *store64 = nullptr;
     uint64_t reserved = 0;       // narrow store: samples of the launches enqueued or about to be (atomic builtins)
+    // A buffer whose intervals keep passing 2^32 samples stays on its wide store and gives the narrow one back (lh_release:
+    // after kStayWide consecutive intervals widened by their ingest), so that a high-rate engine holds what a 64-bit engine
+    // holds, not both stores; kBackToNarrow consecutive intervals below 2^31 samples bring the narrow store back.
+    bool ingest_widened = false; // this interval's ingest moved the buffer to its wide store (widen_buffer, quiesce)
+    uint32_t wide_streak = 0, quiet_streak = 0;
     uint32_t *ranges = nullptr;  // [max_metrics][2]
     uint64_t *ccur = nullptr;    // [max_counters] the interval's counter amounts (metrics.go:425-433)
     uint32_t *cflag = nullptr;   // [max_counters] touched this interval
@@ -386,6 +391,7 @@ int widen_buffer(lh_engine *e, EpochBuffer &b, hipStream_t st, bool quiesce)
     }
     HIPCHK(lh::launch_widen_rows(b.store32, b.store64, b.ranges, (uint32_t)M, st));
     if (quiesce) HIPCHK(hipStreamSynchronize(st));
+    if (quiesce) b.ingest_widened = true;
     b.counts = b.store64;
     e->c_widenings.fetch_add(1, std::memory_order_relaxed);
     return LH_OK;
@@ -2624,6 +2630,51 @@ int lh_snapshot_stream(lh_snapshot *s, void **stream)
     return LH_OK;
 }
 
+namespace {
+// lh_release, narrow engines, behind the clear (xmu held): the store the buffer's next interval starts on.  Normally the
+// narrow one again -- the widening left it clean, the wide store is clean behind the clear and kept for the next time.  A
+// buffer whose ingest passed 2^32 samples in kStayWide consecutive intervals stays on the wide store and FREES the narrow
+// one: at such rates the narrow store only ever holds the first milliseconds of an interval, and keeping both would cost
+// 1.5 x what a 64-bit engine holds.  kBackToNarrow consecutive intervals below 2^31 samples bring it back (and free the
+// wide store).  hipFree waits for the device: these are transitions, not per-interval work.
+constexpr uint32_t kStayWide = 2, kBackToNarrow = 16;
+int next_interval_width(lh_engine *e, EpochBuffer &b)
+{
+    const size_t M = e->cfg.max_metrics;
+    if (b.store32) {
+        b.wide_streak = b.ingest_widened ? b.wide_streak + 1 : 0;
+        if (b.wide_streak >= kStayWide && !lh::cells_narrow(b.counts)) {
+            HIPCHK(hipFree(b.store32));
+            b.store32 = nullptr;
+            b.quiet_streak = 0;
+            return LH_OK; // b.counts stays the wide store
+        }
+        b.counts = lh::cells_tagged(b.store32, 4);
+        return LH_OK;
+    }
+    const uint64_t ns = __atomic_load_n(&b.nsamples, __ATOMIC_RELAXED);
+    b.quiet_streak = ns <= e->widen_at / 2 ? b.quiet_streak + 1 : 0; // (half the bound: 2^31 samples)
+    if (b.quiet_streak < kBackToNarrow) return LH_OK;
+    b.quiet_streak = 0;
+    uint32_t *p = nullptr;
+    if (hipMalloc((void **)&p, M * LH_ROW_STRIDE * sizeof(uint32_t)) != hipSuccess) {
+        (void)hipGetLastError();
+        return LH_OK; // stays wide: nothing is lost
+    }
+    hipError_t me = hipMemsetAsync(p, 0, M * LH_ROW_STRIDE * sizeof(uint32_t), e->xstream);
+    if (me != hipSuccess) {
+        (void)hipFree(p);
+        HIPCHK(me);
+    }
+    HIPCHK(hipFree(b.store64)); // (waits for the clear that was just enqueued)
+    b.store64 = nullptr;
+    b.store32 = p;
+    b.wide_streak = 0;
+    b.counts = lh::cells_tagged(p, 4);
+    return LH_OK;
+}
+} // namespace
+
 int lh_release(lh_snapshot *s)
 {
     if (!s) return LH_EINVAL;
@@ -2648,9 +2699,7 @@ int lh_release(lh_snapshot *s)
         // them (metrics.go:435-458): a snapshot released before any counter call still folds
         keep(fold_counters(s));
         hip(lh::launch_clear(b.counts, b.ranges, e->cfg.max_metrics, e->xstream));
-        // a widened buffer starts its next interval on its narrow store again (left clean by the widening; the wide store
-        // is clean behind this clear and kept for the next time)
-        if (e->narrow) b.counts = lh::cells_tagged(b.store32, 4);
+        if (e->narrow) keep(next_interval_width(e, b));
         if (e->cfg.max_counters) {
             hip(hipMemsetAsync(b.ccur, 0, (size_t)e->cfg.max_counters * sizeof(uint64_t), e->xstream));
             hip(hipMemsetAsync(b.cflag, 0, (size_t)e->cfg.max_counters * sizeof(uint32_t), e->xstream));
@@ -2658,6 +2707,7 @@ int lh_release(lh_snapshot *s)
         hip(hipEventRecord(b.cleared, e->xstream));
         __atomic_store_n(&b.nsamples, 0, __ATOMIC_RELAXED);
         __atomic_store_n(&b.reserved, 0, __ATOMIC_RELAXED);
+        b.ingest_widened = false;
     }
     {
         std::unique_lock<std::shared_mutex> eg(e->epoch_mu);

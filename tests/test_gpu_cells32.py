@@ -64,8 +64,40 @@ def test_every_path_is_exact_on_32_bit_cells_and_across_the_move(native_lib, tor
                 want_one = oracle.histogram_dense(all_v[all_ids == ids[0]])
                 assert np.array_equal(snap.dense_row(int(ids[0])), want_one) and int(got_one[1].sum()) == int(want_one.sum())
         c = e.counters()
-        # the first move allocated the buffer's wide store, the later ones reuse it (two buffers alternate: each moved at least once)
-        assert c["store_bytes"] == M * N.lib().lh_row_stride() * (4 + 4 + 8 + 8)
+        # two buffers alternate.  Buffer 0 (intervals 0, 2, 4) moved once: it holds both stores.  Buffer 1 (intervals 1, 3) moved in
+        # two consecutive intervals: it stays on its wide store and has given the narrow one back (next test).
+        assert c["store_bytes"] == M * N.lib().lh_row_stride() * (4 + 8 + 8)
+
+
+def test_a_buffer_that_keeps_passing_the_bound_stays_wide_and_comes_back(native_lib, torch_cuda):
+    """At rates where every interval passes 2^32 samples the narrow store only ever holds an interval's first milliseconds: after
+    two such intervals in a row a buffer stays on its wide store and frees the narrow one (the engine then holds what a 64-bit
+    engine holds, not 1.5 x that); sixteen intervals in a row below 2^31 samples bring the narrow store back.  Exact throughout."""
+    import loghisto_amd
+    M, n = 9000, 300_000
+    rng = np.random.default_rng(11)
+    ids = _ids(rng, M, n, 1.0)
+    v = _values(rng, "lognormal", ids, n)
+    d_ids, d_v = _dev(torch_cuda, ids), _dev(torch_cuda, v)
+    unit = M * N.lib().lh_row_stride()
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16, cell_bits=0) as e:
+        def interval(check_it=False):
+            e.submit_pairs_device(d_ids, d_v)
+            e.submit_pairs_device(d_ids, d_v)
+            with e.flip() as snap:
+                cb = snap.device_cells()[2]
+                if check_it:
+                    check(snap, np.concatenate([ids, ids]), np.concatenate([v, v]), M, snap.extract(PCTS, M))
+            return cb
+        assert e.counters()["store_bytes"] == unit * 8                                   # 4 + 4
+        e.set_option(N.OPT_WIDEN_AT_SAMPLES, n + 1)                                      # every interval passes the bound
+        assert [interval(i == 3) for i in range(4)] == [8, 8, 8, 8]                      # (both buffers, twice each)
+        assert e.counters()["widenings"] == 4 and e.counters()["store_bytes"] == unit * 16   # 8 + 8: the narrow stores are gone
+        assert [interval(i == 1) for i in range(4)] == [8, 8, 8, 8] and e.counters()["widenings"] == 4   # nothing left to move
+        e.set_option(N.OPT_WIDEN_AT_SAMPLES, 0xffffffff)
+        got = [interval(i in (29, 33)) for i in range(36)]                               # sixteen quiet intervals per buffer
+        assert got[:32] == [8] * 32 and got[32:] == [4] * 4, got
+        assert e.counters()["store_bytes"] == unit * 8 and e.counters()["widenings"] == 4
 
 
 def test_one_cell_beyond_two_to_the_32(native_lib, torch_cuda):
@@ -75,7 +107,7 @@ def test_one_cell_beyond_two_to_the_32(native_lib, torch_cuda):
     torch = torch_cuda
     n = 1 << 28
     d_v = torch.full((n,), 123.0, dtype=torch.float64, device="cuda")
-    with loghisto_amd.Engine(max_metrics=9000, num_buffers=2, num_lanes=1, lane_samples=1 << 12, max_counters=0) as e:
+    with loghisto_amd.Engine(max_metrics=9000, num_buffers=2, num_lanes=1, lane_samples=1 << 12, max_counters=0, cell_bits=0) as e:
         assert _cell_bytes(e) == 4
         for _ in range(17):
             e.submit_device(4242, d_v)
@@ -104,7 +136,7 @@ def test_row_view_and_cell_view(native_lib, torch_cuda):
     rng = np.random.default_rng(5)
     ids = _ids(rng, M, n, 1.0)
     v = _values(rng, "lognormal", ids, n)
-    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16, cell_bits=0) as e:
         e.submit_pairs_device(_dev(torch, ids), _dev(torch, v))
         with e.flip() as snap:
             ptr, nrows, cb = snap.device_cells()
@@ -151,7 +183,7 @@ def test_merge_on_uint64_words_widens_the_snapshot_first(native_lib, torch_cuda)
         rng = np.random.default_rng(6)
         ids = _ids(rng, M, n, 1.0)
         v = _values(rng, "signed", ids, n)
-        with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+        with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16, cell_bits=0) as e:
             for widen in (False, True):
                 e.submit_pairs_device(_dev(torch, ids), _dev(torch, v))
                 with e.flip() as snap:
