@@ -197,3 +197,48 @@ def test_merge_on_uint64_words_widens_the_snapshot_first(native_lib, torch_cuda)
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+def test_concurrent_submitters_across_the_move(native_lib, torch_cuda):
+    """Eight host threads submit through their lanes while a ninth submits device-resident pairs; the bound falls in the middle of
+    the interval, so one of them moves the buffer while the others are enqueueing (cells_mu: a step holds the cells shared from
+    reading the pointer until its launches are enqueued, the move holds them unique behind a device synchronisation)."""
+    import threading
+    import loghisto_amd
+    M, per, T = 12000, 400_000, 8
+    rng = np.random.default_rng(21)
+    parts = []
+    for t in range(T + 1):
+        ids = _ids(rng, M, per, 1.0)
+        parts.append((ids, _values(rng, "lognormal", ids, per)))
+    d_ids, d_v = _dev(torch_cuda, parts[T][0]), _dev(torch_cuda, parts[T][1])
+    with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=4, lane_samples=1 << 15, cell_bits=0) as e:
+        for interval in range(3):
+            e.set_option(N.OPT_WIDEN_AT_SAMPLES, [per * 4, 0xffffffff, per * 2][interval])
+            errs = []
+
+            def host(t):
+                try:
+                    ids, v = parts[t]
+                    for k in range(0, per, 50_000):
+                        e.submit_pairs(ids[k:k + 50_000], v[k:k + 50_000])
+                except Exception as ex:  # noqa: BLE001
+                    errs.append(ex)
+
+            def dev():
+                try:
+                    for k in range(0, per, 100_000):
+                        e.submit_pairs_device(d_ids[k:k + 100_000], d_v[k:k + 100_000])
+                except Exception as ex:  # noqa: BLE001
+                    errs.append(ex)
+
+            th = [threading.Thread(target=host, args=(t,)) for t in range(T)] + [threading.Thread(target=dev)]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            assert not errs, errs
+            with e.flip() as snap:
+                assert snap.device_cells()[2] == (4 if interval == 1 else 8)
+                check(snap, np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]), M, snap.extract(PCTS, M))
+        assert e.counters()["widenings"] == 2
