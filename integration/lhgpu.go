@@ -60,6 +60,8 @@ func newGPUEngine(maxMetrics int) *gpuEngine {
 	C.lh_default_config(&cfg)
 	cfg.max_metrics = C.uint32_t(maxMetrics)
 	cfg.num_lanes = C.uint32_t(runtime.GOMAXPROCS(0)) // concurrent ship() calls: at most one per P
+	// cfg.cell_bits stays 0 (ABI 7): uint64 cells up to 8 192 names, uint32 above -- exact either way (the engine moves an
+	// epoch buffer to uint64 cells before its interval could hold 2^32 samples); 64 pins the reference's cell width
 	g := &gpuEngine{ids: make(map[string]uint32), narrow: maxMetrics <= 65536}
 	if rc := C.lh_create(&cfg, &g.e); rc != C.LH_OK {
 		glog.Errorf("lh_create: %s (%s)", C.GoString(C.lh_strerror(rc)), C.GoString(C.lh_last_error()))

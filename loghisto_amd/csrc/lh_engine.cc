@@ -168,7 +168,7 @@ struct lh_engine {
     std::shared_mutex cells_mu;
     bool narrow = false;                    // the epoch buffers start every interval on uint32 cells
     uint64_t widen_at = 0xffffffffull;      // LH_OPT_WIDEN_AT_SAMPLES (tests): a narrow buffer holds at most this many samples
-    std::atomic<uint64_t> c_widenings{0};
+    std::atomic<uint64_t> c_widenings{0}, c_store_bytes{0}; // (store bytes: kept where a store is allocated or freed)
 
     std::mutex streams_mu;
     std::vector<hipStream_t> epoch_streams; // streams that touched the current epoch buffer
@@ -388,6 +388,7 @@ int widen_buffer(lh_engine *e, EpochBuffer &b, hipStream_t st, bool quiesce)
             b.store64 = nullptr;
             HIPCHK(me);
         }
+        e->c_store_bytes.fetch_add(M * LH_ROW_STRIDE * sizeof(uint64_t), std::memory_order_relaxed);
     }
     HIPCHK(lh::launch_widen_rows(b.store32, b.store64, b.ranges, (uint32_t)M, st));
     if (quiesce) HIPCHK(hipStreamSynchronize(st));
@@ -1064,10 +1065,12 @@ int create_impl(const lh_config *cfg_in, lh_engine *e)
         if (e->narrow) {
             HIPCHK(hipMalloc((void **)&b.store32, M * LH_ROW_STRIDE * sizeof(uint32_t)));
             HIPCHK(hipMemsetAsync(b.store32, 0, M * LH_ROW_STRIDE * sizeof(uint32_t), e->xstream));
+            e->c_store_bytes.fetch_add(M * LH_ROW_STRIDE * sizeof(uint32_t), std::memory_order_relaxed);
             b.counts = lh::cells_tagged(b.store32, 4);
         } else {
             HIPCHK(hipMalloc((void **)&b.store64, M * LH_ROW_STRIDE * sizeof(uint64_t)));
             HIPCHK(hipMemsetAsync(b.store64, 0, M * LH_ROW_STRIDE * sizeof(uint64_t), e->xstream));
+            e->c_store_bytes.fetch_add(M * LH_ROW_STRIDE * sizeof(uint64_t), std::memory_order_relaxed);
             b.counts = b.store64;
         }
         HIPCHK(hipMalloc((void **)&b.ranges, M * 2 * sizeof(uint32_t)));
@@ -2646,6 +2649,7 @@ int next_interval_width(lh_engine *e, EpochBuffer &b)
         if (b.wide_streak >= kStayWide && !lh::cells_narrow(b.counts)) {
             HIPCHK(hipFree(b.store32));
             b.store32 = nullptr;
+            e->c_store_bytes.fetch_sub(M * LH_ROW_STRIDE * sizeof(uint32_t), std::memory_order_relaxed);
             b.quiet_streak = 0;
             return LH_OK; // b.counts stays the wide store
         }
@@ -2669,6 +2673,8 @@ int next_interval_width(lh_engine *e, EpochBuffer &b)
     HIPCHK(hipFree(b.store64)); // (waits for the clear that was just enqueued)
     b.store64 = nullptr;
     b.store32 = p;
+    e->c_store_bytes.fetch_add(M * LH_ROW_STRIDE * sizeof(uint32_t), std::memory_order_relaxed);
+    e->c_store_bytes.fetch_sub(M * LH_ROW_STRIDE * sizeof(uint64_t), std::memory_order_relaxed);
     b.wide_streak = 0;
     b.counts = lh::cells_tagged(p, 4);
     return LH_OK;
@@ -2742,14 +2748,7 @@ int lh_get_counters(lh_engine *e, lh_counters *out)
         out->lane_scratch_bytes = lane;
     }
     out->widenings = e->c_widenings.load();
-    {
-        std::shared_lock<std::shared_mutex> cg(e->cells_mu);
-        std::lock_guard<std::mutex> xg(e->xmu); // (a snapshot's buffer is widened under xmu)
-        uint64_t sb = 0;
-        for (const EpochBuffer &b : e->bufs)
-            sb += (uint64_t)e->cfg.max_metrics * LH_ROW_STRIDE * ((b.store32 ? 4u : 0u) + (b.store64 ? 8u : 0u));
-        out->store_bytes = sb;
-    }
+    out->store_bytes = e->c_store_bytes.load();
     out->sublaunches = e->c_sublaunches.load();
     out->samples_partitioned_v2 = e->c_part2.load();
     out->counter_events = e->c_counts.load();
