@@ -26,7 +26,7 @@
 //                                 most frequent of its 256 names get LDS windows here (96 KiB) and their records end
 //                                 in this pass (under Zipf(1) they are ~70 % of the partition's records); the rest is
 //                                 split into ns fine partitions through LDS regions, exactly like level 1
-//   reduce   k_part_hist3         one workgroup per fine-partition work slot: mpp2 names x W bins of uint32 windows
+//   reduce   k_part_hist3         one workgroup per fine-partition work slot: mpp2 names x W bins of windows (16-bit cells, two slots per CU)
 //                                 (128 KiB), windows placed from the slot's own first chunk and the survey
 //
 // Window width W (1 024 .. 8 192 bins, names per fine partition 32 .. 4) follows the stream: the survey reports
@@ -64,7 +64,28 @@ constexpr uint32_t V3_EXTRA1 = 768;                     // level-1 work slots be
 constexpr uint32_t V3_EXTRA2 = 1024;                    // fine work slots beyond one per fine partition
 constexpr uint32_t V3_MAX_NS = 64;                      // fine partitions per level-1 partition (at most)
 constexpr uint32_t PEEL_WORDS = 24576;                  // level 2: 96 KiB of windows for the partition's top names
-constexpr uint32_t P3_WINWORDS = 32768;                 // reduce: 128 KiB of windows
+constexpr uint32_t P3_WINWORDS = 32768;                 // reduce: 32 768 window cells per slot
+// The reduce pass keeps its window cells as 16-bit fields, two to an LDS word (as level 1's hot windows do): 64 KiB per slot
+// instead of 128, so that TWO workgroups share a CU and one slot's chain of dependent loads (slot -> chunk list -> records)
+// and its flush run beside the other's -- config 4's slice has 2 167 slots, 8.5 per CU one after another, ~23 us each of
+// which most is waiting.  An add that takes a field across a multiple of 2^14 hands 2^14 counts on to the row in HBM
+// (add_one below); the chunk loop runs in rounds that end at a barrier, which bounds what a field can hold.
+#ifndef LH_P3_PACKED
+#define LH_P3_PACKED 1
+#endif
+constexpr uint32_t P3_PACK = LH_P3_PACKED ? 1u : 0u;    // log2 cells per LDS word
+#ifndef LH_P3_SPILL_LOG
+#define LH_P3_SPILL_LOG 14u /* an add that takes its field across a multiple of 2^14 hands 2^14 counts on to the row.  Any value
+                               from 6 (an add carries at most 64) to 15 is exact; tools/round.sh p3spill runs the third
+                               generation's suites on a build with 6, where every busy cell of every slot takes the hand-off
+                               path many times over */
+#endif
+static_assert(LH_P3_SPILL_LOG >= 6u && LH_P3_SPILL_LOG <= 15u, "c <= 64 per add; (2^log - 1) + 2^15 counts of a round must fit 16 bits");
+constexpr uint32_t P3_SPILL = 1u << LH_P3_SPILL_LOG;
+#ifndef LH_P3_DEPTH
+#define LH_P3_DEPTH (LH_P3_PACKED ? 1 : 2)              /* chunks in flight per wave */
+#endif
+static_assert(!LH_P3_PACKED || LH_P3_DEPTH == 1, "a round is ONE chunk per wave");
 constexpr uint32_t SPLIT_TILE = 8192;                   // records per level-2 tile
 constexpr uint32_t SPLIT_REG_WORDS = 12800;             // level 2: LDS regions (>= 5/4 tile + 28 per fine partition)
 
@@ -1416,9 +1437,11 @@ __global__ __launch_bounds__(1024, 4) void k_split_waves(const uint32_t *__restr
 // Reduce: one workgroup per fine-partition work slot.  Fine partition q = fine << 8 | p1 holds the names of ranks
 // fine * mpp2 .. + mpp2 - 1 of level-1 partition p1; record = fine << 24 | rank % mpp2 << 16 | bin.
 // ---------------------------------------------------------------------------
-constexpr size_t P3_LDS_BYTES = (P3_WINWORDS + 6 * 32 + 2 * OV_SLOTS + 2) * sizeof(uint32_t) + 16;
+constexpr uint32_t P3_LDSWORDS = P3_WINWORDS >> P3_PACK;
+constexpr size_t P3_LDS_BYTES = (P3_LDSWORDS + 6 * 32 + 2 * OV_SLOTS + 2) * sizeof(uint32_t) + 16;
+static_assert(!LH_P3_PACKED || 2 * (P3_LDS_BYTES + 1024) <= 160 * 1024, "two slots per CU");
 
-__global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restrict__ records,
+__global__ __launch_bounds__(P2_BLOCK, LH_P3_PACKED ? 8 : 4) void k_part_hist3(const uint32_t *__restrict__ records,
                                                          const uint32_t *__restrict__ cdesc,
                                                          const uint32_t *__restrict__ sorted,
                                                          const uint32_t *__restrict__ part_start,
@@ -1432,7 +1455,7 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *h = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *s_org = h + P3_WINWORDS, *s_mn = s_org + 32, *s_mx = s_mn + 32, *s_name = s_mx + 32, *s_svc = s_name + 32,
+    uint32_t *s_org = h + P3_LDSWORDS, *s_mn = s_org + 32, *s_mx = s_mn + 32, *s_name = s_mx + 32, *s_svc = s_name + 32,
              *s_svm = s_svc + 32;
     uint32_t *ov_key = s_svm + 32, *ov_cnt = ov_key + OV_SLOTS;
     uint32_t *s_all = ov_cnt + OV_SLOTS; // [2]: lowest and highest bin of the slot's first chunk, whatever the name
@@ -1454,7 +1477,9 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
 #pragma unroll
         for (uint32_t k = 0; k < CHUNK / 256; k++) dst[k] = __builtin_nontemporal_load(src + k * 64);
     };
-    constexpr uint32_t WSTEP = P2_BLOCK / 64, DEPTH = 2;
+    // (two workgroups per CU: 32 waves with ONE chunk each in flight are the 128 KiB per CU that 16 waves with two were, in
+    // half the registers -- the kernel has 64 per thread)
+    constexpr uint32_t WSTEP = P2_BLOCK / 64, DEPTH = LH_P3_DEPTH;
     u4_t buf[DEPTH][CHUNK / 256];
     const uint32_t mine = cnt > wave ? (cnt - wave + WSTEP - 1) / WSTEP : 0u; // chunks of this wave: wave, wave + 16, ..
     uint32_t nb = min(mine, 64u), my_cid = 0, my_cn = 0;
@@ -1476,7 +1501,7 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
     for (uint32_t d = 0; d < DEPTH; d++) // (unconditional: a wave without chunks reads chunk 0 and ignores it)
         load_chunk(__builtin_amdgcn_readlane(my_cid, min(d, max(nb, 1u) - 1u)), buf[d]);
     const uint32_t srec = tid < n0 ? srec0 : 0u;
-    for (uint32_t i = tid; i < words; i += P2_BLOCK) h[i] = 0;
+    for (uint32_t i = tid; i < (words >> P3_PACK); i += P2_BLOCK) h[i] = 0;
     ov_init(ov_key, ov_cnt, tid, P2_BLOCK);
     if (tid < mpp2) {
         s_name[tid] = nm < nmetrics ? nm : INVALID;
@@ -1527,45 +1552,77 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
     __syncthreads();
 
     uint32_t nmiss = 0; // records outside their window (self-metric)
-    auto add_one = [&](uint32_t rec, uint32_t c) {
+    // add_one returns true when the add took a packed field across a multiple of P3_SPILL (spill_one must follow, in the same
+    // round).  The add returns the word as it was; the lane whose add crosses takes P3_SPILL off the field again and adds
+    // them to the row in HBM.  With P pending hand-offs a field holds floor(field / P3_SPILL) == P at every instant (an add
+    // that changes the quotient raises P, a hand-off lowers both), so once a round's hand-offs are done -- at the round's
+    // barrier -- the field is below P3_SPILL; within a round it grows by at most 2^15.  It never carries into its neighbour,
+    // and every count is in exactly one place: exact for any slot, any stream.
+    auto add_one = [&](uint32_t rec, uint32_t c) -> bool {
         const uint32_t l = (rec >> 16) & 0xffu, b = rec & 0xffffu;
         const uint32_t rel = b - s_org[l];
-        if (rel < W) atomicAdd(&h[(l << log_w) + rel], c);
-        else {
+        if (rel < W) {
+            const uint32_t i = (l << log_w) + rel;
+            if (P3_PACK) {
+                const uint32_t sh = (i & 1u) << 4;
+                const uint32_t f = (atomicAdd(&h[i >> 1], c << sh) >> sh) & 0xffffu;
+                return ((f + c) >> LH_P3_SPILL_LOG) != (f >> LH_P3_SPILL_LOG);
+            }
+            atomicAdd(&h[i], c);
+        } else {
             nmiss += c;
             if (!ov_add(ov_key, ov_cnt, (l << 16) | b, c)) p2_global_add(counts, ranges, s_name[l], b, c);
         }
+        return false;
+    };
+    auto spill_one = [&](uint32_t rec) {
+        const uint32_t l = (rec >> 16) & 0xffu, b = rec & 0xffffu;
+        const uint32_t i = (l << log_w) + (b - s_org[l]);
+        atomicSub(&h[i >> 1], P3_SPILL << ((i & 1u) << 4));
+        p2_global_add(counts, ranges, s_name[l], b, P3_SPILL);
     };
     auto reduce_chunk = [&](const u4_t (&r4)[CHUNK / 256], uint32_t cn) {
         const bool full = cn == CHUNK; // wave-uniform
 #pragma unroll
         for (uint32_t k = 0; k < CHUNK / 256; k++) {
             const uint32_t rr[4] = {r4[k].x, r4[k].y, r4[k].z, r4[k].w};
+            uint32_t crossed = 0; // bit t: record t's add took its field across 2^15
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 if (full) {
                     // constant streams: the whole wave carries one record value -> one lane adds 64
                     const uint32_t f0 = __builtin_amdgcn_readfirstlane(rr[t]);
                     if (__builtin_amdgcn_ballot_w64(rr[t] != f0) == 0ull) {
-                        if (lane == 0) add_one(rr[t], 64u);
-                    } else {
-                        add_one(rr[t], 1u);
+                        if (lane == 0 && add_one(rr[t], 64u)) crossed |= 1u << t;
+                    } else if (add_one(rr[t], 1u)) {
+                        crossed |= 1u << t;
                     }
                 } else if (k * 256 + lane * 4 + t < cn) {
-                    add_one(rr[t], 1u);
+                    if (add_one(rr[t], 1u)) crossed |= 1u << t;
                 }
+            }
+            if (P3_PACK && __builtin_amdgcn_ballot_w64(crossed != 0) != 0ull) { // (rare: once per 16 384 counts of a cell)
+#pragma unroll 1
+                for (uint32_t t = 0; t < 4; t++)
+                    if (crossed & (1u << t)) spill_one(t == 0 ? rr[0] : t == 1 ? rr[1] : t == 2 ? rr[2] : rr[3]);
             }
         }
     };
     // Each wave walks chunks wave, wave + 16, ...; their indices and descriptors are fetched 64 at a time (lane l holds
     // the wave's l-th chunk of the batch; the first batch above) and two chunks (8 KiB per wave) are in flight while the
     // older is reduced: see k_part_hist2.
-    for (uint32_t b0 = 0; b0 < mine; b0 += 64) {
+    // Packed cells: the loop's trip count is the WORKGROUP's (wave 0 has the most chunks; a wave that has run out keeps
+    // fetching its last chunk and ignores it) and every round ends at a barrier.  That is what makes the 16-bit fields safe
+    // whatever the slot holds: a lane settles its hand-offs inside its round, so every field is below P3_SPILL at a
+    // barrier, and one round adds at most 32 waves x 1 024 records = 2^15 counts to it.
+    constexpr bool ROUNDS = P3_PACK != 0; // (A/B on one box, three runs each: the rounds' barriers cost nothing -- slice 0.81 ms with or without)
+    const uint32_t rounds = ROUNDS ? (cnt + WSTEP - 1) / WSTEP : mine;
+    for (uint32_t b0 = 0; b0 < rounds; b0 += 64) {
         auto fetch = [&](uint32_t k, uint32_t at) { // k: position in the batch (wave-uniform)
             load_chunk(__builtin_amdgcn_readlane(my_cid, min(k, nb - 1u)), buf[at]);
         };
         if (b0) { // (more than 1 024 chunks in the slot)
-            nb = min(mine - b0, 64u);
+            nb = mine > b0 ? min(mine - b0, 64u) : 0u;
             if (lane < nb) {
                 my_cid = list[wave + (b0 + lane) * WSTEP];
                 my_cn = cdesc[my_cid] & CD_MASK;
@@ -1573,12 +1630,14 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
 #pragma unroll
             for (uint32_t d = 0; d < DEPTH; d++) fetch(d, d);
         }
-        for (uint32_t k = 0; k < nb; k += DEPTH) {
+        const uint32_t nb_all = ROUNDS ? min(rounds - b0, 64u) : nb;
+        for (uint32_t k = 0; k < nb_all; k += DEPTH) {
 #pragma unroll
             for (uint32_t d = 0; d < DEPTH; d++) {
                 if (k + d < nb) reduce_chunk(buf[d], __builtin_amdgcn_readlane(my_cn, k + d)); // wave-uniform
                 fetch(k + d + DEPTH, d);
             }
+            if (ROUNDS) __syncthreads();
         }
     }
     if (__builtin_amdgcn_ballot_w64(nmiss != 0) != 0ull) {
@@ -1602,7 +1661,7 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part_hist3(const uint32_t *__restr
 #pragma unroll 8
     for (uint32_t k = 0; k < FL; k++) {
         const uint32_t i = tid + k * P2_BLOCK, l = i >> log_w, b = s_org[l] + (i & (W - 1));
-        const uint32_t c = h[i];
+        const uint32_t c = P3_PACK ? (h[i >> 1] >> ((i & 1u) << 4)) & 0xffffu : h[i];
         const unsigned long long occ = __builtin_amdgcn_ballot_w64(c != 0);
         if (occ != 0ull && lane == 0) {
             atomicMin(&s_mn[l], b + (uint32_t)__builtin_ctzll(occ));

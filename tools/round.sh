@@ -5,6 +5,7 @@
 #   gpurun --timeout 1500 -- 'bash tools/round.sh <sub-command> [tag] [args...]'
 #
 #   tests <tag> [pytest args]   the GPU suite (or a part of it) + smoke()
+#   p3spill <tag>               the third generation's suites on a build whose packed reduce-pass cells hand on at 2^6
 #   cells32 <tag>               the GPU suite on engines of 32-bit cells, and on ones that widen in the middle of every test
 #   profile <tag>               the round's evidence (tools/profile_round.sh: bench lines, kernel traces, PMC passes;
 #                               written to gpurun_out/round/)
@@ -62,15 +63,24 @@ tests)
 profile)
     bash tools/profile_round.sh
     ;;
+p3spill)
+    # the reduce pass's 16-bit window cells (k_part_hist3): the third generation's suites against a build whose fields hand
+    # their counts on at 2^6 instead of 2^14 (python tools/build_tuning.py -DLH_P3_SPILL_LOG=6 --name p3s6) -- every busy
+    # cell of every slot takes the hand-off path hundreds of times
+    (timeout 1500 python tools/run_tests_with_lib.py loghisto_amd/build/liblhgpu_tuning_p3s6.so tests/test_gpu_part3.py \
+        tests/test_gpu_fullsize.py tests/test_gpu_cells32.py tests/test_gpu_lane_blocks.py) > $OUT/p3spill.log 2>&1
+    echo "LH_P3_SPILL_LOG=6: $(grep -E " passed| failed| error" $OUT/p3spill.log | tail -1)" | tee $OUT/summary.txt
+    grep -hE "^(FAILED|ERROR)" $OUT/p3spill.log | cut -c1-250 | tee -a $OUT/summary.txt
+    ;;
 cells32)
     # the GPU suite on engines of 32-bit cells at EVERY name count, and on ones that move to uint64 cells in the middle of every
     # test (the knobs are the Python test wrapper's, loghisto_amd/engine.py; the library reads no environment).  Not in the
     # second run: four 65 536-name engines on one GPU, each with a wide store beside its narrow ones, do not fit 288 GB.
     (LH_TEST_CELL_BITS=32 timeout 1200 python -m pytest tests -m gpu -q) > $OUT/bits32.log 2>&1
-    echo "LH_TEST_CELL_BITS=32: $(tail -1 $OUT/bits32.log)" | tee $OUT/summary.txt
+    echo "LH_TEST_CELL_BITS=32: $(grep -E " passed| failed| error" $OUT/bits32.log | tail -1)" | tee $OUT/summary.txt
     (LH_TEST_CELL_BITS=32 LH_TEST_WIDEN_AT=200000 timeout 1200 python -m pytest tests -m gpu -q \
         --deselect "tests/test_gpu_bench_ranks.py::test_c4_step_with_ranks_as_threads[4-65536]") > $OUT/widen.log 2>&1
-    echo "LH_TEST_CELL_BITS=32 LH_TEST_WIDEN_AT=200000: $(tail -1 $OUT/widen.log)" | tee -a $OUT/summary.txt
+    echo "LH_TEST_CELL_BITS=32 LH_TEST_WIDEN_AT=200000: $(grep -E " passed| failed| error" $OUT/widen.log | tail -1)" | tee -a $OUT/summary.txt
     grep -hE "^(FAILED|ERROR)" $OUT/bits32.log $OUT/widen.log | cut -c1-250 | tee -a $OUT/summary.txt
     ;;
 ab)
