@@ -9,7 +9,9 @@ bytes that travelled (per-row windows: outliers widen two rows, not the matrix).
 The wire: a row travels at 8, 16 or 32 bits per cell, the narrowest that holds nranks x (its largest per-rank cell) --
 the expected class of every row, the packed words and the owner blocks cut on them come from the oracle's per-rank rows.
 
-usage: python tests/_stub_merge_driver.py NRANKS NROWS PLAN OUTLIERS(0/1) [NARROW: 1 on (default), 0 off, 2 off on rank 0 only]
+usage: python tests/_stub_merge_driver.py NRANKS NROWS PLAN OUTLIERS(0/1) [NARROW: 1 on (default), 0 off, 2 off on rank 0 only,
+       3 = uint64 wire words: rank 0's sample count is unknown (lh_snapshot_mark_dirty), the all-reduced bound makes every rank send
+       whole uint64 cells -- and an engine of 32-bit cells moves its snapshot to uint64 cells first]
 """
 import ctypes as C
 import json
@@ -70,6 +72,9 @@ def main():
         if narrow == 0 or (narrow == 2 and r == 0):
             e.set_option(N.OPT_MERGE_NARROW_CELLS, 0)       # one rank is enough: the bound is all-reduced
         snaps.append(e.flip())
+    wide64 = narrow == 3
+    if wide64:  # (a cell the row already holds: the ranges stay as they are)
+        snaps[0].mark_dirty(0, 1, int(want_ranges[0, 0]), int(want_ranges[0, 0]))
     results, errors = [None] * nranks, []
 
     def rank_main(r):
@@ -116,7 +121,9 @@ def main():
         assert info["packed_cells"] == cells, (info, cells)
         # every test stream is far below 2^32 samples: the wire word is uint32, and the equal-block collective pays
         # at most one row's window per block over the packed matrix (ratio <= 1.3)
-        assert info["cell_bytes"] == 4, info
+        assert info["cell_bytes"] == (8 if wide64 else 4), info
+        if wide64:
+            assert snap.device_cells()[2] == 8
         assert info["packed_words"] == W["total"], (info, W["total"])
         assert info["padded_words"] >= info["packed_words"]
         assert info["padded_words"] == W["bmax"] * W["nblocks"], (info, W["bmax"], W["nblocks"])
@@ -134,7 +141,7 @@ def main():
                 assert info["rows_8bit"] > 0.5 * M, info    # most names of a Zipf stream hold small counts
             if M > 4:
                 assert b[1] > 8                             # the one-cell name travels wider than its neighbours
-        assert info["send_bytes"] == 4 * (info["padded_words"] if plan != "allreduce" else info["packed_words"]), info
+        assert info["send_bytes"] == (8 if wide64 else 4) * (info["padded_words"] if plan != "allreduce" else info["packed_words"]), info
         assert info["span_ms"] > 0 and info["collective_ms"] >= 0 and info["pack_ms"] >= 0, info
         assert info["occupied_rows"] == int((want_ranges[:, 0] <= want_ranges[:, 1]).sum())
         # merged ranges: identical on every rank, for every row

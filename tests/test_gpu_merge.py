@@ -133,6 +133,8 @@ def test_native_rccl_merge_through_the_c_abi(native_lib, torch_cuda):
     (3, 130, "reduce_scatter", 1, 1),   # odd window widths against 2- and 4-cell words
     (4, 64, "reduce_scatter", 0, 0),    # LH_OPT_MERGE_NARROW_CELLS = 0 on every rank: every cell a whole word
     (4, 64, "reduce_scatter", 0, 2),    # ... on ONE rank: the all-reduced bound makes every rank send whole words
+    (4, 64, "reduce_scatter", 1, 3),    # uint64 wire words (one rank's sample count unknown): the sums may pass 2^32
+    (3, 37, "allreduce", 0, 4),         # ... on engines of 32-bit cells: every rank's snapshot moves to uint64 cells first
 ])
 def test_c_abi_merge_with_n_ranks_on_one_gpu(native_lib, torch_cuda, nranks, nrows, plan, outliers, narrow):
     """lh_snapshot_merge beyond one rank.  N engines on the one reachable GPU play N ranks;
@@ -141,8 +143,12 @@ def test_c_abi_merge_with_n_ranks_on_one_gpu(native_lib, torch_cuda, nranks, nro
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    if narrow == 4:  # (the test wrapper's knob, loghisto_amd/engine.py: the driver's engines count in uint32 cells)
+        narrow, env["LH_TEST_CELL_BITS"] = 3, "32"
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "_stub_merge_driver.py"), str(nranks), str(nrows),
-                        plan, str(outliers), str(narrow)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+                        plan, str(outliers), str(narrow)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300,
+                       env=env)
     print(r.stdout)
     assert r.returncode == 0, r.stdout
     import json
