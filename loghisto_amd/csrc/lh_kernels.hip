@@ -117,13 +117,16 @@ constexpr size_t K1_LDS_BYTES = (size_t)(K1_MAIN_WORDS + 2 * K1_OVF + K1_CTL_WOR
 static_assert(2 * K1_LDS_BYTES + 2048 <= 160 * 1024, "two workgroups per CU");
 static_assert(K1_OVF >= 64 && K1_OVF <= K1_WIN, "anchor arithmetic");
 
-// A cell outside every LDS window: straight to the global row.  The range only widens, so a stale read of it can cost
-// a redundant atomic, never miss one.
-__device__ __forceinline__ void global_cell_add(uint64_t *row, uint32_t *range, uint32_t bin, uint64_t c)
+// A cell outside every LDS window: straight to the global row, with an atomic that returns nothing, issued from inline asm
+// (lh_cells.h); its bin widens the workgroup's flush range in LDS (s_rng = s_ctl[0 .. 1]), which the end of the kernel
+// folds into the row's range with everything else.  Until round 6 this path LOOKED at the row's range in HBM first: a
+// global load in the middle of the tile loop, for which the compiler drains the tile's loads in flight -- one memory round
+// trip per tile and wave that had a miss.  A 0.1 % tail of far outliers (a miss in every tile) cost 1.46 ms per 1e9 samples.
+__device__ __forceinline__ void global_cell_add(uint64_t *row, uint32_t *s_rng, uint32_t bin, uint32_t c)
 {
-    lh::cell_add(row, bin, c);
-    if (bin < range[0]) atomicMin(&range[0], bin);
-    if (bin > range[1]) atomicMax(&range[1], bin);
+    lh::cell_add_hidden(row, bin, c);
+    if (bin < s_rng[0]) atomicMin(&s_rng[0], bin);
+    if (bin > s_rng[1]) atomicMax(&s_rng[1], bin);
 }
 
 // Where a workgroup puts a floating window when `bin` is its first sample on that side of the main window
@@ -139,7 +142,7 @@ __device__ __forceinline__ uint32_t k1_anchor(uint32_t bin, uint32_t win_lo, uin
 }
 
 // the sample missed the main window.  h0: the workgroup's LDS block.
-__device__ __forceinline__ void k1_miss(uint32_t *h0, uint32_t win_lo, uint32_t win_len, uint64_t *row, uint32_t *range,
+__device__ __forceinline__ void k1_miss(uint32_t *h0, uint32_t win_lo, uint32_t win_len, uint64_t *row, uint32_t *s_rng,
                                         uint32_t bin, uint32_t c)
 {
     const uint32_t side = bin >= win_lo + win_len ? 1u : 0u;
@@ -152,7 +155,7 @@ __device__ __forceinline__ void k1_miss(uint32_t *h0, uint32_t win_lo, uint32_t 
     }
     const uint32_t rel = bin - lo;
     if (rel < K1_OVF) atomicAdd(&h0[K1_MAIN_WORDS + side * K1_OVF + rel], c);
-    else global_cell_add(row, range, bin, c);
+    else global_cell_add(row, s_rng, bin, c);
 }
 
 // the workgroup's window state, wave-uniform: h0 = its LDS block, win_lo = first bin of its main window, win_len = its
@@ -165,11 +168,11 @@ constexpr uint32_t K1_WIDE = K1_WIN * K1_COPIES; // 16 384 bins
 static_assert(K1_WIDE <= K1_MAIN_WORDS, "the wide window lies in the copies' words");
 
 // hc: this lane's copy of the main window (h0 for every lane in wide mode)
-__device__ __forceinline__ void k1_add(const K1Win w, uint32_t *hc, uint64_t *row, uint32_t *range, uint32_t bin, uint32_t c = 1u)
+__device__ __forceinline__ void k1_add(const K1Win w, uint32_t *hc, uint64_t *row, uint32_t *s_rng, uint32_t bin, uint32_t c = 1u)
 {
     const uint32_t rel = bin - w.win_lo;
     if (rel < w.win_len) atomicAdd(&hc[rel], c);
-    else k1_miss(w.h0, w.win_lo, w.win_len, row, range, bin, c);
+    else k1_miss(w.h0, w.win_lo, w.win_len, row, s_rng, bin, c);
 }
 
 // All 64 lanes active.  A wave whose samples mostly share ONE bucket (a constant stream; a stream dominated by one
@@ -182,16 +185,16 @@ __device__ __forceinline__ void k1_add(const K1Win w, uint32_t *hc, uint64_t *ro
 #ifndef LH_K1_AGG_MIN
 #define LH_K1_AGG_MIN 24
 #endif
-__device__ __forceinline__ void k1_add_fullwave(const K1Win w, uint32_t *hc, uint64_t *row, uint32_t *range, uint32_t bin)
+__device__ __forceinline__ void k1_add_fullwave(const K1Win w, uint32_t *hc, uint64_t *row, uint32_t *s_rng, uint32_t bin)
 {
     const uint32_t first = __builtin_amdgcn_readfirstlane(bin);
     const unsigned long long same = __builtin_amdgcn_ballot_w64(bin == first);
     const uint32_t nsame = (uint32_t)__builtin_popcountll(same);
     if (nsame >= LH_K1_AGG_MIN) { // wave-uniform
         const bool leader = __lane_id() == 0;
-        if (leader || bin != first) k1_add(w, hc, row, range, bin, leader ? nsame : 1u);
+        if (leader || bin != first) k1_add(w, hc, row, s_rng, bin, leader ? nsame : 1u);
     } else {
-        k1_add(w, hc, row, range, bin);
+        k1_add(w, hc, row, s_rng, bin);
     }
 }
 
@@ -259,19 +262,19 @@ __global__ __launch_bounds__(K1_BLOCK) void k_ingest_single(const double *__rest
         for (int u = 0; u < K1_UNROLL; u++) r[u] = __builtin_nontemporal_load(p + u * K1_BLOCK);
 #pragma unroll
         for (int u = 0; u < K1_UNROLL; u++) {
-            k1_add_fullwave(w, h, row, range, lh_bin_of(r[u].x, Tx));
-            k1_add_fullwave(w, h, row, range, lh_bin_of(r[u].y, Tx));
+            k1_add_fullwave(w, h, row, s_ctl, lh_bin_of(r[u].x, Tx));
+            k1_add_fullwave(w, h, row, s_ctl, lh_bin_of(r[u].y, Tx));
         }
     }
     // remainder pairs (guarded), owned by the workgroup next in the rotation
     if (blockIdx.x == nfull % gridDim.x) {
         for (size_t i = nfull * tile + tid; i < npair; i += K1_BLOCK) {
             const d2_t r = vp[i];
-            k1_add(w, h, row, range, lh_bin_of(r.x, Tx));
-            k1_add(w, h, row, range, lh_bin_of(r.y, Tx));
+            k1_add(w, h, row, s_ctl, lh_bin_of(r.x, Tx));
+            k1_add(w, h, row, s_ctl, lh_bin_of(r.y, Tx));
         }
-        if (tid == 0 && head) k1_add(w, h, row, range, lh_bin_of(v[0], Tx));
-        if (tid == 1 && ((n - head) & 1)) k1_add(w, h, row, range, lh_bin_of(v[n - 1], Tx));
+        if (tid == 0 && head) k1_add(w, h, row, s_ctl, lh_bin_of(v[0], Tx));
+        if (tid == 1 && ((n - head) & 1)) k1_add(w, h, row, s_ctl, lh_bin_of(v[n - 1], Tx));
     }
     __syncthreads();
 
