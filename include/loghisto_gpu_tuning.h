@@ -42,9 +42,10 @@ extern "C" {
  *                             BASELINE config 4's name count; default 1)
  *   LH_OPT_PART_V3_MIN_PAIRS  smallest launch that takes it (default 3 * 2^20 for device-resident calls -- below, the direct
  *                             path's cell table is faster -- and 2^18 for a host-fed lane's half-buffer; >= 2^17)
- *   LH_OPT_PART_V3_LOG_W      log2 of its second-level window width, 10 .. 13 (32 .. 4 names per fine partition);
- *                             0 (default) = follow the survey: every call's survey reports the width that covers
- *                             95 % of the sampled mass and the following calls use it (lh_counters.window_log2)
+ *   LH_OPT_PART_V3_LOG_W      log2 of its second-level window width, 10 .. 14 (32 .. 4 names per fine partition; 14: 4
+ *                             names in twice the LDS); 0 (default) = follow the survey: every call's survey reports the
+ *                             smallest width within half of which, around their name's mean, 99 % of the sampled values
+ *                             lie, and the following calls use it (lh_counters.window_log2)
  *   LH_OPT_PART_V3_DIRECT_MAX_PAIRS  third generation: a launch of at most this many pairs ends in a reduce pass without
  *                             LDS windows, one global atomic per forwarded record (a host-fed lane's half-buffer leaves a
  *                             fine partition some hundred records: the windowed pass's fixed cost per slot bounded the lanes);
@@ -96,7 +97,7 @@ typedef struct lh_dispatch_query {
     uint64_t lane_samples;    /* lh_config.lane_samples */
     /* adaptive switches (lh_counters.small_path_disabled / regions_disabled; the third generation's skew switch) */
     uint32_t small_disabled, regions_disabled, v3_disabled;
-    uint32_t call_log_w;      /* the third generation's window width of this call, 10 .. 13 (0 = 10) */
+    uint32_t call_log_w;      /* the third generation's window width of this call, 10 .. 14 (0 = 10) */
     /* options, 0 = the default unless stated */
     uint64_t scratch_cap;     /* LH_OPT_SCRATCH_CAP_BYTES */
     uint64_t sublaunch_pairs; /* LH_OPT_SUBLAUNCH_PAIRS */

@@ -775,7 +775,7 @@ void snapshot_dispatch(lh_engine *e, PairsCall &c)
     c.st.call_log_w = c.st.tune.v3_log_w;
     {
         const uint32_t lw = (uint32_t)__atomic_load_n(&e->h_rstat[1], __ATOMIC_RELAXED);
-        if (!log_w_fixed && lw >= 10 && lw <= 13) c.st.call_log_w = lw;
+        if (!log_w_fixed && lw >= 10 && lw <= 14) c.st.call_log_w = lw;
         // second generation (<= 8 192 names): its survey reports 13 / 14 in the same word -- 14: spans wider than the
         // 8 192-bin reduce windows carry at least 5 % of the sampled mass
         c.st.call_wide = e->cfg.max_metrics <= 8192 && lw == 14;
@@ -805,7 +805,7 @@ void probe_width(lh_engine *e, PairsCall &c, lh::Ids d_ids, const double *d_v, s
                                reinterpret_cast<uint32_t *>(e->d_rstat + 1), s) == hipSuccess &&
         hipStreamSynchronize(s) == hipSuccess) {
         const uint32_t lw = (uint32_t)__atomic_load_n(&e->h_rstat[1], __ATOMIC_ACQUIRE);
-        if (lw >= 10 && lw <= 13) c.st.call_log_w = lw;
+        if (lw >= 10 && lw <= 14) c.st.call_log_w = lw;
     } else {
         (void)hipGetLastError();
         (void)hipStreamSynchronize(s); // (the block below is freed: nothing may still write it)
@@ -2765,7 +2765,7 @@ int lh_get_counters(lh_engine *e, lh_counters *out)
     {
         const uint64_t lw = __atomic_load_n(&e->h_rstat[1], __ATOMIC_RELAXED);
         std::lock_guard<std::mutex> g(e->scratch_mu);
-        out->window_log2 = e->v3_log_w_fixed ? e->tune.v3_log_w : (lw >= 10 && lw <= 13 ? lw : e->tune.v3_log_w);
+        out->window_log2 = e->v3_log_w_fixed ? e->tune.v3_log_w : (lw >= 10 && lw <= 14 ? lw : e->tune.v3_log_w);
     }
     return LH_OK;
 }
@@ -2837,7 +2837,7 @@ int lh_set_option(lh_engine *e, int option, uint64_t value)
         if (value > (uint64_t(1) << 30)) return LH_EINVAL;
         return set_tune(e, [&](lh::PartTuning &t) { t.v3_direct_max = (size_t)value; });
     case LH_OPT_PART_V3_LOG_W:
-        if (value != 0 && (value < 10 || value > 13)) return LH_EINVAL;
+        if (value != 0 && (value < 10 || value > 14)) return LH_EINVAL;
         return set_tune(e, [&](lh::PartTuning &t) {
             e->v3_log_w_fixed = value != 0;
             t.v3_log_w = value ? (uint32_t)value : 10u;

@@ -76,7 +76,7 @@ struct PartTuning {
                                     // bit 1: fixed per-partition regions (k_scatter3) instead of the exact per-tile layout
     bool v3 = true;                 // hashed survey + region scatter + in-place second level (lh_kernels_part3.h) for 8 193 .. 65 536 names
     size_t v3_min_samples = 0;      // 0 = default (2^24)
-    uint32_t v3_log_w = 10;         // log2 of the second level's window width, 10 .. 13: the engine follows the survey's report
+    uint32_t v3_log_w = 10;         // log2 of the second level's window width, 10 .. 14: the engine follows the survey's report
     size_t v3_direct_max = 0;       // third generation: launches of at most this many pairs end in k_part_direct3 (one global
                                     // atomic per forwarded record) instead of the windowed reduce pass; 0 = default (2^22), 1 = never
     uint32_t v3_g1_cap = 0;         // third generation: at most this many level-1 workgroups (0 = one per CU).  A host-fed

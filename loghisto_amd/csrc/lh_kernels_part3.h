@@ -30,8 +30,8 @@
 //                                 (128 KiB), windows placed from the slot's own first chunk and the survey
 //
 // Window width W (1 024 .. 8 192 bins, names per fine partition 32 .. 4) follows the stream: the survey reports
-// the span that covers 95 % of the sampled mass (k_survey_plan_h -> pinned host word) and the engine uses it for
-// the following calls.  A wrong W only costs speed: every record outside a window is counted through the small LDS
+// the smallest width within half of which, around their name's sampled mean, 99 % of the samples lie (k_survey_mass,
+// k_survey_plan_h -> pinned host word) and the engine uses it for the following calls.  A wrong W only costs speed: every record outside a window is counted through the small LDS
 // overflow tables and global atomics; a record that finds an LDS region full likewise.  Everything stays exact.
 //
 // HBM traffic per sample at 65 536 Zipf names: 12 B read + (cold share ~0.65) x (4 B written + 4 B read) +
@@ -74,6 +74,7 @@ constexpr uint32_t P3_WINWORDS = 32768;                 // reduce: 32 768 window
 #define LH_P3_PACKED 1
 #endif
 constexpr uint32_t P3_PACK = LH_P3_PACKED ? 1u : 0u;    // log2 cells per LDS word
+constexpr uint32_t V3_MAX_LOG_W = LH_P3_PACKED ? 14u : 13u; // windows of 1 024 .. 16 384 bins (the widest: 4 names x 2^14 packed cells = 128 KiB)
 #ifndef LH_P3_SPILL_LOG
 #define LH_P3_SPILL_LOG 14u /* an add that takes its field across a multiple of 2^14 hands 2^14 counts on to the row.  Any value
                                from 6 (an add carries at most 64) to 15 is exact; tools/round.sh p3spill runs the third
@@ -187,6 +188,54 @@ __global__ __launch_bounds__(1024) void k_survey_pick(const SurveyStat S, uint32
     __syncthreads();
     if (tid < V3_NP && s_pc[tid]) atomicAdd(&g_aux[AUX_PC + tid], s_pc[tid]);
     if (tid < 17 && s_cls[tid]) atomicAdd(&g_aux[AUX_CLS + tid], s_cls[tid]);
+}
+
+// The window width of levels 2 - 3 from the sampled MASS (round 6): the same samples once more, each against its name's
+// sampled mean bin -- how many lie within half a window of 2^10 .. 2^14 bins of it (names with >= 32 samples, like the span
+// classes).  The span classes above go by a name's sampled min and max: ONE far outlier among a hot name's thousand
+// samples puts its whole mass into the widest class, and a stream with a 0.1 % tail of far outliers (every hot name has
+// some) got 8 192-bin windows -- level 2 in lock step with 3 names counted in place, 17 000 reduce slots, row spans and
+// extract to match: 7.5 ms per 1e9 pairs instead of 4.4, 1.89 instead of 0.82 at config 4's slice.
+//   g_aux[AUX_IN + k - 10] samples within 2^(k-1) bins of their name's mean, k = 10 .. 14; g_aux[AUX_IN + 5] all of them
+constexpr uint32_t AUX_IN = AUX_CLS + 20;
+static_assert(AUX_IN + 6 <= AUX_WORDS, "room behind the span classes");
+template <typename IDT>
+__global__ __launch_bounds__(1024) void k_survey_mass(const IDT *__restrict__ ids, const double *__restrict__ v, size_t n,
+                                                      uint32_t nmetrics, const double *__restrict__ Tx, const SurveyStat S,
+                                                      uint32_t *__restrict__ g_aux)
+{
+    __shared__ uint32_t s_in[6];
+    const uint32_t tid = threadIdx.x;
+    if (tid < 6) s_in[tid] = 0;
+    __syncthreads();
+    const size_t npairs = n / 2; // (the samples k_survey_count_h took)
+    const size_t stride = npairs / gridDim.x;
+    const size_t i = (size_t)blockIdx.x * stride + tid;
+    uint32_t in[6] = {0, 0, 0, 0, 0, 0};
+    if (i < npairs && tid < (stride ? stride : npairs)) {
+        typedef IdStream<IDT> IS;
+        const typename IS::raw_t id2 = IS(ids).ld(i);
+        const pd2_t x2 = reinterpret_cast<const pd2_t *>(v)[i];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t id = h ? IS::second(id2) : IS::first(id2);
+            if (id < nmetrics && sv_count(S, id) >= 32u) {
+                const uint32_t bin = lh_bin_of(h ? x2.y : x2.x, Tx), mean = sv_mean(S, id);
+                const uint32_t d = bin > mean ? bin - mean : mean - bin;
+                in[5]++;
+#pragma unroll
+                for (uint32_t k = 0; k < 5; k++) in[k] += d < (512u << k) ? 1u : 0u;
+            }
+        }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 6; k++) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) in[k] += __shfl_xor(in[k], d, 64);
+        if ((tid & 63u) == 0 && in[k]) atomicAdd(&s_in[k], in[k]);
+    }
+    __syncthreads();
+    if (tid < 6 && s_in[tid]) atomicAdd(&g_aux[AUX_IN + tid], s_in[tid]);
 }
 
 // One workgroup, thread t owns hash slot t.  Output:
@@ -311,17 +360,15 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan_h(const SurveyStat S,
         hdr[1] = totw;
         hdr[2] = total_cnt;
         hdr[3] = hot_cnt_total;
-        // the smallest window (as log2, 10 .. 13) that covers the span of 95 % of the sampled mass with 1/8 to spare
-        uint32_t mass = 0, lw = 10;
-        for (uint32_t k = 0; k <= 16; k++) mass += g_aux[AUX_CLS + k];
-        uint32_t run = 0;
-        for (uint32_t k = 0; k <= 16; k++) {
-            run += g_aux[AUX_CLS + k];
-            if ((unsigned long long)run * 20u >= (unsigned long long)mass * 19u) { lw = k; break; }
-        }
-        // class k holds spans in (2^(k-1), 2^k]: such a name wants a window of 2^k bins, and one class more when the
-        // sample is small (the span of a few dozen samples underestimates the name's real span)
-        lw = lw < 10u ? 10u : (lw > 13u ? 13u : lw);
+        // the smallest window (as log2, 10 .. 14) within half of which, around their name's mean, 99 % of the samples lie
+        // (k_survey_mass; until round 6: the class of the names' sampled min .. max spans that covers 95 % of the mass).
+        // 2^14 bins: streams on both sides of key 0 over many decades (+-10^U(-3, 20) spans 9 211 bins: 8 192-bin windows
+        // sent 9 % of the reduce pass's records to global atomics, 5.1 ms of a 12.4 ms call)
+        const uint32_t mass = g_aux[AUX_IN + 5];
+        uint32_t lw = V3_MAX_LOG_W;
+        for (uint32_t k = 10; k < V3_MAX_LOG_W; k++)
+            if ((unsigned long long)g_aux[AUX_IN + k - 10u] * 100u >= (unsigned long long)mass * 99u) { lw = k; break; }
+        if (!mass) lw = 10;
         hdr[4] = lw;
         hdr[HDR_BASE] = 0; // no launch has run on these tables yet (stale_judge, lh_kernels_part2.h)
         if (span_out && mass) __hip_atomic_store(span_out, lw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1437,9 +1484,12 @@ __global__ __launch_bounds__(1024, 4) void k_split_waves(const uint32_t *__restr
 // Reduce: one workgroup per fine-partition work slot.  Fine partition q = fine << 8 | p1 holds the names of ranks
 // fine * mpp2 .. + mpp2 - 1 of level-1 partition p1; record = fine << 24 | rank % mpp2 << 16 | bin.
 // ---------------------------------------------------------------------------
+// Windows of 2^14 bins (round 6): the slot keeps its 4 names and takes twice the cells -- 128 KiB packed, ONE slot per CU.
 constexpr uint32_t P3_LDSWORDS = P3_WINWORDS >> P3_PACK;
-constexpr size_t P3_LDS_BYTES = (P3_LDSWORDS + 6 * 32 + 2 * OV_SLOTS + 2) * sizeof(uint32_t) + 16;
+constexpr size_t p3_lds_bytes(uint32_t ldswords) { return (ldswords + 6 * 32 + 2 * OV_SLOTS + 2) * sizeof(uint32_t) + 16; }
+constexpr size_t P3_LDS_BYTES = p3_lds_bytes(P3_LDSWORDS), P3_LDS_BYTES_WIDE = p3_lds_bytes(2 * P3_LDSWORDS);
 static_assert(!LH_P3_PACKED || 2 * (P3_LDS_BYTES + 1024) <= 160 * 1024, "two slots per CU");
+static_assert(!LH_P3_PACKED || P3_LDS_BYTES_WIDE <= 160 * 1024, "a slot of 2^14-bin windows fits one CU's LDS");
 
 __global__ __launch_bounds__(P2_BLOCK, LH_P3_PACKED ? 8 : 4) void k_part_hist3(const uint32_t *__restrict__ records,
                                                          const uint32_t *__restrict__ cdesc,
@@ -1455,7 +1505,7 @@ __global__ __launch_bounds__(P2_BLOCK, LH_P3_PACKED ? 8 : 4) void k_part_hist3(c
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *h = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *s_org = h + P3_LDSWORDS, *s_mn = s_org + 32, *s_mx = s_mn + 32, *s_name = s_mx + 32, *s_svc = s_name + 32,
+    uint32_t *s_org = h + ((4u << log_w) > P3_WINWORDS ? 2 * P3_LDSWORDS : P3_LDSWORDS), *s_mn = s_org + 32, *s_mx = s_mn + 32, *s_name = s_mx + 32, *s_svc = s_name + 32,
              *s_svm = s_svc + 32;
     uint32_t *ov_key = s_svm + 32, *ov_cnt = ov_key + OV_SLOTS;
     uint32_t *s_all = ov_cnt + OV_SLOTS; // [2]: lowest and highest bin of the slot's first chunk, whatever the name
@@ -1656,10 +1706,11 @@ __global__ __launch_bounds__(P2_BLOCK, LH_P3_PACKED ? 8 : 4) void k_part_hist3(c
     // thread issues all 32 of its cells back to back and never waits for memory.  (One LDS range update per wave,
     // not per cell: the wave's 64 cells are consecutive bins of one name, its lowest and highest occupied bins are
     // those of the first and the last lane that found a count.)
+    static_assert(P3_WINWORDS / P2_BLOCK == 32 && P3_WINWORDS % P2_BLOCK == 0, "a thread flushes 32 cells (64 of 2^14-bin windows)");
     constexpr uint32_t FL = P3_WINWORDS / P2_BLOCK;
-    static_assert(FL == 32 && P3_WINWORDS % P2_BLOCK == 0, "a thread flushes 32 cells");
+    for (uint32_t k0 = 0; k0 < words / P2_BLOCK; k0 += FL)
 #pragma unroll 8
-    for (uint32_t k = 0; k < FL; k++) {
+    for (uint32_t k = k0; k < k0 + FL; k++) {
         const uint32_t i = tid + k * P2_BLOCK, l = i >> log_w, b = s_org[l] + (i & (W - 1));
         const uint32_t c = P3_PACK ? (h[i >> 1] >> ((i & 1u) << 4)) & 0xffffu : h[i];
         const unsigned long long occ = __builtin_amdgcn_ballot_w64(c != 0);
@@ -1779,10 +1830,10 @@ static bool make_plan3(size_t n, uint32_t nmetrics, int num_cus, const PartTunin
     if (!tune.v3 || !(tune.v2_shape & 2u)) return false; // shape bit 1 clear: the engine asked for the exact layout
     if (n < (tune.v3_min_samples ? tune.v3_min_samples : V3_MIN_SAMPLES) || n > (size_t(1) << 31)) return false;
     if (nmetrics <= V2_MAX_NAMES || nmetrics > V3_MAX_NAMES) return false;
-    P.log_w = std::min(13u, std::max(10u, tune.v3_log_w));
-    P.log_mpp2 = 15u - P.log_w;                  // mpp2 x W = 32 768 window words in the reduce pass
+    P.log_w = std::min(V3_MAX_LOG_W, std::max(10u, tune.v3_log_w));
+    P.log_mpp2 = 15u - std::min(13u, P.log_w);   // mpp2 x W = 32 768 window words in the reduce pass (65 536 at W = 2^14)
     P.mpp2 = 1u << P.log_mpp2;
-    P.kp = PEEL_WORDS >> P.log_w;                // names counted in place by level 2: 24, 12, 6, 3
+    P.kp = PEEL_WORDS >> P.log_w;                // names counted in place by level 2: 24, 12, 6, 3, 1
     P.mpp = (nmetrics + V3_NP - 1) >> V3_LOG_NP; // names per level-1 partition: 33 .. 256
     P.ns = 1;
     P.log_ns = 0;
@@ -1894,7 +1945,7 @@ static hipError_t launch_part3_t(const IDT *d_ids, const double *d_v, size_t n, 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPLITW_LDS_BYTES);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_part_hist3),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)P3_LDS_BYTES);
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LH_P3_PACKED ? P3_LDS_BYTES_WIDE : P3_LDS_BYTES));
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_survey_count_h<IDT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(5 * SVH_SLOTS * 4));
@@ -1943,6 +1994,7 @@ static hipError_t launch_part3_t(const IDT *d_ids, const double *d_v, size_t n, 
         hipLaunchKernelGGL(k_survey_count_h<IDT>, dim3(sv_grid), dim3(1024), 5 * SVH_SLOTS * 4, s, d_ids, d_v, survey_n,
                            nmetrics, d_Tx, g_cs, g_mninv, g_mx);
         hipLaunchKernelGGL(k_survey_pick, dim3((nmetrics + 1023) / 1024), dim3(1024), 0, s, S, nmetrics, g_aux);
+        hipLaunchKernelGGL(k_survey_mass<IDT>, dim3(sv_grid), dim3(1024), 0, s, d_ids, d_v, survey_n, nmetrics, d_Tx, S, g_aux);
         hipLaunchKernelGGL(k_survey_plan_h, dim3(1), dim3(V2_BLOCK), 0, s, S, g_aux, P.cells, V3_TILE, P.avail_bytes, P.max_cells, g_hk, g_hs, g_pt,
                            g_hdr, span_stat);
         hipLaunchKernelGGL(k_survey_remap, dim3(V3_NP), dim3(256), 0, s, S, g_hk, nmetrics, P.kp, P.log_mpp2, P.ns,
@@ -1978,7 +2030,7 @@ static hipError_t launch_part3_t(const IDT *d_ids, const double *d_v, size_t n, 
     } else {
         e = run_plan(L2, P.nchunks2, P.nq, 0u, P.extra2, s);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_part_hist3, dim3(P.nq + P.extra2), dim3(P2_BLOCK), P3_LDS_BYTES, s, L2.records, L2.cdesc,
+        hipLaunchKernelGGL(k_part_hist3, dim3(P.nq + P.extra2), dim3(P2_BLOCK), P.log_w > 13u ? P3_LDS_BYTES_WIDE : P3_LDS_BYTES, s, L2.records, L2.cdesc,
                            L2.sorted, L2.part_start, L2.slots, L2.nslots, L2.pc, nmetrics, P.log_mpp2, P.log_w, g_inv, S,
                            counts, ranges, g_stats);
     }
@@ -2010,6 +2062,7 @@ static hipError_t launch_part3_probe_t(const IDT *d_ids, const double *d_v, size
     hipLaunchKernelGGL(k_survey_count_h<IDT>, dim3(sv_grid), dim3(1024), 5 * SVH_SLOTS * 4, s, d_ids, d_v, n, nmetrics, d_Tx,
                        g_cs, g_mninv, g_mx);
     hipLaunchKernelGGL(k_survey_pick, dim3((nmetrics + 1023) / 1024), dim3(1024), 0, s, S, nmetrics, g_aux);
+    hipLaunchKernelGGL(k_survey_mass<IDT>, dim3(sv_grid), dim3(1024), 0, s, d_ids, d_v, n, nmetrics, d_Tx, S, g_aux);
     hipLaunchKernelGGL(k_survey_plan_h, dim3(1), dim3(V2_BLOCK), 0, s, S, g_aux, P.cells, V3_TILE, P.avail_bytes, P.max_cells,
                        reinterpret_cast<pu2_t *>(base + P.off_hk), reinterpret_cast<pu4_t *>(base + P.off_hs),
                        reinterpret_cast<pu2_t *>(base + P.off_pt), reinterpret_cast<uint32_t *>(base + P.off_hdr), span_stat);

@@ -50,6 +50,8 @@ def _values(rng, kind, ids, n):
         return 10.0 ** rng.uniform(-3, 18, n)
     if kind == "huge":                           # spans the whole key space: most samples miss every window
         return 10.0 ** rng.uniform(-6, 140, n) * np.where(rng.random(n) < 0.5, -1.0, 1.0)
+    if kind == "signed_wide":                    # +-10^U(-3, 20): 9 211 bins across key 0 -- wider than an 8 192-bin window
+        return 10.0 ** rng.uniform(-3, 20, n) * np.where(rng.random(n) < 0.5, -1.0, 1.0)
     if kind == "sigma25":
         return rng.lognormal(math.log(1e5), 2.5, n)
     if kind == "drift":                          # the distribution moves during the launch: windows go stale
@@ -117,6 +119,10 @@ CASES = [
     (65536, 2_000_000, "kvalues2", 1.0, False, 0),    # few-valued streams (quantised timers): two cells per name
     (65536, 2_000_000, "kvalues8", 1.0, True, 0),
     (65536, 2_000_000, "bimodal", 1.0, False, 0),
+    (65536, 2_400_000, "signed_wide", 1.0, True, 0),  # the survey asks for 16 384-bin windows: one reduce slot per CU
+    (65536, 2_000_001, "edge", 1.0, False, 14),       # ... pinned: the key-space ends inside such a window
+    (40000, 2_200_000, "huge", 1.2, True, 14),
+    (20000, 2_000_000, "signed_wide", 0.5, False, 14),
 ]
 
 
@@ -136,7 +142,7 @@ def test_third_generation_is_exact(native_lib, torch_cuda, M, n, kind, skew, per
             e.sync()
             c = e.counters()
             assert c["samples_partitioned_v3"] == n * (rep + 1), c
-            assert 10 <= c["window_log2"] <= 13
+            assert 10 <= c["window_log2"] <= 14
             with e.flip() as snap:
                 got = snap.extract(PCTS, M)
                 check(snap, ids, v, M, got)
@@ -266,7 +272,8 @@ def test_names_without_skew_go_back_to_the_first_generation(native_lib, torch_cu
 
 
 def test_window_width_follows_the_stream(native_lib, torch_cuda):
-    """The survey's report: lognormal sigma = 1 spans ~900 bins (1 024-bin windows), 21 decades span 4 147 (8 192)."""
+    """The survey's report (the smallest window within half of which, around their name's mean, 99 % of the samples lie):
+    lognormal sigma = 1 is 100 bins wide (1 024-bin windows), sigma = 2.5 is 251 (2 048), 21 decades span 4 147 (8 192), 23 on either side of key 0 span 9 211 (16 384)."""
     import loghisto_amd
     rng = np.random.default_rng(5)
     M, n = 65536, 1_000_000
@@ -275,7 +282,7 @@ def test_window_width_follows_the_stream(native_lib, torch_cuda):
         e.set_option(N.OPT_PART_V3_MIN_PAIRS, 1 << 17)
         e.set_option(N.OPT_PART_V3_DIRECT_MAX_PAIRS, 1)    # launches this small keep the windowed reduce pass under test
         e.set_option(N.OPT_SURVEY_EVERY, 1)      # every call surveys: the report follows the stream call by call
-        for kind, want in (("lognormal", 10), ("loguniform", 13), ("sigma25", 12), ("lognormal", 10)):
+        for kind, want in (("lognormal", 10), ("loguniform", 13), ("sigma25", 11), ("signed_wide", 14), ("lognormal", 10)):
             e.submit_pairs_device(_dev(torch_cuda, ids), _dev(torch_cuda, _values(rng, kind, ids, n)))
             e.sync()
             assert e.counters()["window_log2"] == want, (kind, e.counters())
