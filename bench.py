@@ -189,7 +189,7 @@ def make_samples(n: int, kind: str, seed: int) -> torch.Tensor:
     v = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
     if kind == "normal":
         return v.mul_(1e3)
-    sigma = 2.5 if kind == "lognormal25" else 1.0
+    sigma = 2.5 if kind == "lognormal25" else 5.0 if kind == "lognormal50" else 1.0
     return v.mul_(sigma).add_(math.log(1e5)).exp_()
 
 

@@ -26,10 +26,11 @@
 //                                 most frequent of its 256 names get LDS windows here (96 KiB) and their records end
 //                                 in this pass (under Zipf(1) they are ~70 % of the partition's records); the rest is
 //                                 split into ns fine partitions through LDS regions, exactly like level 1
-//   reduce   k_part_hist3         one workgroup per fine-partition work slot: mpp2 names x W bins of windows (16-bit cells, two slots per CU)
+//   reduce   k_part_hist3         one workgroup per fine-partition work slot: mpp2 names x W bins of windows (16-bit cells, two slots per CU;
+//                                 W >= 2^13: twice the cells, one slot per CU)
 //                                 (128 KiB), windows placed from the slot's own first chunk and the survey
 //
-// Window width W (1 024 .. 8 192 bins, names per fine partition 32 .. 4) follows the stream: the survey reports
+// Window width W (1 024 .. 16 384 bins, names per fine partition 32, 16, 8, 8, 4) follows the stream: the survey reports
 // the smallest width within half of which, around their name's sampled mean, 99 % of the samples lie (k_survey_mass,
 // k_survey_plan_h -> pinned host word) and the engine uses it for the following calls.  A wrong W only costs speed: every record outside a window is counted through the small LDS
 // overflow tables and global atomics; a record that finds an LDS region full likewise.  Everything stays exact.
@@ -75,6 +76,14 @@ constexpr uint32_t P3_WINWORDS = 32768;                 // reduce: 32 768 window
 #endif
 constexpr uint32_t P3_PACK = LH_P3_PACKED ? 1u : 0u;    // log2 cells per LDS word
 constexpr uint32_t V3_MAX_LOG_W = LH_P3_PACKED ? 14u : 13u; // windows of 1 024 .. 16 384 bins (the widest: 4 names x 2^14 packed cells = 128 KiB)
+#ifndef LH_HOT_CAP_BIG
+#define LH_HOT_CAP_BIG 4096u /* widest hot window of a name with >= 1/64 of the sampled mass (k_survey_plan_h) */
+#endif
+#ifndef LH_P3_WIDE_FROM
+#define LH_P3_WIDE_FROM 13u /* windows from this width on: twice the cells per slot (128 KiB packed, 8 names of 2^13 bins or 4 of 2^14), one slot per CU.
+                               Measured (tools/build_tuning.py -DLH_P3_WIDE_FROM=..): from 13, loguniform[1e-3, 1e18] at 65 536 names 7.65 -> 7.2 ms
+                               per 1e9 pairs (32 fine partitions per partition instead of 64); from 12, lognormal sigma 5 6.1 -> 6.75 */
+#endif
 #ifndef LH_P3_SPILL_LOG
 #define LH_P3_SPILL_LOG 14u /* an add that takes its field across a multiple of 2^14 hands 2^14 counts on to the row.  Any value
                                from 6 (an add carries at most 64) to 15 is exact; tools/round.sh p3spill runs the third
@@ -281,8 +290,25 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan_h(const SurveyStat S,
     uint32_t total_cnt, dummy;
     block_sum2(pc, 0, s_a, s_b, total_cnt, dummy);
     const uint32_t big = total_cnt / 64u;
+    // the smallest window (as log2, 10 .. 14) within half of which, around their name's mean, 99 % of the samples lie
+    // (k_survey_mass; until round 6: the class of the names' sampled min .. max spans that covers 95 % of the mass).
+    // 2^14 bins: streams on both sides of key 0 over many decades (+-10^U(-3, 20) spans 9 211 bins: 8 192-bin windows
+    // sent 9 % of the reduce pass's records to global atomics, 5.1 ms of a 12.4 ms call)
+    const uint32_t mass = g_aux[AUX_IN + 5];
+    uint32_t lw = V3_MAX_LOG_W;
+    for (uint32_t k = 10; k < V3_MAX_LOG_W; k++)
+        if ((unsigned long long)g_aux[AUX_IN + k - 10u] * 100u >= (unsigned long long)mass * 99u) { lw = k; break; }
+    if (!mass) lw = 10;
     if (want) {
-        const uint32_t cap = cnt >= big ? 512u : 256u;
+        // A name with >= 1/64 of the mass may have a window as wide as half of that (512 bins on a lognormal stream, up to
+        // LH_HOT_CAP_BIG on a wide one): where values spread evenly over their span a cell earns cnt / span whatever the
+        // window's width, so the cells belong to the most frequent names' whole spans, not to 512 bins each of many names
+        // (21 decades at 65 536 names: 7.24 -> 6.65 ms per 1e9 pairs, sigma = 5: 6.08 -> 5.78).  By the stream's mass, not
+        // by the name's sampled span: one far outlier among a top name's samples stretches that (a 0.1 % tail to 1e60 with
+        // 4 096-bin windows by span alone: 5.09 -> 5.33 ms).
+        uint32_t cap_big = 1u << (lw - 1u);
+        cap_big = cap_big < 512u ? 512u : cap_big > LH_HOT_CAP_BIG ? LH_HOT_CAP_BIG : cap_big;
+        const uint32_t cap = cnt >= big ? cap_big : 256u; // (the other names at half or a quarter of cap_big instead of 256: within 2 % either way)
         if (want > cap && !whole) want = cap;
     }
     auto pick = [&](uint32_t cells) {
@@ -360,15 +386,6 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan_h(const SurveyStat S,
         hdr[1] = totw;
         hdr[2] = total_cnt;
         hdr[3] = hot_cnt_total;
-        // the smallest window (as log2, 10 .. 14) within half of which, around their name's mean, 99 % of the samples lie
-        // (k_survey_mass; until round 6: the class of the names' sampled min .. max spans that covers 95 % of the mass).
-        // 2^14 bins: streams on both sides of key 0 over many decades (+-10^U(-3, 20) spans 9 211 bins: 8 192-bin windows
-        // sent 9 % of the reduce pass's records to global atomics, 5.1 ms of a 12.4 ms call)
-        const uint32_t mass = g_aux[AUX_IN + 5];
-        uint32_t lw = V3_MAX_LOG_W;
-        for (uint32_t k = 10; k < V3_MAX_LOG_W; k++)
-            if ((unsigned long long)g_aux[AUX_IN + k - 10u] * 100u >= (unsigned long long)mass * 99u) { lw = k; break; }
-        if (!mass) lw = 10;
         hdr[4] = lw;
         hdr[HDR_BASE] = 0; // no launch has run on these tables yet (stale_judge, lh_kernels_part2.h)
         if (span_out && mass) __hip_atomic_store(span_out, lw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1484,7 +1501,7 @@ __global__ __launch_bounds__(1024, 4) void k_split_waves(const uint32_t *__restr
 // Reduce: one workgroup per fine-partition work slot.  Fine partition q = fine << 8 | p1 holds the names of ranks
 // fine * mpp2 .. + mpp2 - 1 of level-1 partition p1; record = fine << 24 | rank % mpp2 << 16 | bin.
 // ---------------------------------------------------------------------------
-// Windows of 2^14 bins (round 6): the slot keeps its 4 names and takes twice the cells -- 128 KiB packed, ONE slot per CU.
+// Windows of 2^13 and 2^14 bins (round 6): 8 / 4 names in twice the cells -- 128 KiB packed, ONE slot per CU.
 constexpr uint32_t P3_LDSWORDS = P3_WINWORDS >> P3_PACK;
 constexpr size_t p3_lds_bytes(uint32_t ldswords) { return (ldswords + 6 * 32 + 2 * OV_SLOTS + 2) * sizeof(uint32_t) + 16; }
 constexpr size_t P3_LDS_BYTES = p3_lds_bytes(P3_LDSWORDS), P3_LDS_BYTES_WIDE = p3_lds_bytes(2 * P3_LDSWORDS);
@@ -1505,7 +1522,7 @@ __global__ __launch_bounds__(P2_BLOCK, LH_P3_PACKED ? 8 : 4) void k_part_hist3(c
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *h = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *s_org = h + ((4u << log_w) > P3_WINWORDS ? 2 * P3_LDSWORDS : P3_LDSWORDS), *s_mn = s_org + 32, *s_mx = s_mn + 32, *s_name = s_mx + 32, *s_svc = s_name + 32,
+    uint32_t *s_org = h + ((1u << (log_mpp2 + log_w)) > P3_WINWORDS ? 2 * P3_LDSWORDS : P3_LDSWORDS), *s_mn = s_org + 32, *s_mx = s_mn + 32, *s_name = s_mx + 32, *s_svc = s_name + 32,
              *s_svm = s_svc + 32;
     uint32_t *ov_key = s_svm + 32, *ov_cnt = ov_key + OV_SLOTS;
     uint32_t *s_all = ov_cnt + OV_SLOTS; // [2]: lowest and highest bin of the slot's first chunk, whatever the name
@@ -1831,7 +1848,7 @@ static bool make_plan3(size_t n, uint32_t nmetrics, int num_cus, const PartTunin
     if (n < (tune.v3_min_samples ? tune.v3_min_samples : V3_MIN_SAMPLES) || n > (size_t(1) << 31)) return false;
     if (nmetrics <= V2_MAX_NAMES || nmetrics > V3_MAX_NAMES) return false;
     P.log_w = std::min(V3_MAX_LOG_W, std::max(10u, tune.v3_log_w));
-    P.log_mpp2 = 15u - std::min(13u, P.log_w);   // mpp2 x W = 32 768 window words in the reduce pass (65 536 at W = 2^14)
+    P.log_mpp2 = (P.log_w >= LH_P3_WIDE_FROM ? 16u : 15u) - P.log_w; // mpp2 x W = 32 768 window cells in the reduce pass, 65 536 from W = 2^13 on
     P.mpp2 = 1u << P.log_mpp2;
     P.kp = PEEL_WORDS >> P.log_w;                // names counted in place by level 2: 24, 12, 6, 3, 1
     P.mpp = (nmetrics + V3_NP - 1) >> V3_LOG_NP; // names per level-1 partition: 33 .. 256
@@ -2030,7 +2047,7 @@ static hipError_t launch_part3_t(const IDT *d_ids, const double *d_v, size_t n, 
     } else {
         e = run_plan(L2, P.nchunks2, P.nq, 0u, P.extra2, s);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_part_hist3, dim3(P.nq + P.extra2), dim3(P2_BLOCK), P.log_w > 13u ? P3_LDS_BYTES_WIDE : P3_LDS_BYTES, s, L2.records, L2.cdesc,
+        hipLaunchKernelGGL(k_part_hist3, dim3(P.nq + P.extra2), dim3(P2_BLOCK), P.log_w >= LH_P3_WIDE_FROM ? P3_LDS_BYTES_WIDE : P3_LDS_BYTES, s, L2.records, L2.cdesc,
                            L2.sorted, L2.part_start, L2.slots, L2.nslots, L2.pc, nmetrics, P.log_mpp2, P.log_w, g_inv, S,
                            counts, ranges, g_stats);
     }

@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--pairs", type=int, default=0, help="if >0: mixed stream over this many names, Zipf(1.0) ids")
     ap.add_argument("--dists", default="lognormal,constant,uniform,exponential,normal,loguniform,loguniform21,lognormal25,kvalues2,kvalues4,"
-                                       "kvalues8,kvalues16,bimodal,far_1e30,negative_far,signed_wide,thin_far_tail")
+                                       "kvalues8,kvalues16,bimodal,far_1e30,negative_far,signed_wide,thin_far_tail")  # (+ lognormal50: sigma 5, 4 096-bin windows)
     ap.add_argument("--ids", default="zipf", choices=["zipf", "uniform", "zipf0.5", "sorted", "drift"],
                     help="name distribution of --pairs (sorted: Zipf(1.0) counts, the stream ordered by name; drift: the ranking of the names is reversed half way through the launch)")
     ap.add_argument("--lib", default=None, help="path of an alternative liblhgpu.so (a -DLH_TUNING build)")
