@@ -170,44 +170,36 @@ __global__ __launch_bounds__(1024) void k_survey_count_h(const IDT *__restrict__
     }
 }
 
-// g_aux (zero-initialised with the statistics): claim[V3_HN] | pc[V3_NP] | cls[17] (sampled mass by ceil(log2 span))
-constexpr uint32_t AUX_CLAIM = 0, AUX_PC = V3_HN, AUX_CLS = V3_HN + V3_NP, AUX_WORDS = V3_HN + V3_NP + 32;
+// g_aux (zero-initialised with the statistics): claim[V3_HN] | pc[V3_NP] | in[6] (k_survey_mass)
+constexpr uint32_t AUX_CLAIM = 0, AUX_PC = V3_HN, AUX_IN = V3_HN + V3_NP, AUX_WORDS = V3_HN + V3_NP + 32;
 
 // One thread per name: a name with >= 16 sampled values claims its hash slot (the larger count wins); per-partition
-// sample counts; the sampled mass by span class.
+// sample counts.
 __global__ __launch_bounds__(1024) void k_survey_pick(const SurveyStat S, uint32_t nmetrics,
                                                       uint32_t *__restrict__ g_aux)
 {
-    __shared__ uint32_t s_pc[V3_NP], s_cls[17];
+    __shared__ uint32_t s_pc[V3_NP];
     const uint32_t tid = threadIdx.x;
     if (tid < V3_NP) s_pc[tid] = 0;
-    if (tid < 17) s_cls[tid] = 0;
     __syncthreads();
     const uint32_t m = blockIdx.x * 1024u + tid;
     const uint32_t c = m < nmetrics ? sv_count(S, m) : 0u;
     if (c) {
         atomicAdd(&s_pc[m & (V3_NP - 1u)], c);
-        const uint32_t span = S.mx[m] - (65535u - S.mninv[m]) + 1u;
         if (c >= 16u) atomicMax(&g_aux[AUX_CLAIM + v3_hash(m)], (min(c, 65535u) << 16) | m);
-        if (c >= 32u) { // class k: spans in (2^(k-1), 2^k]
-            const uint32_t k = span <= 1u ? 0u : 32u - (uint32_t)__clz(span - 1u);
-            atomicAdd(&s_cls[k > 16u ? 16u : k], c);
-        }
     }
     __syncthreads();
     if (tid < V3_NP && s_pc[tid]) atomicAdd(&g_aux[AUX_PC + tid], s_pc[tid]);
-    if (tid < 17 && s_cls[tid]) atomicAdd(&g_aux[AUX_CLS + tid], s_cls[tid]);
 }
 
 // The window width of levels 2 - 3 from the sampled MASS (round 6): the same samples once more, each against its name's
-// sampled mean bin -- how many lie within half a window of 2^10 .. 2^14 bins of it (names with >= 32 samples, like the span
-// classes).  The span classes above go by a name's sampled min and max: ONE far outlier among a hot name's thousand
+// sampled mean bin -- how many lie within half a window of 2^10 .. 2^14 bins of it (names with >= 32 samples).  Until then
+// the sampled mass was classed by the names' sampled min .. max SPANS: ONE far outlier among a hot name's thousand
 // samples puts its whole mass into the widest class, and a stream with a 0.1 % tail of far outliers (every hot name has
 // some) got 8 192-bin windows -- level 2 in lock step with 3 names counted in place, 17 000 reduce slots, row spans and
 // extract to match: 7.5 ms per 1e9 pairs instead of 4.4, 1.89 instead of 0.82 at config 4's slice.
 //   g_aux[AUX_IN + k - 10] samples within 2^(k-1) bins of their name's mean, k = 10 .. 14; g_aux[AUX_IN + 5] all of them
-constexpr uint32_t AUX_IN = AUX_CLS + 20;
-static_assert(AUX_IN + 6 <= AUX_WORDS, "room behind the span classes");
+static_assert(AUX_IN + 6 <= AUX_WORDS, "room behind the partition counts");
 template <typename IDT>
 __global__ __launch_bounds__(1024) void k_survey_mass(const IDT *__restrict__ ids, const double *__restrict__ v, size_t n,
                                                       uint32_t nmetrics, const double *__restrict__ Tx, const SurveyStat S,
@@ -1503,6 +1495,7 @@ __global__ __launch_bounds__(1024, 4) void k_split_waves(const uint32_t *__restr
 // ---------------------------------------------------------------------------
 // Windows of 2^13 and 2^14 bins (round 6): 8 / 4 names in twice the cells -- 128 KiB packed, ONE slot per CU.
 constexpr uint32_t P3_LDSWORDS = P3_WINWORDS >> P3_PACK;
+constexpr uint32_t P3_WIDE_FROM = LH_P3_PACKED ? LH_P3_WIDE_FROM : 99u; // (32-bit window cells: 65 536 of them do not fit a CU)
 constexpr size_t p3_lds_bytes(uint32_t ldswords) { return (ldswords + 6 * 32 + 2 * OV_SLOTS + 2) * sizeof(uint32_t) + 16; }
 constexpr size_t P3_LDS_BYTES = p3_lds_bytes(P3_LDSWORDS), P3_LDS_BYTES_WIDE = p3_lds_bytes(2 * P3_LDSWORDS);
 static_assert(!LH_P3_PACKED || 2 * (P3_LDS_BYTES + 1024) <= 160 * 1024, "two slots per CU");
@@ -1848,7 +1841,7 @@ static bool make_plan3(size_t n, uint32_t nmetrics, int num_cus, const PartTunin
     if (n < (tune.v3_min_samples ? tune.v3_min_samples : V3_MIN_SAMPLES) || n > (size_t(1) << 31)) return false;
     if (nmetrics <= V2_MAX_NAMES || nmetrics > V3_MAX_NAMES) return false;
     P.log_w = std::min(V3_MAX_LOG_W, std::max(10u, tune.v3_log_w));
-    P.log_mpp2 = (P.log_w >= LH_P3_WIDE_FROM ? 16u : 15u) - P.log_w; // mpp2 x W = 32 768 window cells in the reduce pass, 65 536 from W = 2^13 on
+    P.log_mpp2 = (P.log_w >= P3_WIDE_FROM ? 16u : 15u) - P.log_w; // mpp2 x W = 32 768 window cells in the reduce pass, 65 536 from W = 2^13 on
     P.mpp2 = 1u << P.log_mpp2;
     P.kp = PEEL_WORDS >> P.log_w;                // names counted in place by level 2: 24, 12, 6, 3, 1
     P.mpp = (nmetrics + V3_NP - 1) >> V3_LOG_NP; // names per level-1 partition: 33 .. 256
@@ -2047,7 +2040,7 @@ static hipError_t launch_part3_t(const IDT *d_ids, const double *d_v, size_t n, 
     } else {
         e = run_plan(L2, P.nchunks2, P.nq, 0u, P.extra2, s);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_part_hist3, dim3(P.nq + P.extra2), dim3(P2_BLOCK), P.log_w >= LH_P3_WIDE_FROM ? P3_LDS_BYTES_WIDE : P3_LDS_BYTES, s, L2.records, L2.cdesc,
+        hipLaunchKernelGGL(k_part_hist3, dim3(P.nq + P.extra2), dim3(P2_BLOCK), P.log_w >= P3_WIDE_FROM ? P3_LDS_BYTES_WIDE : P3_LDS_BYTES, s, L2.records, L2.cdesc,
                            L2.sorted, L2.part_start, L2.slots, L2.nslots, L2.pc, nmetrics, P.log_mpp2, P.log_w, g_inv, S,
                            counts, ranges, g_stats);
     }
