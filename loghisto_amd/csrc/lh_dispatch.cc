@@ -85,6 +85,7 @@ Step choose_step(const DispatchState &st, uintptr_t ids, uint32_t id_width, uint
         if (st.regions_disabled) tune.v2_shape &= ~6u; // clustered stream: the exact-layout scatter
         if (st.v3_disabled) tune.v3 = false;            // skew-free names: first generation
         tune.v3_log_w = st.call_log_w;
+        tune.v2_yield = st.call_yield;
         // generation 2 (survey + 2-byte records) for <= 8 192 names, generation 3 above, when the launch is large enough for
         // it (each generation has its own minimum; an option may lower one below the others'); otherwise the first
         // generation; a launch none of them takes is the direct path's

@@ -42,6 +42,7 @@ struct DispatchState {
     PartTuning tune;               // lh_set_option
     uint32_t call_log_w = 10;      // third generation: the window width this call runs with (the last survey's report)
     bool call_wide = false;        // second generation: the last survey saw spans wider than the 8 192-bin reduce windows
+    bool call_yield = false;       // 1 025 .. 8 192 names: ... and more than 1/8 of the mass outside the second generation's cold windows
     bool small_disabled = false;   // adaptive switches (lh_engine: window misses / region overflows / forwarded share)
     bool regions_disabled = false;
     bool v3_disabled = false;

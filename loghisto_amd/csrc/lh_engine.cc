@@ -774,8 +774,10 @@ void snapshot_dispatch(lh_engine *e, PairsCall &c)
     // call's own survey stores its report while later sub-launches are still being enqueued.
     c.st.call_log_w = c.st.tune.v3_log_w;
     {
-        const uint32_t lw = (uint32_t)__atomic_load_n(&e->h_rstat[1], __ATOMIC_RELAXED);
+        const uint32_t raw = (uint32_t)__atomic_load_n(&e->h_rstat[1], __ATOMIC_RELAXED), lw = raw & 0xffu;
         if (!log_w_fixed && lw >= 10 && lw <= 14) c.st.call_log_w = lw;
+        // bit 8: more than 1/8 of the sampled mass outside the second generation's cold windows at this name count
+        c.st.call_yield = e->cfg.max_metrics <= 8192 && (raw & 0x100u) != 0;
         // second generation (<= 8 192 names): its survey reports 13 / 14 in the same word -- 14: spans wider than the
         // 8 192-bin reduce windows carry at least 5 % of the sampled mass
         c.st.call_wide = e->cfg.max_metrics <= 8192 && lw == 14;
@@ -804,7 +806,7 @@ void probe_width(lh_engine *e, PairsCall &c, lh::Ids d_ids, const double *d_v, s
     if (lh::launch_part3_probe(d_ids, d_v, n, e->cfg.max_metrics, e->d_Tx, p, e->num_cus, c.st.tune,
                                reinterpret_cast<uint32_t *>(e->d_rstat + 1), s) == hipSuccess &&
         hipStreamSynchronize(s) == hipSuccess) {
-        const uint32_t lw = (uint32_t)__atomic_load_n(&e->h_rstat[1], __ATOMIC_ACQUIRE);
+        const uint32_t lw = (uint32_t)__atomic_load_n(&e->h_rstat[1], __ATOMIC_ACQUIRE) & 0xffu;
         if (lw >= 10 && lw <= 14) c.st.call_log_w = lw;
     } else {
         (void)hipGetLastError();
@@ -2763,7 +2765,7 @@ int lh_get_counters(lh_engine *e, lh_counters *out)
     out->samples_fallback = e->c_fallback.load();
     out->survey_stale_pairs = __atomic_load_n(&e->h_rstat[7], __ATOMIC_RELAXED) + __atomic_load_n(&e->h_rstat[kLaneRstat + 7], __ATOMIC_RELAXED);
     {
-        const uint64_t lw = __atomic_load_n(&e->h_rstat[1], __ATOMIC_RELAXED);
+        const uint64_t lw = __atomic_load_n(&e->h_rstat[1], __ATOMIC_RELAXED) & 0xffu;
         std::lock_guard<std::mutex> g(e->scratch_mu);
         out->window_log2 = e->v3_log_w_fixed ? e->tune.v3_log_w : (lw >= 10 && lw <= 14 ? lw : e->tune.v3_log_w);
     }

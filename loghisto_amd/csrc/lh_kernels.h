@@ -77,6 +77,8 @@ struct PartTuning {
     bool v3 = true;                 // hashed survey + region scatter + in-place second level (lh_kernels_part3.h) for 8 193 .. 65 536 names
     size_t v3_min_samples = 0;      // 0 = default (2^24)
     uint32_t v3_log_w = 10;         // log2 of the second level's window width, 10 .. 14: the engine follows the survey's report
+    bool v2_yield = false;          // 1 025 .. 8 192 names: the last survey saw more than 1/8 of the sampled mass outside the second
+                                    // generation's cold windows -- such launches are the third generation's (the engine follows the report)
     size_t v3_direct_max = 0;       // third generation: launches of at most this many pairs end in k_part_direct3 (one global
                                     // atomic per forwarded record) instead of the windowed reduce pass; 0 = default (2^22), 1 = never
     uint32_t v3_g1_cap = 0;         // third generation: at most this many level-1 workgroups (0 = one per CU).  A host-fed

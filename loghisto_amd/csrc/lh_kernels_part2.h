@@ -50,6 +50,9 @@ constexpr uint32_t P2V2_SLOT_EXTRA = 256;              // P2 work slots beyond o
 
 typedef uint16_t rec16_t;
 
+#ifndef LH_HOT_CAP_BIG2
+#define LH_HOT_CAP_BIG2 4096u /* widest hot window of a name with >= 1/64 of the sampled mass (k_survey_plan) */
+#endif
 #ifndef LH_SC3_CAP_NUM
 #define LH_SC3_CAP_NUM 6
 #endif
@@ -188,6 +191,56 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_count(const IDT *__restrict
     }
 }
 
+// The sampled MASS by width (round 6, as k_survey_mass of the third generation): the same samples once more, each against
+// its name's sampled mean bin -- g_mass[k] = samples within 512 << k bins of it, k = 0 .. 4; g_mass[5] = all of them (names
+// with >= 32 samples).  The plan caps the most frequent names' hot windows by it.
+template <typename IDT>
+__global__ __launch_bounds__(V2_BLOCK) void k_survey_mass2(const IDT *__restrict__ ids, const double *__restrict__ v, size_t n,
+                                                           uint32_t nmetrics, const double *__restrict__ Tx,
+                                                           const uint32_t *__restrict__ g_cnt,
+                                                           const unsigned long long *__restrict__ g_sum,
+                                                           uint32_t *__restrict__ g_mass)
+{
+    __shared__ uint32_t s_in[6];
+    const uint32_t tid = threadIdx.x;
+    if (tid < 6) s_in[tid] = 0;
+    __syncthreads();
+    const size_t npairs = n / 2;
+    const size_t stride = npairs / gridDim.x;
+    const pd2_t *vp = reinterpret_cast<const pd2_t *>(v);
+    typedef IdStream<IDT> IS;
+    const IS ip(ids);
+    uint32_t in[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const size_t i = (size_t)blockIdx.x * stride + (size_t)j * V2_BLOCK + tid;
+        if (i < npairs && (size_t)j * V2_BLOCK + tid < (stride ? stride : npairs)) {
+            const typename IS::raw_t id2 = ip.ld(i);
+            const pd2_t x2 = vp[i];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t id = h ? IS::second(id2) : IS::first(id2);
+                const uint32_t c = id < nmetrics ? g_cnt[id] : 0u;
+                if (c >= 32u) {
+                    const uint32_t bin = lh_bin_of(h ? x2.y : x2.x, Tx), mean = (uint32_t)(g_sum[id] / c);
+                    const uint32_t d = bin > mean ? bin - mean : mean - bin;
+                    in[5]++;
+#pragma unroll
+                    for (uint32_t k = 0; k < 5; k++) in[k] += d < (512u << k) ? 1u : 0u;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 6; k++) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) in[k] += __shfl_xor(in[k], d, 64);
+        if ((tid & 63u) == 0 && in[k]) atomicAdd(&s_in[k], in[k]);
+    }
+    __syncthreads();
+    if (tid < 6 && s_in[tid]) atomicAdd(&g_mass[tid], s_in[tid]);
+}
+
 // sums of a and b over the workgroup, returned to every thread
 __device__ __forceinline__ void block_sum2(uint32_t a, uint32_t b, uint32_t *s_a, uint32_t *s_b, uint32_t &ta,
                                            uint32_t &tb)
@@ -241,6 +294,7 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__rest
                                                           const uint32_t *__restrict__ g_mninv,
                                                           const uint32_t *__restrict__ g_mx,
                                                           const unsigned long long *__restrict__ g_sum,
+                                                          const uint32_t *__restrict__ g_mass,
                                                           uint32_t nmetrics, uint32_t log_w, uint32_t cells_in,
                                                           const RegionFit rf,
                                                           NameEntry *__restrict__ nt, pu4_t *__restrict__ hs,
@@ -320,17 +374,42 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__rest
     }
     // ... reported to the engine (pinned word, as the third generation reports its window class): 14 = at least 5 % of the
     // sampled mass would miss 8 192-bin windows -- the following calls over <= 1 024 names take the WIDE shape (512
-    // partitions of two names x 16 384 bins); 13 otherwise
+    // partitions of two names x 16 384 bins).  Otherwise the stream's width class by its mass (10 .. 13, k_survey_mass2):
+    // above 1 024 names a stream wider than this generation's cold windows goes to the third (part2_yields_to_part3).
+    uint32_t cls = 13;
+    {
+        const uint32_t mass = g_mass[5];
+        for (uint32_t k = 10; k < 13; k++)
+            if ((unsigned long long)g_mass[k - 10u] * 100u >= (unsigned long long)mass * 99u) { cls = k; break; }
+        if (!mass) cls = 10;
+        if ((unsigned long long)g_mass[3] * 100u < (unsigned long long)mass * 99u) cls = 14; // (not within +-4 096 bins)
+        if ((unsigned long long)wide_cnt * 20ull >= total_cnt && nmetrics <= 1024u) cls = 14;
+        // bit 8: more than 1/8 of the mass lies outside THIS generation's cold windows (2^log_w bins around the mean)
+        if (nmetrics > 1024u && log_w >= 10u && log_w <= 14u && (unsigned long long)g_mass[log_w - 10u] * 8u < (unsigned long long)mass * 7u)
+            cls |= 0x100u;
+    }
     if (tid == 0 && span_out && total_cnt)
-        __hip_atomic_store(span_out, (unsigned long long)wide_cnt * 20ull >= total_cnt ? 14u : 13u, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(span_out, cls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 
-    // names that carry at least 1/64 of the surveyed samples may have 512-bin windows, the others 256
+    // names that carry at least 1/64 of the surveyed samples may have windows as wide as half the stream's width class
+    // (the smallest of 2^10 .. 2^14 bins within half of which, around their name's mean, 99 % of the samples lie: 512 bins
+    // on a lognormal stream, up to LH_HOT_CAP_BIG2 on a wide one -- where values spread evenly over their span a cell
+    // earns cnt / span whatever the window's width, so the cells belong to the most frequent names' whole spans), the
+    // others 256.  By the stream's mass, not the name's sampled span: one far outlier stretches that.
     const uint32_t big = total_cnt / 64u;
+    uint32_t cap_big = 512u;
+    {
+        const uint32_t mass = g_mass[5];
+        uint32_t lw = 14;
+        for (uint32_t k = 10; k < 14; k++)
+            if ((unsigned long long)g_mass[k - 10u] * 100u >= (unsigned long long)mass * 99u) { lw = k; break; }
+        if (mass) cap_big = 1u << (lw - 1u);
+        cap_big = cap_big < 512u ? 512u : cap_big > LH_HOT_CAP_BIG2 ? LH_HOT_CAP_BIG2 : cap_big;
+    }
 #pragma unroll
     for (uint32_t e = 0; e < EMAX; e++) {
         if (want[e]) {
-            const uint32_t cap = cnt[e] >= big ? 512u : 256u;
+            const uint32_t cap = cnt[e] >= big ? cap_big : 256u;
             if (want[e] > cap && !(whole & (1u << e))) want[e] = cap;
         }
     }
@@ -1683,10 +1762,28 @@ struct Part2Plan {
     size_t off_rec, off_cd, off_sorted, off_small, off_stat, off_nt, off_hs, off_hdr, off_pt, off_hot, off_resume, total;
 };
 
+// The cold window of this generation narrows with the name count (names per partition x window = 32 768 cells: 8 192 bins
+// at 1 024 names, 1 024 at 8 192), and a sample outside it is a global atomic: normal(0, 1e3) over 8 192 names took 57 ms
+// per 1e9 pairs, 21 decades over 4 096 names 49 (lognormal: 3.0).  Above 1 024 names (below, the WIDE shape answers) a
+// launch of a stream that leaves more than 1/8 of its mass outside those windows (~45 ms per 1e9 pairs of misses: what the
+// third generation costs on 64-bit cells) -- the last survey's report, PartTuning::v2_yield -- is left to the third
+// generation, whose windows follow the stream (defined in lh_kernels_part3.h: it must take the launch).
+static bool part2_yields_to_part3(size_t n, uint32_t nmetrics, const PartTuning &tune);
+static uint32_t part2_cold_log_w(uint32_t nmetrics, uint32_t shape)
+{
+    const uint32_t names_per_part = (shape & 1u) ? 8u : 4u, npt = (shape & 1u) ? 128u : 256u;
+    const uint32_t log_np = std::min(ilog2_ceil(npt), ilog2_ceil((nmetrics + names_per_part - 1) / names_per_part));
+    const uint32_t mpp = (nmetrics + (1u << log_np) - 1) >> log_np;
+    uint32_t lw = 0;
+    while ((mpp << (lw + 1)) <= P2V2_WINWORDS && lw < 13u) lw++;
+    return lw;
+}
+
 static bool make_plan2(size_t n, uint32_t nmetrics, int num_cus, const PartTuning &tune, Part2Plan &P)
 {
     if (!tune.v2 || n < (tune.v2_min_samples ? tune.v2_min_samples : V2_MIN_SAMPLES) || n > (size_t(1) << 31)) return false;
     if (nmetrics < 2 || nmetrics > V2_MAX_NAMES) return false;
+    if (part2_yields_to_part3(n, nmetrics, tune)) return false;
     P.shape = tune.v2_shape & 7u;
     if ((P.shape & 4u) && ((P.shape & 3u) != 2u || nmetrics > 1024u)) P.shape &= 3u; // wide: the region kernel, one workgroup per CU, few names
     const bool half = P.shape & 1u, direct = P.shape & 2u, wide = P.shape & 4u;
@@ -1741,7 +1838,7 @@ static bool make_plan2(size_t n, uint32_t nmetrics, int num_cus, const PartTunin
     auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~size_t(255); return at; };
     // the survey's tables come first: their offsets depend on the name count only, so the sub-launches of one
     // call (whose other regions shrink with n) all find the survey of the first one
-    P.off_stat = take((size_t)nmetrics * 20 + 8);
+    P.off_stat = take((size_t)nmetrics * 20 + 8 + 32); // (+ the six words of k_survey_mass2)
     P.off_nt = take((size_t)nmetrics * sizeof(NameEntry));
     P.off_hs = take((size_t)V2_MAX_SLOTS * sizeof(pu4_t));
     P.off_hdr = take(64);
@@ -1827,13 +1924,16 @@ static hipError_t launch_part2_t(const IDT *d_ids, const double *d_v, size_t n, 
     e = hipMemsetAsync(L1.pc, 0, small_words(P.np, P2V2_SLOT_EXTRA) * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     if (survey_n) {
-        e = hipMemsetAsync(g_cnt, 0, (size_t)nmetrics * 20 + 8, s);
+        e = hipMemsetAsync(g_cnt, 0, (size_t)nmetrics * 20 + 8 + 32, s);
         if (e != hipSuccess) return e;
         const size_t sv_tiles = (survey_n / 2 + 2047) / 2048;
         const unsigned sv_grid = (unsigned)std::min<size_t>(SV_GRID, std::max<size_t>(1, sv_tiles));
         hipLaunchKernelGGL(k_survey_count<IDT>, dim3(sv_grid), dim3(V2_BLOCK), sv_dyn, s, d_ids, d_v, survey_n, nmetrics,
                            d_Tx, g_cnt, g_mninv, g_mx, g_sum);
-        hipLaunchKernelGGL(k_survey_plan, dim3(1), dim3(V2_BLOCK), 0, s, g_cnt, g_mninv, g_mx, g_sum, nmetrics,
+        uint32_t *g_mass = reinterpret_cast<uint32_t *>(g_sum + nmetrics);
+        hipLaunchKernelGGL(k_survey_mass2<IDT>, dim3(sv_grid), dim3(V2_BLOCK), 0, s, d_ids, d_v, survey_n, nmetrics, d_Tx, g_cnt,
+                           g_sum, g_mass);
+        hipLaunchKernelGGL(k_survey_plan, dim3(1), dim3(V2_BLOCK), 0, s, g_cnt, g_mninv, g_mx, g_sum, g_mass, nmetrics,
                            P.log_w, P.cells, P.fit, g_nt, g_hs, g_hdr, g_pt,
                            region_stat ? reinterpret_cast<uint32_t *>(region_stat + 1) : nullptr);
     }

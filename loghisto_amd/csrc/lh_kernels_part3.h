@@ -253,7 +253,7 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan_h(const SurveyStat S,
                                                             uint32_t tile, uint32_t avail_bytes, uint32_t max_cells,
                                                             pu2_t *__restrict__ g_hk,
                                                             pu4_t *__restrict__ g_hs, pu2_t *__restrict__ g_pt,
-                                                            uint32_t *__restrict__ hdr, uint32_t *span_out)
+                                                            uint32_t *__restrict__ hdr, uint32_t *span_out, uint32_t yield_log_w)
 {
     __shared__ uint32_t s_a[V2_BLOCK / 64], s_b[V2_BLOCK / 64];
     __shared__ uint32_t s_cap[V3_NP], s_pcw[V3_NP];
@@ -380,7 +380,10 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan_h(const SurveyStat S,
         hdr[3] = hot_cnt_total;
         hdr[4] = lw;
         hdr[HDR_BASE] = 0; // no launch has run on these tables yet (stale_judge, lh_kernels_part2.h)
-        if (span_out && mass) __hip_atomic_store(span_out, lw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // (<= 8 192 names, yield_log_w = the second generation's cold window there: bit 8 keeps such a stream here)
+        const uint32_t keep = yield_log_w >= 10u && yield_log_w <= 14u &&
+                              (unsigned long long)g_aux[AUX_IN + yield_log_w - 10u] * 8u < (unsigned long long)mass * 7u ? 0x100u : 0u;
+        if (span_out && mass) __hip_atomic_store(span_out, lw | keep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1835,11 +1838,23 @@ struct Part3Plan {
     size_t off_rec1, off_cd1, off_sorted1, off_small1, off_rec2, off_cd2, off_sorted2, off_small2, off_gstats, total;
 };
 
+// 1 025 .. 8 192 names: this generation takes the launches of streams that leave more than 1/8 of their mass outside the
+// second generation's cold windows (lh_kernels_part2.h; both generations' surveys report that in bit 8 of the width word,
+// this one's against part2_cold_log_w of the name count) -- 1e9 pairs of normal(0, 1e3) over 8 192 names 57 -> 7.7 ms, of
+// 21 decades over 4 096 names 49 -> 8.9.
+static bool part2_yields_to_part3(size_t n, uint32_t nmetrics, const PartTuning &tune)
+{
+    if (!tune.v3 || !(tune.v2_shape & 2u) || nmetrics <= 1024u || nmetrics > V2_MAX_NAMES) return false;
+    if (n < (tune.v3_min_samples ? tune.v3_min_samples : V3_MIN_SAMPLES) || n > (size_t(1) << 31)) return false;
+    return tune.v2_yield;
+}
+
 static bool make_plan3(size_t n, uint32_t nmetrics, int num_cus, const PartTuning &tune, Part3Plan &P)
 {
     if (!tune.v3 || !(tune.v2_shape & 2u)) return false; // shape bit 1 clear: the engine asked for the exact layout
     if (n < (tune.v3_min_samples ? tune.v3_min_samples : V3_MIN_SAMPLES) || n > (size_t(1) << 31)) return false;
-    if (nmetrics <= V2_MAX_NAMES || nmetrics > V3_MAX_NAMES) return false;
+    if (nmetrics > V3_MAX_NAMES) return false;
+    if (nmetrics <= V2_MAX_NAMES && !part2_yields_to_part3(n, nmetrics, tune)) return false;
     P.log_w = std::min(V3_MAX_LOG_W, std::max(10u, tune.v3_log_w));
     P.log_mpp2 = (P.log_w >= P3_WIDE_FROM ? 16u : 15u) - P.log_w; // mpp2 x W = 32 768 window cells in the reduce pass, 65 536 from W = 2^13 on
     P.mpp2 = 1u << P.log_mpp2;
@@ -1919,6 +1934,7 @@ size_t part3_tables_bytes(uint32_t nmetrics)
     Part3Plan P;
     PartTuning t;
     t.v3_min_samples = V3_TABLES_SAMPLES;
+    if (nmetrics <= V2_MAX_NAMES) t.v2_yield = true; // (the tables' size depends on the name count only)
     return make_plan3(V3_TABLES_SAMPLES, nmetrics, 256, t, P) ? P.off_rec1 : 0;
 }
 
@@ -2006,7 +2022,7 @@ static hipError_t launch_part3_t(const IDT *d_ids, const double *d_v, size_t n, 
         hipLaunchKernelGGL(k_survey_pick, dim3((nmetrics + 1023) / 1024), dim3(1024), 0, s, S, nmetrics, g_aux);
         hipLaunchKernelGGL(k_survey_mass<IDT>, dim3(sv_grid), dim3(1024), 0, s, d_ids, d_v, survey_n, nmetrics, d_Tx, S, g_aux);
         hipLaunchKernelGGL(k_survey_plan_h, dim3(1), dim3(V2_BLOCK), 0, s, S, g_aux, P.cells, V3_TILE, P.avail_bytes, P.max_cells, g_hk, g_hs, g_pt,
-                           g_hdr, span_stat);
+                           g_hdr, span_stat, nmetrics <= V2_MAX_NAMES ? part2_cold_log_w(nmetrics, tune.v2_shape) : 0u);
         hipLaunchKernelGGL(k_survey_remap, dim3(V3_NP), dim3(256), 0, s, S, g_hk, nmetrics, P.kp, P.log_mpp2, P.ns,
                            g_remap, g_inv, g_pt2);
     }
@@ -2075,7 +2091,8 @@ static hipError_t launch_part3_probe_t(const IDT *d_ids, const double *d_v, size
     hipLaunchKernelGGL(k_survey_mass<IDT>, dim3(sv_grid), dim3(1024), 0, s, d_ids, d_v, n, nmetrics, d_Tx, S, g_aux);
     hipLaunchKernelGGL(k_survey_plan_h, dim3(1), dim3(V2_BLOCK), 0, s, S, g_aux, P.cells, V3_TILE, P.avail_bytes, P.max_cells,
                        reinterpret_cast<pu2_t *>(base + P.off_hk), reinterpret_cast<pu4_t *>(base + P.off_hs),
-                       reinterpret_cast<pu2_t *>(base + P.off_pt), reinterpret_cast<uint32_t *>(base + P.off_hdr), span_stat);
+                       reinterpret_cast<pu2_t *>(base + P.off_pt), reinterpret_cast<uint32_t *>(base + P.off_hdr), span_stat,
+                       nmetrics <= V2_MAX_NAMES ? part2_cold_log_w(nmetrics, tune.v2_shape) : 0u);
     return hipGetLastError();
 }
 
