@@ -193,7 +193,10 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_count(const IDT *__restrict
 
 // The sampled MASS by width (round 6, as k_survey_mass of the third generation): the same samples once more, each against
 // its name's sampled mean bin -- g_mass[k] = samples within 512 << k bins of it, k = 0 .. 4; g_mass[5] = all of them (names
-// with >= 32 samples).  The plan caps the most frequent names' hot windows by it.
+// with >= 32 samples).  The plan caps the most frequent names' hot windows by it.  g_mass[6] = sampled PAIRS of neighbours
+// in the stream, g_mass[7] = those of ONE name: under Zipf(1) over 8 192 names 2 %, in a stream sorted or run-clustered by
+// name nearly all -- such a stream stays with this generation however wide it is (part2_yields_to_part3: the third
+// generation's cell table took 104 ms per 1e9 pairs of 21 decades sorted by name over 8 192 names, this one's 41).
 template <typename IDT>
 __global__ __launch_bounds__(V2_BLOCK) void k_survey_mass2(const IDT *__restrict__ ids, const double *__restrict__ v, size_t n,
                                                            uint32_t nmetrics, const double *__restrict__ Tx,
@@ -201,22 +204,24 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_mass2(const IDT *__restrict
                                                            const unsigned long long *__restrict__ g_sum,
                                                            uint32_t *__restrict__ g_mass)
 {
-    __shared__ uint32_t s_in[6];
+    __shared__ uint32_t s_in[8];
     const uint32_t tid = threadIdx.x;
-    if (tid < 6) s_in[tid] = 0;
+    if (tid < 8) s_in[tid] = 0;
     __syncthreads();
     const size_t npairs = n / 2;
     const size_t stride = npairs / gridDim.x;
     const pd2_t *vp = reinterpret_cast<const pd2_t *>(v);
     typedef IdStream<IDT> IS;
     const IS ip(ids);
-    uint32_t in[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t in[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const size_t i = (size_t)blockIdx.x * stride + (size_t)j * V2_BLOCK + tid;
         if (i < npairs && (size_t)j * V2_BLOCK + tid < (stride ? stride : npairs)) {
             const typename IS::raw_t id2 = ip.ld(i);
             const pd2_t x2 = vp[i];
+            in[6]++;
+            in[7] += IS::first(id2) == IS::second(id2) ? 1u : 0u;
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const uint32_t id = h ? IS::second(id2) : IS::first(id2);
@@ -232,13 +237,13 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_mass2(const IDT *__restrict
         }
     }
 #pragma unroll
-    for (uint32_t k = 0; k < 6; k++) {
+    for (uint32_t k = 0; k < 8; k++) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) in[k] += __shfl_xor(in[k], d, 64);
         if ((tid & 63u) == 0 && in[k]) atomicAdd(&s_in[k], in[k]);
     }
     __syncthreads();
-    if (tid < 6 && s_in[tid]) atomicAdd(&g_mass[tid], s_in[tid]);
+    if (tid < 8 && s_in[tid]) atomicAdd(&g_mass[tid], s_in[tid]);
 }
 
 // sums of a and b over the workgroup, returned to every thread
@@ -385,7 +390,9 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan(const uint32_t *__rest
         if ((unsigned long long)g_mass[3] * 100u < (unsigned long long)mass * 99u) cls = 14; // (not within +-4 096 bins)
         if ((unsigned long long)wide_cnt * 20ull >= total_cnt && nmetrics <= 1024u) cls = 14;
         // bit 8: more than 1/8 of the mass lies outside THIS generation's cold windows (2^log_w bins around the mean)
-        if (nmetrics > 1024u && log_w >= 10u && log_w <= 14u && (unsigned long long)g_mass[log_w - 10u] * 8u < (unsigned long long)mass * 7u)
+        // (... unless the stream is clustered by name: half of its neighbours are one name)
+        if (nmetrics > 1024u && log_w >= 10u && log_w <= 14u && (unsigned long long)g_mass[log_w - 10u] * 8u < (unsigned long long)mass * 7u &&
+            g_mass[7] * 2u < g_mass[6])
             cls |= 0x100u;
     }
     if (tid == 0 && span_out && total_cnt)

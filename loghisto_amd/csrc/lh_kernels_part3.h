@@ -170,7 +170,7 @@ __global__ __launch_bounds__(1024) void k_survey_count_h(const IDT *__restrict__
     }
 }
 
-// g_aux (zero-initialised with the statistics): claim[V3_HN] | pc[V3_NP] | in[6] (k_survey_mass)
+// g_aux (zero-initialised with the statistics): claim[V3_HN] | pc[V3_NP] | in[8] (k_survey_mass)
 constexpr uint32_t AUX_CLAIM = 0, AUX_PC = V3_HN, AUX_IN = V3_HN + V3_NP, AUX_WORDS = V3_HN + V3_NP + 32;
 
 // One thread per name: a name with >= 16 sampled values claims its hash slot (the larger count wins); per-partition
@@ -198,25 +198,28 @@ __global__ __launch_bounds__(1024) void k_survey_pick(const SurveyStat S, uint32
 // samples puts its whole mass into the widest class, and a stream with a 0.1 % tail of far outliers (every hot name has
 // some) got 8 192-bin windows -- level 2 in lock step with 3 names counted in place, 17 000 reduce slots, row spans and
 // extract to match: 7.5 ms per 1e9 pairs instead of 4.4, 1.89 instead of 0.82 at config 4's slice.
-//   g_aux[AUX_IN + k - 10] samples within 2^(k-1) bins of their name's mean, k = 10 .. 14; g_aux[AUX_IN + 5] all of them
-static_assert(AUX_IN + 6 <= AUX_WORDS, "room behind the partition counts");
+//   g_aux[AUX_IN + k - 10] samples within 2^(k-1) bins of their name's mean, k = 10 .. 14; g_aux[AUX_IN + 5] all of them;
+//   g_aux[AUX_IN + 6] sampled pairs of neighbours in the stream, [AUX_IN + 7] those of one name (k_survey_mass2)
+static_assert(AUX_IN + 8 <= AUX_WORDS, "room behind the partition counts");
 template <typename IDT>
 __global__ __launch_bounds__(1024) void k_survey_mass(const IDT *__restrict__ ids, const double *__restrict__ v, size_t n,
                                                       uint32_t nmetrics, const double *__restrict__ Tx, const SurveyStat S,
                                                       uint32_t *__restrict__ g_aux)
 {
-    __shared__ uint32_t s_in[6];
+    __shared__ uint32_t s_in[8];
     const uint32_t tid = threadIdx.x;
-    if (tid < 6) s_in[tid] = 0;
+    if (tid < 8) s_in[tid] = 0;
     __syncthreads();
     const size_t npairs = n / 2; // (the samples k_survey_count_h took)
     const size_t stride = npairs / gridDim.x;
     const size_t i = (size_t)blockIdx.x * stride + tid;
-    uint32_t in[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t in[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (i < npairs && tid < (stride ? stride : npairs)) {
         typedef IdStream<IDT> IS;
         const typename IS::raw_t id2 = IS(ids).ld(i);
         const pd2_t x2 = reinterpret_cast<const pd2_t *>(v)[i];
+        in[6]++;
+        in[7] += IS::first(id2) == IS::second(id2) ? 1u : 0u;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const uint32_t id = h ? IS::second(id2) : IS::first(id2);
@@ -230,13 +233,13 @@ __global__ __launch_bounds__(1024) void k_survey_mass(const IDT *__restrict__ id
         }
     }
 #pragma unroll
-    for (uint32_t k = 0; k < 6; k++) {
+    for (uint32_t k = 0; k < 8; k++) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) in[k] += __shfl_xor(in[k], d, 64);
         if ((tid & 63u) == 0 && in[k]) atomicAdd(&s_in[k], in[k]);
     }
     __syncthreads();
-    if (tid < 6 && s_in[tid]) atomicAdd(&g_aux[AUX_IN + tid], s_in[tid]);
+    if (tid < 8 && s_in[tid]) atomicAdd(&g_aux[AUX_IN + tid], s_in[tid]);
 }
 
 // One workgroup, thread t owns hash slot t.  Output:
@@ -382,7 +385,8 @@ __global__ __launch_bounds__(V2_BLOCK) void k_survey_plan_h(const SurveyStat S,
         hdr[HDR_BASE] = 0; // no launch has run on these tables yet (stale_judge, lh_kernels_part2.h)
         // (<= 8 192 names, yield_log_w = the second generation's cold window there: bit 8 keeps such a stream here)
         const uint32_t keep = yield_log_w >= 10u && yield_log_w <= 14u &&
-                              (unsigned long long)g_aux[AUX_IN + yield_log_w - 10u] * 8u < (unsigned long long)mass * 7u ? 0x100u : 0u;
+                              (unsigned long long)g_aux[AUX_IN + yield_log_w - 10u] * 8u < (unsigned long long)mass * 7u &&
+                              g_aux[AUX_IN + 7] * 2u < g_aux[AUX_IN + 6] ? 0x100u : 0u; // (not clustered by name)
         if (span_out && mass) __hip_atomic_store(span_out, lw | keep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }

@@ -157,6 +157,7 @@ cd $R
   python tools/sweep.py --warmup 40 --samples 1e9 --reps 5 2>/dev/null
   python tools/sweep.py --warmup 40 --samples 1e9 --pairs 1024 --reps 4 --dists lognormal,constant,uniform,exponential,normal,loguniform,lognormal25,kvalues2,kvalues4,kvalues8,kvalues16,bimodal,signed_wide 2>/dev/null
   python tools/sweep.py --warmup 40 --samples 1e9 --pairs 65536 --reps 4 --dists lognormal,constant,normal,kvalues2,kvalues8,bimodal,lognormal25,lognormal50,loguniform,signed_wide,thin_far_tail 2>/dev/null
+  for m in 8192 4096; do python tools/sweep.py --warmup 40 --samples 1e9 --pairs $m --reps 4 --dists lognormal,normal,lognormal25,lognormal50,loguniform,signed_wide,thin_far_tail 2>/dev/null; done
   python tools/sweep.py --warmup 40 --samples 1e9 --pairs 65536 --reps 4 --ids sorted --dists lognormal 2>/dev/null
   python tools/sweep.py --warmup 40 --samples 1e9 --pairs 1024 --reps 4 --ids sorted --dists lognormal 2>/dev/null
 } | cut -c1-700 > $OUT/sweep_final.jsonl
