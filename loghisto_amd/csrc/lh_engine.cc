@@ -793,7 +793,9 @@ void snapshot_dispatch(lh_engine *e, PairsCall &c)
 void probe_width(lh_engine *e, PairsCall &c, lh::Ids d_ids, const double *d_v, size_t n, hipStream_t s)
 {
     constexpr size_t kProbeMinPairs = size_t(1) << 24;
-    if (c.st.max_metrics <= 8192 || c.log_w_fixed || n < kProbeMinPairs || !c.st.tune.v3 || c.st.v3_disabled) return;
+    // (1 025 .. 8 192 names too: there the probe's report decides whether the call is the third generation's at all --
+    // bit 8 of the word, lh_kernels_part2.h -- 1e9 pairs of normal(0, 1e3) over 8 192 names: first call 56 ms without it)
+    if (c.st.max_metrics <= 1024 || c.log_w_fixed || n < kProbeMinPairs || !c.st.tune.v3 || c.st.v3_disabled) return;
     if (__atomic_load_n(&e->h_rstat[1], __ATOMIC_RELAXED) != 0 || !e->d_rstat) return;
     if (lh::peel_first((uintptr_t)d_ids.p, d_ids.width, (uintptr_t)d_v, n)) { d_ids = d_ids.plus(1); d_v += 1; n -= 1; }
     std::lock_guard<std::mutex> g(e->probe_mu);
@@ -803,11 +805,14 @@ void probe_width(lh_engine *e, PairsCall &c, lh::Ids d_ids, const double *d_v, s
     void *p = nullptr;
     if (!tb || hipMalloc(&p, tb) != hipSuccess) { (void)hipGetLastError(); return; }
     n = std::min(n, size_t(1) << 30);
-    if (lh::launch_part3_probe(d_ids, d_v, n, e->cfg.max_metrics, e->d_Tx, p, e->num_cus, c.st.tune,
+    lh::PartTuning pt = c.st.tune;
+    if (c.st.max_metrics <= 8192) pt.v2_yield = true; // (the probe's plan is the third generation's whatever it will report)
+    if (lh::launch_part3_probe(d_ids, d_v, n, e->cfg.max_metrics, e->d_Tx, p, e->num_cus, pt,
                                reinterpret_cast<uint32_t *>(e->d_rstat + 1), s) == hipSuccess &&
         hipStreamSynchronize(s) == hipSuccess) {
-        const uint32_t lw = (uint32_t)__atomic_load_n(&e->h_rstat[1], __ATOMIC_ACQUIRE) & 0xffu;
+        const uint32_t raw = (uint32_t)__atomic_load_n(&e->h_rstat[1], __ATOMIC_ACQUIRE), lw = raw & 0xffu;
         if (lw >= 10 && lw <= 14) c.st.call_log_w = lw;
+        if (c.st.max_metrics <= 8192) c.st.call_yield = (raw & 0x100u) != 0;
     } else {
         (void)hipGetLastError();
         (void)hipStreamSynchronize(s); // (the block below is freed: nothing may still write it)

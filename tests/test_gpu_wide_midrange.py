@@ -58,3 +58,23 @@ def test_wide_streams_between_1025_and_8192_names(native_lib, torch_cuda, M, n, 
         c5 = call(d_n, narrow)
         assert c5["samples_partitioned_v2"] - c4["samples_partitioned_v2"] == n, (c3, c4, c5)
         assert c5["samples_partitioned_v2"] + c5["samples_partitioned_v3"] == 6 * n, c5
+
+
+def test_the_first_call_of_a_wide_stream_is_probed(native_lib, torch_cuda):
+    """A fresh engine's first large call (>= 2^24 pairs) asks the survey before it chooses the path (probe_width, lh_engine.cc):
+    normal(0, 1e4) over 8 192 names is the third generation's from the first call on (56 -> 10 ms per 1e9 pairs), a lognormal
+    stream stays the second's.  Every cell exact."""
+    import loghisto_amd
+    M, n = 8192, (1 << 24) + 4096
+    rng = np.random.default_rng(17)
+    ids = _ids(rng, M, n, 1.0)
+    for kind, gen3 in (("signed", True), ("lognormal", False)):
+        v = _values(rng, kind, ids, n)
+        d_ids, d_v = _dev(torch_cuda, ids), _dev(torch_cuda, v)
+        with loghisto_amd.Engine(max_metrics=M, num_buffers=2, num_lanes=1, lane_samples=1 << 16) as e:
+            e.submit_pairs_device(d_ids, d_v)
+            e.sync()
+            c = e.counters()
+            assert c["samples_partitioned_v3"] == (n if gen3 else 0) and c["samples_partitioned_v2"] == (0 if gen3 else n), (kind, c)
+            with e.flip() as snap:
+                check(snap, ids, v, M, snap.extract(PCTS, M))
